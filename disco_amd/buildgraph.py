@@ -1,0 +1,272 @@
+"""ctypes mirror of the C-ABI in include/disco_hip.h (libdisco_hip.so) — the product's Python host side.
+
+The reference has no Python; this mirrors the order in which its main() drives the path
+(/root/reference/src/BuildGraph/src/main.cpp:55-62: Dataset -> HashTable::insertDataset -> OverlapGraph) with the
+same phase names the C-ABI uses.  There is NO CPU fallback: a missing extension or GPU is a loud error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libdisco_hip.so")
+_lib = None
+
+
+class DiscoError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("min_overlap", C.c_uint32), ("max_edges_per_kmer", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class GenSpecABI(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_uint64), ("contig_len", C.c_uint64), ("n_contigs", C.c_uint32),
+                ("len_min", C.c_uint32), ("len_max", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+CONTAINED_DTYPE = np.dtype([("contained", "<u8"), ("super", "<u8"), ("orient", "<u4"), ("len2", "<u4"), ("len1", "<u4"),
+                            ("start", "<u4"), ("j", "<u4"), ("type", "<u4")])
+EDGE_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("orient", "<u4"), ("offset", "<u4"), ("len_src", "<u4"), ("len_dst", "<u4")])
+COUNTER_NAMES = ("n_reads", "probes", "kmer_hits", "n_contained", "raw_hits", "e_pre", "e_out", "cap_bind_sites",
+                 "asymmetric_pairs", "big_rows", "index_buckets", "hbm_bytes")
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_NAMES]
+
+
+# every symbol include/disco_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+ABI = [
+    ("disco_abi_version", C.c_int, []),
+    ("disco_create", C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(_P)]),
+    ("disco_destroy", None, [_P]),
+    ("disco_last_error", C.c_char_p, [_P]),
+    ("disco_set_stream", C.c_int, [_P, _P]),
+    ("disco_synchronize", C.c_int, [_P]),
+    ("disco_pack_ascii", C.c_int, [C.c_char_p, C.c_uint32, _P]),
+    ("disco_upload_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
+    ("disco_adopt_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
+    ("disco_generate_reads", C.c_int, [_P, C.POINTER(GenSpecABI)]),
+    ("disco_download_reads", C.c_int, [_P, _P, _P]),
+    ("disco_stride_words", C.c_uint32, [_P]),
+    ("disco_num_reads", C.c_uint64, [_P]),
+    ("disco_set_query_range", C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    ("disco_build_index", C.c_int, [_P]),
+    ("disco_probe", C.c_int, [_P]),
+    ("disco_mark_contained", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("disco_build_edges", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("disco_select_edges", C.c_int, [_P]),
+    ("disco_symmetrize", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
+    ("disco_merge_extras", C.c_int, [_P]),
+    ("disco_transitive_reduce", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("disco_transitive_mark", C.c_int, [_P]),
+    ("disco_emit_edges", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("disco_run_graph", C.c_int, [_P]),
+    ("disco_contain_keys", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("disco_adjacency_size", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("disco_export_adjacency", C.c_int, [_P, _P, _P]),
+    ("disco_import_adjacency", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("disco_tr_flags", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("disco_fetch_contained", C.c_int64, [_P, _P, C.c_uint64]),
+    ("disco_fetch_edges", C.c_int64, [_P, _P, C.c_uint64]),
+    ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
+]
+
+
+def lib_path() -> str:
+    return _LIBPATH
+
+
+def load():
+    """dlopen libdisco_hip.so and bind the ABI. Raises DiscoError if the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise DiscoError(f"{_LIBPATH} is missing: build it with `python -m disco_amd.build` (hipcc, gfx950). "
+                             "There is no CPU fallback.")
+        L = C.CDLL(_LIBPATH)
+        for name, res, args in ABI:
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class BuildGraph:
+    """One context = one GPU. Phases in the order the reference's main() runs them."""
+
+    def __init__(self, min_overlap: int = 40, device: int = 0, max_edges_per_kmer: int = 4):
+        self.L = load()
+        self.min_overlap = min_overlap
+        self._h = _P()
+        p = Params(min_overlap, max_edges_per_kmer, 0, 0)
+        rc = self.L.disco_create(device, C.byref(p), C.byref(self._h))
+        if rc != 0:
+            raise DiscoError(f"disco_create failed ({rc}): {self.L.disco_last_error(None).decode()}")
+
+    # -- plumbing ---------------------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc < 0:
+            raise DiscoError(f"libdisco_hip error {rc}: {self.L.disco_last_error(self._h).decode()}")
+        return rc
+
+    def close(self):
+        if self._h:
+            self.L.disco_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr: int | None):
+        self._chk(self.L.disco_set_stream(self._h, _P(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        self._chk(self.L.disco_synchronize(self._h))
+
+    # -- reads -------------------------------------------------------------------------------------------------
+    def upload_reads(self, packed: np.ndarray, lens: np.ndarray):
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        assert packed.ndim == 2 and packed.shape[0] == lens.shape[0]
+        self._keep = (packed, lens)
+        self._chk(self.L.disco_upload_reads(self._h, packed.ctypes.data, packed.shape[1], lens.ctypes.data, packed.shape[0]))
+
+    def upload_ascii(self, reads):
+        """pack upper-case ACGT strings on the host (disco_pack_ascii) and upload them"""
+        n = len(reads)
+        lens = np.fromiter((len(r) for r in reads), dtype=np.uint16, count=n)
+        stride = int((int(lens.max()) + 31) // 32) if n else 1
+        packed = np.zeros((n, stride), dtype=np.uint64)
+        for i, r in enumerate(reads):
+            b = r.encode()
+            if self.L.disco_pack_ascii(b, len(b), packed[i].ctypes.data) != 0:
+                raise DiscoError(f"read {i} contains a non-ACGT base")
+        self.upload_reads(packed, lens)
+
+    def adopt_reads(self, d_packed_ptr: int, stride_words: int, d_len_ptr: int, n: int):
+        self._chk(self.L.disco_adopt_reads(self._h, _P(d_packed_ptr), stride_words, _P(d_len_ptr), n))
+
+    def generate_reads(self, spec):
+        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, 0)
+        self._chk(self.L.disco_generate_reads(self._h, C.byref(s)))
+
+    def download_reads(self):
+        n, s = self.num_reads, self.stride_words
+        packed = np.zeros((n, s), dtype=np.uint64)
+        lens = np.zeros(n, dtype=np.uint16)
+        self._chk(self.L.disco_download_reads(self._h, packed.ctypes.data, lens.ctypes.data))
+        return packed, lens
+
+    @property
+    def num_reads(self) -> int:
+        return int(self.L.disco_num_reads(self._h))
+
+    @property
+    def stride_words(self) -> int:
+        return int(self.L.disco_stride_words(self._h))
+
+    def set_query_range(self, lo: int, hi: int):
+        self._chk(self.L.disco_set_query_range(self._h, lo, hi))
+
+    # -- phases ------------------------------------------------------------------------------------------------
+    def build_index(self):
+        self._chk(self.L.disco_build_index(self._h))
+
+    def probe(self):
+        self._chk(self.L.disco_probe(self._h))
+
+    def mark_contained(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.disco_mark_contained(self._h, C.byref(n)))
+        return n.value
+
+    def build_edges(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.disco_build_edges(self._h, C.byref(n)))
+        return n.value
+
+    def select_edges(self):
+        self._chk(self.L.disco_select_edges(self._h))
+
+    def symmetrize(self, full: bool) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.disco_symmetrize(self._h, 1 if full else 0, C.byref(n)))
+        return n.value
+
+    def merge_extras(self):
+        self._chk(self.L.disco_merge_extras(self._h))
+
+    def transitive_reduce(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.disco_transitive_reduce(self._h, C.byref(n)))
+        return n.value
+
+    def transitive_mark(self):
+        self._chk(self.L.disco_transitive_mark(self._h))
+
+    def emit_edges(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.disco_emit_edges(self._h, C.byref(n)))
+        return n.value
+
+    def run_graph(self):
+        self._chk(self.L.disco_run_graph(self._h))
+
+    # -- multi-GPU exchange points -------------------------------------------------------------------------------
+    def contain_keys(self):
+        p, n = _P(), C.c_uint64()
+        self._chk(self.L.disco_contain_keys(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def adjacency_size(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.disco_adjacency_size(self._h, C.byref(n)))
+        return n.value
+
+    def export_adjacency(self, d_deg_ptr: int, d_entries_ptr: int):
+        self._chk(self.L.disco_export_adjacency(self._h, _P(d_deg_ptr), _P(d_entries_ptr)))
+
+    def import_adjacency(self, d_deg_all_ptr: int, d_entries_all_ptr: int, n_entries: int):
+        self._chk(self.L.disco_import_adjacency(self._h, _P(d_deg_all_ptr), _P(d_entries_all_ptr), n_entries))
+
+    def tr_flags(self):
+        p, lo, hi, tot = _P(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.disco_tr_flags(self._h, C.byref(p), C.byref(lo), C.byref(hi), C.byref(tot)))
+        return p.value, lo.value, hi.value, tot.value
+
+    # -- results -----------------------------------------------------------------------------------------------
+    def fetch_contained(self) -> np.ndarray:
+        n = self._chk(self.L.disco_fetch_contained(self._h, None, 0))
+        out = np.zeros(n, dtype=CONTAINED_DTYPE)
+        if n:
+            self._chk(self.L.disco_fetch_contained(self._h, out.ctypes.data, n))
+        return out
+
+    def fetch_edges(self) -> np.ndarray:
+        n = self._chk(self.L.disco_fetch_edges(self._h, None, 0))
+        out = np.zeros(n, dtype=EDGE_DTYPE)
+        if n:
+            self._chk(self.L.disco_fetch_edges(self._h, out.ctypes.data, n))
+        return out
+
+    def counters(self) -> dict:
+        c = Counters()
+        self._chk(self.L.disco_get_counters(self._h, C.byref(c)))
+        return {n: int(getattr(c, n)) for n in COUNTER_NAMES}

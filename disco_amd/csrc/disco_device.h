@@ -1,0 +1,173 @@
+/*
+ * disco_device.h — device-side primitives on 2-bit packed reads (gfx950, wave64).
+ *
+ * Packing: 32 bases per 64-bit word, base i of a read at bits 62-2(i mod 32) of word i/32, A0 C1 G2 T3
+ * (reference layout: /root/reference/src/BuildGraph/src/HashTable.cpp:456-477, HashTable.h:16-24).
+ * Unused bits of the last word and unused words of the fixed-stride row are zero.
+ */
+#ifndef DISCO_DEVICE_H_
+#define DISCO_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+#define DISCO_WAVE 64
+#define DISCO_NOKEY 0xFFFFFFFFFFFFFFFFull
+
+/* ---- index entry payload: read id | record strand | isSuffix | length ------------------------------------------ */
+#define PAY_LEN(p) ((u32)((p)&0x7FFFu))
+#define PAY_SUFFIX(p) ((u32)(((p) >> 15) & 1u))
+#define PAY_REV(p) ((u32)(((p) >> 16) & 1u))
+#define PAY_ID(p) ((p) >> 17)
+#define PAY_MAKE(id, rev, suf, len) (((u64)(id) << 17) | ((u64)(rev) << 16) | ((u64)(suf) << 15) | (u64)(len))
+
+/* ---- raw verified overlap hit: sorts numerically into the reference's consumption order (j, bucket order) ------- */
+/* bucket order = ascending read id, prefix record before suffix record (BG/HashTable.cpp:451-454,486-489)          */
+#define HIT_MAKE(j, id, suf, rev) (((u64)(j) << 45) | ((u64)(id) << 3) | ((u64)(suf) << 2) | ((u64)(rev) << 1))
+#define HIT_J(h) ((u32)((h) >> 45) & 0x7FFFu)
+#define HIT_ID(h) (((h) >> 3) & ((1ull << 42) - 1))
+#define HIT_SUFFIX(h) ((u32)(((h) >> 2) & 1u))
+#define HIT_REV(h) ((u32)(((h) >> 1) & 1u))
+
+/* ---- adjacency entry: sorts numerically by (offset, dst, orient) = list order of BG/OverlapGraph.cpp:675-676 ---- */
+#define ADJ_MAKE(off, dst, o) (((u64)(off) << 44) | ((u64)(dst) << 2) | (u64)(o))
+#define ADJ_OFF(e) ((u32)((e) >> 44) & 0x7FFFu)
+#define ADJ_DST(e) (((e) >> 2) & ((1ull << 42) - 1))
+#define ADJ_ORI(e) ((u32)((e)&3u))
+
+/* ---- containment key for atomicMin: smallest super id wins, then smallest j, then prefix record first ---------- */
+#define CKEY_MAKE(a, j, suf, rev) (((u64)(a) << 17) | ((u64)(j) << 2) | ((u64)(suf) << 1) | (u64)(rev))
+#define CKEY_SUPER(c) ((c) >> 17)
+#define CKEY_J(c) ((u32)((c) >> 2) & 0x7FFFu)
+#define CKEY_SUFFIX(c) ((u32)(((c) >> 1) & 1u))
+#define CKEY_REV(c) ((u32)((c)&1u))
+
+/* hash-hit type of BG/HashTable.cpp:535-566 from (record kind, strand relation) */
+__host__ __device__ __forceinline__ u32 disco_hit_type(u32 is_suffix, u32 rev)
+{
+    /* prefix record: same strand -> 0, opposite -> 3 ; suffix record: same strand -> 1, opposite -> 2 */
+    return is_suffix ? (rev ? 2u : 1u) : (rev ? 3u : 0u);
+}
+
+/* orientation map of BG/OverlapGraph.cpp:428-434 / :660-666 ; offset = len1 - overlapLen */
+__host__ __device__ __forceinline__ void disco_map_type(u32 type, u32 len1, u32 k, u32 j, u32 *orient, u32 *offset)
+{
+    switch (type) {
+    case 0: *orient = 3; *offset = j; break;              /* ovl = len1 - j */
+    case 1: *orient = 0; *offset = len1 - (k + j); break; /* ovl = k + j    */
+    case 2: *orient = 2; *offset = j; break;
+    default: *orient = 1; *offset = len1 - (k + j); break;
+    }
+}
+
+/* twinEdgeOrientation, BG/OverlapGraph.cpp:770-784 */
+__host__ __device__ __forceinline__ u32 disco_twin_orient(u32 o) { return o == 0 ? 3u : (o == 3 ? 0u : o); }
+
+__host__ __device__ __forceinline__ u64 disco_hash64(u64 x)
+{
+    x ^= x >> 33;
+    x *= 0xFF51AFD7ED558CCDull;
+    x ^= x >> 33;
+    x *= 0xC4CEB9FE1A85EC53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ u64 lane_mask_lt()
+{
+    u32 l = __lane_id();
+    return l ? (~0ull >> (64 - l)) : 0ull;
+}
+
+/* reverse the order of the 32 2-bit groups of x */
+__device__ __forceinline__ u64 rev2_64(u64 x)
+{
+    u64 y = __brevll(x);
+    return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+}
+
+/* 32 bases starting at base position pos (>= 0) of the row p[0..S); positions past the row read as A (0) */
+__device__ __forceinline__ u64 extract32(const u64 *__restrict__ p, int S, int pos)
+{
+    int w = pos >> 5, sh = (pos & 31) * 2;
+    u64 a = (w < S) ? p[w] : 0ull;
+    if (sh == 0) return a;
+    u64 b = (w + 1 < S) ? p[w + 1] : 0ull;
+    return (a << sh) | (b >> (64 - sh));
+}
+
+/* k-mer (k <= 64) at base j as a right-aligned 2k-bit integer hi:lo */
+__device__ __forceinline__ void kmer_at(const u64 *__restrict__ p, int S, int j, int k, u64 &hi, u64 &lo)
+{
+    if (k <= 32) {
+        hi = 0;
+        lo = extract32(p, S, j) >> (64 - 2 * k);
+    } else {
+        hi = extract32(p, S, j) >> (64 - 2 * (k - 32));
+        lo = extract32(p, S, j + k - 32);
+    }
+}
+
+/* reverse complement of a right-aligned 2k-bit k-mer */
+__device__ __forceinline__ void kmer_revcomp(u64 hi, u64 lo, int k, u64 &rhi, u64 &rlo)
+{
+    u64 t_hi = rev2_64(~lo), t_lo = rev2_64(~hi); /* field now left-aligned in t_hi:t_lo */
+    int sh = 128 - 2 * k;
+    if (sh >= 64) {
+        rhi = 0;
+        rlo = (sh == 64) ? t_hi : (t_hi >> (sh - 64));
+    } else if (sh == 0) {
+        rhi = t_hi;
+        rlo = t_lo;
+    } else {
+        rlo = (t_lo >> sh) | (t_hi << (64 - sh));
+        rhi = t_hi >> sh;
+    }
+}
+
+/* canonical k-mer key (min of forward / reverse complement, like getHashIndex BG/HashTable.cpp:383-391);
+ * rev = 1 when the reverse complement is the canonical representative. A palindrome has rev = 0. */
+__device__ __forceinline__ u64 canonical_key(const u64 *__restrict__ p, int S, int j, int k, u32 &rev)
+{
+    u64 hi, lo, rhi, rlo;
+    kmer_at(p, S, j, k, hi, lo);
+    kmer_revcomp(hi, lo, k, rhi, rlo);
+    bool r = (rhi < hi) || (rhi == hi && rlo < lo);
+    rev = r ? 1u : 0u;
+    u64 chi = r ? rhi : hi, clo = r ? rlo : lo;
+    return disco_hash64(clo ^ disco_hash64(chi + 0x9E3779B97F4A7C15ull));
+}
+
+/* A[a0 .. a0+m) == s2[b0 .. b0+m) where s2 = B (rev = 0) or revcomp(B) (rev = 1); LB = length of B */
+__device__ __forceinline__ bool seg_equal(const u64 *__restrict__ pa, const u64 *__restrict__ pb, int S, int LB, int a0,
+                                          int b0, int m, u32 rev)
+{
+    for (int i = 0; i < m; i += 32) {
+        int n = m - i;
+        if (n > 32) n = 32;
+        u64 wa = extract32(pa, S, a0 + i);
+        u64 wb;
+        if (!rev) {
+            wb = extract32(pb, S, b0 + i);
+        } else {
+            /* s2[b0+i+t] = comp(B[LB-1-b0-i-t]) : take B[q .. q+n) and reverse-complement it */
+            int q = LB - b0 - i - n;
+            u64 x = extract32(pb, S, q);
+            wb = rev2_64(~x);
+            if (n < 32) wb <<= 2 * (32 - n);
+        }
+        u64 mask = (n == 32) ? ~0ull : (~0ull << (64 - 2 * n));
+        if ((wa ^ wb) & mask) return false;
+    }
+    return true;
+}
+
+#endif /* __HIPCC__ */
+#endif /* DISCO_DEVICE_H_ */

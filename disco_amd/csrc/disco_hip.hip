@@ -1,0 +1,1052 @@
+/*
+ * disco_hip.hip — C-ABI implementation (include/disco_hip.h) over the kernels in disco_kernels.h.
+ * Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -fPIC -shared -o libdisco_hip.so disco_hip.hip
+ *
+ * Data layout in HBM (n reads, stride S words, T = bucket table size, Eraw = verified overlap hits, E = directed edges):
+ *   reads      u64[n][S]      2-bit packed, fixed stride (coalesced row fetches, no offset indirection)
+ *   len        u16[n]
+ *   bkt        u32[T+1]       CSR bucket table of the end-k-mer index, T = pow2 >= 4n
+ *   ent        {u64 key, u64 payload}[2n]   payload = id | record strand | isSuffix | len
+ *   best       u64[n]         containment keys (atomicMin), all-reduced(MIN) across ranks
+ *   contained  u8[n]
+ *   hits       u64[cap]       raw verified overlap hits, wave-private chunks, rows addressed by row_start/row_cnt
+ *   adj_start  u64[n+1], adj u64[E]   adjacency CSR in node order (offset | dst | orient per entry)
+ *   flag       u8[E]          bit0 = transitive from this end, bit1 = survives (emitted from this end)
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/disco_hip.h"
+#include "disco_kernels.h"
+
+static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
+
+static thread_local std::string g_create_error;
+
+struct disco_ctx {
+    int device = 0;
+    disco_params prm{};
+    int k = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    std::string err;
+    size_t hbm_bytes = 0;
+
+    /* reads */
+    u64 n = 0;
+    int S = 0;
+    u64 *d_reads = nullptr;
+    u16 *d_len = nullptr;
+    bool reads_owned = false;
+    std::vector<uint16_t> h_len; /* lazily mirrored for result decoding */
+    u64 q_lo = 0, q_hi = 0;
+
+    /* index */
+    u64 T = 0;
+    int bshift = 0;
+    u32 *d_bkt = nullptr;
+    ulonglong2 *d_ent = nullptr;
+
+    /* scan temporaries */
+    u64 *d_tile = nullptr;
+    size_t tile_cap = 0;
+    u64 *d_total = nullptr;
+
+    /* counters */
+    u64 *d_ctr = nullptr;
+    u64 h_ctr[CTR_COUNT] = {0};
+
+    /* probe */
+    u64 *d_best = nullptr;
+    u64 *d_hits = nullptr;
+    u64 hits_cap = 0;
+    u64 *d_bump = nullptr;
+    u64 *d_row_start = nullptr;
+    u32 *d_row_cnt = nullptr;
+    u64 *d_big_list = nullptr;
+    u32 *d_big_cnt = nullptr;
+    u32 *d_n_big = nullptr;
+    u32 big_cap = 0;
+    u64 big_rows = 0;
+
+    /* containment */
+    u8 *d_contained = nullptr;
+    u64 n_contained = 0;
+
+    /* edges */
+    u32 *d_deg = nullptr;
+    u64 *d_adj_start = nullptr;
+    u64 *d_adj = nullptr;
+    u64 adj_total = 0; /* slots in the CSR the context currently holds */
+    bool adj_imported = false;
+    u32 *d_extra_cnt = nullptr;
+    u64 *d_extra_node = nullptr, *d_extra_key = nullptr;
+    u32 *d_n_extra = nullptr;
+    u32 extra_cap = 0;
+    u32 n_extra = 0;
+    u64 asym_local = 0;
+
+    /* reduction */
+    u8 *d_flag = nullptr;
+    u32 *d_kept = nullptr;
+    u64 *d_out_pos = nullptr;
+    u64 *d_out_src = nullptr, *d_out_ent = nullptr;
+    u64 n_out = 0;
+
+    int phase = 0; /* 0 none, 1 reads, 2 index, 3 probe, 4 contained, 5 edges selected, 6 symmetrized, 7 marked, 8 emitted */
+};
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+static int fail(disco_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                          \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? DISCO_E_NOMEM : DISCO_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define CHK(expr)                    \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != DISCO_OK) return rc_; \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(disco_ctx *c, T **p, size_t count)
+{
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPCHK(c, hipMalloc((void **)p, bytes));
+    c->hbm_bytes += bytes;
+    return DISCO_OK;
+}
+
+template <typename T>
+static void dev_free(disco_ctx *c, T **p, size_t count)
+{
+    if (*p) {
+        (void)hipFree(*p);
+        size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        c->hbm_bytes = c->hbm_bytes >= bytes ? c->hbm_bytes - bytes : 0;
+        *p = nullptr;
+    }
+}
+
+static DiscoView view(const disco_ctx *c)
+{
+    DiscoView v;
+    v.reads = c->d_reads;
+    v.len = c->d_len;
+    v.n = c->n;
+    v.S = c->S;
+    v.k = c->k;
+    v.bkt = c->d_bkt;
+    v.ent = c->d_ent;
+    v.bshift = c->bshift;
+    v.q_lo = c->q_lo;
+    v.q_hi = c->q_hi;
+    v.ctr = c->d_ctr;
+    return v;
+}
+
+static int wave_grid(const disco_ctx *c, u64 items, int per_cu = 24)
+{
+    u64 g = (u64)c->n_cu * per_cu;
+    if (items < g) g = items;
+    return (int)std::max<u64>(g, 1);
+}
+
+static int flat_grid(const disco_ctx *c, u64 items, int block = 256)
+{
+    u64 g = (items + block - 1) / block;
+    u64 cap = (u64)c->n_cu * 16;
+    return (int)std::max<u64>(std::min(g, cap), 1);
+}
+
+static int read_counters(disco_ctx *c)
+{
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(c->h_ctr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
+}
+
+static int zero_counter(disco_ctx *c, int idx)
+{
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + idx, 0, sizeof(u64), c->stream));
+    return DISCO_OK;
+}
+
+/* exclusive scan of in[0..n) into out[0..n) (+ out[n] = total when write_total); returns total through *total_host
+ * when non-null (this synchronises the stream) */
+template <typename InT, typename OutT>
+static int scan_exclusive(disco_ctx *c, const InT *in, u64 n, OutT *out, bool write_total, u64 *total_host)
+{
+    u64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nt == 0) nt = 1;
+    if (nt > c->tile_cap) {
+        dev_free(c, &c->d_tile, c->tile_cap);
+        CHK(dev_alloc(c, &c->d_tile, nt));
+        c->tile_cap = nt;
+    }
+    hipLaunchKernelGGL((scan_tile_sums_kernel<InT>), dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, c->stream, in, n, c->d_tile);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile, nt, c->d_total);
+    hipLaunchKernelGGL((scan_apply_kernel<InT, OutT>), dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, c->stream, in, n, c->d_tile, out);
+    if (write_total) hipLaunchKernelGGL((scan_write_total_kernel<OutT>), dim3(1), dim3(1), 0, c->stream, c->d_total, out + n);
+    HIPCHK(c, hipGetLastError());
+    if (total_host) {
+        HIPCHK(c, hipMemcpyAsync(total_host, c->d_total, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return DISCO_OK;
+}
+
+static void free_graph_state(disco_ctx *c)
+{
+    dev_free(c, &c->d_bkt, c->T + 1);
+    dev_free(c, &c->d_ent, 2 * c->n);
+    dev_free(c, &c->d_best, c->n);
+    dev_free(c, &c->d_hits, c->hits_cap);
+    c->hits_cap = 0;
+    dev_free(c, &c->d_row_start, c->n);
+    dev_free(c, &c->d_row_cnt, c->n);
+    dev_free(c, &c->d_big_list, c->big_cap);
+    dev_free(c, &c->d_big_cnt, c->big_cap);
+    c->big_cap = 0;
+    dev_free(c, &c->d_contained, c->n);
+    dev_free(c, &c->d_deg, c->n);
+    dev_free(c, &c->d_adj_start, c->n + 1);
+    dev_free(c, &c->d_adj, c->adj_total);
+    dev_free(c, &c->d_extra_cnt, c->n);
+    dev_free(c, &c->d_extra_node, c->extra_cap);
+    dev_free(c, &c->d_extra_key, c->extra_cap);
+    c->extra_cap = 0;
+    dev_free(c, &c->d_flag, c->adj_total);
+    c->adj_total = 0;
+    dev_free(c, &c->d_kept, c->q_hi - c->q_lo);
+    dev_free(c, &c->d_out_pos, c->q_hi - c->q_lo + 1);
+    dev_free(c, &c->d_out_src, c->n_out);
+    dev_free(c, &c->d_out_ent, c->n_out);
+    c->n_out = 0;
+    c->adj_imported = false;
+    c->T = 0;
+}
+
+static void free_reads(disco_ctx *c)
+{
+    if (c->reads_owned) {
+        dev_free(c, &c->d_reads, c->n * (u64)c->S);
+        dev_free(c, &c->d_len, c->n);
+    }
+    c->d_reads = nullptr;
+    c->d_len = nullptr;
+    c->reads_owned = false;
+    c->h_len.clear();
+    c->n = 0;
+}
+
+/* ================================================================================================================ */
+extern "C" {
+
+int disco_abi_version(void) { return DISCO_ABI_VERSION; }
+
+int disco_create(int device, const disco_params *p, disco_ctx **out)
+{
+    if (!p || !out) return fail(nullptr, DISCO_E_ARG, "disco_create: null argument");
+    if (p->min_overlap < 2 || p->min_overlap - 1 > 64)
+        return fail(nullptr, DISCO_E_UNSUPPORTED, "disco_create: min_overlap %u unsupported (k = min_overlap-1 must be in [1,64])", p->min_overlap);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, DISCO_E_HIP, "disco_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, DISCO_E_ARG, "disco_create: device %d out of range (%d devices)", device, ndev);
+    disco_ctx *c = new (std::nothrow) disco_ctx();
+    if (!c) return fail(nullptr, DISCO_E_NOMEM, "disco_create: out of host memory");
+    c->device = device;
+    c->prm = *p;
+    if (c->prm.max_edges_per_kmer == 0) c->prm.max_edges_per_kmer = 4;
+    c->k = (int)p->min_overlap - 1;
+#define CREATE_CHK(call)                                                                              \
+    do {                                                                                              \
+        hipError_t e2 = (call);                                                                       \
+        if (e2 != hipSuccess) {                                                                       \
+            int rc = fail(nullptr, DISCO_E_HIP, "disco_create: %s failed: %s", #call, hipGetErrorString(e2)); \
+            delete c;                                                                                 \
+            return rc;                                                                                \
+        }                                                                                             \
+    } while (0)
+    CREATE_CHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CREATE_CHK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_CHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CREATE_CHK(hipMalloc((void **)&c->d_ctr, sizeof(u64) * CTR_COUNT));
+    CREATE_CHK(hipMemset(c->d_ctr, 0, sizeof(u64) * CTR_COUNT));
+    CREATE_CHK(hipMalloc((void **)&c->d_total, sizeof(u64)));
+    CREATE_CHK(hipMalloc((void **)&c->d_bump, sizeof(u64)));
+    CREATE_CHK(hipMalloc((void **)&c->d_n_big, sizeof(u32)));
+    CREATE_CHK(hipMalloc((void **)&c->d_n_extra, sizeof(u32)));
+#undef CREATE_CHK
+    *out = c;
+    return DISCO_OK;
+}
+
+void disco_destroy(disco_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_graph_state(c);
+    free_reads(c);
+    dev_free(c, &c->d_tile, c->tile_cap);
+    (void)hipFree(c->d_ctr);
+    (void)hipFree(c->d_total);
+    (void)hipFree(c->d_bump);
+    (void)hipFree(c->d_n_big);
+    (void)hipFree(c->d_n_extra);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *disco_last_error(const disco_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int disco_set_stream(disco_ctx *c, void *hip_stream)
+{
+    if (!c) return DISCO_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return DISCO_OK;
+}
+
+int disco_synchronize(disco_ctx *c)
+{
+    if (!c) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
+}
+
+int disco_pack_ascii(const char *seq, uint32_t len, uint64_t *out_words)
+{
+    if (!seq || !out_words) return DISCO_E_ARG;
+    uint32_t nw = (len + 31) / 32;
+    for (uint32_t w = 0; w < nw; w++) out_words[w] = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint64_t b;
+        switch (seq[i]) {
+        case 'A': b = 0; break;
+        case 'C': b = 1; break;
+        case 'G': b = 2; break;
+        case 'T': b = 3; break;
+        default: return DISCO_E_ARG;
+        }
+        out_words[i >> 5] |= b << (62 - 2 * (i & 31));
+    }
+    return DISCO_OK;
+}
+
+static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride)
+{
+    if (n >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "more than 2^31 reads per context are not supported");
+    if (stride == 0 || stride > 1024) return fail(c, DISCO_E_ARG, "stride_words %u out of range", stride);
+    free_graph_state(c);
+    free_reads(c);
+    c->n = n;
+    c->S = (int)stride;
+    c->q_lo = 0;
+    c->q_hi = n;
+    c->phase = 0;
+    return DISCO_OK;
+}
+
+static int validate_reads(disco_ctx *c)
+{
+    CHK(zero_counter(c, CTR_BAD_LEN));
+    if (c->n) hipLaunchKernelGGL(validate_len_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_len, c->n, c->S, (int)c->prm.min_overlap, c->d_ctr);
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_BAD_LEN])
+        return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)c->h_ctr[CTR_BAD_LEN], c->prm.min_overlap);
+    c->phase = 1;
+    return DISCO_OK;
+}
+
+int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n)
+{
+    if (!c || (n && (!packed || !len))) return c ? fail(c, DISCO_E_ARG, "disco_upload_reads: null argument") : DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(set_reads_common(c, n, stride_words));
+    CHK(dev_alloc(c, &c->d_reads, n * (u64)stride_words));
+    CHK(dev_alloc(c, &c->d_len, n));
+    c->reads_owned = true;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_reads, packed, n * (u64)stride_words * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_len, len, n * 2, hipMemcpyHostToDevice, c->stream));
+    }
+    c->h_len.assign(len, len + n);
+    return validate_reads(c);
+}
+
+int disco_adopt_reads(disco_ctx *c, const void *d_packed, uint32_t stride_words, const void *d_len, uint64_t n)
+{
+    if (!c || (n && (!d_packed || !d_len))) return c ? fail(c, DISCO_E_ARG, "disco_adopt_reads: null argument") : DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(set_reads_common(c, n, stride_words));
+    c->d_reads = (u64 *)d_packed;
+    c->d_len = (u16 *)d_len;
+    c->reads_owned = false;
+    return validate_reads(c);
+}
+
+int disco_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
+{
+    if (!c || !s) return c ? fail(c, DISCO_E_ARG, "disco_generate_reads: null argument") : DISCO_E_ARG;
+    if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
+        return fail(c, DISCO_E_ARG, "disco_generate_reads: bad spec");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t stride = (s->len_max + 31) / 32;
+    CHK(set_reads_common(c, s->n_reads, stride));
+    CHK(dev_alloc(c, &c->d_reads, c->n * (u64)stride));
+    CHK(dev_alloc(c, &c->d_len, c->n));
+    c->reads_owned = true;
+    disco_genspec g;
+    memcpy(&g, s, sizeof g);
+    if (c->n) hipLaunchKernelGGL(generate_reads_kernel, dim3(flat_grid(c, c->n * stride)), dim3(256), 0, c->stream, g, c->d_reads, c->d_len, (int)stride);
+    HIPCHK(c, hipGetLastError());
+    return validate_reads(c);
+}
+
+int disco_download_reads(disco_ctx *c, uint64_t *packed, uint16_t *len)
+{
+    if (!c || c->phase < 1) return c ? fail(c, DISCO_E_STATE, "no reads") : DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (packed && c->n) HIPCHK(c, hipMemcpyAsync(packed, c->d_reads, c->n * (u64)c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    if (len && c->n) HIPCHK(c, hipMemcpyAsync(len, c->d_len, c->n * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
+}
+
+uint32_t disco_stride_words(const disco_ctx *c) { return c ? (uint32_t)c->S : 0; }
+uint64_t disco_num_reads(const disco_ctx *c) { return c ? c->n : 0; }
+
+int disco_set_query_range(disco_ctx *c, uint64_t lo, uint64_t hi)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 1 || c->phase > 2) return fail(c, DISCO_E_STATE, "disco_set_query_range: call after the reads are set and before disco_probe");
+    if (lo > hi || hi > c->n) return fail(c, DISCO_E_ARG, "query range [%llu,%llu) outside [0,%llu)", (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)c->n);
+    c->q_lo = lo;
+    c->q_hi = hi;
+    return DISCO_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+int disco_build_index(disco_ctx *c)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 1) return fail(c, DISCO_E_STATE, "disco_build_index: no reads");
+    HIPCHK(c, hipSetDevice(c->device));
+    u64 lo = c->q_lo, hi = c->q_hi;
+    free_graph_state(c);
+    c->q_lo = lo;
+    c->q_hi = hi;
+    u64 T = 1024;
+    int logT = 10;
+    while (T < 4 * c->n) {
+        T <<= 1;
+        logT++;
+    }
+    c->T = T;
+    c->bshift = 64 - logT;
+    CHK(dev_alloc(c, &c->d_bkt, T + 1));
+    CHK(dev_alloc(c, &c->d_ent, 2 * c->n));
+    HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (T + 1) * sizeof(u32), c->stream));
+    DiscoView v = view(c);
+    if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt);
+    CHK((scan_exclusive<u32, u32>(c, c->d_bkt + 1, T, c->d_bkt + 1, false, nullptr)));
+    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt, c->d_ent);
+    HIPCHK(c, hipGetLastError());
+    c->phase = 2;
+    return DISCO_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+int disco_probe(disco_ctx *c)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 2) return fail(c, DISCO_E_STATE, "disco_probe: build the index first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nq = c->q_hi - c->q_lo;
+    if (!c->d_best) {
+        CHK(dev_alloc(c, &c->d_best, c->n));
+        CHK(dev_alloc(c, &c->d_row_start, c->n));
+        CHK(dev_alloc(c, &c->d_row_cnt, c->n));
+    }
+    if (c->n) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, DISCO_NOKEY);
+    HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+    const int grid = wave_grid(c, nq, 28);
+    u64 want_hits = nq * 64 + (u64)grid * PROBE_CHUNK + (1u << 16);
+    u32 want_big = (u32)std::min<u64>(nq, nq / 64 + 1024);
+    for (int attempt = 0; attempt < 8; attempt++) {
+        if (want_hits > c->hits_cap) {
+            dev_free(c, &c->d_hits, c->hits_cap);
+            c->hits_cap = 0;
+            size_t fr = 0, tot = 0;
+            HIPCHK(c, hipMemGetInfo(&fr, &tot));
+            if (want_hits * 8 > fr) {
+                u64 can = fr / 8 / 10 * 9;
+                if (can < (u64)grid * PROBE_CHUNK * 2) return fail(c, DISCO_E_NOMEM, "disco_probe: not enough HBM for the hit buffer (%llu entries wanted)", (unsigned long long)want_hits);
+                want_hits = can;
+            }
+            CHK(dev_alloc(c, &c->d_hits, want_hits));
+            c->hits_cap = want_hits;
+        }
+        if (want_big > c->big_cap) {
+            dev_free(c, &c->d_big_list, c->big_cap);
+            dev_free(c, &c->d_big_cnt, c->big_cap);
+            CHK(dev_alloc(c, &c->d_big_list, want_big));
+            CHK(dev_alloc(c, &c->d_big_cnt, want_big));
+            c->big_cap = want_big;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + CTR_KMER_HITS, 0, sizeof(u64) * 4, c->stream)); /* KMER_HITS, RAW_HITS, HITS_NEEDED, OVERFLOW */
+        CHK(zero_counter(c, CTR_MAX_ROW));
+        ProbeArgs a;
+        a.v = view(c);
+        a.best = c->d_best;
+        a.hits = c->d_hits;
+        a.hits_cap = c->hits_cap;
+        a.bump = c->d_bump;
+        a.row_start = c->d_row_start;
+        a.row_cnt = c->d_row_cnt;
+        a.big_list = c->d_big_list;
+        a.big_cnt = c->d_big_cnt;
+        a.n_big = c->d_n_big;
+        a.big_cap = c->big_cap;
+        if (nq) hipLaunchKernelGGL(probe_kernel<false>, dim3(grid), dim3(64), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        u32 n_big = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        CHK(read_counters(c));
+        if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
+            int g2 = wave_grid(c, n_big, 8);
+            hipLaunchKernelGGL(probe_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
+            HIPCHK(c, hipGetLastError());
+            CHK(read_counters(c));
+        }
+        if (!c->h_ctr[CTR_OVERFLOW]) {
+            c->big_rows = n_big;
+            c->phase = 3;
+            return DISCO_OK;
+        }
+        /* something was too small: grow and redo the pass (atomicMin on best is idempotent) */
+        if (n_big > c->big_cap) want_big = (u32)std::min<u64>(nq, (u64)n_big + n_big / 4 + 1024);
+        u64 needed = c->h_ctr[CTR_HITS_NEEDED];
+        want_hits = std::max<u64>(c->hits_cap * 2, needed + needed / 4 + (u64)grid * PROBE_CHUNK);
+    }
+    return fail(c, DISCO_E_CAPACITY, "disco_probe: hit buffer could not be sized");
+}
+
+int disco_contain_keys(disco_ctx *c, void **d_keys, uint64_t *n)
+{
+    if (!c || !d_keys || !n) return DISCO_E_ARG;
+    if (c->phase < 3) return fail(c, DISCO_E_STATE, "disco_contain_keys: run disco_probe first");
+    *d_keys = c->d_best;
+    *n = c->n;
+    return DISCO_OK;
+}
+
+int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 3) return fail(c, DISCO_E_STATE, "disco_mark_contained: run disco_probe first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n));
+    CHK(zero_counter(c, CTR_N_CONTAINED));
+    if (c->n) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    CHK(read_counters(c));
+    c->n_contained = c->h_ctr[CTR_N_CONTAINED];
+    if (n_contained) *n_contained = c->n_contained;
+    c->phase = 4;
+    return DISCO_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+static int select_edges(disco_ctx *c)
+{
+    const u64 nq = c->q_hi - c->q_lo;
+    if (!c->d_deg) CHK(dev_alloc(c, &c->d_deg, c->n));
+    HIPCHK(c, hipMemsetAsync(c->d_deg, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
+    CHK(zero_counter(c, CTR_CAP_SITES));
+    CHK(zero_counter(c, CTR_OVERFLOW));
+    EdgeSelArgs a;
+    a.v = view(c);
+    a.contained = c->d_contained;
+    a.hits = c->d_hits;
+    a.row_start = c->d_row_start;
+    a.row_cnt = c->d_row_cnt;
+    a.deg = c->d_deg;
+    a.max_per_kmer = c->prm.max_edges_per_kmer;
+    a.big_list = c->d_big_list;
+    a.n_big = c->d_n_big;
+    a.big_cap = c->big_cap;
+    a.scratch = nullptr;
+    a.scratch_cap = 0;
+    if (c->big_cap == 0) { /* probe always allocates it; be safe */
+        CHK(dev_alloc(c, &c->d_big_list, 1024));
+        CHK(dev_alloc(c, &c->d_big_cnt, 1024));
+        c->big_cap = 1024;
+        a.big_list = c->d_big_list;
+        a.big_cap = c->big_cap;
+    }
+    if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    u32 n_big = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "edge selection: big-row list overflow (%u rows)", n_big);
+    if (n_big) {
+        int g2 = (int)std::min<u64>(n_big, 64);
+        u64 cap = c->h_ctr[CTR_MAX_ROW] + 64;
+        u64 *scratch = nullptr;
+        CHK(dev_alloc(c, &scratch, (u64)g2 * 2 * cap));
+        a.scratch = scratch;
+        a.scratch_cap = cap;
+        hipLaunchKernelGGL(edge_select_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
+        hipError_t e = hipGetLastError();
+        int rc = read_counters(c);
+        dev_free(c, &scratch, (u64)g2 * 2 * cap);
+        if (e != hipSuccess) return fail(c, DISCO_E_HIP, "edge_select_kernel<true>: %s", hipGetErrorString(e));
+        CHK(rc);
+    }
+    c->h_ctr[CTR_ES_BIG] = n_big;
+    /* CSR in node order; nodes outside the query range have empty rows */
+    if (!c->d_adj_start) CHK(dev_alloc(c, &c->d_adj_start, c->n + 1));
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_deg, c->n, c->d_adj_start, true, &total)));
+    dev_free(c, &c->d_adj, c->adj_total);
+    dev_free(c, &c->d_flag, c->adj_total);
+    c->adj_total = total;
+    CHK(dev_alloc(c, &c->d_adj, total));
+    if (nq) hipLaunchKernelGGL(csr_copy_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_hits, c->d_row_start, c->d_deg, c->q_lo, c->q_hi, c->d_adj_start, 0ull, c->d_adj);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* the raw hits are dead now: give the memory back */
+    dev_free(c, &c->d_hits, c->hits_cap);
+    c->hits_cap = 0;
+    c->adj_imported = false;
+    c->phase = 5;
+    return DISCO_OK;
+}
+
+/* twin check over targets [lo,hi); collects extras, does not merge */
+static int twin_check(disco_ctx *c, u64 lo, u64 hi)
+{
+    if (!c->d_extra_cnt) CHK(dev_alloc(c, &c->d_extra_cnt, c->n));
+    u32 want = 4096;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (want > c->extra_cap) {
+            dev_free(c, &c->d_extra_node, c->extra_cap);
+            dev_free(c, &c->d_extra_key, c->extra_cap);
+            CHK(dev_alloc(c, &c->d_extra_node, want));
+            CHK(dev_alloc(c, &c->d_extra_key, want));
+            c->extra_cap = want;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_extra_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_n_extra, 0, sizeof(u32), c->stream));
+        CHK(zero_counter(c, CTR_ASYM));
+        CHK(zero_counter(c, CTR_OVERFLOW));
+        TwinArgs a;
+        a.v = view(c);
+        a.adj_start = c->d_adj_start;
+        a.adj = c->d_adj;
+        a.lo = lo;
+        a.hi = hi;
+        a.extra_cnt = c->d_extra_cnt;
+        a.extra_node = c->d_extra_node;
+        a.extra_key = c->d_extra_key;
+        a.n_extra = c->d_n_extra;
+        a.extra_cap = c->extra_cap;
+        if (c->n) hipLaunchKernelGGL(twin_check_kernel, dim3(flat_grid(c, c->n * 64)), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        u32 ne = 0;
+        HIPCHK(c, hipMemcpyAsync(&ne, c->d_n_extra, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        CHK(read_counters(c));
+        if (!c->h_ctr[CTR_OVERFLOW]) {
+            c->n_extra = ne;
+            c->asym_local = c->h_ctr[CTR_ASYM];
+            return DISCO_OK;
+        }
+        want = ne + ne / 4 + 4096;
+    }
+    return fail(c, DISCO_E_CAPACITY, "twin check: extras list could not be sized");
+}
+
+/* merge the collected extras into the CSR (rare: only when pairs were found from one side only) */
+static int merge_extras(disco_ctx *c)
+{
+    if (c->n_extra == 0) return DISCO_OK;
+    u32 *new_deg = nullptr, *fill = nullptr;
+    u64 *new_start = nullptr, *new_adj = nullptr, *scratch = nullptr;
+    CHK(dev_alloc(c, &new_deg, c->n));
+    CHK(dev_alloc(c, &fill, c->n));
+    CHK(dev_alloc(c, &new_start, c->n + 1));
+    hipLaunchKernelGGL(add_u32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_start, c->d_extra_cnt, c->n, new_deg);
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, new_deg, c->n, new_start, true, &total)));
+    CHK(dev_alloc(c, &new_adj, total));
+    HIPCHK(c, hipMemsetAsync(fill, 0, c->n * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(merge_copy_kernel, dim3(wave_grid(c, c->n, 16)), dim3(64), 0, c->stream, c->d_adj_start, c->d_adj, new_start, new_adj, c->n);
+    hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_start, new_start, fill, new_adj);
+    /* row scratch: the longest merged row */
+    u64 maxdeg = 0;
+    {
+        std::vector<u32> h(c->n);
+        HIPCHK(c, hipMemcpyAsync(h.data(), new_deg, c->n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (u32 d : h) maxdeg = std::max<u64>(maxdeg, d);
+    }
+    int g = (int)std::min<u64>(c->n, 256);
+    CHK(dev_alloc(c, &scratch, (u64)g * (maxdeg + 1)));
+    hipLaunchKernelGGL(merge_sort_kernel, dim3(g), dim3(64), 0, c->stream, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &scratch, (u64)g * (maxdeg + 1));
+    dev_free(c, &new_deg, c->n);
+    dev_free(c, &fill, c->n);
+    dev_free(c, &c->d_adj, c->adj_total);
+    dev_free(c, &c->d_adj_start, c->n + 1);
+    c->d_adj = new_adj;
+    c->d_adj_start = new_start;
+    c->adj_total = total;
+    c->n_extra = 0;
+    return DISCO_OK;
+}
+
+int disco_select_edges(disco_ctx *c)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase != 4) return fail(c, DISCO_E_STATE, "disco_select_edges: run disco_mark_contained first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return select_edges(c);
+}
+
+/* full != 0: check (and complete) the lists of ALL nodes; else only those of the query range */
+int disco_symmetrize(disco_ctx *c, int full, uint64_t *n_asym)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_symmetrize: select edges first");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(twin_check(c, full ? 0 : c->q_lo, full ? c->n : c->q_hi));
+    if (n_asym) *n_asym = c->asym_local;
+    c->phase = 6;
+    return DISCO_OK;
+}
+
+int disco_merge_extras(disco_ctx *c)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 6) return fail(c, DISCO_E_STATE, "disco_merge_extras: symmetrize first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return merge_extras(c);
+}
+
+int disco_build_edges(disco_ctx *c, uint64_t *n_pre)
+{
+    if (!c) return DISCO_E_ARG;
+    CHK(disco_select_edges(c));
+    CHK(disco_symmetrize(c, 1, nullptr));
+    CHK(merge_extras(c));
+    if (n_pre) *n_pre = c->adj_total / 2;
+    return DISCO_OK;
+}
+
+int disco_adjacency_size(disco_ctx *c, uint64_t *n_entries)
+{
+    if (!c || !n_entries) return DISCO_E_ARG;
+    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_adjacency_size: select edges first");
+    *n_entries = c->adj_total;
+    return DISCO_OK;
+}
+
+int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
+{
+    if (!c || !d_deg_u32) return DISCO_E_ARG;
+    if (c->phase < 5 || c->adj_imported) return fail(c, DISCO_E_STATE, "disco_export_adjacency: needs the locally selected edges");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nq = c->q_hi - c->q_lo;
+    if (nq) hipLaunchKernelGGL(deg_from_start_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_start, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
+    HIPCHK(c, hipGetLastError());
+    if (c->adj_total && d_entries_u64) HIPCHK(c, hipMemcpyAsync(d_entries_u64, c->d_adj, c->adj_total * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
+}
+
+int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all)
+{
+    if (!c || !d_deg_u32_all) return DISCO_E_ARG;
+    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_import_adjacency: select edges first");
+    HIPCHK(c, hipSetDevice(c->device));
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, c->d_adj_start, true, &total)));
+    if (total != n_entries_all) return fail(c, DISCO_E_ARG, "disco_import_adjacency: degrees sum to %llu but %llu entries were passed", (unsigned long long)total, (unsigned long long)n_entries_all);
+    dev_free(c, &c->d_adj, c->adj_total);
+    dev_free(c, &c->d_flag, c->adj_total);
+    c->adj_total = total;
+    CHK(dev_alloc(c, &c->d_adj, total));
+    if (total) HIPCHK(c, hipMemcpyAsync(c->d_adj, d_entries_u64_all, total * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->adj_imported = true;
+    c->phase = 5;
+    return DISCO_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+int disco_transitive_mark(disco_ctx *c)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 6) return fail(c, DISCO_E_STATE, "disco_transitive_mark: build edges first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nq = c->q_hi - c->q_lo;
+    if (!c->d_flag) CHK(dev_alloc(c, &c->d_flag, c->adj_total));
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_total, 1), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
+    CHK(zero_counter(c, CTR_OVERFLOW));
+    if (c->big_cap == 0) {
+        CHK(dev_alloc(c, &c->d_big_list, 1024));
+        CHK(dev_alloc(c, &c->d_big_cnt, 1024));
+        c->big_cap = 1024;
+    }
+    TrArgs a;
+    a.v = view(c);
+    a.adj_start = c->d_adj_start;
+    a.adj = c->d_adj;
+    a.flag = c->d_flag;
+    a.big_list = c->d_big_list;
+    a.n_big = c->d_n_big;
+    a.big_cap = c->big_cap;
+    a.scratch = nullptr;
+    a.hcap = 0;
+    if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wave_grid(c, nq, 20)), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    u32 n_big = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking: big-node list overflow (%u nodes)", n_big);
+    if (n_big) {
+        /* longest list among the big nodes bounds the hash size */
+        std::vector<u64> big(n_big);
+        HIPCHK(c, hipMemcpyAsync(big.data(), c->d_big_list, n_big * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        u64 maxd = 0;
+        for (u64 v : big) {
+            u64 se[2];
+            HIPCHK(c, hipMemcpy(se, c->d_adj_start + v, 16, hipMemcpyDeviceToHost));
+            maxd = std::max(maxd, se[1] - se[0]);
+        }
+        u64 hcap = 64;
+        while (hcap < 2 * maxd) hcap <<= 1;
+        int g2 = (int)std::min<u64>(n_big, 128);
+        u64 per = hcap * 8 + hcap * 4 + hcap;
+        u8 *scratch = nullptr;
+        CHK(dev_alloc(c, &scratch, (u64)g2 * per));
+        a.scratch = (u64 *)scratch;
+        a.hcap = hcap;
+        hipLaunchKernelGGL(transitive_mark_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
+        hipError_t e = hipGetLastError();
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        dev_free(c, &scratch, (u64)g2 * per);
+        if (e != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel<true>: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    c->h_ctr[CTR_TR_BIG] = n_big;
+    c->phase = 7;
+    return DISCO_OK;
+}
+
+/* flags of the local nodes' slots live at d_flags[slot_lo .. slot_hi) of a u8 array with `total` slots; ranks all-gather
+ * those byte ranges between disco_transitive_mark and disco_emit_edges */
+int disco_tr_flags(disco_ctx *c, void **d_flags, uint64_t *slot_lo, uint64_t *slot_hi, uint64_t *total)
+{
+    if (!c || !d_flags || !slot_lo || !slot_hi || !total) return DISCO_E_ARG;
+    if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_tr_flags: run disco_transitive_mark first");
+    HIPCHK(c, hipSetDevice(c->device));
+    u64 lo = 0, hi = 0;
+    HIPCHK(c, hipMemcpy(&lo, c->d_adj_start + c->q_lo, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&hi, c->d_adj_start + c->q_hi, 8, hipMemcpyDeviceToHost));
+    *d_flags = c->d_flag;
+    *slot_lo = lo;
+    *slot_hi = hi;
+    *total = c->adj_total;
+    return DISCO_OK;
+}
+
+int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_emit_edges: run disco_transitive_mark first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nq = c->q_hi - c->q_lo;
+    if (!c->d_kept) {
+        CHK(dev_alloc(c, &c->d_kept, nq));
+        CHK(dev_alloc(c, &c->d_out_pos, nq + 1));
+    }
+    EmitArgs a;
+    a.v = view(c);
+    a.adj_start = c->d_adj_start;
+    a.adj = c->d_adj;
+    a.flag = c->d_flag;
+    a.kept = c->d_kept;
+    a.out_pos = c->d_out_pos;
+    a.out_src = nullptr;
+    a.out_ent = nullptr;
+    if (nq) hipLaunchKernelGGL(emit_kernel<false>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_kept, nq, c->d_out_pos, true, &total)));
+    dev_free(c, &c->d_out_src, c->n_out);
+    dev_free(c, &c->d_out_ent, c->n_out);
+    c->n_out = total;
+    CHK(dev_alloc(c, &c->d_out_src, total));
+    CHK(dev_alloc(c, &c->d_out_ent, total));
+    a.out_src = c->d_out_src;
+    a.out_ent = c->d_out_ent;
+    if (nq) hipLaunchKernelGGL(emit_kernel<true>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = total;
+    c->phase = 8;
+    return DISCO_OK;
+}
+
+int disco_transitive_reduce(disco_ctx *c, uint64_t *n_out)
+{
+    CHK(disco_transitive_mark(c));
+    return disco_emit_edges(c, n_out);
+}
+
+int disco_run_graph(disco_ctx *c)
+{
+    CHK(disco_build_index(c));
+    CHK(disco_probe(c));
+    CHK(disco_mark_contained(c, nullptr));
+    CHK(disco_build_edges(c, nullptr));
+    return disco_transitive_reduce(c, nullptr);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+static int ensure_host_len(disco_ctx *c)
+{
+    if (c->h_len.size() == c->n) return DISCO_OK;
+    c->h_len.resize(c->n);
+    if (c->n) HIPCHK(c, hipMemcpy(c->h_len.data(), c->d_len, c->n * 2, hipMemcpyDeviceToHost));
+    return DISCO_OK;
+}
+
+int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t cap)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 4) return fail(c, DISCO_E_STATE, "disco_fetch_contained: run disco_mark_contained first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nc = c->n_contained;
+    if (!out) return (int64_t)nc;
+    if (cap < nc) return fail(c, DISCO_E_ARG, "disco_fetch_contained: need room for %llu rows", (unsigned long long)nc);
+    if (nc == 0) return 0;
+    CHK(ensure_host_len(c));
+    u64 *pos = nullptr, *ids = nullptr, *keys = nullptr;
+    CHK(dev_alloc(c, &pos, c->n + 1));
+    CHK(dev_alloc(c, &ids, nc));
+    CHK(dev_alloc(c, &keys, nc));
+    CHK((scan_exclusive<u8, u64>(c, c->d_contained, c->n, pos, false, nullptr)));
+    hipLaunchKernelGGL(contain_rows_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->d_contained, pos, c->n, ids, keys);
+    std::vector<u64> hid(nc), hkey(nc);
+    HIPCHK(c, hipMemcpyAsync(hid.data(), ids, nc * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hkey.data(), keys, nc * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &pos, c->n + 1);
+    dev_free(c, &ids, nc);
+    dev_free(c, &keys, nc);
+    for (u64 i = 0; i < nc; i++) {
+        const u64 key = hkey[i];
+        disco_contained_row &r = out[i];
+        r.contained = hid[i];
+        r.super = CKEY_SUPER(key);
+        r.j = CKEY_J(key);
+        r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
+        r.len2 = c->h_len[r.contained];
+        r.len1 = c->h_len[r.super];
+        u32 orient, off;
+        disco_map_type(r.type, r.len1, (u32)c->k, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
+        r.orient = orient;
+        r.start = off;
+    }
+    return (int64_t)nc;
+}
+
+int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edges: run disco_transitive_reduce first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 ne = c->n_out;
+    if (!out) return (int64_t)ne;
+    if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edges: need room for %llu edges", (unsigned long long)ne);
+    if (ne == 0) return 0;
+    CHK(ensure_host_len(c));
+    std::vector<u64> hs(ne), he(ne);
+    HIPCHK(c, hipMemcpyAsync(hs.data(), c->d_out_src, ne * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(he.data(), c->d_out_ent, ne * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (u64 i = 0; i < ne; i++) {
+        disco_edge &e = out[i];
+        e.src = hs[i];
+        e.dst = ADJ_DST(he[i]);
+        e.orient = ADJ_ORI(he[i]);
+        e.offset = ADJ_OFF(he[i]);
+        e.len_src = c->h_len[e.src];
+        e.len_dst = c->h_len[e.dst];
+    }
+    return (int64_t)ne;
+}
+
+int disco_get_counters(disco_ctx *c, disco_counters *o)
+{
+    if (!c || !o) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    memset(o, 0, sizeof *o);
+    o->n_reads = c->n;
+    if (c->phase >= 1) {
+        CHK(ensure_host_len(c));
+        u64 q = 0;
+        for (u64 i = c->q_lo; i < c->q_hi; i++) q += c->h_len[i] - c->k;
+        o->probes = q;
+    }
+    o->kmer_hits = c->h_ctr[CTR_KMER_HITS];
+    o->raw_hits = c->h_ctr[CTR_RAW_HITS];
+    o->n_contained = c->n_contained;
+    o->e_pre = c->phase >= 6 ? c->adj_total / 2 : 0;
+    o->e_out = c->n_out;
+    o->cap_bind_sites = c->h_ctr[CTR_CAP_SITES];
+    o->asymmetric_pairs = c->asym_local;
+    o->big_rows = c->big_rows;
+    o->index_buckets = c->T;
+    o->hbm_bytes = c->hbm_bytes;
+    return DISCO_OK;
+}
+
+} /* extern "C" */

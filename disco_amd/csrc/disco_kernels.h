@@ -1,0 +1,896 @@
+/*
+ * disco_kernels.h — hand-written HIP kernels of the BuildGraph hot path for gfx950 (MI355X, wave64).
+ *
+ * Everything here is integer / compare work bounded by HBM traffic (no MFMA).  One wavefront (= one 64-thread
+ * workgroup, so __syncthreads() is a wave-level fence) owns one read / graph node at a time; cross-lane
+ * compaction uses ballot + popcount prefix, per-read staging lives in LDS.
+ *
+ * Reference semantics restated by each kernel are cited as BG/<file>:<lines>
+ * (BG/ = /root/reference/src/BuildGraph/src/).
+ */
+#ifndef DISCO_KERNELS_H_
+#define DISCO_KERNELS_H_
+
+#include "disco_device.h"
+#include "readgen.h"
+
+/* ---- tunables -------------------------------------------------------------------------------------------------- */
+#define PROBE_ROWCAP 512  /* verified overlap hits of one read staged in LDS before the flush                  */
+#define PROBE_QCAP 128    /* candidate queue (k-mer key matches waiting for verification)                       */
+#define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
+#define ES_CAP 512        /* edge_select: hits of one read sorted in LDS                                        */
+#define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
+#define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+/* global counters (u64 each) */
+enum {
+    CTR_KMER_HITS = 0,
+    CTR_RAW_HITS,
+    CTR_HITS_NEEDED,   /* high-water mark of the hit bump pointer                       */
+    CTR_OVERFLOW,      /* != 0: a buffer was too small, results incomplete -> regrow      */
+    CTR_CAP_SITES,
+    CTR_ASYM,
+    CTR_N_CONTAINED,
+    CTR_BAD_LEN,
+    CTR_BIG_ROWS,
+    CTR_ES_BIG,
+    CTR_TR_BIG,
+    CTR_MAX_DEG,
+    CTR_MAX_ROW,
+    CTR_COUNT
+};
+
+struct DiscoView {
+    const u64 *reads; /* [n][S] */
+    const u16 *len;   /* [n]    */
+    u64 n;
+    int S;
+    int k;
+    /* index */
+    const u32 *bkt;         /* [T+1] bucket b = entries [bkt[b], bkt[b+1]) */
+    const ulonglong2 *ent;  /* [2n] {key, payload}                          */
+    int bshift;             /* bucket = key >> bshift                       */
+    /* query shard */
+    u64 q_lo, q_hi;
+    u64 *ctr;
+};
+
+/* ================================================================================================================
+ * synthetic reads straight into HBM (bench / tests) — twin of readgen.h / readgen.py
+ * ============================================================================================================== */
+__global__ void generate_reads_kernel(disco_genspec spec, u64 *__restrict__ reads, u16 *__restrict__ len, int S)
+{
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 total = spec.n_reads * (u64)S;
+    for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
+        u64 r = gid / S;
+        int w = (int)(gid % S);
+        disco_readloc loc = disco_read_location(&spec, r);
+        u64 word = 0;
+        int base0 = w * 32;
+        for (int i = 0; i < 32; i++) {
+            int p = base0 + i;
+            if (p < (int)loc.len) word |= (u64)disco_read_base(&spec, &loc, (u32)p) << (62 - 2 * i);
+        }
+        reads[gid] = word;
+        if (w == 0) len[r] = (u16)loc.len;
+    }
+}
+
+/* reads must satisfy min_overlap < len <= 32767 (BG/Dataset.cpp:305, BG/HashTable.cpp:531) and fit the stride */
+__global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, int min_overlap, u64 *ctr)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 bad = 0;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u32 L = len[i];
+        if (L <= (u32)min_overlap || L > 32767u || L > (u32)S * 32u) bad++;
+    }
+    if (bad) atomicAdd(&ctr[CTR_BAD_LEN], (u64)bad);
+}
+
+/* ================================================================================================================
+ * index build — replaces HashTable::insertDataset (BG/HashTable.cpp:46-114): count per bucket (populateReadLengths),
+ * exclusive prefix sum (:58-67), fill (populateReadData / insertIntoTable :423-514).
+ * In-bucket order is arbitrary here: every consumer re-establishes the reference's bucket order (ascending read id,
+ * prefix record before suffix record) from the ids carried in the hits (see HIT_MAKE / CKEY_MAKE).
+ * bkt has T+1 slots; counts go to bkt[1+b]; after the in-place exclusive scan of bkt[1..T] and the fill (which
+ * bumps bkt[1+b] by the bucket size) bucket b is [bkt[b], bkt[b+1]).
+ * ============================================================================================================== */
+__global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 *p = v.reads + i * v.S;
+        int L = v.len[i];
+        u32 rev;
+        u64 kp = canonical_key(p, v.S, 0, v.k, rev);
+        u64 ks = canonical_key(p, v.S, L - v.k, v.k, rev);
+        atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
+        atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
+    }
+}
+
+__global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ ent)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 *p = v.reads + i * v.S;
+        int L = v.len[i];
+        u32 rp, rs;
+        u64 kp = canonical_key(p, v.S, 0, v.k, rp);
+        u64 ks = canonical_key(p, v.S, L - v.k, v.k, rs);
+        u32 pos = atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
+        ent[pos] = make_ulonglong2(kp, PAY_MAKE(i, rp, 0, L));
+        pos = atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
+        ent[pos] = make_ulonglong2(ks, PAY_MAKE(i, rs, 1, L));
+    }
+}
+
+/* ================================================================================================================
+ * exclusive scan (hand-written, three launches): tile sums -> scan of tile sums -> per-tile scan + offset.
+ * InT in {u8,u32}; OutT in {u32,u64}; out may alias in when sizeof(InT)==sizeof(OutT). out[n] = total if write_total.
+ * ============================================================================================================== */
+template <typename InT>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_tile_sums_kernel(const InT *__restrict__ in, u64 n, u64 *__restrict__ tile_sums)
+{
+    __shared__ u64 s_part[SCAN_BLOCK / DISCO_WAVE];
+    u64 base = (u64)blockIdx.x * SCAN_TILE;
+    u64 sum = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        u64 idx = base + (u64)i * SCAN_BLOCK + threadIdx.x;
+        if (idx < n) sum += (u64)in[idx];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0;
+        for (int w = 0; w < SCAN_BLOCK / DISCO_WAVE; w++) t += s_part[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+/* single block: exclusive scan of tile_sums[0..nt) in place; total -> *total */
+__global__ void __launch_bounds__(1024) scan_sums_kernel(u64 *__restrict__ tile_sums, u64 nt, u64 *__restrict__ total)
+{
+    __shared__ u64 s_w[16];
+    __shared__ u64 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nt; base += 1024) {
+        u64 idx = base + threadIdx.x;
+        u64 x = idx < nt ? tile_sums[idx] : 0;
+        u64 incl = x;
+        for (int o = 1; o < 64; o <<= 1) {
+            u64 y = __shfl_up(incl, o);
+            if ((int)(threadIdx.x & 63) >= o) incl += y;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        u64 woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += s_w[w];
+        u64 carry = s_carry;
+        if (idx < nt) tile_sums[idx] = carry + woff + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+template <typename InT, typename OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const InT *in, u64 n, const u64 *__restrict__ tile_sums, OutT *out)
+{
+    __shared__ u64 s_w[SCAN_BLOCK / DISCO_WAVE];
+    /* thread t owns SCAN_ITEMS consecutive elements so that the tile is scanned in order */
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u64 vals[SCAN_ITEMS];
+    u64 sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        u64 idx = base + i;
+        vals[i] = idx < n ? (u64)in[idx] : 0;
+        sum += vals[i];
+    }
+    u64 incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        u64 y = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u64 off = tile_sums[blockIdx.x] + incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_w[w];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        u64 idx = base + i;
+        if (idx < n) out[idx] = (OutT)off;
+        off += vals[i];
+    }
+}
+
+template <typename OutT>
+__global__ void scan_write_total_kernel(const u64 *total, OutT *out_n) { *out_n = (OutT)*total; }
+
+/* ================================================================================================================
+ * probe + verify — the dominant kernel.
+ *   getListOfReads (BG/HashTable.cpp:521-571) for every k-mer j of every query read A, then on every candidate
+ *   checkOverlapForContainedRead (BG/OverlapGraph.cpp:517-554) and checkOverlap (:567-595), both as ONE shifted
+ *   packed compare over the whole aligned region (which also re-checks the k-mer itself, so a 64-bit key collision
+ *   can never produce a hit).
+ * Containment is resolved with atomicMin on a packed key (closed form of the sequential loop):
+ *   super(x) = smallest id A that contains x with len(A) > len(x), or len equal and A < x (BG/OverlapGraph.cpp:424,449);
+ *   the recorded row is the first hit in (j, bucket order).
+ * Verified overlap hits of one read are staged in LDS, then flushed to a wave-private chunk of the global hit buffer.
+ * ============================================================================================================== */
+struct ProbeArgs {
+    DiscoView v;
+    u64 *best;      /* [n] containment keys                           */
+    u64 *hits;      /* global hit buffer                              */
+    u64 hits_cap;
+    u64 *bump;      /* bump pointer into hits                         */
+    u64 *row_start; /* [n]                                            */
+    u32 *row_cnt;   /* [n]                                            */
+    u64 *big_list;  /* reads whose row did not fit PROBE_ROWCAP       */
+    u32 *big_cnt;
+    u32 *n_big;
+    u32 big_cap;
+};
+
+template <bool BIG>
+__global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
+{
+    __shared__ u64 s_row[BIG ? 1 : PROBE_ROWCAP];
+    __shared__ u64 s_cq[PROBE_QCAP];
+    __shared__ u32 s_cj[PROBE_QCAP];
+    const u32 lane = threadIdx.x;
+    const int S = a.v.S, k = a.v.k;
+    u64 chunk_base = 0;
+    u32 chunk_used = PROBE_CHUNK;
+    u64 my_khits = 0, my_raw = 0;
+    u32 my_maxrow = 0;
+    const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
+
+    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
+        const u64 *pa = a.v.reads + A * S;
+        const int LA = a.v.len[A];
+        const int npos = LA - k; /* j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
+        u32 nrow = 0, ncand = 0;
+        u64 read_khits = 0; /* per-lane, this read only */
+        u64 *grow = nullptr;
+        if (BIG) {
+            u64 base = 0;
+            u32 want = a.big_cnt[it];
+            if (lane == 0) {
+                base = atomicAdd(a.bump, (u64)want);
+                atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + want);
+                a.row_start[A] = base;
+            }
+            base = __shfl(base, 0);
+            if (base + want <= a.hits_cap) grow = a.hits + base;
+            else if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+        }
+
+        /* verify the first cnt queued candidates (cnt <= 64), one per lane */
+        auto verify = [&](u32 cnt) {
+            bool ov = false;
+            u64 hit = 0;
+            if (lane < cnt) {
+                const u64 c = s_cq[lane];
+                const int j = (int)s_cj[lane];
+                const u64 B = PAY_ID(c);
+                const int LB = (int)PAY_LEN(c);
+                const u32 suf = PAY_SUFFIX(c), rev = PAY_REV(c);
+                const u64 *pb = a.v.reads + B * S;
+                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
+                /* exact k-mer re-check (the index compares only 64-bit keys) */
+                if (seg_equal(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
+                    read_khits++;
+                    int a0, b0, m;
+                    bool contain, overlap;
+                    if (prefix_align) {
+                        int rem = LA - j;
+                        contain = rem >= LB;              /* BG/OverlapGraph.cpp:532 */
+                        overlap = !contain && j >= 1;     /* :579 */
+                        a0 = j;
+                        b0 = 0;
+                        m = contain ? LB : rem;
+                    } else {
+                        int sft = j + k - LB;             /* where s2 starts in A */
+                        contain = sft >= 0;               /* :547 */
+                        overlap = sft <= 0 && j >= 1;     /* :591 */
+                        a0 = sft > 0 ? sft : 0;
+                        b0 = sft < 0 ? -sft : 0;
+                        m = j + k - a0;
+                    }
+                    if (seg_equal(pa, pb, S, LB, a0, b0, m, rev)) {
+                        if (contain && (LA > LB || (LA == LB && A < B)))
+                            atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                        if (overlap) {
+                            ov = true;
+                            hit = HIT_MAKE(j, B, suf, rev);
+                        }
+                    }
+                }
+            }
+            u64 m = __ballot(ov);
+            if (ov) {
+                u32 pos = nrow + __popcll(m & lane_mask_lt());
+                if (BIG) {
+                    if (grow && pos < a.big_cnt[it]) grow[pos] = hit;
+                } else if (pos < PROBE_ROWCAP)
+                    s_row[pos] = hit;
+            }
+            nrow += __popcll(m);
+        };
+
+        for (int j0 = 0; j0 < npos; j0 += 64) {
+            const int j = j0 + (int)lane;
+            u32 s = 0, e = 0, fq = 0;
+            u64 key = 0;
+            if (j < npos) {
+                key = canonical_key(pa, S, j, k, fq);
+                u64 b = key >> a.v.bshift;
+                s = a.v.bkt[b];
+                e = a.v.bkt[b + 1];
+            }
+            while (__any(s < e)) {
+                bool match = false;
+                u64 pay = 0;
+                if (s < e) {
+                    ulonglong2 en = a.v.ent[s];
+                    s++;
+                    pay = en.y;
+                    match = (en.x == key) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
+                }
+                u64 mm = __ballot(match);
+                if (match) {
+                    u32 pos = ncand + __popcll(mm & lane_mask_lt());
+                    /* strand relation query vs record replaces the record's own strand bit */
+                    s_cq[pos] = (pay & ~(1ull << 16)) | ((u64)(PAY_REV(pay) ^ fq) << 16);
+                    s_cj[pos] = (u32)j;
+                }
+                ncand += __popcll(mm);
+                if (ncand >= 64) {
+                    __syncthreads();
+                    verify(64);
+                    __syncthreads();
+                    u64 c2 = 0;
+                    u32 j2 = 0;
+                    if (lane + 64 < ncand) {
+                        c2 = s_cq[lane + 64];
+                        j2 = s_cj[lane + 64];
+                    }
+                    __syncthreads();
+                    if (lane + 64 < ncand) {
+                        s_cq[lane] = c2;
+                        s_cj[lane] = j2;
+                    }
+                    ncand -= 64;
+                }
+            }
+        }
+        __syncthreads();
+        if (ncand) verify(ncand);
+        __syncthreads();
+
+        if (BIG || nrow <= PROBE_ROWCAP) { /* a row that overflows LDS is recounted by the big-row pass */
+            my_khits += read_khits;
+            my_raw += (lane == 0) ? nrow : 0;
+        }
+        if (nrow > my_maxrow) my_maxrow = nrow;
+        if (BIG) {
+            if (lane == 0) a.row_cnt[A] = grow ? nrow : 0;
+        } else if (nrow > PROBE_ROWCAP) {
+            if (lane == 0) {
+                u32 idx = atomicAdd(a.n_big, 1u);
+                if (idx < a.big_cap) {
+                    a.big_list[idx] = A;
+                    a.big_cnt[idx] = nrow;
+                } else
+                    atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                a.row_cnt[A] = 0;
+                a.row_start[A] = 0;
+            }
+        } else if (nrow == 0) {
+            if (lane == 0) {
+                a.row_cnt[A] = 0;
+                a.row_start[A] = 0;
+            }
+        } else {
+            if (chunk_used + nrow > PROBE_CHUNK) {
+                u64 base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(a.bump, (u64)PROBE_CHUNK);
+                    atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + PROBE_CHUNK);
+                    if (base + PROBE_CHUNK > a.hits_cap) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                }
+                chunk_base = __shfl(base, 0);
+                chunk_used = 0;
+            }
+            const bool ok = chunk_base + PROBE_CHUNK <= a.hits_cap;
+            if (ok)
+                for (u32 i = lane; i < nrow; i += 64) a.hits[chunk_base + chunk_used + i] = s_row[i];
+            if (lane == 0) {
+                a.row_start[A] = chunk_base + chunk_used;
+                a.row_cnt[A] = ok ? nrow : 0;
+            }
+            chunk_used += nrow;
+        }
+        __syncthreads();
+    }
+    /* counters: one atomic per wave */
+    for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
+    if (lane == 0) {
+        if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
+        if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
+        atomicMax(&a.v.ctr[CTR_MAX_ROW], (u64)my_maxrow);
+    }
+}
+
+/* ================================================================================================================
+ * containment finalisation — contained flag per read from the reduced keys (BG/OverlapGraph.cpp:495-503 count)
+ * ============================================================================================================== */
+__global__ void contain_flags_kernel(const u64 *__restrict__ best, u64 n, u8 *__restrict__ contained, u64 *ctr)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u8 f = best[i] != DISCO_NOKEY;
+        contained[i] = f;
+        c += f;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ctr[CTR_N_CONTAINED], (u64)c);
+}
+
+/* gather (read id, key) of the contained reads in ascending id order; pos = exclusive scan of the flags */
+__global__ void contain_rows_kernel(const u64 *__restrict__ best, const u8 *__restrict__ contained, const u64 *__restrict__ pos,
+                                    u64 n, u64 *__restrict__ out_id, u64 *__restrict__ out_key)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (contained[i]) {
+            out_id[pos[i]] = i;
+            out_key[pos[i]] = best[i];
+        }
+}
+
+/* ================================================================================================================
+ * edge selection — insertAllEdgesOfRead (BG/OverlapGraph.cpp:631-678) for every non-contained query read, from the
+ * verified hits of the probe: drop hits to contained reads (:657; getListOfReads skips them :533), order the rest as
+ * the reference consumes them (j ascending, then bucket order), accept at most max_edges_per_kmer per j (:645), one
+ * edge per destination (insertedEdgeList :656), then sort the finds by overlap offset (:675-676).
+ * Finds overwrite the head of the read's hit row in place.
+ * h / t are two work arrays of cap entries: LDS for ordinary rows, global scratch for the big-row variant.
+ * ============================================================================================================== */
+struct EdgeSelArgs {
+    DiscoView v;
+    const u8 *contained;
+    u64 *hits;
+    const u64 *row_start;
+    const u32 *row_cnt;
+    u32 *deg;      /* [n] out                                   */
+    u32 max_per_kmer;
+    u64 *big_list; /* rows with more than ES_CAP hits (out/in)   */
+    u32 *n_big;
+    u32 big_cap;
+    u64 *scratch;  /* BIG: gridDim.x * 2 * scratch_cap entries   */
+    u64 scratch_cap;
+};
+
+/* stable-free rank sort of m distinct keys from src into dst (wave cooperative) */
+__device__ __forceinline__ void wave_rank_sort(const u64 *src, u64 *dst, u32 m, u32 lane)
+{
+    for (u32 i = lane; i < m; i += 64) {
+        u64 x = src[i];
+        u32 r = 0;
+        for (u32 t = 0; t < m; t++) r += (src[t] < x);
+        dst[r] = x;
+    }
+}
+
+__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 &cap_sites)
+{
+    u64 *row = a.hits + a.row_start[A];
+    const u32 LA = a.v.len[A];
+    /* 1. drop hits to contained reads */
+    u32 m = 0;
+    for (u32 i0 = 0; i0 < c; i0 += 64) {
+        u32 i = i0 + lane;
+        u64 hit = 0;
+        bool keep = false;
+        if (i < c) {
+            hit = row[i];
+            keep = !a.contained[HIT_ID(hit)];
+        }
+        u64 mk = __ballot(keep);
+        if (keep) h[m + __popcll(mk & lane_mask_lt())] = hit;
+        m += __popcll(mk);
+    }
+    __syncthreads();
+    /* 2. consumption order */
+    wave_rank_sort(h, t, m, lane);
+    __syncthreads();
+    /* 3. sequential accept scan (wave-uniform control flow; lanes share the membership test) */
+    u32 nacc = 0, ctr = 0, curj = 0xFFFFFFFFu;
+    bool capflag = false;
+    for (u32 i = 0; i < m; i++) {
+        const u64 hit = t[i];
+        const u32 j = HIT_J(hit);
+        const u64 B = HIT_ID(hit);
+        if (j != curj) {
+            curj = j;
+            ctr = 0;
+            capflag = false;
+        }
+        if (ctr >= a.max_per_kmer && capflag) continue;
+        bool seen = false;
+        for (u32 x = lane; x < nacc; x += 64) seen |= (ADJ_DST(h[x]) == B);
+        if (__any(seen)) continue;
+        if (ctr < a.max_per_kmer) {
+            u32 orient, off;
+            disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
+            if (lane == 0) h[nacc] = ADJ_MAKE(off, B, orient);
+            nacc++;
+            ctr++;
+            __syncthreads();
+        } else {
+            cap_sites++; /* the cap cut off a hit that would have been accepted */
+            capflag = true;
+        }
+    }
+    __syncthreads();
+    /* 4. list order of the reference: ascending overlap offset (total tie-break: dst, orient) */
+    wave_rank_sort(h, t, nacc, lane);
+    __syncthreads();
+    for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
+    if (lane == 0) a.deg[A] = nacc;
+    __syncthreads();
+}
+
+template <bool BIG>
+__global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
+{
+    __shared__ u64 s_h[BIG ? 1 : ES_CAP];
+    __shared__ u64 s_t[BIG ? 1 : ES_CAP];
+    const u32 lane = threadIdx.x;
+    u32 cap_sites = 0;
+    const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
+    u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
+    u64 *t = BIG ? h + a.scratch_cap : s_t;
+    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
+        const u32 c = a.row_cnt[A];
+        if (a.contained[A] || c == 0) { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
+            if (lane == 0) a.deg[A] = 0;
+            continue;
+        }
+        if (!BIG && c > ES_CAP) {
+            if (lane == 0) {
+                u32 idx = atomicAdd(a.n_big, 1u);
+                if (idx < a.big_cap) a.big_list[idx] = A;
+                else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                a.deg[A] = 0;
+            }
+            continue;
+        }
+        edge_select_row(a, A, h, t, c, lane, cap_sites);
+    }
+    if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+}
+
+/* ================================================================================================================
+ * adjacency CSR: rows of the query shard copied out of the hit buffer into node order (adj_start = scan of deg)
+ * ============================================================================================================== */
+__global__ void __launch_bounds__(64) csr_copy_kernel(const u64 *__restrict__ hits, const u64 *__restrict__ row_start,
+                                                      const u32 *__restrict__ deg, u64 lo, u64 hi,
+                                                      const u64 *__restrict__ dst_start, u64 dst_base, u64 *__restrict__ dst)
+{
+    /* dst_start is indexed by global node id; entries are written at dst[dst_start[v] - dst_base + i] */
+    for (u64 v = lo + blockIdx.x; v < hi; v += gridDim.x) {
+        u32 d = deg[v];
+        const u64 *src = hits + row_start[v];
+        u64 *o = dst + (dst_start[v] - dst_base);
+        for (u32 i = threadIdx.x; i < d; i += 64) o[i] = src[i];
+    }
+}
+
+/* binary search of key in the sorted row r[0..d) ignoring nothing (rows hold plain ADJ entries); returns index or -1 */
+__device__ __forceinline__ int adj_find(const u64 *__restrict__ r, u32 d, u64 key)
+{
+    u32 lo = 0, hi = d;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        u64 x = r[mid];
+        if (x < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < d && r[lo] == key) ? (int)lo : -1;
+}
+
+/* ================================================================================================================
+ * twin check — insertEdge puts the twin of every find into the other read's list (BG/OverlapGraph.cpp:614-626).
+ * For every entry (u -> w) of the gathered adjacency with w in [lo,hi): its twin (w -> u) must be in adj[w];
+ * if not, the pair was found from one side only (asymmetric) and the twin is appended to the extras of w.
+ * ============================================================================================================== */
+struct TwinArgs {
+    DiscoView v;
+    const u64 *adj_start; /* [n+1] */
+    const u64 *adj;
+    u64 lo, hi;           /* nodes whose lists are completed by this launch */
+    u32 *extra_cnt;       /* [n]                                            */
+    u64 *extra_node;      /* extras list                                    */
+    u64 *extra_key;
+    u32 *n_extra;
+    u32 extra_cap;
+};
+
+__global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    u32 asym = 0;
+    for (u64 u = wave; u < a.v.n; u += nwaves) {
+        const u64 s = a.adj_start[u], e = a.adj_start[u + 1];
+        const u32 Lu = a.v.len[u];
+        for (u64 p = s + lane; p < e; p += 64) {
+            const u64 ent = a.adj[p];
+            const u64 w = ADJ_DST(ent);
+            if (w < a.lo || w >= a.hi) continue;
+            const u32 Lw = a.v.len[w];
+            const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent))); /* :617-619 */
+            const u64 ws = a.adj_start[w];
+            const u32 dw = (u32)(a.adj_start[w + 1] - ws);
+            if (adj_find(a.adj + ws, dw, twin) < 0) {
+                asym++;
+                u32 idx = atomicAdd(a.n_extra, 1u);
+                if (idx < a.extra_cap) {
+                    a.extra_node[idx] = w;
+                    a.extra_key[idx] = twin;
+                    atomicAdd(&a.extra_cnt[w], 1u);
+                } else
+                    atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) asym += __shfl_down(asym, o);
+    if (lane == 0 && asym) atomicAdd(&a.v.ctr[CTR_ASYM], (u64)asym);
+}
+
+/* extras merge (only when asymmetric pairs exist): new_deg = deg + extra_cnt -> scan -> copy rows -> scatter extras
+ * -> re-sort the rows that received extras */
+__global__ void add_u32_kernel(const u64 *__restrict__ adj_start, const u32 *__restrict__ extra_cnt, u64 n, u32 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = (u32)(adj_start[i + 1] - adj_start[i]) + extra_cnt[i];
+}
+
+__global__ void __launch_bounds__(64) merge_copy_kernel(const u64 *__restrict__ old_start, const u64 *__restrict__ old_adj,
+                                                        const u64 *__restrict__ new_start, u64 *__restrict__ new_adj, u64 n)
+{
+    for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
+        u64 s = old_start[v];
+        u32 d = (u32)(old_start[v + 1] - s);
+        u64 o = new_start[v];
+        for (u32 i = threadIdx.x; i < d; i += 64) new_adj[o + i] = old_adj[s + i];
+    }
+}
+
+__global__ void merge_scatter_kernel(const u64 *__restrict__ extra_node, const u64 *__restrict__ extra_key, u32 n_extra,
+                                     const u64 *__restrict__ old_start, const u64 *__restrict__ new_start,
+                                     u32 *__restrict__ fill, u64 *__restrict__ new_adj)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_extra; i += gridDim.x * blockDim.x) {
+        u64 w = extra_node[i];
+        u32 d = (u32)(old_start[w + 1] - old_start[w]);
+        u32 slot = atomicAdd(&fill[w], 1u);
+        new_adj[new_start[w] + d + slot] = extra_key[i];
+    }
+}
+
+/* sort (ascending) the rows that received extras; simple in-place selection by rank through a global scratch row */
+__global__ void __launch_bounds__(64) merge_sort_kernel(const u32 *__restrict__ extra_cnt, const u64 *__restrict__ new_start,
+                                                        u64 *__restrict__ new_adj, u64 n, u64 *__restrict__ scratch, u64 scratch_cap)
+{
+    u64 *tmp = scratch + (u64)blockIdx.x * scratch_cap;
+    for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
+        if (!extra_cnt[v]) continue;
+        u64 s = new_start[v];
+        u32 d = (u32)(new_start[v + 1] - s);
+        wave_rank_sort(new_adj + s, tmp, d, threadIdx.x);
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < d; i += 64) new_adj[s + i] = tmp[i];
+        __syncthreads();
+    }
+}
+
+/* ================================================================================================================
+ * transitive marking — markTransitiveEdges (BG/OverlapGraph.cpp:687-723), Myers 2005, one wavefront per node v.
+ * N(v) goes into an LDS hash keyed by read id (the reference's markedNodes map, :689-691); neighbours are visited in
+ * list order (ascending offset); for every still-INPLAY neighbour u the lanes sweep adj[u] and ELIMINATE the w in N(v)
+ * reachable by a consistent walk v->u->w (:701-708). flag[slot] = 1 for edges v->ELIMINATED (:713-720); the twin's
+ * flag is the other node's business and is combined at emission.
+ * ============================================================================================================== */
+struct TrArgs {
+    DiscoView v;
+    const u64 *adj_start;
+    const u64 *adj;
+    u8 *flag;      /* [total slots], indexed by global slot */
+    u64 *big_list;
+    u32 *n_big;
+    u32 big_cap;
+    u64 *scratch;  /* BIG variant: per block hkey[hcap] | ent(u32)[cap] | state(u8)[hcap] */
+    u64 hcap;      /* power of two >= 2 * max degree */
+};
+
+#define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey, u8 *hstate, u32 *sent, u32 hmask, u32 lane)
+{
+    const u64 vs = a.adj_start[v];
+    const u64 *row = a.adj + vs;
+    for (u32 i = lane; i <= hmask; i += 64) {
+        hkey[i] = TR_EMPTY;
+        hstate[i] = 0;
+    }
+    __syncthreads();
+    for (u32 s = lane; s < d; s += 64) { /* markedNodes->insert(dst, INPLAY) */
+        u64 id = ADJ_DST(row[s]);
+        u32 idx = (u32)disco_hash64(id) & hmask;
+        for (;;) {
+            u64 old = atomicCAS(&hkey[idx], TR_EMPTY, id);
+            if (old == TR_EMPTY || old == id) break;
+            idx = (idx + 1) & hmask;
+        }
+        sent[s] = idx;
+    }
+    __syncthreads();
+    for (u32 i = 0; i < d; i++) {                 /* :693 list order */
+        if (hstate[sent[i]]) continue;            /* :696 only INPLAY neighbours */
+        const u64 e1 = row[i];
+        const u64 u = ADJ_DST(e1);
+        const u32 type1 = ADJ_ORI(e1);
+        const u64 us = a.adj_start[u];
+        const u32 du = (u32)(a.adj_start[u + 1] - us);
+        const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
+        for (u32 t = lane; t < du; t += 64) {        /* :698 */
+            const u64 e2 = a.adj[us + t];
+            const u32 type2 = ADJ_ORI(e2);
+            const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
+            if (!ok) continue;
+            const u64 w = ADJ_DST(e2);
+            u32 idx = (u32)disco_hash64(w) & hmask;
+            for (;;) {
+                u64 kk = hkey[idx];
+                if (kk == TR_EMPTY) break;
+                if (kk == w) {
+                    hstate[idx] = 1; /* ELIMINATED */
+                    break;
+                }
+                idx = (idx + 1) & hmask;
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 s = lane; s < d; s += 64) a.flag[vs + s] = hstate[sent[s]];
+    __syncthreads();
+}
+
+template <bool BIG>
+__global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
+{
+    __shared__ u64 s_hkey[BIG ? 1 : 2 * TR_CAP];
+    __shared__ u32 s_ent[BIG ? 1 : TR_CAP];
+    __shared__ u8 s_state[BIG ? 1 : 2 * TR_CAP];
+    const u32 lane = threadIdx.x;
+    const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
+    u64 *hkey = s_hkey;
+    u32 *sent = s_ent;
+    u8 *hstate = s_state;
+    if (BIG) {
+        u8 *base = (u8 *)a.scratch + (u64)blockIdx.x * (a.hcap * 8 + a.hcap * 4 + a.hcap);
+        hkey = (u64 *)base;
+        sent = (u32 *)(base + a.hcap * 8);
+        hstate = base + a.hcap * 8 + a.hcap * 4;
+    }
+    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const u64 v = BIG ? a.big_list[it] : a.v.q_lo + it;
+        const u32 d = (u32)(a.adj_start[v + 1] - a.adj_start[v]);
+        if (d == 0) continue;
+        if (!BIG && d > TR_CAP) {
+            if (lane == 0) {
+                u32 idx = atomicAdd(a.n_big, 1u);
+                if (idx < a.big_cap) a.big_list[idx] = v;
+                else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+            }
+            continue;
+        }
+        u32 hmask;
+        if (BIG) hmask = (u32)a.hcap - 1;
+        else {
+            u32 hc = 64;
+            while (hc < 2 * d) hc <<= 1;
+            hmask = hc - 1;
+        }
+        tr_node(a, v, d, hkey, hstate, sent, hmask, lane);
+    }
+}
+
+/* ================================================================================================================
+ * emission — removeTransitiveEdges (BG/OverlapGraph.cpp:731-761) + the canonical side of saveParGraphToFile (:808):
+ * edge (v,w) with v < w survives iff it is flagged from neither end. keep bit -> flag |= 2, kept[v] = survivors.
+ * ============================================================================================================== */
+struct EmitArgs {
+    DiscoView v;
+    const u64 *adj_start;
+    const u64 *adj;
+    u8 *flag;
+    u32 *kept;          /* [n] (only [q_lo,q_hi) written) */
+    const u64 *out_pos; /* fill pass: exclusive scan of kept over [q_lo,q_hi), indexed by v - q_lo */
+    u64 *out_src;
+    u64 *out_ent;
+};
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) emit_kernel(EmitArgs a)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 v = a.v.q_lo + wave; v < a.v.q_hi; v += nwaves) {
+        const u64 vs = a.adj_start[v];
+        const u32 d = (u32)(a.adj_start[v + 1] - vs);
+        const u32 Lv = a.v.len[v];
+        u32 cnt = 0;
+        for (u32 s0 = 0; s0 < d; s0 += 64) {
+            const u32 s = s0 + lane;
+            bool keep = false;
+            u64 e = 0;
+            if (s < d) {
+                e = a.adj[vs + s];
+                if (FILL) keep = (a.flag[vs + s] & 2) != 0;
+                else {
+                    const u64 w = ADJ_DST(e);
+                    if (v < w && !(a.flag[vs + s] & 1)) {
+                        const u32 Lw = a.v.len[w];
+                        const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)));
+                        const u64 ws = a.adj_start[w];
+                        const int ti = adj_find(a.adj + ws, (u32)(a.adj_start[w + 1] - ws), twin);
+                        keep = (ti >= 0) && !(a.flag[ws + ti] & 1);
+                    }
+                    if (keep) a.flag[vs + s] |= 2;
+                }
+            }
+            u64 mk = __ballot(keep);
+            if (FILL && keep) {
+                u64 pos = a.out_pos[v - a.v.q_lo] + cnt + __popcll(mk & lane_mask_lt());
+                a.out_src[pos] = v;
+                a.out_ent[pos] = e;
+            }
+            cnt += __popcll(mk);
+        }
+        if (!FILL && lane == 0) a.kept[v - a.v.q_lo] = cnt;
+    }
+}
+
+__global__ void fill_u64_kernel(u64 *p, u64 n, u64 val)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = val;
+}
+
+/* deg[v] = adj_start[v+1]-adj_start[v] for v in [lo,hi) -> out[v-lo] */
+__global__ void deg_from_start_kernel(const u64 *__restrict__ adj_start, u64 lo, u64 hi, u32 *__restrict__ out)
+{
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < hi; i += (u64)gridDim.x * blockDim.x) out[i - lo] = (u32)(adj_start[i + 1] - adj_start[i]);
+}
+
+#endif /* DISCO_KERNELS_H_ */

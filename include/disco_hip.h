@@ -1,0 +1,180 @@
+/*
+ * disco_hip.h — C ABI of the MI355X-native BuildGraph hot path (libdisco_hip.so).
+ *
+ * This is the drop-in boundary INSIDE the buildG process.  The reference has no FFI for
+ * this path; its nearest analogue is the HashTable / OverlapGraph surface that main.cpp drives
+ * (/root/reference/src/BuildGraph/src/main.cpp:55-62):
+ *
+ *     Dataset  -> HashTable::insertDataset -> OverlapGraph ctor (markContainedReads, BFS edge discovery,
+ *                                             markTransitiveEdges/removeTransitiveEdges, saveParGraphToFile)
+ *
+ * Each entry point below names the reference interface it replaces (BG/ = src/BuildGraph/src/).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DISCO_E_* code; disco_last_error() gives the message
+ *   - the caller owns host buffers, the library owns device buffers (except disco_adopt_reads)
+ *   - one context per GPU; a context is not thread-safe; different contexts are independent
+ *   - read ids are 0-based ranks of the good reads in file order (reference readNumber - 1, BG/Dataset.cpp:133-134)
+ *   - reads are 2-bit packed, 32 bases per 64-bit word, MSB first, A0 C1 G2 T3 (BG/HashTable.cpp:456-477,
+ *     BG/HashTable.h:16-24), one read per row of a fixed-stride [n][stride_words] array, unused bits zero
+ *   - no C++ types, exceptions or torch types cross this boundary
+ */
+#ifndef DISCO_HIP_H_
+#define DISCO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISCO_ABI_VERSION 1
+
+enum {
+    DISCO_OK = 0,
+    DISCO_E_ARG = -1,      /* bad argument                                               */
+    DISCO_E_HIP = -2,      /* a HIP runtime call failed                                  */
+    DISCO_E_NOMEM = -3,    /* device or host allocation failed                           */
+    DISCO_E_STATE = -4,    /* phases called out of order                                 */
+    DISCO_E_CAPACITY = -5, /* an internal buffer could not be grown to the needed size   */
+    DISCO_E_UNSUPPORTED = -6
+};
+
+typedef struct disco_ctx disco_ctx;
+
+typedef struct disco_params {
+    uint32_t min_overlap;        /* MinOverlap4BuildGraph (disco.cfg:9); k = min_overlap - 1 (BG/HashTable.cpp:50) */
+    uint32_t max_edges_per_kmer; /* MAX_EDGE_PER_KMER (BG/Common.h:62); 0 -> 4                                       */
+    uint32_t flags;              /* reserved, 0                                                                      */
+    uint32_t reserved;
+} disco_params;
+
+/* synthetic reads, see disco_amd/csrc/readgen.h (replaces bbmap/randomreads.sh for the BASELINE configs) */
+typedef struct disco_genspec_abi {
+    uint64_t seed, n_reads, contig_len;
+    uint32_t n_contigs, len_min, len_max, reserved;
+} disco_genspec_abi;
+
+/* one row of <prefix>_<t>_containedReads.txt (BG/OverlapGraph.cpp:438-447) in read ids */
+typedef struct disco_contained_row {
+    uint64_t contained; /* read2                                        */
+    uint64_t super;     /* read1, the containing read                   */
+    uint32_t orient;    /* BG/OverlapGraph.cpp:428-434                   */
+    uint32_t len2;
+    uint32_t len1;
+    uint32_t start;     /* len1 - overlapLen                            */
+    uint32_t j;         /* k-mer position in read1                      */
+    uint32_t type;      /* hash-hit type 0..3 (BG/HashTable.cpp:535-566) */
+} disco_contained_row;
+
+/* one line of <prefix>_<t>_parGraph.txt (BG/OverlapGraph.cpp:808-867) in read ids, src < dst */
+typedef struct disco_edge {
+    uint64_t src;
+    uint64_t dst;
+    uint32_t orient; /* BG/Edge.h:30-34, as seen from src */
+    uint32_t offset; /* overlap offset in src              */
+    uint32_t len_src;
+    uint32_t len_dst;
+} disco_edge;
+
+typedef struct disco_counters {
+    uint64_t n_reads;
+    uint64_t probes;           /* Q : k-mer probes issued                                              */
+    uint64_t kmer_hits;        /* H : (probe, index record) pairs with an exact k-mer match, self excluded */
+    uint64_t n_contained;      /* C                                                                    */
+    uint64_t raw_hits;         /* verified overlap hits before the contained filter / cap             */
+    uint64_t e_pre;            /* undirected overlaps in the pre-reduction graph (the metric's unit)   */
+    uint64_t e_out;            /* undirected edges after transitive reduction                          */
+    uint64_t cap_bind_sites;   /* (read, j) sites where max_edges_per_kmer cut off a valid hit         */
+    uint64_t asymmetric_pairs; /* directed finds whose twin was not found from the other read         */
+    uint64_t big_rows;         /* reads that took the large-row path in the probe                      */
+    uint64_t index_buckets;    /* bucket table size                                                    */
+    uint64_t hbm_bytes;        /* device bytes currently allocated by this context                     */
+} disco_counters;
+
+/* ---- lifetime -------------------------------------------------------------------------------------------------- */
+int disco_abi_version(void);
+/* replaces: `new HashTable()` + parameters read by main (BG/main.cpp:42,57) */
+int disco_create(int device, const disco_params *p, disco_ctx **out);
+void disco_destroy(disco_ctx *ctx);
+const char *disco_last_error(const disco_ctx *ctx); /* ctx may be NULL: error of the last failed disco_create */
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the context's own stream */
+int disco_set_stream(disco_ctx *ctx, void *hip_stream);
+int disco_synchronize(disco_ctx *ctx);
+
+/* ---- reads: replaces HashTable::populateReadData / insertIntoTable packing (BG/HashTable.cpp:97-114,423-514) ---- */
+/* host helper: pack one upper-case ACGT read into ceil(len/32) words; returns DISCO_E_ARG on a non-ACGT byte
+ * (the reference throws std::invalid_argument, BG/HashTable.cpp:474-475) */
+int disco_pack_ascii(const char *seq, uint32_t len, uint64_t *out_words);
+/* copy host reads into HBM. packed = [n][stride_words], len[i] in (min_overlap, 32767] (BG/Dataset.cpp:305,
+ * 15-bit length field BG/HashTable.cpp:531) */
+int disco_upload_reads(disco_ctx *ctx, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n);
+/* use reads that are already resident in HBM (caller-owned device pointers, must outlive the context's use) */
+int disco_adopt_reads(disco_ctx *ctx, const void *d_packed, uint32_t stride_words, const void *d_len, uint64_t n);
+/* generate synthetic reads directly in HBM (bench / tests) */
+int disco_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
+/* copy the packed reads / lengths back to the host (tests, writer) */
+int disco_download_reads(disco_ctx *ctx, uint64_t *packed, uint16_t *len);
+uint32_t disco_stride_words(const disco_ctx *ctx);
+uint64_t disco_num_reads(const disco_ctx *ctx);
+
+/* restrict the QUERY side of the probe / edge / reduction phases to reads [lo, hi) (multi-GPU sharding, replaces the
+ * per-rank read ranges of MPI/OverlapGraph.cpp:524-528). The index always covers all reads. Default: [0, n). */
+int disco_set_query_range(disco_ctx *ctx, uint64_t lo, uint64_t hi);
+
+/* ---- phases ---------------------------------------------------------------------------------------------------- */
+/* replaces HashTable::insertDataset: populateReadLengths -> prefix sum -> populateReadData (BG/HashTable.cpp:46-114) */
+int disco_build_index(disco_ctx *ctx);
+/* fused probe + verify: HashTable::getListOfReads (BG/HashTable.cpp:521-571) for every k-mer of every query read,
+ * checkOverlapForContainedRead (BG/OverlapGraph.cpp:517-554) and checkOverlap (:567-595) on every candidate */
+int disco_probe(disco_ctx *ctx);
+/* replaces OverlapGraph::markContainedReads (BG/OverlapGraph.cpp:333-505); closed form of SURVEY.md §8c-7 */
+int disco_mark_contained(disco_ctx *ctx, uint64_t *n_contained);
+/* replaces insertAllEdgesOfRead for every non-contained read (BG/OverlapGraph.cpp:631-678) + twin insertion (:614-626)
+ * = disco_select_edges + disco_symmetrize(full) + disco_merge_extras */
+int disco_build_edges(disco_ctx *ctx, uint64_t *n_pre);
+/*   the three steps separately (multi-GPU: select -> export/all-gather/import -> symmetrize -> merge):            */
+/*   per-read edge selection: cap of max_edges_per_kmer per k-mer, one edge per destination, sort by offset          */
+int disco_select_edges(disco_ctx *ctx);
+/*   every find's twin must be in the other read's list (insertEdge, BG/OverlapGraph.cpp:614-626); counts the finds
+ *   whose twin is missing (asymmetric pairs) for targets in the query range (full = 0) or for all nodes (full != 0) */
+int disco_symmetrize(disco_ctx *ctx, int full, uint64_t *n_asym);
+/*   add the missing twins collected by disco_symmetrize to the lists */
+int disco_merge_extras(disco_ctx *ctx);
+/* replaces markTransitiveEdges / removeTransitiveEdges (BG/OverlapGraph.cpp:687-761)
+ * = disco_transitive_mark + disco_emit_edges */
+int disco_transitive_reduce(disco_ctx *ctx, uint64_t *n_out);
+int disco_transitive_mark(disco_ctx *ctx);
+int disco_emit_edges(disco_ctx *ctx, uint64_t *n_out);
+/* all five phases back to back on the context's stream */
+int disco_run_graph(disco_ctx *ctx);
+
+/* ---- multi-GPU exchange points (the collectives themselves are the caller's: RCCL via torch.distributed) -------- */
+/* device pointer to the per-read containment keys (uint64[n], smaller = better, UINT64_MAX = not contained). Ranks
+ * combine them with an all-reduce(MIN) between disco_probe and disco_mark_contained
+ * (replaces the contained-read exchange MPI/OverlapGraph.cpp:480-506,559-588). */
+int disco_contain_keys(disco_ctx *ctx, void **d_keys, uint64_t *n);
+/* adjacency of the local query range after disco_build_edges: deg[i] (uint32) for i in [lo,hi) and the concatenated
+ * rows (uint64 entries).  Exported to caller-provided device buffers / imported from the gathered ones so that the
+ * transitive reduction of a shard can see the lists of neighbours owned by other ranks
+ * (replaces the full-replica partial graphs of MPI/OverlapGraph.cpp:244-279). */
+int disco_adjacency_size(disco_ctx *ctx, uint64_t *n_entries);
+int disco_export_adjacency(disco_ctx *ctx, void *d_deg_u32, void *d_entries_u64);
+int disco_import_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all);
+/* transitive flags (uint8 per adjacency slot, `total` slots): this rank computed [slot_lo, slot_hi); ranks all-gather
+ * those byte ranges in place between disco_transitive_mark and disco_emit_edges, because an edge survives only if it is
+ * flagged from neither end (BG/OverlapGraph.cpp:717-718 flags the twin too). */
+int disco_tr_flags(disco_ctx *ctx, void **d_flags, uint64_t *slot_lo, uint64_t *slot_hi, uint64_t *total);
+
+/* ---- results --------------------------------------------------------------------------------------------------- */
+/* rows in ascending contained-read id; returns the number of rows written, or a negative error */
+int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
+/* edges of the local query range, ascending (src, then adjacency order); returns count or negative error */
+int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
+int disco_get_counters(disco_ctx *ctx, disco_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCO_HIP_H_ */

@@ -1,0 +1,42 @@
+"""shared helpers for the parity tests: run the HIP path through the C-ABI and compare canonical forms with the oracle."""
+from __future__ import annotations
+
+import numpy as np
+
+from disco_amd import readgen
+from oracle import pyoracle
+
+
+def canon_hip(edges, rows, file_index=None):
+    n_ids = None
+    fi = (lambda x: x.astype(np.int64) + 1) if file_index is None else (lambda x: np.asarray(file_index, dtype=np.int64)[x.astype(np.int64)])
+    ce = pyoracle.canonical_edges(fi(edges["src"]), fi(edges["dst"]), edges["orient"], edges["offset"], edges["len_src"], edges["len_dst"])
+    cc = pyoracle.canonical_contained(fi(rows["contained"]), fi(rows["super"]), rows["orient"], rows["len2"], rows["len1"], rows["start"])
+    return ce, cc
+
+
+def run_hip_reads(reads, min_overlap, **kw):
+    from disco_amd import buildgraph
+
+    with buildgraph.BuildGraph(min_overlap=min_overlap, **kw) as g:
+        g.upload_ascii(reads)
+        g.run_graph()
+        return g.fetch_edges(), g.fetch_contained(), g.counters()
+
+
+def run_oracle_reads(reads, min_overlap, count_hits=True):
+    codes, off = pyoracle.encode_reads(reads)
+    rows, edges, cnt = pyoracle.build_graph(codes, off, min_overlap, count_hits)
+    return edges, rows, cnt
+
+
+def assert_parity(reads, min_overlap, label=""):
+    he, hr, hc = run_hip_reads(reads, min_overlap)
+    oe, orows, oc = run_oracle_reads(reads, min_overlap)
+    ce, cc = canon_hip(he, hr)
+    oce, occ = canon_hip(oe, orows)
+    assert np.array_equal(cc, occ), f"{label}: contained rows differ ({len(cc)} vs {len(occ)})"
+    assert np.array_equal(ce, oce), f"{label}: edge list differs ({len(ce)} vs {len(oce)})"
+    for key in ("probes", "kmer_hits", "n_contained", "e_pre", "e_out", "cap_bind_sites", "asymmetric_pairs"):
+        assert hc[key] == oc[key], f"{label}: counter {key}: hip {hc[key]} oracle {oc[key]}"
+    return hc
