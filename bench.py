@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — overlaps/sec of the BuildGraph stage on synthetic 150 bp reads (BASELINE.json metric).
+
+A step = one pass of the hot path (index build -> fused probe+verify -> containment -> edge selection -> twin check ->
+transitive reduction -> emission) over reads that are already resident in HBM, results left in HBM.
+  N = 1 : the whole pass on one MI355X.
+  N > 1 : strong scaling — the same reads on every GPU, query reads range-partitioned, three RCCL collectives
+          (disco_amd/distributed.py).  value = E_pre of the whole job / max-over-ranks time.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is attainable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("DISCO_BENCH_READS", 50_000_000)))
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--min-overlap", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(cnt, n_reads, words_mean):
+    """SURVEY.md §8(d) contract. Returns (whole path, probe kernel) bytes for one pass."""
+    R = 8.0 * words_mean
+    N, Q, H = n_reads, cnt["probes"], cnt["kmer_hits"]
+    E_pre, E_out, C = cnt["e_pre"], cnt["e_out"], cnt["n_contained"]
+    total = N * R + 2 * N * 16 + N * R + Q * 8 + H * R + E_pre * 16 + 2 * E_pre * 16 + E_out * 16 + C * 16
+    probe = N * R + Q * 8 + H * R + E_pre * 16  # read queries + one index word per probe + candidate rows + overlap records
+    return total, probe
+
+
+def cpu_baseline(args, spec_full):
+    """reference buildG (oracle/_ref/buildG_ref, kind 'reference') or the C restatement (kind 'port') on a bounded
+    sample of the same workload: same read length / coverage / min-overlap, smaller genome."""
+    import numpy as np
+
+    from disco_amd import buildgraph, readgen
+    from oracle import pyoracle, refrun
+
+    n = min(args.cpu_sample_reads, args.reads)
+    spec = readgen.GenSpec.coverage(args.seed + 1, n, args.read_len, args.coverage)
+    # the unit count of the sample comes from the (parity-checked) HIP path
+    with buildgraph.BuildGraph(min_overlap=args.min_overlap, device=0) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        e_pre = g.counters()["e_pre"]
+    cores = os.cpu_count() or 1
+    sample = f"{n} x {args.read_len} bp reads, {args.coverage:g}x of a {spec.contig_len * spec.n_contigs} bp random genome, min-overlap {args.min_overlap}"
+    if refrun.available():
+        d = tempfile.mkdtemp(prefix="disco_cpu_")
+        fa = os.path.join(d, "sample.fasta")
+        readgen.write_fasta(fa, readgen.generate_reads(spec))
+        r = refrun.run_reference([fa], args.min_overlap, threads=cores, mem_gb=max(8, 2 * cores), workdir=d)
+        # graph timer of the reference = HashTable::insertDataset + OverlapGraph (containment, edges, reduction, write)
+        t = 0.0
+        for fn in ("insertDataset", "buildOverlapGraphFromHashTable"):
+            m = re.search(r"Function %s\(\) finished in ([0-9.eE+-]+) Seconds" % fn, r["log"])
+            t += float(m.group(1)) if m else 0.0
+        if t <= 0:
+            t = r["wall"]
+        return dict(value=e_pre / t, unit="overlaps/s", cores=cores, kind="reference",
+                    sample=sample + f"; reference buildG -t {cores}: graph {t:.2f} s, whole process {r['wall']:.2f} s")
+    codes, off = readgen.generate_codes(spec)
+    t0 = time.perf_counter()
+    pyoracle.build_graph(codes, off, args.min_overlap)
+    t = time.perf_counter() - t0
+    return dict(value=e_pre / t, unit="overlaps/s", cores=1, kind="port", sample=sample + f"; C restatement {t:.2f} s")
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    from disco_amd import buildgraph, distributed, readgen
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    genome = int(args.reads * args.read_len / args.coverage)
+    n_contigs = max(1, genome // 5_000_000)  # 5 Mbp contigs, reads never span contigs
+    spec = readgen.GenSpec.coverage(args.seed, args.reads, args.read_len, args.coverage, n_contigs=n_contigs)
+    g = buildgraph.BuildGraph(min_overlap=args.min_overlap, device=local_rank)
+    g.generate_reads(spec)  # inputs resident in HBM before the timed region
+    engine = distributed.HipEngine(g, device)
+
+    info = {}
+
+    def step():
+        if world == 1:
+            g.run_graph()
+        else:
+            info.update(distributed.distributed_step(engine))
+
+    def fence():
+        g.synchronize()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    probe_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        probe_ms.append(g.phase_ms()["probe_kernel"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+
+    cnt = g.counters()
+    phases = g.phase_ms()
+    e_pre = cnt["e_pre"] if world == 1 else info["e_pre"]
+    e_out = cnt["e_out"] if world == 1 else info["e_out"]
+    words_mean = float(g.stride_words)
+    if world > 1:  # probe counters are per shard: sum them for the roofline bookkeeping
+        v = torch.tensor([cnt["probes"], cnt["kmer_hits"]], dtype=torch.int64, device=device)
+        dist.all_reduce(v)
+        cnt_all = dict(cnt, probes=int(v[0]), kmer_hits=int(v[1]), e_pre=e_pre, e_out=e_out)
+    else:
+        cnt_all = cnt
+    total_b, probe_b = algorithmic_bytes(cnt_all, args.reads, words_mean)
+    probe_b_launch = probe_b / world  # one launch processes one shard
+    avg_probe_ms = sum(probe_ms) / max(len(probe_ms), 1)
+    achieved = probe_b_launch / (avg_probe_ms * 1e-3) / 1e9 if avg_probe_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "probe_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("reads") == args.reads and tj.get("gpus", 1) == world:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "overlaps/sec (BuildGraph stage), 150 bp reads",
+        "value": e_pre / (ms_per_step * 1e-3),
+        "unit": "overlaps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.reads} x {args.read_len} bp synthetic reads, {args.coverage:g}x of {n_contigs} x {spec.contig_len} bp "
+                        f"uniform-random contigs, both strands, error-free, min-overlap {args.min_overlap} (k={args.min_overlap - 1}), "
+                        f"transitive reduction on, seed {args.seed}",
+            "reads": args.reads, "read_len": args.read_len, "min_overlap": args.min_overlap,
+            "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: reads replicated, queries range-partitioned, 3 RCCL collectives",
+            "e_pre": e_pre, "e_out": e_out, "n_contained": cnt["n_contained"],
+            "cap_bind_sites": cnt["cap_bind_sites"], "asymmetric_pairs": cnt["asymmetric_pairs"],
+            "probes": cnt_all["probes"], "kmer_hits": cnt_all["kmer_hits"],
+            "reads_per_s": args.reads / (ms_per_step * 1e-3),
+            "phase_ms_rank0": {k: round(v, 3) for k, v in phases.items()},
+            "algorithmic_bytes_per_step": total_b,
+            "path_gbs": total_b / (ms_per_step * 1e-3) / 1e9,
+        },
+        "roofline": {"bound": "hbm", "kernel": "probe_kernel<false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": probe_b_launch,
+                     "avg_launch_ms": avg_probe_ms},
+    }
+    g.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, spec)
+        except Exception as e:  # the baseline is a reported extra; never lose the bench line over it
+            out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e}"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -76,7 +76,11 @@ ABI = [
     ("disco_fetch_contained", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_fetch_edges", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
+    ("disco_phase_ms", C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
+    ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
 ]
+
+PHASES = ("index", "probe_kernel", "contain", "select", "csr", "twin", "trmark", "emit")
 
 
 def lib_path() -> str:
@@ -265,6 +269,14 @@ class BuildGraph:
         if n:
             self._chk(self.L.disco_fetch_edges(self._h, out.ctypes.data, n))
         return out
+
+    def phase_ms(self) -> dict:
+        a = (C.c_float * len(PHASES))()
+        self._chk(self.L.disco_phase_ms(self._h, a, len(PHASES)))
+        return {n: float(a[i]) for i, n in enumerate(PHASES)}
+
+    def memcpy_d2d(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        self._chk(self.L.disco_memcpy_d2d(self._h, _P(dst_ptr), _P(src_ptr), nbytes))
 
     def counters(self) -> dict:
         c = Counters()

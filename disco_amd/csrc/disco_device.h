@@ -17,7 +17,8 @@ typedef unsigned short u16;
 typedef unsigned char u8;
 
 #define DISCO_WAVE 64
-#define DISCO_NOKEY 0xFFFFFFFFFFFFFFFFull
+/* 'not contained': largest value that is also positive as int64, so that a signed all-reduce(MIN) orders keys correctly */
+#define DISCO_NOKEY 0x7FFFFFFFFFFFFFFFull
 
 /* ---- index entry payload: read id | record strand | isSuffix | length ------------------------------------------ */
 #define PAY_LEN(p) ((u32)((p)&0x7FFFu))

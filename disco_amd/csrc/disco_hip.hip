@@ -101,6 +101,11 @@ struct disco_ctx {
     u64 *d_out_src = nullptr, *d_out_ent = nullptr;
     u64 n_out = 0;
 
+    /* live kernel timing (HIP events on the stream the kernels are launched on) */
+    hipEvent_t ev0[DISCO_PH_COUNT] = {nullptr}, ev1[DISCO_PH_COUNT] = {nullptr};
+    bool ev_pending[DISCO_PH_COUNT] = {false};
+    float ph_ms[DISCO_PH_COUNT] = {0};
+
     int phase = 0; /* 0 none, 1 reads, 2 index, 3 probe, 4 contained, 5 edges selected, 6 symmetrized, 7 marked, 8 emitted */
 };
 
@@ -128,6 +133,26 @@ static int fail(disco_ctx *c, int code, const char *fmt, ...)
         int rc_ = (expr);            \
         if (rc_ != DISCO_OK) return rc_; \
     } while (0)
+
+static void ph_begin(disco_ctx *c, int id)
+{
+    (void)hipEventRecord(c->ev0[id], c->stream);
+}
+static void ph_end(disco_ctx *c, int id)
+{
+    (void)hipEventRecord(c->ev1[id], c->stream);
+    c->ev_pending[id] = true;
+}
+/* call after the stream has been synchronised */
+static void ph_collect(disco_ctx *c)
+{
+    for (int i = 0; i < DISCO_PH_COUNT; i++)
+        if (c->ev_pending[i]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]) == hipSuccess) c->ph_ms[i] = ms;
+            c->ev_pending[i] = false;
+        }
+}
 
 template <typename T>
 static int dev_alloc(disco_ctx *c, T **p, size_t count)
@@ -302,6 +327,10 @@ int disco_create(int device, const disco_params *p, disco_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_bump, sizeof(u64)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_big, sizeof(u32)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_extra, sizeof(u32)));
+    for (int i = 0; i < DISCO_PH_COUNT; i++) {
+        CREATE_CHK(hipEventCreate(&c->ev0[i]));
+        CREATE_CHK(hipEventCreate(&c->ev1[i]));
+    }
 #undef CREATE_CHK
     *out = c;
     return DISCO_OK;
@@ -320,6 +349,10 @@ void disco_destroy(disco_ctx *c)
     (void)hipFree(c->d_bump);
     (void)hipFree(c->d_n_big);
     (void)hipFree(c->d_n_extra);
+    for (int i = 0; i < DISCO_PH_COUNT; i++) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -474,12 +507,14 @@ int disco_build_index(disco_ctx *c)
     c->bshift = 64 - logT;
     CHK(dev_alloc(c, &c->d_bkt, T + 1));
     CHK(dev_alloc(c, &c->d_ent, 2 * c->n));
+    ph_begin(c, DISCO_PH_INDEX);
     HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (T + 1) * sizeof(u32), c->stream));
     DiscoView v = view(c);
     if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt);
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt + 1, T, c->d_bkt + 1, false, nullptr)));
     if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
+    ph_end(c, DISCO_PH_INDEX);
     c->phase = 2;
     return DISCO_OK;
 }
@@ -538,7 +573,9 @@ int disco_probe(disco_ctx *c)
         a.big_cnt = c->d_big_cnt;
         a.n_big = c->d_n_big;
         a.big_cap = c->big_cap;
+        ph_begin(c, DISCO_PH_PROBE_KERNEL);
         if (nq) hipLaunchKernelGGL(probe_kernel<false>, dim3(grid), dim3(64), 0, c->stream, a);
+        ph_end(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipGetLastError());
         u32 n_big = 0;
         HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -552,6 +589,7 @@ int disco_probe(disco_ctx *c)
         if (!c->h_ctr[CTR_OVERFLOW]) {
             c->big_rows = n_big;
             c->phase = 3;
+            ph_collect(c);
             return DISCO_OK;
         }
         /* something was too small: grow and redo the pass (atomicMin on best is idempotent) */
@@ -578,9 +616,12 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n));
     CHK(zero_counter(c, CTR_N_CONTAINED));
+    ph_begin(c, DISCO_PH_CONTAIN);
     if (c->n) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_ctr);
     HIPCHK(c, hipGetLastError());
+    ph_end(c, DISCO_PH_CONTAIN);
     CHK(read_counters(c));
+    ph_collect(c);
     c->n_contained = c->h_ctr[CTR_N_CONTAINED];
     if (n_contained) *n_contained = c->n_contained;
     c->phase = 4;
@@ -616,7 +657,9 @@ static int select_edges(disco_ctx *c)
         a.big_list = c->d_big_list;
         a.big_cap = c->big_cap;
     }
+    ph_begin(c, DISCO_PH_SELECT);
     if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, a);
+    ph_end(c, DISCO_PH_SELECT);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
     HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -640,14 +683,17 @@ static int select_edges(disco_ctx *c)
     /* CSR in node order; nodes outside the query range have empty rows */
     if (!c->d_adj_start) CHK(dev_alloc(c, &c->d_adj_start, c->n + 1));
     u64 total = 0;
+    ph_begin(c, DISCO_PH_CSR);
     CHK((scan_exclusive<u32, u64>(c, c->d_deg, c->n, c->d_adj_start, true, &total)));
     dev_free(c, &c->d_adj, c->adj_total);
     dev_free(c, &c->d_flag, c->adj_total);
     c->adj_total = total;
     CHK(dev_alloc(c, &c->d_adj, total));
     if (nq) hipLaunchKernelGGL(csr_copy_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_hits, c->d_row_start, c->d_deg, c->q_lo, c->q_hi, c->d_adj_start, 0ull, c->d_adj);
+    ph_end(c, DISCO_PH_CSR);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    ph_collect(c);
     /* the raw hits are dead now: give the memory back */
     dev_free(c, &c->d_hits, c->hits_cap);
     c->hits_cap = 0;
@@ -684,11 +730,14 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
         a.extra_key = c->d_extra_key;
         a.n_extra = c->d_n_extra;
         a.extra_cap = c->extra_cap;
+        ph_begin(c, DISCO_PH_TWIN);
         if (c->n) hipLaunchKernelGGL(twin_check_kernel, dim3(flat_grid(c, c->n * 64)), dim3(256), 0, c->stream, a);
+        ph_end(c, DISCO_PH_TWIN);
         HIPCHK(c, hipGetLastError());
         u32 ne = 0;
         HIPCHK(c, hipMemcpyAsync(&ne, c->d_n_extra, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
         CHK(read_counters(c));
+        ph_collect(c);
         if (!c->h_ctr[CTR_OVERFLOW]) {
             c->n_extra = ne;
             c->asym_local = c->h_ctr[CTR_ASYM];
@@ -844,11 +893,14 @@ int disco_transitive_mark(disco_ctx *c)
     a.big_cap = c->big_cap;
     a.scratch = nullptr;
     a.hcap = 0;
+    ph_begin(c, DISCO_PH_TRMARK);
     if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wave_grid(c, nq, 20)), dim3(64), 0, c->stream, a);
+    ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
     HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     CHK(read_counters(c));
+    ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking: big-node list overflow (%u nodes)", n_big);
     if (n_big) {
         /* longest list among the big nodes bounds the hash size */
@@ -916,6 +968,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     a.out_pos = c->d_out_pos;
     a.out_src = nullptr;
     a.out_ent = nullptr;
+    ph_begin(c, DISCO_PH_EMIT);
     if (nq) hipLaunchKernelGGL(emit_kernel<false>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
     u64 total = 0;
     CHK((scan_exclusive<u32, u64>(c, c->d_kept, nq, c->d_out_pos, true, &total)));
@@ -927,8 +980,10 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     a.out_src = c->d_out_src;
     a.out_ent = c->d_out_ent;
     if (nq) hipLaunchKernelGGL(emit_kernel<true>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
+    ph_end(c, DISCO_PH_EMIT);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    ph_collect(c);
     if (n_out) *n_out = total;
     c->phase = 8;
     return DISCO_OK;
@@ -1022,6 +1077,25 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
         e.len_dst = c->h_len[e.dst];
     }
     return (int64_t)ne;
+}
+
+int disco_phase_ms(disco_ctx *c, float *ms, int n)
+{
+    if (!c || !ms) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ph_collect(c);
+    for (int i = 0; i < n && i < DISCO_PH_COUNT; i++) ms[i] = c->ph_ms[i];
+    return DISCO_OK;
+}
+
+int disco_memcpy_d2d(disco_ctx *c, void *dst, const void *src, uint64_t bytes)
+{
+    if (!c || (bytes && (!dst || !src))) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
 }
 
 int disco_get_counters(disco_ctx *c, disco_counters *o)

@@ -151,7 +151,7 @@ int disco_emit_edges(disco_ctx *ctx, uint64_t *n_out);
 int disco_run_graph(disco_ctx *ctx);
 
 /* ---- multi-GPU exchange points (the collectives themselves are the caller's: RCCL via torch.distributed) -------- */
-/* device pointer to the per-read containment keys (uint64[n], smaller = better, UINT64_MAX = not contained). Ranks
+/* device pointer to the per-read containment keys (uint64[n], smaller = better, INT64_MAX = not contained). Ranks
  * combine them with an all-reduce(MIN) between disco_probe and disco_mark_contained
  * (replaces the contained-read exchange MPI/OverlapGraph.cpp:480-506,559-588). */
 int disco_contain_keys(disco_ctx *ctx, void **d_keys, uint64_t *n);
@@ -173,6 +173,22 @@ int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t
 /* edges of the local query range, ascending (src, then adjacency order); returns count or negative error */
 int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
 int disco_get_counters(disco_ctx *ctx, disco_counters *out);
+/* milliseconds of the last run of each phase, measured with HIP events on the stream the kernels were launched on
+ * (index = DISCO_PH_*). DISCO_PH_PROBE_KERNEL brackets exactly one launch of the dominant kernel. */
+enum {
+    DISCO_PH_INDEX = 0,    /* memset + count + scan + fill                       */
+    DISCO_PH_PROBE_KERNEL, /* one launch of probe_kernel<false>                  */
+    DISCO_PH_CONTAIN,
+    DISCO_PH_SELECT,       /* edge_select_kernel<false>                          */
+    DISCO_PH_CSR,          /* degree scan + row copy                             */
+    DISCO_PH_TWIN,         /* twin_check_kernel                                  */
+    DISCO_PH_TRMARK,       /* transitive_mark_kernel<false>                      */
+    DISCO_PH_EMIT,         /* emit mark + scan + emit fill                       */
+    DISCO_PH_COUNT
+};
+int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
+/* device-to-device copy on the context's stream (staging for caller-side collectives) */
+int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 
 #ifdef __cplusplus
 }
