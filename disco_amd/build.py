@@ -51,7 +51,14 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(BUILDG, deps):
         os.makedirs(os.path.dirname(BUILDG), exist_ok=True)
         cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", BUILDG] + srcs + [
-            "-L", HERE, "-ldisco_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+            "-L", HERE, "-ldisco_hip", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    dump = os.path.join(HERE, "bin", "fastx_dump")
+    dsrc = [os.path.join(HERE, "host", "fastx_dump.cpp"), os.path.join(HERE, "host", "fastx.cpp")]
+    if force or _stale(dump, dsrc + [os.path.join(HERE, "host", "fastx.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", "-o", dump] + dsrc + ["-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,0 +1,50 @@
+/*
+ * fastx.h — host-side read input of the buildG drop-in: FASTA/FASTQ(/gz) record splitting, the read-quality filter and
+ * 2-bit packing into the fixed-stride layout libdisco_hip.so consumes.
+ *
+ * Behaviour follows the reference's Dataset (cited as BG/ = /root/reference/src/BuildGraph/src/):
+ *   record splitting   BG/Dataset.cpp:255-294   (file type from the first byte; FASTA record = header line + everything up
+ *                                                to the next '>' with '\n' removed; FASTQ record = 4 lines)
+ *   file index         BG/Dataset.cpp:294       (1-based over ALL records of all -pe files then all -se files)
+ *   keep rule          BG/Dataset.cpp:303-305   (upper-case, len > min_overlap, testRead)
+ *   testRead           BG/Dataset.cpp:403-452
+ *   read ids           file order among the kept reads (== buildG-MPI, MPI/Dataset.cpp:153-170)
+ */
+#ifndef DISCO_FASTX_H_
+#define DISCO_FASTX_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace disco {
+
+struct FileRange {
+    std::string name;
+    bool paired;
+    uint64_t first_index; /* 1-based file index of its first record */
+    uint64_t last_index;  /* file index of its last record          */
+    uint64_t good, bad;
+};
+
+struct ReadSet {
+    uint32_t stride_words = 0;
+    std::vector<uint64_t> packed;     /* [n][stride_words]                    */
+    std::vector<uint16_t> len;        /* [n]                                  */
+    std::vector<uint64_t> file_index; /* [n] 1-based index over all records   */
+    std::vector<FileRange> files;
+    uint64_t total_records = 0;
+    uint32_t shortest = 0, longest = 0;
+    uint64_t size() const { return len.size(); }
+};
+
+/* Dataset::testRead on an upper-cased read */
+bool test_read(const char *s, size_t n);
+
+/* Reads every file, filters, packs. Returns false and sets err on failure (unreadable file, unknown format, empty file:
+ * BG/Dataset.cpp:113-114,244-245,267). */
+bool load_reads(const std::vector<std::string> &pe, const std::vector<std::string> &se, uint32_t min_overlap, int threads,
+                ReadSet &out, std::string &err);
+
+} // namespace disco
+#endif

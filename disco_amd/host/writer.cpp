@@ -1,0 +1,161 @@
+/* writer.cpp — see writer.h */
+#include "writer.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace disco {
+
+namespace {
+
+inline char *put_u64(char *p, uint64_t v)
+{
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+/* node v belongs to file owner(v): contiguous id ranges. A node is "marked" in its owner's file, where ALL its edges are
+ * written (parsimplify contracts marked nodes that have exactly two edges in that file, SG/OverlapGraphSimple.cpp:344) */
+inline int owner_of(uint64_t v, uint64_t n, int files) { return (int)((__uint128_t)v * (unsigned)files / (n ? n : 1)); }
+
+bool flush(const std::string &path, const std::string &data, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) {
+        err = "Unable to open file: " + path;
+        return false;
+    }
+    if (!data.empty() && fwrite(data.data(), 1, data.size(), f) != data.size()) {
+        fclose(f);
+        err = "Short write: " + path;
+        return false;
+    }
+    fclose(f);
+    return true;
+}
+
+} // namespace
+
+bool write_read_id_map(const std::string &prefix, const ReadSet &rs, std::string &err)
+{
+    std::string s;
+    int npe = 0, nse = 0;
+    for (auto &fr : rs.files) { /* BG/Dataset.cpp:115-116,126-127 */
+        s += fr.name + (fr.paired ? ": Paired-end file " : ": Singleton file ") + std::to_string(fr.paired ? ++npe : ++nse) + "\nReadID Range: (" +
+             std::to_string(fr.first_index) + "," + std::to_string(fr.last_index) + ")\n";
+    }
+    return flush(prefix + "_ReadIDMap.txt", s, err);
+}
+
+bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err)
+{
+    /* rows of one containing read must be contiguous (SG/DataSet.cpp:316-335); the reference emits them per super read in
+     * (j, bucket order) = ascending (j, contained id, record kind) */
+    std::sort(rows.begin(), rows.end(), [](const disco_contained_row &a, const disco_contained_row &b) {
+        if (a.super != b.super) return a.super < b.super;
+        if (a.j != b.j) return a.j < b.j;
+        return a.contained < b.contained;
+    });
+    const uint64_t n = rs.size();
+    std::vector<std::string> out(n_files);
+    for (const auto &r : rows) {
+        char buf[160], *p = buf;
+        p = put_u64(p, rs.file_index[r.contained]); *p++ = '\t';
+        p = put_u64(p, rs.file_index[r.super]); *p++ = '\t';
+        p = put_u64(p, r.orient); *p++ = ',';
+        p = put_u64(p, r.len2); memcpy(p, ",0,0,", 5); p += 5;
+        p = put_u64(p, r.len2); memcpy(p, ",0,", 3); p += 3;
+        p = put_u64(p, r.len2); *p++ = ',';
+        p = put_u64(p, r.len1); *p++ = ',';
+        p = put_u64(p, r.start); *p++ = ',';
+        p = put_u64(p, (uint64_t)r.start + r.len2); *p++ = '\n';
+        out[owner_of(r.super, n, n_files)].append(buf, (size_t)(p - buf));
+    }
+    for (int t = 0; t < n_files; t++)
+        if (!flush(prefix + "_" + std::to_string(t) + "_containedReads.txt", out[t], err)) return false;
+    return true;
+}
+
+bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err)
+{
+    const uint64_t n = rs.size();
+    std::vector<std::string> out(n_files);
+    bool ok = true;
+#pragma omp parallel for schedule(static, 1) num_threads(std::min(threads, n_files))
+    for (int t = 0; t < n_files; t++) {
+        std::string &o = out[t];
+        for (const auto &e : edges) {
+            const int os = owner_of(e.src, n, n_files), od = owner_of(e.dst, n, n_files);
+            if (os != t && od != t) continue;
+            /* 2: both ends marked in this file; 0: only column 1; 1: only column 2 (BG/OverlapGraph.cpp:826-833,852-859) */
+            const int flag = (os == od) ? 2 : (os == t ? 0 : 1);
+            const uint64_t ovl = (uint64_t)e.len_src - e.offset; /* :814 */
+            char buf[200], *p = buf;
+            p = put_u64(p, rs.file_index[e.src]); *p++ = '\t';
+            p = put_u64(p, rs.file_index[e.dst]); *p++ = '\t';
+            p = put_u64(p, e.orient); *p++ = ',';
+            p = put_u64(p, ovl); memcpy(p, ",0,0,", 5); p += 5;
+            p = put_u64(p, e.len_src); *p++ = ',';
+            p = put_u64(p, e.offset); *p++ = ',';
+            p = put_u64(p, e.len_src - 1); *p++ = ',';
+            p = put_u64(p, e.len_dst); memcpy(p, ",0,", 3); p += 3;
+            p = put_u64(p, ovl - 1); memcpy(p, ",NA,", 4); p += 4;
+            *p++ = (char)('0' + flag); *p++ = '\n';
+            o.append(buf, (size_t)(p - buf));
+        }
+        std::string e2;
+        if (!flush(prefix + "_" + std::to_string(t) + "_parGraph.txt", o, e2)) {
+#pragma omp critical
+            {
+                ok = false;
+                err = e2;
+            }
+        }
+        /* layout compatibility: one start id per file (BG/OverlapGraph.cpp:211) */
+        uint64_t first = n_files ? (uint64_t)(((__uint128_t)n * (unsigned)t + n_files - 1) / n_files) + 1 : 1;
+        flush(prefix + "_" + std::to_string(t) + "_startRead.txt", std::to_string(first) + "\n", e2);
+    }
+    return ok;
+}
+
+bool write_checkpoint(const std::string &prefix, bool ccr, bool gc, bool append, std::string &err)
+{
+    std::ofstream f(prefix + "_CheckpointInfo.txt", append ? std::ios::app : std::ios::trunc);
+    if (!f) {
+        err = "Unable to open file: " + prefix + "_CheckpointInfo.txt";
+        return false;
+    }
+    if (ccr) f << "CCR=Complete\n";
+    if (gc) f << "GC=Complete\n";
+    return true;
+}
+
+void read_checkpoint(const std::string &prefix, bool &ccr, bool &gc)
+{
+    ccr = gc = false;
+    std::ifstream f(prefix + "_CheckpointInfo.txt");
+    std::string line;
+    auto trim = [](std::string s) {
+        size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+        return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+    };
+    while (std::getline(f, line)) { /* BG/main.cpp:178-203 */
+        size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        std::string k = trim(line.substr(0, eq)), v = trim(line.substr(eq + 1));
+        if (k == "CCR" && v == "Complete") ccr = true;
+        if (k == "GC" && v == "Complete") gc = true;
+    }
+}
+
+} // namespace disco

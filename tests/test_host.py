@@ -1,0 +1,131 @@
+"""the C++ host of the buildG drop-in: input stage on CPU (vs the oracle's restatement of Dataset), whole CLI on the GPU."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from disco_amd import build
+from oracle import pyoracle, refrun
+from tests import golden_util as gu
+
+BIN = os.path.join(os.path.dirname(build.HERE), "disco_amd", "bin")
+
+
+def _dump(min_overlap, pe=(), se=()):
+    build.build_host()
+    cmd = [os.path.join(BIN, "fastx_dump"), str(min_overlap)]
+    if pe:
+        cmd += ["-pe", ",".join(pe)]
+    if se:
+        cmd += ["-se", ",".join(se)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, check=True, text=True).stdout.strip().split("\n")
+    tail = out[-1].split()
+    reads = [l.split("\t") for l in out[:-1] if l]
+    return [r[1] for r in reads], np.array([int(r[0]) for r in reads], dtype=np.uint64), int(tail[1]), int(tail[3])
+
+
+def test_input_stage_matches_oracle_on_the_multifile_case():
+    c = gu.CASES["multifile"]
+    pe = [os.path.join(gu.GOLD, f) for f in c["pe"]]
+    se = [os.path.join(gu.GOLD, f) for f in c["se"]]
+    reads, fidx, total, stride = _dump(c["min_overlap"], pe, se)
+    oreads, ofidx, ototal = pyoracle.load_good_reads(pe + se, c["min_overlap"])
+    assert total == ototal and reads == oreads and np.array_equal(fidx, ofidx)
+    assert stride == (max(map(len, reads)) + 31) // 32
+
+
+def test_input_stage_reference_fastas_and_gz(tmp_path):
+    import gzip
+
+    fa = os.path.join(gu.GOLD, "reference_data", "10reads_containedReads.fasta")
+    reads, fidx, total, _ = _dump(30, se=[fa])
+    oreads, ofidx, ototal = pyoracle.load_good_reads([fa], 30)
+    assert (reads, total) == (oreads, ototal) and np.array_equal(fidx, ofidx)
+    gz = str(tmp_path / "r.fasta.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(open(fa, "rb").read())
+    reads2, fidx2, total2, _ = _dump(30, se=[gz])
+    assert reads2 == reads and total2 == total
+
+
+def test_input_stage_errors(tmp_path):
+    build.build_host()
+    bad = tmp_path / "bad.txt"
+    bad.write_text("ACGT\n")
+    p = subprocess.run([os.path.join(BIN, "fastx_dump"), "30", "-se", str(bad)], stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "Unknown input file format" in p.stderr
+    p = subprocess.run([os.path.join(BIN, "fastx_dump"), "30", "-se", str(tmp_path / "missing.fa")], stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "Unable to open file" in p.stderr
+
+
+def test_cli_usage_and_unknown_flag():
+    build.build_host()
+    exe = os.path.join(BIN, "buildG")
+    p = subprocess.run([exe], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "Usage: buildG" in p.stderr          # BG/main.cpp:93-102
+    p = subprocess.run([exe, "-x"], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 1 and "Unknown option: -x" in p.stderr     # BG/main.cpp:133-148
+    p = subprocess.run([exe, "-h"], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0
+    p = subprocess.run([exe, "-se", "x.fa", "-f", "/tmp/none", "-p", "/nonexistent.cfg"], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 1 and "Unable to open parameter file" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 4])
+def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
+    """whole drop-in: argv in, files out; canonical content identical to the real reference's files"""
+    build.build_host()
+    c = gu.CASES["multifile"]
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text(f"# test\nMinOverlap4BuildGraph = {c['min_overlap']}\nPrintContigs = false\n")
+    prefix = str(tmp_path / "g")
+    pe = ",".join(os.path.join(gu.GOLD, f) for f in c["pe"])
+    se = ",".join(os.path.join(gu.GOLD, f) for f in c["se"])
+    cmd = [os.path.join(BIN, "buildG"), "-pe", pe, "-se", se, "-f", prefix, "-p", str(cfg), "-t", str(threads), "-m", "8"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    for t in range(threads):  # every file must exist, empty or not (SG/DataSet.cpp:294-295)
+        assert os.path.exists(f"{prefix}_{t}_parGraph.txt") and os.path.exists(f"{prefix}_{t}_containedReads.txt")
+    edges = refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt")))
+    cont = refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt")))
+    gu.check_against_golden("multifile", edges, cont)
+    idmap = open(prefix + "_ReadIDMap.txt").read().replace(gu.GOLD + "/", "")
+    assert idmap == c["read_id_map"]
+    assert open(prefix + "_CheckpointInfo.txt").read() == "CCR=Complete\nGC=Complete\n"
+    # flag rule: a node flagged as marked in file t has ALL its edges in file t
+    all_edges = {}
+    per_file = []
+    for t in range(threads):
+        rows = [l.rstrip("\n").split("\t") for l in open(f"{prefix}_{t}_parGraph.txt")]
+        per_file.append(rows)
+        for a, b, info in rows:
+            all_edges.setdefault(int(a), set()).add((int(a), int(b)))
+            all_edges.setdefault(int(b), set()).add((int(a), int(b)))
+    for rows in per_file:
+        here = {}
+        marked = set()
+        for a, b, info in rows:
+            a, b, flag = int(a), int(b), int(info.rsplit(",", 1)[1])
+            here.setdefault(a, set()).add((a, b))
+            here.setdefault(b, set()).add((a, b))
+            if flag in (0, 2):
+                marked.add(a)
+            if flag in (1, 2):
+                marked.add(b)
+        for v in marked:
+            assert here[v] == all_edges[v]
+    # contained rows of one containing read are contiguous (SG/DataSet.cpp:316-335)
+    for t in range(threads):
+        supers = [l.split("\t")[1] for l in open(f"{prefix}_{t}_containedReads.txt")]
+        seen, prev = set(), None
+        for s in supers:
+            if s != prev:
+                assert s not in seen
+                seen.add(s)
+                prev = s
+    # re-running the same command is a no-op (BG/main.cpp:48-52)
+    p2 = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p2.returncode == 0 and "Graph already exists" in p2.stdout
