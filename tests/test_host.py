@@ -92,7 +92,7 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
     edges = refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt")))
     cont = refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt")))
     gu.check_against_golden("multifile", edges, cont)
-    idmap = open(prefix + "_ReadIDMap.txt").read().replace(gu.GOLD + "/", "")
+    idmap = open(prefix + "_ReadIDMap.txt").read().replace(gu.GOLD + "/inputs/", "")
     assert idmap == c["read_id_map"]
     assert open(prefix + "_CheckpointInfo.txt").read() == "CCR=Complete\nGC=Complete\n"
     # flag rule: a node flagged as marked in file t has ALL its edges in file t
