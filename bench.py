@@ -147,7 +147,7 @@ def main():
     phases = g.phase_ms()
     e_pre = cnt["e_pre"] if world == 1 else info["e_pre"]
     e_out = cnt["e_out"] if world == 1 else info["e_out"]
-    words_mean = float(g.stride_words)
+    words_mean = float((args.read_len + 31) // 32)  # W of SURVEY.md §8: packed words per read (device rows are padded to 64 B)
     if world > 1:  # probe counters are per shard: sum them for the roofline bookkeeping
         v = torch.tensor([cnt["probes"], cnt["kmer_hits"]], dtype=torch.int64, device=device)
         dist.all_reduce(v)

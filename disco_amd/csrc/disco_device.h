@@ -28,18 +28,23 @@ typedef unsigned char u8;
 #define PAY_MAKE(id, rev, suf, len) (((u64)(id) << 17) | ((u64)(rev) << 16) | ((u64)(suf) << 15) | (u64)(len))
 
 /* ---- raw verified overlap hit: sorts numerically into the reference's consumption order (j, bucket order) ------- */
-/* bucket order = ascending read id, prefix record before suffix record (BG/HashTable.cpp:451-454,486-489)          */
-#define HIT_MAKE(j, id, suf, rev) (((u64)(j) << 45) | ((u64)(id) << 3) | ((u64)(suf) << 2) | ((u64)(rev) << 1))
-#define HIT_J(h) ((u32)((h) >> 45) & 0x7FFFu)
-#define HIT_ID(h) (((h) >> 3) & ((1ull << 42) - 1))
-#define HIT_SUFFIX(h) ((u32)(((h) >> 2) & 1u))
-#define HIT_REV(h) ((u32)(((h) >> 1) & 1u))
+/* bucket order = ascending read id, prefix record before suffix record (BG/HashTable.cpp:451-454,486-489).          */
+/* The length of the hit read rides along in the low bits (a function of id, so it never changes the order).         */
+#define HIT_MAKE(j, id, suf, rev, len) (((u64)(j) << 48) | ((u64)(id) << 17) | ((u64)(suf) << 16) | ((u64)(rev) << 15) | (u64)(len))
+#define HIT_J(h) ((u32)((h) >> 48) & 0x7FFFu)
+#define HIT_ID(h) (((h) >> 17) & 0x7FFFFFFFull)
+#define HIT_SUFFIX(h) ((u32)(((h) >> 16) & 1u))
+#define HIT_REV(h) ((u32)(((h) >> 15) & 1u))
+#define HIT_LEN(h) ((u32)((h)&0x7FFFu))
 
 /* ---- adjacency entry: sorts numerically by (offset, dst, orient) = list order of BG/OverlapGraph.cpp:675-676 ---- */
-#define ADJ_MAKE(off, dst, o) (((u64)(off) << 44) | ((u64)(dst) << 2) | (u64)(o))
-#define ADJ_OFF(e) ((u32)((e) >> 44) & 0x7FFFu)
-#define ADJ_DST(e) (((e) >> 2) & ((1ull << 42) - 1))
-#define ADJ_ORI(e) ((u32)((e)&3u))
+/* offset(15) | dst(31) | orient(2) | len(dst)(15): the destination's length rides along so that the twin's offset     */
+/* (BG/OverlapGraph.cpp:617) needs no extra gather.                                                                    */
+#define ADJ_MAKE(off, dst, o, dlen) (((u64)(off) << 49) | ((u64)(dst) << 18) | ((u64)(o) << 16) | (u64)(dlen))
+#define ADJ_OFF(e) ((u32)((e) >> 49) & 0x7FFFu)
+#define ADJ_DST(e) (((e) >> 18) & 0x7FFFFFFFull)
+#define ADJ_ORI(e) ((u32)(((e) >> 16) & 3u))
+#define ADJ_DLEN(e) ((u32)((e)&0x7FFFu))
 
 /* ---- containment key for atomicMin: smallest super id wins, then smallest j, then prefix record first ---------- */
 #define CKEY_MAKE(a, j, suf, rev) (((u64)(a) << 17) | ((u64)(j) << 2) | ((u64)(suf) << 1) | (u64)(rev))
@@ -85,6 +90,23 @@ __device__ __forceinline__ u64 lane_mask_lt()
 {
     u32 l = __lane_id();
     return l ? (~0ull >> (64 - l)) : 0ull;
+}
+
+/* ascending bitonic sort of one u64 per lane across the wavefront (21 compare-exchange steps) */
+__device__ __forceinline__ u64 wave_bitonic_sort(u64 x, u32 lane)
+{
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            const u64 y = __shfl_xor(x, j2);
+            const bool up = (lane & k2) == 0;
+            const bool lower = (lane & j2) == 0;
+            const bool take_min = (up == lower);
+            x = take_min ? (x < y ? x : y) : (x < y ? y : x);
+        }
+    }
+    return x;
 }
 
 /* reverse the order of the 32 2-bit groups of x */

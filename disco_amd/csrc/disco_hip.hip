@@ -423,12 +423,15 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
 {
     if (!c || (n && (!packed || !len))) return c ? fail(c, DISCO_E_ARG, "disco_upload_reads: null argument") : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(set_reads_common(c, n, stride_words));
-    CHK(dev_alloc(c, &c->d_reads, n * (u64)stride_words));
+    /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
+    const uint32_t dstride = (stride_words + 7u) & ~7u;
+    CHK(set_reads_common(c, n, dstride));
+    CHK(dev_alloc(c, &c->d_reads, n * (u64)dstride));
     CHK(dev_alloc(c, &c->d_len, n));
     c->reads_owned = true;
     if (n) {
-        HIPCHK(c, hipMemcpyAsync(c->d_reads, packed, n * (u64)stride_words * 8, hipMemcpyHostToDevice, c->stream));
+        if (dstride != stride_words) HIPCHK(c, hipMemsetAsync(c->d_reads, 0, n * (u64)dstride * 8, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(c->d_reads, (size_t)dstride * 8, packed, (size_t)stride_words * 8, (size_t)stride_words * 8, n, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_len, len, n * 2, hipMemcpyHostToDevice, c->stream));
     }
     c->h_len.assign(len, len + n);
@@ -452,7 +455,7 @@ int disco_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
     if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
         return fail(c, DISCO_E_ARG, "disco_generate_reads: bad spec");
     HIPCHK(c, hipSetDevice(c->device));
-    uint32_t stride = (s->len_max + 31) / 32;
+    uint32_t stride = (((s->len_max + 31) / 32) + 7u) & ~7u; /* 64-B aligned rows */
     CHK(set_reads_common(c, s->n_reads, stride));
     CHK(dev_alloc(c, &c->d_reads, c->n * (u64)stride));
     CHK(dev_alloc(c, &c->d_len, c->n));
@@ -706,6 +709,34 @@ static int select_edges(disco_ctx *c)
 static int twin_check(disco_ctx *c, u64 lo, u64 hi)
 {
     if (!c->d_extra_cnt) CHK(dev_alloc(c, &c->d_extra_cnt, c->n));
+    {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
+        CHK(zero_counter(c, CTR_ASYM));
+        CHK(zero_counter(c, CTR_TW_UP));
+        CHK(zero_counter(c, CTR_TW_DOWN));
+        TwinArgs a;
+        a.v = view(c);
+        a.adj_start = c->d_adj_start;
+        a.adj = c->d_adj;
+        a.lo = lo;
+        a.hi = hi;
+        a.extra_cnt = c->d_extra_cnt;
+        a.extra_node = nullptr;
+        a.extra_key = nullptr;
+        a.n_extra = c->d_n_extra;
+        a.extra_cap = 0;
+        a.up_only = 1;
+        ph_begin(c, DISCO_PH_TWIN);
+        if (c->n) hipLaunchKernelGGL(twin_check_kernel, dim3(flat_grid(c, c->n * 64)), dim3(256), 0, c->stream, a);
+        ph_end(c, DISCO_PH_TWIN);
+        HIPCHK(c, hipGetLastError());
+        CHK(read_counters(c));
+        ph_collect(c);
+        if (c->h_ctr[CTR_ASYM] == 0 && c->h_ctr[CTR_TW_UP] == c->h_ctr[CTR_TW_DOWN]) {
+            c->n_extra = 0;
+            c->asym_local = 0;
+            return DISCO_OK;
+        }
+    }
     u32 want = 4096;
     for (int attempt = 0; attempt < 6; attempt++) {
         if (want > c->extra_cap) {
@@ -730,6 +761,7 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
         a.extra_key = c->d_extra_key;
         a.n_extra = c->d_n_extra;
         a.extra_cap = c->extra_cap;
+        a.up_only = 0;
         ph_begin(c, DISCO_PH_TWIN);
         if (c->n) hipLaunchKernelGGL(twin_check_kernel, dim3(flat_grid(c, c->n * 64)), dim3(256), 0, c->stream, a);
         ph_end(c, DISCO_PH_TWIN);
@@ -1074,7 +1106,7 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
         e.orient = ADJ_ORI(he[i]);
         e.offset = ADJ_OFF(he[i]);
         e.len_src = c->h_len[e.src];
-        e.len_dst = c->h_len[e.dst];
+        e.len_dst = ADJ_DLEN(he[i]);
     }
     return (int64_t)ne;
 }

@@ -39,6 +39,8 @@ enum {
     CTR_TR_BIG,
     CTR_MAX_DEG,
     CTR_MAX_ROW,
+    CTR_TW_UP,
+    CTR_TW_DOWN,
     CTR_COUNT
 };
 
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
                             atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                         if (overlap) {
                             ov = true;
-                            hit = HIT_MAKE(j, B, suf, rev);
+                            hit = HIT_MAKE(j, B, suf, rev, LB);
                         }
                     }
                 }
@@ -535,7 +537,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         if (ctr < a.max_per_kmer) {
             u32 orient, off;
             disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
-            if (lane == 0) h[nacc] = ADJ_MAKE(off, B, orient);
+            if (lane == 0) h[nacc] = ADJ_MAKE(off, B, orient, HIT_LEN(hit));
             nacc++;
             ctr++;
             __syncthreads();
@@ -551,6 +553,52 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
     if (lane == 0) a.deg[A] = nacc;
     __syncthreads();
+}
+
+/* rows of at most 64 hits entirely in registers: bitonic sort into consumption order, first occurrence of every
+ * destination = accepted (valid while no k-mer group has more than max_per_kmer acceptable hits, i.e. the cap never
+ * blocks anything — otherwise return false and let the sequential scan decide), bitonic sort by offset, write back. */
+__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u32 c, u32 lane)
+{
+    u64 *row = a.hits + a.row_start[A];
+    const u32 LA = a.v.len[A];
+    u64 hit = ~0ull;
+    if (lane < c) {
+        hit = row[lane];
+        if (a.contained[HIT_ID(hit)]) hit = ~0ull;
+    }
+    hit = wave_bitonic_sort(hit, lane);
+    const bool valid = hit != ~0ull;
+    const u32 m = __popcll(__ballot(valid));
+    const u32 B = (u32)HIT_ID(hit);
+    const u32 j = HIT_J(hit);
+    bool dup = false;
+    for (u32 t = 0; t + 1 < m; t++) {
+        const u32 bt = (u32)__builtin_amdgcn_readlane((int)B, (int)t);
+        dup |= (lane > t) && (B == bt);
+    }
+    const bool nondup = valid && !dup;
+    const u32 jprev = __shfl_up(j, 1);
+    const bool start = valid && (lane == 0 || j != jprev);
+    const u64 sm = __ballot(start), nd = __ballot(nondup);
+    const u64 lt = lane_mask_lt();
+    const u64 le = lt | (1ull << lane);
+    const u64 smle = sm & le;
+    const u32 gs = smle ? 63u - (u32)__clzll((long long)smle) : 0u;
+    const u64 range = lt & ~((1ull << gs) - 1ull);
+    const bool viol = nondup && (u32)__popcll(nd & range) >= a.max_per_kmer;
+    if (__any(viol)) return false;
+    u64 ent = ~0ull;
+    if (nondup) {
+        u32 orient, off;
+        disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
+        ent = ADJ_MAKE(off, B, orient, HIT_LEN(hit));
+    }
+    ent = wave_bitonic_sort(ent, lane);
+    const u32 nacc = __popcll(nd);
+    if (lane < nacc) row[lane] = ent;
+    if (lane == 0) a.deg[A] = nacc;
+    return true;
 }
 
 template <bool BIG>
@@ -579,6 +627,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             }
             continue;
         }
+        if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane)) continue;
         edge_select_row(a, A, h, t, c, lane, cap_sites);
     }
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
@@ -628,6 +677,8 @@ struct TwinArgs {
     u64 *extra_key;
     u32 *n_extra;
     u32 extra_cap;
+    int up_only;          /* 1: search only finds with src < dst and count both kinds; equality of the two counts plus no
+                             missing twin proves symmetry (the up-finds inject into the down-finds); no extras recorded */
 };
 
 __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
@@ -635,32 +686,52 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
     const u32 lane = threadIdx.x & 63;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    u32 asym = 0;
+    u32 asym = 0, n_up = 0, n_down = 0;
     for (u64 u = wave; u < a.v.n; u += nwaves) {
         const u64 s = a.adj_start[u], e = a.adj_start[u + 1];
+        if (s == e) continue;
         const u32 Lu = a.v.len[u];
+        const bool u_in = (u >= a.lo && u < a.hi);
         for (u64 p = s + lane; p < e; p += 64) {
             const u64 ent = a.adj[p];
             const u64 w = ADJ_DST(ent);
-            if (w < a.lo || w >= a.hi) continue;
-            const u32 Lw = a.v.len[w];
-            const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent))); /* :617-619 */
+            if (a.up_only) {
+                if (w < u) { /* a down-find, counted at its source */
+                    n_down += u_in ? 1u : 0u;
+                    continue;
+                }
+                if (w < a.lo || w >= a.hi) continue;
+                n_up++;
+            } else if (w < a.lo || w >= a.hi)
+                continue;
+            const u32 Lw = ADJ_DLEN(ent);
+            const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent)), Lu); /* :617-619 */
             const u64 ws = a.adj_start[w];
             const u32 dw = (u32)(a.adj_start[w + 1] - ws);
             if (adj_find(a.adj + ws, dw, twin) < 0) {
                 asym++;
-                u32 idx = atomicAdd(a.n_extra, 1u);
-                if (idx < a.extra_cap) {
-                    a.extra_node[idx] = w;
-                    a.extra_key[idx] = twin;
-                    atomicAdd(&a.extra_cnt[w], 1u);
-                } else
-                    atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                if (!a.up_only) {
+                    u32 idx = atomicAdd(a.n_extra, 1u);
+                    if (idx < a.extra_cap) {
+                        a.extra_node[idx] = w;
+                        a.extra_key[idx] = twin;
+                        atomicAdd(&a.extra_cnt[w], 1u);
+                    } else
+                        atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                }
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) asym += __shfl_down(asym, o);
-    if (lane == 0 && asym) atomicAdd(&a.v.ctr[CTR_ASYM], (u64)asym);
+    for (int o = 32; o > 0; o >>= 1) {
+        asym += __shfl_down(asym, o);
+        n_up += __shfl_down(n_up, o);
+        n_down += __shfl_down(n_down, o);
+    }
+    if (lane == 0) {
+        if (asym) atomicAdd(&a.v.ctr[CTR_ASYM], (u64)asym);
+        if (n_up) atomicAdd(&a.v.ctr[CTR_TW_UP], (u64)n_up);
+        if (n_down) atomicAdd(&a.v.ctr[CTR_TW_DOWN], (u64)n_down);
+    }
 }
 
 /* extras merge (only when asymmetric pairs exist): new_deg = deg + extra_cnt -> scan -> copy rows -> scatter extras
@@ -859,8 +930,8 @@ __global__ void __launch_bounds__(256) emit_kernel(EmitArgs a)
                 else {
                     const u64 w = ADJ_DST(e);
                     if (v < w && !(a.flag[vs + s] & 1)) {
-                        const u32 Lw = a.v.len[w];
-                        const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)));
+                        const u32 Lw = ADJ_DLEN(e);
+                        const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
                         const u64 ws = a.adj_start[w];
                         const int ti = adj_find(a.adj + ws, (u32)(a.adj_start[w + 1] - ws), twin);
                         keep = (ti >= 0) && !(a.flag[ws + ti] & 1);

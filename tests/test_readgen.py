@@ -54,8 +54,8 @@ def test_hip_generator_equals_numpy_twin():
 
     spec = readgen.GenSpec.coverage(seed=5, n_reads=4000, read_len=100, cov=20.0, len_max=250, n_contigs=2)
     codes, off = readgen.generate_codes(spec)
-    want, lens = readgen.pack_reads(codes, off)
     with buildgraph.BuildGraph(min_overlap=40) as g:
         g.generate_reads(spec)
         packed, l2 = g.download_reads()
+        want, lens = readgen.pack_reads(codes, off, stride_words=g.stride_words)  # device rows are padded to 64 B
     assert np.array_equal(lens, l2) and np.array_equal(want, packed)
