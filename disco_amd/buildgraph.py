@@ -80,7 +80,7 @@ ABI = [
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
 ]
 
-PHASES = ("index", "probe_kernel", "contain", "select", "csr", "twin", "trmark", "emit")
+PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit")
 
 
 def lib_path() -> str:

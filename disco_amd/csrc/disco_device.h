@@ -20,12 +20,14 @@ typedef unsigned char u8;
 /* 'not contained': largest value that is also positive as int64, so that a signed all-reduce(MIN) orders keys correctly */
 #define DISCO_NOKEY 0x7FFFFFFFFFFFFFFFull
 
-/* ---- index entry payload: read id | record strand | isSuffix | length ------------------------------------------ */
+/* ---- index entry payload: read id | minimizer offset t | record strand | isSuffix | length ----------------------- */
+/* t = offset of the end k-mer's minimizer inside the CANONICAL orientation of that k-mer (0 .. k-m <= 63)           */
 #define PAY_LEN(p) ((u32)((p)&0x7FFFu))
 #define PAY_SUFFIX(p) ((u32)(((p) >> 15) & 1u))
 #define PAY_REV(p) ((u32)(((p) >> 16) & 1u))
-#define PAY_ID(p) ((p) >> 17)
-#define PAY_MAKE(id, rev, suf, len) (((u64)(id) << 17) | ((u64)(rev) << 16) | ((u64)(suf) << 15) | (u64)(len))
+#define PAY_T(p) ((u32)(((p) >> 17) & 0x7Fu))
+#define PAY_ID(p) ((p) >> 24)
+#define PAY_MAKE(id, t, rev, suf, len) (((u64)(id) << 24) | ((u64)(t) << 17) | ((u64)(rev) << 16) | ((u64)(suf) << 15) | (u64)(len))
 
 /* ---- raw verified overlap hit: sorts numerically into the reference's consumption order (j, bucket order) ------- */
 /* bucket order = ascending read id, prefix record before suffix record (BG/HashTable.cpp:451-454,486-489).          */
@@ -155,17 +157,53 @@ __device__ __forceinline__ void kmer_revcomp(u64 hi, u64 lo, int k, u64 &rhi, u6
     }
 }
 
-/* canonical k-mer key (min of forward / reverse complement, like getHashIndex BG/HashTable.cpp:383-391);
- * rev = 1 when the reverse complement is the canonical representative. A palindrome has rev = 0. */
-__device__ __forceinline__ u64 canonical_key(const u64 *__restrict__ p, int S, int j, int k, u32 &rev)
+/* canonical orientation of the k-mer at j (the reference canonicalises through min(hash(fwd), hash(rc)),
+ * BG/HashTable.cpp:383-391; any strand-symmetric choice gives the same buckets' contents up to order):
+ * 1 when the reverse complement is the smaller 2k-bit integer. A palindrome (k even) has 0. */
+__device__ __forceinline__ u32 kmer_is_rev(const u64 *__restrict__ p, int S, int j, int k)
 {
     u64 hi, lo, rhi, rlo;
     kmer_at(p, S, j, k, hi, lo);
     kmer_revcomp(hi, lo, k, rhi, rlo);
-    bool r = (rhi < hi) || (rhi == hi && rlo < lo);
-    rev = r ? 1u : 0u;
-    u64 chi = r ? rhi : hi, clo = r ? rlo : lo;
-    return disco_hash64(clo ^ disco_hash64(chi + 0x9E3779B97F4A7C15ull));
+    return ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
+}
+
+/* strand-symmetric hash of the m-mer (m <= 32) at base pos: hash of min(m-mer, reverse complement).
+ * disco_hash64 is a bijection, so distinct canonical m-mers never tie. */
+__device__ __forceinline__ u64 mmer_hash(const u64 *__restrict__ p, int S, int pos, int m)
+{
+    const u64 v = extract32(p, S, pos) >> (64 - 2 * m);
+    const u64 r = rev2_64(~v) >> (64 - 2 * m);
+    return disco_hash64(v < r ? v : r);
+}
+
+/* minimizer length for a given k: odd (no m-mer is its own reverse complement), at most 21 */
+__host__ __device__ __forceinline__ int disco_minimizer_len(int k)
+{
+    int m = k < 21 ? k : 21;
+    if ((m & 1) == 0) m -= 1;
+    return m < 1 ? 1 : m;
+}
+
+/* Minimizer of a k-mer window from the hashes h[0..k-m] of its m-mers (forward offsets): the smallest hash; on ties the
+ * LEFTMOST occurrence in the canonical orientation of the k-mer (= rightmost forward offset when rev). Returns the chosen
+ * forward offset; key = the hash. Index and probe both go through this function, so a k-mer and its reverse complement
+ * always agree on (key, offset in canonical orientation). */
+template <typename F>
+__device__ __forceinline__ int window_minimizer(F h, int nf, u32 rev, u64 &key)
+{
+    u64 best = h(0);
+    int ffirst = 0, flast = 0;
+    for (int f = 1; f < nf; f++) {
+        const u64 x = h(f);
+        if (x < best) {
+            best = x;
+            ffirst = flast = f;
+        } else if (x == best)
+            flast = f;
+    }
+    key = best;
+    return rev ? flast : ffirst;
 }
 
 /* A[a0 .. a0+m) == s2[b0 .. b0+m) where s2 = B (rev = 0) or revcomp(B) (rev = 1); LB = length of B */

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +87,7 @@ struct disco_ctx {
     u64 *d_adj_start = nullptr;
     u64 *d_adj = nullptr;
     u64 adj_total = 0; /* slots in the CSR the context currently holds */
+    u64 adj_cap = 0, flag_cap = 0, out_cap = 0, kept_cap = 0, bkt_cap = 0, ent_cap = 0; /* buffers are kept across passes */
     bool adj_imported = false;
     u32 *d_extra_cnt = nullptr;
     u64 *d_extra_node = nullptr, *d_extra_key = nullptr;
@@ -174,6 +176,18 @@ static void dev_free(disco_ctx *c, T **p, size_t count)
     }
 }
 
+/* grow-only buffer: reallocate when the need exceeds the capacity (steady-state passes allocate nothing) */
+template <typename T>
+static int ensure_cap(disco_ctx *c, T **p, u64 *cap, u64 need)
+{
+    if (*p && need <= *cap) return DISCO_OK;
+    dev_free(c, p, *cap);
+    *cap = 0;
+    CHK(dev_alloc(c, p, need));
+    *cap = std::max<u64>(need, 1);
+    return DISCO_OK;
+}
+
 static DiscoView view(const disco_ctx *c)
 {
     DiscoView v;
@@ -182,6 +196,7 @@ static DiscoView view(const disco_ctx *c)
     v.n = c->n;
     v.S = c->S;
     v.k = c->k;
+    v.m = disco_minimizer_len(c->k);
     v.bkt = c->d_bkt;
     v.ent = c->d_ent;
     v.bshift = c->bshift;
@@ -244,8 +259,9 @@ static int scan_exclusive(disco_ctx *c, const InT *in, u64 n, OutT *out, bool wr
 
 static void free_graph_state(disco_ctx *c)
 {
-    dev_free(c, &c->d_bkt, c->T + 1);
-    dev_free(c, &c->d_ent, 2 * c->n);
+    dev_free(c, &c->d_bkt, c->bkt_cap);
+    dev_free(c, &c->d_ent, c->ent_cap);
+    c->bkt_cap = c->ent_cap = 0;
     dev_free(c, &c->d_best, c->n);
     dev_free(c, &c->d_hits, c->hits_cap);
     c->hits_cap = 0;
@@ -257,18 +273,18 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_contained, c->n);
     dev_free(c, &c->d_deg, c->n);
     dev_free(c, &c->d_adj_start, c->n + 1);
-    dev_free(c, &c->d_adj, c->adj_total);
+    dev_free(c, &c->d_adj, c->adj_cap);
     dev_free(c, &c->d_extra_cnt, c->n);
     dev_free(c, &c->d_extra_node, c->extra_cap);
     dev_free(c, &c->d_extra_key, c->extra_cap);
     c->extra_cap = 0;
-    dev_free(c, &c->d_flag, c->adj_total);
-    c->adj_total = 0;
-    dev_free(c, &c->d_kept, c->q_hi - c->q_lo);
-    dev_free(c, &c->d_out_pos, c->q_hi - c->q_lo + 1);
-    dev_free(c, &c->d_out_src, c->n_out);
-    dev_free(c, &c->d_out_ent, c->n_out);
-    c->n_out = 0;
+    dev_free(c, &c->d_flag, c->flag_cap);
+    c->adj_total = c->adj_cap = c->flag_cap = 0;
+    dev_free(c, &c->d_kept, c->kept_cap);
+    dev_free(c, &c->d_out_pos, c->kept_cap + 1);
+    dev_free(c, &c->d_out_src, c->out_cap);
+    dev_free(c, &c->d_out_ent, c->out_cap);
+    c->n_out = c->out_cap = c->kept_cap = 0;
     c->adj_imported = false;
     c->T = 0;
 }
@@ -496,20 +512,19 @@ int disco_build_index(disco_ctx *c)
     if (!c) return DISCO_E_ARG;
     if (c->phase < 1) return fail(c, DISCO_E_STATE, "disco_build_index: no reads");
     HIPCHK(c, hipSetDevice(c->device));
-    u64 lo = c->q_lo, hi = c->q_hi;
-    free_graph_state(c);
-    c->q_lo = lo;
-    c->q_hi = hi;
     u64 T = 1024;
     int logT = 10;
-    while (T < 4 * c->n) {
+    /* records are keyed by minimizer: about one distinct key per 7-8 records at 30x, so n buckets keep most buckets at
+     * one key while the table (4 B per bucket) stays small enough to live in the 256 MB Infinity Cache */
+    while (T < c->n) {
         T <<= 1;
         logT++;
     }
     c->T = T;
     c->bshift = 64 - logT;
-    CHK(dev_alloc(c, &c->d_bkt, T + 1));
-    CHK(dev_alloc(c, &c->d_ent, 2 * c->n));
+    CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
+    CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
+    c->adj_imported = false;
     ph_begin(c, DISCO_PH_INDEX);
     HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (T + 1) * sizeof(u32), c->stream));
     DiscoView v = view(c);
@@ -566,7 +581,6 @@ int disco_probe(disco_ctx *c)
         CHK(zero_counter(c, CTR_MAX_ROW));
         ProbeArgs a;
         a.v = view(c);
-        a.best = c->d_best;
         a.hits = c->d_hits;
         a.hits_cap = c->hits_cap;
         a.bump = c->d_bump;
@@ -591,10 +605,24 @@ int disco_probe(disco_ctx *c)
         }
         if (!c->h_ctr[CTR_OVERFLOW]) {
             c->big_rows = n_big;
-            c->phase = 3;
+            VerifyArgs va;
+            va.v = view(c);
+            va.best = c->d_best;
+            va.hits = c->d_hits;
+            va.row_start = c->d_row_start;
+            va.row_cnt = c->d_row_cnt;
+            ph_begin(c, DISCO_PH_VERIFY);
+            if (nq) hipLaunchKernelGGL(verify_kernel, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, va);
+            ph_end(c, DISCO_PH_VERIFY);
+            HIPCHK(c, hipGetLastError());
+            CHK(read_counters(c));
             ph_collect(c);
+            c->phase = 3;
             return DISCO_OK;
         }
+        if (getenv("DISCO_VERBOSE"))
+            fprintf(stderr, "[disco] probe attempt %d overflowed: hits_cap=%llu needed=%llu n_big=%u big_cap=%u overflow=%llu\n", attempt,
+                    (unsigned long long)c->hits_cap, (unsigned long long)c->h_ctr[CTR_HITS_NEEDED], n_big, c->big_cap, (unsigned long long)c->h_ctr[CTR_OVERFLOW]);
         /* something was too small: grow and redo the pass (atomicMin on best is idempotent) */
         if (n_big > c->big_cap) want_big = (u32)std::min<u64>(nq, (u64)n_big + n_big / 4 + 1024);
         u64 needed = c->h_ctr[CTR_HITS_NEEDED];
@@ -688,18 +716,21 @@ static int select_edges(disco_ctx *c)
     u64 total = 0;
     ph_begin(c, DISCO_PH_CSR);
     CHK((scan_exclusive<u32, u64>(c, c->d_deg, c->n, c->d_adj_start, true, &total)));
-    dev_free(c, &c->d_adj, c->adj_total);
-    dev_free(c, &c->d_flag, c->adj_total);
     c->adj_total = total;
-    CHK(dev_alloc(c, &c->d_adj, total));
+    CHK(ensure_cap(c, &c->d_adj, &c->adj_cap, total));
     if (nq) hipLaunchKernelGGL(csr_copy_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_hits, c->d_row_start, c->d_deg, c->q_lo, c->q_hi, c->d_adj_start, 0ull, c->d_adj);
     ph_end(c, DISCO_PH_CSR);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ph_collect(c);
-    /* the raw hits are dead now: give the memory back */
-    dev_free(c, &c->d_hits, c->hits_cap);
-    c->hits_cap = 0;
+    /* the raw hits are dead now; the buffer is kept for the next pass unless HBM is getting tight */
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < tot / 8) {
+            dev_free(c, &c->d_hits, c->hits_cap);
+            c->hits_cap = 0;
+        }
+    }
     c->adj_imported = false;
     c->phase = 5;
     return DISCO_OK;
@@ -812,11 +843,12 @@ static int merge_extras(disco_ctx *c)
     dev_free(c, &scratch, (u64)g * (maxdeg + 1));
     dev_free(c, &new_deg, c->n);
     dev_free(c, &fill, c->n);
-    dev_free(c, &c->d_adj, c->adj_total);
+    dev_free(c, &c->d_adj, c->adj_cap);
     dev_free(c, &c->d_adj_start, c->n + 1);
     c->d_adj = new_adj;
     c->d_adj_start = new_start;
     c->adj_total = total;
+    c->adj_cap = std::max<u64>(total, 1);
     c->n_extra = 0;
     return DISCO_OK;
 }
@@ -888,10 +920,8 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     u64 total = 0;
     CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, c->d_adj_start, true, &total)));
     if (total != n_entries_all) return fail(c, DISCO_E_ARG, "disco_import_adjacency: degrees sum to %llu but %llu entries were passed", (unsigned long long)total, (unsigned long long)n_entries_all);
-    dev_free(c, &c->d_adj, c->adj_total);
-    dev_free(c, &c->d_flag, c->adj_total);
     c->adj_total = total;
-    CHK(dev_alloc(c, &c->d_adj, total));
+    CHK(ensure_cap(c, &c->d_adj, &c->adj_cap, total));
     if (total) HIPCHK(c, hipMemcpyAsync(c->d_adj, d_entries_u64_all, total * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->adj_imported = true;
@@ -906,7 +936,7 @@ int disco_transitive_mark(disco_ctx *c)
     if (c->phase < 6) return fail(c, DISCO_E_STATE, "disco_transitive_mark: build edges first");
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
-    if (!c->d_flag) CHK(dev_alloc(c, &c->d_flag, c->adj_total));
+    CHK(ensure_cap(c, &c->d_flag, &c->flag_cap, c->adj_total));
     HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_total, 1), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
@@ -987,9 +1017,12 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_emit_edges: run disco_transitive_mark first");
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
-    if (!c->d_kept) {
+    if (!c->d_kept || nq > c->kept_cap) {
+        dev_free(c, &c->d_kept, c->kept_cap);
+        dev_free(c, &c->d_out_pos, c->kept_cap + 1);
         CHK(dev_alloc(c, &c->d_kept, nq));
         CHK(dev_alloc(c, &c->d_out_pos, nq + 1));
+        c->kept_cap = nq;
     }
     EmitArgs a;
     a.v = view(c);
@@ -1004,11 +1037,14 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     if (nq) hipLaunchKernelGGL(emit_kernel<false>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
     u64 total = 0;
     CHK((scan_exclusive<u32, u64>(c, c->d_kept, nq, c->d_out_pos, true, &total)));
-    dev_free(c, &c->d_out_src, c->n_out);
-    dev_free(c, &c->d_out_ent, c->n_out);
     c->n_out = total;
-    CHK(dev_alloc(c, &c->d_out_src, total));
-    CHK(dev_alloc(c, &c->d_out_ent, total));
+    if (!c->d_out_src || total > c->out_cap) {
+        dev_free(c, &c->d_out_src, c->out_cap);
+        dev_free(c, &c->d_out_ent, c->out_cap);
+        CHK(dev_alloc(c, &c->d_out_src, total));
+        CHK(dev_alloc(c, &c->d_out_ent, total));
+        c->out_cap = std::max<u64>(total, 1);
+    }
     a.out_src = c->d_out_src;
     a.out_ent = c->d_out_ent;
     if (nq) hipLaunchKernelGGL(emit_kernel<true>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
@@ -1029,11 +1065,23 @@ int disco_transitive_reduce(disco_ctx *c, uint64_t *n_out)
 
 int disco_run_graph(disco_ctx *c)
 {
+    const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now();
     CHK(disco_build_index(c));
+    auto t1 = now();
     CHK(disco_probe(c));
+    auto t2 = now();
     CHK(disco_mark_contained(c, nullptr));
+    auto t3 = now();
     CHK(disco_build_edges(c, nullptr));
-    return disco_transitive_reduce(c, nullptr);
+    auto t4 = now();
+    int rc = disco_transitive_reduce(c, nullptr);
+    auto t5 = now();
+    if (verbose)
+        fprintf(stderr, "[disco] host wall ms: index %.1f probe %.1f contain %.1f edges %.1f reduce %.1f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5));
+    return rc;
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */

@@ -15,8 +15,9 @@
 #include "readgen.h"
 
 /* ---- tunables -------------------------------------------------------------------------------------------------- */
-#define PROBE_ROWCAP 512  /* verified overlap hits of one read staged in LDS before the flush                  */
-#define PROBE_QCAP 128    /* candidate queue (k-mer key matches waiting for verification)                       */
+#define PROBE_ROWCAP 256  /* candidates of one read staged in LDS before the flush                                */
+#define PROBE_MCAP 128    /* m-mer positions covered by one round of 64 windows: 64 + (k - m) <= 127            */
+#define PROBE_ACAP 32     /* words of the query read's own row staged in LDS (reads up to 1024 bp)              */
 #define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
 #define ES_CAP 512        /* edge_select: hits of one read sorted in LDS                                        */
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
@@ -50,6 +51,7 @@ struct DiscoView {
     u64 n;
     int S;
     int k;
+    int m; /* minimizer length, disco_minimizer_len(k) */
     /* index */
     const u32 *bkt;         /* [T+1] bucket b = entries [bkt[b], bkt[b+1]) */
     const ulonglong2 *ent;  /* [2n] {key, payload}                          */
@@ -96,20 +98,36 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
 /* ================================================================================================================
  * index build — replaces HashTable::insertDataset (BG/HashTable.cpp:46-114): count per bucket (populateReadLengths),
  * exclusive prefix sum (:58-67), fill (populateReadData / insertIntoTable :423-514).
+ * The reference keys a record by a hash of the whole end k-mer and probes once per k-mer of every read (111 random
+ * probes per 150 bp read). Here a record is keyed by the k-mer's MINIMIZER (smallest strand-symmetric m-mer hash, m = 21)
+ * and carries the minimizer's offset t inside the canonical k-mer: consecutive k-mer windows of a query read share their
+ * minimizer, so the probe needs one bucket lookup per minimizer occurrence (about 13 per read) and recovers the window
+ * from t by arithmetic. Which records a k-mer window matches is unchanged (exact k-mer equality, re-checked by the
+ * verify compare), so the hit set is the reference's.
  * In-bucket order is arbitrary here: every consumer re-establishes the reference's bucket order (ascending read id,
  * prefix record before suffix record) from the ids carried in the hits (see HIT_MAKE / CKEY_MAKE).
  * bkt has T+1 slots; counts go to bkt[1+b]; after the in-place exclusive scan of bkt[1..T] and the fill (which
  * bumps bkt[1+b] by the bucket size) bucket b is [bkt[b], bkt[b+1]).
  * ============================================================================================================== */
+/* index record of the end k-mer at base pos of read row p: key = minimizer hash, t = minimizer offset in canonical orientation */
+__device__ __forceinline__ u64 end_kmer_record(const u64 *__restrict__ p, int S, int pos, int k, int m, u32 &t, u32 &rev)
+{
+    rev = kmer_is_rev(p, S, pos, k);
+    u64 key;
+    const int f = window_minimizer([&](int x) { return mmer_hash(p, S, pos + x, m); }, k - m + 1, rev, key);
+    t = rev ? (u32)(k - m - f) : (u32)f;
+    return key;
+}
+
 __global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
         const u64 *p = v.reads + i * v.S;
         int L = v.len[i];
-        u32 rev;
-        u64 kp = canonical_key(p, v.S, 0, v.k, rev);
-        u64 ks = canonical_key(p, v.S, L - v.k, v.k, rev);
+        u32 t, rev;
+        u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, t, rev);
+        u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, t, rev);
         atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
         atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
     }
@@ -121,13 +139,13 @@ __global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2
     for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
         const u64 *p = v.reads + i * v.S;
         int L = v.len[i];
-        u32 rp, rs;
-        u64 kp = canonical_key(p, v.S, 0, v.k, rp);
-        u64 ks = canonical_key(p, v.S, L - v.k, v.k, rs);
+        u32 tp, rp, ts, rs;
+        u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, tp, rp);
+        u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, ts, rs);
         u32 pos = atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
-        ent[pos] = make_ulonglong2(kp, PAY_MAKE(i, rp, 0, L));
+        ent[pos] = make_ulonglong2(kp, PAY_MAKE(i, tp, rp, 0, L));
         pos = atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
-        ent[pos] = make_ulonglong2(ks, PAY_MAKE(i, rs, 1, L));
+        ent[pos] = make_ulonglong2(ks, PAY_MAKE(i, ts, rs, 1, L));
     }
 }
 
@@ -218,19 +236,17 @@ template <typename OutT>
 __global__ void scan_write_total_kernel(const u64 *total, OutT *out_n) { *out_n = (OutT)*total; }
 
 /* ================================================================================================================
- * probe + verify — the dominant kernel.
- *   getListOfReads (BG/HashTable.cpp:521-571) for every k-mer j of every query read A, then on every candidate
- *   checkOverlapForContainedRead (BG/OverlapGraph.cpp:517-554) and checkOverlap (:567-595), both as ONE shifted
- *   packed compare over the whole aligned region (which also re-checks the k-mer itself, so a 64-bit key collision
- *   can never produce a hit).
- * Containment is resolved with atomicMin on a packed key (closed form of the sequential loop):
- *   super(x) = smallest id A that contains x with len(A) > len(x), or len equal and A < x (BG/OverlapGraph.cpp:424,449);
- *   the recorded row is the first hit in (j, bucket order).
- * Verified overlap hits of one read are staged in LDS, then flushed to a wave-private chunk of the global hit buffer.
+ * probe — candidate generation (getListOfReads, BG/HashTable.cpp:521-571, for every k-mer window of every query read).
+ * One wavefront per read. Per round of 64 windows:
+ *   1. lanes hash the m-mers the round covers (LDS), 2. every window picks its minimizer occurrence and canonical strand,
+ *   the first window of each occurrence leads ONE bucket lookup, 3. the records of all led buckets are walked 64 at a
+ *   time (lane = record): a record names the window(s) it can match through its minimizer offset t, and the window's own
+ *   (occurrence, strand) must agree. Every surviving (window, record) pair is a candidate: the exact k-mer compare and the
+ *   overlap / containment extension happen in verify_kernel. Candidates of one read are staged in LDS and flushed,
+ *   coalesced, to a wave-private chunk of the global hit buffer (one atomic per PROBE_CHUNK slots).
  * ============================================================================================================== */
 struct ProbeArgs {
     DiscoView v;
-    u64 *best;      /* [n] containment keys                           */
     u64 *hits;      /* global hit buffer                              */
     u64 hits_cap;
     u64 *bump;      /* bump pointer into hits                         */
@@ -246,27 +262,41 @@ template <bool BIG>
 __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
 {
     __shared__ u64 s_row[BIG ? 1 : PROBE_ROWCAP];
-    __shared__ u64 s_cq[PROBE_QCAP];
-    __shared__ u32 s_cj[PROBE_QCAP];
+    __shared__ u64 s_hc[PROBE_MCAP];    /* m-mer hashes of the current round of 64 windows */
+    __shared__ u32 s_first[PROBE_MCAP]; /* first window (lane) that chose the occurrence at this relative position */
+    __shared__ u16 s_wp[64];            /* per window: chosen occurrence (relative position) | strand << 15 */
+    __shared__ u64 s_occ_key[64];       /* occurrences led in this round: minimizer hash, bucket start, running record count, position */
+    __shared__ u32 s_occ_start[64];
+    __shared__ u32 s_occ_excl[64];
+    __shared__ u32 s_occ_prel[64];
+    __shared__ u64 s_a[PROBE_ACAP];     /* the query read's own packed row */
     const u32 lane = threadIdx.x;
     const int S = a.v.S, k = a.v.k;
+    const int m = a.v.m, nf = k - m + 1;
     u64 chunk_base = 0;
     u32 chunk_used = PROBE_CHUNK;
-    u64 my_khits = 0, my_raw = 0;
     u32 my_maxrow = 0;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
 
     for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
-        const u64 *pa = a.v.reads + A * S;
+        const u64 *ga = a.v.reads + A * S;
         const int LA = a.v.len[A];
-        const int npos = LA - k; /* j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
-        u32 nrow = 0, ncand = 0;
-        u64 read_khits = 0; /* per-lane, this read only */
+        const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
+        const int n_mpos = LA - m + 1;
+        /* stage the read's row in LDS when it fits: every later extract is then a broadcast LDS read, not a global load */
+        const u64 *pa = ga;
+        __syncthreads();
+        if (S <= PROBE_ACAP) {
+            for (int w = (int)lane; w < S; w += 64) s_a[w] = ga[w];
+            pa = s_a;
+        }
+        u32 nrow = 0;
         u64 *grow = nullptr;
+        u32 want = 0;
         if (BIG) {
             u64 base = 0;
-            u32 want = a.big_cnt[it];
+            want = a.big_cnt[it];
             if (lane == 0) {
                 base = atomicAdd(a.bump, (u64)want);
                 atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + want);
@@ -277,113 +307,94 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             else if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
         }
 
-        /* verify the first cnt queued candidates (cnt <= 64), one per lane */
-        auto verify = [&](u32 cnt) {
-            bool ov = false;
-            u64 hit = 0;
-            if (lane < cnt) {
-                const u64 c = s_cq[lane];
-                const int j = (int)s_cj[lane];
-                const u64 B = PAY_ID(c);
-                const int LB = (int)PAY_LEN(c);
-                const u32 suf = PAY_SUFFIX(c), rev = PAY_REV(c);
-                const u64 *pb = a.v.reads + B * S;
-                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
-                /* exact k-mer re-check (the index compares only 64-bit keys) */
-                if (seg_equal(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
-                    read_khits++;
-                    int a0, b0, m;
-                    bool contain, overlap;
-                    if (prefix_align) {
-                        int rem = LA - j;
-                        contain = rem >= LB;              /* BG/OverlapGraph.cpp:532 */
-                        overlap = !contain && j >= 1;     /* :579 */
-                        a0 = j;
-                        b0 = 0;
-                        m = contain ? LB : rem;
-                    } else {
-                        int sft = j + k - LB;             /* where s2 starts in A */
-                        contain = sft >= 0;               /* :547 */
-                        overlap = sft <= 0 && j >= 1;     /* :591 */
-                        a0 = sft > 0 ? sft : 0;
-                        b0 = sft < 0 ? -sft : 0;
-                        m = j + k - a0;
-                    }
-                    if (seg_equal(pa, pb, S, LB, a0, b0, m, rev)) {
-                        if (contain && (LA > LB || (LA == LB && A < B)))
-                            atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
-                        if (overlap) {
-                            ov = true;
-                            hit = HIT_MAKE(j, B, suf, rev, LB);
-                        }
-                    }
-                }
-            }
-            u64 m = __ballot(ov);
-            if (ov) {
-                u32 pos = nrow + __popcll(m & lane_mask_lt());
+        /* append the candidates flagged by `take` to the row */
+        auto push = [&](bool take, u64 pay, u32 rev, int jj) {
+            const u64 mm = __ballot(take);
+            if (take) {
+                const u32 pos = nrow + __popcll(mm & lane_mask_lt());
+                const u64 hit = HIT_MAKE(jj, PAY_ID(pay), PAY_SUFFIX(pay), rev, PAY_LEN(pay));
                 if (BIG) {
-                    if (grow && pos < a.big_cnt[it]) grow[pos] = hit;
+                    if (grow && pos < want) grow[pos] = hit;
                 } else if (pos < PROBE_ROWCAP)
                     s_row[pos] = hit;
             }
-            nrow += __popcll(m);
+            nrow += __popcll(mm);
         };
 
         for (int j0 = 0; j0 < npos; j0 += 64) {
-            const int j = j0 + (int)lane;
-            u32 s = 0, e = 0, fq = 0;
-            u64 key = 0;
-            if (j < npos) {
-                key = canonical_key(pa, S, j, k, fq);
-                u64 b = key >> a.v.bshift;
-                s = a.v.bkt[b];
-                e = a.v.bkt[b + 1];
+            /* 1. strand-symmetric hashes of the m-mers that the 64 windows of this round cover */
+            __syncthreads();
+            {
+                int nm = 63 + nf;
+                if (nm > n_mpos - j0) nm = n_mpos - j0;
+                for (int q = (int)lane; q < PROBE_MCAP; q += 64) {
+                    s_first[q] = 0xFFFFFFFFu;
+                    if (q < nm) s_hc[q] = mmer_hash(pa, S, j0 + q, m);
+                }
             }
-            while (__any(s < e)) {
+            __syncthreads();
+            /* 2. every window picks its minimizer occurrence; the first window of an occurrence leads its lookup */
+            const int j = j0 + (int)lane;
+            const bool valid = j < npos;
+            u32 rev_j = 0, prel = 0;
+            u64 key = 0;
+            if (valid) {
+                rev_j = kmer_is_rev(pa, S, j, k);
+                const int f = window_minimizer([&](int x) { return s_hc[(int)lane + x]; }, nf, rev_j, key);
+                prel = lane + (u32)f; /* occurrence position relative to j0 */
+                atomicMin(&s_first[prel], lane);
+            }
+            s_wp[lane] = valid ? (u16)(prel | (rev_j << 15)) : (u16)0x7FFF;
+            __syncthreads();
+            const bool leader = valid && s_first[prel] == lane;
+            /* 3. one bucket lookup per occurrence, then all records of all led buckets, lane = record */
+            u32 s = 0, cnt = 0;
+            if (leader) {
+                const u64 b = key >> a.v.bshift;
+                s = a.v.bkt[b];
+                cnt = a.v.bkt[b + 1] - s;
+            }
+            u32 incl = cnt;
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 y = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += y;
+            }
+            const u32 total = __shfl(incl, 63);
+            const u64 lm = __ballot(leader);
+            const u32 nocc = __popcll(lm);
+            if (leader) {
+                const u32 slot = __popcll(lm & lane_mask_lt());
+                s_occ_key[slot] = key;
+                s_occ_start[slot] = s;
+                s_occ_excl[slot] = incl - cnt;
+                s_occ_prel[slot] = prel;
+            }
+            __syncthreads();
+            for (u32 base = 0; base < total; base += 64) {
+                const u32 idx = base + lane;
                 bool match = false;
                 u64 pay = 0;
-                if (s < e) {
-                    ulonglong2 en = a.v.ent[s];
-                    s++;
+                u32 oprel = 0;
+                if (idx < total) {
+                    u32 o = 0; /* largest o with excl[o] <= idx; nocc is small (about 8) */
+                    for (u32 x = 1; x < nocc; x++) o = (s_occ_excl[x] <= idx) ? x : o;
+                    const ulonglong2 en = a.v.ent[s_occ_start[o] + (idx - s_occ_excl[o])];
                     pay = en.y;
-                    match = (en.x == key) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
+                    oprel = s_occ_prel[o];
+                    match = (en.x == s_occ_key[o]) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
                 }
-                u64 mm = __ballot(match);
-                if (match) {
-                    u32 pos = ncand + __popcll(mm & lane_mask_lt());
-                    /* strand relation query vs record replaces the record's own strand bit */
-                    s_cq[pos] = (pay & ~(1ull << 16)) | ((u64)(PAY_REV(pay) ^ fq) << 16);
-                    s_cj[pos] = (u32)j;
-                }
-                ncand += __popcll(mm);
-                if (ncand >= 64) {
-                    __syncthreads();
-                    verify(64);
-                    __syncthreads();
-                    u64 c2 = 0;
-                    u32 j2 = 0;
-                    if (lane + 64 < ncand) {
-                        c2 = s_cq[lane + 64];
-                        j2 = s_cj[lane + 64];
-                    }
-                    __syncthreads();
-                    if (lane + 64 < ncand) {
-                        s_cq[lane] = c2;
-                        s_cj[lane] = j2;
-                    }
-                    ncand -= 64;
-                }
+                /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k-m-t before */
+                const int t = (int)PAY_T(pay);
+                const int w1 = (int)oprel - t, w2 = (int)oprel - (nf - 1 - t);
+                const bool take1 = match && w1 >= 0 && w1 < 64 && s_wp[w1] == (u16)oprel;
+                const bool take2 = match && w2 >= 0 && w2 < 64 && s_wp[w2] == (u16)(oprel | 0x8000u);
+                /* strand relation query window vs record (0 = same strand) */
+                push(take1, pay, PAY_REV(pay), j0 + w1);
+                push(take2, pay, PAY_REV(pay) ^ 1u, j0 + w2);
             }
         }
         __syncthreads();
-        if (ncand) verify(ncand);
-        __syncthreads();
 
-        if (BIG || nrow <= PROBE_ROWCAP) { /* a row that overflows LDS is recounted by the big-row pass */
-            my_khits += read_khits;
-            my_raw += (lane == 0) ? nrow : 0;
-        }
         if (nrow > my_maxrow) my_maxrow = nrow;
         if (BIG) {
             if (lane == 0) a.row_cnt[A] = grow ? nrow : 0;
@@ -423,14 +434,117 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             }
             chunk_used += nrow;
         }
-        __syncthreads();
     }
-    /* counters: one atomic per wave */
+    if (lane == 0) atomicMax(&a.v.ctr[CTR_MAX_ROW], (u64)my_maxrow);
+}
+
+/* ================================================================================================================
+ * verify — checkOverlapForContainedRead (BG/OverlapGraph.cpp:517-554) and checkOverlap (:567-595) on every candidate,
+ * both as ONE shifted packed compare over the whole aligned region, preceded by the exact k-mer compare (the index
+ * matches on minimizers only, so this is what makes a candidate a hit of getListOfReads).
+ * One wavefront per query read, lane = candidate, no LDS: the read's own row is shared by all lanes, each lane fetches one
+ * 64-byte candidate row. Containment is resolved with atomicMin on a packed key (closed form of the sequential loop,
+ * SURVEY.md §8c-7): super(x) = smallest id A containing x with len(A) > len(x), or equal length and A < x
+ * (BG/OverlapGraph.cpp:424,449); the recorded row is the first hit in (j, bucket order).
+ * Candidates that are not overlap hits are overwritten with ~0 (dropped later by edge selection).
+ * ============================================================================================================== */
+struct VerifyArgs {
+    DiscoView v;
+    u64 *best;
+    u64 *hits;
+    const u64 *row_start;
+    u32 *row_cnt; /* in: candidates, out: verified overlap hits (row compacted in place) */
+};
+
+#define VERIFY_SW 8 /* row words staged per lane in LDS: rows of at most 8 words (reads up to 256 bp, 64-B rows) */
+
+__global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
+{
+    /* per lane: the candidate's row; +1 word of padding keeps the 64 rows on different banks */
+    __shared__ u64 s_b[64 * (VERIFY_SW + 1)];
+    __shared__ u64 s_a[VERIFY_SW];
+    const u32 lane = threadIdx.x;
+    const int S = a.v.S, k = a.v.k;
+    const bool staged = (S == VERIFY_SW);
+    u64 my_khits = 0, my_raw = 0;
+    for (u64 A = a.v.q_lo + blockIdx.x; A < a.v.q_hi; A += gridDim.x) {
+        const u32 c = a.row_cnt[A];
+        if (c == 0) continue;
+        u64 *row = a.hits + a.row_start[A];
+        const u64 *ga = a.v.reads + A * S;
+        const int LA = a.v.len[A];
+        const u64 *pa = ga;
+        __syncthreads();
+        if (staged) {
+            if (lane < VERIFY_SW) s_a[lane] = ga[lane];
+            pa = s_a;
+        }
+        u32 nkeep = 0;
+        for (u32 i0 = 0; i0 < c; i0 += 64) {
+            const u32 i = i0 + lane;
+            bool ov = false;
+            u64 h = 0;
+            const u64 *pb = nullptr;
+            if (i < c) {
+                h = row[i];
+                const u64 *gb = a.v.reads + HIT_ID(h) * S;
+                pb = gb;
+                if (staged) { /* four independent 16-byte loads, then everything else is LDS */
+                    const ulonglong2 *g2 = (const ulonglong2 *)gb;
+                    const ulonglong2 r0 = g2[0], r1 = g2[1], r2 = g2[2], r3 = g2[3];
+                    u64 *sb = s_b + lane * (VERIFY_SW + 1);
+                    sb[0] = r0.x; sb[1] = r0.y; sb[2] = r1.x; sb[3] = r1.y;
+                    sb[4] = r2.x; sb[5] = r2.y; sb[6] = r3.x; sb[7] = r3.y;
+                    pb = sb;
+                }
+            }
+            __syncthreads();
+            if (i < c) {
+                const int j = (int)HIT_J(h);
+                const u64 B = HIT_ID(h);
+                const int LB = (int)HIT_LEN(h);
+                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
+                if (seg_equal(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
+                    my_khits++;
+                    int a0, b0, mlen;
+                    bool contain, overlap;
+                    if (prefix_align) {
+                        const int rem = LA - j;
+                        contain = rem >= LB;          /* BG/OverlapGraph.cpp:532 */
+                        overlap = !contain && j >= 1; /* :579 */
+                        a0 = j;
+                        b0 = 0;
+                        mlen = contain ? LB : rem;
+                    } else {
+                        const int sft = j + k - LB;   /* where s2 starts in A */
+                        contain = sft >= 0;           /* :547 */
+                        overlap = sft <= 0 && j >= 1; /* :591 */
+                        a0 = sft > 0 ? sft : 0;
+                        b0 = sft < 0 ? -sft : 0;
+                        mlen = j + k - a0;
+                    }
+                    if (seg_equal(pa, pb, S, LB, a0, b0, mlen, rev)) {
+                        if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                        ov = overlap;
+                    }
+                }
+            }
+            /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
+            const u64 mk = __ballot(ov);
+            if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+            nkeep += __popcll(mk);
+            __syncthreads();
+        }
+        if (lane == 0) {
+            a.row_cnt[A] = nkeep;
+            my_raw += nkeep;
+        }
+    }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {
         if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
         if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
-        atomicMax(&a.v.ctr[CTR_MAX_ROW], (u64)my_maxrow);
     }
 }
 
@@ -508,7 +622,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         bool keep = false;
         if (i < c) {
             hit = row[i];
-            keep = !a.contained[HIT_ID(hit)];
+            keep = (hit != ~0ull) && !a.contained[HIT_ID(hit)];
         }
         u64 mk = __ballot(keep);
         if (keep) h[m + __popcll(mk & lane_mask_lt())] = hit;
@@ -565,7 +679,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     u64 hit = ~0ull;
     if (lane < c) {
         hit = row[lane];
-        if (a.contained[HIT_ID(hit)]) hit = ~0ull;
+        if (hit != ~0ull && a.contained[HIT_ID(hit)]) hit = ~0ull;
     }
     hit = wave_bitonic_sort(hit, lane);
     const bool valid = hit != ~0ull;

@@ -177,7 +177,8 @@ int disco_get_counters(disco_ctx *ctx, disco_counters *out);
  * (index = DISCO_PH_*). DISCO_PH_PROBE_KERNEL brackets exactly one launch of the dominant kernel. */
 enum {
     DISCO_PH_INDEX = 0,    /* memset + count + scan + fill                       */
-    DISCO_PH_PROBE_KERNEL, /* one launch of probe_kernel<false>                  */
+    DISCO_PH_PROBE_KERNEL, /* one launch of probe_kernel<false> (candidate generation) */
+    DISCO_PH_VERIFY,       /* one launch of verify_kernel                         */
     DISCO_PH_CONTAIN,
     DISCO_PH_SELECT,       /* edge_select_kernel<false>                          */
     DISCO_PH_CSR,          /* degree scan + row copy                             */
