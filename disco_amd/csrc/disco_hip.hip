@@ -95,6 +95,7 @@ struct disco_ctx {
     u32 extra_cap = 0;
     u32 n_extra = 0;
     u64 asym_local = 0;
+    u64 dropped = 0; /* hits edge selection dropped in the local query range (0 => the selected edges are symmetric) */
 
     /* reduction */
     u8 *d_flag = nullptr;
@@ -667,6 +668,7 @@ static int select_edges(disco_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_deg, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_CAP_SITES));
+    CHK(zero_counter(c, CTR_DROPPED));
     CHK(zero_counter(c, CTR_OVERFLOW));
     EdgeSelArgs a;
     a.v = view(c);
@@ -711,6 +713,7 @@ static int select_edges(disco_ctx *c)
         CHK(rc);
     }
     c->h_ctr[CTR_ES_BIG] = n_big;
+    c->dropped = c->h_ctr[CTR_DROPPED];
     /* CSR in node order; nodes outside the query range have empty rows */
     if (!c->d_adj_start) CHK(dev_alloc(c, &c->d_adj_start, c->n + 1));
     u64 total = 0;
@@ -740,6 +743,17 @@ static int select_edges(disco_ctx *c)
 static int twin_check(disco_ctx *c, u64 lo, u64 hi)
 {
     if (!c->d_extra_cnt) CHK(dev_alloc(c, &c->d_extra_cnt, c->n));
+    /* After the contained filter the verified-hit relation is symmetric: a hit A->B at window j >= 1 of overlap length
+     * ovl >= k+1 shows up from B's side at window ovl-k >= 1 against A's other end record, and verifies over the same
+     * region. A find can therefore miss its twin only if the twin's owner DROPPED a verified hit (second hit to the same
+     * destination, BG/OverlapGraph.cpp:656, or the per-k-mer cap, :645). If no read of the target range dropped anything,
+     * every list in the range already holds all twins and nothing needs to be searched. */
+    if (c->dropped == 0 && lo >= c->q_lo && hi <= c->q_hi && !getenv("DISCO_FORCE_TWIN_CHECK")) {
+        c->n_extra = 0;
+        c->asym_local = 0;
+        c->ph_ms[DISCO_PH_TWIN] = 0;
+        return DISCO_OK;
+    }
     {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
         CHK(zero_counter(c, CTR_ASYM));
         CHK(zero_counter(c, CTR_TW_UP));

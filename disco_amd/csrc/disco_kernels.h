@@ -42,6 +42,7 @@ enum {
     CTR_MAX_ROW,
     CTR_TW_UP,
     CTR_TW_DOWN,
+    CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
     CTR_COUNT
 };
 
@@ -610,7 +611,7 @@ __device__ __forceinline__ void wave_rank_sort(const u64 *src, u64 *dst, u32 m, 
     }
 }
 
-__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 &cap_sites)
+__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 &cap_sites, u32 &dropped)
 {
     u64 *row = a.hits + a.row_start[A];
     const u32 LA = a.v.len[A];
@@ -666,13 +667,14 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     __syncthreads();
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
     if (lane == 0) a.deg[A] = nacc;
+    dropped += m - nacc;
     __syncthreads();
 }
 
 /* rows of at most 64 hits entirely in registers: bitonic sort into consumption order, first occurrence of every
  * destination = accepted (valid while no k-mer group has more than max_per_kmer acceptable hits, i.e. the cap never
  * blocks anything — otherwise return false and let the sequential scan decide), bitonic sort by offset, write back. */
-__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u32 c, u32 lane)
+__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 &dropped)
 {
     u64 *row = a.hits + a.row_start[A];
     const u32 LA = a.v.len[A];
@@ -712,6 +714,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     const u32 nacc = __popcll(nd);
     if (lane < nacc) row[lane] = ent;
     if (lane == 0) a.deg[A] = nacc;
+    dropped += m - nacc; /* second and later hits to a destination already linked (BG/OverlapGraph.cpp:656) */
     return true;
 }
 
@@ -721,7 +724,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];
     const u32 lane = threadIdx.x;
-    u32 cap_sites = 0;
+    u32 cap_sites = 0, dropped = 0;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
     u64 *t = BIG ? h + a.scratch_cap : s_t;
@@ -741,10 +744,11 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             }
             continue;
         }
-        if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane)) continue;
-        edge_select_row(a, A, h, t, c, lane, cap_sites);
+        if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane, dropped)) continue;
+        edge_select_row(a, A, h, t, c, lane, cap_sites, dropped);
     }
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+    if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
 
 /* ================================================================================================================

@@ -62,3 +62,19 @@ def test_tiny_and_empty_graphs():
     reads = _gen(21, 50, 100, 2.0)       # 2x coverage: few overlaps
     assert_parity(reads, 40, "sparse")
     assert_parity(reads[:1], 40, "single read")
+
+
+def test_twin_check_shortcut_is_sound(monkeypatch):
+    """edge selection that drops nothing implies symmetric lists (proof in disco_hip.hip:twin_check); force the search anyway
+    and require the same answer, on data where nothing is dropped and on data where hits are dropped"""
+    from tests import golden_util as gu
+    from tests.util import run_hip_reads
+
+    for name in ("mixed_4k", "repeats_8k"):
+        reads, fidx, mo = gu.case_inputs(name)
+        monkeypatch.delenv("DISCO_FORCE_TWIN_CHECK", raising=False)
+        e1, r1, c1 = run_hip_reads(reads, mo)
+        monkeypatch.setenv("DISCO_FORCE_TWIN_CHECK", "1")
+        e2, r2, c2 = run_hip_reads(reads, mo)
+        assert np.array_equal(e1, e2) and np.array_equal(r1, r2)
+        assert c1["asymmetric_pairs"] == c2["asymmetric_pairs"] and c1["e_pre"] == c2["e_pre"]
