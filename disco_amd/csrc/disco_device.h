@@ -20,14 +20,19 @@ typedef unsigned char u8;
 /* 'not contained': largest value that is also positive as int64, so that a signed all-reduce(MIN) orders keys correctly */
 #define DISCO_NOKEY 0x7FFFFFFFFFFFFFFFull
 
-/* ---- index entry payload: read id | minimizer offset t | record strand | isSuffix | length ----------------------- */
-/* t = offset of the end k-mer's minimizer inside the CANONICAL orientation of that k-mer (0 .. k-m <= 63)           */
+/* ---- index entry (8 bytes): key fingerprint | read id | minimizer offset t | record strand | isSuffix | length ---- */
+/* t = offset of the end k-mer's minimizer inside the CANONICAL orientation of that k-mer (0 .. k-m <= 63).           */
+/* The fingerprint (low 10 bits of the minimizer hash; the bucket uses the high bits) only prunes the records of other */
+/* keys that share the bucket: every candidate is exactly re-checked by verify_kernel.                                 */
 #define PAY_LEN(p) ((u32)((p)&0x7FFFu))
 #define PAY_SUFFIX(p) ((u32)(((p) >> 15) & 1u))
 #define PAY_REV(p) ((u32)(((p) >> 16) & 1u))
-#define PAY_T(p) ((u32)(((p) >> 17) & 0x7Fu))
-#define PAY_ID(p) ((p) >> 24)
-#define PAY_MAKE(id, t, rev, suf, len) (((u64)(id) << 24) | ((u64)(t) << 17) | ((u64)(rev) << 16) | ((u64)(suf) << 15) | (u64)(len))
+#define PAY_T(p) ((u32)(((p) >> 17) & 0x3Fu))
+#define PAY_ID(p) (((p) >> 23) & 0x7FFFFFFFull)
+#define PAY_FP(p) ((u32)((p) >> 54))
+#define KEY_FP(key) ((u32)((key)&0x3FFu))
+#define PAY_MAKE(key, id, t, rev, suf, len) \
+    (((u64)KEY_FP(key) << 54) | ((u64)(id) << 23) | ((u64)(t) << 17) | ((u64)(rev) << 16) | ((u64)(suf) << 15) | (u64)(len))
 
 /* ---- raw verified overlap hit: sorts numerically into the reference's consumption order (j, bucket order) ------- */
 /* bucket order = ascending read id, prefix record before suffix record (BG/HashTable.cpp:451-454,486-489).          */

@@ -6,7 +6,7 @@
  *   reads      u64[n][S]      2-bit packed, fixed stride (coalesced row fetches, no offset indirection)
  *   len        u16[n]
  *   bkt        u32[T+1]       CSR bucket table of the end-k-mer index, T = pow2 >= 4n
- *   ent        {u64 key, u64 payload}[2n]   payload = id | record strand | isSuffix | len
+ *   ent        u64[2n]        8-byte records: key fingerprint | id | minimizer offset | record strand | isSuffix | len
  *   best       u64[n]         containment keys (atomicMin), all-reduced(MIN) across ranks
  *   contained  u8[n]
  *   hits       u64[cap]       raw verified overlap hits, wave-private chunks, rows addressed by row_start/row_cnt
@@ -54,7 +54,7 @@ struct disco_ctx {
     u64 T = 0;
     int bshift = 0;
     u32 *d_bkt = nullptr;
-    ulonglong2 *d_ent = nullptr;
+    u64 *d_ent = nullptr;
 
     /* scan temporaries */
     u64 *d_tile = nullptr;
@@ -517,7 +517,9 @@ int disco_build_index(disco_ctx *c)
     int logT = 10;
     /* records are keyed by minimizer: about one distinct key per 7-8 records at 30x, so n buckets keep most buckets at
      * one key while the table (4 B per bucket) stays small enough to live in the 256 MB Infinity Cache */
-    while (T < c->n) {
+    double tscale = 4.0;
+    if (const char *e = getenv("DISCO_BUCKET_SCALE")) tscale = atof(e);
+    while ((double)T < tscale * (double)c->n) {
         T <<= 1;
         logT++;
     }
@@ -592,7 +594,11 @@ int disco_probe(disco_ctx *c)
         a.n_big = c->d_n_big;
         a.big_cap = c->big_cap;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
-        if (nq) hipLaunchKernelGGL(probe_kernel<false>, dim3(grid), dim3(64), 0, c->stream, a);
+        const bool ldsrow = c->S <= PROBE_ACAP;
+        if (nq) {
+            if (ldsrow) hipLaunchKernelGGL((probe_kernel<false, true>), dim3(grid), dim3(64), 0, c->stream, a);
+            else hipLaunchKernelGGL((probe_kernel<false, false>), dim3(grid), dim3(64), 0, c->stream, a);
+        }
         ph_end(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipGetLastError());
         u32 n_big = 0;
@@ -600,7 +606,8 @@ int disco_probe(disco_ctx *c)
         CHK(read_counters(c));
         if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
             int g2 = wave_grid(c, n_big, 8);
-            hipLaunchKernelGGL(probe_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
+            if (ldsrow) hipLaunchKernelGGL((probe_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
+            else hipLaunchKernelGGL((probe_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));
         }
@@ -613,7 +620,10 @@ int disco_probe(disco_ctx *c)
             va.row_start = c->d_row_start;
             va.row_cnt = c->d_row_cnt;
             ph_begin(c, DISCO_PH_VERIFY);
-            if (nq) hipLaunchKernelGGL(verify_kernel, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, va);
+            if (nq) {
+                if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<true>, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, va);
+                else hipLaunchKernelGGL(verify_kernel<false>, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, va);
+            }
             ph_end(c, DISCO_PH_VERIFY);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));

@@ -55,7 +55,7 @@ struct DiscoView {
     int m; /* minimizer length, disco_minimizer_len(k) */
     /* index */
     const u32 *bkt;         /* [T+1] bucket b = entries [bkt[b], bkt[b+1]) */
-    const ulonglong2 *ent;  /* [2n] {key, payload}                          */
+    const u64 *ent;         /* [2n] 8-byte records (PAY_MAKE)               */
     int bshift;             /* bucket = key >> bshift                       */
     /* query shard */
     u64 q_lo, q_hi;
@@ -134,7 +134,7 @@ __global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt)
     }
 }
 
-__global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ ent)
+__global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, u64 *__restrict__ ent)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
@@ -144,9 +144,9 @@ __global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2
         u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, tp, rp);
         u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, ts, rs);
         u32 pos = atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
-        ent[pos] = make_ulonglong2(kp, PAY_MAKE(i, tp, rp, 0, L));
+        ent[pos] = PAY_MAKE(kp, i, tp, rp, 0, L);
         pos = atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
-        ent[pos] = make_ulonglong2(ks, PAY_MAKE(i, ts, rs, 1, L));
+        ent[pos] = PAY_MAKE(ks, i, ts, rs, 1, L);
     }
 }
 
@@ -259,14 +259,16 @@ struct ProbeArgs {
     u32 big_cap;
 };
 
-template <bool BIG>
+template <bool BIG, bool LDSROW>
 __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
 {
+    /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
+     * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
     __shared__ u64 s_row[BIG ? 1 : PROBE_ROWCAP];
     __shared__ u64 s_hc[PROBE_MCAP];    /* m-mer hashes of the current round of 64 windows */
     __shared__ u32 s_first[PROBE_MCAP]; /* first window (lane) that chose the occurrence at this relative position */
     __shared__ u16 s_wp[64];            /* per window: chosen occurrence (relative position) | strand << 15 */
-    __shared__ u64 s_occ_key[64];       /* occurrences led in this round: minimizer hash, bucket start, running record count, position */
+    __shared__ u32 s_occ_fp[64];        /* occurrences led in this round: key fingerprint, bucket start, running record count, position */
     __shared__ u32 s_occ_start[64];
     __shared__ u32 s_occ_excl[64];
     __shared__ u32 s_occ_prel[64];
@@ -285,13 +287,10 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
         const int LA = a.v.len[A];
         const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
         const int n_mpos = LA - m + 1;
-        /* stage the read's row in LDS when it fits: every later extract is then a broadcast LDS read, not a global load */
-        const u64 *pa = ga;
         __syncthreads();
-        if (S <= PROBE_ACAP) {
+        if (LDSROW)
             for (int w = (int)lane; w < S; w += 64) s_a[w] = ga[w];
-            pa = s_a;
-        }
+        const u64 *pa = LDSROW ? (const u64 *)s_a : ga;
         u32 nrow = 0;
         u64 *grow = nullptr;
         u32 want = 0;
@@ -365,7 +364,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             const u32 nocc = __popcll(lm);
             if (leader) {
                 const u32 slot = __popcll(lm & lane_mask_lt());
-                s_occ_key[slot] = key;
+                s_occ_fp[slot] = KEY_FP(key);
                 s_occ_start[slot] = s;
                 s_occ_excl[slot] = incl - cnt;
                 s_occ_prel[slot] = prel;
@@ -379,10 +378,9 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
                 if (idx < total) {
                     u32 o = 0; /* largest o with excl[o] <= idx; nocc is small (about 8) */
                     for (u32 x = 1; x < nocc; x++) o = (s_occ_excl[x] <= idx) ? x : o;
-                    const ulonglong2 en = a.v.ent[s_occ_start[o] + (idx - s_occ_excl[o])];
-                    pay = en.y;
+                    pay = a.v.ent[s_occ_start[o] + (idx - s_occ_excl[o])];
                     oprel = s_occ_prel[o];
-                    match = (en.x == s_occ_key[o]) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
+                    match = (PAY_FP(pay) == s_occ_fp[o]) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
                 }
                 /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k-m-t before */
                 const int t = (int)PAY_T(pay);
@@ -459,88 +457,119 @@ struct VerifyArgs {
 
 #define VERIFY_SW 8 /* row words staged per lane in LDS: rows of at most 8 words (reads up to 256 bp, 64-B rows) */
 
+template <bool staged>
 __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 {
-    /* per lane: the candidate's row; +1 word of padding keeps the 64 rows on different banks */
-    __shared__ u64 s_b[64 * (VERIFY_SW + 1)];
+    /* staged (S == VERIFY_SW, decided by the host): rows live in LDS with a statically known address space.
+     * per lane: the candidate's row; +1 word of padding keeps the 64 rows on different banks */
+    __shared__ u64 s_b[staged ? 64 * (VERIFY_SW + 1) : 1];
     __shared__ u64 s_a[VERIFY_SW];
     const u32 lane = threadIdx.x;
-    const int S = a.v.S, k = a.v.k;
-    const bool staged = (S == VERIFY_SW);
+    const int S = staged ? VERIFY_SW : a.v.S, k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
-    for (u64 A = a.v.q_lo + blockIdx.x; A < a.v.q_hi; A += gridDim.x) {
-        const u32 c = a.row_cnt[A];
-        if (c == 0) continue;
-        u64 *row = a.hits + a.row_start[A];
-        const u64 *ga = a.v.reads + A * S;
-        const int LA = a.v.len[A];
-        const u64 *pa = ga;
-        __syncthreads();
-        if (staged) {
-            if (lane < VERIFY_SW) s_a[lane] = ga[lane];
-            pa = s_a;
+    const u64 stride = gridDim.x;
+    const u64 A_first = a.v.q_lo + blockIdx.x;
+
+    /* 3-stage software pipeline over the reads of this wave: while read t is verified, the candidates of read t+1 and the
+     * row header of read t+2 are already in flight, so each read exposes ONE memory latency (its candidate rows) */
+    struct Meta {
+        u32 c;
+        int L;
+        u64 rs;
+        u64 aw; /* lane < S: word `lane` of the read's own row */
+    };
+    auto load_meta = [&](u64 A) {
+        Meta mt;
+        mt.c = 0;
+        mt.L = 0;
+        mt.rs = 0;
+        mt.aw = 0;
+        if (A < a.v.q_hi) {
+            mt.c = a.row_cnt[A];
+            mt.rs = a.row_start[A];
+            mt.L = a.v.len[A];
+            if (staged && lane < VERIFY_SW) mt.aw = a.v.reads[A * S + lane];
         }
-        u32 nkeep = 0;
-        for (u32 i0 = 0; i0 < c; i0 += 64) {
-            const u32 i = i0 + lane;
-            bool ov = false;
-            u64 h = 0;
-            const u64 *pb = nullptr;
-            if (i < c) {
-                h = row[i];
-                const u64 *gb = a.v.reads + HIT_ID(h) * S;
-                pb = gb;
-                if (staged) { /* four independent 16-byte loads, then everything else is LDS */
-                    const ulonglong2 *g2 = (const ulonglong2 *)gb;
-                    const ulonglong2 r0 = g2[0], r1 = g2[1], r2 = g2[2], r3 = g2[3];
-                    u64 *sb = s_b + lane * (VERIFY_SW + 1);
-                    sb[0] = r0.x; sb[1] = r0.y; sb[2] = r1.x; sb[3] = r1.y;
-                    sb[4] = r2.x; sb[5] = r2.y; sb[6] = r3.x; sb[7] = r3.y;
-                    pb = sb;
-                }
-            }
+        return mt;
+    };
+    Meta m0 = load_meta(A_first), m1 = load_meta(A_first + stride);
+    u64 h0 = (lane < m0.c) ? a.hits[m0.rs + lane] : 0ull;
+
+    for (u64 A = A_first; A < a.v.q_hi; A += stride) {
+        const Meta m2 = load_meta(A + 2 * stride);
+        const u64 h1 = (lane < m1.c) ? a.hits[m1.rs + lane] : 0ull;
+        const u32 c = m0.c;
+        if (c != 0) {
+            u64 *row = a.hits + m0.rs;
+            const u64 *ga = a.v.reads + A * S;
+            const int LA = m0.L;
             __syncthreads();
-            if (i < c) {
-                const int j = (int)HIT_J(h);
-                const u64 B = HIT_ID(h);
-                const int LB = (int)HIT_LEN(h);
-                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
-                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
-                if (seg_equal(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
-                    my_khits++;
-                    int a0, b0, mlen;
-                    bool contain, overlap;
-                    if (prefix_align) {
-                        const int rem = LA - j;
-                        contain = rem >= LB;          /* BG/OverlapGraph.cpp:532 */
-                        overlap = !contain && j >= 1; /* :579 */
-                        a0 = j;
-                        b0 = 0;
-                        mlen = contain ? LB : rem;
-                    } else {
-                        const int sft = j + k - LB;   /* where s2 starts in A */
-                        contain = sft >= 0;           /* :547 */
-                        overlap = sft <= 0 && j >= 1; /* :591 */
-                        a0 = sft > 0 ? sft : 0;
-                        b0 = sft < 0 ? -sft : 0;
-                        mlen = j + k - a0;
-                    }
-                    if (seg_equal(pa, pb, S, LB, a0, b0, mlen, rev)) {
-                        if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
-                        ov = overlap;
+            if (staged && lane < VERIFY_SW) s_a[lane] = m0.aw;
+            const u64 *pa = staged ? (const u64 *)s_a : ga;
+            u32 nkeep = 0;
+            for (u32 i0 = 0; i0 < c; i0 += 64) {
+                const u32 i = i0 + lane;
+                bool ov = false;
+                u64 h = 0;
+                const u64 *gb = nullptr;
+                if (i < c) {
+                    h = (i0 == 0) ? h0 : row[i];
+                    gb = a.v.reads + HIT_ID(h) * S;
+                    if (staged) { /* four independent 16-byte loads, then everything else is LDS */
+                        const ulonglong2 *g2 = (const ulonglong2 *)gb;
+                        const ulonglong2 r0 = g2[0], r1 = g2[1], r2 = g2[2], r3 = g2[3];
+                        u64 *sb = s_b + lane * (VERIFY_SW + 1);
+                        sb[0] = r0.x; sb[1] = r0.y; sb[2] = r1.x; sb[3] = r1.y;
+                        sb[4] = r2.x; sb[5] = r2.y; sb[6] = r3.x; sb[7] = r3.y;
                     }
                 }
+                const u64 *pb = staged ? (const u64 *)(s_b + lane * (VERIFY_SW + 1)) : gb;
+                __syncthreads();
+                if (i < c) {
+                    const int j = (int)HIT_J(h);
+                    const u64 B = HIT_ID(h);
+                    const int LB = (int)HIT_LEN(h);
+                    const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+                    const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
+                    if (seg_equal(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
+                        my_khits++;
+                        int a0, b0, mlen;
+                        bool contain, overlap;
+                        if (prefix_align) {
+                            const int rem = LA - j;
+                            contain = rem >= LB;          /* BG/OverlapGraph.cpp:532 */
+                            overlap = !contain && j >= 1; /* :579 */
+                            a0 = j;
+                            b0 = 0;
+                            mlen = contain ? LB : rem;
+                        } else {
+                            const int sft = j + k - LB;   /* where s2 starts in A */
+                            contain = sft >= 0;           /* :547 */
+                            overlap = sft <= 0 && j >= 1; /* :591 */
+                            a0 = sft > 0 ? sft : 0;
+                            b0 = sft < 0 ? -sft : 0;
+                            mlen = j + k - a0;
+                        }
+                        if (seg_equal(pa, pb, S, LB, a0, b0, mlen, rev)) {
+                            if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                            ov = overlap;
+                        }
+                    }
+                }
+                /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
+                const u64 mk = __ballot(ov);
+                if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+                nkeep += __popcll(mk);
+                __syncthreads();
             }
-            /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
-            const u64 mk = __ballot(ov);
-            if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
-            nkeep += __popcll(mk);
-            __syncthreads();
+            if (lane == 0) {
+                a.row_cnt[A] = nkeep;
+                my_raw += nkeep;
+            }
         }
-        if (lane == 0) {
-            a.row_cnt[A] = nkeep;
-            my_raw += nkeep;
-        }
+        m0 = m1;
+        m1 = m2;
+        h0 = h1;
     }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {
