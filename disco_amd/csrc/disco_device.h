@@ -173,13 +173,30 @@ __device__ __forceinline__ u32 kmer_is_rev(const u64 *__restrict__ p, int S, int
     return ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
 }
 
-/* strand-symmetric hash of the m-mer (m <= 32) at base pos: hash of min(m-mer, reverse complement).
- * disco_hash64 is a bijection, so distinct canonical m-mers never tie. */
-__device__ __forceinline__ u64 mmer_hash(const u64 *__restrict__ p, int S, int pos, int m)
+/* canonical m-mer (m <= 32) at base pos: value of min(m-mer, reverse complement); strand = 1 when the reverse complement
+ * is the smaller one (m is odd, so the two never tie) */
+__device__ __forceinline__ u64 mmer_canonical(const u64 *p, int S, int pos, int m, u32 &strand)
 {
     const u64 v = extract32(p, S, pos) >> (64 - 2 * m);
     const u64 r = rev2_64(~v) >> (64 - 2 * m);
-    return disco_hash64(v < r ? v : r);
+    strand = r < v ? 1u : 0u;
+    return strand ? r : v;
+}
+
+/* 31-bit order hash of the canonical m-mer in bits 31..1, its strand in bit 0. Minimizers are chosen by the order hash. */
+__device__ __forceinline__ u32 mmer_order(const u64 *p, int S, int pos, int m)
+{
+    u32 strand;
+    const u64 c = mmer_canonical(p, S, pos, m, strand);
+    const u32 h = (u32)((c * 0x9E3779B97F4A7C15ull) >> 33);
+    return (h << 1) | strand;
+}
+
+/* 64-bit bucket key of the m-mer at pos (bijective mix of the canonical m-mer: distinct m-mers never share a key) */
+__device__ __forceinline__ u64 mmer_key(const u64 *p, int S, int pos, int m)
+{
+    u32 strand;
+    return disco_hash64(mmer_canonical(p, S, pos, m, strand));
 }
 
 /* minimizer length for a given k: odd (no m-mer is its own reverse complement), at most 21 */
@@ -190,24 +207,36 @@ __host__ __device__ __forceinline__ int disco_minimizer_len(int k)
     return m < 1 ? 1 : m;
 }
 
-/* Minimizer of a k-mer window from the hashes h[0..k-m] of its m-mers (forward offsets): the smallest hash; on ties the
- * LEFTMOST occurrence in the canonical orientation of the k-mer (= rightmost forward offset when rev). Returns the chosen
- * forward offset; key = the hash. Index and probe both go through this function, so a k-mer and its reverse complement
- * always agree on (key, offset in canonical orientation). */
+/* Minimizer of the k-mer window at base j from the order hashes h(0..nf-1) of its m-mers (forward offsets).
+ * The window's CANONICAL ORIENTATION and the chosen occurrence are defined together, strand-symmetrically:
+ *   - unique smallest order hash: that m-mer is the minimizer; the window is "reversed" (rev = 1) iff the m-mer sits on
+ *     its non-canonical strand. (A k-mer and its reverse complement contain the same physical m-mer on opposite strands.)
+ *   - several positions tie (the same canonical m-mer twice, or an order-hash collision; rare): rev = 1 iff the reverse
+ *     complement of the whole k-mer is the smaller integer (a palindrome has rev = 0, like BG/HashTable.cpp:539-549
+ *     tries the forward match first), and the LEFTMOST tied position in the canonical orientation is taken.
+ * Returns the chosen forward offset. Index and probe both call this, so a k-mer and its reverse complement always agree on
+ * the minimizer and on its offset t = rev ? nf-1-f : f inside the canonical orientation. */
 template <typename F>
-__device__ __forceinline__ int window_minimizer(F h, int nf, u32 rev, u64 &key)
+__device__ __forceinline__ int window_minimizer(F h, int nf, const u64 *p, int S, int j, int k, u32 &rev)
 {
-    u64 best = h(0);
+    u32 h0 = h(0);
+    u32 best = h0 >> 1, sbit = h0 & 1u;
     int ffirst = 0, flast = 0;
     for (int f = 1; f < nf; f++) {
-        const u64 x = h(f);
-        if (x < best) {
-            best = x;
+        const u32 x = h(f);
+        const u32 v = x >> 1;
+        if (v < best) {
+            best = v;
+            sbit = x & 1u;
             ffirst = flast = f;
-        } else if (x == best)
+        } else if (v == best)
             flast = f;
     }
-    key = best;
+    if (ffirst == flast) {
+        rev = sbit;
+        return ffirst;
+    }
+    rev = kmer_is_rev(p, S, j, k);
     return rev ? flast : ffirst;
 }
 

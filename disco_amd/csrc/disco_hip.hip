@@ -554,7 +554,9 @@ int disco_probe(disco_ctx *c)
     }
     if (c->n) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, DISCO_NOKEY);
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
-    const int grid = wave_grid(c, nq, 28);
+    int per_cu = 28;
+    if (const char *e = getenv("DISCO_PROBE_WAVES")) per_cu = atoi(e);
+    const int grid = wave_grid(c, nq, per_cu);
     u64 want_hits = nq * 64 + (u64)grid * PROBE_CHUNK + (1u << 16);
     u32 want_big = (u32)std::min<u64>(nq, nq / 64 + 1024);
     for (int attempt = 0; attempt < 8; attempt++) {

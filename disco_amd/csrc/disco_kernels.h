@@ -16,7 +16,8 @@
 
 /* ---- tunables -------------------------------------------------------------------------------------------------- */
 #define PROBE_ROWCAP 256  /* candidates of one read staged in LDS before the flush                                */
-#define PROBE_MCAP 128    /* m-mer positions covered by one round of 64 windows: 64 + (k - m) <= 127            */
+#define PROBE_SEGW 256    /* k-mer windows of a read handled per segment (reads up to 256+k bp: one segment)    */
+#define PROBE_SEGP (PROBE_SEGW + 64) /* m-mer positions a segment covers: windows + (k - m) <= 63              */
 #define PROBE_ACAP 32     /* words of the query read's own row staged in LDS (reads up to 1024 bp)              */
 #define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
 #define ES_CAP 512        /* edge_select: hits of one read sorted in LDS                                        */
@@ -110,14 +111,13 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * bkt has T+1 slots; counts go to bkt[1+b]; after the in-place exclusive scan of bkt[1..T] and the fill (which
  * bumps bkt[1+b] by the bucket size) bucket b is [bkt[b], bkt[b+1]).
  * ============================================================================================================== */
-/* index record of the end k-mer at base pos of read row p: key = minimizer hash, t = minimizer offset in canonical orientation */
+/* index record of the end k-mer at base pos of read row p: key = minimizer key, t = minimizer offset in canonical orientation */
 __device__ __forceinline__ u64 end_kmer_record(const u64 *__restrict__ p, int S, int pos, int k, int m, u32 &t, u32 &rev)
 {
-    rev = kmer_is_rev(p, S, pos, k);
-    u64 key;
-    const int f = window_minimizer([&](int x) { return mmer_hash(p, S, pos + x, m); }, k - m + 1, rev, key);
-    t = rev ? (u32)(k - m - f) : (u32)f;
-    return key;
+    const int nf = k - m + 1;
+    const int f = window_minimizer([&](int x) { return mmer_order(p, S, pos + x, m); }, nf, p, S, pos, k, rev);
+    t = rev ? (u32)(nf - 1 - f) : (u32)f;
+    return mmer_key(p, S, pos + f, m);
 }
 
 __global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt)
@@ -265,13 +265,14 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
      * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
     __shared__ u64 s_row[BIG ? 1 : PROBE_ROWCAP];
-    __shared__ u64 s_hc[PROBE_MCAP];    /* m-mer hashes of the current round of 64 windows */
-    __shared__ u32 s_first[PROBE_MCAP]; /* first window (lane) that chose the occurrence at this relative position */
-    __shared__ u16 s_wp[64];            /* per window: chosen occurrence (relative position) | strand << 15 */
-    __shared__ u32 s_occ_fp[64];        /* occurrences led in this round: key fingerprint, bucket start, running record count, position */
-    __shared__ u32 s_occ_start[64];
+    __shared__ u32 s_h[PROBE_SEGP];     /* order hash | strand of every m-mer position of the segment                */
+    __shared__ u32 s_first[PROBE_SEGP]; /* first window of the segment that chose the occurrence at this position     */
+    __shared__ u16 s_wp[PROBE_SEGW];    /* per window: chosen occurrence (position in the segment) | strand << 15      */
+    __shared__ u16 s_lead[PROBE_SEGW];  /* windows that lead a bucket lookup                                          */
+    __shared__ u32 s_occ_fp[64];        /* current batch of led occurrences: key fingerprint, bucket start,            */
+    __shared__ u32 s_occ_start[64];     /*   running record count, position                                            */
     __shared__ u32 s_occ_excl[64];
-    __shared__ u32 s_occ_prel[64];
+    __shared__ u16 s_occ_prel[64];
     __shared__ u64 s_a[PROBE_ACAP];     /* the query read's own packed row */
     const u32 lane = threadIdx.x;
     const int S = a.v.S, k = a.v.k;
@@ -281,15 +282,35 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
     u32 my_maxrow = 0;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
 
+    /* the next read's row and length are fetched while the current read is processed (LDSROW implies S <= 64 words) */
+    u64 pre_w = 0;
+    int pre_len = 0;
+    if (!BIG && LDSROW && blockIdx.x < n_items) {
+        const u64 A0 = a.v.q_lo + blockIdx.x;
+        pre_len = a.v.len[A0];
+        if ((int)lane < S) pre_w = a.v.reads[A0 * S + lane];
+    }
+
     for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
         const u64 *ga = a.v.reads + A * S;
-        const int LA = a.v.len[A];
-        const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
-        const int n_mpos = LA - m + 1;
+        int LA;
         __syncthreads();
-        if (LDSROW)
-            for (int w = (int)lane; w < S; w += 64) s_a[w] = ga[w];
+        if (!BIG && LDSROW) {
+            LA = pre_len;
+            if ((int)lane < S) s_a[lane] = pre_w;
+            const u64 itn = it + gridDim.x;
+            if (itn < n_items) {
+                const u64 An = a.v.q_lo + itn;
+                pre_len = a.v.len[An];
+                if ((int)lane < S) pre_w = a.v.reads[An * S + lane];
+            }
+        } else {
+            LA = a.v.len[A];
+            if (LDSROW)
+                for (int w = (int)lane; w < S; w += 64) s_a[w] = ga[w];
+        }
+        const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
         const u64 *pa = LDSROW ? (const u64 *)s_a : ga;
         u32 nrow = 0;
         u64 *grow = nullptr;
@@ -321,75 +342,88 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             nrow += __popcll(mm);
         };
 
-        for (int j0 = 0; j0 < npos; j0 += 64) {
-            /* 1. strand-symmetric hashes of the m-mers that the 64 windows of this round cover */
+        for (int w0 = 0; w0 < npos; w0 += PROBE_SEGW) { /* segments of PROBE_SEGW windows (one for reads up to 256+k bp) */
+            const int nw = min(PROBE_SEGW, npos - w0);
+            const int np = nw + nf - 1; /* m-mer positions the segment's windows cover */
+            /* 1. order hashes of the segment's m-mers */
             __syncthreads();
-            {
-                int nm = 63 + nf;
-                if (nm > n_mpos - j0) nm = n_mpos - j0;
-                for (int q = (int)lane; q < PROBE_MCAP; q += 64) {
-                    s_first[q] = 0xFFFFFFFFu;
-                    if (q < nm) s_hc[q] = mmer_hash(pa, S, j0 + q, m);
+            for (int q = (int)lane; q < PROBE_SEGP; q += 64) {
+                s_first[q] = 0xFFFFFFFFu;
+                if (q < np) s_h[q] = mmer_order(pa, S, w0 + q, m);
+            }
+            __syncthreads();
+            /* 2. every window picks its minimizer occurrence and canonical strand */
+            for (int ws = 0; ws < nw; ws += 64) {
+                const int w = ws + (int)lane;
+                if (w < nw) {
+                    u32 rev_w;
+                    const int f = window_minimizer([&](int x) { return s_h[w + x]; }, nf, pa, S, w0 + w, k, rev_w);
+                    const u32 prel = (u32)(w + f);
+                    s_wp[w] = (u16)(prel | (rev_w << 15));
+                    atomicMin(&s_first[prel], (u32)w);
                 }
             }
             __syncthreads();
-            /* 2. every window picks its minimizer occurrence; the first window of an occurrence leads its lookup */
-            const int j = j0 + (int)lane;
-            const bool valid = j < npos;
-            u32 rev_j = 0, prel = 0;
-            u64 key = 0;
-            if (valid) {
-                rev_j = kmer_is_rev(pa, S, j, k);
-                const int f = window_minimizer([&](int x) { return s_hc[(int)lane + x]; }, nf, rev_j, key);
-                prel = lane + (u32)f; /* occurrence position relative to j0 */
-                atomicMin(&s_first[prel], lane);
-            }
-            s_wp[lane] = valid ? (u16)(prel | (rev_j << 15)) : (u16)0x7FFF;
-            __syncthreads();
-            const bool leader = valid && s_first[prel] == lane;
-            /* 3. one bucket lookup per occurrence, then all records of all led buckets, lane = record */
-            u32 s = 0, cnt = 0;
-            if (leader) {
-                const u64 b = key >> a.v.bshift;
-                s = a.v.bkt[b];
-                cnt = a.v.bkt[b + 1] - s;
-            }
-            u32 incl = cnt;
-            for (int o = 1; o < 64; o <<= 1) {
-                const u32 y = __shfl_up(incl, o);
-                if ((int)lane >= o) incl += y;
-            }
-            const u32 total = __shfl(incl, 63);
-            const u64 lm = __ballot(leader);
-            const u32 nocc = __popcll(lm);
-            if (leader) {
-                const u32 slot = __popcll(lm & lane_mask_lt());
-                s_occ_fp[slot] = KEY_FP(key);
-                s_occ_start[slot] = s;
-                s_occ_excl[slot] = incl - cnt;
-                s_occ_prel[slot] = prel;
+            /* 3. the first window of every occurrence leads one bucket lookup */
+            u32 nlead = 0;
+            for (int ws = 0; ws < nw; ws += 64) {
+                const int w = ws + (int)lane;
+                const bool isl = (w < nw) && s_first[s_wp[w] & 0x7FFFu] == (u32)w;
+                const u64 lm = __ballot(isl);
+                if (isl) s_lead[nlead + __popcll(lm & lane_mask_lt())] = (u16)w;
+                nlead += __popcll(lm);
             }
             __syncthreads();
-            for (u32 base = 0; base < total; base += 64) {
-                const u32 idx = base + lane;
-                bool match = false;
-                u64 pay = 0;
-                u32 oprel = 0;
-                if (idx < total) {
-                    u32 o = 0; /* largest o with excl[o] <= idx; nocc is small (about 8) */
-                    for (u32 x = 1; x < nocc; x++) o = (s_occ_excl[x] <= idx) ? x : o;
-                    pay = a.v.ent[s_occ_start[o] + (idx - s_occ_excl[o])];
-                    oprel = s_occ_prel[o];
-                    match = (PAY_FP(pay) == s_occ_fp[o]) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
+            for (u32 lb = 0; lb < nlead; lb += 64) {
+                const u32 li = lb + lane;
+                const u32 nocc = min(64u, nlead - lb);
+                u32 s = 0, cnt = 0;
+                if (li < nlead) {
+                    const u32 prel = s_wp[s_lead[li]] & 0x7FFFu;
+                    const u64 key = mmer_key(pa, S, w0 + (int)prel, m);
+                    const u64 b = key >> a.v.bshift;
+                    s = a.v.bkt[b];
+                    cnt = a.v.bkt[b + 1] - s;
+                    s_occ_fp[lane] = KEY_FP(key);
+                    s_occ_prel[lane] = (u16)prel;
                 }
-                /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k-m-t before */
-                const int t = (int)PAY_T(pay);
-                const int w1 = (int)oprel - t, w2 = (int)oprel - (nf - 1 - t);
-                const bool take1 = match && w1 >= 0 && w1 < 64 && s_wp[w1] == (u16)oprel;
-                const bool take2 = match && w2 >= 0 && w2 < 64 && s_wp[w2] == (u16)(oprel | 0x8000u);
-                /* strand relation query window vs record (0 = same strand) */
-                push(take1, pay, PAY_REV(pay), j0 + w1);
-                push(take2, pay, PAY_REV(pay) ^ 1u, j0 + w2);
+                u32 incl = cnt;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const u32 y = __shfl_up(incl, o);
+                    if ((int)lane >= o) incl += y;
+                }
+                const u32 total = __shfl(incl, 63);
+                s_occ_start[lane] = s;
+                s_occ_excl[lane] = incl - cnt;
+                __syncthreads();
+                /* 4. all records of all led buckets, lane = record: a record names the window(s) it can match through its
+                 *    minimizer offset t; the window's own (occurrence, strand) must agree */
+                for (u32 base = 0; base < total; base += 64) {
+                    const u32 idx = base + lane;
+                    bool match = false;
+                    u64 pay = 0;
+                    int oprel = 0;
+                    if (idx < total) {
+                        u32 lo = 0, hi = nocc; /* largest o with excl[o] <= idx */
+                        while (hi - lo > 1) {
+                            const u32 mid = (lo + hi) >> 1;
+                            if (s_occ_excl[mid] <= idx) lo = mid;
+                            else hi = mid;
+                        }
+                        pay = a.v.ent[s_occ_start[lo] + (idx - s_occ_excl[lo])];
+                        oprel = (int)s_occ_prel[lo];
+                        match = (PAY_FP(pay) == s_occ_fp[lo]) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
+                    }
+                    /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k-m-t before */
+                    const int t = (int)PAY_T(pay);
+                    const int w1 = oprel - t, w2 = oprel - (nf - 1 - t);
+                    const bool take1 = match && w1 >= 0 && w1 < nw && s_wp[w1] == (u16)oprel;
+                    const bool take2 = match && w2 >= 0 && w2 < nw && s_wp[w2] == (u16)(oprel | 0x8000);
+                    /* strand relation query window vs record (0 = same strand) */
+                    push(take1, pay, PAY_REV(pay), w0 + w1);
+                    push(take2, pay, PAY_REV(pay) ^ 1u, w0 + w2);
+                }
+                __syncthreads();
             }
         }
         __syncthreads();

@@ -1,9 +1,10 @@
+# PMC passes for the BuildGraph kernels (one counter group per run; rocprofv3 --pmc with --kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
-export DISCO_BUCKET_SCALE=4
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof4; mkdir -p $O
-B="python3 $R/bench.py --reads 20000000 --steps 1 --warmup 0 --no-cpu-baseline"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pmc}; mkdir -p $O
+N=${2:-20000000}
+B="python3 $R/bench.py --reads $N --steps 1 --warmup 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/sq -o p -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/sq2 -o p -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O/tcc -o p -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/sq2 -o p -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $O/tcc -o p -- $B > /dev/null 2>&1
