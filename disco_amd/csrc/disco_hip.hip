@@ -80,6 +80,7 @@ struct disco_ctx {
 
     /* containment */
     u8 *d_contained = nullptr;
+    u64 *d_cbits = nullptr; /* one bit per read */
     u64 n_contained = 0;
 
     /* edges */
@@ -272,6 +273,7 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_big_cnt, c->big_cap);
     c->big_cap = 0;
     dev_free(c, &c->d_contained, c->n);
+    dev_free(c, &c->d_cbits, c->n / 64 + 1);
     dev_free(c, &c->d_deg, c->n);
     dev_free(c, &c->d_adj_start, c->n + 1);
     dev_free(c, &c->d_adj, c->adj_cap);
@@ -659,9 +661,10 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
     if (c->phase < 3) return fail(c, DISCO_E_STATE, "disco_mark_contained: run disco_probe first");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n));
+    if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n / 64 + 1));
     CHK(zero_counter(c, CTR_N_CONTAINED));
     ph_begin(c, DISCO_PH_CONTAIN);
-    if (c->n) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_ctr);
+    if (c->n) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     ph_end(c, DISCO_PH_CONTAIN);
     CHK(read_counters(c));
@@ -681,10 +684,11 @@ static int select_edges(disco_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_CAP_SITES));
     CHK(zero_counter(c, CTR_DROPPED));
+    CHK(zero_counter(c, CTR_ES_SLOW));
     CHK(zero_counter(c, CTR_OVERFLOW));
     EdgeSelArgs a;
     a.v = view(c);
-    a.contained = c->d_contained;
+    a.contained = c->d_cbits;
     a.hits = c->d_hits;
     a.row_start = c->d_row_start;
     a.row_cnt = c->d_row_cnt;
@@ -703,7 +707,7 @@ static int select_edges(disco_ctx *c)
         a.big_cap = c->big_cap;
     }
     ph_begin(c, DISCO_PH_SELECT);
-    if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, a);
+    if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
@@ -726,6 +730,7 @@ static int select_edges(disco_ctx *c)
     }
     c->h_ctr[CTR_ES_BIG] = n_big;
     c->dropped = c->h_ctr[CTR_DROPPED];
+    if (getenv("DISCO_VERBOSE")) fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n", (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
     /* CSR in node order; nodes outside the query range have empty rows */
     if (!c->d_adj_start) CHK(dev_alloc(c, &c->d_adj_start, c->n + 1));
     u64 total = 0;

@@ -20,7 +20,7 @@
 #define PROBE_SEGP (PROBE_SEGW + 64) /* m-mer positions a segment covers: windows + (k - m) <= 63              */
 #define PROBE_ACAP 32     /* words of the query read's own row staged in LDS (reads up to 1024 bp)              */
 #define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
-#define ES_CAP 512        /* edge_select: hits of one read sorted in LDS                                        */
+#define ES_CAP 256        /* edge_select: hits of one read sorted in LDS (longer rows: global-scratch variant)  */
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
 #define SCAN_BLOCK 256
@@ -43,6 +43,7 @@ enum {
     CTR_MAX_ROW,
     CTR_TW_UP,
     CTR_TW_DOWN,
+    CTR_ES_SLOW, /* rows that took the sequential accept scan */
     CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
     CTR_COUNT
 };
@@ -615,13 +616,17 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 /* ================================================================================================================
  * containment finalisation — contained flag per read from the reduced keys (BG/OverlapGraph.cpp:495-503 count)
  * ============================================================================================================== */
-__global__ void contain_flags_kernel(const u64 *__restrict__ best, u64 n, u8 *__restrict__ contained, u64 *ctr)
+__global__ void contain_flags_kernel(const u64 *__restrict__ best, u64 n, u8 *__restrict__ contained, u64 *__restrict__ cbits, u64 *ctr)
 {
+    /* cbits: one bit per read (n/8 bytes: 6 MB at 50 M reads, L2-resident for the gathers of edge selection) */
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 0;
-    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
-        u8 f = best[i] != DISCO_NOKEY;
-        contained[i] = f;
+    const u64 n64 = (n + 63) & ~63ull;
+    for (; i < n64; i += (u64)gridDim.x * blockDim.x) {
+        u8 f = (i < n) && best[i] != DISCO_NOKEY;
+        if (i < n) contained[i] = f;
+        const u64 mk = __ballot(f);
+        if ((threadIdx.x & 63) == 0) cbits[i >> 6] = mk;
         c += f;
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
@@ -648,9 +653,14 @@ __global__ void contain_rows_kernel(const u64 *__restrict__ best, const u8 *__re
  * Finds overwrite the head of the read's hit row in place.
  * h / t are two work arrays of cap entries: LDS for ordinary rows, global scratch for the big-row variant.
  * ============================================================================================================== */
+__device__ __forceinline__ bool is_contained(const u64 *__restrict__ cbits, u64 id)
+{
+    return (((const u32 *)cbits)[id >> 5] >> (id & 31)) & 1u;
+}
+
 struct EdgeSelArgs {
     DiscoView v;
-    const u8 *contained;
+    const u64 *contained; /* bitmap */
     u64 *hits;
     const u64 *row_start;
     const u32 *row_cnt;
@@ -686,7 +696,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         bool keep = false;
         if (i < c) {
             hit = row[i];
-            keep = (hit != ~0ull) && !a.contained[HIT_ID(hit)];
+            keep = (hit != ~0ull) && !is_contained(a.contained, HIT_ID(hit));
         }
         u64 mk = __ballot(keep);
         if (keep) h[m + __popcll(mk & lane_mask_lt())] = hit;
@@ -744,7 +754,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     u64 hit = ~0ull;
     if (lane < c) {
         hit = row[lane];
-        if (hit != ~0ull && a.contained[HIT_ID(hit)]) hit = ~0ull;
+        if (hit != ~0ull && is_contained(a.contained, HIT_ID(hit))) hit = ~0ull;
     }
     hit = wave_bitonic_sort(hit, lane);
     const bool valid = hit != ~0ull;
@@ -787,14 +797,14 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];
     const u32 lane = threadIdx.x;
-    u32 cap_sites = 0, dropped = 0;
+    u32 cap_sites = 0, dropped = 0, n_slow = 0;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
     u64 *t = BIG ? h + a.scratch_cap : s_t;
     for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
         const u32 c = a.row_cnt[A];
-        if (a.contained[A] || c == 0) { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
+        if (c == 0 || is_contained(a.contained, A)) { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
             if (lane == 0) a.deg[A] = 0;
             continue;
         }
@@ -808,8 +818,10 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             continue;
         }
         if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane, dropped)) continue;
+        n_slow++;
         edge_select_row(a, A, h, t, c, lane, cap_sites, dropped);
     }
+    if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
     if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
