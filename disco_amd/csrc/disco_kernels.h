@@ -1047,6 +1047,103 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
     __syncthreads();
 }
 
+/* nodes of at most 64 neighbours (virtually all of them): the node's list lives in registers (lane = slot), the rows of the
+ * two neighbours that are INPLAY for certain or almost certainly — the first of the list and the first on the other side of
+ * v — are fetched speculatively together with the hash build, and the next node's list is fetched while this one is
+ * processed. The sequential INPLAY/ELIMINATED logic is unchanged; a speculative row is simply not used if its neighbour
+ * turns out to be eliminated. */
+struct TrNodeRegs {
+    u64 vs;
+    u32 d;
+    u64 e; /* lane's entry (lane < d) */
+};
+
+__device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, (int)l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), (int)l);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs &nd, u64 *hkey, u8 *hstate, u32 lane)
+{
+    const u32 d = nd.d;
+    const u64 e = nd.e;
+    u32 hc = 64;
+    while (hc < 2 * d) hc <<= 1;
+    const u32 hmask = hc - 1;
+    for (u32 i = lane; i <= hmask; i += 64) {
+        hkey[i] = TR_EMPTY;
+        hstate[i] = 0;
+    }
+    /* speculative rows: slot 0 and the first slot on the other side of v (side = strand of v in the edge, bit 1) */
+    const u32 side0 = ADJ_ORI(readlane_u64(e, 0)) >> 1;
+    const u64 om = __ballot(lane < d && (ADJ_ORI(e) >> 1) != side0);
+    const u32 s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
+    const u64 u0 = ADJ_DST(readlane_u64(e, 0)), u2 = ADJ_DST(readlane_u64(e, s2));
+    const u64 st0 = a.adj_start[u0], en0 = a.adj_start[u0 + 1];
+    const u64 st2 = a.adj_start[u2], en2 = a.adj_start[u2 + 1];
+    const u64 p0 = (lane < en0 - st0) ? a.adj[st0 + lane] : 0ull;
+    const u64 p2 = (lane < en2 - st2) ? a.adj[st2 + lane] : 0ull;
+    __syncthreads();
+    u32 sent = 0;
+    if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
+        const u64 id = ADJ_DST(e);
+        u32 idx = (u32)disco_hash64(id) & hmask;
+        for (;;) {
+            u64 old = atomicCAS(&hkey[idx], TR_EMPTY, id);
+            if (old == TR_EMPTY || old == id) break;
+            idx = (idx + 1) & hmask;
+        }
+        sent = idx;
+    }
+    __syncthreads();
+    for (u32 i = 0; i < d; i++) { /* BG/OverlapGraph.cpp:693 list order */
+        const u32 si = (u32)__builtin_amdgcn_readlane((int)sent, (int)i);
+        if (hstate[si]) continue; /* :696 only INPLAY neighbours */
+        const u64 e1 = readlane_u64(e, i);
+        const u32 type1 = ADJ_ORI(e1);
+        u64 us;
+        u32 du;
+        u64 pre;
+        if (i == 0) {
+            us = st0;
+            du = (u32)(en0 - st0);
+            pre = p0;
+        } else if (i == s2) {
+            us = st2;
+            du = (u32)(en2 - st2);
+            pre = p2;
+        } else {
+            const u64 u = ADJ_DST(e1);
+            us = a.adj_start[u];
+            du = (u32)(a.adj_start[u + 1] - us);
+            pre = (lane < du) ? a.adj[us + lane] : 0ull;
+        }
+        const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
+        for (u32 t = lane; t < du; t += 64) {        /* :698 */
+            const u64 e2 = (t < 64) ? pre : a.adj[us + t];
+            const u32 type2 = ADJ_ORI(e2);
+            const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
+            if (!ok) continue;
+            const u64 w = ADJ_DST(e2);
+            u32 idx = (u32)disco_hash64(w) & hmask;
+            for (;;) {
+                const u64 kk = hkey[idx];
+                if (kk == TR_EMPTY) break;
+                if (kk == w) {
+                    hstate[idx] = 1; /* ELIMINATED */
+                    break;
+                }
+                idx = (idx + 1) & hmask;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < d) a.flag[nd.vs + lane] = hstate[sent];
+    __syncthreads();
+}
+
 template <bool BIG>
 __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
 {
@@ -1064,26 +1161,44 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
         sent = (u32 *)(base + a.hcap * 8);
         hstate = base + a.hcap * 8 + a.hcap * 4;
     }
+    auto load_node = [&](u64 it) {
+        TrNodeRegs r;
+        r.vs = 0;
+        r.d = 0;
+        r.e = 0;
+        if (it < n_items) {
+            const u64 v = a.v.q_lo + it;
+            r.vs = a.adj_start[v];
+            r.d = (u32)(a.adj_start[v + 1] - r.vs);
+            if (lane < r.d) r.e = a.adj[r.vs + lane];
+        }
+        return r;
+    };
+    TrNodeRegs cur;
+    if (!BIG) cur = load_node(blockIdx.x);
     for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const u64 v = BIG ? a.big_list[it] : a.v.q_lo + it;
-        const u32 d = (u32)(a.adj_start[v + 1] - a.adj_start[v]);
-        if (d == 0) continue;
-        if (!BIG && d > TR_CAP) {
-            if (lane == 0) {
-                u32 idx = atomicAdd(a.n_big, 1u);
-                if (idx < a.big_cap) a.big_list[idx] = v;
-                else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+        if (!BIG) {
+            const TrNodeRegs nxt = load_node(it + gridDim.x); /* in flight while `cur` is processed */
+            const u64 v = a.v.q_lo + it;
+            if (cur.d != 0) {
+                if (cur.d <= 64) tr_node_small(a, cur, s_hkey, s_state, lane);
+                else if (cur.d <= TR_CAP) {
+                    u32 hc = 64;
+                    while (hc < 2 * cur.d) hc <<= 1;
+                    tr_node(a, v, cur.d, hkey, hstate, sent, hc - 1, lane);
+                } else if (lane == 0) {
+                    u32 idx = atomicAdd(a.n_big, 1u);
+                    if (idx < a.big_cap) a.big_list[idx] = v;
+                    else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                }
             }
-            continue;
+            cur = nxt;
+        } else {
+            const u64 v = a.big_list[it];
+            const u32 d = (u32)(a.adj_start[v + 1] - a.adj_start[v]);
+            if (d == 0) continue;
+            tr_node(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
         }
-        u32 hmask;
-        if (BIG) hmask = (u32)a.hcap - 1;
-        else {
-            u32 hc = 64;
-            while (hc < 2 * d) hc <<= 1;
-            hmask = hc - 1;
-        }
-        tr_node(a, v, d, hkey, hstate, sent, hmask, lane);
     }
 }
 
