@@ -78,3 +78,28 @@ def test_twin_check_shortcut_is_sound(monkeypatch):
         e2, r2, c2 = run_hip_reads(reads, mo)
         assert np.array_equal(e1, e2) and np.array_equal(r1, r2)
         assert c1["asymmetric_pairs"] == c2["asymmetric_pairs"] and c1["e_pre"] == c2["e_pre"]
+
+
+def test_long_reads_generic_stride_paths():
+    """reads of 1.2-3 kbp: rows wider than the LDS staging limits (probe_kernel<.,false>, verify_kernel<false>) and more than one
+    256-window probe segment per read"""
+    reads = _gen(31, 400, 1200, 12.0, 3000)
+    c = assert_parity(reads, 40, "long")
+    assert c["e_pre"] > 0
+
+
+def test_high_multiplicity_rows_take_the_big_paths():
+    """deep coverage of a 50-copy repeat: hundreds of candidates per read -> rows beyond the LDS capacities
+    (probe big-row pass, edge-selection global-scratch pass, big-node transitive marking)"""
+    rng = np.random.default_rng(5)
+    rep = "".join(rng.choice(list("ACGT"), 260))
+    genome = "".join("".join(rng.choice(list("ACGT"), 90)) + rep for _ in range(50))
+    reads = []
+    comp = str.maketrans("ACGT", "TGCA")
+    for _ in range(9000):
+        L = int(rng.integers(110, 160))
+        p = int(rng.integers(0, len(genome) - L))
+        s = genome[p:p + L]
+        reads.append(s.translate(comp)[::-1] if rng.random() < 0.5 else s)
+    c = assert_parity(reads, 40, "multiplicity")
+    assert c["big_rows"] > 0
