@@ -116,6 +116,23 @@ __device__ __forceinline__ u64 wave_bitonic_sort(u64 x, u32 lane)
     return x;
 }
 
+/* ascending bitonic sort of one u32 per lane across the wavefront */
+__device__ __forceinline__ u32 wave_bitonic_sort32(u32 x, u32 lane)
+{
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            const u32 y = __shfl_xor(x, j2);
+            const bool up = (lane & k2) == 0;
+            const bool lower = (lane & j2) == 0;
+            const bool take_min = (up == lower);
+            x = take_min ? (x < y ? x : y) : (x < y ? y : x);
+        }
+    }
+    return x;
+}
+
 /* reverse the order of the 32 2-bit groups of x */
 __device__ __forceinline__ u64 rev2_64(u64 x)
 {

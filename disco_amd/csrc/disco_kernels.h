@@ -791,11 +791,51 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     return true;
 }
 
+/* the common case of the common case: no destination occurs twice and no k-mer has more than max_per_kmer hits, so every
+ * verified hit to a non-contained read becomes an edge and the consumption order is irrelevant: one 32-bit sort of the
+ * destinations proves the first condition, an LDS histogram of the windows the second, and only the sort by offset remains.
+ * Anything else falls through to edge_select_row_fast (exact for every row of at most 64 hits). */
+__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 *s_jcnt)
+{
+    u64 *row = a.hits + a.row_start[A];
+    const u32 LA = a.v.len[A];
+    u64 hit = ~0ull;
+    if (lane < c) {
+        hit = row[lane];
+        if (hit != ~0ull && is_contained(a.contained, HIT_ID(hit))) hit = ~0ull;
+    }
+    const bool valid = hit != ~0ull;
+    const u32 j = HIT_J(hit);
+    s_jcnt[lane] = 0;
+    s_jcnt[lane + 64] = 0;
+    const u32 bkey = valid ? (u32)HIT_ID(hit) : (0x80000000u | lane);
+    const u32 sb = wave_bitonic_sort32(bkey, lane);
+    const u32 nb = __shfl_down(sb, 1);
+    const bool dup = (lane < 63) && (sb == nb);
+    __syncthreads();
+    if (valid) atomicAdd(&s_jcnt[j & 127u], 1u);
+    __syncthreads();
+    const bool capped = valid && s_jcnt[j & 127u] > a.max_per_kmer;
+    if (__any(dup || capped)) return false;
+    u64 ent = ~0ull;
+    if (valid) {
+        u32 orient, off;
+        disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
+        ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit));
+    }
+    ent = wave_bitonic_sort(ent, lane);
+    const u32 nacc = __popcll(__ballot(valid));
+    if (lane < nacc) row[lane] = ent;
+    if (lane == 0) a.deg[A] = nacc;
+    return true;
+}
+
 template <bool BIG>
 __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
 {
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];
+    __shared__ u32 s_jcnt[128];
     const u32 lane = threadIdx.x;
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
@@ -817,6 +857,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             }
             continue;
         }
+        if (!BIG && c <= 64 && edge_select_row_all(a, A, c, lane, s_jcnt)) continue;
         if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane, dropped)) continue;
         n_slow++;
         edge_select_row(a, A, h, t, c, lane, cap_sites, dropped);
