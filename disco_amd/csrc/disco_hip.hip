@@ -84,11 +84,12 @@ struct disco_ctx {
     u64 n_contained = 0;
 
     /* edges */
-    u32 *d_deg = nullptr;
-    u64 *d_adj_start = nullptr;
-    u64 *d_adj = nullptr;
-    u64 adj_total = 0; /* slots in the CSR the context currently holds */
-    u64 adj_cap = 0, flag_cap = 0, out_cap = 0, kept_cap = 0, bkt_cap = 0, ent_cap = 0; /* buffers are kept across passes */
+    u64 *d_adj_ref = nullptr; /* [n] position | degree << 40 */
+    u64 *d_adj = nullptr;     /* entries: the hit buffer itself (single GPU) or an owned node-ordered array (imported / merged) */
+    bool adj_owned = false;
+    u64 adj_total = 0; /* directed edges the context currently addresses */
+    u64 adj_cap = 0, flag_cap = 0, out_cap = 0, valid_cap = 0, bkt_cap = 0, ent_cap = 0; /* buffers are kept across passes */
+    bool flags_pending = false; /* sharded flow: gathered flag bytes wait to be OR-ed into the entries */
     bool adj_imported = false;
     u32 *d_extra_cnt = nullptr;
     u64 *d_extra_node = nullptr, *d_extra_key = nullptr;
@@ -100,9 +101,10 @@ struct disco_ctx {
 
     /* reduction */
     u8 *d_flag = nullptr;
-    u32 *d_kept = nullptr;
+    u8 *d_out_valid = nullptr;
     u64 *d_out_pos = nullptr;
     u64 *d_out_src = nullptr, *d_out_ent = nullptr;
+    u64 out_used = 0; /* chunk slots written by the emission (survivors + ~0 tails) */
     u64 n_out = 0;
 
     /* live kernel timing (HIP events on the stream the kernels are launched on) */
@@ -274,20 +276,22 @@ static void free_graph_state(disco_ctx *c)
     c->big_cap = 0;
     dev_free(c, &c->d_contained, c->n);
     dev_free(c, &c->d_cbits, c->n / 64 + 1);
-    dev_free(c, &c->d_deg, c->n);
-    dev_free(c, &c->d_adj_start, c->n + 1);
-    dev_free(c, &c->d_adj, c->adj_cap);
+    dev_free(c, &c->d_adj_ref, c->n);
+    if (c->adj_owned) dev_free(c, &c->d_adj, c->adj_cap);
+    c->d_adj = nullptr;
+    c->adj_owned = false;
     dev_free(c, &c->d_extra_cnt, c->n);
     dev_free(c, &c->d_extra_node, c->extra_cap);
     dev_free(c, &c->d_extra_key, c->extra_cap);
     c->extra_cap = 0;
     dev_free(c, &c->d_flag, c->flag_cap);
     c->adj_total = c->adj_cap = c->flag_cap = 0;
-    dev_free(c, &c->d_kept, c->kept_cap);
-    dev_free(c, &c->d_out_pos, c->kept_cap + 1);
+    dev_free(c, &c->d_out_valid, c->valid_cap);
+    dev_free(c, &c->d_out_pos, c->valid_cap + 1);
     dev_free(c, &c->d_out_src, c->out_cap);
     dev_free(c, &c->d_out_ent, c->out_cap);
-    c->n_out = c->out_cap = c->kept_cap = 0;
+    c->n_out = c->out_cap = c->valid_cap = c->out_used = 0;
+    c->flags_pending = false;
     c->adj_imported = false;
     c->T = 0;
 }
@@ -679,12 +683,13 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
 static int select_edges(disco_ctx *c)
 {
     const u64 nq = c->q_hi - c->q_lo;
-    if (!c->d_deg) CHK(dev_alloc(c, &c->d_deg, c->n));
-    HIPCHK(c, hipMemsetAsync(c->d_deg, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+    if (!c->d_adj_ref) CHK(dev_alloc(c, &c->d_adj_ref, c->n));
+    HIPCHK(c, hipMemsetAsync(c->d_adj_ref, 0, std::max<u64>(c->n, 1) * sizeof(u64), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_CAP_SITES));
     CHK(zero_counter(c, CTR_DROPPED));
     CHK(zero_counter(c, CTR_ES_SLOW));
+    CHK(zero_counter(c, CTR_ADJ_TOTAL));
     CHK(zero_counter(c, CTR_OVERFLOW));
     EdgeSelArgs a;
     a.v = view(c);
@@ -692,7 +697,7 @@ static int select_edges(disco_ctx *c)
     a.hits = c->d_hits;
     a.row_start = c->d_row_start;
     a.row_cnt = c->d_row_cnt;
-    a.deg = c->d_deg;
+    a.ref = c->d_adj_ref;
     a.max_per_kmer = c->prm.max_edges_per_kmer;
     a.big_list = c->d_big_list;
     a.n_big = c->d_n_big;
@@ -713,6 +718,7 @@ static int select_edges(disco_ctx *c)
     u32 n_big = 0;
     HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     CHK(read_counters(c));
+    ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "edge selection: big-row list overflow (%u rows)", n_big);
     if (n_big) {
         int g2 = (int)std::min<u64>(n_big, 64);
@@ -728,30 +734,18 @@ static int select_edges(disco_ctx *c)
         if (e != hipSuccess) return fail(c, DISCO_E_HIP, "edge_select_kernel<true>: %s", hipGetErrorString(e));
         CHK(rc);
     }
-    c->h_ctr[CTR_ES_BIG] = n_big;
     c->dropped = c->h_ctr[CTR_DROPPED];
-    if (getenv("DISCO_VERBOSE")) fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n", (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
-    /* CSR in node order; nodes outside the query range have empty rows */
-    if (!c->d_adj_start) CHK(dev_alloc(c, &c->d_adj_start, c->n + 1));
-    u64 total = 0;
-    ph_begin(c, DISCO_PH_CSR);
-    CHK((scan_exclusive<u32, u64>(c, c->d_deg, c->n, c->d_adj_start, true, &total)));
-    c->adj_total = total;
-    CHK(ensure_cap(c, &c->d_adj, &c->adj_cap, total));
-    if (nq) hipLaunchKernelGGL(csr_copy_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_hits, c->d_row_start, c->d_deg, c->q_lo, c->q_hi, c->d_adj_start, 0ull, c->d_adj);
-    ph_end(c, DISCO_PH_CSR);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    ph_collect(c);
-    /* the raw hits are dead now; the buffer is kept for the next pass unless HBM is getting tight */
-    {
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < tot / 8) {
-            dev_free(c, &c->d_hits, c->hits_cap);
-            c->hits_cap = 0;
-        }
-    }
+    if (getenv("DISCO_VERBOSE"))
+        fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
+                (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
+    /* the finds stay where they are: the hit buffer IS the adjacency array of the local rows */
+    if (c->adj_owned) dev_free(c, &c->d_adj, c->adj_cap);
+    c->adj_owned = false;
+    c->adj_cap = 0;
+    c->d_adj = c->d_hits;
+    c->adj_total = c->h_ctr[CTR_ADJ_TOTAL];
     c->adj_imported = false;
+    c->ph_ms[DISCO_PH_CSR] = 0;
     c->phase = 5;
     return DISCO_OK;
 }
@@ -771,20 +765,20 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
         c->ph_ms[DISCO_PH_TWIN] = 0;
         return DISCO_OK;
     }
+    TwinArgs a;
+    a.v = view(c);
+    a.ref = c->d_adj_ref;
+    a.adj = c->d_adj;
+    a.lo = lo;
+    a.hi = hi;
+    a.extra_cnt = c->d_extra_cnt;
+    a.n_extra = c->d_n_extra;
     {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
         CHK(zero_counter(c, CTR_ASYM));
         CHK(zero_counter(c, CTR_TW_UP));
         CHK(zero_counter(c, CTR_TW_DOWN));
-        TwinArgs a;
-        a.v = view(c);
-        a.adj_start = c->d_adj_start;
-        a.adj = c->d_adj;
-        a.lo = lo;
-        a.hi = hi;
-        a.extra_cnt = c->d_extra_cnt;
         a.extra_node = nullptr;
         a.extra_key = nullptr;
-        a.n_extra = c->d_n_extra;
         a.extra_cap = 0;
         a.up_only = 1;
         ph_begin(c, DISCO_PH_TWIN);
@@ -812,16 +806,8 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
         HIPCHK(c, hipMemsetAsync(c->d_n_extra, 0, sizeof(u32), c->stream));
         CHK(zero_counter(c, CTR_ASYM));
         CHK(zero_counter(c, CTR_OVERFLOW));
-        TwinArgs a;
-        a.v = view(c);
-        a.adj_start = c->d_adj_start;
-        a.adj = c->d_adj;
-        a.lo = lo;
-        a.hi = hi;
-        a.extra_cnt = c->d_extra_cnt;
         a.extra_node = c->d_extra_node;
         a.extra_key = c->d_extra_key;
-        a.n_extra = c->d_n_extra;
         a.extra_cap = c->extra_cap;
         a.up_only = 0;
         ph_begin(c, DISCO_PH_TWIN);
@@ -842,7 +828,7 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
     return fail(c, DISCO_E_CAPACITY, "twin check: extras list could not be sized");
 }
 
-/* merge the collected extras into the CSR (rare: only when pairs were found from one side only) */
+/* merge the collected extras into a node-ordered CSR (rare: only when pairs were found from one side only) */
 static int merge_extras(disco_ctx *c)
 {
     if (c->n_extra == 0) return DISCO_OK;
@@ -851,13 +837,13 @@ static int merge_extras(disco_ctx *c)
     CHK(dev_alloc(c, &new_deg, c->n));
     CHK(dev_alloc(c, &fill, c->n));
     CHK(dev_alloc(c, &new_start, c->n + 1));
-    hipLaunchKernelGGL(add_u32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_start, c->d_extra_cnt, c->n, new_deg);
+    hipLaunchKernelGGL(merge_deg_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, new_deg);
     u64 total = 0;
     CHK((scan_exclusive<u32, u64>(c, new_deg, c->n, new_start, true, &total)));
     CHK(dev_alloc(c, &new_adj, total));
     HIPCHK(c, hipMemsetAsync(fill, 0, c->n * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(merge_copy_kernel, dim3(wave_grid(c, c->n, 16)), dim3(64), 0, c->stream, c->d_adj_start, c->d_adj, new_start, new_adj, c->n);
-    hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_start, new_start, fill, new_adj);
+    hipLaunchKernelGGL(merge_copy_kernel, dim3(wave_grid(c, c->n, 16)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, new_start, new_adj, c->n);
+    hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_ref, new_start, fill, new_adj);
     /* row scratch: the longest merged row */
     u64 maxdeg = 0;
     {
@@ -869,17 +855,18 @@ static int merge_extras(disco_ctx *c)
     int g = (int)std::min<u64>(c->n, 256);
     CHK(dev_alloc(c, &scratch, (u64)g * (maxdeg + 1)));
     hipLaunchKernelGGL(merge_sort_kernel, dim3(g), dim3(64), 0, c->stream, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);
+    hipLaunchKernelGGL(ref_from_start_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, new_start, new_deg, c->n, c->d_adj_ref);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dev_free(c, &scratch, (u64)g * (maxdeg + 1));
     dev_free(c, &new_deg, c->n);
     dev_free(c, &fill, c->n);
-    dev_free(c, &c->d_adj, c->adj_cap);
-    dev_free(c, &c->d_adj_start, c->n + 1);
+    dev_free(c, &new_start, c->n + 1);
+    if (c->adj_owned) dev_free(c, &c->d_adj, c->adj_cap);
     c->d_adj = new_adj;
-    c->d_adj_start = new_start;
-    c->adj_total = total;
+    c->adj_owned = true;
     c->adj_cap = std::max<u64>(total, 1);
+    c->adj_total = total;
     c->n_extra = 0;
     return DISCO_OK;
 }
@@ -936,10 +923,24 @@ int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
     if (c->phase < 5 || c->adj_imported) return fail(c, DISCO_E_STATE, "disco_export_adjacency: needs the locally selected edges");
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
-    if (nq) hipLaunchKernelGGL(deg_from_start_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_start, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
+    ph_begin(c, DISCO_PH_CSR);
+    if (nq) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_ref, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
     HIPCHK(c, hipGetLastError());
-    if (c->adj_total && d_entries_u64) HIPCHK(c, hipMemcpyAsync(d_entries_u64, c->d_adj, c->adj_total * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (nq && c->adj_total && d_entries_u64) { /* compact the local rows into node order */
+        u64 *start = nullptr;
+        CHK(dev_alloc(c, &start, nq + 1));
+        u64 total = 0;
+        int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32, nq, start, true, &total);
+        if (rc == DISCO_OK && total != c->adj_total) rc = fail(c, DISCO_E_STATE, "disco_export_adjacency: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
+        if (rc == DISCO_OK) hipLaunchKernelGGL(rows_gather_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, c->q_lo, c->q_hi, start, (u64 *)d_entries_u64);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        dev_free(c, &start, nq + 1);
+        CHK(rc);
+        if (e != hipSuccess) return fail(c, DISCO_E_HIP, "disco_export_adjacency: %s", hipGetErrorString(e));
+    }
+    ph_end(c, DISCO_PH_CSR);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    ph_collect(c);
     return DISCO_OK;
 }
 
@@ -948,13 +949,28 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     if (!c || !d_deg_u32_all) return DISCO_E_ARG;
     if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_import_adjacency: select edges first");
     HIPCHK(c, hipSetDevice(c->device));
+    u64 *start = nullptr;
+    CHK(dev_alloc(c, &start, c->n + 1));
     u64 total = 0;
-    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, c->d_adj_start, true, &total)));
-    if (total != n_entries_all) return fail(c, DISCO_E_ARG, "disco_import_adjacency: degrees sum to %llu but %llu entries were passed", (unsigned long long)total, (unsigned long long)n_entries_all);
-    c->adj_total = total;
+    int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, start, true, &total);
+    if (rc == DISCO_OK && total != n_entries_all)
+        rc = fail(c, DISCO_E_ARG, "disco_import_adjacency: degrees sum to %llu but %llu entries were passed", (unsigned long long)total, (unsigned long long)n_entries_all);
+    if (rc != DISCO_OK) {
+        dev_free(c, &start, c->n + 1);
+        return rc;
+    }
+    if (!c->adj_owned) {
+        c->d_adj = nullptr;
+        c->adj_cap = 0;
+    }
+    c->adj_owned = true;
     CHK(ensure_cap(c, &c->d_adj, &c->adj_cap, total));
+    c->adj_total = total;
     if (total) HIPCHK(c, hipMemcpyAsync(c->d_adj, d_entries_u64_all, total * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (c->n) hipLaunchKernelGGL(ref_from_start_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, start, (const u32 *)d_deg_u32_all, c->n, c->d_adj_ref);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, &start, c->n + 1);
     c->adj_imported = true;
     c->phase = 5;
     return DISCO_OK;
@@ -967,8 +983,6 @@ int disco_transitive_mark(disco_ctx *c)
     if (c->phase < 6) return fail(c, DISCO_E_STATE, "disco_transitive_mark: build edges first");
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
-    CHK(ensure_cap(c, &c->d_flag, &c->flag_cap, c->adj_total));
-    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_total, 1), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
     if (c->big_cap == 0) {
@@ -978,9 +992,8 @@ int disco_transitive_mark(disco_ctx *c)
     }
     TrArgs a;
     a.v = view(c);
-    a.adj_start = c->d_adj_start;
+    a.ref = c->d_adj_ref;
     a.adj = c->d_adj;
-    a.flag = c->d_flag;
     a.big_list = c->d_big_list;
     a.n_big = c->d_n_big;
     a.big_cap = c->big_cap;
@@ -1002,9 +1015,9 @@ int disco_transitive_mark(disco_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         u64 maxd = 0;
         for (u64 v : big) {
-            u64 se[2];
-            HIPCHK(c, hipMemcpy(se, c->d_adj_start + v, 16, hipMemcpyDeviceToHost));
-            maxd = std::max(maxd, se[1] - se[0]);
+            u64 r = 0;
+            HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + v, 8, hipMemcpyDeviceToHost));
+            maxd = std::max<u64>(maxd, REF_DEG(r));
         }
         u64 hcap = 64;
         while (hcap < 2 * maxd) hcap <<= 1;
@@ -1020,21 +1033,38 @@ int disco_transitive_mark(disco_ctx *c)
         dev_free(c, &scratch, (u64)g2 * per);
         if (e != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel<true>: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     }
-    c->h_ctr[CTR_TR_BIG] = n_big;
+    c->flags_pending = false;
     c->phase = 7;
     return DISCO_OK;
 }
 
-/* flags of the local nodes' slots live at d_flags[slot_lo .. slot_hi) of a u8 array with `total` slots; ranks all-gather
- * those byte ranges between disco_transitive_mark and disco_emit_edges */
+/* Sharded flow only (adjacency imported): the transitive flags of this rank's slots [slot_lo, slot_hi) of the gathered CSR
+ * are extracted into a byte array of `total` slots; ranks all-gather those byte ranges in place, then disco_emit_edges
+ * ORs the complete array back into the entries. */
 int disco_tr_flags(disco_ctx *c, void **d_flags, uint64_t *slot_lo, uint64_t *slot_hi, uint64_t *total)
 {
     if (!c || !d_flags || !slot_lo || !slot_hi || !total) return DISCO_E_ARG;
     if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_tr_flags: run disco_transitive_mark first");
+    if (!c->adj_imported) return fail(c, DISCO_E_STATE, "disco_tr_flags: only meaningful after disco_import_adjacency (the flags of a single-GPU run live in the entries)");
     HIPCHK(c, hipSetDevice(c->device));
-    u64 lo = 0, hi = 0;
-    HIPCHK(c, hipMemcpy(&lo, c->d_adj_start + c->q_lo, 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&hi, c->d_adj_start + c->q_hi, 8, hipMemcpyDeviceToHost));
+    u64 lo = c->adj_total, hi = c->adj_total, r = 0;
+    if (c->q_lo < c->n) {
+        HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + c->q_lo, 8, hipMemcpyDeviceToHost));
+        lo = REF_POS(r);
+    }
+    if (c->q_hi < c->n) {
+        HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + c->q_hi, 8, hipMemcpyDeviceToHost));
+        hi = REF_POS(r);
+    }
+    if (c->q_lo >= c->q_hi) lo = hi;
+    CHK(ensure_cap(c, &c->d_flag, &c->flag_cap, c->adj_total));
+    if (!c->flags_pending) {
+        HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_total, 1), c->stream));
+        if (hi > lo) hipLaunchKernelGGL(flags_extract_kernel, dim3(flat_grid(c, hi - lo)), dim3(256), 0, c->stream, c->d_adj, lo, hi, c->d_flag);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->flags_pending = true;
+    }
     *d_flags = c->d_flag;
     *slot_lo = lo;
     *slot_hi = hi;
@@ -1048,41 +1078,61 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_emit_edges: run disco_transitive_mark first");
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
-    if (!c->d_kept || nq > c->kept_cap) {
-        dev_free(c, &c->d_kept, c->kept_cap);
-        dev_free(c, &c->d_out_pos, c->kept_cap + 1);
-        CHK(dev_alloc(c, &c->d_kept, nq));
-        CHK(dev_alloc(c, &c->d_out_pos, nq + 1));
-        c->kept_cap = nq;
-    }
-    EmitArgs a;
-    a.v = view(c);
-    a.adj_start = c->d_adj_start;
-    a.adj = c->d_adj;
-    a.flag = c->d_flag;
-    a.kept = c->d_kept;
-    a.out_pos = c->d_out_pos;
-    a.out_src = nullptr;
-    a.out_ent = nullptr;
     ph_begin(c, DISCO_PH_EMIT);
-    if (nq) hipLaunchKernelGGL(emit_kernel<false>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
-    u64 total = 0;
-    CHK((scan_exclusive<u32, u64>(c, c->d_kept, nq, c->d_out_pos, true, &total)));
-    c->n_out = total;
-    if (!c->d_out_src || total > c->out_cap) {
-        dev_free(c, &c->d_out_src, c->out_cap);
-        dev_free(c, &c->d_out_ent, c->out_cap);
-        CHK(dev_alloc(c, &c->d_out_src, total));
-        CHK(dev_alloc(c, &c->d_out_ent, total));
-        c->out_cap = std::max<u64>(total, 1);
+    if (c->flags_pending) { /* gathered flags of all ranks -> entries */
+        if (c->adj_total) hipLaunchKernelGGL(flags_apply_kernel, dim3(flat_grid(c, c->adj_total)), dim3(256), 0, c->stream, c->d_adj, c->adj_total, c->d_flag);
+        c->flags_pending = false;
     }
-    a.out_src = c->d_out_src;
-    a.out_ent = c->d_out_ent;
-    if (nq) hipLaunchKernelGGL(emit_kernel<true>, dim3(flat_grid(c, nq * 64)), dim3(256), 0, c->stream, a);
+    const int grid = flat_grid(c, nq * 64);
+    const u64 nwaves = (u64)grid * 4;
+    u64 want = std::max<u64>(2 * nq, 1024) + nwaves * EMIT_CHUNK;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (!c->d_out_src || want > c->out_cap) {
+            dev_free(c, &c->d_out_src, c->out_cap);
+            dev_free(c, &c->d_out_ent, c->out_cap);
+            c->out_cap = 0;
+            CHK(dev_alloc(c, &c->d_out_src, want));
+            CHK(dev_alloc(c, &c->d_out_ent, want));
+            c->out_cap = want;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
+        EmitArgs a;
+        a.v = view(c);
+        a.ref = c->d_adj_ref;
+        a.adj = c->d_adj;
+        a.out_src = c->d_out_src;
+        a.out_ent = c->d_out_ent;
+        a.out_cap = c->out_cap;
+        a.bump = c->d_bump;
+        if (nq) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        u64 used = 0;
+        HIPCHK(c, hipMemcpyAsync(&used, c->d_bump, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (used <= c->out_cap) {
+            c->out_used = used;
+            break;
+        }
+        want = used + used / 8 + nwaves * EMIT_CHUNK;
+        if (attempt == 5) return fail(c, DISCO_E_CAPACITY, "disco_emit_edges: output buffer could not be sized");
+    }
+    /* survivors = chunk slots that are not the ~0 tail marker: count them (the compaction happens at fetch time) */
+    u64 total = 0;
+    if (c->out_used) {
+        if (!c->d_out_valid || c->out_used > c->valid_cap) {
+            dev_free(c, &c->d_out_valid, c->valid_cap);
+            dev_free(c, &c->d_out_pos, c->valid_cap + 1);
+            CHK(dev_alloc(c, &c->d_out_valid, c->out_cap));
+            CHK(dev_alloc(c, &c->d_out_pos, c->out_cap + 1));
+            c->valid_cap = c->out_cap;
+        }
+        hipLaunchKernelGGL(emit_valid_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->out_used, c->d_out_valid);
+        CHK((scan_exclusive<u8, u64>(c, c->d_out_valid, c->out_used, c->d_out_pos, true, &total)));
+    }
     ph_end(c, DISCO_PH_EMIT);
-    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ph_collect(c);
+    c->n_out = total;
     if (n_out) *n_out = total;
     c->phase = 8;
     return DISCO_OK;
@@ -1174,10 +1224,18 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edges: need room for %llu edges", (unsigned long long)ne);
     if (ne == 0) return 0;
     CHK(ensure_host_len(c));
+    /* drop the unused chunk tails of the emission, then copy out */
+    u64 *csrc = nullptr, *cent = nullptr;
+    CHK(dev_alloc(c, &csrc, ne));
+    CHK(dev_alloc(c, &cent, ne));
+    hipLaunchKernelGGL(emit_compact_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos, c->out_used, csrc, cent);
     std::vector<u64> hs(ne), he(ne);
-    HIPCHK(c, hipMemcpyAsync(hs.data(), c->d_out_src, ne * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(he.data(), c->d_out_ent, ne * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e1 = hipMemcpyAsync(hs.data(), csrc, ne * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipMemcpyAsync(he.data(), cent, ne * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    dev_free(c, &csrc, ne);
+    dev_free(c, &cent, ne);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edges: copy failed");
     for (u64 i = 0; i < ne; i++) {
         disco_edge &e = out[i];
         e.src = hs[i];

@@ -26,6 +26,12 @@
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
 
+/* adjacency reference word of a node: position(40) | degree(24) << 40 ; transitive flag = bit 15 of an entry */
+#define REF_MAKE(pos, deg) (((u64)(deg) << 40) | (u64)(pos))
+#define REF_POS(r) ((r)&0xFFFFFFFFFFull)
+#define REF_DEG(r) ((u32)((r) >> 40))
+#define ADJ_FLAG (1ull << 15)
+
 /* global counters (u64 each) */
 enum {
     CTR_KMER_HITS = 0,
@@ -44,6 +50,7 @@ enum {
     CTR_TW_UP,
     CTR_TW_DOWN,
     CTR_ES_SLOW, /* rows that took the sequential accept scan */
+    CTR_ADJ_TOTAL, /* directed edges selected (sum of degrees of the query range) */
     CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
     CTR_COUNT
 };
@@ -664,7 +671,7 @@ struct EdgeSelArgs {
     u64 *hits;
     const u64 *row_start;
     const u32 *row_cnt;
-    u32 *deg;      /* [n] out                                   */
+    u64 *ref;      /* [n] out: row position | finds << 40          */
     u32 max_per_kmer;
     u64 *big_list; /* rows with more than ES_CAP hits (out/in)   */
     u32 *n_big;
@@ -684,7 +691,7 @@ __device__ __forceinline__ void wave_rank_sort(const u64 *src, u64 *dst, u32 m, 
     }
 }
 
-__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 &cap_sites, u32 &dropped)
+__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 &cap_sites, u32 &dropped, u64 &n_edges)
 {
     u64 *row = a.hits + a.row_start[A];
     const u32 LA = a.v.len[A];
@@ -739,7 +746,8 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     wave_rank_sort(h, t, nacc, lane);
     __syncthreads();
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
-    if (lane == 0) a.deg[A] = nacc;
+    if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
+    n_edges += nacc;
     dropped += m - nacc;
     __syncthreads();
 }
@@ -747,7 +755,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
 /* rows of at most 64 hits entirely in registers: bitonic sort into consumption order, first occurrence of every
  * destination = accepted (valid while no k-mer group has more than max_per_kmer acceptable hits, i.e. the cap never
  * blocks anything — otherwise return false and let the sequential scan decide), bitonic sort by offset, write back. */
-__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 &dropped)
+__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 &dropped, u64 &n_edges)
 {
     u64 *row = a.hits + a.row_start[A];
     const u32 LA = a.v.len[A];
@@ -786,7 +794,8 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     ent = wave_bitonic_sort(ent, lane);
     const u32 nacc = __popcll(nd);
     if (lane < nacc) row[lane] = ent;
-    if (lane == 0) a.deg[A] = nacc;
+    if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
+    n_edges += nacc;
     dropped += m - nacc; /* second and later hits to a destination already linked (BG/OverlapGraph.cpp:656) */
     return true;
 }
@@ -795,7 +804,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
  * verified hit to a non-contained read becomes an edge and the consumption order is irrelevant: one 32-bit sort of the
  * destinations proves the first condition, an LDS histogram of the windows the second, and only the sort by offset remains.
  * Anything else falls through to edge_select_row_fast (exact for every row of at most 64 hits). */
-__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 *s_jcnt)
+__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 *s_jcnt, u64 &n_edges)
 {
     u64 *row = a.hits + a.row_start[A];
     const u32 LA = a.v.len[A];
@@ -826,7 +835,8 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
     ent = wave_bitonic_sort(ent, lane);
     const u32 nacc = __popcll(__ballot(valid));
     if (lane < nacc) row[lane] = ent;
-    if (lane == 0) a.deg[A] = nacc;
+    if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
+    n_edges += nacc;
     return true;
 }
 
@@ -838,6 +848,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     __shared__ u32 s_jcnt[128];
     const u32 lane = threadIdx.x;
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
+    u64 n_edges = 0; /* wave-uniform */
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
     u64 *t = BIG ? h + a.scratch_cap : s_t;
@@ -845,7 +856,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
         const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
         const u32 c = a.row_cnt[A];
         if (c == 0 || is_contained(a.contained, A)) { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
-            if (lane == 0) a.deg[A] = 0;
+            if (lane == 0) a.ref[A] = 0;
             continue;
         }
         if (!BIG && c > ES_CAP) {
@@ -853,66 +864,86 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
                 u32 idx = atomicAdd(a.n_big, 1u);
                 if (idx < a.big_cap) a.big_list[idx] = A;
                 else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-                a.deg[A] = 0;
+                a.ref[A] = 0;
             }
             continue;
         }
-        if (!BIG && c <= 64 && edge_select_row_all(a, A, c, lane, s_jcnt)) continue;
-        if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane, dropped)) continue;
+        if (!BIG && c <= 64 && edge_select_row_all(a, A, c, lane, s_jcnt, n_edges)) continue;
+        if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane, dropped, n_edges)) continue;
         n_slow++;
-        edge_select_row(a, A, h, t, c, lane, cap_sites, dropped);
+        edge_select_row(a, A, h, t, c, lane, cap_sites, dropped, n_edges);
     }
+    if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
     if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
 
 /* ================================================================================================================
- * adjacency CSR: rows of the query shard copied out of the hit buffer into node order (adj_start = scan of deg)
+ * adjacency addressing. Every node has one reference word  ref[v] = position(40) | degree(24) << 40  into an entry
+ * array `adj`. On a single GPU `adj` IS the hit buffer: edge selection leaves each read's finds at the head of its hit row
+ * and nothing is copied. In the sharded flow the rows are compacted into node order for the exchange and the gathered
+ * array is addressed the same way. The transitive flag lives in bit 15 of the entry itself (free between len and orient),
+ * so the twin's flag arrives with the twin and no flag array is touched on a single GPU.
  * ============================================================================================================== */
-__global__ void __launch_bounds__(64) csr_copy_kernel(const u64 *__restrict__ hits, const u64 *__restrict__ row_start,
-                                                      const u32 *__restrict__ deg, u64 lo, u64 hi,
-                                                      const u64 *__restrict__ dst_start, u64 dst_base, u64 *__restrict__ dst)
+
+/* degree of the nodes [lo,hi) -> out[v-lo] */
+__global__ void deg_from_ref_kernel(const u64 *__restrict__ ref, u64 lo, u64 hi, u32 *__restrict__ out)
 {
-    /* dst_start is indexed by global node id; entries are written at dst[dst_start[v] - dst_base + i] */
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < hi; i += (u64)gridDim.x * blockDim.x) out[i - lo] = REF_DEG(ref[i]);
+}
+
+/* ref[v] = start[v] | deg << 40 from a node-ordered CSR (start = exclusive scan of deg) */
+__global__ void ref_from_start_kernel(const u64 *__restrict__ start, const u32 *__restrict__ deg, u64 n, u64 *__restrict__ ref)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) ref[i] = REF_MAKE(start[i], deg[i]);
+}
+
+/* rows of the nodes [lo,hi) copied into node order: dst[dst_start[v-lo] + i] (export for the all-gather; flags stripped) */
+__global__ void __launch_bounds__(64) rows_gather_kernel(const u64 *__restrict__ adj, const u64 *__restrict__ ref, u64 lo, u64 hi,
+                                                         const u64 *__restrict__ dst_start, u64 *__restrict__ dst)
+{
     for (u64 v = lo + blockIdx.x; v < hi; v += gridDim.x) {
-        u32 d = deg[v];
-        const u64 *src = hits + row_start[v];
-        u64 *o = dst + (dst_start[v] - dst_base);
-        for (u32 i = threadIdx.x; i < d; i += 64) o[i] = src[i];
+        const u64 r = ref[v];
+        const u32 d = REF_DEG(r);
+        const u64 *src = adj + REF_POS(r);
+        u64 *o = dst + dst_start[v - lo];
+        for (u32 i = threadIdx.x; i < d; i += 64) o[i] = src[i] & ~ADJ_FLAG;
     }
 }
 
-/* binary search of key in the sorted row r[0..d) ignoring nothing (rows hold plain ADJ entries); returns index or -1 */
+/* binary search of key in the sorted row r[0..d) (flag bit ignored); returns index or -1 */
 __device__ __forceinline__ int adj_find(const u64 *__restrict__ r, u32 d, u64 key)
 {
     u32 lo = 0, hi = d;
     while (lo < hi) {
         u32 mid = (lo + hi) >> 1;
-        u64 x = r[mid];
+        u64 x = r[mid] & ~ADJ_FLAG;
         if (x < key) lo = mid + 1;
         else hi = mid;
     }
-    return (lo < d && r[lo] == key) ? (int)lo : -1;
+    return (lo < d && (r[lo] & ~ADJ_FLAG) == key) ? (int)lo : -1;
 }
 
 /* ================================================================================================================
  * twin check — insertEdge puts the twin of every find into the other read's list (BG/OverlapGraph.cpp:614-626).
- * For every entry (u -> w) of the gathered adjacency with w in [lo,hi): its twin (w -> u) must be in adj[w];
- * if not, the pair was found from one side only (asymmetric) and the twin is appended to the extras of w.
+ * For every entry (u -> w) with w in [lo,hi): its twin (w -> u) must be in the list of w; if not, the pair was found from
+ * one side only (asymmetric) and the twin is appended to the extras of w.
  * ============================================================================================================== */
 struct TwinArgs {
     DiscoView v;
-    const u64 *adj_start; /* [n+1] */
+    const u64 *ref; /* [n] */
     const u64 *adj;
-    u64 lo, hi;           /* nodes whose lists are completed by this launch */
-    u32 *extra_cnt;       /* [n]                                            */
-    u64 *extra_node;      /* extras list                                    */
+    u64 lo, hi;     /* nodes whose lists are completed by this launch */
+    u32 *extra_cnt; /* [n]                                            */
+    u64 *extra_node;
     u64 *extra_key;
     u32 *n_extra;
     u32 extra_cap;
-    int up_only;          /* 1: search only finds with src < dst and count both kinds; equality of the two counts plus no
-                             missing twin proves symmetry (the up-finds inject into the down-finds); no extras recorded */
+    int up_only;    /* 1: search only finds with src < dst and count both kinds; equality of the two counts plus no
+                       missing twin proves symmetry (the up-finds inject into the down-finds); no extras recorded */
 };
 
 __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
@@ -922,12 +953,14 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     u32 asym = 0, n_up = 0, n_down = 0;
     for (u64 u = wave; u < a.v.n; u += nwaves) {
-        const u64 s = a.adj_start[u], e = a.adj_start[u + 1];
-        if (s == e) continue;
+        const u64 ru = a.ref[u];
+        const u32 du = REF_DEG(ru);
+        if (du == 0) continue;
+        const u64 s = REF_POS(ru);
         const u32 Lu = a.v.len[u];
         const bool u_in = (u >= a.lo && u < a.hi);
-        for (u64 p = s + lane; p < e; p += 64) {
-            const u64 ent = a.adj[p];
+        for (u32 p = lane; p < du; p += 64) {
+            const u64 ent = a.adj[s + p] & ~ADJ_FLAG;
             const u64 w = ADJ_DST(ent);
             if (a.up_only) {
                 if (w < u) { /* a down-find, counted at its source */
@@ -940,9 +973,8 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
                 continue;
             const u32 Lw = ADJ_DLEN(ent);
             const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent)), Lu); /* :617-619 */
-            const u64 ws = a.adj_start[w];
-            const u32 dw = (u32)(a.adj_start[w + 1] - ws);
-            if (adj_find(a.adj + ws, dw, twin) < 0) {
+            const u64 rw = a.ref[w];
+            if (adj_find(a.adj + REF_POS(rw), REF_DEG(rw), twin) < 0) {
                 asym++;
                 if (!a.up_only) {
                     u32 idx = atomicAdd(a.n_extra, 1u);
@@ -969,38 +1001,39 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
 }
 
 /* extras merge (only when asymmetric pairs exist): new_deg = deg + extra_cnt -> scan -> copy rows -> scatter extras
- * -> re-sort the rows that received extras */
-__global__ void add_u32_kernel(const u64 *__restrict__ adj_start, const u32 *__restrict__ extra_cnt, u64 n, u32 *__restrict__ out)
+ * -> re-sort the rows that received extras -> node-ordered CSR */
+__global__ void merge_deg_kernel(const u64 *__restrict__ ref, const u32 *__restrict__ extra_cnt, u64 n, u32 *__restrict__ out)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = (u32)(adj_start[i + 1] - adj_start[i]) + extra_cnt[i];
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = REF_DEG(ref[i]) + extra_cnt[i];
 }
 
-__global__ void __launch_bounds__(64) merge_copy_kernel(const u64 *__restrict__ old_start, const u64 *__restrict__ old_adj,
+__global__ void __launch_bounds__(64) merge_copy_kernel(const u64 *__restrict__ old_ref, const u64 *__restrict__ old_adj,
                                                         const u64 *__restrict__ new_start, u64 *__restrict__ new_adj, u64 n)
 {
     for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
-        u64 s = old_start[v];
-        u32 d = (u32)(old_start[v + 1] - s);
-        u64 o = new_start[v];
-        for (u32 i = threadIdx.x; i < d; i += 64) new_adj[o + i] = old_adj[s + i];
+        const u64 r = old_ref[v];
+        const u64 s = REF_POS(r);
+        const u32 d = REF_DEG(r);
+        const u64 o = new_start[v];
+        for (u32 i = threadIdx.x; i < d; i += 64) new_adj[o + i] = old_adj[s + i] & ~ADJ_FLAG;
     }
 }
 
 __global__ void merge_scatter_kernel(const u64 *__restrict__ extra_node, const u64 *__restrict__ extra_key, u32 n_extra,
-                                     const u64 *__restrict__ old_start, const u64 *__restrict__ new_start,
+                                     const u64 *__restrict__ old_ref, const u64 *__restrict__ new_start,
                                      u32 *__restrict__ fill, u64 *__restrict__ new_adj)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n_extra; i += gridDim.x * blockDim.x) {
         u64 w = extra_node[i];
-        u32 d = (u32)(old_start[w + 1] - old_start[w]);
+        u32 d = REF_DEG(old_ref[w]);
         u32 slot = atomicAdd(&fill[w], 1u);
         new_adj[new_start[w] + d + slot] = extra_key[i];
     }
 }
 
-/* sort (ascending) the rows that received extras; simple in-place selection by rank through a global scratch row */
+/* sort (ascending) the rows that received extras through a global scratch row */
 __global__ void __launch_bounds__(64) merge_sort_kernel(const u32 *__restrict__ extra_cnt, const u64 *__restrict__ new_start,
                                                         u64 *__restrict__ new_adj, u64 n, u64 *__restrict__ scratch, u64 scratch_cap)
 {
@@ -1019,19 +1052,18 @@ __global__ void __launch_bounds__(64) merge_sort_kernel(const u32 *__restrict__ 
 /* ================================================================================================================
  * transitive marking — markTransitiveEdges (BG/OverlapGraph.cpp:687-723), Myers 2005, one wavefront per node v.
  * N(v) goes into an LDS hash keyed by read id (the reference's markedNodes map, :689-691); neighbours are visited in
- * list order (ascending offset); for every still-INPLAY neighbour u the lanes sweep adj[u] and ELIMINATE the w in N(v)
- * reachable by a consistent walk v->u->w (:701-708). flag[slot] = 1 for edges v->ELIMINATED (:713-720); the twin's
- * flag is the other node's business and is combined at emission.
+ * list order (ascending offset); for every still-INPLAY neighbour u the lanes sweep the list of u and ELIMINATE the w in
+ * N(v) reachable by a consistent walk v->u->w (:701-708). Edges v->ELIMINATED get ADJ_FLAG (:713-720); the twin's flag is
+ * the other node's business and is combined at emission.
  * ============================================================================================================== */
 struct TrArgs {
     DiscoView v;
-    const u64 *adj_start;
-    const u64 *adj;
-    u8 *flag;      /* [total slots], indexed by global slot */
+    const u64 *ref;
+    u64 *adj;      /* only the flag bit of the node's own row is written */
     u64 *big_list;
     u32 *n_big;
     u32 big_cap;
-    u64 *scratch;  /* BIG variant: per block hkey[hcap] | ent(u32)[cap] | state(u8)[hcap] */
+    u64 *scratch;  /* BIG variant: per block hkey[hcap] | ent(u32)[hcap] | state(u8)[hcap] */
     u64 hcap;      /* power of two >= 2 * max degree */
 };
 
@@ -1039,8 +1071,8 @@ struct TrArgs {
 
 __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey, u8 *hstate, u32 *sent, u32 hmask, u32 lane)
 {
-    const u64 vs = a.adj_start[v];
-    const u64 *row = a.adj + vs;
+    const u64 vs = REF_POS(a.ref[v]);
+    u64 *row = a.adj + vs;
     for (u32 i = lane; i <= hmask; i += 64) {
         hkey[i] = TR_EMPTY;
         hstate[i] = 0;
@@ -1062,8 +1094,9 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         const u64 e1 = row[i];
         const u64 u = ADJ_DST(e1);
         const u32 type1 = ADJ_ORI(e1);
-        const u64 us = a.adj_start[u];
-        const u32 du = (u32)(a.adj_start[u + 1] - us);
+        const u64 ru = a.ref[u];
+        const u64 us = REF_POS(ru);
+        const u32 du = REF_DEG(ru);
         const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
         for (u32 t = lane; t < du; t += 64) {        /* :698 */
             const u64 e2 = a.adj[us + t];
@@ -1084,7 +1117,8 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         }
         __syncthreads();
     }
-    for (u32 s = lane; s < d; s += 64) a.flag[vs + s] = hstate[sent[s]];
+    for (u32 s = lane; s < d; s += 64)
+        if (hstate[sent[s]]) row[s] |= ADJ_FLAG;
     __syncthreads();
 }
 
@@ -1122,10 +1156,11 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     const u64 om = __ballot(lane < d && (ADJ_ORI(e) >> 1) != side0);
     const u32 s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
     const u64 u0 = ADJ_DST(readlane_u64(e, 0)), u2 = ADJ_DST(readlane_u64(e, s2));
-    const u64 st0 = a.adj_start[u0], en0 = a.adj_start[u0 + 1];
-    const u64 st2 = a.adj_start[u2], en2 = a.adj_start[u2 + 1];
-    const u64 p0 = (lane < en0 - st0) ? a.adj[st0 + lane] : 0ull;
-    const u64 p2 = (lane < en2 - st2) ? a.adj[st2 + lane] : 0ull;
+    const u64 r0 = a.ref[u0], r2 = a.ref[u2];
+    const u64 st0 = REF_POS(r0), st2 = REF_POS(r2);
+    const u32 d0 = REF_DEG(r0), d2 = REF_DEG(r2);
+    const u64 p0 = (lane < d0) ? a.adj[st0 + lane] : 0ull;
+    const u64 p2 = (lane < d2) ? a.adj[st2 + lane] : 0ull;
     __syncthreads();
     u32 sent = 0;
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
@@ -1149,16 +1184,16 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         u64 pre;
         if (i == 0) {
             us = st0;
-            du = (u32)(en0 - st0);
+            du = d0;
             pre = p0;
         } else if (i == s2) {
             us = st2;
-            du = (u32)(en2 - st2);
+            du = d2;
             pre = p2;
         } else {
-            const u64 u = ADJ_DST(e1);
-            us = a.adj_start[u];
-            du = (u32)(a.adj_start[u + 1] - us);
+            const u64 ru = a.ref[ADJ_DST(e1)];
+            us = REF_POS(ru);
+            du = REF_DEG(ru);
             pre = (lane < du) ? a.adj[us + lane] : 0ull;
         }
         const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
@@ -1181,7 +1216,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         }
         __syncthreads();
     }
-    if (lane < d) a.flag[nd.vs + lane] = hstate[sent];
+    if (lane < d && hstate[sent]) a.adj[nd.vs + lane] = e | ADJ_FLAG;
     __syncthreads();
 }
 
@@ -1208,10 +1243,10 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
         r.d = 0;
         r.e = 0;
         if (it < n_items) {
-            const u64 v = a.v.q_lo + it;
-            r.vs = a.adj_start[v];
-            r.d = (u32)(a.adj_start[v + 1] - r.vs);
-            if (lane < r.d) r.e = a.adj[r.vs + lane];
+            const u64 rv = a.ref[a.v.q_lo + it];
+            r.vs = REF_POS(rv);
+            r.d = REF_DEG(rv);
+            if (lane < r.d) r.e = a.adj[r.vs + lane] & ~ADJ_FLAG;
         }
         return r;
     };
@@ -1236,81 +1271,127 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
             cur = nxt;
         } else {
             const u64 v = a.big_list[it];
-            const u32 d = (u32)(a.adj_start[v + 1] - a.adj_start[v]);
+            const u32 d = REF_DEG(a.ref[v]);
             if (d == 0) continue;
             tr_node(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
         }
     }
 }
 
+/* sharded flow: transitive flags of the slots [lo,hi) of the gathered CSR as bytes (export) / OR them back in (import) */
+__global__ void flags_extract_kernel(const u64 *__restrict__ adj, u64 lo, u64 hi, u8 *__restrict__ flag)
+{
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < hi; i += (u64)gridDim.x * blockDim.x) flag[i] = (adj[i] & ADJ_FLAG) ? 1 : 0;
+}
+
+__global__ void flags_apply_kernel(u64 *__restrict__ adj, u64 total, const u8 *__restrict__ flag)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < total; i += (u64)gridDim.x * blockDim.x)
+        if (flag[i] & 1) adj[i] |= ADJ_FLAG;
+}
+
 /* ================================================================================================================
  * emission — removeTransitiveEdges (BG/OverlapGraph.cpp:731-761) + the canonical side of saveParGraphToFile (:808):
- * edge (v,w) with v < w survives iff it is flagged from neither end. keep bit -> flag |= 2, kept[v] = survivors.
+ * edge (v,w) with v < w survives iff it is flagged from neither end. One pass: survivors are appended to the output
+ * through wave-private chunks of a global bump pointer (order is irrelevant: the canonical form is sorted, and the
+ * reference's own file order depends on its BFS).
  * ============================================================================================================== */
+#define EMIT_CHUNK 256
 struct EmitArgs {
     DiscoView v;
-    const u64 *adj_start;
+    const u64 *ref;
     const u64 *adj;
-    u8 *flag;
-    u32 *kept;          /* [n] (only [q_lo,q_hi) written) */
-    const u64 *out_pos; /* fill pass: exclusive scan of kept over [q_lo,q_hi), indexed by v - q_lo */
     u64 *out_src;
     u64 *out_ent;
+    u64 out_cap;
+    u64 *bump;
 };
 
-template <bool FILL>
 __global__ void __launch_bounds__(256) emit_kernel(EmitArgs a)
 {
     const u32 lane = threadIdx.x & 63;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    u64 chunk_base = 0;
+    u32 chunk_used = EMIT_CHUNK; /* no chunk yet */
+    bool have_chunk = false;
+    /* slots of a chunk that stay unused are marked ~0 so that the compaction can drop them */
+    auto close_chunk = [&]() {
+        if (have_chunk)
+            for (u32 i = chunk_used + lane; i < EMIT_CHUNK; i += 64)
+                if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
+    };
     for (u64 v = a.v.q_lo + wave; v < a.v.q_hi; v += nwaves) {
-        const u64 vs = a.adj_start[v];
-        const u32 d = (u32)(a.adj_start[v + 1] - vs);
+        const u64 rv = a.ref[v];
+        const u32 d = REF_DEG(rv);
+        if (d == 0) continue;
+        const u64 vs = REF_POS(rv);
         const u32 Lv = a.v.len[v];
-        u32 cnt = 0;
         for (u32 s0 = 0; s0 < d; s0 += 64) {
             const u32 s = s0 + lane;
             bool keep = false;
             u64 e = 0;
             if (s < d) {
                 e = a.adj[vs + s];
-                if (FILL) keep = (a.flag[vs + s] & 2) != 0;
-                else {
-                    const u64 w = ADJ_DST(e);
-                    if (v < w && !(a.flag[vs + s] & 1)) {
-                        const u32 Lw = ADJ_DLEN(e);
-                        const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
-                        const u64 ws = a.adj_start[w];
-                        const int ti = adj_find(a.adj + ws, (u32)(a.adj_start[w + 1] - ws), twin);
-                        keep = (ti >= 0) && !(a.flag[ws + ti] & 1);
-                    }
-                    if (keep) a.flag[vs + s] |= 2;
+                const u64 w = ADJ_DST(e);
+                if (v < w && !(e & ADJ_FLAG)) {
+                    const u32 Lw = ADJ_DLEN(e);
+                    const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
+                    const u64 rw = a.ref[w];
+                    const u64 *roww = a.adj + REF_POS(rw);
+                    const int ti = adj_find(roww, REF_DEG(rw), twin);
+                    keep = (ti >= 0) && !(roww[ti] & ADJ_FLAG);
                 }
             }
-            u64 mk = __ballot(keep);
-            if (FILL && keep) {
-                u64 pos = a.out_pos[v - a.v.q_lo] + cnt + __popcll(mk & lane_mask_lt());
-                a.out_src[pos] = v;
-                a.out_ent[pos] = e;
+            const u64 mk = __ballot(keep);
+            const u32 cnt = __popcll(mk);
+            if (cnt) {
+                if (chunk_used + cnt > EMIT_CHUNK) {
+                    close_chunk();
+                    u64 base = 0;
+                    if (lane == 0) base = atomicAdd(a.bump, (u64)EMIT_CHUNK);
+                    chunk_base = __shfl(base, 0);
+                    chunk_used = 0;
+                    have_chunk = true;
+                }
+                if (keep) {
+                    const u64 pos = chunk_base + chunk_used + __popcll(mk & lane_mask_lt());
+                    if (pos < a.out_cap) {
+                        a.out_src[pos] = v;
+                        a.out_ent[pos] = e & ~ADJ_FLAG;
+                    }
+                }
+                chunk_used += cnt;
             }
-            cnt += __popcll(mk);
         }
-        if (!FILL && lane == 0) a.kept[v - a.v.q_lo] = cnt;
     }
+    close_chunk();
+}
+
+/* compact the chunked emission (drop the ~0 tails): count + gather are done on the host side of fetch via a scan */
+__global__ void emit_valid_kernel(const u64 *__restrict__ out_src, u64 n, u8 *__restrict__ valid)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) valid[i] = out_src[i] != ~0ull;
+}
+
+__global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *__restrict__ out_ent, const u8 *__restrict__ valid,
+                                    const u64 *__restrict__ pos, u64 n, u64 *__restrict__ dst_src, u64 *__restrict__ dst_ent)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (valid[i]) {
+            dst_src[pos[i]] = out_src[i];
+            dst_ent[pos[i]] = out_ent[i];
+        }
 }
 
 __global__ void fill_u64_kernel(u64 *p, u64 n, u64 val)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = val;
-}
-
-/* deg[v] = adj_start[v+1]-adj_start[v] for v in [lo,hi) -> out[v-lo] */
-__global__ void deg_from_start_kernel(const u64 *__restrict__ adj_start, u64 lo, u64 hi, u32 *__restrict__ out)
-{
-    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < hi; i += (u64)gridDim.x * blockDim.x) out[i - lo] = (u32)(adj_start[i + 1] - adj_start[i]);
 }
 
 #endif /* DISCO_KERNELS_H_ */

@@ -162,15 +162,16 @@ int disco_contain_keys(disco_ctx *ctx, void **d_keys, uint64_t *n);
 int disco_adjacency_size(disco_ctx *ctx, uint64_t *n_entries);
 int disco_export_adjacency(disco_ctx *ctx, void *d_deg_u32, void *d_entries_u64);
 int disco_import_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all);
-/* transitive flags (uint8 per adjacency slot, `total` slots): this rank computed [slot_lo, slot_hi); ranks all-gather
- * those byte ranges in place between disco_transitive_mark and disco_emit_edges, because an edge survives only if it is
- * flagged from neither end (BG/OverlapGraph.cpp:717-718 flags the twin too). */
+/* sharded flow only (after disco_import_adjacency): transitive flags as uint8 per slot of the gathered adjacency (`total`
+ * slots). This rank computed [slot_lo, slot_hi); ranks all-gather those byte ranges in place between
+ * disco_transitive_mark and disco_emit_edges, because an edge survives only if it is flagged from neither end
+ * (BG/OverlapGraph.cpp:717-718 flags the twin too). On a single GPU the flag is a bit of the entry and nothing is exchanged. */
 int disco_tr_flags(disco_ctx *ctx, void **d_flags, uint64_t *slot_lo, uint64_t *slot_hi, uint64_t *total);
 
 /* ---- results --------------------------------------------------------------------------------------------------- */
 /* rows in ascending contained-read id; returns the number of rows written, or a negative error */
 int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
-/* edges of the local query range, ascending (src, then adjacency order); returns count or negative error */
+/* edges of the local query range (src < dst), in no particular order; returns count or negative error */
 int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
 int disco_get_counters(disco_ctx *ctx, disco_counters *out);
 /* milliseconds of the last run of each phase, measured with HIP events on the stream the kernels were launched on
