@@ -140,10 +140,17 @@ __device__ __forceinline__ u64 rev2_64(u64 x)
     return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
 }
 
-/* 32 bases starting at base position pos (>= 0) of the row p[0..S); positions past the row read as A (0) */
-__device__ __forceinline__ u64 extract32(const u64 *__restrict__ p, int S, int pos)
+/* 32 bases starting at base position pos (>= 0) of the row p[0..S); positions past the row read as A (0).
+ * NB = true: branch-free form for rows staged in LDS with one readable word of padding after the row (callers mask what
+ * lies beyond the read); the bounds checks of the generic form cost an exec-mask branch per word. */
+template <bool NB = false>
+__device__ __forceinline__ u64 extract32(const u64 *p, int S, int pos)
 {
-    int w = pos >> 5, sh = (pos & 31) * 2;
+    const int w = pos >> 5, sh = (pos & 31) * 2;
+    if (NB) {
+        const u64 a = p[w], b = p[w + 1];
+        return (a << sh) | ((b >> 1) >> (63 - sh)); /* (b >> 1) >> (63 - sh) == b >> (64 - sh), and 0 for sh == 0 */
+    }
     u64 a = (w < S) ? p[w] : 0ull;
     if (sh == 0) return a;
     u64 b = (w + 1 < S) ? p[w + 1] : 0ull;
@@ -151,14 +158,15 @@ __device__ __forceinline__ u64 extract32(const u64 *__restrict__ p, int S, int p
 }
 
 /* k-mer (k <= 64) at base j as a right-aligned 2k-bit integer hi:lo */
-__device__ __forceinline__ void kmer_at(const u64 *__restrict__ p, int S, int j, int k, u64 &hi, u64 &lo)
+template <bool NB = false>
+__device__ __forceinline__ void kmer_at(const u64 *p, int S, int j, int k, u64 &hi, u64 &lo)
 {
     if (k <= 32) {
         hi = 0;
-        lo = extract32(p, S, j) >> (64 - 2 * k);
+        lo = extract32<NB>(p, S, j) >> (64 - 2 * k);
     } else {
-        hi = extract32(p, S, j) >> (64 - 2 * (k - 32));
-        lo = extract32(p, S, j + k - 32);
+        hi = extract32<NB>(p, S, j) >> (64 - 2 * (k - 32));
+        lo = extract32<NB>(p, S, j + k - 32);
     }
 }
 
@@ -182,96 +190,107 @@ __device__ __forceinline__ void kmer_revcomp(u64 hi, u64 lo, int k, u64 &rhi, u6
 /* canonical orientation of the k-mer at j (the reference canonicalises through min(hash(fwd), hash(rc)),
  * BG/HashTable.cpp:383-391; any strand-symmetric choice gives the same buckets' contents up to order):
  * 1 when the reverse complement is the smaller 2k-bit integer. A palindrome (k even) has 0. */
-__device__ __forceinline__ u32 kmer_is_rev(const u64 *__restrict__ p, int S, int j, int k)
+template <bool NB = false>
+__device__ __forceinline__ u32 kmer_is_rev(const u64 *p, int S, int j, int k)
 {
     u64 hi, lo, rhi, rlo;
-    kmer_at(p, S, j, k, hi, lo);
+    kmer_at<NB>(p, S, j, k, hi, lo);
     kmer_revcomp(hi, lo, k, rhi, rlo);
     return ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
 }
 
 /* canonical m-mer (m <= 32) at base pos: value of min(m-mer, reverse complement); strand = 1 when the reverse complement
  * is the smaller one (m is odd, so the two never tie) */
+template <bool NB = false>
 __device__ __forceinline__ u64 mmer_canonical(const u64 *p, int S, int pos, int m, u32 &strand)
 {
-    const u64 v = extract32(p, S, pos) >> (64 - 2 * m);
+    const u64 v = extract32<NB>(p, S, pos) >> (64 - 2 * m);
     const u64 r = rev2_64(~v) >> (64 - 2 * m);
     strand = r < v ? 1u : 0u;
     return strand ? r : v;
 }
 
-/* 31-bit order hash of the canonical m-mer in bits 31..1, its strand in bit 0. Minimizers are chosen by the order hash. */
+/* order word of the m-mer at pos: 25-bit order hash of the canonical m-mer in bits 31..7, bits 6..1 zero (room for a
+ * window offset), the m-mer's strand in bit 0. Minimizers are chosen by the order hash. */
+template <bool NB = false>
 __device__ __forceinline__ u32 mmer_order(const u64 *p, int S, int pos, int m)
 {
     u32 strand;
-    const u64 c = mmer_canonical(p, S, pos, m, strand);
-    const u32 h = (u32)((c * 0x9E3779B97F4A7C15ull) >> 33);
-    return (h << 1) | strand;
+    const u64 c = mmer_canonical<NB>(p, S, pos, m, strand);
+    const u32 h = (u32)((c * 0x9E3779B97F4A7C15ull) >> 39);
+    return (h << 7) | strand;
 }
 
 /* 64-bit bucket key of the m-mer at pos (bijective mix of the canonical m-mer: distinct m-mers never share a key) */
+template <bool NB = false>
 __device__ __forceinline__ u64 mmer_key(const u64 *p, int S, int pos, int m)
 {
     u32 strand;
-    return disco_hash64(mmer_canonical(p, S, pos, m, strand));
+    return disco_hash64(mmer_canonical<NB>(p, S, pos, m, strand));
 }
 
-/* minimizer length for a given k: odd (no m-mer is its own reverse complement), at most 21 */
+/* minimizer length for a given k: odd (no m-mer is its own reverse complement), at most 23 (a 150-bp read then has
+ * 127 m-mer positions under its k-mer windows: two full 64-lane passes) */
 __host__ __device__ __forceinline__ int disco_minimizer_len(int k)
 {
-    int m = k < 21 ? k : 21;
+    int m = k < 23 ? k : 23;
     if ((m & 1) == 0) m -= 1;
     return m < 1 ? 1 : m;
 }
 
 /* Minimizer of the k-mer window at base j from the order hashes h(0..nf-1) of its m-mers (forward offsets).
  * The window's CANONICAL ORIENTATION and the chosen occurrence are defined together, strand-symmetrically:
- *   - unique smallest order hash: that m-mer is the minimizer; the window is "reversed" (rev = 1) iff the m-mer sits on
- *     its non-canonical strand. (A k-mer and its reverse complement contain the same physical m-mer on opposite strands.)
+ *   - unique smallest order hash (25 bits): that m-mer is the minimizer; the window is "reversed" (rev = 1) iff the
+ *     m-mer sits on its non-canonical strand. (A k-mer and its reverse complement contain the same physical m-mer on opposite strands.)
  *   - several positions tie (the same canonical m-mer twice, or an order-hash collision; rare): rev = 1 iff the reverse
  *     complement of the whole k-mer is the smaller integer (a palindrome has rev = 0, like BG/HashTable.cpp:539-549
  *     tries the forward match first), and the LEFTMOST tied position in the canonical orientation is taken.
  * Returns the chosen forward offset. Index and probe both call this, so a k-mer and its reverse complement always agree on
  * the minimizer and on its offset t = rev ? nf-1-f : f inside the canonical orientation. */
-template <typename F>
+template <bool NB = false, typename F>
 __device__ __forceinline__ int window_minimizer(F h, int nf, const u64 *p, int S, int j, int k, u32 &rev)
 {
-    u32 h0 = h(0);
-    u32 best = h0 >> 1, sbit = h0 & 1u;
-    int ffirst = 0, flast = 0;
-    for (int f = 1; f < nf; f++) {
-        const u32 x = h(f);
-        const u32 v = x >> 1;
-        if (v < best) {
-            best = v;
-            sbit = x & 1u;
-            ffirst = flast = f;
-        } else if (v == best)
-            flast = f;
+    /* two running minima over keys  order hash | offset << 1 | strand : k1 carries the offset f (smallest hash, then
+     * LEFTMOST position), k2 carries 63 - f (smallest hash, then RIGHTMOST position). Branch-free, eight order words
+     * fetched at a time so that their LDS loads are in flight together. nf <= 64. */
+    u32 k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    for (int f0 = 0; f0 < nf; f0 += 8) {
+        u32 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = h(f0 + i < nf ? f0 + i : nf - 1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int f = f0 + i;
+            const u32 a = (f < nf) ? x[i] + ((u32)f << 1) : 0xFFFFFFFFu;
+            const u32 b = (f < nf) ? x[i] + ((u32)(63 - f) << 1) : 0xFFFFFFFFu;
+            k1 = a < k1 ? a : k1;
+            k2 = b < k2 ? b : k2;
+        }
     }
+    const int ffirst = (int)((k1 >> 1) & 63u), flast = 63 - (int)((k2 >> 1) & 63u);
     if (ffirst == flast) {
-        rev = sbit;
+        rev = k1 & 1u;
         return ffirst;
     }
-    rev = kmer_is_rev(p, S, j, k);
+    rev = kmer_is_rev<NB>(p, S, j, k);
     return rev ? flast : ffirst;
 }
 
 /* A[a0 .. a0+m) == s2[b0 .. b0+m) where s2 = B (rev = 0) or revcomp(B) (rev = 1); LB = length of B */
-__device__ __forceinline__ bool seg_equal(const u64 *__restrict__ pa, const u64 *__restrict__ pb, int S, int LB, int a0,
-                                          int b0, int m, u32 rev)
+template <bool NB = false>
+__device__ __forceinline__ bool seg_equal(const u64 *pa, const u64 *pb, int S, int LB, int a0, int b0, int m, u32 rev)
 {
     for (int i = 0; i < m; i += 32) {
         int n = m - i;
         if (n > 32) n = 32;
-        u64 wa = extract32(pa, S, a0 + i);
+        u64 wa = extract32<NB>(pa, S, a0 + i);
         u64 wb;
         if (!rev) {
-            wb = extract32(pb, S, b0 + i);
+            wb = extract32<NB>(pb, S, b0 + i);
         } else {
             /* s2[b0+i+t] = comp(B[LB-1-b0-i-t]) : take B[q .. q+n) and reverse-complement it */
             int q = LB - b0 - i - n;
-            u64 x = extract32(pb, S, q);
+            u64 x = extract32<NB>(pb, S, q);
             wb = rev2_64(~x);
             if (n < 32) wb <<= 2 * (32 - n);
         }

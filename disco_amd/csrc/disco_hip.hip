@@ -601,6 +601,7 @@ int disco_probe(disco_ctx *c)
         a.big_cnt = c->d_big_cnt;
         a.n_big = c->d_n_big;
         a.big_cap = c->big_cap;
+        a.ablate = getenv("DISCO_PROBE_ABLATE") ? (u32)atoi(getenv("DISCO_PROBE_ABLATE")) : 0u;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         const bool ldsrow = c->S <= PROBE_ACAP;
         if (nq) {

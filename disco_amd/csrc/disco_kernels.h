@@ -265,6 +265,7 @@ struct ProbeArgs {
     u32 *big_cnt;
     u32 *n_big;
     u32 big_cap;
+    u32 ablate;     /* diagnostics only (DISCO_PROBE_ABLATE): 1 = stop after the window pass, 2 = stop after the bucket lookups */
 };
 
 template <bool BIG, bool LDSROW>
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
     __shared__ u32 s_occ_start[64];     /*   running record count, position                                            */
     __shared__ u32 s_occ_excl[64];
     __shared__ u16 s_occ_prel[64];
-    __shared__ u64 s_a[PROBE_ACAP];     /* the query read's own packed row */
+    __shared__ u64 s_a[PROBE_ACAP + 2]; /* the query read's own packed row + zero padding for the branch-free extracts */
     const u32 lane = threadIdx.x;
     const int S = a.v.S, k = a.v.k;
     const int m = a.v.m, nf = k - m + 1;
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
         __syncthreads();
         if (!BIG && LDSROW) {
             LA = pre_len;
-            if ((int)lane < S) s_a[lane] = pre_w;
+            if ((int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? pre_w : 0ull;
             const u64 itn = it + gridDim.x;
             if (itn < n_items) {
                 const u64 An = a.v.q_lo + itn;
@@ -315,8 +316,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             }
         } else {
             LA = a.v.len[A];
-            if (LDSROW)
-                for (int w = (int)lane; w < S; w += 64) s_a[w] = ga[w];
+            if (LDSROW && (int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? ga[lane] : 0ull;
         }
         const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
         const u64 *pa = LDSROW ? (const u64 *)s_a : ga;
@@ -353,11 +353,12 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
         for (int w0 = 0; w0 < npos; w0 += PROBE_SEGW) { /* segments of PROBE_SEGW windows (one for reads up to 256+k bp) */
             const int nw = min(PROBE_SEGW, npos - w0);
             const int np = nw + nf - 1; /* m-mer positions the segment's windows cover */
+            if (a.ablate == 4) continue;
             /* 1. order hashes of the segment's m-mers */
             __syncthreads();
-            for (int q = (int)lane; q < PROBE_SEGP; q += 64) {
+            for (int q = (int)lane; q < np; q += 64) {
                 s_first[q] = 0xFFFFFFFFu;
-                if (q < np) s_h[q] = mmer_order(pa, S, w0 + q, m);
+                s_h[q] = mmer_order<LDSROW>(pa, S, w0 + q, m);
             }
             __syncthreads();
             /* 2. every window picks its minimizer occurrence and canonical strand */
@@ -365,13 +366,14 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
                 const int w = ws + (int)lane;
                 if (w < nw) {
                     u32 rev_w;
-                    const int f = window_minimizer([&](int x) { return s_h[w + x]; }, nf, pa, S, w0 + w, k, rev_w);
+                    const int f = window_minimizer<LDSROW>([&](int x) { return s_h[w + x]; }, nf, pa, S, w0 + w, k, rev_w);
                     const u32 prel = (u32)(w + f);
                     s_wp[w] = (u16)(prel | (rev_w << 15));
                     atomicMin(&s_first[prel], (u32)w);
                 }
             }
             __syncthreads();
+            if (a.ablate == 1) continue;
             /* 3. the first window of every occurrence leads one bucket lookup */
             u32 nlead = 0;
             for (int ws = 0; ws < nw; ws += 64) {
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
                 u32 s = 0, cnt = 0;
                 if (li < nlead) {
                     const u32 prel = s_wp[s_lead[li]] & 0x7FFFu;
-                    const u64 key = mmer_key(pa, S, w0 + (int)prel, m);
+                    const u64 key = mmer_key<LDSROW>(pa, S, w0 + (int)prel, m);
                     const u64 b = key >> a.v.bshift;
                     s = a.v.bkt[b];
                     cnt = a.v.bkt[b + 1] - s;
@@ -404,6 +406,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
                 s_occ_start[lane] = s;
                 s_occ_excl[lane] = incl - cnt;
                 __syncthreads();
+                if (a.ablate == 2) continue;
                 /* 4. all records of all led buckets, lane = record: a record names the window(s) it can match through its
                  *    minimizer offset t; the window's own (occurrence, strand) must agree */
                 for (u32 base = 0; base < total; base += 64) {
@@ -504,8 +507,8 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 {
     /* staged (S == VERIFY_SW, decided by the host): rows live in LDS with a statically known address space.
      * per lane: the candidate's row; +1 word of padding keeps the 64 rows on different banks */
-    __shared__ u64 s_b[staged ? 64 * (VERIFY_SW + 1) : 1];
-    __shared__ u64 s_a[VERIFY_SW];
+    __shared__ u64 s_b[staged ? 64 * (VERIFY_SW + 1) + 1 : 1];
+    __shared__ u64 s_a[VERIFY_SW + 2];
     const u32 lane = threadIdx.x;
     const int S = staged ? VERIFY_SW : a.v.S, k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
@@ -573,7 +576,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                     const int LB = (int)HIT_LEN(h);
                     const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
                     const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
-                    if (seg_equal(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
+                    if (seg_equal<staged>(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
                         my_khits++;
                         int a0, b0, mlen;
                         bool contain, overlap;
@@ -592,7 +595,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                             b0 = sft < 0 ? -sft : 0;
                             mlen = j + k - a0;
                         }
-                        if (seg_equal(pa, pb, S, LB, a0, b0, mlen, rev)) {
+                        if (seg_equal<staged>(pa, pb, S, LB, a0, b0, mlen, rev)) {
                             if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                             ov = overlap;
                         }
