@@ -63,6 +63,7 @@ struct disco_ctx {
 
     /* counters */
     u64 *d_ctr = nullptr;
+    u64 *d_wq = nullptr; /* work-queue counter shared by the wave-per-item kernels (one launch at a time) */
     u64 h_ctr[CTR_COUNT] = {0};
 
     /* probe */
@@ -207,13 +208,35 @@ static DiscoView view(const disco_ctx *c)
     v.q_lo = c->q_lo;
     v.q_hi = c->q_hi;
     v.ctr = c->d_ctr;
+    v.wq = c->d_wq;
     return v;
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 static int wave_grid(const disco_ctx *c, u64 items, int per_cu = 24)
 {
     u64 g = (u64)c->n_cu * per_cu;
     if (items < g) g = items;
+    return (int)std::max<u64>(g, 1);
+}
+
+/* grid for a work-queue kernel: every workgroup that can be resident (the queue balances the load), zeroes the queue */
+template <typename K>
+static int wq_grid(disco_ctx *c, K kernel, u64 items, const char *env)
+{
+    (void)hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (per_cu > 32) per_cu = 32;
+    per_cu = env_int(env, per_cu);
+    u64 g = (u64)c->n_cu * per_cu;
+    const u64 chunks = (items + WQ_CHUNK - 1) / WQ_CHUNK;
+    if (chunks < g) g = chunks;
     return (int)std::max<u64>(g, 1);
 }
 
@@ -347,6 +370,7 @@ int disco_create(int device, const disco_params *p, disco_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_ctr, sizeof(u64) * CTR_COUNT));
     CREATE_CHK(hipMemset(c->d_ctr, 0, sizeof(u64) * CTR_COUNT));
     CREATE_CHK(hipMalloc((void **)&c->d_total, sizeof(u64)));
+    CREATE_CHK(hipMalloc((void **)&c->d_wq, sizeof(u64)));
     CREATE_CHK(hipMalloc((void **)&c->d_bump, sizeof(u64)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_big, sizeof(u32)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_extra, sizeof(u32)));
@@ -369,6 +393,7 @@ void disco_destroy(disco_ctx *c)
     dev_free(c, &c->d_tile, c->tile_cap);
     (void)hipFree(c->d_ctr);
     (void)hipFree(c->d_total);
+    (void)hipFree(c->d_wq);
     (void)hipFree(c->d_bump);
     (void)hipFree(c->d_n_big);
     (void)hipFree(c->d_n_extra);
@@ -560,9 +585,8 @@ int disco_probe(disco_ctx *c)
     }
     if (c->n) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, DISCO_NOKEY);
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
-    int per_cu = 28;
-    if (const char *e = getenv("DISCO_PROBE_WAVES")) per_cu = atoi(e);
-    const int grid = wave_grid(c, nq, per_cu);
+    const bool ldsrow = c->S <= PROBE_ACAP;
+    const int grid = ldsrow ? wq_grid(c, probe_kernel<false, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<false, false>, nq, "DISCO_PROBE_WAVES");
     u64 want_hits = nq * 64 + (u64)grid * PROBE_CHUNK + (1u << 16);
     u32 want_big = (u32)std::min<u64>(nq, nq / 64 + 1024);
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -603,7 +627,7 @@ int disco_probe(disco_ctx *c)
         a.big_cap = c->big_cap;
         a.ablate = getenv("DISCO_PROBE_ABLATE") ? (u32)atoi(getenv("DISCO_PROBE_ABLATE")) : 0u;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
-        const bool ldsrow = c->S <= PROBE_ACAP;
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {
             if (ldsrow) hipLaunchKernelGGL((probe_kernel<false, true>), dim3(grid), dim3(64), 0, c->stream, a);
             else hipLaunchKernelGGL((probe_kernel<false, false>), dim3(grid), dim3(64), 0, c->stream, a);
@@ -614,7 +638,8 @@ int disco_probe(disco_ctx *c)
         HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
         CHK(read_counters(c));
         if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
-            int g2 = wave_grid(c, n_big, 8);
+            int g2 = wave_grid(c, (n_big + WQ_CHUNK - 1) / WQ_CHUNK, 8);
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
             if (ldsrow) hipLaunchKernelGGL((probe_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
             else hipLaunchKernelGGL((probe_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
             HIPCHK(c, hipGetLastError());
@@ -630,8 +655,8 @@ int disco_probe(disco_ctx *c)
             va.row_cnt = c->d_row_cnt;
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
-                if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<true>, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, va);
-                else hipLaunchKernelGGL(verify_kernel<false>, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, va);
+                if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<true>, dim3(wq_grid(c, verify_kernel<true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else hipLaunchKernelGGL(verify_kernel<false>, dim3(wq_grid(c, verify_kernel<false>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
             }
             ph_end(c, DISCO_PH_VERIFY);
             HIPCHK(c, hipGetLastError());
@@ -713,7 +738,7 @@ static int select_edges(disco_ctx *c)
         a.big_cap = c->big_cap;
     }
     ph_begin(c, DISCO_PH_SELECT);
-    if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wave_grid(c, nq, 32)), dim3(64), 0, c->stream, a);
+    if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
@@ -728,6 +753,7 @@ static int select_edges(disco_ctx *c)
         CHK(dev_alloc(c, &scratch, (u64)g2 * 2 * cap));
         a.scratch = scratch;
         a.scratch_cap = cap;
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         hipLaunchKernelGGL(edge_select_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
         int rc = read_counters(c);
@@ -1001,7 +1027,7 @@ int disco_transitive_mark(disco_ctx *c)
     a.scratch = nullptr;
     a.hcap = 0;
     ph_begin(c, DISCO_PH_TRMARK);
-    if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wave_grid(c, nq, 20)), dim3(64), 0, c->stream, a);
+    if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wq_grid(c, transitive_mark_kernel<false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
@@ -1028,6 +1054,7 @@ int disco_transitive_mark(disco_ctx *c)
         CHK(dev_alloc(c, &scratch, (u64)g2 * per));
         a.scratch = (u64 *)scratch;
         a.hcap = hcap;
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         hipLaunchKernelGGL(transitive_mark_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
         hipError_t e2 = hipStreamSynchronize(c->stream);

@@ -55,6 +55,20 @@ enum {
     CTR_COUNT
 };
 
+/* dynamic work distribution: a wave grabs WQ_CHUNK consecutive items at a time from a global counter, so the run time does
+ * not depend on how many workgroups happen to be resident (a static blockIdx-strided loop ran 30-40 % slower whenever
+ * the grid was not a multiple of the resident workgroups) */
+#define WQ_CHUNK 32
+__device__ __forceinline__ bool wq_grab(u64 *counter, u64 n, u64 &beg, u64 &end)
+{
+    u64 b = 0;
+    if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, (u64)WQ_CHUNK);
+    b = __shfl(b, 0);
+    beg = b;
+    end = (b + WQ_CHUNK < n) ? b + WQ_CHUNK : n;
+    return b < n;
+}
+
 struct DiscoView {
     const u64 *reads; /* [n][S] */
     const u16 *len;   /* [n]    */
@@ -69,6 +83,7 @@ struct DiscoView {
     /* query shard */
     u64 q_lo, q_hi;
     u64 *ctr;
+    u64 *wq; /* work-queue counter of the launch (zeroed by the host) */
 };
 
 /* ================================================================================================================
@@ -294,13 +309,14 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
     /* the next read's row and length are fetched while the current read is processed (LDSROW implies S <= 64 words) */
     u64 pre_w = 0;
     int pre_len = 0;
-    if (!BIG && LDSROW && blockIdx.x < n_items) {
-        const u64 A0 = a.v.q_lo + blockIdx.x;
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
+    if (!BIG && LDSROW) {
+        const u64 A0 = a.v.q_lo + cbeg;
         pre_len = a.v.len[A0];
         if ((int)lane < S) pre_w = a.v.reads[A0 * S + lane];
     }
-
-    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+    for (u64 it = cbeg; it < cend; it++) {
         const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
         const u64 *ga = a.v.reads + A * S;
         int LA;
@@ -308,8 +324,8 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
         if (!BIG && LDSROW) {
             LA = pre_len;
             if ((int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? pre_w : 0ull;
-            const u64 itn = it + gridDim.x;
-            if (itn < n_items) {
+            const u64 itn = it + 1;
+            if (itn < cend) {
                 const u64 An = a.v.q_lo + itn;
                 pre_len = a.v.len[An];
                 if ((int)lane < S) pre_w = a.v.reads[An * S + lane];
@@ -479,6 +495,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             chunk_used += nrow;
         }
     }
+    }
     if (lane == 0) atomicMax(&a.v.ctr[CTR_MAX_ROW], (u64)my_maxrow);
 }
 
@@ -512,8 +529,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
     const u32 lane = threadIdx.x;
     const int S = staged ? VERIFY_SW : a.v.S, k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
-    const u64 stride = gridDim.x;
-    const u64 A_first = a.v.q_lo + blockIdx.x;
+    const u64 stride = 1;
 
     /* 3-stage software pipeline over the reads of this wave: while read t is verified, the candidates of read t+1 and the
      * row header of read t+2 are already in flight, so each read exposes ONE memory latency (its candidate rows) */
@@ -523,13 +539,14 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         u64 rs;
         u64 aw; /* lane < S: word `lane` of the read's own row */
     };
+    u64 cbeg = 0, cend = 0;
     auto load_meta = [&](u64 A) {
         Meta mt;
         mt.c = 0;
         mt.L = 0;
         mt.rs = 0;
         mt.aw = 0;
-        if (A < a.v.q_hi) {
+        if (A < a.v.q_lo + cend) {
             mt.c = a.row_cnt[A];
             mt.rs = a.row_start[A];
             mt.L = a.v.len[A];
@@ -537,10 +554,12 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         }
         return mt;
     };
+    while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
+    const u64 A_first = a.v.q_lo + cbeg;
     Meta m0 = load_meta(A_first), m1 = load_meta(A_first + stride);
     u64 h0 = (lane < m0.c) ? a.hits[m0.rs + lane] : 0ull;
 
-    for (u64 A = A_first; A < a.v.q_hi; A += stride) {
+    for (u64 A = A_first; A < a.v.q_lo + cend; A += stride) {
         const Meta m2 = load_meta(A + 2 * stride);
         const u64 h1 = (lane < m1.c) ? a.hits[m1.rs + lane] : 0ull;
         const u32 c = m0.c;
@@ -615,6 +634,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         m0 = m1;
         m1 = m2;
         h0 = h1;
+    }
     }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {
@@ -855,7 +875,9 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
     u64 *t = BIG ? h + a.scratch_cap : s_t;
-    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, n_items, cbeg, cend))
+    for (u64 it = cbeg; it < cend; it++) {
         const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
         const u32 c = a.row_cnt[A];
         if (c == 0 || is_contained(a.contained, A)) { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
@@ -1254,10 +1276,18 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
         return r;
     };
     TrNodeRegs cur;
-    if (!BIG) cur = load_node(blockIdx.x);
-    for (u64 it = blockIdx.x; it < n_items; it += gridDim.x) {
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
+    if (!BIG) cur = load_node(cbeg);
+    for (u64 it = cbeg; it < cend; it++) {
         if (!BIG) {
-            const TrNodeRegs nxt = load_node(it + gridDim.x); /* in flight while `cur` is processed */
+            TrNodeRegs nxt; /* in flight while `cur` is processed */
+            if (it + 1 < cend) nxt = load_node(it + 1);
+            else {
+                nxt.vs = 0;
+                nxt.d = 0;
+                nxt.e = 0;
+            }
             const u64 v = a.v.q_lo + it;
             if (cur.d != 0) {
                 if (cur.d <= 64) tr_node_small(a, cur, s_hkey, s_state, lane);
@@ -1278,6 +1308,7 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
             if (d == 0) continue;
             tr_node(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
         }
+    }
     }
 }
 
