@@ -1111,8 +1111,8 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         if (c->adj_total) hipLaunchKernelGGL(flags_apply_kernel, dim3(flat_grid(c, c->adj_total)), dim3(256), 0, c->stream, c->d_adj, c->adj_total, c->d_flag);
         c->flags_pending = false;
     }
-    const int grid = flat_grid(c, nq * 64);
-    const u64 nwaves = (u64)grid * 4;
+    const int grid = wq_grid(c, emit_kernel, nq, "DISCO_EMIT_WAVES");
+    const u64 nwaves = (u64)grid;
     u64 want = std::max<u64>(2 * nq, 1024) + nwaves * EMIT_CHUNK;
     for (int attempt = 0; attempt < 6; attempt++) {
         if (!c->d_out_src || want > c->out_cap) {
@@ -1132,7 +1132,8 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.out_ent = c->d_out_ent;
         a.out_cap = c->out_cap;
         a.bump = c->d_bump;
-        if (nq) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+        if (nq) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(64), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
         u64 used = 0;
         HIPCHK(c, hipMemcpyAsync(&used, c->d_bump, sizeof(u64), hipMemcpyDeviceToHost, c->stream));

@@ -1343,11 +1343,9 @@ struct EmitArgs {
     u64 *bump;
 };
 
-__global__ void __launch_bounds__(256) emit_kernel(EmitArgs a)
+__global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
 {
-    const u32 lane = threadIdx.x & 63;
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u32 lane = threadIdx.x;
     u64 chunk_base = 0;
     u32 chunk_used = EMIT_CHUNK; /* no chunk yet */
     bool have_chunk = false;
@@ -1357,7 +1355,9 @@ __global__ void __launch_bounds__(256) emit_kernel(EmitArgs a)
             for (u32 i = chunk_used + lane; i < EMIT_CHUNK; i += 64)
                 if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
     };
-    for (u64 v = a.v.q_lo + wave; v < a.v.q_hi; v += nwaves) {
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend))
+    for (u64 v = a.v.q_lo + cbeg; v < a.v.q_lo + cend; v++) {
         const u64 rv = a.ref[v];
         const u32 d = REF_DEG(rv);
         if (d == 0) continue;
