@@ -55,6 +55,8 @@ struct disco_ctx {
     int bshift = 0;
     u32 *d_bkt = nullptr;
     u64 *d_ent = nullptr;
+    ulonglong2 *d_rec = nullptr; /* {key, record}[2n] scratch of the index build */
+    u64 rec_cap = 0;
 
     /* scan temporaries */
     u64 *d_tile = nullptr;
@@ -102,6 +104,9 @@ struct disco_ctx {
 
     /* reduction */
     u8 *d_flag = nullptr;
+    u64 *d_half = nullptr; /* [n][HALF_CAP] */
+    u32 *d_hcnt = nullptr; /* [n] */
+    bool use_half = false;
     u8 *d_out_valid = nullptr;
     u64 *d_out_pos = nullptr;
     u64 *d_out_src = nullptr, *d_out_ent = nullptr;
@@ -288,7 +293,8 @@ static void free_graph_state(disco_ctx *c)
 {
     dev_free(c, &c->d_bkt, c->bkt_cap);
     dev_free(c, &c->d_ent, c->ent_cap);
-    c->bkt_cap = c->ent_cap = 0;
+    dev_free(c, &c->d_rec, c->rec_cap);
+    c->bkt_cap = c->ent_cap = c->rec_cap = 0;
     dev_free(c, &c->d_best, c->n);
     dev_free(c, &c->d_hits, c->hits_cap);
     c->hits_cap = 0;
@@ -308,6 +314,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_extra_key, c->extra_cap);
     c->extra_cap = 0;
     dev_free(c, &c->d_flag, c->flag_cap);
+    dev_free(c, &c->d_half, c->n * HALF_CAP);
+    dev_free(c, &c->d_hcnt, c->n);
     c->adj_total = c->adj_cap = c->flag_cap = 0;
     dev_free(c, &c->d_out_valid, c->valid_cap);
     dev_free(c, &c->d_out_pos, c->valid_cap + 1);
@@ -562,9 +570,12 @@ int disco_build_index(disco_ctx *c)
     ph_begin(c, DISCO_PH_INDEX);
     HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (T + 1) * sizeof(u32), c->stream));
     DiscoView v = view(c);
-    if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt);
+    /* {key, record} of both end k-mers of every read, computed once by the count pass and re-read by the fill pass */
+    CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
+    ulonglong2 *rec = c->d_rec;
+    if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt, rec);
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt + 1, T, c->d_bkt + 1, false, nullptr)));
-    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt, c->d_ent);
+    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, c->bshift, rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
     ph_end(c, DISCO_PH_INDEX);
     c->phase = 2;
@@ -1026,6 +1037,16 @@ int disco_transitive_mark(disco_ctx *c)
     a.big_cap = c->big_cap;
     a.scratch = nullptr;
     a.hcap = 0;
+    a.half = nullptr;
+    a.hcnt = nullptr;
+    c->use_half = !c->adj_imported && !getenv("DISCO_NO_HALF"); /* the survivors' lists of remote nodes are not exchanged */
+    if (c->use_half) {
+        if (!c->d_half) CHK(dev_alloc(c, &c->d_half, c->n * HALF_CAP));
+        if (!c->d_hcnt) CHK(dev_alloc(c, &c->d_hcnt, c->n));
+        HIPCHK(c, hipMemsetAsync(c->d_hcnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+        a.half = c->d_half;
+        a.hcnt = c->d_hcnt;
+    }
     ph_begin(c, DISCO_PH_TRMARK);
     if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wq_grid(c, transitive_mark_kernel<false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
@@ -1112,7 +1133,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         c->flags_pending = false;
     }
     const int grid = wq_grid(c, emit_kernel, nq, "DISCO_EMIT_WAVES");
-    const u64 nwaves = (u64)grid;
+    const u64 nwaves = (u64)grid * 2; /* emit_half_kernel + emit_kernel */
     u64 want = std::max<u64>(2 * nq, 1024) + nwaves * EMIT_CHUNK;
     for (int attempt = 0; attempt < 6; attempt++) {
         if (!c->d_out_src || want > c->out_cap) {
@@ -1124,10 +1145,25 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             c->out_cap = want;
         }
         HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
+        if (c->use_half && nq) {
+            EmitHalfArgs h;
+            h.v = view(c);
+            h.ref = c->d_adj_ref;
+            h.adj = c->d_adj;
+            h.half = c->d_half;
+            h.hcnt = c->d_hcnt;
+            h.out_src = c->d_out_src;
+            h.out_ent = c->d_out_ent;
+            h.out_cap = c->out_cap;
+            h.bump = c->d_bump;
+            const int gh = wq_grid(c, emit_half_kernel, (nq + 63) / 64, "DISCO_EMIT_WAVES");
+            hipLaunchKernelGGL(emit_half_kernel, dim3(gh), dim3(64), 0, c->stream, h);
+        }
         EmitArgs a;
         a.v = view(c);
         a.ref = c->d_adj_ref;
         a.adj = c->d_adj;
+        a.hcnt = c->use_half ? c->d_hcnt : nullptr;
         a.out_src = c->d_out_src;
         a.out_ent = c->d_out_ent;
         a.out_cap = c->out_cap;

@@ -143,22 +143,9 @@ __device__ __forceinline__ u64 end_kmer_record(const u64 *__restrict__ p, int S,
     return mmer_key(p, S, pos + f, m);
 }
 
-__global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt)
+__global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 *p = v.reads + i * v.S;
-        int L = v.len[i];
-        u32 t, rev;
-        u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, t, rev);
-        u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, t, rev);
-        atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
-        atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
-    }
-}
-
-__global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, u64 *__restrict__ ent)
-{
+    /* rec[2i], rec[2i+1] = {bucket key, record} of the prefix / suffix k-mer of read i, kept for the fill pass */
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
         const u64 *p = v.reads + i * v.S;
@@ -166,10 +153,20 @@ __global__ void index_fill_kernel(DiscoView v, u32 *__restrict__ bkt, u64 *__res
         u32 tp, rp, ts, rs;
         u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, tp, rp);
         u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, ts, rs);
-        u32 pos = atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
-        ent[pos] = PAY_MAKE(kp, i, tp, rp, 0, L);
-        pos = atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
-        ent[pos] = PAY_MAKE(ks, i, ts, rs, 1, L);
+        atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
+        atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
+        rec[2 * i] = make_ulonglong2(kp, PAY_MAKE(kp, i, tp, rp, 0, L));
+        rec[2 * i + 1] = make_ulonglong2(ks, PAY_MAKE(ks, i, ts, rs, 1, L));
+    }
+}
+
+__global__ void index_fill_kernel(u64 n2, int bshift, const ulonglong2 *__restrict__ rec, u32 *__restrict__ bkt, u64 *__restrict__ ent)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n2; i += (u64)gridDim.x * blockDim.x) {
+        const ulonglong2 r = rec[i];
+        const u32 pos = atomicAdd(&bkt[1 + (r.x >> bshift)], 1u);
+        ent[pos] = r.y;
     }
 }
 
@@ -1081,10 +1078,13 @@ __global__ void __launch_bounds__(64) merge_sort_kernel(const u32 *__restrict__ 
  * N(v) reachable by a consistent walk v->u->w (:701-708). Edges v->ELIMINATED get ADJ_FLAG (:713-720); the twin's flag is
  * the other node's business and is combined at emission.
  * ============================================================================================================== */
+#define HALF_CAP 4 /* edges of a node that survive its own marking, kept aside for the emission (almost always 2) */
 struct TrArgs {
     DiscoView v;
     const u64 *ref;
     u64 *adj;      /* only the flag bit of the node's own row is written */
+    u64 *half;     /* [n][HALF_CAP] entries not flagged from this node (first HALF_CAP in list order), or null */
+    u32 *hcnt;     /* [n] how many there are (may exceed HALF_CAP: the emission then reads the row) */
     u64 *big_list;
     u32 *n_big;
     u32 big_cap;
@@ -1142,8 +1142,20 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         }
         __syncthreads();
     }
-    for (u32 s = lane; s < d; s += 64)
-        if (hstate[sent[s]]) row[s] |= ADJ_FLAG;
+    u32 nfree = 0;
+    for (u32 s0 = 0; s0 < d; s0 += 64) {
+        const u32 s = s0 + lane;
+        const bool fl = (s < d) && hstate[sent[s]];
+        const bool fr = (s < d) && !fl;
+        if (fl) row[s] |= ADJ_FLAG;
+        const u64 mk = __ballot(fr);
+        if (a.half && fr) {
+            const u32 r = nfree + __popcll(mk & lane_mask_lt());
+            if (r < HALF_CAP) a.half[v * HALF_CAP + r] = row[s] & ~ADJ_FLAG;
+        }
+        nfree += __popcll(mk);
+    }
+    if (a.hcnt && lane == 0) a.hcnt[v] = nfree;
     __syncthreads();
 }
 
@@ -1153,6 +1165,7 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
  * processed. The sequential INPLAY/ELIMINATED logic is unchanged; a speculative row is simply not used if its neighbour
  * turns out to be eliminated. */
 struct TrNodeRegs {
+    u64 v;
     u64 vs;
     u32 d;
     u64 e; /* lane's entry (lane < d) */
@@ -1241,7 +1254,15 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         }
         __syncthreads();
     }
-    if (lane < d && hstate[sent]) a.adj[nd.vs + lane] = e | ADJ_FLAG;
+    const bool fl = lane < d && hstate[sent];
+    const bool fr = lane < d && !fl;
+    if (fl) a.adj[nd.vs + lane] = e | ADJ_FLAG;
+    const u64 mk = __ballot(fr);
+    if (a.half && fr) {
+        const u32 r = __popcll(mk & lane_mask_lt());
+        if (r < HALF_CAP) a.half[nd.v * HALF_CAP + r] = e;
+    }
+    if (a.hcnt && lane == 0) a.hcnt[nd.v] = __popcll(mk);
     __syncthreads();
 }
 
@@ -1264,6 +1285,7 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
     }
     auto load_node = [&](u64 it) {
         TrNodeRegs r;
+        r.v = a.v.q_lo + it;
         r.vs = 0;
         r.d = 0;
         r.e = 0;
@@ -1284,6 +1306,7 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
             TrNodeRegs nxt; /* in flight while `cur` is processed */
             if (it + 1 < cend) nxt = load_node(it + 1);
             else {
+                nxt.v = 0;
                 nxt.vs = 0;
                 nxt.d = 0;
                 nxt.e = 0;
@@ -1337,6 +1360,7 @@ struct EmitArgs {
     DiscoView v;
     const u64 *ref;
     const u64 *adj;
+    const u32 *hcnt; /* non-null: only nodes with more than HALF_CAP survivors (the others went through emit_half_kernel) */
     u64 *out_src;
     u64 *out_ent;
     u64 out_cap;
@@ -1358,6 +1382,7 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
     u64 cbeg = 0, cend = 0;
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend))
     for (u64 v = a.v.q_lo + cbeg; v < a.v.q_lo + cend; v++) {
+        if (a.hcnt && a.hcnt[v] <= HALF_CAP) continue;
         const u64 rv = a.ref[v];
         const u32 d = REF_DEG(rv);
         if (d == 0) continue;
@@ -1398,6 +1423,89 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
                     }
                 }
                 chunk_used += cnt;
+            }
+        }
+    }
+    close_chunk();
+}
+
+/* Emission from the half-edge lists (single GPU): lane = node. A node's few edges that survived its own marking sit in
+ * half[v][0..hcnt) (written by transitive_mark_kernel); the edge (v,w), v < w, survives iff its twin is among the
+ * survivors of w as well — one 32-byte gather instead of a binary search through the row of w. Nodes with more than
+ * HALF_CAP survivors (and neighbours of such nodes) take the row path: `wide` nodes are left to emit_kernel. */
+struct EmitHalfArgs {
+    DiscoView v;
+    const u64 *ref;
+    const u64 *adj;
+    const u64 *half;
+    const u32 *hcnt;
+    u64 *out_src;
+    u64 *out_ent;
+    u64 out_cap;
+    u64 *bump;
+};
+
+__global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
+{
+    const u32 lane = threadIdx.x;
+    u64 chunk_base = 0;
+    u32 chunk_used = EMIT_CHUNK;
+    bool have_chunk = false;
+    auto close_chunk = [&]() {
+        if (have_chunk)
+            for (u32 i = chunk_used + lane; i < EMIT_CHUNK; i += 64)
+                if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
+    };
+    const u64 nq = a.v.q_hi - a.v.q_lo;
+    /* a work item = 64 consecutive nodes */
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, (nq + 63) / 64, cbeg, cend))
+    for (u64 blk = cbeg; blk < cend; blk++) {
+        const u64 v = a.v.q_lo + blk * 64 + lane;
+        const bool live = v < a.v.q_hi;
+        const u32 cnt = live ? a.hcnt[v] : 0u;
+        const u32 Lv = live ? (u32)a.v.len[v] : 0u;
+#pragma unroll
+        for (u32 r = 0; r < HALF_CAP; r++) {
+            bool keep = false;
+            u64 e = 0;
+            if (cnt <= HALF_CAP && r < cnt) { /* wide nodes (cnt > HALF_CAP) are emitted by emit_kernel */
+                e = a.half[v * HALF_CAP + r];
+                const u64 w = ADJ_DST(e);
+                if (v < w) {
+                    const u64 twin = ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
+                    const u32 cw = a.hcnt[w];
+                    if (cw <= HALF_CAP) {
+                        const ulonglong2 *hw = (const ulonglong2 *)(a.half + w * HALF_CAP);
+                        const ulonglong2 h0 = hw[0], h1 = hw[1];
+                        keep = (cw > 0 && h0.x == twin) || (cw > 1 && h0.y == twin) || (cw > 2 && h1.x == twin) || (cw > 3 && h1.y == twin);
+                    } else { /* neighbour with many survivors: look the twin up in its row */
+                        const u64 rw = a.ref[w];
+                        const u64 *roww = a.adj + REF_POS(rw);
+                        const int ti = adj_find(roww, REF_DEG(rw), twin);
+                        keep = (ti >= 0) && !(roww[ti] & ADJ_FLAG);
+                    }
+                }
+            }
+            const u64 mk = __ballot(keep);
+            const u32 kc = __popcll(mk);
+            if (kc) {
+                if (chunk_used + kc > EMIT_CHUNK) {
+                    close_chunk();
+                    u64 base = 0;
+                    if (lane == 0) base = atomicAdd(a.bump, (u64)EMIT_CHUNK);
+                    chunk_base = __shfl(base, 0);
+                    chunk_used = 0;
+                    have_chunk = true;
+                }
+                if (keep) {
+                    const u64 pos = chunk_base + chunk_used + __popcll(mk & lane_mask_lt());
+                    if (pos < a.out_cap) {
+                        a.out_src[pos] = v;
+                        a.out_ent[pos] = e;
+                    }
+                }
+                chunk_used += kc;
             }
         }
     }
