@@ -107,6 +107,9 @@ struct disco_ctx {
     u64 *d_half = nullptr; /* [n][HALF_CAP] */
     u32 *d_hcnt = nullptr; /* [n] */
     bool use_half = false;
+    u64 *d_wide = nullptr; /* nodes with more than HALF_CAP surviving edges */
+    u32 *d_n_wide = nullptr;
+    u32 wide_cap = 0, n_wide = 0;
     u8 *d_out_valid = nullptr;
     u64 *d_out_pos = nullptr;
     u64 *d_out_src = nullptr, *d_out_ent = nullptr;
@@ -316,6 +319,9 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_flag, c->flag_cap);
     dev_free(c, &c->d_half, c->n * HALF_CAP);
     dev_free(c, &c->d_hcnt, c->n);
+    dev_free(c, &c->d_wide, c->wide_cap);
+    dev_free(c, &c->d_n_wide, 1);
+    c->wide_cap = 0;
     c->adj_total = c->adj_cap = c->flag_cap = 0;
     dev_free(c, &c->d_out_valid, c->valid_cap);
     dev_free(c, &c->d_out_pos, c->valid_cap + 1);
@@ -1044,9 +1050,18 @@ int disco_transitive_mark(disco_ctx *c)
         if (!c->d_half) CHK(dev_alloc(c, &c->d_half, c->n * HALF_CAP));
         if (!c->d_hcnt) CHK(dev_alloc(c, &c->d_hcnt, c->n));
         HIPCHK(c, hipMemsetAsync(c->d_hcnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+        if (!c->d_wide) {
+            c->wide_cap = (u32)std::min<u64>(c->n, c->n / 32 + 4096);
+            CHK(dev_alloc(c, &c->d_wide, c->wide_cap));
+            CHK(dev_alloc(c, &c->d_n_wide, 1));
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_n_wide, 0, sizeof(u32), c->stream));
         a.half = c->d_half;
         a.hcnt = c->d_hcnt;
     }
+    a.wide_list = c->d_wide;
+    a.n_wide = c->d_n_wide;
+    a.wide_cap = c->wide_cap;
     ph_begin(c, DISCO_PH_TRMARK);
     if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wq_grid(c, transitive_mark_kernel<false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
@@ -1081,6 +1096,10 @@ int disco_transitive_mark(disco_ctx *c)
         hipError_t e2 = hipStreamSynchronize(c->stream);
         dev_free(c, &scratch, (u64)g2 * per);
         if (e != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel<true>: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    c->n_wide = 0;
+    if (c->use_half) {
+        HIPCHK(c, hipMemcpy(&c->n_wide, c->d_n_wide, sizeof(u32), hipMemcpyDeviceToHost));
     }
     c->flags_pending = false;
     c->phase = 7;
@@ -1164,12 +1183,15 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.ref = c->d_adj_ref;
         a.adj = c->d_adj;
         a.hcnt = c->use_half ? c->d_hcnt : nullptr;
+        const bool listed = c->use_half && c->n_wide <= c->wide_cap; /* else the list overflowed: scan the whole range */
+        a.list = listed ? c->d_wide : nullptr;
+        a.n_list = listed ? c->n_wide : 0;
         a.out_src = c->d_out_src;
         a.out_ent = c->d_out_ent;
         a.out_cap = c->out_cap;
         a.bump = c->d_bump;
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-        if (nq) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(64), 0, c->stream, a);
+        if (nq && !(listed && c->n_wide == 0)) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(64), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
         u64 used = 0;
         HIPCHK(c, hipMemcpyAsync(&used, c->d_bump, sizeof(u64), hipMemcpyDeviceToHost, c->stream));

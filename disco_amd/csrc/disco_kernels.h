@@ -1085,6 +1085,9 @@ struct TrArgs {
     u64 *adj;      /* only the flag bit of the node's own row is written */
     u64 *half;     /* [n][HALF_CAP] entries not flagged from this node (first HALF_CAP in list order), or null */
     u32 *hcnt;     /* [n] how many there are (may exceed HALF_CAP: the emission then reads the row) */
+    u64 *wide_list; /* nodes with more than HALF_CAP survivors */
+    u32 *n_wide;
+    u32 wide_cap;
     u64 *big_list;
     u32 *n_big;
     u32 big_cap;
@@ -1155,7 +1158,13 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         }
         nfree += __popcll(mk);
     }
-    if (a.hcnt && lane == 0) a.hcnt[v] = nfree;
+    if (a.hcnt && lane == 0) {
+        a.hcnt[v] = nfree;
+        if (nfree > HALF_CAP) {
+            const u32 idx = atomicAdd(a.n_wide, 1u);
+            if (idx < a.wide_cap) a.wide_list[idx] = v;
+        }
+    }
     __syncthreads();
 }
 
@@ -1262,7 +1271,14 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         const u32 r = __popcll(mk & lane_mask_lt());
         if (r < HALF_CAP) a.half[nd.v * HALF_CAP + r] = e;
     }
-    if (a.hcnt && lane == 0) a.hcnt[nd.v] = __popcll(mk);
+    if (a.hcnt && lane == 0) {
+        const u32 nfree = __popcll(mk);
+        a.hcnt[nd.v] = nfree;
+        if (nfree > HALF_CAP) {
+            const u32 idx = atomicAdd(a.n_wide, 1u);
+            if (idx < a.wide_cap) a.wide_list[idx] = nd.v;
+        }
+    }
     __syncthreads();
 }
 
@@ -1361,6 +1377,8 @@ struct EmitArgs {
     const u64 *ref;
     const u64 *adj;
     const u32 *hcnt; /* non-null: only nodes with more than HALF_CAP survivors (the others went through emit_half_kernel) */
+    const u64 *list; /* non-null: the nodes to emit (n_list of them) instead of the whole query range */
+    u64 n_list;
     u64 *out_src;
     u64 *out_ent;
     u64 out_cap;
@@ -1380,8 +1398,9 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
                 if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
     };
     u64 cbeg = 0, cend = 0;
-    while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend))
-    for (u64 v = a.v.q_lo + cbeg; v < a.v.q_lo + cend; v++) {
+    while (wq_grab(a.v.wq, a.list ? a.n_list : a.v.q_hi - a.v.q_lo, cbeg, cend))
+    for (u64 it = cbeg; it < cend; it++) {
+        const u64 v = a.list ? a.list[it] : a.v.q_lo + it;
         if (a.hcnt && a.hcnt[v] <= HALF_CAP) continue;
         const u64 rv = a.ref[v];
         const u32 d = REF_DEG(rv);
