@@ -1221,9 +1221,17 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         sent = idx;
     }
     __syncthreads();
-    for (u32 i = 0; i < d; i++) { /* BG/OverlapGraph.cpp:693 list order */
-        const u32 si = (u32)__builtin_amdgcn_readlane((int)sent, (int)i);
-        if (hstate[si]) continue; /* :696 only INPLAY neighbours */
+    /* BG/OverlapGraph.cpp:693-696: walk the list in order, sweeping only neighbours that are still INPLAY when their turn
+     * comes. States only ever go INPLAY -> ELIMINATED, so "the next INPLAY slot after the one just swept, judged with the
+     * states as they are now" is exactly the sequential loop — found with one ballot instead of one LDS read per slot. */
+    int cur = -1;
+    for (;;) {
+        const bool inplay = (lane < d) && !hstate[sent];
+        u64 mk = __ballot(inplay);
+        if (cur >= 0) mk &= ~((2ull << cur) - 1ull); /* slots after cur */
+        if (!mk) break;
+        const u32 i = (u32)__ffsll((long long)mk) - 1u;
+        cur = (int)i;
         const u64 e1 = readlane_u64(e, i);
         const u32 type1 = ADJ_ORI(e1);
         u64 us;
