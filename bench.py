@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="run the sharded code path (RCCL collectives) even with one rank")
     return ap.parse_args()
 
 
@@ -106,7 +107,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_distributed
+    if sharded:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -118,22 +122,25 @@ def main():
     engine = distributed.HipEngine(g, device)
 
     info = {}
+    dist_timing = {} if os.environ.get("DISCO_DIST_TIMING") else None
 
     def step():
-        if world == 1:
+        if not sharded:
             g.run_graph()
         else:
-            info.update(distributed.distributed_step(engine))
+            info.update(distributed.distributed_step(engine, timing=dist_timing))
 
     def fence():
         g.synchronize()
         torch.cuda.synchronize(device)
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         step()
+    if dist_timing is not None:
+        dist_timing.clear()
     kern_ms = {"probe_kernel": [], "verify_kernel": []}
     fence()
     t0 = time.perf_counter()
@@ -152,8 +159,8 @@ def main():
 
     cnt = g.counters()
     phases = g.phase_ms()
-    e_pre = cnt["e_pre"] if world == 1 else info["e_pre"]
-    e_out = cnt["e_out"] if world == 1 else info["e_out"]
+    e_pre = cnt["e_pre"] if not sharded else info["e_pre"]
+    e_out = cnt["e_out"] if not sharded else info["e_out"]
     words_mean = float((args.read_len + 31) // 32)  # W of SURVEY.md §8: packed words per read (device rows are padded to 64 B)
     if world > 1:  # probe counters are per shard: sum them for the roofline bookkeeping
         v = torch.tensor([cnt["probes"], cnt["kmer_hits"]], dtype=torch.int64, device=device)
@@ -217,10 +224,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, spec)
         except Exception as e:  # the baseline is a reported extra; never lose the bench line over it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e}"}
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if dist_timing:
+            print("[dist timing, rank 0, ms summed over all steps]", {k: round(v, 1) for k, v in dist_timing.items()}, file=sys.stderr)
         print(json.dumps(out))
 
 

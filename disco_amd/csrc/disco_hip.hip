@@ -88,8 +88,9 @@ struct disco_ctx {
 
     /* edges */
     u64 *d_adj_ref = nullptr; /* [n] position | degree << 40 */
-    u64 *d_adj = nullptr;     /* entries: the hit buffer itself (single GPU) or an owned node-ordered array (imported / merged) */
-    bool adj_owned = false;
+    u64 *d_adj = nullptr;     /* entries: the hit buffer itself (single GPU) or d_adj_own (imported / merged, node-ordered) */
+    u64 *d_adj_own = nullptr; /* kept across passes: re-allocating GBs every pass costs more than the kernels */
+    u64 *d_start_tmp = nullptr; /* [n+1] scan scratch of export / import */
     u64 adj_total = 0; /* directed edges the context currently addresses */
     u64 adj_cap = 0, flag_cap = 0, out_cap = 0, valid_cap = 0, bkt_cap = 0, ent_cap = 0; /* buffers are kept across passes */
     bool flags_pending = false; /* sharded flow: gathered flag bytes wait to be OR-ed into the entries */
@@ -309,9 +310,9 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_contained, c->n);
     dev_free(c, &c->d_cbits, c->n / 64 + 1);
     dev_free(c, &c->d_adj_ref, c->n);
-    if (c->adj_owned) dev_free(c, &c->d_adj, c->adj_cap);
+    dev_free(c, &c->d_adj_own, c->adj_cap);
+    dev_free(c, &c->d_start_tmp, c->n + 1);
     c->d_adj = nullptr;
-    c->adj_owned = false;
     dev_free(c, &c->d_extra_cnt, c->n);
     dev_free(c, &c->d_extra_node, c->extra_cap);
     dev_free(c, &c->d_extra_key, c->extra_cap);
@@ -783,9 +784,6 @@ static int select_edges(disco_ctx *c)
         fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
                 (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
     /* the finds stay where they are: the hit buffer IS the adjacency array of the local rows */
-    if (c->adj_owned) dev_free(c, &c->d_adj, c->adj_cap);
-    c->adj_owned = false;
-    c->adj_cap = 0;
     c->d_adj = c->d_hits;
     c->adj_total = c->h_ctr[CTR_ADJ_TOTAL];
     c->adj_imported = false;
@@ -906,9 +904,9 @@ static int merge_extras(disco_ctx *c)
     dev_free(c, &new_deg, c->n);
     dev_free(c, &fill, c->n);
     dev_free(c, &new_start, c->n + 1);
-    if (c->adj_owned) dev_free(c, &c->d_adj, c->adj_cap);
+    dev_free(c, &c->d_adj_own, c->adj_cap);
+    c->d_adj_own = new_adj;
     c->d_adj = new_adj;
-    c->adj_owned = true;
     c->adj_cap = std::max<u64>(total, 1);
     c->adj_total = total;
     c->n_extra = 0;
@@ -971,14 +969,13 @@ int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
     if (nq) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_ref, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
     HIPCHK(c, hipGetLastError());
     if (nq && c->adj_total && d_entries_u64) { /* compact the local rows into node order */
-        u64 *start = nullptr;
-        CHK(dev_alloc(c, &start, nq + 1));
+        if (!c->d_start_tmp) CHK(dev_alloc(c, &c->d_start_tmp, c->n + 1));
+        u64 *start = c->d_start_tmp;
         u64 total = 0;
         int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32, nq, start, true, &total);
         if (rc == DISCO_OK && total != c->adj_total) rc = fail(c, DISCO_E_STATE, "disco_export_adjacency: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
         if (rc == DISCO_OK) hipLaunchKernelGGL(rows_gather_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, c->q_lo, c->q_hi, start, (u64 *)d_entries_u64);
         hipError_t e = hipStreamSynchronize(c->stream);
-        dev_free(c, &start, nq + 1);
         CHK(rc);
         if (e != hipSuccess) return fail(c, DISCO_E_HIP, "disco_export_adjacency: %s", hipGetErrorString(e));
     }
@@ -993,28 +990,19 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     if (!c || !d_deg_u32_all) return DISCO_E_ARG;
     if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_import_adjacency: select edges first");
     HIPCHK(c, hipSetDevice(c->device));
-    u64 *start = nullptr;
-    CHK(dev_alloc(c, &start, c->n + 1));
+    if (!c->d_start_tmp) CHK(dev_alloc(c, &c->d_start_tmp, c->n + 1));
+    u64 *start = c->d_start_tmp;
     u64 total = 0;
-    int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, start, true, &total);
-    if (rc == DISCO_OK && total != n_entries_all)
-        rc = fail(c, DISCO_E_ARG, "disco_import_adjacency: degrees sum to %llu but %llu entries were passed", (unsigned long long)total, (unsigned long long)n_entries_all);
-    if (rc != DISCO_OK) {
-        dev_free(c, &start, c->n + 1);
-        return rc;
-    }
-    if (!c->adj_owned) {
-        c->d_adj = nullptr;
-        c->adj_cap = 0;
-    }
-    c->adj_owned = true;
-    CHK(ensure_cap(c, &c->d_adj, &c->adj_cap, total));
+    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, start, true, &total)));
+    if (total != n_entries_all)
+        return fail(c, DISCO_E_ARG, "disco_import_adjacency: degrees sum to %llu but %llu entries were passed", (unsigned long long)total, (unsigned long long)n_entries_all);
+    CHK(ensure_cap(c, &c->d_adj_own, &c->adj_cap, total));
+    c->d_adj = c->d_adj_own;
     c->adj_total = total;
     if (total) HIPCHK(c, hipMemcpyAsync(c->d_adj, d_entries_u64_all, total * 8, hipMemcpyDeviceToDevice, c->stream));
     if (c->n) hipLaunchKernelGGL(ref_from_start_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, start, (const u32 *)d_deg_u32_all, c->n, c->d_adj_ref);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    dev_free(c, &start, c->n + 1);
     c->adj_imported = true;
     c->phase = 5;
     return DISCO_OK;

@@ -45,9 +45,22 @@ def allgather_ragged(t: torch.Tensor, group=None):
     return out, counts
 
 
-def distributed_step(engine, group=None):
+def distributed_step(engine, group=None, timing=None):
     """one BuildGraph pass over the engine's resident reads, sharded over the ranks of `group`.
-    Returns dict(e_pre, e_out_local, e_out, n_contained, asymmetric_pairs)."""
+    Returns dict(e_pre, e_out_local, e_out, n_contained, asymmetric_pairs). `timing`: optional dict that receives wall
+    milliseconds per stage of this rank."""
+    import time as _time
+
+    t_prev = [_time.perf_counter()]
+
+    def lap(name):
+        if timing is not None:
+            if hasattr(engine, "device"):
+                torch.cuda.synchronize(engine.device)
+            t = _time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + (t - t_prev[0]) * 1e3
+            t_prev[0] = t
+
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = engine.num_reads
@@ -55,30 +68,40 @@ def distributed_step(engine, group=None):
     engine.build_index()              # replicated: ~2 % of the work
     engine.set_query_range(lo, hi)
     engine.probe()
+    lap("index+probe")
     # (1) containment: smallest key wins across ranks
     keys = engine.get_keys()
     dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
     engine.set_keys(keys)
+    lap("allreduce_keys")
     n_contained = engine.mark_contained()
     engine.select_edges()
+    lap("contain+select")
     # (2) adjacency of every shard to everybody: the reduction of node v reads the lists of v's neighbours
     deg, rows = engine.export_adjacency()
+    lap("export")
     deg_all, _ = allgather_ragged(deg, group)
     rows_all, _ = allgather_ragged(rows, group)
+    lap("allgather_adjacency")
     engine.import_adjacency(deg_all, rows_all)
+    lap("import")
     asym = torch.tensor([engine.symmetrize(False)], dtype=torch.int64, device=keys.device)
     dist.all_reduce(asym, op=dist.ReduceOp.SUM, group=group)
     if int(asym.item()):
         # pairs found from one side only (order-dependent regime of the reference): every rank completes all lists
         engine.symmetrize(True)
         engine.merge_extras()
+    lap("symmetrize")
     engine.transitive_mark()
+    lap("mark")
     # (3) an edge survives only if it is flagged from neither end -> everybody needs everybody's flags
     flags_local, slot_lo, slot_hi, total = engine.get_flags()
     flags_all, counts = allgather_ragged(flags_local, group)
     assert flags_all.numel() == total, (flags_all.numel(), total)
     engine.set_flags(flags_all)
+    lap("allgather_flags")
     e_out_local = engine.emit_edges()
+    lap("emit")
     tot = torch.tensor([e_out_local], dtype=torch.int64, device=keys.device)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     return dict(e_pre=total // 2, e_out_local=e_out_local, e_out=int(tot.item()), n_contained=n_contained,
