@@ -72,6 +72,9 @@ ABI = [
     ("disco_adjacency_size", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("disco_export_adjacency", C.c_int, [_P, _P, _P]),
     ("disco_import_adjacency", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("disco_adopt_adjacency", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
+    ("disco_half_lists", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("disco_half_complete", C.c_int, [_P, C.c_int]),
     ("disco_tr_flags", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("disco_fetch_contained", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_fetch_edges", C.c_int64, [_P, _P, C.c_uint64]),
@@ -249,6 +252,17 @@ class BuildGraph:
 
     def import_adjacency(self, d_deg_all_ptr: int, d_entries_all_ptr: int, n_entries: int):
         self._chk(self.L.disco_import_adjacency(self._h, _P(d_deg_all_ptr), _P(d_entries_all_ptr), n_entries))
+
+    def adopt_adjacency(self, d_deg_all_ptr: int, d_rows_padded_ptr: int, per_rank_nodes: int, max_per_rank: int, world: int):
+        self._chk(self.L.disco_adopt_adjacency(self._h, _P(d_deg_all_ptr), _P(d_rows_padded_ptr), per_rank_nodes, max_per_rank, world))
+
+    def half_lists(self):
+        h, c, w = _P(), _P(), C.c_uint64()
+        self._chk(self.L.disco_half_lists(self._h, C.byref(h), C.byref(c), C.byref(w)))
+        return h.value, c.value, w.value
+
+    def half_complete(self, complete: bool = True):
+        self._chk(self.L.disco_half_complete(self._h, 1 if complete else 0))
 
     def tr_flags(self):
         p, lo, hi, tot = _P(), C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -95,6 +95,9 @@ struct disco_ctx {
     u64 adj_cap = 0, flag_cap = 0, out_cap = 0, valid_cap = 0, bkt_cap = 0, ent_cap = 0; /* buffers are kept across passes */
     bool flags_pending = false; /* sharded flow: gathered flag bytes wait to be OR-ed into the entries */
     bool adj_imported = false;
+    u64 adj_span = 0;          /* size of the position space of d_adj in the sharded flow (compact: adj_total, padded: world*max) */
+    bool half_complete = false; /* half/hcnt hold the survivor lists of ALL nodes */
+    u64 start_cap = 0;
     u32 *d_extra_cnt = nullptr;
     u64 *d_extra_node = nullptr, *d_extra_key = nullptr;
     u32 *d_n_extra = nullptr;
@@ -311,7 +314,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_cbits, c->n / 64 + 1);
     dev_free(c, &c->d_adj_ref, c->n);
     dev_free(c, &c->d_adj_own, c->adj_cap);
-    dev_free(c, &c->d_start_tmp, c->n + 1);
+    dev_free(c, &c->d_start_tmp, c->start_cap);
+    c->start_cap = 0;
     c->d_adj = nullptr;
     dev_free(c, &c->d_extra_cnt, c->n);
     dev_free(c, &c->d_extra_node, c->extra_cap);
@@ -787,6 +791,8 @@ static int select_edges(disco_ctx *c)
     c->d_adj = c->d_hits;
     c->adj_total = c->h_ctr[CTR_ADJ_TOTAL];
     c->adj_imported = false;
+    c->adj_span = 0;
+    c->half_complete = true; /* one rank: the local lists are all the lists */
     c->ph_ms[DISCO_PH_CSR] = 0;
     c->phase = 5;
     return DISCO_OK;
@@ -909,6 +915,7 @@ static int merge_extras(disco_ctx *c)
     c->d_adj = new_adj;
     c->adj_cap = std::max<u64>(total, 1);
     c->adj_total = total;
+    c->adj_span = total; /* compact, node ordered */
     c->n_extra = 0;
     return DISCO_OK;
 }
@@ -969,7 +976,7 @@ int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
     if (nq) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_ref, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
     HIPCHK(c, hipGetLastError());
     if (nq && c->adj_total && d_entries_u64) { /* compact the local rows into node order */
-        if (!c->d_start_tmp) CHK(dev_alloc(c, &c->d_start_tmp, c->n + 1));
+        CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, c->n + 1));
         u64 *start = c->d_start_tmp;
         u64 total = 0;
         int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32, nq, start, true, &total);
@@ -990,7 +997,7 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     if (!c || !d_deg_u32_all) return DISCO_E_ARG;
     if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_import_adjacency: select edges first");
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->d_start_tmp) CHK(dev_alloc(c, &c->d_start_tmp, c->n + 1));
+    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, c->n + 1));
     u64 *start = c->d_start_tmp;
     u64 total = 0;
     CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, c->n, start, true, &total)));
@@ -1004,7 +1011,56 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->adj_imported = true;
+    c->adj_span = total;
+    c->half_complete = false;
     c->phase = 5;
+    return DISCO_OK;
+}
+
+/* Sharded flow without copies: the caller all-gathers the shards IN PLACE into rank-major padded device buffers and the
+ * context addresses them where they lie. d_deg_u32_all[v] = degree of node v (world*per entries, v = r*per + i);
+ * d_rows_u64_padded[r*max_per_rank ...] = rows of rank r's nodes in node order. The buffers stay the caller's and must
+ * live until the pass is over; transitive marking sets flag bits in them. */
+int disco_adopt_adjacency(disco_ctx *c, const void *d_deg_u32_all, void *d_rows_u64_padded, uint64_t per_rank_nodes, uint64_t max_per_rank, uint32_t world)
+{
+    if (!c || !d_deg_u32_all || !world || !per_rank_nodes) return DISCO_E_ARG;
+    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_adopt_adjacency: select edges first");
+    if ((u64)world * per_rank_nodes < c->n) return fail(c, DISCO_E_ARG, "disco_adopt_adjacency: world*per (%llu) < reads (%llu)", (unsigned long long)((u64)world * per_rank_nodes), (unsigned long long)c->n);
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 slots = (u64)world * per_rank_nodes;
+    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, slots + 1));
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, slots, c->d_start_tmp, true, &total)));
+    if (c->n) hipLaunchKernelGGL(ref_from_padded_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_start_tmp, (const u32 *)d_deg_u32_all, c->n, per_rank_nodes, max_per_rank, c->d_adj_ref);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->d_adj = (u64 *)d_rows_u64_padded;
+    c->adj_total = total;
+    c->adj_span = (u64)world * max_per_rank;
+    c->adj_imported = true;
+    c->half_complete = false;
+    c->phase = 5;
+    return DISCO_OK;
+}
+
+/* survivor lists of disco_transitive_mark: half = u64[n][4] (first 4 unflagged entries of a node in list order),
+ * hcnt = u32[n]; n_wide = nodes of the local range with more than 4. In the sharded flow ranks all-gather their ranges of
+ * both arrays and then call disco_half_complete(ctx, 1); the emission then needs neither rows nor flags of other ranks. */
+int disco_half_lists(disco_ctx *c, void **d_half, void **d_hcnt, uint64_t *n_wide)
+{
+    if (!c || !d_half || !d_hcnt || !n_wide) return DISCO_E_ARG;
+    if (c->phase < 7 || !c->use_half) return fail(c, DISCO_E_STATE, "disco_half_lists: run disco_transitive_mark first (survivor lists enabled)");
+    *d_half = c->d_half;
+    *d_hcnt = c->d_hcnt;
+    *n_wide = c->n_wide;
+    return DISCO_OK;
+}
+
+int disco_half_complete(disco_ctx *c, int complete)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_half_complete: run disco_transitive_mark first");
+    c->half_complete = complete != 0;
     return DISCO_OK;
 }
 
@@ -1033,7 +1089,7 @@ int disco_transitive_mark(disco_ctx *c)
     a.hcap = 0;
     a.half = nullptr;
     a.hcnt = nullptr;
-    c->use_half = !c->adj_imported && !getenv("DISCO_NO_HALF"); /* the survivors' lists of remote nodes are not exchanged */
+    c->use_half = !getenv("DISCO_NO_HALF");
     if (c->use_half) {
         if (!c->d_half) CHK(dev_alloc(c, &c->d_half, c->n * HALF_CAP));
         if (!c->d_hcnt) CHK(dev_alloc(c, &c->d_hcnt, c->n));
@@ -1103,19 +1159,17 @@ int disco_tr_flags(disco_ctx *c, void **d_flags, uint64_t *slot_lo, uint64_t *sl
     if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_tr_flags: run disco_transitive_mark first");
     if (!c->adj_imported) return fail(c, DISCO_E_STATE, "disco_tr_flags: only meaningful after disco_import_adjacency (the flags of a single-GPU run live in the entries)");
     HIPCHK(c, hipSetDevice(c->device));
-    u64 lo = c->adj_total, hi = c->adj_total, r = 0;
-    if (c->q_lo < c->n) {
+    /* the local rows are contiguous in both sharded layouts: from the first local node's position to the end of the last one */
+    u64 lo = 0, hi = 0, r = 0;
+    if (c->q_lo < c->q_hi) {
         HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + c->q_lo, 8, hipMemcpyDeviceToHost));
         lo = REF_POS(r);
+        HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + (c->q_hi - 1), 8, hipMemcpyDeviceToHost));
+        hi = REF_POS(r) + REF_DEG(r);
     }
-    if (c->q_hi < c->n) {
-        HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + c->q_hi, 8, hipMemcpyDeviceToHost));
-        hi = REF_POS(r);
-    }
-    if (c->q_lo >= c->q_hi) lo = hi;
-    CHK(ensure_cap(c, &c->d_flag, &c->flag_cap, c->adj_total));
+    CHK(ensure_cap(c, &c->d_flag, &c->flag_cap, c->adj_span));
     if (!c->flags_pending) {
-        HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_total, 1), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_span, 1), c->stream));
         if (hi > lo) hipLaunchKernelGGL(flags_extract_kernel, dim3(flat_grid(c, hi - lo)), dim3(256), 0, c->stream, c->d_adj, lo, hi, c->d_flag);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1124,7 +1178,7 @@ int disco_tr_flags(disco_ctx *c, void **d_flags, uint64_t *slot_lo, uint64_t *sl
     *d_flags = c->d_flag;
     *slot_lo = lo;
     *slot_hi = hi;
-    *total = c->adj_total;
+    *total = c->adj_span;
     return DISCO_OK;
 }
 
@@ -1136,7 +1190,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     const u64 nq = c->q_hi - c->q_lo;
     ph_begin(c, DISCO_PH_EMIT);
     if (c->flags_pending) { /* gathered flags of all ranks -> entries */
-        if (c->adj_total) hipLaunchKernelGGL(flags_apply_kernel, dim3(flat_grid(c, c->adj_total)), dim3(256), 0, c->stream, c->d_adj, c->adj_total, c->d_flag);
+        if (c->adj_span) hipLaunchKernelGGL(flags_apply_kernel, dim3(flat_grid(c, c->adj_span)), dim3(256), 0, c->stream, c->d_adj, c->adj_span, c->d_flag);
         c->flags_pending = false;
     }
     const int grid = wq_grid(c, emit_kernel, nq, "DISCO_EMIT_WAVES");
@@ -1152,7 +1206,8 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             c->out_cap = want;
         }
         HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
-        if (c->use_half && nq) {
+        const bool half_emit = c->use_half && c->half_complete; /* else: rows + flags of every node (sharded fallback) */
+        if (half_emit && nq) {
             EmitHalfArgs h;
             h.v = view(c);
             h.ref = c->d_adj_ref;
@@ -1170,8 +1225,8 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.v = view(c);
         a.ref = c->d_adj_ref;
         a.adj = c->d_adj;
-        a.hcnt = c->use_half ? c->d_hcnt : nullptr;
-        const bool listed = c->use_half && c->n_wide <= c->wide_cap; /* else the list overflowed: scan the whole range */
+        a.hcnt = half_emit ? c->d_hcnt : nullptr;
+        const bool listed = half_emit && c->n_wide <= c->wide_cap; /* else the list overflowed: scan the whole range */
         a.list = listed ? c->d_wide : nullptr;
         a.n_list = listed ? c->n_wide : 0;
         a.out_src = c->d_out_src;

@@ -923,6 +923,17 @@ __global__ void ref_from_start_kernel(const u64 *__restrict__ start, const u32 *
     for (; i < n; i += (u64)gridDim.x * blockDim.x) ref[i] = REF_MAKE(start[i], deg[i]);
 }
 
+/* rank-major padded adjacency (sharded flow): the rows of rank r = nodes [r*per, (r+1)*per) sit in node order at
+ * rows[r*mx ...]; gstart = exclusive scan of the degrees over all world*per node slots */
+__global__ void ref_from_padded_kernel(const u64 *__restrict__ gstart, const u32 *__restrict__ deg, u64 n, u64 per, u64 mx, u64 *__restrict__ ref)
+{
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; v < n; v += (u64)gridDim.x * blockDim.x) {
+        const u64 r = v / per;
+        ref[v] = REF_MAKE(r * mx + (gstart[v] - gstart[r * per]), deg[v]);
+    }
+}
+
 /* rows of the nodes [lo,hi) copied into node order: dst[dst_start[v-lo] + i] (export for the all-gather; flags stripped) */
 __global__ void __launch_bounds__(64) rows_gather_kernel(const u64 *__restrict__ adj, const u64 *__restrict__ ref, u64 lo, u64 hi,
                                                          const u64 *__restrict__ dst_start, u64 *__restrict__ dst)

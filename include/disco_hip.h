@@ -162,7 +162,19 @@ int disco_contain_keys(disco_ctx *ctx, void **d_keys, uint64_t *n);
 int disco_adjacency_size(disco_ctx *ctx, uint64_t *n_entries);
 int disco_export_adjacency(disco_ctx *ctx, void *d_deg_u32, void *d_entries_u64);
 int disco_import_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all);
-/* sharded flow only (after disco_import_adjacency): transitive flags as uint8 per slot of the gathered adjacency (`total`
+/* sharded flow without copies: the caller all-gathers the shards IN PLACE into rank-major padded device buffers
+ * (d_deg_u32_all[v], v = r*per_rank_nodes + i; rows of rank r in node order at d_rows_u64_padded[r*max_per_rank ...]) and the
+ * context addresses them where they lie (caller-owned, must outlive the pass; marking sets flag bits in them). */
+int disco_adopt_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, void *d_rows_u64_padded, uint64_t per_rank_nodes,
+                          uint64_t max_per_rank, uint32_t world);
+/* survivor lists written by disco_transitive_mark: half = uint64[n][4] (the first 4 edges of a node not flagged from its own
+ * end, list order), hcnt = uint32[n] (how many there are), n_wide = local nodes with more than 4. Ranks all-gather their
+ * node ranges of both arrays into these buffers and call disco_half_complete(ctx, 1): the emission then needs neither the
+ * rows nor the flags of other ranks (an edge survives iff it is among the survivors of BOTH ends). If any rank has wide
+ * nodes, exchange the flags instead (disco_tr_flags). */
+int disco_half_lists(disco_ctx *ctx, void **d_half, void **d_hcnt, uint64_t *n_wide);
+int disco_half_complete(disco_ctx *ctx, int complete);
+/* sharded flow only (after disco_import_adjacency / disco_adopt_adjacency): transitive flags as uint8 per slot of the gathered adjacency (`total`
  * slots). This rank computed [slot_lo, slot_hi); ranks all-gather those byte ranges in place between
  * disco_transitive_mark and disco_emit_edges, because an edge survives only if it is flagged from neither end
  * (BG/OverlapGraph.cpp:717-718 flags the twin too). On a single GPU the flag is a bit of the entry and nothing is exchanged. */
