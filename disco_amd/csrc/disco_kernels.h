@@ -526,15 +526,18 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
     const u32 lane = threadIdx.x;
     const int S = staged ? VERIFY_SW : a.v.S, k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
-    const u64 stride = 1;
 
-    /* 3-stage software pipeline over the reads of this wave: while read t is verified, the candidates of read t+1 and the
-     * row header of read t+2 are already in flight, so each read exposes ONE memory latency (its candidate rows) */
+    /* 4-stage software pipeline over the reads of this wave: while read t is verified from registers, the candidate ROWS of
+     * read t+1, the candidate list of read t+2 and the row header of read t+3 are in flight, so the random row fetch — the
+     * one long latency of this kernel — overlaps the compare work of the previous read */
     struct Meta {
         u32 c;
         int L;
         u64 rs;
         u64 aw; /* lane < S: word `lane` of the read's own row */
+    };
+    struct Rows {
+        ulonglong2 r0, r1, r2, r3;
     };
     u64 cbeg = 0, cend = 0;
     auto load_meta = [&](u64 A) {
@@ -551,14 +554,29 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         }
         return mt;
     };
+    auto load_cands = [&](const Meta &mt) { return (lane < mt.c) ? a.hits[mt.rs + lane] : 0ull; };
+    auto load_rows = [&](const Meta &mt, u64 h) {
+        Rows r;
+        r.r0 = r.r1 = r.r2 = r.r3 = make_ulonglong2(0, 0);
+        if (staged && lane < mt.c) { /* four independent 16-byte loads of the 64-byte row */
+            const ulonglong2 *g2 = (const ulonglong2 *)(a.v.reads + HIT_ID(h) * S);
+            r.r0 = g2[0];
+            r.r1 = g2[1];
+            r.r2 = g2[2];
+            r.r3 = g2[3];
+        }
+        return r;
+    };
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
     const u64 A_first = a.v.q_lo + cbeg;
-    Meta m0 = load_meta(A_first), m1 = load_meta(A_first + stride);
-    u64 h0 = (lane < m0.c) ? a.hits[m0.rs + lane] : 0ull;
+    Meta m0 = load_meta(A_first), m1 = load_meta(A_first + 1), m2 = load_meta(A_first + 2);
+    u64 h0 = load_cands(m0), h1 = load_cands(m1);
+    Rows R0 = load_rows(m0, h0);
 
-    for (u64 A = A_first; A < a.v.q_lo + cend; A += stride) {
-        const Meta m2 = load_meta(A + 2 * stride);
-        const u64 h1 = (lane < m1.c) ? a.hits[m1.rs + lane] : 0ull;
+    for (u64 A = A_first; A < a.v.q_lo + cend; A++) {
+        const Meta m3 = load_meta(A + 3);
+        const u64 h2 = load_cands(m2);
+        const Rows R1 = load_rows(m1, h1);
         const u32 c = m0.c;
         if (c != 0) {
             u64 *row = a.hits + m0.rs;
@@ -576,12 +594,12 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                 if (i < c) {
                     h = (i0 == 0) ? h0 : row[i];
                     gb = a.v.reads + HIT_ID(h) * S;
-                    if (staged) { /* four independent 16-byte loads, then everything else is LDS */
-                        const ulonglong2 *g2 = (const ulonglong2 *)gb;
-                        const ulonglong2 r0 = g2[0], r1 = g2[1], r2 = g2[2], r3 = g2[3];
+                    if (staged) {
+                        Rows r = R0;
+                        if (i0 != 0) r = load_rows(m0, h); /* rows beyond the first 64 candidates are fetched on the spot */
                         u64 *sb = s_b + lane * (VERIFY_SW + 1);
-                        sb[0] = r0.x; sb[1] = r0.y; sb[2] = r1.x; sb[3] = r1.y;
-                        sb[4] = r2.x; sb[5] = r2.y; sb[6] = r3.x; sb[7] = r3.y;
+                        sb[0] = r.r0.x; sb[1] = r.r0.y; sb[2] = r.r1.x; sb[3] = r.r1.y;
+                        sb[4] = r.r2.x; sb[5] = r.r2.y; sb[6] = r.r3.x; sb[7] = r.r3.y;
                     }
                 }
                 const u64 *pb = staged ? (const u64 *)(s_b + lane * (VERIFY_SW + 1)) : gb;
@@ -630,7 +648,10 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         }
         m0 = m1;
         m1 = m2;
+        m2 = m3;
         h0 = h1;
+        h1 = h2;
+        R0 = R1;
     }
     }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
