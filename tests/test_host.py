@@ -129,3 +129,49 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
     # re-running the same command is a no-op (BG/main.cpp:48-52)
     p2 = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p2.returncode == 0 and "Graph already exists" in p2.stdout
+
+
+def _parsimplify(edge_file, out_file, min_ovl):
+    exe = os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref")
+    p = subprocess.run([exe, edge_file, out_file, str(min_ovl), "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout[-2000:]
+    comps = []
+    for line in open(out_file):
+        f = line.rstrip("\n").split("\t")
+        if len(f) < 3:
+            continue
+        ids = {int(f[0]), int(f[1])}
+        if len(f) > 3:
+            ids |= {int(t.split(",")[0]) for t in f[3].strip("()").split(")(") if t}
+        comps.append(frozenset(ids))
+    return sorted(comps, key=lambda s: (len(s), min(s)))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (refrun.available() and os.path.exists(os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref"))),
+                    reason="prebuilt reference binaries (make -C oracle ref ref_parsimplify) not present")
+def test_files_load_in_the_reference_parsimplify(tmp_path):
+    """loader compatibility with the immediate consumer: the reference's own parsimplify contracts the
+    drop-in's edge file into the same composite edges as it does the reference buildG's edge file"""
+    from disco_amd import readgen
+
+    build.build_host()
+    # two contigs, mixed lengths -> several composite edges, contained reads, both strands
+    spec = readgen.GenSpec.coverage(seed=77, n_reads=6000, read_len=120, cov=18.0, n_contigs=3, len_max=180)
+    fa = str(tmp_path / "r.fasta")
+    readgen.write_fasta(fa, readgen.generate_reads(spec))
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\n")
+    ours = str(tmp_path / "ours")
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-se", fa, "-f", ours, "-p", str(cfg), "-t", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    ref = refrun.run_reference([fa], 40, threads=1, workdir=str(tmp_path / "ref") if os.makedirs(tmp_path / "ref", exist_ok=True) is None else None)
+    a = _parsimplify(ours + "_0_parGraph.txt", str(tmp_path / "ours_simple.txt"), 40)
+    b = _parsimplify(ref["prefix"] + "_0_parGraph.txt", str(tmp_path / "ref_simple.txt"), 40)
+    assert len(a) > 1 and a == b
+    # and with several partial-graph files every file loads
+    ours3 = str(tmp_path / "ours3")
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-se", fa, "-f", ours3, "-p", str(cfg), "-t", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    for t in range(3):
+        _parsimplify(f"{ours3}_{t}_parGraph.txt", str(tmp_path / f"ours3_{t}.txt"), 40)
