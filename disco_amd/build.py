@@ -62,6 +62,13 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    gen = os.path.join(HERE, "bin", "readgen")
+    gsrc = [os.path.join(HERE, "host", "readgen_main.cpp"), os.path.join(HERE, "csrc", "readgen.h")]
+    if force or _stale(gen, gsrc):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", gen, gsrc[0]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return BUILDG
 
 
