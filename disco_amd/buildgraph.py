@@ -50,6 +50,8 @@ ABI = [
     ("disco_set_stream", C.c_int, [_P, _P]),
     ("disco_synchronize", C.c_int, [_P]),
     ("disco_pack_ascii", C.c_int, [C.c_char_p, C.c_uint32, _P]),
+    ("disco_host_alloc", _P, [C.c_size_t]),
+    ("disco_host_free", None, [_P]),
     ("disco_upload_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
     ("disco_adopt_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
     ("disco_generate_reads", C.c_int, [_P, C.POINTER(GenSpecABI)]),

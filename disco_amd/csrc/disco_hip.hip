@@ -461,6 +461,18 @@ int disco_pack_ascii(const char *seq, uint32_t len, uint64_t *out_words)
     return DISCO_OK;
 }
 
+void *disco_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void disco_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride)
 {
     if (n >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "more than 2^31 reads per context are not supported");

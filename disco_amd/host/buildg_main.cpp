@@ -134,7 +134,10 @@ int main(int argc, char **argv)
     auto t0 = Clock::now();
     disco::ReadSet rs;
     std::string err;
-    if (!disco::load_reads(pe, se, min_overlap, threads, rs, err)) return die(err);
+    disco::HostAlloc pinned;
+    pinned.alloc = disco_host_alloc;
+    pinned.free = disco_host_free;
+    if (!disco::load_reads(pe, se, min_overlap, threads, rs, err, pinned)) return die(err);
     for (auto &fr : rs.files) {
         std::cout << "File name: " << fr.name << "\n"
                   << "  " << fr.good << " good reads in current dataset.\n  " << fr.bad << " bad reads in current dataset.\n  "
@@ -151,7 +154,7 @@ int main(int argc, char **argv)
     disco_params prm{min_overlap, 4, 0, 0};
     disco_ctx *ctx = nullptr;
     if (disco_create(gpu, &prm, &ctx) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
-    DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed.data(), rs.stride_words, rs.len.data(), rs.size()));
+    DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed, rs.stride_words, rs.len.data(), rs.size()));
     const double t_h2d = secs(t0);
     t0 = Clock::now();
     DISCO_CALL(ctx, disco_build_index(ctx));

@@ -1,7 +1,22 @@
-/* fastx.cpp — see fastx.h. Single pass over each input: split -> filter (parallel) -> pack (parallel). */
+/* fastx.cpp — see fastx.h.
+ *
+ * One parallel pass per input file (the reference reads every input three times, serially:
+ * BG/Dataset.cpp:161-380, BG/HashTable.cpp:119-337):
+ *   the file is mapped, cut into byte ranges, every thread finds the records that START in its range, cleans them
+ *   (newlines out, upper case), runs the read filter and remembers (good, length); a prefix sum over the threads gives
+ *   every good read its id (= rank in file order) and every record its file index; a second parallel sweep packs the good
+ *   reads 2-bit into pinned host memory at their final place.
+ * Exactness: the FASTA fast path requires every '>' of the file to be the first byte of a line (then "record = header line
+ * + everything up to the next '>'", BG/Dataset.cpp:270-281, is decidable locally); any other file falls back to the
+ * sequential splitter below, which follows the reference's getline calls literally.
+ */
 #include "fastx.h"
 
+#include <fcntl.h>
 #include <omp.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -40,7 +55,20 @@ size_t covered_by(const char *s, size_t n, const char *motif, size_t m)
     return hits * m;
 }
 
-bool slurp(const std::string &path, std::string &data, std::string &err)
+/* an input file in memory: mmap for plain files, a heap buffer for .gz */
+struct Blob {
+    const char *data = nullptr;
+    size_t n = 0;
+    std::string owned;
+    void *map = nullptr;
+    size_t map_len = 0;
+    ~Blob()
+    {
+        if (map) munmap(map, map_len);
+    }
+};
+
+bool load_blob(const std::string &path, Blob &b, std::string &err)
 {
     const bool gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0; /* BG/Dataset.cpp:167 */
     if (gz) {
@@ -49,36 +77,53 @@ bool slurp(const std::string &path, std::string &data, std::string &err)
             err = "Unable to open file: " + path;
             return false;
         }
-        char buf[1 << 16];
+        gzbuffer(f, 1 << 20);
+        std::vector<char> buf(1 << 22);
         int got;
-        while ((got = gzread(f, buf, sizeof buf)) > 0) data.append(buf, (size_t)got);
+        while ((got = gzread(f, buf.data(), (unsigned)buf.size())) > 0) b.owned.append(buf.data(), (size_t)got);
         gzclose(f);
+        b.data = b.owned.data();
+        b.n = b.owned.size();
         return true;
     }
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) {
         err = "Unable to open file: " + path;
         return false;
     }
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    data.resize(sz > 0 ? (size_t)sz : 0);
-    size_t rd = sz > 0 ? fread(&data[0], 1, (size_t)sz, f) : 0;
-    fclose(f);
-    data.resize(rd);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        err = "Unable to open file: " + path;
+        return false;
+    }
+    b.n = (size_t)st.st_size;
+    if (b.n) {
+        void *m = mmap(nullptr, b.n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            close(fd);
+            err = "Unable to map file: " + path;
+            return false;
+        }
+        madvise(m, b.n, MADV_SEQUENTIAL);
+        b.map = m;
+        b.map_len = b.n;
+        b.data = (const char *)m;
+    }
+    close(fd);
     return true;
 }
 
-struct Span {
-    size_t off;
-    uint32_t len;
+/* a record's sequence: up to two pieces of the file (the bytes between them are skipped newlines are handled by clean()) */
+struct Rec {
+    size_t s, e; /* raw sequence bytes [s, e) in the blob; '\n' inside is dropped when cleaning */
 };
 
-/* split one file into records; sequences are copied (newline-free) into arena */
-bool split_records(const std::string &d, std::string &arena, std::vector<Span> &recs, std::string &err)
+/* literal sequential splitter: the reference's getline calls (BG/Dataset.cpp:255-293) */
+bool split_sequential(const Blob &b, std::vector<Rec> &recs, std::string &err)
 {
-    const size_t n = d.size();
+    const char *d = b.data;
+    const size_t n = b.n;
     if (n == 0) return true;
     bool fasta;
     if (d[0] == '>') fasta = true;
@@ -89,37 +134,65 @@ bool split_records(const std::string &d, std::string &arena, std::vector<Span> &
     }
     size_t p = 0;
     while (p < n) {
-        const char *nl = (const char *)memchr(d.data() + p, '\n', n - p); /* header line */
-        p = nl ? (size_t)(nl - d.data()) + 1 : n;
+        const char *nl = (const char *)memchr(d + p, '\n', n - p); /* header line */
+        p = nl ? (size_t)(nl - d) + 1 : n;
         if (fasta) {
-            const size_t start = arena.size();
-            size_t q = p;
-            while (q < n && d[q] != '>') {
-                const char *e = (const char *)memchr(d.data() + q, '\n', n - q);
-                size_t line_end = e ? (size_t)(e - d.data()) : n;
-                const char *gt = (const char *)memchr(d.data() + q, '>', line_end - q);
-                if (gt) line_end = (size_t)(gt - d.data());
-                arena.append(d, q, line_end - q);
-                q = line_end;
-                if (q < n && d[q] == '\n') q++;
-            }
-            recs.push_back(Span{start, (uint32_t)(arena.size() - start)});
+            const char *gt = p < n ? (const char *)memchr(d + p, '>', n - p) : nullptr;
+            const size_t q = gt ? (size_t)(gt - d) : n;
+            recs.push_back(Rec{p, q});
             p = q < n ? q + 1 : n; /* consume the '>' */
             if (p >= n) break;
         } else {
-            size_t s[3], e[3];
-            for (int l = 0; l < 3; l++) {
-                s[l] = p;
-                const char *x = p < n ? (const char *)memchr(d.data() + p, '\n', n - p) : nullptr;
-                e[l] = x ? (size_t)(x - d.data()) : n;
-                p = x ? e[l] + 1 : n;
+            size_t s0 = p;
+            const char *x = p < n ? (const char *)memchr(d + p, '\n', n - p) : nullptr;
+            size_t e0 = x ? (size_t)(x - d) : n;
+            p = x ? e0 + 1 : n;
+            for (int l = 0; l < 2; l++) { /* '+' line and quality line */
+                const char *y = p < n ? (const char *)memchr(d + p, '\n', n - p) : nullptr;
+                p = y ? (size_t)(y - d) + 1 : n;
             }
-            const size_t start = arena.size();
-            arena.append(d, s[0], e[0] - s[0]);
-            recs.push_back(Span{start, (uint32_t)(e[0] - s[0])});
+            recs.push_back(Rec{s0, e0});
         }
     }
     return true;
+}
+
+/* clean a record into buf (newlines dropped, upper case); returns the length */
+inline uint32_t clean(const char *d, const Rec &r, std::string &buf)
+{
+    buf.clear();
+    for (size_t i = r.s; i < r.e; i++) {
+        const char c = d[i];
+        if (c != '\n') buf.push_back((char)toupper((unsigned char)c)); /* BG/Dataset.cpp:276,303-304 */
+    }
+    return (uint32_t)buf.size();
+}
+
+/* record starts of a FASTA blob whose every '>' begins a line, found in parallel; false if the precondition fails */
+bool fasta_starts_parallel(const Blob &b, int threads, std::vector<std::vector<size_t>> &starts)
+{
+    const char *d = b.data;
+    const size_t n = b.n;
+    starts.assign(threads, {});
+    bool ok = true;
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < threads; t++) {
+        const size_t b0 = n * (size_t)t / threads, b1 = n * (size_t)(t + 1) / threads;
+        size_t p = b0;
+        while (p < b1) {
+            const char *gt = (const char *)memchr(d + p, '>', b1 - p);
+            if (!gt) break;
+            const size_t q = (size_t)(gt - d);
+            if (q != 0 && d[q - 1] != '\n') {
+#pragma omp atomic write
+                ok = false;
+                break;
+            }
+            starts[t].push_back(q);
+            p = q + 1;
+        }
+    }
+    return ok;
 }
 
 } // namespace
@@ -152,77 +225,150 @@ bool test_read(const char *s, size_t n)
 }
 
 bool load_reads(const std::vector<std::string> &pe, const std::vector<std::string> &se, uint32_t min_overlap, int threads,
-                ReadSet &out, std::string &err)
+                ReadSet &out, std::string &err, HostAlloc alloc)
 {
-    std::string arena;
-    std::vector<Span> recs;
+    if (threads < 1) threads = 1;
     std::vector<std::pair<std::string, bool>> inputs;
     for (auto &f : pe) inputs.push_back({f, true});
     for (auto &f : se) inputs.push_back({f, false});
-    std::vector<size_t> file_first;
-    for (auto &in : inputs) {
-        std::string data;
-        if (!slurp(in.first, data, err)) return false;
-        const size_t before = recs.size();
-        if (!split_records(data, arena, recs, err)) return false;
-        if (recs.size() == before) {
-            err = "File empty. No reads loaded from " + in.first; /* BG/Dataset.cpp:113-114 */
+
+    /* ---- pass A: records + (good, length) of every file ---------------------------------------------------------- */
+    std::vector<Blob> blobs(inputs.size());
+    std::vector<std::vector<Rec>> recs(inputs.size());
+    std::vector<std::vector<uint16_t>> glen(inputs.size()); /* 0 = rejected, else the read length */
+    uint64_t total_records = 0;
+    for (size_t fi = 0; fi < inputs.size(); fi++) {
+        Blob &b = blobs[fi];
+        if (!load_blob(inputs[fi].first, b, err)) return false;
+        std::vector<Rec> &R = recs[fi];
+        bool done = false;
+        if (b.n && b.data[0] == '>' && threads > 1) { /* FASTA fast path */
+            std::vector<std::vector<size_t>> starts;
+            if (fasta_starts_parallel(b, threads, starts)) {
+                size_t cnt = 0;
+                for (auto &v : starts) cnt += v.size();
+                std::vector<size_t> all;
+                all.reserve(cnt + 1);
+                for (auto &v : starts) all.insert(all.end(), v.begin(), v.end());
+                /* a '>' that is the very last byte starts nothing (the reference's next getline fails) unless it is the only
+                 * one; it still ends the sequence of the record before it */
+                const std::vector<size_t> orig = all;
+                if (all.size() > 1 && all.back() == b.n - 1) all.pop_back();
+                R.resize(all.size());
+#pragma omp parallel for schedule(static) num_threads(threads)
+                for (size_t i = 0; i < all.size(); i++) {
+                    const size_t end = (i + 1 < orig.size()) ? orig[i + 1] : b.n;
+                    const char *nl = (const char *)memchr(b.data + all[i], '\n', end - all[i]);
+                    R[i] = Rec{nl ? (size_t)(nl - b.data) + 1 : end, end};
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            R.clear();
+            if (!split_sequential(b, R, err)) return false;
+        }
+        if (R.empty()) {
+            err = "File empty. No reads loaded from " + inputs[fi].first; /* BG/Dataset.cpp:113-114 */
             return false;
         }
-        FileRange fr;
-        fr.name = in.first;
-        fr.paired = in.second;
-        fr.first_index = before + 1;
-        fr.last_index = recs.size();
-        fr.good = fr.bad = 0;
-        out.files.push_back(fr);
-    }
-    const size_t nrec = recs.size();
-    out.total_records = nrec;
-    std::vector<uint8_t> good(nrec, 0);
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(threads)
-    for (size_t i = 0; i < nrec; i++) {
-        char *s = &arena[recs[i].off];
-        const uint32_t L = recs[i].len;
-        for (uint32_t t = 0; t < L; t++) s[t] = (char)toupper((unsigned char)s[t]);
-        good[i] = (L > min_overlap && L <= 32767 && test_read(s, L)) ? 1 : 0;
-    }
-    std::vector<uint64_t> rank(nrec + 1, 0);
-    uint32_t lo = UINT32_MAX, hi = 0;
-    for (size_t i = 0; i < nrec; i++) {
-        rank[i + 1] = rank[i] + good[i];
-        if (good[i]) {
-            lo = std::min(lo, recs[i].len);
-            hi = std::max(hi, recs[i].len);
+        glen[fi].assign(R.size(), 0);
+        std::vector<uint16_t> &G = glen[fi];
+#pragma omp parallel num_threads(threads)
+        {
+            std::string buf;
+#pragma omp for schedule(dynamic, 2048)
+            for (size_t i = 0; i < R.size(); i++) {
+                const uint32_t L = clean(b.data, R[i], buf);
+                G[i] = (L > min_overlap && L <= 32767 && test_read(buf.data(), L)) ? (uint16_t)L : (uint16_t)0; /* BG/Dataset.cpp:305 */
+            }
         }
+        FileRange fr;
+        fr.name = inputs[fi].first;
+        fr.paired = inputs[fi].second;
+        fr.first_index = total_records + 1;
+        fr.last_index = total_records + R.size();
+        fr.good = fr.bad = 0;
+        for (uint16_t g : G) (g ? fr.good : fr.bad)++;
+        out.files.push_back(fr);
+        total_records += R.size();
     }
-    const uint64_t n = rank[nrec];
-    for (auto &fr : out.files) {
-        fr.good = rank[fr.last_index] - rank[fr.first_index - 1];
-        fr.bad = (fr.last_index - fr.first_index + 1) - fr.good;
-    }
+    out.total_records = total_records;
+
+    /* ---- ids: rank among the good reads in file order; stride from the longest good read ------------------------- */
+    uint64_t n = 0;
+    uint32_t lo = UINT32_MAX, hi = 0;
+    for (auto &G : glen)
+        for (uint16_t g : G)
+            if (g) {
+                n++;
+                lo = std::min<uint32_t>(lo, g);
+                hi = std::max<uint32_t>(hi, g);
+            }
     out.shortest = n ? lo : 0;
     out.longest = hi;
     out.stride_words = std::max<uint32_t>(1, (hi + 31) / 32);
-    out.packed.assign((size_t)n * out.stride_words, 0);
+    const uint32_t S = out.stride_words;
+    out.n_reads = n;
+    out.alloc = alloc;
+    const size_t words = (size_t)n * S;
+    out.packed = nullptr;
+    if (alloc.alloc) out.packed = (uint64_t *)alloc.alloc(std::max<size_t>(words, 1) * 8);
+    if (!out.packed) {
+        out.packed_fallback.assign(std::max<size_t>(words, 1), 0);
+        out.packed = out.packed_fallback.data();
+        out.alloc = HostAlloc{};
+    }
     out.len.resize(n);
     out.file_index.resize(n);
-    const uint32_t S = out.stride_words;
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(threads)
-    for (size_t i = 0; i < nrec; i++) {
-        if (!good[i]) continue;
-        const uint64_t id = rank[i];
-        const char *s = &arena[recs[i].off];
-        const uint32_t L = recs[i].len;
-        uint64_t *w = &out.packed[(size_t)id * S];
-        for (uint32_t t = 0; t < L; t++) {
-            const uint64_t b = (s[t] == 'A') ? 0 : (s[t] == 'C') ? 1 : (s[t] == 'G') ? 2 : 3;
-            w[t >> 5] |= b << (62 - 2 * (t & 31)); /* BG/HashTable.cpp:456-477 */
+
+    /* ---- pass B: pack the good reads at their final place -------------------------------------------------------- */
+    uint64_t id_base = 0, rec_base = 0;
+    for (size_t fi = 0; fi < inputs.size(); fi++) {
+        const Blob &b = blobs[fi];
+        const std::vector<Rec> &R = recs[fi];
+        const std::vector<uint16_t> &G = glen[fi];
+        const int nt = threads;
+        std::vector<uint64_t> tbase(nt + 1, 0);
+        const size_t nr = R.size();
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++) {
+            uint64_t c = 0;
+            for (size_t i = nr * (size_t)t / nt; i < nr * (size_t)(t + 1) / nt; i++) c += G[i] != 0;
+            tbase[t + 1] = c;
         }
-        out.len[id] = (uint16_t)L;
-        out.file_index[id] = i + 1;
+        for (int t = 0; t < nt; t++) tbase[t + 1] += tbase[t];
+#pragma omp parallel num_threads(nt)
+        {
+            std::string buf;
+#pragma omp for schedule(static, 1)
+            for (int t = 0; t < nt; t++) {
+                uint64_t id = id_base + tbase[t];
+                for (size_t i = nr * (size_t)t / nt; i < nr * (size_t)(t + 1) / nt; i++) {
+                    if (!G[i]) continue;
+                    const uint32_t L = clean(b.data, R[i], buf);
+                    uint64_t *w = out.packed + (size_t)id * S;
+                    for (uint32_t x = 0; x < S; x++) w[x] = 0;
+                    for (uint32_t x = 0; x < L; x++) {
+                        const char ch = buf[x];
+                        const uint64_t bb = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : 3;
+                        w[x >> 5] |= bb << (62 - 2 * (x & 31)); /* BG/HashTable.cpp:456-477 */
+                    }
+                    out.len[id] = (uint16_t)L;
+                    out.file_index[id] = rec_base + i + 1; /* BG/Dataset.cpp:294: every record counts */
+                    id++;
+                }
+            }
+        }
+        id_base += tbase[nt];
+        rec_base += nr;
     }
     return true;
+}
+
+ReadSet::~ReadSet()
+{
+    if (packed && alloc.free && packed != packed_fallback.data()) alloc.free(packed);
 }
 
 } // namespace disco

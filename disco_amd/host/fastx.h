@@ -27,15 +27,28 @@ struct FileRange {
     uint64_t good, bad;
 };
 
+/* optional allocator for the packed reads (buildG passes pinned host memory so that the upload runs at PCIe rate) */
+struct HostAlloc {
+    void *(*alloc)(size_t bytes) = nullptr;
+    void (*free)(void *p) = nullptr;
+};
+
 struct ReadSet {
     uint32_t stride_words = 0;
-    std::vector<uint64_t> packed;     /* [n][stride_words]                    */
+    uint64_t n_reads = 0;
+    uint64_t *packed = nullptr;       /* [n][stride_words], from `alloc` or packed_fallback */
+    std::vector<uint64_t> packed_fallback;
+    HostAlloc alloc;
     std::vector<uint16_t> len;        /* [n]                                  */
     std::vector<uint64_t> file_index; /* [n] 1-based index over all records   */
     std::vector<FileRange> files;
     uint64_t total_records = 0;
     uint32_t shortest = 0, longest = 0;
-    uint64_t size() const { return len.size(); }
+    uint64_t size() const { return n_reads; }
+    ReadSet() = default;
+    ReadSet(const ReadSet &) = delete;
+    ReadSet &operator=(const ReadSet &) = delete;
+    ~ReadSet();
 };
 
 /* Dataset::testRead on an upper-cased read */
@@ -44,7 +57,7 @@ bool test_read(const char *s, size_t n);
 /* Reads every file, filters, packs. Returns false and sets err on failure (unreadable file, unknown format, empty file:
  * BG/Dataset.cpp:113-114,244-245,267). */
 bool load_reads(const std::vector<std::string> &pe, const std::vector<std::string> &se, uint32_t min_overlap, int threads,
-                ReadSet &out, std::string &err);
+                ReadSet &out, std::string &err, HostAlloc alloc = HostAlloc());
 
 } // namespace disco
 #endif

@@ -89,18 +89,57 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
 bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err)
 {
     const uint64_t n = rs.size();
-    std::vector<std::string> out(n_files);
-    bool ok = true;
-#pragma omp parallel for schedule(static, 1) num_threads(std::min(threads, n_files))
-    for (int t = 0; t < n_files; t++) {
-        std::string &o = out[t];
-        for (const auto &e : edges) {
-            const int os = owner_of(e.src, n, n_files), od = owner_of(e.dst, n, n_files);
-            if (os != t && od != t) continue;
+    const size_t ne = edges.size();
+    if (threads < 1) threads = 1;
+    /* an edge goes to the file that owns its source and, if different, to the file that owns its destination: bucket the
+     * (edge, file, flag) items by file with a counting sort, then format fixed-size chunks of items in parallel */
+    std::vector<uint64_t> cnt((size_t)n_files + 1, 0);
+    std::vector<int32_t> os(ne), od(ne);
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t i = 0; i < ne; i++) {
+        os[i] = owner_of(edges[i].src, n, n_files);
+        od[i] = owner_of(edges[i].dst, n, n_files);
+    }
+    for (size_t i = 0; i < ne; i++) {
+        cnt[os[i] + 1]++;
+        if (od[i] != os[i]) cnt[od[i] + 1]++;
+    }
+    for (int t = 0; t < n_files; t++) cnt[t + 1] += cnt[t];
+    const uint64_t n_items = cnt[n_files];
+    std::vector<uint64_t> item(n_items); /* edge index << 2 | flag */
+    {
+        std::vector<uint64_t> cur(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < ne; i++) {
             /* 2: both ends marked in this file; 0: only column 1; 1: only column 2 (BG/OverlapGraph.cpp:826-833,852-859) */
-            const int flag = (os == od) ? 2 : (os == t ? 0 : 1);
+            if (od[i] == os[i]) item[cur[os[i]]++] = ((uint64_t)i << 2) | 2;
+            else {
+                item[cur[os[i]]++] = ((uint64_t)i << 2) | 0;
+                item[cur[od[i]]++] = ((uint64_t)i << 2) | 1;
+            }
+        }
+    }
+    const uint64_t CH = 1 << 16;
+    const uint64_t n_chunks = (n_items + CH - 1) / CH;
+    std::vector<std::string> text(n_chunks);
+    /* chunks never straddle files: cut at file boundaries */
+    std::vector<std::pair<uint64_t, uint64_t>> range;
+    std::vector<int> chunk_file;
+    for (int t = 0; t < n_files; t++)
+        for (uint64_t b = cnt[t]; b < cnt[t + 1]; b += CH) {
+            range.push_back({b, std::min<uint64_t>(b + CH, cnt[t + 1])});
+            chunk_file.push_back(t);
+        }
+    text.assign(range.size(), std::string());
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (size_t c = 0; c < range.size(); c++) {
+        std::string &o = text[c];
+        o.reserve((range[c].second - range[c].first) * 56);
+        char buf[200];
+        for (uint64_t k = range[c].first; k < range[c].second; k++) {
+            const disco_edge &e = edges[item[k] >> 2];
+            const int flag = (int)(item[k] & 3);
             const uint64_t ovl = (uint64_t)e.len_src - e.offset; /* :814 */
-            char buf[200], *p = buf;
+            char *p = buf;
             p = put_u64(p, rs.file_index[e.src]); *p++ = '\t';
             p = put_u64(p, rs.file_index[e.dst]); *p++ = '\t';
             p = put_u64(p, e.orient); *p++ = ',';
@@ -113,15 +152,30 @@ bool write_edges(const std::string &prefix, int n_files, const std::vector<disco
             *p++ = (char)('0' + flag); *p++ = '\n';
             o.append(buf, (size_t)(p - buf));
         }
-        std::string e2;
-        if (!flush(prefix + "_" + std::to_string(t) + "_parGraph.txt", o, e2)) {
+    }
+    /* one writer per file, chunks in order */
+    std::vector<size_t> first_chunk((size_t)n_files + 1, 0);
+    for (size_t c = 0; c < chunk_file.size(); c++) first_chunk[chunk_file[c] + 1] = c + 1;
+    for (int t = 0; t < n_files; t++)
+        if (first_chunk[t + 1] < first_chunk[t]) first_chunk[t + 1] = first_chunk[t];
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(threads, n_files))
+    for (int t = 0; t < n_files; t++) {
+        const std::string path = prefix + "_" + std::to_string(t) + "_parGraph.txt";
+        FILE *f = fopen(path.c_str(), "wb");
+        bool good = f != nullptr;
+        for (size_t c = first_chunk[t]; good && c < first_chunk[t + 1]; c++)
+            good = text[c].empty() || fwrite(text[c].data(), 1, text[c].size(), f) == text[c].size();
+        if (f) fclose(f);
+        if (!good) {
 #pragma omp critical
             {
                 ok = false;
-                err = e2;
+                err = "Unable to write file: " + path;
             }
         }
         /* layout compatibility: one start id per file (BG/OverlapGraph.cpp:211) */
+        std::string e2;
         uint64_t first = n_files ? (uint64_t)(((__uint128_t)n * (unsigned)t + n_files - 1) / n_files) + 1 : 1;
         flush(prefix + "_" + std::to_string(t) + "_startRead.txt", std::to_string(first) + "\n", e2);
     }

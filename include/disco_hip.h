@@ -107,6 +107,9 @@ int disco_synchronize(disco_ctx *ctx);
 /* host helper: pack one upper-case ACGT read into ceil(len/32) words; returns DISCO_E_ARG on a non-ACGT byte
  * (the reference throws std::invalid_argument, BG/HashTable.cpp:474-475) */
 int disco_pack_ascii(const char *seq, uint32_t len, uint64_t *out_words);
+/* page-locked host memory for the packed reads (so that disco_upload_reads runs at PCIe rate); NULL on failure */
+void *disco_host_alloc(size_t bytes);
+void disco_host_free(void *p);
 /* copy host reads into HBM. packed = [n][stride_words], len[i] in (min_overlap, 32767] (BG/Dataset.cpp:305,
  * 15-bit length field BG/HashTable.cpp:531) */
 int disco_upload_reads(disco_ctx *ctx, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n);

@@ -175,3 +175,16 @@ def test_files_load_in_the_reference_parsimplify(tmp_path):
     assert p.returncode == 0, p.stdout
     for t in range(3):
         _parsimplify(f"{ours3}_{t}_parGraph.txt", str(tmp_path / f"ours3_{t}.txt"), 40)
+
+
+def test_input_stage_falls_back_on_awkward_fasta(tmp_path):
+    """'>' inside a header line and in the middle of a sequence line: the parallel splitter must hand over to the literal
+    sequential one (the reference treats EVERY '>' after the header line as a record delimiter, BG/Dataset.cpp:273)"""
+    good = "ACGTTGCAAGCTTAGCCGATCGGATTACAGCTAGCTAGGATCCGATTAGCATGCAAGT"
+    fa = tmp_path / "awkward.fasta"
+    fa.write_text(f">r1 desc>more\n{good}\n>r2\n{good[:30]}>{good[5:]}\n>r3\n{good[::-1]}\n>")
+    reads, fidx, total, _ = _dump(30, se=[str(fa)])
+    oreads, ofidx, ototal = pyoracle.load_good_reads([str(fa)], 30)
+    assert (reads, total) == (oreads, ototal) and np.array_equal(fidx, ofidx)
+    # r1 | r2 up to the stray '>' | a record whose "header" is the rest of that line and whose sequence is empty | r3
+    assert total == 4 and len(reads) == 3
