@@ -55,6 +55,23 @@ def algorithmic_bytes(cnt, n_reads, words_mean):
     return total, per_kernel
 
 
+def usable_cores():
+    """host cores this process may actually use: the cgroup CPU quota when there is one (os.cpu_count() reports the
+    machine's cores even inside a container limited to a fraction of them)"""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, spec_full):
     """reference buildG (oracle/_ref/buildG_ref, kind 'reference') or the C restatement (kind 'port') on a bounded
     sample of the same workload: same read length / coverage / min-overlap, smaller genome."""
@@ -70,7 +87,7 @@ def cpu_baseline(args, spec_full):
         g.generate_reads(spec)
         g.run_graph()
         e_pre = g.counters()["e_pre"]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     sample = f"{n} x {args.read_len} bp reads, {args.coverage:g}x of a {spec.contig_len * spec.n_contigs} bp random genome, min-overlap {args.min_overlap}"
     if refrun.available():
         d = tempfile.mkdtemp(prefix="disco_cpu_")

@@ -181,14 +181,25 @@ int main(int argc, char **argv)
 
     /* ---- outputs -------------------------------------------------------------------------------------------------- */
     t0 = Clock::now();
+    const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
+    auto t1 = Clock::now();
+    auto lap = [&](const char *what) {
+        if (verbose) fprintf(stderr, "[disco host] %-28s %.3f s\n", what, secs(t1));
+        t1 = Clock::now();
+    };
     std::vector<disco_contained_row> rows(n_cont);
     if (n_cont && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
+    lap("fetch contained rows");
     if (!disco::write_contained(prefix, threads, rows, rs, err)) return die(err);
+    lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
     std::vector<disco_edge> edges(e_out);
     if (e_out && disco_fetch_edges(ctx, edges.data(), e_out) < 0) return die(disco_last_error(ctx));
+    lap("fetch edges");
     disco_destroy(ctx);
+    lap("release GPU context");
     if (!disco::write_edges(prefix, threads, edges, rs, threads, err)) return die(err);
+    lap("write edges");
     if (!disco::write_checkpoint(prefix, false, true, true, err)) return die(err);
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;
     std::cout << "Function main() finished in " << secs(t_main) << " Seconds." << std::endl;

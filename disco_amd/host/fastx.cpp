@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace disco {
@@ -68,7 +69,7 @@ struct Blob {
     }
 };
 
-bool load_blob(const std::string &path, Blob &b, std::string &err)
+bool load_blob(const std::string &path, Blob &b, std::string &err, int threads)
 {
     const bool gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0; /* BG/Dataset.cpp:167 */
     if (gz) {
@@ -99,16 +100,37 @@ bool load_blob(const std::string &path, Blob &b, std::string &err)
     }
     b.n = (size_t)st.st_size;
     if (b.n) {
-        void *m = mmap(nullptr, b.n, PROT_READ, MAP_PRIVATE, fd, 0);
+        /* parallel pread into anonymous memory: faulting a file mapping from many threads serialises on the mapping lock */
+        void *m = mmap(nullptr, b.n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) {
             close(fd);
-            err = "Unable to map file: " + path;
+            err = "Unable to allocate memory for file: " + path;
             return false;
         }
-        madvise(m, b.n, MADV_SEQUENTIAL);
+        madvise(m, b.n, MADV_HUGEPAGE);
         b.map = m;
         b.map_len = b.n;
         b.data = (const char *)m;
+        const int nt = std::max(1, std::min(threads, 16));
+        bool ok = true;
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++) {
+            size_t p0 = b.n * (size_t)t / nt, p1 = b.n * (size_t)(t + 1) / nt;
+            while (p0 < p1) {
+                ssize_t got = pread(fd, (char *)m + p0, std::min<size_t>(p1 - p0, (size_t)1 << 26), (off_t)p0);
+                if (got <= 0) {
+#pragma omp atomic write
+                    ok = false;
+                    break;
+                }
+                p0 += (size_t)got;
+            }
+        }
+        if (!ok) {
+            close(fd);
+            err = "Unable to read file: " + path;
+            return false;
+        }
     }
     close(fd);
     return true;
@@ -157,15 +179,30 @@ bool split_sequential(const Blob &b, std::vector<Rec> &recs, std::string &err)
     return true;
 }
 
+/* upper-casing table (BG/Dataset.cpp:303-304 uses toupper in the "C" locale) */
+struct UpperTable {
+    unsigned char t[256];
+    UpperTable()
+    {
+        for (int i = 0; i < 256; i++) t[i] = (unsigned char)((i >= 'a' && i <= 'z') ? i - 32 : i);
+    }
+};
+const UpperTable kUpper;
+
 /* clean a record into buf (newlines dropped, upper case); returns the length */
 inline uint32_t clean(const char *d, const Rec &r, std::string &buf)
 {
-    buf.clear();
-    for (size_t i = r.s; i < r.e; i++) {
-        const char c = d[i];
-        if (c != '\n') buf.push_back((char)toupper((unsigned char)c)); /* BG/Dataset.cpp:276,303-304 */
+    buf.resize(r.e - r.s);
+    char *o = &buf[0];
+    size_t m = 0, p = r.s;
+    while (p < r.e) { /* copy line by line (BG/Dataset.cpp:276 removes the newlines) */
+        const char *nl = (const char *)memchr(d + p, '\n', r.e - p);
+        const size_t q = nl ? (size_t)(nl - d) : r.e;
+        for (size_t i = p; i < q; i++) o[m++] = (char)kUpper.t[(unsigned char)d[i]];
+        p = q + 1;
     }
-    return (uint32_t)buf.size();
+    buf.resize(m);
+    return (uint32_t)m;
 }
 
 /* record starts of a FASTA blob whose every '>' begins a line, found in parallel; false if the precondition fails */
@@ -214,13 +251,23 @@ bool test_read(const char *s, size_t n)
     for (size_t c : cnt)
         if (c >= thr) return false;
     for (const char *r : kEndRepeats) {
-        const size_t m = strlen(r);
+        const size_t m = 29;
         if (n < m) return false;
-        if (memcmp(r, s, m) == 0 || memcmp(r, s + n - m, m) == 0) return false;
+        if ((s[0] == r[0] && memcmp(r, s, m) == 0) || (s[n - m] == r[0] && memcmp(r, s + n - m, m) == 0)) return false;
     }
     thr = (size_t)((double)n * .5);
-    for (const char *m : kMotifs)
-        if (covered_by(s, n, m, strlen(m)) >= thr) return false;
+    for (const char *mo : kMotifs) {
+        const size_t m = strlen(mo);
+        /* the non-overlapping occurrences of a motif cannot outnumber what the read's base counts allow: if even that bound
+         * stays under the threshold the scan is pointless (exact: an upper bound on countSubstring, BG/Common.h:173-183) */
+        size_t need[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < m; i++) need[mo[i] == 'A' ? 0 : mo[i] == 'C' ? 1 : mo[i] == 'G' ? 2 : 3]++;
+        size_t bound = n;
+        for (int b = 0; b < 4; b++)
+            if (need[b]) bound = std::min(bound, cnt[b] / need[b]);
+        if (bound * m < thr) continue;
+        if (covered_by(s, n, mo, m) >= thr) return false;
+    }
     return true;
 }
 
@@ -228,6 +275,13 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
                 ReadSet &out, std::string &err, HostAlloc alloc)
 {
     if (threads < 1) threads = 1;
+    const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
+    double t_last = omp_get_wtime();
+    auto lap = [&](const char *what) {
+        const double t = omp_get_wtime();
+        if (verbose) fprintf(stderr, "[disco host] %-28s %.3f s\n", what, t - t_last);
+        t_last = t;
+    };
     std::vector<std::pair<std::string, bool>> inputs;
     for (auto &f : pe) inputs.push_back({f, true});
     for (auto &f : se) inputs.push_back({f, false});
@@ -236,10 +290,12 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
     std::vector<Blob> blobs(inputs.size());
     std::vector<std::vector<Rec>> recs(inputs.size());
     std::vector<std::vector<uint16_t>> glen(inputs.size()); /* 0 = rejected, else the read length */
+    std::vector<std::vector<std::vector<uint64_t>>> arenas(inputs.size()); /* [file][thread] packed good reads */
     uint64_t total_records = 0;
     for (size_t fi = 0; fi < inputs.size(); fi++) {
         Blob &b = blobs[fi];
-        if (!load_blob(inputs[fi].first, b, err)) return false;
+        if (!load_blob(inputs[fi].first, b, err, threads)) return false;
+        lap("read file");
         std::vector<Rec> &R = recs[fi];
         bool done = false;
         if (b.n && b.data[0] == '>' && threads > 1) { /* FASTA fast path */
@@ -272,17 +328,35 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
             err = "File empty. No reads loaded from " + inputs[fi].first; /* BG/Dataset.cpp:113-114 */
             return false;
         }
+        lap("split records");
         glen[fi].assign(R.size(), 0);
         std::vector<uint16_t> &G = glen[fi];
+        /* thread t owns the records [nr*t/T, nr*(t+1)/T) in BOTH passes; the good reads are packed right away into the
+         * thread's arena (ceil(L/32) words each) so that pass B only has to move words */
+        arenas[fi].assign(threads, {});
+        const size_t nr0 = R.size();
 #pragma omp parallel num_threads(threads)
         {
             std::string buf;
-#pragma omp for schedule(dynamic, 2048)
-            for (size_t i = 0; i < R.size(); i++) {
-                const uint32_t L = clean(b.data, R[i], buf);
-                G[i] = (L > min_overlap && L <= 32767 && test_read(buf.data(), L)) ? (uint16_t)L : (uint16_t)0; /* BG/Dataset.cpp:305 */
+#pragma omp for schedule(static, 1)
+            for (int t = 0; t < threads; t++) {
+                std::vector<uint64_t> &ar = arenas[fi][t];
+                for (size_t i = nr0 * (size_t)t / threads; i < nr0 * (size_t)(t + 1) / threads; i++) {
+                    const uint32_t L = clean(b.data, R[i], buf);
+                    if (!(L > min_overlap && L <= 32767 && test_read(buf.data(), L))) continue; /* BG/Dataset.cpp:305 */
+                    G[i] = (uint16_t)L;
+                    const size_t w0 = ar.size(), W = (L + 31) / 32;
+                    ar.resize(w0 + W, 0);
+                    uint64_t *w = &ar[w0];
+                    for (uint32_t x = 0; x < L; x++) {
+                        const char ch = buf[x];
+                        const uint64_t bb = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : 3;
+                        w[x >> 5] |= bb << (62 - 2 * (x & 31)); /* BG/HashTable.cpp:456-477 */
+                    }
+                }
             }
         }
+        lap("clean + filter");
         FileRange fr;
         fr.name = inputs[fi].first;
         fr.paired = inputs[fi].second;
@@ -321,11 +395,11 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
     }
     out.len.resize(n);
     out.file_index.resize(n);
+    lap("allocate packed reads");
 
     /* ---- pass B: pack the good reads at their final place -------------------------------------------------------- */
     uint64_t id_base = 0, rec_base = 0;
     for (size_t fi = 0; fi < inputs.size(); fi++) {
-        const Blob &b = blobs[fi];
         const std::vector<Rec> &R = recs[fi];
         const std::vector<uint16_t> &G = glen[fi];
         const int nt = threads;
@@ -338,31 +412,27 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
             tbase[t + 1] = c;
         }
         for (int t = 0; t < nt; t++) tbase[t + 1] += tbase[t];
-#pragma omp parallel num_threads(nt)
-        {
-            std::string buf;
-#pragma omp for schedule(static, 1)
-            for (int t = 0; t < nt; t++) {
-                uint64_t id = id_base + tbase[t];
-                for (size_t i = nr * (size_t)t / nt; i < nr * (size_t)(t + 1) / nt; i++) {
-                    if (!G[i]) continue;
-                    const uint32_t L = clean(b.data, R[i], buf);
-                    uint64_t *w = out.packed + (size_t)id * S;
-                    for (uint32_t x = 0; x < S; x++) w[x] = 0;
-                    for (uint32_t x = 0; x < L; x++) {
-                        const char ch = buf[x];
-                        const uint64_t bb = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : 3;
-                        w[x >> 5] |= bb << (62 - 2 * (x & 31)); /* BG/HashTable.cpp:456-477 */
-                    }
-                    out.len[id] = (uint16_t)L;
-                    out.file_index[id] = rec_base + i + 1; /* BG/Dataset.cpp:294: every record counts */
-                    id++;
-                }
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++) {
+            uint64_t id = id_base + tbase[t];
+            const uint64_t *src = arenas[fi][t].data();
+            for (size_t i = nr * (size_t)t / nt; i < nr * (size_t)(t + 1) / nt; i++) {
+                if (!G[i]) continue;
+                const uint32_t L = G[i], W = (L + 31) / 32;
+                uint64_t *w = out.packed + (size_t)id * S;
+                memcpy(w, src, W * 8);
+                for (uint32_t x = W; x < S; x++) w[x] = 0;
+                src += W;
+                out.len[id] = (uint16_t)L;
+                out.file_index[id] = rec_base + i + 1; /* BG/Dataset.cpp:294: every record counts */
+                id++;
             }
+            std::vector<uint64_t>().swap(arenas[fi][t]);
         }
         id_base += tbase[nt];
         rec_base += nr;
     }
+    lap("pack");
     return true;
 }
 

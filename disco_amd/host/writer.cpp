@@ -67,23 +67,69 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
         return a.contained < b.contained;
     });
     const uint64_t n = rs.size();
-    std::vector<std::string> out(n_files);
-    for (const auto &r : rows) {
-        char buf[160], *p = buf;
-        p = put_u64(p, rs.file_index[r.contained]); *p++ = '\t';
-        p = put_u64(p, rs.file_index[r.super]); *p++ = '\t';
-        p = put_u64(p, r.orient); *p++ = ',';
-        p = put_u64(p, r.len2); memcpy(p, ",0,0,", 5); p += 5;
-        p = put_u64(p, r.len2); memcpy(p, ",0,", 3); p += 3;
-        p = put_u64(p, r.len2); *p++ = ',';
-        p = put_u64(p, r.len1); *p++ = ',';
-        p = put_u64(p, r.start); *p++ = ',';
-        p = put_u64(p, (uint64_t)r.start + r.len2); *p++ = '\n';
-        out[owner_of(r.super, n, n_files)].append(buf, (size_t)(p - buf));
+    /* rows are sorted by containing read, so every file owns one contiguous run of them: format fixed-size chunks in
+     * parallel, then one writer per file */
+    const size_t nr = rows.size();
+    std::vector<size_t> fbeg((size_t)n_files + 1, nr);
+    {
+        size_t i = 0;
+        for (int t = 0; t < n_files; t++) {
+            while (i < nr && owner_of(rows[i].super, n, n_files) < t) i++;
+            fbeg[t] = i;
+        }
+        fbeg[n_files] = nr;
     }
+    const size_t CH = 1 << 15;
+    std::vector<std::pair<size_t, size_t>> range;
+    std::vector<int> chunk_file;
     for (int t = 0; t < n_files; t++)
-        if (!flush(prefix + "_" + std::to_string(t) + "_containedReads.txt", out[t], err)) return false;
-    return true;
+        for (size_t b = fbeg[t]; b < fbeg[t + 1]; b += CH) {
+            range.push_back({b, std::min(b + CH, fbeg[t + 1])});
+            chunk_file.push_back(t);
+        }
+    std::vector<std::string> text(range.size());
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t c = 0; c < range.size(); c++) {
+        std::string &o = text[c];
+        o.reserve((range[c].second - range[c].first) * 48);
+        char buf[160];
+        for (size_t k = range[c].first; k < range[c].second; k++) {
+            const disco_contained_row &r = rows[k];
+            char *p = buf;
+            p = put_u64(p, rs.file_index[r.contained]); *p++ = '\t';
+            p = put_u64(p, rs.file_index[r.super]); *p++ = '\t';
+            p = put_u64(p, r.orient); *p++ = ',';
+            p = put_u64(p, r.len2); memcpy(p, ",0,0,", 5); p += 5;
+            p = put_u64(p, r.len2); memcpy(p, ",0,", 3); p += 3;
+            p = put_u64(p, r.len2); *p++ = ',';
+            p = put_u64(p, r.len1); *p++ = ',';
+            p = put_u64(p, r.start); *p++ = ',';
+            p = put_u64(p, (uint64_t)r.start + r.len2); *p++ = '\n';
+            o.append(buf, (size_t)(p - buf));
+        }
+    }
+    std::vector<size_t> first_chunk((size_t)n_files + 1, 0);
+    for (size_t c = 0; c < chunk_file.size(); c++) first_chunk[chunk_file[c] + 1] = c + 1;
+    for (int t = 0; t < n_files; t++)
+        if (first_chunk[t + 1] < first_chunk[t]) first_chunk[t + 1] = first_chunk[t];
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 0; t < n_files; t++) {
+        const std::string path = prefix + "_" + std::to_string(t) + "_containedReads.txt";
+        FILE *f = fopen(path.c_str(), "wb");
+        bool good = f != nullptr;
+        for (size_t c = first_chunk[t]; good && c < first_chunk[t + 1]; c++)
+            good = text[c].empty() || fwrite(text[c].data(), 1, text[c].size(), f) == text[c].size();
+        if (f) fclose(f);
+        if (!good) {
+#pragma omp critical
+            {
+                ok = false;
+                err = "Unable to write file: " + path;
+            }
+        }
+    }
+    return ok;
 }
 
 bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err)

@@ -187,4 +187,50 @@ def test_input_stage_falls_back_on_awkward_fasta(tmp_path):
     oreads, ofidx, ototal = pyoracle.load_good_reads([str(fa)], 30)
     assert (reads, total) == (oreads, ototal) and np.array_equal(fidx, ofidx)
     # r1 | r2 up to the stray '>' | a record whose "header" is the rest of that line and whose sequence is empty | r3
-    assert total == 4 and len(reads) == 3
+    assert total == 4 and len(reads) == 2  # the 30-base half of r2 is not longer than the minimum overlap
+
+
+def test_read_filter_matches_oracle_on_adversarial_reads(tmp_path):
+    """low-complexity, motif-rich and micro-repeat reads around every threshold of Dataset::testRead (BG/Dataset.cpp:403-452):
+    the host filter (which skips motif scans that cannot reach the threshold) must keep exactly what the restatement keeps"""
+    rng = np.random.default_rng(123)
+    motifs = ["AC", "AG", "AT", "CG", "CT", "GT", "AAT", "ATA", "TAA", "AAC", "ACA", "CAA", "AAG", "AGA", "GAA", "GGGGCC"]
+    reads = []
+    for i in range(6000):
+        L = int(rng.integers(31, 200))
+        kind = i % 6
+        if kind == 0:      # random
+            s = "".join(rng.choice(list("ACGT"), L))
+        elif kind == 1:    # one base near the 70 % threshold
+            b = "ACGT"[i % 4]
+            frac = rng.uniform(0.62, 0.78)
+            s = "".join(b if rng.random() < frac else rng.choice(list("ACGT")) for _ in range(L))
+        elif kind == 2:    # motif covering about half of the read, scattered
+            m = motifs[int(rng.integers(0, len(motifs)))]
+            reps = int(L * rng.uniform(0.40, 0.60) / len(m))
+            parts = [m] * reps + list(rng.choice(list("ACGT"), max(L - reps * len(m), 0)))
+            rng.shuffle(parts)
+            s = "".join(parts)[:L]
+        elif kind == 3:    # motif run + random tail
+            m = motifs[int(rng.integers(0, len(motifs)))]
+            run = int(L * rng.uniform(0.45, 0.55))
+            s = (m * (run // len(m) + 1))[:run] + "".join(rng.choice(list("ACGT"), L - run))
+        elif kind == 4:    # micro-repeat prefix / suffix
+            unit = ["AC", "AAG", "AAAT", "AATT", "TACA", "GTTT", "AGGG"][i % 7]
+            rep = (unit * 10)[:29]
+            body = "".join(rng.choice(list("ACGT"), L))
+            s = rep + body if i % 2 else body + rep
+        else:              # lower case, N, short
+            s = "".join(rng.choice(list("ACGT"), L))
+            if i % 3 == 0:
+                s = s.lower()
+            elif i % 3 == 1:
+                s = s[:10] + "N" + s[11:]
+        reads.append(s)
+    fa = tmp_path / "adv.fasta"
+    fa.write_text("".join(f">a{i}\n{s}\n" for i, s in enumerate(reads)))
+    got, fidx, total, _ = _dump(30, se=[str(fa)])
+    want, wfidx, wtotal = pyoracle.load_good_reads([str(fa)], 30)
+    assert total == wtotal == len(reads)
+    assert np.array_equal(fidx, wfidx) and got == want
+    assert 1000 < len(got) < 5000  # both outcomes are well represented
