@@ -180,6 +180,38 @@ def digest(text: str) -> str:
     return hashlib.sha256(text.encode()).hexdigest()
 
 
+def digest_array(canon) -> str:
+    """digest of a canonical (sorted, unique) int64 array — for cases too large to serialise as text"""
+    a = np.ascontiguousarray(canon, dtype=np.int64)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def canonical_edges_large(src_f, dst_f, orient, offset, len_src, len_dst):
+    """canonical_edges for tens of millions of edges: same result, sorted with lexsort instead of np.unique(axis=0)"""
+    src_f = np.asarray(src_f, dtype=np.int64)
+    dst_f = np.asarray(dst_f, dtype=np.int64)
+    orient = np.asarray(orient, dtype=np.int64)
+    offset = np.asarray(offset, dtype=np.int64)
+    l1 = np.asarray(len_src, dtype=np.int64)
+    l2 = np.asarray(len_dst, dtype=np.int64)
+    swap = src_f > dst_f
+    tw = np.array([3, 1, 2, 0])[orient]
+    o2 = np.where(swap, tw, orient)
+    off2 = np.where(swap, l2 + offset - l1, offset)
+    a = np.where(swap, dst_f, src_f)
+    b = np.where(swap, src_f, dst_f)
+    la = np.where(swap, l2, l1)
+    lb = np.where(swap, l1, l2)
+    t = np.stack([a, b, o2, la - off2, la, off2, lb], axis=1)
+    order = np.lexsort((t[:, 6], t[:, 5], t[:, 4], t[:, 3], t[:, 2], t[:, 1], t[:, 0]))
+    t = t[order]
+    if len(t) > 1:
+        keep = np.ones(len(t), dtype=bool)
+        keep[1:] = np.any(t[1:] != t[:-1], axis=1)
+        t = t[keep]
+    return t
+
+
 def oracle_canonical(reads, file_index, min_overlap: int, count_hits: bool = False):
     """run the C oracle on good reads; returns (canonical edges, canonical contained rows, counters)."""
     codes, off = encode_reads(reads)
