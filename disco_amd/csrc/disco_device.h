@@ -210,15 +210,19 @@ __device__ __forceinline__ u64 mmer_canonical(const u64 *p, int S, int pos, int 
     return strand ? r : v;
 }
 
-/* order word of the m-mer at pos: 25-bit order hash of the canonical m-mer in bits 31..7, bits 6..1 zero (room for a
- * window offset), the m-mer's strand in bit 0. Minimizers are chosen by the order hash. */
+/* order word of the m-mer at pos: 23-bit order hash of the canonical m-mer in bits 31..9, bits 8..1 zero (room for a
+ * position), the m-mer's strand in bit 0. Minimizers are chosen by the order hash. m <= 23, so the canonical m-mer has at
+ * most 46 bits: two full-rate 24-bit multiplies fold it into 32 bits and one 32-bit multiply mixes the result (the order
+ * only has to be strand symmetric and unrelated to the base composition; bucket keys use the bijective disco_hash64). */
 template <bool NB = false>
 __device__ __forceinline__ u32 mmer_order(const u64 *p, int S, int pos, int m)
 {
     u32 strand;
     const u64 c = mmer_canonical<NB>(p, S, pos, m, strand);
-    const u32 h = (u32)((c * 0x9E3779B97F4A7C15ull) >> 39);
-    return (h << 7) | strand;
+    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24), 0x85EBCBu) + 0x7F4A7C15u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    return (h & ~0x1FFu) | strand;
 }
 
 /* 64-bit bucket key of the m-mer at pos (bijective mix of the canonical m-mer: distinct m-mers never share a key) */
@@ -252,7 +256,8 @@ __device__ __forceinline__ int window_minimizer(F h, int nf, const u64 *p, int S
 {
     /* two running minima over keys  order hash | offset << 1 | strand : k1 carries the offset f (smallest hash, then
      * LEFTMOST position), k2 carries 63 - f (smallest hash, then RIGHTMOST position). Branch-free, eight order words
-     * fetched at a time so that their LDS loads are in flight together. nf <= 64. */
+     * at a time. nf <= 64. (The probe computes the same choice for all windows of a read at once with a range-minimum
+     * table, probe_kernel step 2; this serial form serves the two end k-mers of the index.) */
     u32 k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
     for (int f0 = 0; f0 < nf; f0 += 8) {
         u32 x[8];

@@ -15,8 +15,8 @@
 #include "readgen.h"
 
 /* ---- tunables -------------------------------------------------------------------------------------------------- */
-#define PROBE_ROWCAP 256  /* candidates of one read staged in LDS before the flush                                */
-#define PROBE_SEGW 256    /* k-mer windows of a read handled per segment (reads up to 256+k bp: one segment)    */
+#define PROBE_ROWCAP 512  /* room a wave makes sure of in its chunk before it starts a read (longer rows: BIG pass)    */
+#define PROBE_SEGW 128    /* k-mer windows of a read handled per segment (reads up to 128+k bp: one segment)    */
 #define PROBE_SEGP (PROBE_SEGW + 64) /* m-mer positions a segment covers: windows + (k - m) <= 63              */
 #define PROBE_ACAP 32     /* words of the query read's own row staged in LDS (reads up to 1024 bp)              */
 #define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
@@ -258,13 +258,15 @@ __global__ void scan_write_total_kernel(const u64 *total, OutT *out_n) { *out_n 
 
 /* ================================================================================================================
  * probe — candidate generation (getListOfReads, BG/HashTable.cpp:521-571, for every k-mer window of every query read).
- * One wavefront per read. Per round of 64 windows:
- *   1. lanes hash the m-mers the round covers (LDS), 2. every window picks its minimizer occurrence and canonical strand,
- *   the first window of each occurrence leads ONE bucket lookup, 3. the records of all led buckets are walked 64 at a
- *   time (lane = record): a record names the window(s) it can match through its minimizer offset t, and the window's own
- *   (occurrence, strand) must agree. Every surviving (window, record) pair is a candidate: the exact k-mer compare and the
- *   overlap / containment extension happen in verify_kernel. Candidates of one read are staged in LDS and flushed,
- *   coalesced, to a wave-private chunk of the global hit buffer (one atomic per PROBE_CHUNK slots).
+ * One wavefront per read. Per segment of PROBE_SEGW windows:
+ *   1. lanes hash the m-mers the segment covers, 2. a range-minimum table (doubling in LDS) gives every window its minimizer
+ *   occurrence and canonical strand, 3. the first window of each occurrence leads ONE bucket lookup, 4. the records of all
+ *   led buckets are walked 64 at a time (lane = record): a record names the window(s) it can match through its minimizer
+ *   offset t, and the window's own (occurrence, strand) must agree. Every surviving (window, record) pair is a candidate:
+ *   the exact k-mer compare and the overlap / containment extension happen in verify_kernel. Candidates are written
+ *   straight to a wave-private chunk of the global hit buffer (one atomic per PROBE_CHUNK slots).
+ * The kernel is latency bound (two dependent random loads per read), so its footprint is kept at 8 waves per SIMD:
+ * at most 64 VGPRs and 5 KB of LDS per wave.
  * ============================================================================================================== */
 struct ProbeArgs {
     DiscoView v;
@@ -281,12 +283,13 @@ struct ProbeArgs {
 };
 
 template <bool BIG, bool LDSROW>
-__global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
+__global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
 {
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
      * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
-    __shared__ u64 s_row[BIG ? 1 : PROBE_ROWCAP];
-    __shared__ u32 s_h[PROBE_SEGP];     /* order hash | strand of every m-mer position of the segment                */
+    __shared__ u32 s_k1[PROBE_SEGP + 32]; /* range-minimum tables over the order hashes of the segment's m-mers (+ slack  */
+    __shared__ u32 s_k2[PROBE_SEGP + 32]; /*   for the doubling reads past the last position)                             */
+    __shared__ u8 s_strand[PROBE_SEGP];   /* strand of every m-mer position                                              */
     __shared__ u32 s_first[PROBE_SEGP]; /* first window of the segment that chose the occurrence at this position     */
     __shared__ u16 s_wp[PROBE_SEGW];    /* per window: chosen occurrence (position in the segment) | strand << 15      */
     __shared__ u16 s_lead[PROBE_SEGW];  /* windows that lead a bucket lookup                                          */
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
         const u64 *pa = LDSROW ? (const u64 *)s_a : ga;
         u32 nrow = 0;
         u64 *grow = nullptr;
-        u32 want = 0;
+        u32 want = 0; /* slots the row may use at grow */
         if (BIG) {
             u64 base = 0;
             want = a.big_cnt[it];
@@ -346,7 +349,27 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             }
             base = __shfl(base, 0);
             if (base + want <= a.hits_cap) grow = a.hits + base;
-            else if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+            else {
+                want = 0;
+                if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+            }
+        } else {
+            /* candidates go straight to the wave's private chunk of the hit buffer (consecutive lanes, consecutive slots);
+             * a row that outgrows what is left of the chunk (at least PROBE_ROWCAP slots) is redone by the BIG pass */
+            if (PROBE_CHUNK - chunk_used < PROBE_ROWCAP) {
+                u64 base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(a.bump, (u64)PROBE_CHUNK);
+                    atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + PROBE_CHUNK);
+                    if (base + PROBE_CHUNK > a.hits_cap) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                }
+                chunk_base = __shfl(base, 0);
+                chunk_used = 0;
+            }
+            if (chunk_base + PROBE_CHUNK <= a.hits_cap) {
+                grow = a.hits + chunk_base + chunk_used;
+                want = PROBE_CHUNK - chunk_used;
+            }
         }
 
         /* append the candidates flagged by `take` to the row */
@@ -354,11 +377,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             const u64 mm = __ballot(take);
             if (take) {
                 const u32 pos = nrow + __popcll(mm & lane_mask_lt());
-                const u64 hit = HIT_MAKE(jj, PAY_ID(pay), PAY_SUFFIX(pay), rev, PAY_LEN(pay));
-                if (BIG) {
-                    if (grow && pos < want) grow[pos] = hit;
-                } else if (pos < PROBE_ROWCAP)
-                    s_row[pos] = hit;
+                if (pos < want) grow[pos] = HIT_MAKE(jj, PAY_ID(pay), PAY_SUFFIX(pay), rev, PAY_LEN(pay));
             }
             nrow += __popcll(mm);
         };
@@ -367,20 +386,44 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
             const int nw = min(PROBE_SEGW, npos - w0);
             const int np = nw + nf - 1; /* m-mer positions the segment's windows cover */
             if (a.ablate == 4) continue;
-            /* 1. order hashes of the segment's m-mers */
+            /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
+             *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
             __syncthreads();
             for (int q = (int)lane; q < np; q += 64) {
+                const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
                 s_first[q] = 0xFFFFFFFFu;
-                s_h[q] = mmer_order<LDSROW>(pa, S, w0 + q, m);
+                s_strand[q] = (u8)(o & 1u);
+                s_k1[q] = (o & ~0x1FFu) | (u32)q;
+                s_k2[q] = (o & ~0x1FFu) | (511u - (u32)q);
             }
             __syncthreads();
-            /* 2. every window picks its minimizer occurrence and canonical strand */
+            /* 2. minimum over [q, q + P) for every q by doubling, P = largest power of two <= nf; in place, ascending
+             *    passes (a pass reads only positions it has not written: d <= 32 < 64). Entries whose range leaves the
+             *    segment are never used by a window. Then every window w takes min(T[w], T[w + nf - P]) and so has its
+             *    minimizer occurrence and canonical strand (window_minimizer's rule, disco_device.h). */
+            int P = 1;
+            for (; 2 * P <= nf; P <<= 1)
+                for (int q0 = 0; q0 < np; q0 += 64) {
+                    const int q = min(q0 + (int)lane, np - 1);
+                    const u32 a1 = s_k1[q], b1 = s_k1[q + P], a2 = s_k2[q], b2 = s_k2[q + P];
+                    __syncthreads();
+                    s_k1[q] = a1 < b1 ? a1 : b1;
+                    s_k2[q] = a2 < b2 ? a2 : b2;
+                }
+            __syncthreads();
             for (int ws = 0; ws < nw; ws += 64) {
                 const int w = ws + (int)lane;
                 if (w < nw) {
-                    u32 rev_w;
-                    const int f = window_minimizer<LDSROW>([&](int x) { return s_h[w + x]; }, nf, pa, S, w0 + w, k, rev_w);
-                    const u32 prel = (u32)(w + f);
+                    const int e = nf - P;
+                    const u32 a1 = s_k1[w], b1 = s_k1[w + e], a2 = s_k2[w], b2 = s_k2[w + e];
+                    const u32 p1 = (a1 < b1 ? a1 : b1) & 511u, p2 = 511u - ((a2 < b2 ? a2 : b2) & 511u);
+                    u32 rev_w, prel = p1;
+                    if (p1 == p2)
+                        rev_w = s_strand[p1];
+                    else { /* the smallest hash occurs more than once in the window */
+                        rev_w = kmer_is_rev<LDSROW>(pa, S, w0 + w, k);
+                        prel = rev_w ? p2 : p1;
+                    }
                     s_wp[w] = (u16)(prel | (rev_w << 15));
                     atomicMin(&s_first[prel], (u32)w);
                 }
@@ -455,7 +498,7 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
         if (nrow > my_maxrow) my_maxrow = nrow;
         if (BIG) {
             if (lane == 0) a.row_cnt[A] = grow ? nrow : 0;
-        } else if (nrow > PROBE_ROWCAP) {
+        } else if (grow && nrow > want) {
             if (lane == 0) {
                 u32 idx = atomicAdd(a.n_big, 1u);
                 if (idx < a.big_cap) {
@@ -466,30 +509,12 @@ __global__ void __launch_bounds__(64) probe_kernel(ProbeArgs a)
                 a.row_cnt[A] = 0;
                 a.row_start[A] = 0;
             }
-        } else if (nrow == 0) {
-            if (lane == 0) {
-                a.row_cnt[A] = 0;
-                a.row_start[A] = 0;
-            }
         } else {
-            if (chunk_used + nrow > PROBE_CHUNK) {
-                u64 base = 0;
-                if (lane == 0) {
-                    base = atomicAdd(a.bump, (u64)PROBE_CHUNK);
-                    atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + PROBE_CHUNK);
-                    if (base + PROBE_CHUNK > a.hits_cap) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-                }
-                chunk_base = __shfl(base, 0);
-                chunk_used = 0;
-            }
-            const bool ok = chunk_base + PROBE_CHUNK <= a.hits_cap;
-            if (ok)
-                for (u32 i = lane; i < nrow; i += 64) a.hits[chunk_base + chunk_used + i] = s_row[i];
             if (lane == 0) {
-                a.row_start[A] = chunk_base + chunk_used;
-                a.row_cnt[A] = ok ? nrow : 0;
+                a.row_start[A] = grow ? chunk_base + chunk_used : 0;
+                a.row_cnt[A] = grow ? nrow : 0;
             }
-            chunk_used += nrow;
+            if (grow) chunk_used += nrow;
         }
     }
     }
@@ -796,15 +821,9 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
 /* rows of at most 64 hits entirely in registers: bitonic sort into consumption order, first occurrence of every
  * destination = accepted (valid while no k-mer group has more than max_per_kmer acceptable hits, i.e. the cap never
  * blocks anything — otherwise return false and let the sequential scan decide), bitonic sort by offset, write back. */
-__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 &dropped, u64 &n_edges)
+__device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u64 rs, u32 LA, u64 hit, u32 lane, u32 &dropped, u64 &n_edges)
 {
-    u64 *row = a.hits + a.row_start[A];
-    const u32 LA = a.v.len[A];
-    u64 hit = ~0ull;
-    if (lane < c) {
-        hit = row[lane];
-        if (hit != ~0ull && is_contained(a.contained, HIT_ID(hit))) hit = ~0ull;
-    }
+    u64 *row = a.hits + rs;
     hit = wave_bitonic_sort(hit, lane);
     const bool valid = hit != ~0ull;
     const u32 m = __popcll(__ballot(valid));
@@ -835,7 +854,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     ent = wave_bitonic_sort(ent, lane);
     const u32 nacc = __popcll(nd);
     if (lane < nacc) row[lane] = ent;
-    if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
+    if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
     n_edges += nacc;
     dropped += m - nacc; /* second and later hits to a destination already linked (BG/OverlapGraph.cpp:656) */
     return true;
@@ -845,15 +864,9 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
  * verified hit to a non-contained read becomes an edge and the consumption order is irrelevant: one 32-bit sort of the
  * destinations proves the first condition, an LDS histogram of the windows the second, and only the sort by offset remains.
  * Anything else falls through to edge_select_row_fast (exact for every row of at most 64 hits). */
-__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u32 c, u32 lane, u32 *s_jcnt, u64 &n_edges)
+__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u64 rs, u32 LA, u64 hit, u32 lane, u32 *s_jcnt, u64 &n_edges)
 {
-    u64 *row = a.hits + a.row_start[A];
-    const u32 LA = a.v.len[A];
-    u64 hit = ~0ull;
-    if (lane < c) {
-        hit = row[lane];
-        if (hit != ~0ull && is_contained(a.contained, HIT_ID(hit))) hit = ~0ull;
-    }
+    u64 *row = a.hits + rs;
     const bool valid = hit != ~0ull;
     const u32 j = HIT_J(hit);
     s_jcnt[lane] = 0;
@@ -876,7 +889,7 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
     ent = wave_bitonic_sort(ent, lane);
     const u32 nacc = __popcll(__ballot(valid));
     if (lane < nacc) row[lane] = ent;
-    if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
+    if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
     n_edges += nacc;
     return true;
 }
@@ -894,27 +907,65 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
     u64 *t = BIG ? h + a.scratch_cap : s_t;
     u64 cbeg = 0, cend = 0;
-    while (wq_grab(a.v.wq, n_items, cbeg, cend))
-    for (u64 it = cbeg; it < cend; it++) {
-        const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
-        const u32 c = a.row_cnt[A];
-        if (c == 0 || is_contained(a.contained, A)) { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
-            if (lane == 0) a.ref[A] = 0;
-            continue;
+    /* software pipeline over the reads of a chunk (ordinary variant): row metadata three reads ahead, the hit row two ahead,
+     * the contained-bitmap gather of its destinations one ahead, so that the dependent chain meta -> row -> bitmap of one
+     * read overlaps the sorting of the previous ones. c = 0 stands for "nothing to do" (empty row, contained read). */
+    auto ld_meta = [&](u64 it, u32 &c, u64 &rs, u32 &LA) {
+        c = 0;
+        rs = 0;
+        LA = 0;
+        if (it < cend) {
+            const u64 A = a.v.q_lo + it;
+            c = a.row_cnt[A];
+            rs = a.row_start[A];
+            LA = a.v.len[A];
+            if (is_contained(a.contained, A)) c = 0; /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
         }
-        if (!BIG && c > ES_CAP) {
-            if (lane == 0) {
-                u32 idx = atomicAdd(a.n_big, 1u);
-                if (idx < a.big_cap) a.big_list[idx] = A;
-                else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-                a.ref[A] = 0;
+    };
+    auto ld_row = [&](u32 c, u64 rs) -> u64 { return (c <= 64 && lane < c) ? a.hits[rs + lane] : ~0ull; };
+    auto ld_filter = [&](u64 h) -> u64 { return (h != ~0ull && is_contained(a.contained, HIT_ID(h))) ? ~0ull : h; };
+    while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
+        if (BIG) {
+            for (u64 it = cbeg; it < cend; it++) {
+                const u64 A = a.big_list[it];
+                n_slow++;
+                edge_select_row(a, A, h, t, a.row_cnt[A], lane, cap_sites, dropped, n_edges);
             }
             continue;
         }
-        if (!BIG && c <= 64 && edge_select_row_all(a, A, c, lane, s_jcnt, n_edges)) continue;
-        if (!BIG && c <= 64 && edge_select_row_fast(a, A, c, lane, dropped, n_edges)) continue;
-        n_slow++;
-        edge_select_row(a, A, h, t, c, lane, cap_sites, dropped, n_edges);
+        u32 c0, c1, c2, c3, L0, L1, L2, L3;
+        u64 s0, s1, s2, s3;
+        ld_meta(cbeg, c0, s0, L0);
+        ld_meta(cbeg + 1, c1, s1, L1);
+        ld_meta(cbeg + 2, c2, s2, L2);
+        u64 r1 = ld_row(c1, s1), r2;
+        u64 g0 = ld_filter(ld_row(c0, s0)), g1;
+        for (u64 it = cbeg; it < cend; it++) {
+            ld_meta(it + 3, c3, s3, L3);
+            r2 = ld_row(c2, s2);
+            g1 = ld_filter(r1);
+            const u64 A = a.v.q_lo + it;
+            if (c0 == 0) {
+                if (lane == 0) a.ref[A] = 0;
+            } else if (c0 > ES_CAP) {
+                if (lane == 0) {
+                    u32 idx = atomicAdd(a.n_big, 1u);
+                    if (idx < a.big_cap) a.big_list[idx] = A;
+                    else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                    a.ref[A] = 0;
+                }
+            } else if (c0 <= 64 && edge_select_row_all(a, A, s0, L0, g0, lane, s_jcnt, n_edges)) {
+            } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
+            } else {
+                n_slow++;
+                edge_select_row(a, A, h, t, c0, lane, cap_sites, dropped, n_edges);
+            }
+            c0 = c1; s0 = s1; L0 = L1;
+            c1 = c2; s1 = s2; L1 = L2;
+            c2 = c3; s2 = s3; L2 = L3;
+            r1 = r2;
+            g0 = g1;
+        }
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
