@@ -83,6 +83,8 @@ ABI = [
     ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
     ("disco_phase_ms", C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+    ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
 ]
 
 PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit")
@@ -290,6 +292,18 @@ class BuildGraph:
         a = (C.c_float * len(PHASES))()
         self._chk(self.L.disco_phase_ms(self._h, a, len(PHASES)))
         return {n: float(a[i]) for i, n in enumerate(PHASES)}
+
+    def measure_hbm(self, nbytes: int = 4 << 30, reps: int = 5) -> float:
+        """attainable HBM bandwidth in GB/s (read + write bytes of a streaming copy kernel)"""
+        out = C.c_double(0.0)
+        self._chk(self.L.disco_measure_hbm(self._h, nbytes, reps, C.byref(out)))
+        return out.value
+
+    def measure_gather(self, nbytes: int = 3 << 30, reps: int = 3) -> float:
+        """attainable bandwidth in GB/s of random 64-byte row fetches out of a table of nbytes"""
+        out = C.c_double(0.0)
+        self._chk(self.L.disco_measure_gather(self._h, nbytes, reps, C.byref(out)))
+        return out.value
 
     def memcpy_d2d(self, dst_ptr: int, src_ptr: int, nbytes: int):
         self._chk(self.L.disco_memcpy_d2d(self._h, _P(dst_ptr), _P(src_ptr), nbytes))

@@ -80,6 +80,7 @@ struct disco_ctx {
     u32 *d_n_big = nullptr;
     u32 big_cap = 0;
     u64 big_rows = 0;
+    u32 max_len = 0; /* longest read (validate_reads) */
 
     /* containment */
     u8 *d_contained = nullptr;
@@ -490,10 +491,12 @@ static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride)
 static int validate_reads(disco_ctx *c)
 {
     CHK(zero_counter(c, CTR_BAD_LEN));
+    CHK(zero_counter(c, CTR_MAX_LEN));
     if (c->n) hipLaunchKernelGGL(validate_len_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_len, c->n, c->S, (int)c->prm.min_overlap, c->d_ctr);
     CHK(read_counters(c));
     if (c->h_ctr[CTR_BAD_LEN])
         return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)c->h_ctr[CTR_BAD_LEN], c->prm.min_overlap);
+    c->max_len = (u32)c->h_ctr[CTR_MAX_LEN];
     c->phase = 1;
     return DISCO_OK;
 }
@@ -689,8 +692,9 @@ int disco_probe(disco_ctx *c)
             va.row_cnt = c->d_row_cnt;
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
-                if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<true>, dim3(wq_grid(c, verify_kernel<true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
-                else hipLaunchKernelGGL(verify_kernel<false>, dim3(wq_grid(c, verify_kernel<false>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<8>, dim3(wq_grid(c, verify_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else hipLaunchKernelGGL(verify_kernel<0>, dim3(wq_grid(c, verify_kernel<0>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
             }
             ph_end(c, DISCO_PH_VERIFY);
             HIPCHK(c, hipGetLastError());
@@ -1406,6 +1410,72 @@ int disco_memcpy_d2d(disco_ctx *c, void *dst, const void *src, uint64_t bytes)
     HIPCHK(c, hipSetDevice(c->device));
     if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
+}
+
+int disco_measure_hbm(disco_ctx *c, uint64_t bytes, int reps, double *gb_per_s)
+{
+    if (!c || !gb_per_s || bytes < 4096 || reps < 1) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 n = bytes / sizeof(ulonglong2);
+    ulonglong2 *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, n * sizeof(ulonglong2)) != hipSuccess || hipMalloc(&dst, n * sizeof(ulonglong2)) != hipSuccess) {
+        if (src) (void)hipFree(src);
+        return fail(c, DISCO_E_NOMEM, "disco_measure_hbm: cannot allocate 2 x %llu bytes", (unsigned long long)bytes);
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipMemsetAsync(src, 0x5A, n * sizeof(ulonglong2), c->stream));
+    const int grid = c->n_cu * 16;
+    float best = 1e30f;
+    for (int r = 0; r <= reps; r++) { /* launch 0 warms up */
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, c->stream, src, dst, n);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    *gb_per_s = 2.0 * (double)(n * sizeof(ulonglong2)) / ((double)best * 1e-3) / 1e9;
+    return DISCO_OK;
+}
+
+int disco_measure_gather(disco_ctx *c, uint64_t bytes, int reps, double *gb_per_s)
+{
+    if (!c || !gb_per_s || bytes < 4096 || reps < 1) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nrows = bytes / 64;
+    ulonglong2 *tab = nullptr;
+    u64 *sink = nullptr;
+    if (hipMalloc(&tab, nrows * 64) != hipSuccess) return fail(c, DISCO_E_NOMEM, "disco_measure_gather: cannot allocate %llu bytes", (unsigned long long)bytes);
+    HIPCHK(c, hipMalloc(&sink, 64));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipMemsetAsync(tab, 0x5A, nrows * 64, c->stream));
+    const int grid = c->n_cu * 64; /* 8 waves per SIMD */
+    const u32 per_lane = 256;
+    float best = 1e30f;
+    for (int r = 0; r <= reps; r++) { /* launch 0 warms up */
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, c->stream, tab, nrows, per_lane, sink);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(tab);
+    (void)hipFree(sink);
+    *gb_per_s = (double)grid * 256.0 * per_lane * 64.0 / ((double)best * 1e-3) / 1e9;
     return DISCO_OK;
 }
 

@@ -51,6 +51,7 @@ enum {
     CTR_TW_DOWN,
     CTR_ES_SLOW, /* rows that took the sequential accept scan */
     CTR_ADJ_TOTAL, /* directed edges selected (sum of degrees of the query range) */
+    CTR_MAX_LEN, /* longest read */
     CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
     CTR_COUNT
 };
@@ -112,12 +113,15 @@ __global__ void generate_reads_kernel(disco_genspec spec, u64 *__restrict__ read
 __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, int min_overlap, u64 *ctr)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 bad = 0;
+    u32 bad = 0, mx = 0;
     for (; i < n; i += (u64)gridDim.x * blockDim.x) {
         u32 L = len[i];
         if (L <= (u32)min_overlap || L > 32767u || L > (u32)S * 32u) bad++;
+        mx = L > mx ? L : mx;
     }
     if (bad) atomicAdd(&ctr[CTR_BAD_LEN], (u64)bad);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (u32)__shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&ctr[CTR_MAX_LEN], (u64)mx);
 }
 
 /* ================================================================================================================
@@ -539,122 +543,210 @@ struct VerifyArgs {
     u32 *row_cnt; /* in: candidates, out: verified overlap hits (row compacted in place) */
 };
 
-#define VERIFY_SW 8 /* row words staged per lane in LDS: rows of at most 8 words (reads up to 256 bp, 64-B rows) */
+#define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
 
-template <bool staged>
+/* 32 bases starting at base position pos >= -32 of a row staged in LDS with a zero word in front and zero words behind */
+__device__ __forceinline__ u64 extract32_padded(const u64 *row, int pos)
+{
+    const int w = pos >> 5, sh = (pos & 31) * 2;
+    const u64 a = row[w], b = row[w + 1];
+    return (a << sh) | ((b >> 1) >> (63 - sh));
+}
+
+__device__ __forceinline__ u32 uniform_u32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ u64 uniform_u64(u64 x)
+{
+    return ((u64)uniform_u32((u32)(x >> 32)) << 32) | uniform_u32((u32)x);
+}
+
+/* NW = 0: generic variant (any stride, rows read from global memory). NW = 5 / 8: staged variants for a row stride of
+ * VERIFY_SW words whose reads have at most 32*NW bases (decided by the host): only the first NW words of a row are moved. */
+template <int NW>
 __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 {
-    /* staged (S == VERIFY_SW, decided by the host): rows live in LDS with a statically known address space.
-     * per lane: the candidate's row; +1 word of padding keeps the 64 rows on different banks */
-    __shared__ u64 s_b[staged ? 64 * (VERIFY_SW + 1) + 1 : 1];
-    __shared__ u64 s_a[VERIFY_SW + 2];
+    /* staged: the candidate rows (one per lane, NW words + zero words behind; odd stride; the last zero word of a lane is
+     * the zero word in front of the next lane's row), the read's own row and its reverse complement live in LDS with a
+     * statically known address space; the zero words make the shifted extracts branch free */
+    constexpr bool staged = NW != 0;
+    constexpr int BST = (NW + 3) | 1;
+    __shared__ u64 s_b[staged ? 1 + 64 * BST : 1];
+    __shared__ u64 s_a[VERIFY_SW + 4];   /* [0] = 0, [1..NW] = the read's own row, zeros behind */
+    __shared__ u64 s_arc[VERIFY_SW + 4]; /* same layout: reverse complement of the read, left aligned */
     const u32 lane = threadIdx.x;
     const int S = staged ? VERIFY_SW : a.v.S, k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
+    if (staged) {
+        for (u32 i = lane; i < 1 + 64 * BST; i += 64) s_b[i] = 0;
+        if (lane < VERIFY_SW + 4) {
+            s_a[lane] = 0;
+            s_arc[lane] = 0;
+        }
+        __syncthreads();
+    }
 
     /* 4-stage software pipeline over the reads of this wave: while read t is verified from registers, the candidate ROWS of
-     * read t+1, the candidate list of read t+2 and the row header of read t+3 are in flight, so the random row fetch — the
-     * one long latency of this kernel — overlaps the compare work of the previous read */
+     * read t+1 (and its own row), the candidate list of read t+2 and the row header of read t+3 are in flight, so the random
+     * row fetch — the one long latency of this kernel — overlaps the compare work of the previous read. */
     struct Meta {
         u32 c;
         int L;
         u64 rs;
-        u64 aw; /* lane < S: word `lane` of the read's own row */
     };
     struct Rows {
-        ulonglong2 r0, r1, r2, r3;
+        u64 w[staged ? NW : 1];
+        u64 aw; /* lane < NW: word `lane` of the read's own row */
     };
     u64 cbeg = 0, cend = 0;
+    /* every pipelined load is UNCONDITIONAL (clamped address + select): a load under an exec-mask branch makes the number
+     * of loads in flight unknown to the compiler, which then waits for (nearly) all of them at the next use and the
+     * pipeline collapses into one exposed latency per stage */
     auto load_meta = [&](u64 A) {
         Meta mt;
-        mt.c = 0;
-        mt.L = 0;
-        mt.rs = 0;
-        mt.aw = 0;
-        if (A < a.v.q_lo + cend) {
-            mt.c = a.row_cnt[A];
-            mt.rs = a.row_start[A];
-            mt.L = a.v.len[A];
-            if (staged && lane < VERIFY_SW) mt.aw = a.v.reads[A * S + lane];
-        }
+        const bool ok = A < a.v.q_lo + cend;
+        const u64 Ac = ok ? A : a.v.q_lo + cend - 1;
+        mt.c = a.row_cnt[Ac];
+        mt.rs = a.row_start[Ac];
+        mt.L = a.v.len[Ac];
+        mt.c = ok ? mt.c : 0u;
         return mt;
     };
-    auto load_cands = [&](const Meta &mt) { return (lane < mt.c) ? a.hits[mt.rs + lane] : 0ull; };
-    auto load_rows = [&](const Meta &mt, u64 h) {
+    /* idle lanes load something the wave touches anyway (never one fixed address: with every wave of the chip doing that,
+     * the line's L2 channel becomes a hot spot) */
+    auto load_cands = [&](const Meta &mt, u64 A) {
+        const bool ok = lane < mt.c;
+        const u64 h = a.hits[ok ? mt.rs + lane : (mt.c ? mt.rs : (A & 0xFFFFull))]; /* the hit buffer has more than 65536 slots */
+        return ok ? h : 0ull;
+    };
+    auto load_row = [&](u64 (&w)[staged ? NW : 1], const u64 *g) {
+        if (NW == 5) { /* 16 + 16 + 8 bytes */
+            const ulonglong2 q0 = ((const ulonglong2 *)g)[0], q1 = ((const ulonglong2 *)g)[1];
+            w[0] = q0.x; w[1] = q0.y; w[2 % (staged ? NW : 1)] = q1.x; w[3 % (staged ? NW : 1)] = q1.y; w[4 % (staged ? NW : 1)] = g[4];
+        } else if (NW == 8) {
+            const ulonglong2 q0 = ((const ulonglong2 *)g)[0], q1 = ((const ulonglong2 *)g)[1], q2 = ((const ulonglong2 *)g)[2], q3 = ((const ulonglong2 *)g)[3];
+            w[0] = q0.x; w[1] = q0.y; w[2 % (staged ? NW : 1)] = q1.x; w[3 % (staged ? NW : 1)] = q1.y;
+            w[4 % (staged ? NW : 1)] = q2.x; w[5 % (staged ? NW : 1)] = q2.y; w[6 % (staged ? NW : 1)] = q3.x; w[7 % (staged ? NW : 1)] = q3.y;
+        }
+    };
+    auto load_rows = [&](const Meta &mt, u64 h, u64 A) {
         Rows r;
-        r.r0 = r.r1 = r.r2 = r.r3 = make_ulonglong2(0, 0);
-        if (staged && lane < mt.c) { /* four independent 16-byte loads of the 64-byte row */
-            const ulonglong2 *g2 = (const ulonglong2 *)(a.v.reads + HIT_ID(h) * S);
-            r.r0 = g2[0];
-            r.r1 = g2[1];
-            r.r2 = g2[2];
-            r.r3 = g2[3];
+        r.w[0] = 0;
+        r.aw = 0;
+        if (staged) {
+            const u64 *own = a.v.reads + (A < a.v.q_lo + cend ? A : a.v.q_lo + cend - 1) * S;
+            r.aw = own[lane < (u32)NW ? lane : 0u];
+            load_row(r.w, lane < mt.c ? a.v.reads + HIT_ID(h) * S : own);
         }
         return r;
     };
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
     const u64 A_first = a.v.q_lo + cbeg;
     Meta m0 = load_meta(A_first), m1 = load_meta(A_first + 1), m2 = load_meta(A_first + 2);
-    u64 h0 = load_cands(m0), h1 = load_cands(m1);
-    Rows R0 = load_rows(m0, h0);
+    u64 h0 = load_cands(m0, A_first), h1 = load_cands(m1, A_first + 1);
+    Rows R0 = load_rows(m0, h0, A_first);
 
     for (u64 A = A_first; A < a.v.q_lo + cend; A++) {
         const Meta m3 = load_meta(A + 3);
-        const u64 h2 = load_cands(m2);
-        const Rows R1 = load_rows(m1, h1);
-        const u32 c = m0.c;
+        const u64 h2 = load_cands(m2, A + 2);
+        const Rows R1 = load_rows(m1, h1, A + 1);
+        const u32 c = uniform_u32(m0.c); /* wave uniform: scalar from here on (the loads themselves stay in flight as vectors) */
         if (c != 0) {
-            u64 *row = a.hits + m0.rs;
+            u64 *row = a.hits + uniform_u64(m0.rs);
             const u64 *ga = a.v.reads + A * S;
-            const int LA = m0.L;
+            const int LA = (int)uniform_u32((u32)m0.L);
             __syncthreads();
-            if (staged && lane < VERIFY_SW) s_a[lane] = m0.aw;
-            const u64 *pa = staged ? (const u64 *)s_a : ga;
-            u32 nkeep = 0;
-            for (u32 i0 = 0; i0 < c; i0 += 64) {
-                const u32 i = i0 + lane;
-                bool ov = false;
-                u64 h = 0;
-                const u64 *gb = nullptr;
-                if (i < c) {
-                    h = (i0 == 0) ? h0 : row[i];
-                    gb = a.v.reads + HIT_ID(h) * S;
-                    if (staged) {
-                        Rows r = R0;
-                        if (i0 != 0) r = load_rows(m0, h); /* rows beyond the first 64 candidates are fetched on the spot */
-                        u64 *sb = s_b + lane * (VERIFY_SW + 1);
-                        sb[0] = r.r0.x; sb[1] = r.r0.y; sb[2] = r.r1.x; sb[3] = r.r1.y;
-                        sb[4] = r.r2.x; sb[5] = r.r2.y; sb[6] = r.r3.x; sb[7] = r.r3.y;
-                    }
-                }
-                const u64 *pb = staged ? (const u64 *)(s_b + lane * (VERIFY_SW + 1)) : gb;
+            if (staged) {
+                if (lane < (u32)NW) s_a[1 + lane] = R0.aw;
                 __syncthreads();
-                if (i < c) {
-                    const int j = (int)HIT_J(h);
-                    const u64 B = HIT_ID(h);
-                    const int LB = (int)HIT_LEN(h);
-                    const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
-                    const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
-                    if (seg_equal<staged>(pa, pb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
-                        my_khits++;
-                        int a0, b0, mlen;
-                        bool contain, overlap;
-                        if (prefix_align) {
-                            const int rem = LA - j;
-                            contain = rem >= LB;          /* BG/OverlapGraph.cpp:532 */
-                            overlap = !contain && j >= 1; /* :579 */
-                            a0 = j;
-                            b0 = 0;
-                            mlen = contain ? LB : rem;
-                        } else {
-                            const int sft = j + k - LB;   /* where s2 starts in A */
-                            contain = sft >= 0;           /* :547 */
-                            overlap = sft <= 0 && j >= 1; /* :591 */
-                            a0 = sft > 0 ? sft : 0;
-                            b0 = sft < 0 ? -sft : 0;
-                            mlen = j + k - a0;
+                /* word i of revcomp(A) = reverse complement of A[LA - 32(i+1), LA - 32i); what lies beyond the read is masked by
+                 * every consumer */
+                if (lane < (u32)NW) {
+                    const int pos = LA - 32 * ((int)lane + 1);
+                    s_arc[1 + lane] = pos > -32 ? rev2_64(~extract32_padded(s_a + 1, pos)) : 0ull;
+                }
+            }
+            u32 nkeep = 0;
+            /* one batch of 64 candidates: lane = candidate h with its row words w (staged variants) */
+            auto batch = [&](const bool act, const u64 h, const u64 (&w)[staged ? NW : 1]) {
+                bool ov = false;
+                const int j = (int)HIT_J(h);
+                const u64 B = HIT_ID(h);
+                const int LB = act ? (int)HIT_LEN(h) : k;
+                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
+                /* s2 = B or revcomp(B); s2[p] lies under A[p + d]; aligned region in A coordinates [x0, x1) */
+                const int d = prefix_align ? j : j + k - LB;
+                const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
+                bool contain, overlap;
+                if (prefix_align) {
+                    contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
+                    overlap = !contain && j >= 1; /* :579 */
+                } else {
+                    contain = d >= 0;           /* :547 */
+                    overlap = d <= 0 && j >= 1; /* :591 */
+                }
+                if (staged) {
+                    if (act) {
+                        u64 *sb = s_b + 1 + lane * BST;
+#pragma unroll
+                        for (int t = 0; t < NW; t++) sb[t] = w[t % (staged ? NW : 1)];
+                    }
+                    __syncthreads();
+                    /* ONE pass of XORs over the aligned region. A reversed candidate is compared as revcomp(A) against B itself
+                     * (coordinates y = LA-1-x), so no candidate row is ever reverse-complemented:
+                     * T[X] == B[X - dd] for X in [X0, X1), T = A or revcomp(A). */
+                    const u64 *T = rev ? s_arc + 1 : s_a + 1;
+                    const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
+                    const int dd = rev ? LA - LB - d : d;
+                    const int w0 = X0 >> 5, nl = act ? ((X1 - 1) >> 5) - w0 : -1;
+                    const int p = 32 * w0 - dd; /* >= -31: at most one word in front of the row is touched */
+                    const u64 *bp = s_b + 1 + lane * BST + (p >> 5);
+                    const int sh = (p & 31) * 2;
+                    const u64 firstmask = ~0ull >> (2 * (X0 & 31)), lastmask = ~0ull << (62 - 2 * ((X1 - 1) & 31));
+                    auto xor_word = [&](int t, u64 blo, u64 bhi) { /* word t of the region: T word ^ shifted B window, masked */
+                        u64 xt = T[w0 + t] ^ ((blo << sh) | ((bhi >> 1) >> (63 - sh)));
+                        if (t == 0) xt &= firstmask;
+                        if (t == nl) xt &= lastmask;
+                        return xt;
+                    };
+                    u64 diff = 0, blo = 0;
+                    if (act) blo = bp[0];
+#pragma unroll
+                    for (int t = 0; t < NW; t++) {
+                        if (!__any(t <= nl)) continue;
+                        if (t <= nl) {
+                            const u64 bhi = bp[t + 1];
+                            diff |= xor_word(t, blo, bhi);
+                            blo = bhi;
                         }
-                        if (seg_equal<staged>(pa, pb, S, LB, a0, b0, mlen, rev)) {
+                    }
+                    const bool full_ok = act && diff == 0;
+                    bool kmer_ok = full_ok; /* the k-mer lies inside the aligned region */
+                    if (__any(act && !full_ok)) {
+                        /* the exact k-mer compare on its own (what makes a candidate a hit of getListOfReads), over the same
+                         * XOR words: k-mer region [K0, K1) in T coordinates */
+                        const int K0 = rev ? LA - j - k : j, K1 = K0 + k;
+                        const int kw0 = (K0 >> 5) - w0, kw1 = ((K1 - 1) >> 5) - w0;
+                        const u64 kfirst = ~0ull >> (2 * (K0 & 31)), klast = ~0ull << (62 - 2 * ((K1 - 1) & 31));
+                        u64 kd = 0;
+                        if (act && !full_ok)
+                            for (int t = kw0; t <= kw1; t++) {
+                                u64 xt = xor_word(t, bp[t], bp[t + 1]);
+                                if (t == kw0) xt &= kfirst;
+                                if (t == kw1) xt &= klast;
+                                kd |= xt;
+                            }
+                        kmer_ok = act && kd == 0;
+                    }
+                    if (kmer_ok) my_khits++;
+                    if (full_ok) {
+                        if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                        ov = overlap;
+                    }
+                } else if (act) {
+                    const u64 *gb = a.v.reads + B * S;
+                    if (seg_equal<false>(ga, gb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
+                        my_khits++;
+                        if (seg_equal<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev)) {
                             if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                             ov = overlap;
                         }
@@ -665,6 +757,17 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                 if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
                 nkeep += __popcll(mk);
                 __syncthreads();
+            };
+            /* the first 64 candidates and their rows were prefetched; longer rows fetch the rest on the spot (kept out of the
+             * first batch's code path: a load there would make the compiler drain the whole pipeline) */
+            batch(lane < c, h0, R0.w);
+            for (u32 i0 = 64; i0 < c; i0 += 64) {
+                const bool act = i0 + lane < c;
+                const u64 h = row[act ? i0 + lane : 0];
+                u64 w[staged ? NW : 1];
+                w[0] = 0;
+                if (staged) load_row(w, act ? a.v.reads + HIT_ID(h) * S : ga);
+                batch(act, act ? h : 0ull, w);
             }
             if (lane == 0) {
                 a.row_cnt[A] = nkeep;
@@ -895,7 +998,7 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
 }
 
 template <bool BIG>
-__global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
+__global__ void __launch_bounds__(64, 8) edge_select_kernel(EdgeSelArgs a)
 {
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];
@@ -1638,6 +1741,43 @@ __global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *
             dst_src[pos[i]] = out_src[i];
             dst_ent[pos[i]] = out_ent[i];
         }
+}
+
+/* streaming copy, 16 bytes per lane per iteration (bandwidth probe of disco_measure_hbm) */
+__global__ void __launch_bounds__(256) stream_copy_kernel(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ dst, u64 n)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 step = (u64)gridDim.x * blockDim.x;
+    for (; i + 3 * step < n; i += 4 * step) {
+        const ulonglong2 x0 = src[i], x1 = src[i + step], x2 = src[i + 2 * step], x3 = src[i + 3 * step];
+        dst[i] = x0;
+        dst[i + step] = x1;
+        dst[i + 2 * step] = x2;
+        dst[i + 3 * step] = x3;
+    }
+    for (; i < n; i += step) dst[i] = src[i];
+}
+
+/* random 64-byte row gather (bandwidth probe of disco_measure_gather): every lane fetches `per_lane` rows, four at a time */
+__global__ void __launch_bounds__(256) gather_rows_kernel(const ulonglong2 *__restrict__ tab, u64 nrows, u32 per_lane, u64 *__restrict__ sink)
+{
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 acc = 0;
+    for (u32 it = 0; it < per_lane; it += 4) {
+        ulonglong2 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 r = disco_hash64(tid * per_lane + it + u) % nrows;
+            const ulonglong2 *g = tab + r * 4;
+            v[u][0] = g[0];
+            v[u][1] = g[1];
+            v[u][2] = g[2];
+            v[u][3] = g[3];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc ^= v[u][0].x ^ v[u][1].y ^ v[u][2].x ^ v[u][3].y;
+    }
+    if (acc == 0x1234567ull) sink[0] = acc; /* keeps the loads alive */
 }
 
 __global__ void fill_u64_kernel(u64 *p, u64 n, u64 val)

@@ -206,6 +206,16 @@ enum {
 int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* attainable HBM bandwidth on this device (SURVEY.md §8d "Roofline that bounds the path": nominal AND measured): a
+ * streaming copy kernel over two scratch buffers of `bytes` each, `reps` timed launches after one warm-up;
+ * *gb_per_s = read + written bytes per second / 1e9 of the best launch. Measurement aid for bench.py, no reference
+ * counterpart. */
+int disco_measure_hbm(disco_ctx *ctx, uint64_t bytes, int reps, double *gb_per_s);
+/* attainable bandwidth of the access pattern that dominates the path — one random, 64-byte aligned 64-byte row per lane
+ * out of a table of `bytes` (the candidate-row fetch of verify, the bucket walk of probe): *gb_per_s = 64 B x rows
+ * fetched per second / 1e9 of the best of `reps` launches. The ceiling the gather-bound kernels are priced against in
+ * DESIGN.md, next to the nominal and the streaming figure. */
+int disco_measure_gather(disco_ctx *ctx, uint64_t bytes, int reps, double *gb_per_s);
 
 #ifdef __cplusplus
 }
