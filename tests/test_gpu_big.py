@@ -1,0 +1,42 @@
+"""-m gpu : BASELINE-size parity. Reads are generated on the device from the committed generator parameters; the canonical
+edge list and contained rows of the HIP path must hash to the digests of the files the REAL reference buildG wrote for the
+same reads (tests/golden/make_big_digest.py, run once in the build container). Cases above 2 M reads only run with
+DISCO_RUN_BIG=1 (the canonicalisation of 45 M edges takes minutes of host time)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from disco_amd import buildgraph, readgen
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = json.load(open(os.path.join(HERE, "golden", "cases_big.json")))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_digest_matches_reference_files(name):
+    c = CASES[name]
+    if c["reads"] > 2_000_000 and not os.environ.get("DISCO_RUN_BIG"):
+        pytest.skip("set DISCO_RUN_BIG=1 to run the full-size parity check")
+    spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"])
+    with buildgraph.BuildGraph(min_overlap=c["min_overlap"]) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        cnt = g.counters()
+        e = g.fetch_edges()
+        r = g.fetch_contained()
+    assert cnt["asymmetric_pairs"] == 0 and cnt["cap_bind_sites"] == 0  # inside the reference's order-independent domain
+    one = np.int64(1)  # every generated read passes the reference's filter: file index = read id + 1
+    ce = pyoracle.canonical_edges_large(e["src"].astype(np.int64) + one, e["dst"].astype(np.int64) + one, e["orient"], e["offset"],
+                                        e["len_src"], e["len_dst"])
+    del e
+    assert len(ce) == c["n_edges"]
+    assert pyoracle.digest_array(ce) == c["edges_sha256"]
+    cc = np.stack([r["contained"].astype(np.int64) + one, r["super"].astype(np.int64) + one] +
+                  [np.asarray(r[k], dtype=np.int64) for k in ("orient", "len2", "len1", "start")], axis=1)
+    cc = cc[np.lexsort(tuple(cc[:, i] for i in range(5, -1, -1)))]
+    assert len(cc) == c["n_contained"]
+    assert pyoracle.digest_array(cc) == c["contained_sha256"]
