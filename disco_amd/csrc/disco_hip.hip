@@ -215,6 +215,10 @@ static DiscoView view(const disco_ctx *c)
     v.S = c->S;
     v.k = c->k;
     v.m = disco_minimizer_len(c->k);
+    if (const char *e = getenv("DISCO_MINIMIZER_LEN")) { /* tuning knob: odd, <= min(k, 23), k - m <= 63 */
+        const int m = atoi(e);
+        if (m >= 1 && (m & 1) && m <= v.m && c->k - m <= 63) v.m = m;
+    }
     v.bkt = c->d_bkt;
     v.ent = c->d_ent;
     v.bshift = c->bshift;

@@ -1362,8 +1362,12 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
 struct TrNodeRegs {
     u64 v;
     u64 vs;
-    u32 d;
-    u64 e; /* lane's entry (lane < d) */
+    u32 d;      /* 0: nothing to do or not a register-resident node (no prefetch) */
+    u32 dfull;  /* the node's degree */
+    u64 e;      /* lane's entry (lane < d) */
+    u32 s2;     /* first slot on the other side of v */
+    u64 r0, r2; /* reference words of the neighbours in slot 0 and s2 */
+    u64 p0, p2; /* lane's entry of their rows */
 };
 
 __device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
@@ -1384,16 +1388,12 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         hkey[i] = TR_EMPTY;
         hstate[i] = 0;
     }
-    /* speculative rows: slot 0 and the first slot on the other side of v (side = strand of v in the edge, bit 1) */
-    const u32 side0 = ADJ_ORI(readlane_u64(e, 0)) >> 1;
-    const u64 om = __ballot(lane < d && (ADJ_ORI(e) >> 1) != side0);
-    const u32 s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
-    const u64 u0 = ADJ_DST(readlane_u64(e, 0)), u2 = ADJ_DST(readlane_u64(e, s2));
-    const u64 r0 = a.ref[u0], r2 = a.ref[u2];
-    const u64 st0 = REF_POS(r0), st2 = REF_POS(r2);
-    const u32 d0 = REF_DEG(r0), d2 = REF_DEG(r2);
-    const u64 p0 = (lane < d0) ? a.adj[st0 + lane] : 0ull;
-    const u64 p2 = (lane < d2) ? a.adj[st2 + lane] : 0ull;
+    /* speculative rows (fetched by the pipeline of the kernel): slot 0 and the first slot on the other side of v */
+    const u32 s2 = nd.s2;
+    const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
+    const u32 d0 = REF_DEG(nd.r0), d2 = REF_DEG(nd.r2);
+    const u64 p0 = (lane < d0) ? nd.p0 : 0ull;
+    const u64 p2 = (lane < d2) ? nd.p2 : 0ull;
     __syncthreads();
     u32 sent = 0;
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
@@ -1420,29 +1420,11 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         cur = (int)i;
         const u64 e1 = readlane_u64(e, i);
         const u32 type1 = ADJ_ORI(e1);
-        u64 us;
-        u32 du;
-        u64 pre;
-        if (i == 0) {
-            us = st0;
-            du = d0;
-            pre = p0;
-        } else if (i == s2) {
-            us = st2;
-            du = d2;
-            pre = p2;
-        } else {
-            const u64 ru = a.ref[ADJ_DST(e1)];
-            us = REF_POS(ru);
-            du = REF_DEG(ru);
-            pre = (lane < du) ? a.adj[us + lane] : 0ull;
-        }
         const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
-        for (u32 t = lane; t < du; t += 64) {        /* :698 */
-            const u64 e2 = (t < 64) ? pre : a.adj[us + t];
+        auto mark = [&](u64 e2) {
             const u32 type2 = ADJ_ORI(e2);
             const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
-            if (!ok) continue;
+            if (!ok) return;
             const u64 w = ADJ_DST(e2);
             u32 idx = (u32)disco_hash64(w) & hmask;
             for (;;) {
@@ -1454,6 +1436,23 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
                 }
                 idx = (idx + 1) & hmask;
             }
+        };
+        auto sweep = [&](u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
+            if (lane < du) mark(pre);
+            if (du > 64)
+                for (u32 t = 64 + lane; t < du; t += 64) mark(a.adj[us + t]);
+        };
+        /* three copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
+         * lands on the common path and drains the kernel's prefetch pipeline */
+        if (i == 0)
+            sweep(st0, d0, p0);
+        else if (i == s2)
+            sweep(st2, d2, p2);
+        else {
+            const u64 ru = a.ref[ADJ_DST(e1)];
+            const u64 us = REF_POS(ru);
+            const u32 du = REF_DEG(ru);
+            sweep(us, du, (lane < du) ? a.adj[us + lane] : 0ull);
         }
         __syncthreads();
     }
@@ -1493,54 +1492,82 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
         sent = (u32 *)(base + a.hcap * 8);
         hstate = base + a.hcap * 8 + a.hcap * 4;
     }
-    auto load_node = [&](u64 it) {
+    /* Software pipeline over the nodes of a chunk, one dependent load per stage and iteration:
+     *   chunk start: ref[v] of all nodes of the chunk (one coalesced load),
+     *   node t+3: its row, node t+2: ref of its two speculative neighbours (slot 0 and the first slot on the other side of
+     *   v; side = strand of v in the edge, bit 1), node t+1: their rows, node t: the sweep.
+     * Every pipelined load is unconditional (clamped address): a load under an exec-mask branch makes the number of loads in
+     * flight unknown to the compiler, which then drains the pipeline at the next use. */
+    const u64 n_nodes = a.v.n;
+    u64 cbeg = 0, cend = 0;
+    u64 rv_chunk = 0;
+    auto stage_row = [&](u64 it) { /* needs rv_chunk */
         TrNodeRegs r;
-        r.v = a.v.q_lo + it;
-        r.vs = 0;
-        r.d = 0;
-        r.e = 0;
-        if (it < n_items) {
-            const u64 rv = a.ref[a.v.q_lo + it];
-            r.vs = REF_POS(rv);
-            r.d = REF_DEG(rv);
-            if (lane < r.d) r.e = a.adj[r.vs + lane] & ~ADJ_FLAG;
-        }
+        const bool ok = it < cend;
+        const u64 itc = ok ? it : cend - 1;
+        const u64 rv = readlane_u64(rv_chunk, (u32)(itc - cbeg));
+        r.v = a.v.q_lo + itc;
+        r.vs = REF_POS(rv);
+        r.dfull = ok ? REF_DEG(rv) : 0u;
+        r.d = (r.dfull <= 64) ? r.dfull : 0u;
+        r.e = a.adj[r.vs + (lane < r.d ? lane : 0u)];
+        r.s2 = 0;
+        r.r0 = r.r2 = r.p0 = r.p2 = 0;
         return r;
     };
-    TrNodeRegs cur;
-    u64 cbeg = 0, cend = 0;
+    auto stage_refs = [&](TrNodeRegs &r) { /* needs r.e */
+        r.e = (lane < r.d) ? (r.e & ~ADJ_FLAG) : 0ull;
+        const u32 side0 = ADJ_ORI(readlane_u64(r.e, 0)) >> 1;
+        const u64 om = __ballot(lane < r.d && (ADJ_ORI(r.e) >> 1) != side0);
+        r.s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
+        const u64 u0 = r.d ? ADJ_DST(readlane_u64(r.e, 0)) : r.v, u2 = r.d ? ADJ_DST(readlane_u64(r.e, r.s2)) : r.v;
+        r.r0 = a.ref[u0 < n_nodes ? u0 : r.v];
+        r.r2 = a.ref[u2 < n_nodes ? u2 : r.v];
+    };
+    auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 */
+        const u32 d0 = r.d ? REF_DEG(r.r0) : 0u, d2 = r.d ? REF_DEG(r.r2) : 0u;
+        r.p0 = a.adj[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : r.vs];
+        r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
+    };
     while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
-    if (!BIG) cur = load_node(cbeg);
-    for (u64 it = cbeg; it < cend; it++) {
-        if (!BIG) {
-            TrNodeRegs nxt; /* in flight while `cur` is processed */
-            if (it + 1 < cend) nxt = load_node(it + 1);
-            else {
-                nxt.v = 0;
-                nxt.vs = 0;
-                nxt.d = 0;
-                nxt.e = 0;
-            }
-            const u64 v = a.v.q_lo + it;
-            if (cur.d != 0) {
-                if (cur.d <= 64) tr_node_small(a, cur, s_hkey, s_state, lane);
-                else if (cur.d <= TR_CAP) {
-                    u32 hc = 64;
-                    while (hc < 2 * cur.d) hc <<= 1;
-                    tr_node(a, v, cur.d, hkey, hstate, sent, hc - 1, lane);
-                } else if (lane == 0) {
-                    u32 idx = atomicAdd(a.n_big, 1u);
-                    if (idx < a.big_cap) a.big_list[idx] = v;
-                    else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-                }
-            }
-            cur = nxt;
-        } else {
+    if (BIG) {
+        for (u64 it = cbeg; it < cend; it++) {
             const u64 v = a.big_list[it];
             const u32 d = REF_DEG(a.ref[v]);
             if (d == 0) continue;
             tr_node(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
         }
+        continue;
+    }
+    {
+        const u64 idx = cbeg + lane;
+        rv_chunk = a.ref[a.v.q_lo + (idx < cend ? idx : cend - 1)];
+    }
+    TrNodeRegs n0 = stage_row(cbeg), n1 = stage_row(cbeg + 1), n2 = stage_row(cbeg + 2);
+    stage_refs(n0);
+    stage_refs(n1);
+    stage_rows(n0);
+    for (u64 it = cbeg; it < cend; it++) {
+        stage_rows(n1);
+        stage_refs(n2);
+        TrNodeRegs n3 = stage_row(it + 3);
+        const u64 v = a.v.q_lo + it;
+        if (n0.d != 0)
+            tr_node_small(a, n0, s_hkey, s_state, lane);
+        else if (n0.dfull != 0) {
+            if (n0.dfull <= TR_CAP) {
+                u32 hc = 64;
+                while (hc < 2 * n0.dfull) hc <<= 1;
+                tr_node(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
+            } else if (lane == 0) {
+                u32 idx = atomicAdd(a.n_big, 1u);
+                if (idx < a.big_cap) a.big_list[idx] = v;
+                else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+            }
+        }
+        n0 = n1;
+        n1 = n2;
+        n2 = n3;
     }
     }
 }
