@@ -1475,8 +1475,11 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     __syncthreads();
 }
 
+#ifndef TR_WAVES_PER_SIMD
+#define TR_WAVES_PER_SIMD 6
+#endif
 template <bool BIG>
-__global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
+__global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(TrArgs a)
 {
     __shared__ u64 s_hkey[BIG ? 1 : 2 * TR_CAP];
     __shared__ u32 s_ent[BIG ? 1 : TR_CAP];
@@ -1524,7 +1527,9 @@ __global__ void __launch_bounds__(64) transitive_mark_kernel(TrArgs a)
         r.r0 = a.ref[u0 < n_nodes ? u0 : r.v];
         r.r2 = a.ref[u2 < n_nodes ? u2 : r.v];
     };
-    auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 */
+    auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 (broadcast loads: scalar from here on) */
+        r.r0 = uniform_u64(r.r0);
+        r.r2 = uniform_u64(r.r2);
         const u32 d0 = r.d ? REF_DEG(r.r0) : 0u, d2 = r.d ? REF_DEG(r.r2) : 0u;
         r.p0 = a.adj[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : r.vs];
         r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
