@@ -998,7 +998,7 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
 }
 
 template <bool BIG>
-__global__ void __launch_bounds__(64, 8) edge_select_kernel(EdgeSelArgs a)
+__global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
 {
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];
@@ -1013,20 +1013,31 @@ __global__ void __launch_bounds__(64, 8) edge_select_kernel(EdgeSelArgs a)
     /* software pipeline over the reads of a chunk (ordinary variant): row metadata three reads ahead, the hit row two ahead,
      * the contained-bitmap gather of its destinations one ahead, so that the dependent chain meta -> row -> bitmap of one
      * read overlaps the sorting of the previous ones. c = 0 stands for "nothing to do" (empty row, contained read). */
-    auto ld_meta = [&](u64 it, u32 &c, u64 &rs, u32 &LA) {
-        c = 0;
-        rs = 0;
-        LA = 0;
-        if (it < cend) {
-            const u64 A = a.v.q_lo + it;
-            c = a.row_cnt[A];
-            rs = a.row_start[A];
-            LA = a.v.len[A];
-            if (is_contained(a.contained, A)) c = 0; /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
-        }
+    /* every pipelined load is unconditional (clamped address) and nothing is computed from a loaded value in the iteration
+     * that issues the load (the compiler waits for a load at its first use), see verify_kernel: ld_* issue, fin_* consume */
+    struct SelMeta {
+        u32 c, LA, cw; /* raw: candidates, length, bitmap word holding the read's own contained bit */
+        u64 rs;
     };
-    auto ld_row = [&](u32 c, u64 rs) -> u64 { return (c <= 64 && lane < c) ? a.hits[rs + lane] : ~0ull; };
-    auto ld_filter = [&](u64 h) -> u64 { return (h != ~0ull && is_contained(a.contained, HIT_ID(h))) ? ~0ull : h; };
+    auto read_of = [&](u64 it) { return a.v.q_lo + (it < cend ? it : cend - 1); };
+    auto ld_meta = [&](u64 it) {
+        SelMeta m;
+        const u64 A = read_of(it);
+        m.c = a.row_cnt[A];
+        m.rs = a.row_start[A];
+        m.LA = a.v.len[A];
+        m.cw = ((const u32 *)a.contained)[A >> 5];
+        return m;
+    };
+    auto fin_meta = [&](const SelMeta &m, u64 it) -> u32 { /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
+        return (it < cend && !((m.cw >> (read_of(it) & 31)) & 1u)) ? m.c : 0u;
+    };
+    auto ld_row = [&](u32 c, u64 rs, u64 it) -> u64 { /* the hit buffer has more than 65536 slots */
+        return a.hits[(c <= 64 && lane < c) ? rs + lane : (c ? rs : (it & 0xFFFFull))];
+    };
+    auto fin_row = [&](u32 c, u64 h) -> u64 { return (c <= 64 && lane < c) ? h : ~0ull; };
+    auto ld_gather = [&](u64 h, u64 it) -> u32 { return ((const u32 *)a.contained)[(h != ~0ull ? HIT_ID(h) : read_of(it)) >> 5]; };
+    auto fin_gather = [&](u64 h, u32 w) -> u64 { return (h != ~0ull && !((w >> (HIT_ID(h) & 31)) & 1u)) ? h : ~0ull; };
     while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
         if (BIG) {
             for (u64 it = cbeg; it < cend; it++) {
@@ -1036,17 +1047,21 @@ __global__ void __launch_bounds__(64, 8) edge_select_kernel(EdgeSelArgs a)
             }
             continue;
         }
-        u32 c0, c1, c2, c3, L0, L1, L2, L3;
-        u64 s0, s1, s2, s3;
-        ld_meta(cbeg, c0, s0, L0);
-        ld_meta(cbeg + 1, c1, s1, L1);
-        ld_meta(cbeg + 2, c2, s2, L2);
-        u64 r1 = ld_row(c1, s1), r2;
-        u64 g0 = ld_filter(ld_row(c0, s0)), g1;
+        /* stages: meta of read it+3 | hit row of it+2 | bitmap gather of it+1 | selection of it */
+        SelMeta m0 = ld_meta(cbeg), m1 = ld_meta(cbeg + 1), m2 = ld_meta(cbeg + 2);
+        u32 c0 = fin_meta(m0, cbeg), c1 = fin_meta(m1, cbeg + 1);
+        u64 s0 = m0.rs, s1 = m1.rs;
+        u32 L0 = m0.LA, L1 = m1.LA;
+        u64 r0 = ld_row(c0, s0, cbeg), r1 = ld_row(c1, s1, cbeg + 1);
+        u64 h0 = fin_row(c0, r0);
+        u32 w0 = ld_gather(h0, cbeg);
         for (u64 it = cbeg; it < cend; it++) {
-            ld_meta(it + 3, c3, s3, L3);
-            r2 = ld_row(c2, s2);
-            g1 = ld_filter(r1);
+            const SelMeta m3 = ld_meta(it + 3);
+            const u32 c2 = fin_meta(m2, it + 2);
+            const u64 r2 = ld_row(c2, m2.rs, it + 2);
+            const u64 h1 = fin_row(c1, r1);
+            const u32 w1 = ld_gather(h1, it + 1);
+            const u64 g0 = fin_gather(h0, w0);
             const u64 A = a.v.q_lo + it;
             if (c0 == 0) {
                 if (lane == 0) a.ref[A] = 0;
@@ -1063,11 +1078,9 @@ __global__ void __launch_bounds__(64, 8) edge_select_kernel(EdgeSelArgs a)
                 n_slow++;
                 edge_select_row(a, A, h, t, c0, lane, cap_sites, dropped, n_edges);
             }
-            c0 = c1; s0 = s1; L0 = L1;
-            c1 = c2; s1 = s2; L1 = L2;
-            c2 = c3; s2 = s3; L2 = L3;
-            r1 = r2;
-            g0 = g1;
+            c0 = c1; s0 = s1; L0 = L1; h0 = h1; w0 = w1;
+            c1 = c2; s1 = m2.rs; L1 = m2.LA; r1 = r2;
+            m2 = m3;
         }
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
