@@ -15,6 +15,7 @@ import json
 import os
 import re
 import sys
+import subprocess
 import tempfile
 import time
 
@@ -34,7 +35,7 @@ def parse_args():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--min-overlap", type=int, default=40)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)  # = BASELINE config 2
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded code path (RCCL collectives) even with one rank")
     return ap.parse_args()
@@ -92,7 +93,12 @@ def cpu_baseline(args, spec_full):
     if refrun.available():
         d = tempfile.mkdtemp(prefix="disco_cpu_")
         fa = os.path.join(d, "sample.fasta")
-        readgen.write_fasta(fa, readgen.generate_reads(spec))
+        gen = os.path.join(ROOT, "disco_amd", "bin", "readgen")  # same generator, C++ (the numpy twin needs ~1 s per 100 k reads)
+        if os.path.exists(gen) and spec.n_contigs == 1:
+            subprocess.run([gen, fa, str(n), str(args.read_len), repr(float(args.coverage)), str(args.seed + 1), str(args.read_len),
+                            str(spec.contig_len)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        else:
+            readgen.write_fasta(fa, readgen.generate_reads(spec))
         r = refrun.run_reference([fa], args.min_overlap, threads=cores, mem_gb=max(8, 2 * cores), workdir=d)
         # graph timer of the reference = HashTable::insertDataset + OverlapGraph (containment, edges, reduction, write)
         t = 0.0
