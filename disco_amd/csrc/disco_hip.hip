@@ -80,6 +80,8 @@ struct disco_ctx {
     u32 *d_n_big = nullptr;
     u32 big_cap = 0;
     u64 big_rows = 0;
+    ProbeRare h_probe_rare;
+    ProbeRare *d_probe_rare = nullptr;
     u32 max_len = 0; /* longest read (validate_reads) */
 
     /* containment */
@@ -421,6 +423,7 @@ void disco_destroy(disco_ctx *c)
     (void)hipFree(c->d_bump);
     (void)hipFree(c->d_n_big);
     (void)hipFree(c->d_n_extra);
+    dev_free(c, &c->d_probe_rare, 1);
     for (int i = 0; i < DISCO_PH_COUNT; i++) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -658,15 +661,19 @@ int disco_probe(disco_ctx *c)
         ProbeArgs a;
         a.v = view(c);
         a.hits = c->d_hits;
-        a.hits_cap = c->hits_cap;
-        a.bump = c->d_bump;
         a.row_start = c->d_row_start;
         a.row_cnt = c->d_row_cnt;
-        a.big_list = c->d_big_list;
-        a.big_cnt = c->d_big_cnt;
-        a.n_big = c->d_n_big;
-        a.big_cap = c->big_cap;
-        a.ablate = getenv("DISCO_PROBE_ABLATE") ? (u32)atoi(getenv("DISCO_PROBE_ABLATE")) : 0u;
+        c->h_probe_rare.bump = c->d_bump;
+        c->h_probe_rare.hits_cap = c->hits_cap;
+        c->h_probe_rare.big_list = c->d_big_list;
+        c->h_probe_rare.big_cnt = c->d_big_cnt;
+        c->h_probe_rare.n_big = c->d_n_big;
+        c->h_probe_rare.big_cap = c->big_cap;
+        c->h_probe_rare.reserved = 0;
+        c->h_probe_rare.ctr = c->d_ctr;
+        if (!c->d_probe_rare) CHK(dev_alloc(c, &c->d_probe_rare, 1));
+        HIPCHK(c, hipMemcpyAsync(c->d_probe_rare, &c->h_probe_rare, sizeof(ProbeRare), hipMemcpyHostToDevice, c->stream));
+        a.rare = c->d_probe_rare;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {

@@ -272,22 +272,32 @@ __global__ void scan_write_total_kernel(const u64 *total, OutT *out_n) { *out_n 
  * The kernel is latency bound (two dependent random loads per read), so its footprint is kept at 8 waves per SIMD:
  * at most 64 VGPRs and 5 KB of LDS per wave.
  * ============================================================================================================== */
-struct ProbeArgs {
-    DiscoView v;
-    u64 *hits;      /* global hit buffer                              */
-    u64 hits_cap;
+/* arguments the hot loop does not touch live in device memory and are fetched where they are used (chunk allocation, row
+ * overflow): as kernel arguments they occupied 14 scalar registers for the whole kernel, which at 8 waves per SIMD
+ * (96 SGPRs) made hipcc spill 61 scalars into VGPR lanes — 305 of the kernel's 868 vector instructions were reloads */
+struct ProbeRare {
     u64 *bump;      /* bump pointer into hits                         */
-    u64 *row_start; /* [n]                                            */
-    u32 *row_cnt;   /* [n]                                            */
-    u64 *big_list;  /* reads whose row did not fit PROBE_ROWCAP       */
+    u64 hits_cap;
+    u64 *big_list;  /* reads whose row did not fit their chunk        */
     u32 *big_cnt;
     u32 *n_big;
     u32 big_cap;
-    u32 ablate;     /* diagnostics only (DISCO_PROBE_ABLATE): 1 = stop after the window pass, 2 = stop after the bucket lookups */
+    u32 reserved;
+    u64 *ctr;
+};
+struct ProbeArgs {
+    DiscoView v;
+    u64 *hits;      /* global hit buffer                              */
+    u64 *row_start; /* [n]                                            */
+    u32 *row_cnt;   /* [n]                                            */
+    const ProbeRare *rare;
 };
 
+#ifndef PROBE_WAVES_PER_SIMD
+#define PROBE_WAVES_PER_SIMD 8
+#endif
 template <bool BIG, bool LDSROW>
-__global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
+__global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
 {
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
      * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
@@ -308,7 +318,7 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
     u64 chunk_base = 0;
     u32 chunk_used = PROBE_CHUNK;
     u32 my_maxrow = 0;
-    const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
+    const u64 n_items = BIG ? (u64)min(*a.rare->n_big, a.rare->big_cap) : (a.v.q_hi - a.v.q_lo);
 
     /* the next read's row and length are fetched while the current read is processed (LDSROW implies S <= 64 words) */
     u64 pre_w = 0;
@@ -321,7 +331,7 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
         if ((int)lane < S) pre_w = a.v.reads[A0 * S + lane];
     }
     for (u64 it = cbeg; it < cend; it++) {
-        const u64 A = BIG ? a.big_list[it] : a.v.q_lo + it;
+        const u64 A = BIG ? a.rare->big_list[it] : a.v.q_lo + it;
         const u64 *ga = a.v.reads + A * S;
         int LA;
         __syncthreads();
@@ -345,17 +355,17 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
         u32 want = 0; /* slots the row may use at grow */
         if (BIG) {
             u64 base = 0;
-            want = a.big_cnt[it];
+            want = a.rare->big_cnt[it];
             if (lane == 0) {
-                base = atomicAdd(a.bump, (u64)want);
-                atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + want);
+                base = atomicAdd(a.rare->bump, (u64)want);
+                atomicMax(&a.rare->ctr[CTR_HITS_NEEDED], base + want);
                 a.row_start[A] = base;
             }
             base = __shfl(base, 0);
-            if (base + want <= a.hits_cap) grow = a.hits + base;
+            if (base + want <= a.rare->hits_cap) grow = a.hits + base;
             else {
                 want = 0;
-                if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                if (lane == 0) atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
             }
         } else {
             /* candidates go straight to the wave's private chunk of the hit buffer (consecutive lanes, consecutive slots);
@@ -363,14 +373,17 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
             if (PROBE_CHUNK - chunk_used < PROBE_ROWCAP) {
                 u64 base = 0;
                 if (lane == 0) {
-                    base = atomicAdd(a.bump, (u64)PROBE_CHUNK);
-                    atomicMax(&a.v.ctr[CTR_HITS_NEEDED], base + PROBE_CHUNK);
-                    if (base + PROBE_CHUNK > a.hits_cap) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                    base = atomicAdd(a.rare->bump, (u64)PROBE_CHUNK);
+                    atomicMax(&a.rare->ctr[CTR_HITS_NEEDED], base + PROBE_CHUNK);
+                    if (base + PROBE_CHUNK > a.rare->hits_cap) {
+                        atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
+                        base = ~0ull; /* no room: this wave writes nothing any more */
+                    }
                 }
                 chunk_base = __shfl(base, 0);
                 chunk_used = 0;
             }
-            if (chunk_base + PROBE_CHUNK <= a.hits_cap) {
+            if (chunk_base != ~0ull) {
                 grow = a.hits + chunk_base + chunk_used;
                 want = PROBE_CHUNK - chunk_used;
             }
@@ -389,7 +402,6 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
         for (int w0 = 0; w0 < npos; w0 += PROBE_SEGW) { /* segments of PROBE_SEGW windows (one for reads up to 256+k bp) */
             const int nw = min(PROBE_SEGW, npos - w0);
             const int np = nw + nf - 1; /* m-mer positions the segment's windows cover */
-            if (a.ablate == 4) continue;
             /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
              *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
             __syncthreads();
@@ -433,7 +445,6 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
                 }
             }
             __syncthreads();
-            if (a.ablate == 1) continue;
             /* 3. the first window of every occurrence leads one bucket lookup */
             u32 nlead = 0;
             for (int ws = 0; ws < nw; ws += 64) {
@@ -466,7 +477,6 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
                 s_occ_start[lane] = s;
                 s_occ_excl[lane] = incl - cnt;
                 __syncthreads();
-                if (a.ablate == 2) continue;
                 /* 4. all records of all led buckets, lane = record: a record names the window(s) it can match through its
                  *    minimizer offset t; the window's own (occurrence, strand) must agree */
                 for (u32 base = 0; base < total; base += 64) {
@@ -504,12 +514,12 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
             if (lane == 0) a.row_cnt[A] = grow ? nrow : 0;
         } else if (grow && nrow > want) {
             if (lane == 0) {
-                u32 idx = atomicAdd(a.n_big, 1u);
-                if (idx < a.big_cap) {
-                    a.big_list[idx] = A;
-                    a.big_cnt[idx] = nrow;
+                u32 idx = atomicAdd(a.rare->n_big, 1u);
+                if (idx < a.rare->big_cap) {
+                    a.rare->big_list[idx] = A;
+                    a.rare->big_cnt[idx] = nrow;
                 } else
-                    atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                    atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
                 a.row_cnt[A] = 0;
                 a.row_start[A] = 0;
             }
@@ -522,7 +532,7 @@ __global__ void __launch_bounds__(64, 8) probe_kernel(ProbeArgs a)
         }
     }
     }
-    if (lane == 0) atomicMax(&a.v.ctr[CTR_MAX_ROW], (u64)my_maxrow);
+    if (lane == 0) atomicMax(&a.rare->ctr[CTR_MAX_ROW], (u64)my_maxrow);
 }
 
 /* ================================================================================================================
