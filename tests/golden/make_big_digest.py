@@ -10,7 +10,7 @@ and this script turns out/x_<t>_parGraph.txt / _containedReads.txt into the cano
 their sha256 (over the sorted int64 arrays, oracle/pyoracle.digest_array) in tests/golden/cases_big.json. Only the digests
 and the generator parameters are committed; the GPU test regenerates the reads on the device from the same parameters.
 
-usage: make_big_digest.py NAME PREFIX THREADS --reads N --contigs C [--seed 42 --len 150 --coverage 30 --min-overlap 40]
+usage: make_big_digest.py NAME PREFIX THREADS --reads N --contigs C [--seed 42 --len 150 --len-max 0 --coverage 30 --min-overlap 40]
 """
 import argparse
 import json
@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--contigs", type=int, required=True)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--len", type=int, default=150)
+    ap.add_argument("--len-max", type=int, default=0, help="longest read (uniform lengths in [len, len-max]); 0 = fixed length")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--min-overlap", type=int, default=40)
     a = ap.parse_args()
@@ -60,7 +61,7 @@ def main():
     assert len(np.unique(cc[:, 0])) == len(cc), "a contained read is listed twice"
     out = os.path.join(HERE, "cases_big.json")
     cases = json.load(open(out)) if os.path.exists(out) else {}
-    cases[a.name] = dict(kind="generated", seed=a.seed, reads=a.reads, read_len=a.len, coverage=a.coverage, n_contigs=a.contigs,
+    cases[a.name] = dict(kind="generated", seed=a.seed, reads=a.reads, read_len=a.len, len_max=a.len_max or a.len, coverage=a.coverage, n_contigs=a.contigs,
                          min_overlap=a.min_overlap, n_edges=int(len(ce)), n_contained=int(len(cc)),
                          edges_sha256=pyoracle.digest_array(ce), contained_sha256=pyoracle.digest_array(cc),
                          reference="oracle/_ref/buildG_ref -se <generated fasta> -t %d" % a.threads)

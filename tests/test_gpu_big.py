@@ -21,7 +21,8 @@ def test_hip_digest_matches_reference_files(name):
     c = CASES[name]
     if c["reads"] > 2_000_000 and not os.environ.get("DISCO_RUN_BIG"):
         pytest.skip("set DISCO_RUN_BIG=1 to run the full-size parity check")
-    spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"])
+    spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"],
+                                    len_max=c.get("len_max", c["read_len"]))
     with buildgraph.BuildGraph(min_overlap=c["min_overlap"]) as g:
         g.generate_reads(spec)
         g.run_graph()
