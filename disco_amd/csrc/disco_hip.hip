@@ -591,7 +591,7 @@ int disco_build_index(disco_ctx *c)
      * one key while the table (4 B per bucket) stays small enough to live in the 256 MB Infinity Cache */
     double tscale = 4.0;
     if (const char *e = getenv("DISCO_BUCKET_SCALE")) tscale = atof(e);
-    while ((double)T < tscale * (double)c->n) {
+    while ((double)T < tscale * (double)c->n && logT < 32) {
         T <<= 1;
         logT++;
     }
@@ -607,8 +607,8 @@ int disco_build_index(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
     ulonglong2 *rec = c->d_rec;
     if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt, rec);
-    CHK((scan_exclusive<u32, u32>(c, c->d_bkt + 1, T, c->d_bkt + 1, false, nullptr)));
-    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, c->bshift, rec, c->d_bkt, c->d_ent);
+    CHK((scan_exclusive<u32, u32>(c, c->d_bkt, T + 1, c->d_bkt, false, nullptr)));
+    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
     ph_end(c, DISCO_PH_INDEX);
     c->phase = 2;

@@ -135,8 +135,8 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * verify compare), so the hit set is the reference's.
  * In-bucket order is arbitrary here: every consumer re-establishes the reference's bucket order (ascending read id,
  * prefix record before suffix record) from the ids carried in the hits (see HIT_MAKE / CKEY_MAKE).
- * bkt has T+1 slots; counts go to bkt[1+b]; after the in-place exclusive scan of bkt[1..T] and the fill (which
- * bumps bkt[1+b] by the bucket size) bucket b is [bkt[b], bkt[b+1]).
+ * bkt has T+1 slots (T <= 2^32); counts go to bkt[b] (the counting atomic hands each record its slot inside the bucket);
+ * after the in-place exclusive scan of bkt[0..T] bucket b is [bkt[b], bkt[b+1]) and the fill is a plain scatter.
  * ============================================================================================================== */
 /* index record of the end k-mer at base pos of read row p: key = minimizer key, t = minimizer offset in canonical orientation */
 __device__ __forceinline__ u64 end_kmer_record(const u64 *__restrict__ p, int S, int pos, int k, int m, u32 &t, u32 &rev)
@@ -149,7 +149,8 @@ __device__ __forceinline__ u64 end_kmer_record(const u64 *__restrict__ p, int S,
 
 __global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec)
 {
-    /* rec[2i], rec[2i+1] = {bucket key, record} of the prefix / suffix k-mer of read i, kept for the fill pass */
+    /* rec[2i], rec[2i+1] = {bucket << 32 | slot inside the bucket, record} of the prefix / suffix k-mer of read i: the slot is
+     * what the counting atomic returns, so the fill pass needs no second round of atomics */
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
         const u64 *p = v.reads + i * v.S;
@@ -157,20 +158,21 @@ __global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong
         u32 tp, rp, ts, rs;
         u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, tp, rp);
         u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, ts, rs);
-        atomicAdd(&bkt[1 + (kp >> v.bshift)], 1u);
-        atomicAdd(&bkt[1 + (ks >> v.bshift)], 1u);
-        rec[2 * i] = make_ulonglong2(kp, PAY_MAKE(kp, i, tp, rp, 0, L));
-        rec[2 * i + 1] = make_ulonglong2(ks, PAY_MAKE(ks, i, ts, rs, 1, L));
+        const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
+        const u32 sp = atomicAdd(&bkt[bp], 1u);
+        const u32 ss = atomicAdd(&bkt[bs], 1u);
+        rec[2 * i] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
+        rec[2 * i + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
     }
 }
 
-__global__ void index_fill_kernel(u64 n2, int bshift, const ulonglong2 *__restrict__ rec, u32 *__restrict__ bkt, u64 *__restrict__ ent)
+/* bkt = exclusive scan of the counts: record goes to bkt[bucket] + slot */
+__global__ void index_fill_kernel(u64 n2, const ulonglong2 *__restrict__ rec, const u32 *__restrict__ bkt, u64 *__restrict__ ent)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n2; i += (u64)gridDim.x * blockDim.x) {
         const ulonglong2 r = rec[i];
-        const u32 pos = atomicAdd(&bkt[1 + (r.x >> bshift)], 1u);
-        ent[pos] = r.y;
+        ent[(u64)bkt[r.x >> 32] + (u32)r.x] = r.y;
     }
 }
 
