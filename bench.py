@@ -263,7 +263,13 @@ def main():
     if rank == 0:
         if dist_timing:
             print("[dist timing, rank 0, ms summed over all steps]", {k: round(v, 1) for k, v in dist_timing.items()}, file=sys.stderr)
-        print(json.dumps(out))
+        try:  # RCCL writes its version banner through C stdio, which is flushed at exit: push it out before the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -105,3 +105,14 @@ def test_high_multiplicity_rows_take_the_big_paths():
         reads.append(s.translate(comp)[::-1] if rng.random() < 0.5 else s)
     c = assert_parity(reads, 40, "multiplicity")
     assert c["big_rows"] > 0
+
+
+def test_bandwidth_probes_report_sane_numbers():
+    """disco_measure_hbm / disco_measure_gather (the measured ceilings bench.py prints beside the nominal 8 TB/s)"""
+    from disco_amd import buildgraph
+
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        copy = g.measure_hbm(256 << 20, 2)
+        gather = g.measure_gather(256 << 20, 2)
+    assert 500.0 < copy < 8000.0, copy      # GB/s, read + write bytes of a streaming copy
+    assert 200.0 < gather < 8000.0, gather  # GB/s of random 64-byte rows
