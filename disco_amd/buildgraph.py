@@ -83,6 +83,10 @@ ABI = [
     ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
     ("disco_phase_ms", C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("disco_export_adjacency32", C.c_int, [_P, _P, _P]),
+    ("disco_adopt_neighbours32", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
+    ("disco_dropped_hits", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("disco_set_global_dropped", C.c_int, [_P, C.c_uint64]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
 ]
@@ -292,6 +296,20 @@ class BuildGraph:
         a = (C.c_float * len(PHASES))()
         self._chk(self.L.disco_phase_ms(self._h, a, len(PHASES)))
         return {n: float(a[i]) for i, n in enumerate(PHASES)}
+
+    def export_adjacency32(self, deg_ptr: int, rows32_ptr: int):
+        self._chk(self.L.disco_export_adjacency32(self._h, _P(deg_ptr), _P(rows32_ptr)))
+
+    def adopt_neighbours32(self, deg_all_ptr: int, rows32_ptr: int, per: int, mx: int, world: int):
+        self._chk(self.L.disco_adopt_neighbours32(self._h, _P(deg_all_ptr), _P(rows32_ptr), per, mx, world))
+
+    def dropped_hits(self) -> int:
+        out = C.c_uint64(0)
+        self._chk(self.L.disco_dropped_hits(self._h, C.byref(out)))
+        return out.value
+
+    def set_global_dropped(self, n_all: int):
+        self._chk(self.L.disco_set_global_dropped(self._h, n_all))
 
     def measure_hbm(self, nbytes: int = 4 << 30, reps: int = 5) -> float:
         """attainable HBM bandwidth in GB/s (read + write bytes of a streaming copy kernel)"""

@@ -80,6 +80,12 @@ struct disco_ctx {
     u32 *d_n_big = nullptr;
     u32 big_cap = 0;
     u64 big_rows = 0;
+    /* sharded flow, compact exchange: neighbour rows as 4-byte entries in a caller-owned gathered array */
+    const u32 *d_nadj32 = nullptr;
+    u64 *d_nref = nullptr;
+    u64 nref_cap = 0;
+    bool nbr32 = false;
+    u64 dropped_local = 0, adj_total_global = 0;
     ProbeRare h_probe_rare;
     ProbeRare *d_probe_rare = nullptr;
     u32 max_len = 0; /* longest read (validate_reads) */
@@ -810,7 +816,8 @@ static int select_edges(disco_ctx *c)
         if (e != hipSuccess) return fail(c, DISCO_E_HIP, "edge_select_kernel<true>: %s", hipGetErrorString(e));
         CHK(rc);
     }
-    c->dropped = c->h_ctr[CTR_DROPPED];
+    c->dropped = c->dropped_local = c->h_ctr[CTR_DROPPED];
+    c->nbr32 = false;
     if (getenv("DISCO_VERBOSE"))
         fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
                 (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
@@ -1019,6 +1026,69 @@ int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
     return DISCO_OK;
 }
 
+int disco_export_adjacency32(disco_ctx *c, void *d_deg_u32, void *d_entries_u32)
+{
+    if (!c || !d_deg_u32) return DISCO_E_ARG;
+    if (c->phase < 5 || c->adj_imported) return fail(c, DISCO_E_STATE, "disco_export_adjacency32: needs the locally selected edges");
+    if (c->n >= (1ull << 30)) return fail(c, DISCO_E_ARG, "disco_export_adjacency32: needs fewer than 2^30 reads");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nq = c->q_hi - c->q_lo;
+    ph_begin(c, DISCO_PH_CSR);
+    if (nq) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_ref, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
+    HIPCHK(c, hipGetLastError());
+    if (nq && c->adj_total && d_entries_u32) {
+        CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, c->n + 1));
+        u64 total = 0;
+        int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32, nq, c->d_start_tmp, true, &total);
+        if (rc == DISCO_OK && total != c->adj_total) rc = fail(c, DISCO_E_STATE, "disco_export_adjacency32: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
+        if (rc == DISCO_OK) hipLaunchKernelGGL(rows_gather32_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, c->q_lo, c->q_hi, c->d_start_tmp, (u32 *)d_entries_u32);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        CHK(rc);
+        if (e != hipSuccess) return fail(c, DISCO_E_HIP, "disco_export_adjacency32: %s", hipGetErrorString(e));
+    }
+    ph_end(c, DISCO_PH_CSR);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ph_collect(c);
+    return DISCO_OK;
+}
+
+int disco_adopt_neighbours32(disco_ctx *c, const void *d_deg_u32_all, const void *d_rows_u32_padded, uint64_t per_rank_nodes, uint64_t max_per_rank, uint32_t world)
+{
+    if (!c || !d_deg_u32_all || !world || !per_rank_nodes) return DISCO_E_ARG;
+    if (c->phase < 5 || c->adj_imported) return fail(c, DISCO_E_STATE, "disco_adopt_neighbours32: needs the locally selected edges");
+    if ((u64)world * per_rank_nodes < c->n) return fail(c, DISCO_E_ARG, "disco_adopt_neighbours32: world*per (%llu) < reads (%llu)", (unsigned long long)((u64)world * per_rank_nodes), (unsigned long long)c->n);
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 slots = (u64)world * per_rank_nodes;
+    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, slots + 1));
+    CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, c->n + 1));
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, slots, c->d_start_tmp, true, &total)));
+    if (c->n) hipLaunchKernelGGL(ref_from_padded_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_start_tmp, (const u32 *)d_deg_u32_all, c->n, per_rank_nodes, max_per_rank, c->d_nref);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->d_nadj32 = (const u32 *)d_rows_u32_padded;
+    c->nbr32 = true;
+    c->adj_total_global = total;
+    c->half_complete = false;
+    return DISCO_OK;
+}
+
+int disco_dropped_hits(disco_ctx *c, uint64_t *n_local)
+{
+    if (!c || !n_local) return DISCO_E_ARG;
+    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_dropped_hits: select edges first");
+    *n_local = c->dropped_local;
+    return DISCO_OK;
+}
+
+int disco_set_global_dropped(disco_ctx *c, uint64_t n_all_ranks)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_set_global_dropped: select edges first");
+    c->dropped = n_all_ranks;
+    return DISCO_OK;
+}
+
 int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all)
 {
     if (!c || !d_deg_u32_all) return DISCO_E_ARG;
@@ -1065,6 +1135,7 @@ int disco_adopt_adjacency(disco_ctx *c, const void *d_deg_u32_all, void *d_rows_
     c->adj_total = total;
     c->adj_span = (u64)world * max_per_rank;
     c->adj_imported = true;
+    c->nbr32 = false;
     c->half_complete = false;
     c->phase = 5;
     return DISCO_OK;
@@ -1133,8 +1204,13 @@ int disco_transitive_mark(disco_ctx *c)
     a.wide_list = c->d_wide;
     a.n_wide = c->d_n_wide;
     a.wide_cap = c->wide_cap;
+    a.nref = c->nbr32 ? c->d_nref : nullptr;
+    a.nadj32 = c->nbr32 ? c->d_nadj32 : nullptr;
     ph_begin(c, DISCO_PH_TRMARK);
-    if (nq) hipLaunchKernelGGL(transitive_mark_kernel<false>, dim3(wq_grid(c, transitive_mark_kernel<false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    if (nq) {
+        if (c->nbr32) hipLaunchKernelGGL((transitive_mark_kernel<false, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    }
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
@@ -1162,11 +1238,12 @@ int disco_transitive_mark(disco_ctx *c)
         a.scratch = (u64 *)scratch;
         a.hcap = hcap;
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(transitive_mark_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
+        if (c->nbr32) hipLaunchKernelGGL((transitive_mark_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL((transitive_mark_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
         hipError_t e2 = hipStreamSynchronize(c->stream);
         dev_free(c, &scratch, (u64)g2 * per);
-        if (e != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel<true>: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        if (e != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel (big nodes): %s", hipGetErrorString(e != hipSuccess ? e : e2));
     }
     c->n_wide = 0;
     if (c->use_half) {

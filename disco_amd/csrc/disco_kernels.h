@@ -1147,6 +1147,22 @@ __global__ void __launch_bounds__(64) rows_gather_kernel(const u64 *__restrict__
     }
 }
 
+/* the same rows as 4-byte entries dst(30) | orient(2) << 30: all the transitive marking reads of a NEIGHBOUR's row
+ * (BG/OverlapGraph.cpp:698-708 use the destination and the orientation only). Needs n < 2^30. */
+#define NBR32_MAKE(e) ((u32)ADJ_DST(e) | (ADJ_ORI(e) << 30))
+#define NBR32_ENTRY(x) ADJ_MAKE(0u, (u64)((x)&0x3FFFFFFFu), (x) >> 30, 0u)
+__global__ void __launch_bounds__(64) rows_gather32_kernel(const u64 *__restrict__ adj, const u64 *__restrict__ ref, u64 lo, u64 hi,
+                                                           const u64 *__restrict__ dst_start, u32 *__restrict__ dst)
+{
+    for (u64 v = lo + blockIdx.x; v < hi; v += gridDim.x) {
+        const u64 r = ref[v];
+        const u32 d = REF_DEG(r);
+        const u64 *src = adj + REF_POS(r);
+        u32 *o = dst + dst_start[v - lo];
+        for (u32 i = threadIdx.x; i < d; i += 64) o[i] = NBR32_MAKE(src[i]);
+    }
+}
+
 /* binary search of key in the sorted row r[0..d) (flag bit ignored); returns index or -1 */
 __device__ __forceinline__ int adj_find(const u64 *__restrict__ r, u32 d, u64 key)
 {
@@ -1304,10 +1320,27 @@ struct TrArgs {
     u32 big_cap;
     u64 *scratch;  /* BIG variant: per block hkey[hcap] | ent(u32)[hcap] | state(u8)[hcap] */
     u64 hcap;      /* power of two >= 2 * max degree */
+    /* N32 variants (sharded flow): the rows of the NEIGHBOURS come from an all-gathered array of 4-byte entries with its own
+     * reference words; ref / adj above then hold the rank's own rows only */
+    const u64 *nref;
+    const u32 *nadj32;
 };
+
+template <bool N32>
+__device__ __forceinline__ u64 tr_nref(const TrArgs &a, u64 u) { return N32 ? a.nref[u] : a.ref[u]; }
+template <bool N32>
+__device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
+{
+    if (N32) {
+        const u32 x = a.nadj32[pos];
+        return NBR32_ENTRY(x);
+    }
+    return a.adj[pos];
+}
 
 #define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
 
+template <bool N32>
 __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey, u8 *hstate, u32 *sent, u32 hmask, u32 lane)
 {
     const u64 vs = REF_POS(a.ref[v]);
@@ -1333,12 +1366,12 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         const u64 e1 = row[i];
         const u64 u = ADJ_DST(e1);
         const u32 type1 = ADJ_ORI(e1);
-        const u64 ru = a.ref[u];
+        const u64 ru = tr_nref<N32>(a, u);
         const u64 us = REF_POS(ru);
         const u32 du = REF_DEG(ru);
         const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
         for (u32 t = lane; t < du; t += 64) {        /* :698 */
-            const u64 e2 = a.adj[us + t];
+            const u64 e2 = tr_nent<N32>(a, us + t);
             const u32 type2 = ADJ_ORI(e2);
             const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
             if (!ok) continue;
@@ -1402,6 +1435,7 @@ __device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
     return ((u64)hi << 32) | lo;
 }
 
+template <bool N32>
 __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs &nd, u64 *hkey, u8 *hstate, u32 lane)
 {
     const u32 d = nd.d;
@@ -1417,8 +1451,8 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     const u32 s2 = nd.s2;
     const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
     const u32 d0 = REF_DEG(nd.r0), d2 = REF_DEG(nd.r2);
-    const u64 p0 = (lane < d0) ? nd.p0 : 0ull;
-    const u64 p2 = (lane < d2) ? nd.p2 : 0ull;
+    const u64 p0 = (lane < d0) ? (N32 ? NBR32_ENTRY((u32)nd.p0) : nd.p0) : 0ull;
+    const u64 p2 = (lane < d2) ? (N32 ? NBR32_ENTRY((u32)nd.p2) : nd.p2) : 0ull;
     __syncthreads();
     u32 sent = 0;
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
@@ -1465,7 +1499,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         auto sweep = [&](u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
             if (lane < du) mark(pre);
             if (du > 64)
-                for (u32 t = 64 + lane; t < du; t += 64) mark(a.adj[us + t]);
+                for (u32 t = 64 + lane; t < du; t += 64) mark(tr_nent<N32>(a, us + t));
         };
         /* three copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
          * lands on the common path and drains the kernel's prefetch pipeline */
@@ -1474,10 +1508,10 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         else if (i == s2)
             sweep(st2, d2, p2);
         else {
-            const u64 ru = a.ref[ADJ_DST(e1)];
+            const u64 ru = tr_nref<N32>(a, ADJ_DST(e1));
             const u64 us = REF_POS(ru);
             const u32 du = REF_DEG(ru);
-            sweep(us, du, (lane < du) ? a.adj[us + lane] : 0ull);
+            sweep(us, du, (lane < du) ? tr_nent<N32>(a, us + lane) : 0ull);
         }
         __syncthreads();
     }
@@ -1503,7 +1537,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 #ifndef TR_WAVES_PER_SIMD
 #define TR_WAVES_PER_SIMD 6
 #endif
-template <bool BIG>
+template <bool BIG, bool N32>
 __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(TrArgs a)
 {
     __shared__ u64 s_hkey[BIG ? 1 : 2 * TR_CAP];
@@ -1549,15 +1583,22 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         const u64 om = __ballot(lane < r.d && (ADJ_ORI(r.e) >> 1) != side0);
         r.s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
         const u64 u0 = r.d ? ADJ_DST(readlane_u64(r.e, 0)) : r.v, u2 = r.d ? ADJ_DST(readlane_u64(r.e, r.s2)) : r.v;
-        r.r0 = a.ref[u0 < n_nodes ? u0 : r.v];
-        r.r2 = a.ref[u2 < n_nodes ? u2 : r.v];
+        r.r0 = tr_nref<N32>(a, u0 < n_nodes ? u0 : r.v);
+        r.r2 = tr_nref<N32>(a, u2 < n_nodes ? u2 : r.v);
     };
     auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 (broadcast loads: scalar from here on) */
         r.r0 = uniform_u64(r.r0);
         r.r2 = uniform_u64(r.r2);
         const u32 d0 = r.d ? REF_DEG(r.r0) : 0u, d2 = r.d ? REF_DEG(r.r2) : 0u;
-        r.p0 = a.adj[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : r.vs];
-        r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
+        /* raw words only: N32 entries are expanded where they are consumed (nothing is computed from a loaded value in the
+         * iteration that issues the load) */
+        if (N32) {
+            r.p0 = a.nadj32[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : 0];
+            r.p2 = a.nadj32[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : 0];
+        } else {
+            r.p0 = a.adj[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : r.vs];
+            r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
+        }
     };
     while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
     if (BIG) {
@@ -1565,7 +1606,7 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
             const u64 v = a.big_list[it];
             const u32 d = REF_DEG(a.ref[v]);
             if (d == 0) continue;
-            tr_node(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
+            tr_node<N32>(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
         }
         continue;
     }
@@ -1583,12 +1624,12 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         TrNodeRegs n3 = stage_row(it + 3);
         const u64 v = a.v.q_lo + it;
         if (n0.d != 0)
-            tr_node_small(a, n0, s_hkey, s_state, lane);
+            tr_node_small<N32>(a, n0, s_hkey, s_state, lane);
         else if (n0.dfull != 0) {
             if (n0.dfull <= TR_CAP) {
                 u32 hc = 64;
                 while (hc < 2 * n0.dfull) hc <<= 1;
-                tr_node(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
+                tr_node<N32>(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
             } else if (lane == 0) {
                 u32 idx = atomicAdd(a.n_big, 1u);
                 if (idx < a.big_cap) a.big_list[idx] = v;

@@ -6,7 +6,9 @@ Replaces the reference's two multi-process variants (design e-1)
   * buildG-MPIRMA : the same with the hash data behind MPI_Get (RMA/HashTable.cpp:615-708)
 with three bulk collectives over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests):
   1. all-reduce(MIN) of the containment keys                               (after the probe)
-  2. in-place all-gather of the per-shard adjacency (degrees + rows)        (after edge selection)
+  2. in-place all-gather of the per-shard adjacency (degrees + rows)        (after edge selection); in the regular regime
+     (nobody dropped a verified hit, fewer than 2^30 reads) the rows travel as 4-byte (destination, orientation) entries —
+     all the marking reads of a neighbour's row — which halves the bytes of the step that bounds the flow on xGMI
   3. in-place all-gather of each node's few surviving edges (32 B / node)   (after marking; one flag byte per adjacency
      slot instead when some node has more than 4 survivors)
 Results stay sharded: rank r emits the edges whose smaller endpoint lies in its range.
@@ -16,6 +18,8 @@ gloo (tests/test_distributed_gloo.py); HipEngine adapts disco_amd.buildgraph.Bui
 tensors through disco_memcpy_d2d).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -119,12 +123,46 @@ def distributed_step(engine, group=None, timing=None, comm=None):
     engine.select_edges()
     lap("contain+select")
     # (2) adjacency of every shard to everybody: the reduction of node v reads the lists of v's neighbours
-    cnt = torch.tensor([engine.adjacency_size()], dtype=torch.int64, device=keys.device)
+    dev = keys.device
+    cnt = torch.tensor([engine.adjacency_size()], dtype=torch.int64, device=dev)
     comm.all_reduce(cnt, "max")
     mx = max(int(cnt.item()), 1)
+    tot = torch.tensor([engine.adjacency_size(), engine.dropped_hits()], dtype=torch.int64, device=dev)
+    comm.all_reduce(tot, "sum")
+    total_entries, dropped_all = int(tot[0].item()), int(tot[1].item())
+    # a list can miss a twin only if the twin's owner dropped a verified hit, and the owner may sit on another rank: the
+    # shortcut of the twin search needs the count of ALL ranks
+    engine.set_global_dropped(dropped_all)
     deg_pad = engine.buffer("deg", world * per, torch.int32)
-    rows_pad = engine.buffer("rows", world * mx, torch.int64)
     deg_pad[rank * per + nloc:(rank + 1) * per].zero_()
+    compact = (getattr(engine, "supports_compact", False) and n < (1 << 30) and dropped_all == 0
+               and not os.environ.get("DISCO_NO_COMPACT"))
+    if compact:
+        rows32_pad = engine.buffer("rows32", world * mx, torch.int32)
+        engine.export_adjacency32(deg_pad[rank * per:rank * per + nloc], rows32_pad[rank * mx:(rank + 1) * mx])
+        lap("export")
+        comm.allgather_inplace(deg_pad, per)
+        comm.allgather_inplace(rows32_pad, mx)
+        lap("allgather_adjacency")
+        engine.adopt_neighbours32(deg_pad, rows32_pad, per, mx, world)
+        lap("adopt")
+        engine.symmetrize(False)  # nothing was dropped anywhere: symmetric by construction, no search
+        engine.transitive_mark()
+        lap("mark")
+        wide = torch.tensor([engine.n_wide()], dtype=torch.int64, device=dev)
+        comm.all_reduce(wide, "sum")
+        if int(wide.item()) == 0:
+            _exchange_half(engine, comm, world, rank, per, nloc, n)
+            lap("exchange_survivors")
+            e_out_local = engine.emit_edges()
+            lap("emit")
+            out = torch.tensor([e_out_local], dtype=torch.int64, device=dev)
+            comm.all_reduce(out, "sum")
+            return dict(e_pre=total_entries // 2, e_out_local=e_out_local, e_out=int(out[0].item()), n_contained=n_contained,
+                        asymmetric_pairs=0, range=(lo, hi), exchange="rows32")
+        # some node keeps more than 4 edges: its survivors do not fit the 32-byte lists and the flag exchange needs the
+        # slots of the full rows -> redo the exchange with 8-byte entries (flags are stripped by the export)
+    rows_pad = engine.buffer("rows", world * mx, torch.int64)
     engine.export_adjacency(deg_pad[rank * per:rank * per + nloc], rows_pad[rank * mx:(rank + 1) * mx])
     lap("export")
     comm.allgather_inplace(deg_pad, per)
@@ -146,12 +184,7 @@ def distributed_step(engine, group=None, timing=None, comm=None):
     wide = torch.tensor([engine.n_wide()], dtype=torch.int64, device=keys.device)
     comm.all_reduce(wide, "sum")
     if int(wide.item()) == 0 and int(asym.item()) == 0:
-        half_pad = engine.buffer("half", world * per * 4, torch.int64)
-        hcnt_pad = engine.buffer("hcnt", world * per, torch.int32)
-        engine.export_half(half_pad[rank * per * 4:(rank * per + nloc) * 4], hcnt_pad[rank * per:rank * per + nloc])
-        comm.allgather_inplace(half_pad, per * 4)
-        comm.allgather_inplace(hcnt_pad, per)
-        engine.import_half(half_pad[: n * 4], hcnt_pad[:n])
+        _exchange_half(engine, comm, world, rank, per, nloc, n)
     else:
         flags_local, slot_lo, slot_hi, span = engine.get_flags()
         if int(asym.item()):  # every rank merged all lists into a compact node-ordered array: ragged exchange
@@ -169,7 +202,17 @@ def distributed_step(engine, group=None, timing=None, comm=None):
     tot = torch.tensor([e_out_local], dtype=torch.int64, device=keys.device)
     comm.all_reduce(tot, "sum")
     return dict(e_pre=engine.total_edges() // 2, e_out_local=e_out_local, e_out=int(tot[0].item()), n_contained=n_contained,
-                asymmetric_pairs=int(asym.item()), range=(lo, hi))
+                asymmetric_pairs=int(asym.item()), range=(lo, hi), exchange="rows64")
+
+
+def _exchange_half(engine, comm, world, rank, per, nloc, n):
+    """in-place all-gather of every node's survivor list (4 entries) and survivor count"""
+    half_pad = engine.buffer("half", world * per * 4, torch.int64)
+    hcnt_pad = engine.buffer("hcnt", world * per, torch.int32)
+    engine.export_half(half_pad[rank * per * 4:(rank * per + nloc) * 4], hcnt_pad[rank * per:rank * per + nloc])
+    comm.allgather_inplace(half_pad, per * 4)
+    comm.allgather_inplace(hcnt_pad, per)
+    engine.import_half(half_pad[: n * 4], hcnt_pad[:n])
 
 
 class HipEngine:
@@ -237,6 +280,26 @@ class HipEngine:
         self.g.export_adjacency(deg_view.data_ptr() if deg_view.numel() else self.buffer("dummy", 16, torch.int32).data_ptr(),
                                 rows_view.data_ptr() if total else 0)
         return deg_view, rows_view[:total]
+
+    supports_compact = True
+
+    def dropped_hits(self):
+        return self.g.dropped_hits()
+
+    def set_global_dropped(self, n_all):
+        self.g.set_global_dropped(n_all)
+
+    def export_adjacency32(self, deg_view, rows32_view):
+        torch.cuda.synchronize(self.device)
+        total = self.g.adjacency_size()
+        assert rows32_view.numel() >= total
+        self.g.export_adjacency32(deg_view.data_ptr() if deg_view.numel() else self.buffer("dummy", 16, torch.int32).data_ptr(),
+                                  rows32_view.data_ptr() if total else 0)
+
+    def adopt_neighbours32(self, deg_pad, rows32_pad, per, mx, world):
+        torch.cuda.synchronize(self.device)
+        self._adopted = (deg_pad, rows32_pad)  # keep the tensors alive while the context addresses them
+        self.g.adopt_neighbours32(deg_pad.data_ptr(), rows32_pad.data_ptr(), per, mx, world)
 
     def import_adjacency(self, deg_all, rows_all):
         torch.cuda.synchronize(self.device)

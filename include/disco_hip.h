@@ -170,6 +170,21 @@ int disco_import_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, const void
  * context addresses them where they lie (caller-owned, must outlive the pass; marking sets flag bits in them). */
 int disco_adopt_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, void *d_rows_u64_padded, uint64_t per_rank_nodes,
                           uint64_t max_per_rank, uint32_t world);
+/* Compact form of the exchange for the regular regime (no read dropped a verified hit anywhere, fewer than 2^30 reads):
+ * the transitive marking reads only (destination, orientation) of a NEIGHBOUR's row (BG/OverlapGraph.cpp:698-708), so the
+ * rows travel as 4-byte entries dst(30) | orient(2) << 30 — half the bytes of disco_export_adjacency, and the all-gather of
+ * the rows is what bounds the sharded flow on xGMI. disco_export_adjacency32 writes this rank's degrees and rows (node
+ * order), disco_adopt_neighbours32 makes the context read neighbour rows from the gathered, rank-major padded array
+ * (layout of disco_adopt_adjacency) while its own rows stay where edge selection left them. The survivor lists
+ * (disco_half_lists) then carry the result; with wide nodes the caller falls back to the 8-byte exchange. */
+int disco_export_adjacency32(disco_ctx *ctx, void *d_deg_u32, void *d_entries_u32);
+int disco_adopt_neighbours32(disco_ctx *ctx, const void *d_deg_u32_all, const void *d_rows_u32_padded, uint64_t per_rank_nodes,
+                             uint64_t max_per_rank, uint32_t world);
+/* verified hits that edge selection did not turn into an edge on THIS rank (second hit to a destination, per-k-mer cap);
+ * lists can be asymmetric only if some rank dropped one, so the sharded caller sums the counts over all ranks and hands the
+ * total back before disco_symmetrize (the twin search is skipped only when nobody dropped anything) */
+int disco_dropped_hits(disco_ctx *ctx, uint64_t *n_local);
+int disco_set_global_dropped(disco_ctx *ctx, uint64_t n_all_ranks);
 /* survivor lists written by disco_transitive_mark: half = uint64[n][4] (the first 4 edges of a node not flagged from its own
  * end, list order), hcnt = uint32[n] (how many there are), n_wide = local nodes with more than 4. Ranks all-gather their
  * node ranges of both arrays into these buffers and call disco_half_complete(ctx, 1): the emission then needs neither the

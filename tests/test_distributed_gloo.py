@@ -28,8 +28,10 @@ def row_of(v):
 
 
 class MockEngine:
-    def __init__(self, rank, world, asym_on_rank=None, wide_on_rank=None):
+    def __init__(self, rank, world, asym_on_rank=None, wide_on_rank=None, compact=False, dropped_on_rank=None):
         self.rank, self.world = rank, world
+        self.supports_compact = compact
+        self.dropped_on_rank = dropped_on_rank
         self.num_reads = N_READS
         self.asym_on_rank = asym_on_rank
         self.wide_on_rank = wide_on_rank
@@ -81,6 +83,21 @@ class MockEngine:
         rows = [x for v in range(self.lo, self.hi) for x in row_of(v)]
         rows_view[: len(rows)] = torch.tensor(rows, dtype=torch.int64)
 
+    def dropped_hits(self):
+        return 5 if self.dropped_on_rank == self.rank else 0
+
+    def set_global_dropped(self, n_all):
+        self.global_dropped = n_all
+
+    def export_adjacency32(self, deg_view, rows32_view):
+        self.log.append("export32")
+        deg_view.copy_(torch.tensor([deg_of(v) for v in range(self.lo, self.hi)], dtype=torch.int32))
+        rows = [x % 100003 for v in range(self.lo, self.hi) for x in row_of(v)]
+        rows32_view[: len(rows)] = torch.tensor(rows, dtype=torch.int32)
+
+    def adopt_neighbours32(self, deg_pad, rows32_pad, per, mx, world):
+        self.adopted32 = (deg_pad.clone(), rows32_pad.clone(), per, mx, world)
+
     def adopt_adjacency(self, deg_pad, rows_pad, per, mx, world):
         self.adopted = (deg_pad.clone(), rows_pad.clone(), per, mx, world)
 
@@ -122,6 +139,45 @@ class MockEngine:
 
     def emit_edges(self):
         return self.hi - self.lo
+
+
+def _worker_compact(rank, world, port, wide_on_rank, dropped_on_rank, q):
+    """the 4-byte row exchange: used iff nobody dropped a hit; falls back to the 8-byte exchange when a rank reports wide nodes"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = MockEngine(rank, world, None, wide_on_rank, compact=True, dropped_on_rank=dropped_on_rank)
+        res = D.distributed_step(eng)
+        per = (N_READS + world - 1) // world
+        shard_tot = [sum(deg_of(v) for v in range(*D.shard_range(N_READS, r, world))) for r in range(world)]
+        assert eng.global_dropped == (5 if dropped_on_rank is not None else 0)  # every rank learns the sum over all ranks
+        assert res["e_pre"] == sum(shard_tot) // 2 and res["e_out"] == N_READS
+        if dropped_on_rank is not None:
+            assert "export32" not in eng.log and res["exchange"] == "rows64"
+        else:
+            deg_pad, rows32_pad, per2, mx, w2 = eng.adopted32
+            assert (per2, w2, mx) == (per, world, max(shard_tot))
+            assert deg_pad[:N_READS].tolist() == [deg_of(v) for v in range(N_READS)]
+            for r in range(world):
+                lo, hi = D.shard_range(N_READS, r, world)
+                want = [x % 100003 for v in range(lo, hi) for x in row_of(v)]
+                assert rows32_pad[r * mx:r * mx + len(want)].tolist() == want
+            if wide_on_rank is None:
+                assert res["exchange"] == "rows32" and eng.log.count("mark") == 1 and "flags" not in eng.log
+                assert eng.half_all.tolist() == [v * 10 + r for v in range(N_READS) for r in range(4)]
+            else:  # wide nodes: the marking is redone on the 8-byte rows and the flags travel
+                assert res["exchange"] == "rows64" and eng.log.count("mark") == 2 and "flags" in eng.log
+                mx64 = eng.adopted[3]
+                for r in range(world):
+                    assert eng.flags_all[r * mx64:r * mx64 + shard_tot[r]].tolist() == [r + 1] * shard_tot[r]
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, f"FAIL: {type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
 
 
 def _worker(rank, world, port, asym_on_rank, wide_on_rank, q):
@@ -189,6 +245,20 @@ def test_distributed_step_over_gloo(world, asym, wide):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, asym, wide, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+@pytest.mark.parametrize("world,wide,dropped", [(2, None, None), (3, None, None), (3, 1, None), (2, None, 1)])
+def test_distributed_step_compact_exchange_over_gloo(world, wide, dropped):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_compact, args=(r, world, port, wide, dropped, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]

@@ -75,6 +75,7 @@ def run_sharded(reads, min_overlap, G):
         edges = np.concatenate([g.fetch_edges() for g in gs])
         rows = gs[0].fetch_contained()
         assert sum(r["e_out_local"] for r in results) == len(edges) == results[0]["e_out"]
+        run_sharded.last_exchange = results[0]["exchange"]
         return edges, rows, results[0]["e_pre"], results[0]["asymmetric_pairs"]
     finally:
         for g in gs:
@@ -84,11 +85,23 @@ def run_sharded(reads, min_overlap, G):
 @pytest.mark.parametrize("name", ["u150_5k", "mixed_4k"])
 @pytest.mark.parametrize("G", [1, 2, 3, 4])
 def test_sharded_equals_reference(name, G):
+    """regular regime: neighbour rows travel as 4-byte entries"""
     reads, fidx, mo = gu.case_inputs(name)
     edges, rows, e_pre, asym = run_sharded(reads, mo, G)
     ce, cc = canon_hip(edges, rows, fidx)
     gu.check_against_golden(name, ce, cc)
-    assert asym == 0
+    assert asym == 0 and run_sharded.last_exchange == "rows32"
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_sharded_full_row_exchange_equals_reference(G, monkeypatch):
+    """the 8-byte exchange (what reads >= 2^30, dropped hits or wide nodes fall back to), forced"""
+    monkeypatch.setenv("DISCO_NO_COMPACT", "1")
+    reads, fidx, mo = gu.case_inputs("mixed_4k")
+    edges, rows, e_pre, asym = run_sharded(reads, mo, G)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden("mixed_4k", ce, cc)
+    assert asym == 0 and run_sharded.last_exchange == "rows64"
 
 
 @pytest.mark.parametrize("G", [2, 3])
@@ -112,3 +125,4 @@ def test_sharded_many_survivor_nodes_take_the_flag_exchange(monkeypatch):
     edges, rows, e_pre, asym = run_sharded(reads, mo, 2)
     ce, cc = canon_hip(edges, rows, fidx)
     gu.check_against_golden("mixed_4k", ce, cc)
+    assert run_sharded.last_exchange == "rows64"  # the 4-byte attempt was abandoned after the marking
