@@ -20,6 +20,8 @@
 #define PROBE_SEGP (PROBE_SEGW + 64) /* m-mer positions a segment covers: windows + (k - m) <= 63              */
 #define PROBE_ACAP 32     /* words of the query read's own row staged in LDS (reads up to 1024 bp)              */
 #define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
+#define ES_DUPBITS 11     /* edge_select: byte table of the duplicate-destination pre-check                         */
+#define ES_DUPTAB (1 << ES_DUPBITS)
 #define ES_CAP 256        /* edge_select: hits of one read sorted in LDS (longer rows: global-scratch variant)  */
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
@@ -979,17 +981,30 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
  * verified hit to a non-contained read becomes an edge and the consumption order is irrelevant: one 32-bit sort of the
  * destinations proves the first condition, an LDS histogram of the windows the second, and only the sort by offset remains.
  * Anything else falls through to edge_select_row_fast (exact for every row of at most 64 hits). */
-__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u64 rs, u32 LA, u64 hit, u32 lane, u32 *s_jcnt, u64 &n_edges)
+__device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u64 rs, u32 LA, u64 hit, u32 lane, u32 *s_jcnt, u8 *s_dup,
+                                                    u64 &n_edges)
 {
     u64 *row = a.hits + rs;
     const bool valid = hit != ~0ull;
     const u32 j = HIT_J(hit);
     s_jcnt[lane] = 0;
     s_jcnt[lane + 64] = 0;
-    const u32 bkey = valid ? (u32)HIT_ID(hit) : (0x80000000u | lane);
-    const u32 sb = wave_bitonic_sort32(bkey, lane);
-    const u32 nb = __shfl_down(sb, 1);
-    const bool dup = (lane < 63) && (sb == nb);
+    /* "no destination twice": every hit stamps its lane on a hashed byte slot (ES_DUPTAB slots, all zero between reads); if
+     * every lane reads its own stamp back no two destinations even share a slot. Otherwise (true duplicate or a slot
+     * collision, about a third of the rows) the 32-bit sort of the destinations decides. */
+    const u32 slot = ((u32)HIT_ID(hit) * 0x9E3779B1u) >> (32 - ES_DUPBITS);
+    if (valid) s_dup[slot] = (u8)(lane + 1);
+    __syncthreads();
+    const bool lost = valid && s_dup[slot] != (u8)(lane + 1);
+    __syncthreads();
+    if (valid) s_dup[slot] = 0;
+    bool dup = false;
+    if (__any(lost)) {
+        const u32 bkey = valid ? (u32)HIT_ID(hit) : (0x80000000u | lane);
+        const u32 sb = wave_bitonic_sort32(bkey, lane);
+        const u32 nb = __shfl_down(sb, 1);
+        dup = (lane < 63) && (sb == nb);
+    }
     __syncthreads();
     if (valid) atomicAdd(&s_jcnt[j & 127u], 1u);
     __syncthreads();
@@ -1015,7 +1030,12 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];
     __shared__ u32 s_jcnt[128];
+    __shared__ u8 s_dup[BIG ? 1 : ES_DUPTAB];
     const u32 lane = threadIdx.x;
+    if (!BIG) {
+        for (u32 i = lane; i < ES_DUPTAB; i += 64) s_dup[i] = 0;
+        __syncthreads();
+    }
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
     u64 n_edges = 0; /* wave-uniform */
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
@@ -1084,7 +1104,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
                     else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
                     a.ref[A] = 0;
                 }
-            } else if (c0 <= 64 && edge_select_row_all(a, A, s0, L0, g0, lane, s_jcnt, n_edges)) {
+            } else if (c0 <= 64 && edge_select_row_all(a, A, s0, L0, g0, lane, s_jcnt, s_dup, n_edges)) {
             } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
             } else {
                 n_slow++;
