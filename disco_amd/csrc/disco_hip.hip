@@ -593,9 +593,9 @@ int disco_build_index(disco_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     u64 T = 1024;
     int logT = 10;
-    /* records are keyed by minimizer: about one distinct key per 7-8 records at 30x, so n buckets keep most buckets at
-     * one key while the table (4 B per bucket) stays small enough to live in the 256 MB Infinity Cache */
-    double tscale = 4.0;
+    /* records are keyed by minimizer: about one distinct key per 3-4 records at 30x. T >= 2n buckets (measured at 50 M reads:
+     * n / 2n / 4n / 8n buckets -> index 15.2 / 16.4 / 18.6 / 21.0 ms, probe 47.0 / 45.6 / 45.4 / 45.4 ms) */
+    double tscale = 2.0;
     if (const char *e = getenv("DISCO_BUCKET_SCALE")) tscale = atof(e);
     while ((double)T < tscale * (double)c->n && logT < 32) {
         T <<= 1;
