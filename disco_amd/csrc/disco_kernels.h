@@ -61,7 +61,7 @@ enum {
 /* dynamic work distribution: a wave grabs WQ_CHUNK consecutive items at a time from a global counter, so the run time does
  * not depend on how many workgroups happen to be resident (a static blockIdx-strided loop ran 30-40 % slower whenever
  * the grid was not a multiple of the resident workgroups) */
-#define WQ_CHUNK 32
+#define WQ_CHUNK 64
 __device__ __forceinline__ bool wq_grab(u64 *counter, u64 n, u64 &beg, u64 &end)
 {
     u64 b = 0;
