@@ -874,7 +874,28 @@ __device__ __forceinline__ void wave_rank_sort(const u64 *src, u64 *dst, u32 m, 
     }
 }
 
-__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 &cap_sites, u32 &dropped, u64 &n_edges)
+/* ascending bitonic sort of h[0..P) in LDS, P a power of two >= 64 (wave cooperative, P/2 compare-exchanges per step) */
+__device__ __forceinline__ void lds_bitonic_sort(u64 *h, u32 P, u32 lane)
+{
+    for (u32 k2 = 2; k2 <= P; k2 <<= 1)
+        for (u32 j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (u32 t = lane; t < P / 2; t += 64) {
+                const u32 i = 2 * t - (t & (j2 - 1)); /* t with a zero inserted at bit log2(j2) */
+                const u64 x = h[i], y = h[i + j2];
+                const bool up = (i & k2) == 0;
+                if ((x > y) == up) {
+                    h[i] = y;
+                    h[i + j2] = x;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+/* LDS_WIDE: h / t are LDS arrays of ES_CAP entries and s_jcnt a 128-slot LDS histogram (ordinary variant) */
+template <bool LDS_WIDE>
+__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 *s_jcnt, u32 &cap_sites,
+                                                u32 &dropped, u64 &n_edges)
 {
     u64 *row = a.hits + a.row_start[A];
     const u32 LA = a.v.len[A];
@@ -893,6 +914,57 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         m += __popcll(mk);
     }
     __syncthreads();
+    if (LDS_WIDE && m <= ES_CAP) {
+        /* 1b. rows of 65..ES_CAP hits (45x-170x coverage): the same shortcut as edge_select_row_all. No destination twice —
+         * decided exactly by an LDS hash set (linear probing, 512 slots in the space of t) — and no window over the cap
+         * (LDS histogram; slots shared by windows 128 apart only make the test conservative): every hit becomes an edge and
+         * only the sort by offset remains (bitonic in LDS). Otherwise the sequential scan below decides. */
+        u32 *hs = (u32 *)t;
+        for (u32 i = lane; i < 512; i += 64) hs[i] = 0xFFFFFFFFu;
+        s_jcnt[lane] = 0;
+        s_jcnt[lane + 64] = 0;
+        __syncthreads();
+        bool bad = false;
+        for (u32 i = lane; i < m; i += 64) {
+            const u64 hit = h[i];
+            const u32 id = (u32)HIT_ID(hit);
+            u32 idx = (id * 0x9E3779B1u) >> 23;
+            for (;;) {
+                const u32 old = atomicCAS(&hs[idx], 0xFFFFFFFFu, id);
+                if (old == 0xFFFFFFFFu) break;
+                if (old == id) {
+                    bad = true;
+                    break;
+                }
+                idx = (idx + 1) & 511u;
+            }
+            atomicAdd(&s_jcnt[HIT_J(hit) & 127u], 1u);
+        }
+        __syncthreads();
+        for (u32 i = lane; i < m; i += 64) bad |= s_jcnt[HIT_J(h[i]) & 127u] > a.max_per_kmer;
+        if (!__any(bad)) {
+            u32 P = 64;
+            while (P < m) P <<= 1;
+            for (u32 i = lane; i < P; i += 64) {
+                u64 ent = ~0ull;
+                if (i < m) {
+                    const u64 hit = h[i];
+                    u32 orient, off;
+                    disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, HIT_J(hit), &orient, &off);
+                    ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit));
+                }
+                h[i] = ent;
+            }
+            __syncthreads();
+            lds_bitonic_sort(h, P, lane);
+            for (u32 i = lane; i < m; i += 64) row[i] = h[i];
+            if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], m);
+            n_edges += m;
+            __syncthreads();
+            return;
+        }
+        __syncthreads();
+    }
     /* 2. consumption order */
     wave_rank_sort(h, t, m, lane);
     __syncthreads();
@@ -1075,7 +1147,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             for (u64 it = cbeg; it < cend; it++) {
                 const u64 A = a.big_list[it];
                 n_slow++;
-                edge_select_row(a, A, h, t, a.row_cnt[A], lane, cap_sites, dropped, n_edges);
+                edge_select_row<false>(a, A, h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges);
             }
             continue;
         }
@@ -1108,7 +1180,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
             } else {
                 n_slow++;
-                edge_select_row(a, A, h, t, c0, lane, cap_sites, dropped, n_edges);
+                edge_select_row<true>(a, A, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges);
             }
             c0 = c1; s0 = s1; L0 = L1; h0 = h1; w0 = w1;
             c1 = c2; s1 = m2.rs; L1 = m2.LA; r1 = r2;
