@@ -761,6 +761,27 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */
+/* the big-item lists (rows / nodes beyond the LDS capacities) must hold every such item: count them first */
+static int ensure_big_cap(disco_ctx *c, const u32 *cnt, const u64 *ref, u32 thr)
+{
+    const u64 nq = c->q_hi - c->q_lo;
+    CHK(zero_counter(c, CTR_ES_BIG));
+    if (nq) hipLaunchKernelGGL(count_above_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, cnt, ref, c->q_lo, c->q_hi, thr, c->d_ctr + CTR_ES_BIG);
+    HIPCHK(c, hipGetLastError());
+    CHK(read_counters(c));
+    const u64 need = c->h_ctr[CTR_ES_BIG] + 1024;
+    if (need > c->big_cap) {
+        if (need > 0xFFFFFFFFull) return fail(c, DISCO_E_CAPACITY, "more than 2^32 big rows");
+        dev_free(c, &c->d_big_list, c->big_cap);
+        dev_free(c, &c->d_big_cnt, c->big_cap);
+        c->big_cap = 0;
+        CHK(dev_alloc(c, &c->d_big_list, need));
+        CHK(dev_alloc(c, &c->d_big_cnt, need));
+        c->big_cap = (u32)need;
+    }
+    return DISCO_OK;
+}
+
 static int select_edges(disco_ctx *c)
 {
     const u64 nq = c->q_hi - c->q_lo;
@@ -772,6 +793,7 @@ static int select_edges(disco_ctx *c)
     CHK(zero_counter(c, CTR_ES_SLOW));
     CHK(zero_counter(c, CTR_ADJ_TOTAL));
     CHK(zero_counter(c, CTR_OVERFLOW));
+    CHK(ensure_big_cap(c, c->d_row_cnt, nullptr, ES_CAP)); /* the kernel rewrites rows in place: it cannot be rerun after an overflow */
     EdgeSelArgs a;
     a.v = view(c);
     a.contained = c->d_cbits;
@@ -785,13 +807,6 @@ static int select_edges(disco_ctx *c)
     a.big_cap = c->big_cap;
     a.scratch = nullptr;
     a.scratch_cap = 0;
-    if (c->big_cap == 0) { /* probe always allocates it; be safe */
-        CHK(dev_alloc(c, &c->d_big_list, 1024));
-        CHK(dev_alloc(c, &c->d_big_cnt, 1024));
-        c->big_cap = 1024;
-        a.big_list = c->d_big_list;
-        a.big_cap = c->big_cap;
-    }
     ph_begin(c, DISCO_PH_SELECT);
     if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);
@@ -802,7 +817,7 @@ static int select_edges(disco_ctx *c)
     ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "edge selection: big-row list overflow (%u rows)", n_big);
     if (n_big) {
-        int g2 = (int)std::min<u64>(n_big, 64);
+        int g2 = (int)std::min<u64>(n_big, (u64)c->n_cu * 8); /* work queue, one big row per grab */
         u64 cap = c->h_ctr[CTR_MAX_ROW] + 64;
         u64 *scratch = nullptr;
         CHK(dev_alloc(c, &scratch, (u64)g2 * 2 * cap));
@@ -1171,11 +1186,7 @@ int disco_transitive_mark(disco_ctx *c)
     const u64 nq = c->q_hi - c->q_lo;
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    if (c->big_cap == 0) {
-        CHK(dev_alloc(c, &c->d_big_list, 1024));
-        CHK(dev_alloc(c, &c->d_big_cnt, 1024));
-        c->big_cap = 1024;
-    }
+    CHK(ensure_big_cap(c, nullptr, c->d_adj_ref, TR_CAP));
     TrArgs a;
     a.v = view(c);
     a.ref = c->d_adj_ref;
@@ -1231,7 +1242,7 @@ int disco_transitive_mark(disco_ctx *c)
         }
         u64 hcap = 64;
         while (hcap < 2 * maxd) hcap <<= 1;
-        int g2 = (int)std::min<u64>(n_big, 128);
+        int g2 = (int)std::min<u64>(n_big, (u64)c->n_cu * 8);
         u64 per = hcap * 8 + hcap * 4 + hcap;
         u8 *scratch = nullptr;
         CHK(dev_alloc(c, &scratch, (u64)g2 * per));

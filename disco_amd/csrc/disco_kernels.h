@@ -62,13 +62,14 @@ enum {
  * not depend on how many workgroups happen to be resident (a static blockIdx-strided loop ran 30-40 % slower whenever
  * the grid was not a multiple of the resident workgroups) */
 #define WQ_CHUNK 64
+template <u32 CHUNK = WQ_CHUNK>
 __device__ __forceinline__ bool wq_grab(u64 *counter, u64 n, u64 &beg, u64 &end)
 {
     u64 b = 0;
-    if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, (u64)WQ_CHUNK);
+    if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, (u64)CHUNK);
     b = __shfl(b, 0);
     beg = b;
-    end = (b + WQ_CHUNK < n) ? b + WQ_CHUNK : n;
+    end = (b + CHUNK < n) ? b + CHUNK : n;
     return b < n;
 }
 
@@ -1142,7 +1143,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
     auto fin_row = [&](u32 c, u64 h) -> u64 { return (c <= 64 && lane < c) ? h : ~0ull; };
     auto ld_gather = [&](u64 h, u64 it) -> u32 { return ((const u32 *)a.contained)[(h != ~0ull ? HIT_ID(h) : read_of(it)) >> 5]; };
     auto fin_gather = [&](u64 h, u32 w) -> u64 { return (h != ~0ull && !((w >> (HIT_ID(h) & 31)) & 1u)) ? h : ~0ull; };
-    while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
+    while (BIG ? wq_grab<1>(a.v.wq, n_items, cbeg, cend) : wq_grab(a.v.wq, n_items, cbeg, cend)) { /* big rows: one per grab */
         if (BIG) {
             for (u64 it = cbeg; it < cend; it++) {
                 const u64 A = a.big_list[it];
@@ -1692,7 +1693,7 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
             r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
         }
     };
-    while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
+    while (BIG ? wq_grab<1>(a.v.wq, n_items, cbeg, cend) : wq_grab(a.v.wq, n_items, cbeg, cend)) { /* big nodes: one per grab */
     if (BIG) {
         for (u64 it = cbeg; it < cend; it++) {
             const u64 v = a.big_list[it];
@@ -1931,6 +1932,17 @@ __global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *
             dst_src[pos[i]] = out_src[i];
             dst_ent[pos[i]] = out_ent[i];
         }
+}
+
+/* how many items of [lo,hi) exceed a threshold: rows longer than ES_CAP (cnt = row_cnt) / nodes of degree above TR_CAP
+ * (ref != null: degree field of the reference word) — sizes the big-item lists before the kernels that fill them */
+__global__ void count_above_kernel(const u32 *__restrict__ cnt, const u64 *__restrict__ ref, u64 lo, u64 hi, u32 thr, u64 *out)
+{
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0;
+    for (; i < hi; i += (u64)gridDim.x * blockDim.x) c += (ref ? REF_DEG(ref[i]) : cnt[i]) > thr;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (u64)c);
 }
 
 /* streaming copy, 16 bytes per lane per iteration (bandwidth probe of disco_measure_hbm) */
