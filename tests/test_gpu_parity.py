@@ -118,3 +118,19 @@ def test_bandwidth_probes_report_sane_numbers():
         gather = g.measure_gather(256 << 20, 2)
     assert 500.0 < copy < 8000.0, copy      # GB/s, read + write bytes of a streaming copy
     assert 200.0 < gather < 8000.0, gather  # GB/s of random 64-byte rows
+
+
+@pytest.mark.parametrize("rate,lmin,lmax", [(0.01, 150, 150), (0.004, 100, 250)])
+def test_reads_with_substitution_errors(rate, lmin, lmax):
+    """sequencing errors: many candidates whose end k-mer matches exactly but whose overlap region does not (the k-mer-only
+    branch of verify_kernel; `kmer_hits` must still equal the oracle's count) and k-mers broken by an error"""
+    reads = _gen(23, 6000, lmin, 40.0, lmax)
+    rng = np.random.default_rng(99)
+    out = []
+    for s in reads:
+        b = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+        hit = rng.random(len(b)) < rate
+        b[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        out.append(b.tobytes().decode())
+    c = assert_parity(out, 40, f"errors{rate}")
+    assert c["kmer_hits"] > 2 * c["e_pre"] > 0
