@@ -107,8 +107,24 @@ def cpu_baseline(args, spec_full):
             t += float(m.group(1)) if m else 0.0
         if t <= 0:
             t = r["wall"]
-        return dict(value=e_pre / t, unit="overlaps/s", cores=cores, kind="reference",
-                    sample=sample + f"; reference buildG -t {cores}: graph {t:.2f} s, whole process {r['wall']:.2f} s")
+        out = dict(value=e_pre / t, unit="overlaps/s", cores=cores, kind="reference",
+                   sample=sample + f"; reference buildG -t {cores}: graph {t:.2f} s, whole process {r['wall']:.2f} s")
+        # the same FASTA through the drop-in executable: the *stage* wall of SURVEY.md 8(d) (argv to files closed: parse + filter +
+        # pack on the host cores, upload, graph on the GPU, fetch, text output), next to the reference's whole-process time
+        mine = os.path.join(ROOT, "disco_amd", "bin", "buildG")
+        if os.path.exists(mine):
+            try:
+                os.makedirs(os.path.join(d, "mine"), exist_ok=True)
+                t0 = time.perf_counter()
+                p = subprocess.run([mine, "-se", fa, "-f", os.path.join(d, "mine", "g"), "-p", os.path.join(d, "disco.cfg"), "-t", str(cores)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                wall = time.perf_counter() - t0
+                if p.returncode == 0:
+                    out["stage_drop_in"] = {"wall_s": wall, "overlaps_per_s": e_pre / wall, "reference_wall_s": r["wall"],
+                                            "what": "disco_amd/bin/buildG on the same FASTA, process start to files closed"}
+            except Exception:
+                pass
+        return out
     codes, off = readgen.generate_codes(spec)
     t0 = time.perf_counter()
     pyoracle.build_graph(codes, off, args.min_overlap)
