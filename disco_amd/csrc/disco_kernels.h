@@ -131,7 +131,7 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * index build — replaces HashTable::insertDataset (BG/HashTable.cpp:46-114): count per bucket (populateReadLengths),
  * exclusive prefix sum (:58-67), fill (populateReadData / insertIntoTable :423-514).
  * The reference keys a record by a hash of the whole end k-mer and probes once per k-mer of every read (111 random
- * probes per 150 bp read). Here a record is keyed by the k-mer's MINIMIZER (smallest strand-symmetric m-mer hash, m = 21)
+ * probes per 150 bp read). Here a record is keyed by the k-mer's MINIMIZER (smallest strand-symmetric m-mer hash, m = min(k, 23), odd)
  * and carries the minimizer's offset t inside the canonical k-mer: consecutive k-mer windows of a query read share their
  * minimizer, so the probe needs one bucket lookup per minimizer occurrence (about 13 per read) and recovers the window
  * from t by arithmetic. Which records a k-mer window matches is unchanged (exact k-mer equality, re-checked by the

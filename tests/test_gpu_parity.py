@@ -86,7 +86,7 @@ def test_twin_check_shortcut_is_sound(monkeypatch):
 
 def test_long_reads_generic_stride_paths():
     """reads of 1.2-3 kbp: rows wider than the LDS staging limits (probe_kernel<.,false>, verify_kernel<false>) and more than one
-    256-window probe segment per read"""
+    probe segment of PROBE_SEGW windows per read"""
     reads = _gen(31, 400, 1200, 12.0, 3000)
     c = assert_parity(reads, 40, "long")
     assert c["e_pre"] > 0
