@@ -1454,33 +1454,44 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         sent[s] = idx;
     }
     __syncthreads();
-    for (u32 i = 0; i < d; i++) {                 /* :693 list order */
-        if (hstate[sent[i]]) continue;            /* :696 only INPLAY neighbours */
-        const u64 e1 = row[i];
-        const u64 u = ADJ_DST(e1);
-        const u32 type1 = ADJ_ORI(e1);
-        const u64 ru = tr_nref<N32>(a, u);
-        const u64 us = REF_POS(ru);
-        const u32 du = REF_DEG(ru);
-        const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
-        for (u32 t = lane; t < du; t += 64) {        /* :698 */
-            const u64 e2 = tr_nent<N32>(a, us + t);
-            const u32 type2 = ADJ_ORI(e2);
-            const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
-            if (!ok) continue;
-            const u64 w = ADJ_DST(e2);
-            u32 idx = (u32)disco_hash64(w) & hmask;
-            for (;;) {
-                u64 kk = hkey[idx];
-                if (kk == TR_EMPTY) break;
-                if (kk == w) {
-                    hstate[idx] = 1; /* ELIMINATED */
-                    break;
+    /* :693 list order, :696 only neighbours that are still INPLAY when their turn comes. States only go INPLAY ->
+     * ELIMINATED, so the next slot to sweep is the first INPLAY slot after the current one judged with the states as they are
+     * now: found with one ballot per 64 slots instead of polling every slot */
+    for (u32 g0 = 0; g0 < d; g0 += 64) {
+        int cur = -1;
+        for (;;) {
+            const u32 s = g0 + lane;
+            u64 mk = __ballot(s < d && !hstate[sent[s]]);
+            if (cur >= 0) mk &= ~((2ull << cur) - 1ull);
+            if (!mk) break;
+            cur = (int)__ffsll((long long)mk) - 1;
+            const u32 i = g0 + (u32)cur;
+            const u64 e1 = row[i];
+            const u64 u = ADJ_DST(e1);
+            const u32 type1 = ADJ_ORI(e1);
+            const u64 ru = tr_nref<N32>(a, u);
+            const u64 us = REF_POS(ru);
+            const u32 du = REF_DEG(ru);
+            const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
+            for (u32 t = lane; t < du; t += 64) {        /* :698 */
+                const u64 e2 = tr_nent<N32>(a, us + t);
+                const u32 type2 = ADJ_ORI(e2);
+                const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
+                if (!ok) continue;
+                const u64 w = ADJ_DST(e2);
+                u32 idx = (u32)disco_hash64(w) & hmask;
+                for (;;) {
+                    u64 kk = hkey[idx];
+                    if (kk == TR_EMPTY) break;
+                    if (kk == w) {
+                        hstate[idx] = 1; /* ELIMINATED */
+                        break;
+                    }
+                    idx = (idx + 1) & hmask;
                 }
-                idx = (idx + 1) & hmask;
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     u32 nfree = 0;
     for (u32 s0 = 0; s0 < d; s0 += 64) {
