@@ -816,7 +816,13 @@ static int select_edges(disco_ctx *c)
     CHK(read_counters(c));
     ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "edge selection: big-row list overflow (%u rows)", n_big);
-    if (n_big) {
+    if (n_big) { /* rows of up to ES_MID hits: LDS arrays of their own */
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(edge_select_mid_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 8)), dim3(64), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        CHK(read_counters(c));
+    }
+    if (n_big && c->h_ctr[CTR_MAX_ROW] > ES_MID) {
         int g2 = (int)std::min<u64>(n_big, (u64)c->n_cu * 8); /* work queue, one big row per grab */
         u64 cap = c->h_ctr[CTR_MAX_ROW] + 64;
         u64 *scratch = nullptr;

@@ -20,6 +20,7 @@
 #define PROBE_SEGP (PROBE_SEGW + 64) /* m-mer positions a segment covers: windows + (k - m) <= 63              */
 #define PROBE_ACAP 32     /* words of the query read's own row staged in LDS (reads up to 1024 bp)              */
 #define PROBE_CHUNK 4096  /* hit slots a wave reserves from the global bump pointer at a time                   */
+#define ES_MID 1024       /* edge_select: rows of ES_CAP+1..ES_MID hits get LDS arrays of their own (edge_select_mid_kernel) */
 #define ES_DUPBITS 11     /* edge_select: byte table of the duplicate-destination pre-check                         */
 #define ES_DUPTAB (1 << ES_DUPBITS)
 #define ES_CAP 256        /* edge_select: hits of one read sorted in LDS (longer rows: global-scratch variant)  */
@@ -893,8 +894,9 @@ __device__ __forceinline__ void lds_bitonic_sort(u64 *h, u32 P, u32 lane)
         }
 }
 
-/* LDS_WIDE: h / t are LDS arrays of ES_CAP entries and s_jcnt a 128-slot LDS histogram (ordinary variant) */
-template <bool LDS_WIDE>
+/* WCAP > 0: h / t are LDS arrays of WCAP entries (a power of two) and s_jcnt a 128-slot LDS histogram: rows of up to WCAP hits
+ * may take the accept-all shortcut */
+template <int WCAP>
 __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 *s_jcnt, u32 &cap_sites,
                                                 u32 &dropped, u64 &n_edges)
 {
@@ -915,13 +917,14 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         m += __popcll(mk);
     }
     __syncthreads();
-    if (LDS_WIDE && m <= ES_CAP) {
-        /* 1b. rows of 65..ES_CAP hits (45x-170x coverage): the same shortcut as edge_select_row_all. No destination twice —
-         * decided exactly by an LDS hash set (linear probing, 512 slots in the space of t) — and no window over the cap
+    if (WCAP > 0 && m <= (u32)WCAP) {
+        /* 1b. rows of 65..WCAP hits (coverage above 45x): the same shortcut as edge_select_row_all. No destination twice —
+         * decided exactly by an LDS hash set (linear probing, 2 WCAP slots in the space of t) — and no window over the cap
          * (LDS histogram; slots shared by windows 128 apart only make the test conservative): every hit becomes an edge and
          * only the sort by offset remains (bitonic in LDS). Otherwise the sequential scan below decides. */
         u32 *hs = (u32 *)t;
-        for (u32 i = lane; i < 512; i += 64) hs[i] = 0xFFFFFFFFu;
+        constexpr u32 HS = 2u * (u32)(WCAP > 0 ? WCAP : 1);
+        for (u32 i = lane; i < HS; i += 64) hs[i] = 0xFFFFFFFFu;
         s_jcnt[lane] = 0;
         s_jcnt[lane + 64] = 0;
         __syncthreads();
@@ -929,7 +932,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         for (u32 i = lane; i < m; i += 64) {
             const u64 hit = h[i];
             const u32 id = (u32)HIT_ID(hit);
-            u32 idx = (id * 0x9E3779B1u) >> 23;
+            u32 idx = ((id * 0x9E3779B1u) >> 8) & (HS - 1u);
             for (;;) {
                 const u32 old = atomicCAS(&hs[idx], 0xFFFFFFFFu, id);
                 if (old == 0xFFFFFFFFu) break;
@@ -937,7 +940,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
                     bad = true;
                     break;
                 }
-                idx = (idx + 1) & 511u;
+                idx = (idx + 1) & (HS - 1u);
             }
             atomicAdd(&s_jcnt[HIT_J(hit) & 127u], 1u);
         }
@@ -1148,7 +1151,8 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             for (u64 it = cbeg; it < cend; it++) {
                 const u64 A = a.big_list[it];
                 n_slow++;
-                edge_select_row<false>(a, A, h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges);
+                if (a.row_cnt[A] <= ES_MID) continue; /* done by edge_select_mid_kernel */
+                edge_select_row<0>(a, A, h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges);
             }
             continue;
         }
@@ -1181,12 +1185,37 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
             } else {
                 n_slow++;
-                edge_select_row<true>(a, A, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges);
+                edge_select_row<ES_CAP>(a, A, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges);
             }
             c0 = c1; s0 = s1; L0 = L1; h0 = h1; w0 = w1;
             c1 = c2; s1 = m2.rs; L1 = m2.LA; r1 = r2;
             m2 = m3;
         }
+    }
+    if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
+    if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
+    if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+    if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
+}
+
+/* rows of ES_CAP+1 .. ES_MID hits (coverage of a few hundred): the big-row list again, with LDS arrays large enough for the
+ * accept-all shortcut; longer rows are left to the global-scratch variant */
+__global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a)
+{
+    __shared__ u64 s_h[ES_MID];
+    __shared__ u64 s_t[ES_MID];
+    __shared__ u32 s_jcnt[128];
+    const u32 lane = threadIdx.x;
+    u32 cap_sites = 0, dropped = 0, n_slow = 0;
+    u64 n_edges = 0;
+    const u64 n_items = (u64)min(*a.n_big, a.big_cap);
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab<1>(a.v.wq, n_items, cbeg, cend)) {
+        const u64 A = a.big_list[cbeg];
+        const u32 c = a.row_cnt[A];
+        if (c > ES_MID) continue;
+        n_slow++;
+        edge_select_row<ES_MID>(a, A, s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges);
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);

@@ -25,6 +25,8 @@ def _gen(seed, n, lmin, cov, lmax=None, contigs=1):
     (5, 2000, 300, 600, 20.0, 40),      # long reads, many words per row
     (17, 6000, 150, 150, 100.0, 40),    # 100x coverage: rows of 65..256 hits (wide-row paths of edge selection / marking)
     (19, 5000, 100, 250, 120.0, 40),    # the same with mixed lengths (containment inside wide rows)
+    (29, 4000, 150, 150, 300.0, 40),    # 300x: rows of 257..1024 hits (edge_select_mid_kernel), big-node marking
+    (31, 6000, 150, 150, 900.0, 40),    # 900x: rows beyond every LDS capacity (global-scratch passes), cap / duplicates bind
 ])
 def test_generated(seed, n, lmin, lmax, cov, minovl):
     if minovl == 66:
