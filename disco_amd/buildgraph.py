@@ -26,7 +26,7 @@ class Params(C.Structure):
 
 class GenSpecABI(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_uint64), ("contig_len", C.c_uint64), ("n_contigs", C.c_uint32),
-                ("len_min", C.c_uint32), ("len_max", C.c_uint32), ("reserved", C.c_uint32)]
+                ("len_min", C.c_uint32), ("len_max", C.c_uint32), ("skew", C.c_uint32)]
 
 
 CONTAINED_DTYPE = np.dtype([("contained", "<u8"), ("super", "<u8"), ("orient", "<u4"), ("len2", "<u4"), ("len1", "<u4"),
@@ -179,7 +179,7 @@ class BuildGraph:
         self._chk(self.L.disco_adopt_reads(self._h, _P(d_packed_ptr), stride_words, _P(d_len_ptr), n))
 
     def generate_reads(self, spec):
-        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, 0)
+        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
         self._chk(self.L.disco_generate_reads(self._h, C.byref(s)))
 
     def download_reads(self):

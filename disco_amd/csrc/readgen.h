@@ -13,6 +13,10 @@
  *             contig = h0 % n_contigs            (reads never span contigs)
  *             pos    = h1 % (contig_len - len + 1)
  *             strand = h0 >> 63                  (1 = reverse complement of the genome window)
+ *   skew = 1 : contig = ((h0 % n_contigs) * (h3 % n_contigs)) / n_contigs with h3 = mix(seed_r + 4r + 3): the product of two
+ *             uniform draws, i.e. P(contig <= x n) ~ x (1 - ln x): the first contigs are covered tens of times deeper than the
+ *             average, the last ones a fraction of it (abundance spread of a metagenome), integer
+ *             arithmetic only so that all twins agree bit for bit.
  * Bases are coded A0 C1 G2 T3 (reference packing, BG/HashTable.h:16-24).
  */
 #ifndef DISCO_READGEN_H_
@@ -33,7 +37,7 @@ typedef struct disco_genspec {
     uint32_t n_contigs;   /* number of contigs                                   */
     uint32_t len_min;     /* shortest read                                       */
     uint32_t len_max;     /* longest read (== len_min for fixed length)          */
-    uint32_t reserved;
+    uint32_t skew;        /* 0: contigs equally abundant; 1: "metagenome-like" abundances (see disco_read_location)  */
 } disco_genspec;
 
 DISCO_HD uint64_t disco_mix64(uint64_t x)
@@ -70,6 +74,7 @@ DISCO_HD disco_readloc disco_read_location(const disco_genspec *s, uint64_t r)
     disco_readloc loc;
     loc.len = s->len_min + (uint32_t)(h2 % (uint64_t)(s->len_max - s->len_min + 1));
     uint64_t contig = (h0 & 0x7FFFFFFFFFFFFFFFull) % s->n_contigs;
+    if (s->skew) contig = (contig * (disco_mix64(sr + 4 * r + 3) % s->n_contigs)) / s->n_contigs;
     uint64_t pos = h1 % (s->contig_len - loc.len + 1);
     loc.gpos = contig * s->contig_len + pos;
     loc.strand = (uint32_t)(h0 >> 63);

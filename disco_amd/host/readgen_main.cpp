@@ -11,7 +11,7 @@
 int main(int argc, char **argv)
 {
     if (argc < 3) {
-        fprintf(stderr, "usage: readgen <out.fasta> <n_reads> [read_len=150] [coverage=30] [seed=42] [len_max=read_len] [contig_len=5000000]\n");
+        fprintf(stderr, "usage: readgen <out.fasta> <n_reads> [read_len=150] [coverage=30] [seed=42] [len_max=read_len] [contig_len=5000000] [skew=0]\n");
         return 1;
     }
     disco_genspec s;
@@ -21,7 +21,7 @@ int main(int argc, char **argv)
     s.seed = argc > 5 ? strtoull(argv[5], nullptr, 10) : 42;
     s.len_max = argc > 6 ? (uint32_t)atoi(argv[6]) : s.len_min;
     const uint64_t want_contig = argc > 7 ? strtoull(argv[7], nullptr, 10) : 5000000ull;
-    s.reserved = 0;
+    s.skew = argc > 8 ? (uint32_t)atoi(argv[8]) : 0;
     /* same sizing rule as disco_amd.readgen.GenSpec.coverage / bench.py */
     const double mean = (s.len_min + s.len_max) / 2.0;
     uint64_t genome = (uint64_t)(s.n_reads * mean / cov);

@@ -47,15 +47,16 @@ class GenSpec:
     n_contigs: int = 1
     len_min: int = 150
     len_max: int = 150
+    skew: int = 0  # 1: metagenome-like contig abundances (product of two uniform draws, see csrc/readgen.h)
 
     @staticmethod
     def coverage(seed: int, n_reads: int, read_len: int = 150, cov: float = 30.0, n_contigs: int = 1,
-                 len_max: int | None = None) -> "GenSpec":
-        """uniform-random genome sized for the given coverage."""
+                 len_max: int | None = None, skew: int = 0) -> "GenSpec":
+        """uniform-random genome sized for the given (mean) coverage (skew=1: config 5)."""
         len_max = read_len if len_max is None else len_max
         mean = (read_len + len_max) / 2.0
         total = max(int(n_reads * mean / cov), n_contigs * (len_max + 1))
-        return GenSpec(seed, n_reads, max(total // n_contigs, len_max + 1), n_contigs, read_len, len_max)
+        return GenSpec(seed, n_reads, max(total // n_contigs, len_max + 1), n_contigs, read_len, len_max, skew)
 
 
 def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None):
@@ -68,6 +69,9 @@ def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None):
         h2 = mix64(sr + np.uint64(4) * r + np.uint64(2))
         length = (np.uint64(spec.len_min) + h2 % np.uint64(spec.len_max - spec.len_min + 1)).astype(np.uint64)
         contig = (h0 & np.uint64(0x7FFFFFFFFFFFFFFF)) % np.uint64(spec.n_contigs)
+        if spec.skew:
+            h3 = mix64(sr + np.uint64(4) * r + np.uint64(3))
+            contig = (contig * (h3 % np.uint64(spec.n_contigs))) // np.uint64(spec.n_contigs)
         pos = h1 % (np.uint64(spec.contig_len) - length + np.uint64(1))
         gpos = contig * np.uint64(spec.contig_len) + pos
         strand = (h0 >> np.uint64(63)).astype(np.uint8)

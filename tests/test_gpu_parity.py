@@ -136,3 +136,10 @@ def test_reads_with_substitution_errors(rate, lmin, lmax):
         out.append(b.tobytes().decode())
     c = assert_parity(out, 40, f"errors{rate}")
     assert c["kmer_hits"] > 2 * c["e_pre"] > 0
+
+
+def test_metagenome_like_abundances():
+    """contig abundances spread over two orders of magnitude (generator skew = 1): narrow, wide and big rows in one data set"""
+    spec = readgen.GenSpec.coverage(37, 12000, 100, 30.0, n_contigs=40, len_max=250, skew=1)
+    c = assert_parity(readgen.generate_reads(spec), 40, "skew")
+    assert c["e_out"] > 0 and c["n_contained"] > 0

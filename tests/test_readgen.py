@@ -27,11 +27,12 @@ void gen_codes(const disco_genspec *s, unsigned long long r0, unsigned long long
 
 class Spec(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("n_reads", ctypes.c_uint64), ("contig_len", ctypes.c_uint64), ("n_contigs", ctypes.c_uint32),
-                ("len_min", ctypes.c_uint32), ("len_max", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("len_min", ctypes.c_uint32), ("len_max", ctypes.c_uint32), ("skew", ctypes.c_uint32)]
 
 
 @pytest.mark.parametrize("kw", [dict(seed=42, n_reads=700, read_len=150, cov=30.0),
-                                dict(seed=3, n_reads=500, read_len=100, cov=10.0, len_max=250, n_contigs=3)])
+                                dict(seed=3, n_reads=500, read_len=100, cov=10.0, len_max=250, n_contigs=3),
+                                dict(seed=9, n_reads=900, read_len=100, cov=10.0, len_max=250, n_contigs=7, skew=1)])
 def test_numpy_twin_equals_c_twin(tmp_path, kw):
     src = tmp_path / "g.c"
     src.write_text(C_SRC)
@@ -40,7 +41,7 @@ def test_numpy_twin_equals_c_twin(tmp_path, kw):
     L = ctypes.CDLL(so)
     spec = readgen.GenSpec.coverage(**kw)
     codes, off = readgen.generate_codes(spec)
-    s = Spec(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, 0)
+    s = Spec(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, spec.skew)
     c2 = np.zeros(len(codes), dtype=np.uint8)
     o2 = np.zeros(len(off), dtype=np.uint64)
     L.gen_codes(ctypes.byref(s), ctypes.c_ulonglong(0), ctypes.c_ulonglong(spec.n_reads), c2.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p))
@@ -49,10 +50,11 @@ def test_numpy_twin_equals_c_twin(tmp_path, kw):
 
 
 @pytest.mark.gpu
-def test_hip_generator_equals_numpy_twin():
+@pytest.mark.parametrize("skew", [0, 1])
+def test_hip_generator_equals_numpy_twin(skew):
     from disco_amd import buildgraph
 
-    spec = readgen.GenSpec.coverage(seed=5, n_reads=4000, read_len=100, cov=20.0, len_max=250, n_contigs=2)
+    spec = readgen.GenSpec.coverage(seed=5, n_reads=4000, read_len=100, cov=20.0, len_max=250, n_contigs=5, skew=skew)
     codes, off = readgen.generate_codes(spec)
     with buildgraph.BuildGraph(min_overlap=40) as g:
         g.generate_reads(spec)

@@ -1,12 +1,14 @@
 """one BuildGraph pass at an arbitrary size / length range on one GPU (robustness probe for BASELINE config-5-like shapes):
-   python tools/scale_probe.py READS LEN_MIN LEN_MAX [COVERAGE=30]"""
+   python tools/scale_probe.py READS LEN_MIN LEN_MAX [COVERAGE=30] [SKEW=0] [N_CONTIGS]"""
 import sys, time
 sys.path.insert(0, '.')
 from disco_amd import buildgraph, readgen
 n, lmin, lmax = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 cov = float(sys.argv[4]) if len(sys.argv) > 4 else 30.0
 genome = int(n * (lmin + lmax) / 2 / cov)
-spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=max(1, genome // 5_000_000), len_max=lmax)
+skew = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+nc = int(sys.argv[6]) if len(sys.argv) > 6 else max(1, genome // 5_000_000)
+spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
 g = buildgraph.BuildGraph(min_overlap=40, device=0)
 g.generate_reads(spec)
 for r in range(2):
