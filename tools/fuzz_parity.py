@@ -1,0 +1,64 @@
+"""differential fuzzing: HIP path (C-ABI) vs the CPU oracle on random generator settings.
+   python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1]"""
+import sys, time, traceback
+sys.path.insert(0, '.')
+import numpy as np
+from disco_amd import readgen
+from tests.util import assert_parity
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fails = 0
+t0 = time.time()
+for it in range(iters):
+    lmin = int(rng.choice([45, 60, 80, 100, 150, 151, 168, 200, 256, 257, 300, 500, 1000]))
+    lmax = lmin if rng.random() < 0.4 else int(lmin + rng.integers(1, 2 * lmin))
+    mo = int(rng.choice([31, 32, 33, 40, 41, 50, 64, 65]))
+    if mo >= lmin:
+        mo = max(31, lmin - 8)
+    cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700]))
+    n = int(rng.integers(300, 5000))
+    if cov >= 300:
+        n = min(n, 2500)
+    nc = int(rng.integers(1, 6))
+    skew = int(rng.random() < 0.3)
+    err = float(rng.choice([0, 0, 0, 0.002, 0.01]))
+    seed = int(rng.integers(1, 1 << 30))
+    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} err={err}"
+    try:
+        spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
+        reads = list(readgen.generate_reads(spec))
+        if err:
+            r2 = np.random.default_rng(seed)
+            out = []
+            for s in reads:
+                b = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+                hit = r2.random(len(b)) < err
+                b[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[r2.integers(0, 4, int(hit.sum()))]
+                out.append(b.tobytes().decode())
+            reads = out
+        if rng.random() < 0.2:  # a genome with repeat copies: duplicate destinations, the per-k-mer cap, one-sided pairs
+            r3 = np.random.default_rng(seed + 1)
+            rep = "".join(r3.choice(list("ACGT"), int(r3.integers(60, 400))))
+            genome = "".join("".join(r3.choice(list("ACGT"), int(r3.integers(30, 300)))) + rep for _ in range(int(r3.integers(3, 40))))
+            comp0 = str.maketrans("ACGT", "TGCA")
+            reads = []
+            for _ in range(n):
+                L = int(r3.integers(lmin, lmax + 1))
+                if L >= len(genome):
+                    continue
+                p0 = int(r3.integers(0, len(genome) - L))
+                s0 = genome[p0:p0 + L]
+                reads.append(s0.translate(comp0)[::-1] if r3.random() < 0.5 else s0)
+            label += " repeats"
+        if rng.random() < 0.2:  # exact and reverse-complement duplicates
+            comp = str.maketrans("ACGT", "TGCA")
+            reads += [reads[i] if rng.random() < 0.5 else reads[i].translate(comp)[::-1] for i in rng.integers(0, len(reads), len(reads) // 10)]
+        c = assert_parity(reads, mo, label)
+        print("ok  ", label, "e_pre", c["e_pre"], "e_out", c["e_out"], "contained", c["n_contained"], "cap", c["cap_bind_sites"], "asym", c["asymmetric_pairs"], flush=True)
+    except Exception as e:
+        fails += 1
+        print("FAIL", label, repr(e)[:300], flush=True)
+        traceback.print_exc()
+print(f"{iters - fails}/{iters} ok in {time.time() - t0:.0f} s")
+sys.exit(1 if fails else 0)
