@@ -172,9 +172,12 @@ def distributed_step(engine, group=None, timing=None, comm=None):
     lap("adopt")
     asym = torch.tensor([engine.symmetrize(False)], dtype=torch.int64, device=keys.device)
     comm.all_reduce(asym, "sum")
+    n_asym = 0
     if int(asym.item()):
-        # pairs found from one side only (order-dependent regime of the reference): every rank completes all lists
-        engine.symmetrize(True)
+        # pairs found from one side only (order-dependent regime of the reference): every rank completes all lists. The
+        # per-range counts above only say WHETHER something is missing (a rank whose one-sided pass balances reports 0 even
+        # if lists of its range lack twins that the owner of the larger id notices); the full pass returns the count.
+        n_asym = engine.symmetrize(True)
         engine.merge_extras()
     lap("symmetrize")
     engine.transitive_mark()
@@ -202,7 +205,7 @@ def distributed_step(engine, group=None, timing=None, comm=None):
     tot = torch.tensor([e_out_local], dtype=torch.int64, device=keys.device)
     comm.all_reduce(tot, "sum")
     return dict(e_pre=engine.total_edges() // 2, e_out_local=e_out_local, e_out=int(tot[0].item()), n_contained=n_contained,
-                asymmetric_pairs=int(asym.item()), range=(lo, hi), exchange="rows64")
+                asymmetric_pairs=n_asym, range=(lo, hi), exchange="rows64")
 
 
 def _exchange_half(engine, comm, world, rank, per, nloc, n):

@@ -103,7 +103,9 @@ class MockEngine:
 
     def symmetrize(self, full):
         self.log.append("sym_full" if full else "sym")
-        return 3 if (self.asym_on_rank == self.rank and not full) else 0
+        if full:  # the full pass returns the count of all ranks' lists
+            return 3 if self.asym_on_rank is not None else 0
+        return 3 if self.asym_on_rank == self.rank else 0
 
     def merge_extras(self):
         self.log.append("merge")

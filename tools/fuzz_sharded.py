@@ -15,6 +15,8 @@ for it in range(iters):
     lmin = int(rng.choice([60, 100, 150, 200, 300]))
     lmax = lmin if rng.random() < 0.4 else int(lmin + rng.integers(1, lmin))
     mo = int(rng.choice([31, 40, 50, 65]))
+    if mo >= lmin:
+        mo = 40
     cov = float(rng.choice([8, 30, 60, 150, 400]))
     n = int(rng.integers(300, 4000))
     G = int(rng.integers(2, 5))
