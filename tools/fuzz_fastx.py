@@ -1,0 +1,106 @@
+"""differential fuzzing of the input stage (disco_amd/bin/fastx_dump = the parser / filter / id assignment of the drop-in buildG)
+against the oracle's restatement of Dataset::readDataset + testRead, on randomly malformed FASTA / FASTQ text.
+   python tools/fuzz_fastx.py [ITERATIONS=200] [SEED=1]      (CPU only)"""
+import gzip, os, subprocess, sys, tempfile
+sys.path.insert(0, '.')
+import numpy as np
+from oracle import pyoracle
+from disco_amd import build
+
+build.build_host()
+BIN = os.path.join("disco_amd", "bin", "fastx_dump")
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def dump(mo, paths):
+    p = subprocess.run([BIN, str(mo), "-se", ",".join(paths)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if p.returncode != 0:
+        return None
+    out = p.stdout.strip().split("\n")
+    tail = out[-1].split()
+    reads = [l.split("\t") for l in out[:-1] if l]
+    return [r[1] for r in reads], [int(r[0]) for r in reads], int(tail[1])
+
+
+def rand_seq(L):
+    kind = rng.integers(0, 10)
+    s = "".join(rng.choice(list("ACGT"), L))
+    if kind == 0:
+        s = s.lower()
+    elif kind == 1 and L > 3:
+        i = int(rng.integers(0, L))
+        s = s[:i] + rng.choice(list("NnRY-*")) + s[i + 1:]
+    elif kind == 2:
+        s = (rng.choice(["AC", "AAT", "GGGGCC", "A", "TAA"]) * L)[:L]
+    return s
+
+
+def fasta(nrec):
+    eol = "\r\n" if rng.random() < 0.15 else "\n"
+    t = ""
+    for i in range(nrec):
+        L = int(rng.integers(0, 260))
+        s = rand_seq(L)
+        hdr = ">r%d" % i + (" x>y" if rng.random() < 0.05 else "")
+        w = int(rng.choice([0, 0, 60, 70, 7]))
+        body = s if not w or not s else eol.join(s[j:j + w] for j in range(0, L, w))
+        if rng.random() < 0.03 and L > 10:
+            body = body[:5] + ">" + body[5:]
+        t += hdr + eol + body + eol
+        if rng.random() < 0.05:
+            t += eol
+    if rng.random() < 0.3:
+        t = t.rstrip("\r\n")
+    if rng.random() < 0.05:
+        t += ">"
+    return t
+
+
+def fastq(nrec):
+    t = ""
+    for i in range(nrec):
+        L = int(rng.integers(0, 260))
+        s = rand_seq(L)
+        q = "".join(rng.choice(list("IIII@>+#!5"), L))
+        t += "@q%d\n%s\n+%s\n%s\n" % (i, s, "" if rng.random() < 0.7 else "q%d" % i, q)
+    if rng.random() < 0.3:
+        t = t.rstrip("\n")
+    return t
+
+
+fails = 0
+with tempfile.TemporaryDirectory() as d:
+    for it in range(iters):
+        mo = int(rng.choice([31, 40, 65]))
+        paths, plain = [], []
+        for f in range(int(rng.integers(1, 4))):
+            text = fasta(int(rng.integers(0, 60))) if rng.random() < 0.6 else fastq(int(rng.integers(0, 60)))
+            p = os.path.join(d, "f%d_%d.%s" % (it, f, "fa"))
+            open(p, "w", newline="").write(text)
+            plain.append(p)
+            if rng.random() < 0.2:  # the drop-in reads the gzip, the oracle the same bytes uncompressed
+                with gzip.open(p + ".gz", "wb") as fh:
+                    fh.write(text.encode())
+                p += ".gz"
+            paths.append(p)
+        # the reference exits when a file contributes no record (BG/Dataset.cpp:113-114,124-125)
+        if any(len(pyoracle.parse_records(open(p, "rb").read())) == 0 for p in plain):
+            oreads = None
+        else:
+            want = pyoracle.load_good_reads(plain, mo)
+            oreads, ofidx, ototal = want[0], [int(x) for x in want[1]], want[2]
+        got = dump(mo, paths)
+        ok = (got is None and oreads is None) or (got is not None and oreads is not None and got[0] == oreads and got[1] == ofidx and got[2] == ototal)
+        if not ok:
+            fails += 1
+            keep = os.path.join(tempfile.gettempdir(), "fuzz_fastx_fail_%d" % it)
+            os.makedirs(keep, exist_ok=True)
+            for p in paths:
+                subprocess.run(["cp", p, keep])
+            print("FAIL it%d mo=%d files=%s kept in %s : got %s want %s" % (it, mo, [os.path.basename(p) for p in paths], keep,
+                  None if got is None else (len(got[0]), got[2]), None if oreads is None else (len(oreads), ototal)), flush=True)
+        for p in set(paths + plain):
+            os.remove(p)
+print("%d/%d ok" % (iters - fails, iters))
+sys.exit(1 if fails else 0)
