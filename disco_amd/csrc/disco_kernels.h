@@ -317,6 +317,7 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
     __shared__ u32 s_occ_start[64];     /*   running record count, position                                            */
     __shared__ u32 s_occ_excl[64];
     __shared__ u16 s_occ_prel[64];
+    __shared__ u8 s_mark[64];           /* starts of the non-empty buckets in the concatenated record list             */
     __shared__ u64 s_a[PROBE_ACAP + 2]; /* the query read's own packed row + zero padding for the branch-free extracts */
     const u32 lane = threadIdx.x;
     const int S = a.v.S, k = a.v.k;
@@ -480,9 +481,25 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
                     if ((int)lane >= o) incl += y;
                 }
                 const u32 total = __shfl(incl, 63);
-                s_occ_start[lane] = s;
-                s_occ_excl[lane] = incl - cnt;
+                /* only the buckets that hold records keep a slot (compacted): their start offsets in the concatenated record
+                 * list are then strictly increasing, and a byte mark at every start turns "which bucket owns record i" into a
+                 * ballot and a population count for the first 64 records (a binary search for the rest) */
+                const u64 nz = __ballot(cnt > 0);
+                const u32 nne = __popcll(nz);
+                const u32 fp_o = s_occ_fp[lane];
+                const u16 prel_o = s_occ_prel[lane];
+                s_mark[lane] = 0;
                 __syncthreads();
+                if (cnt > 0) {
+                    const u32 r = __popcll(nz & lane_mask_lt());
+                    s_occ_fp[r] = fp_o;
+                    s_occ_prel[r] = prel_o;
+                    s_occ_start[r] = s;
+                    s_occ_excl[r] = incl - cnt;
+                    if (incl - cnt < 64) s_mark[incl - cnt] = 1;
+                }
+                __syncthreads();
+                const u64 startmask = __ballot(s_mark[lane] != 0);
                 /* 4. all records of all led buckets, lane = record: a record names the window(s) it can match through its
                  *    minimizer offset t; the window's own (occurrence, strand) must agree */
                 for (u32 base = 0; base < total; base += 64) {
@@ -491,11 +508,17 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
                     u64 pay = 0;
                     int oprel = 0;
                     if (idx < total) {
-                        u32 lo = 0, hi = nocc; /* largest o with excl[o] <= idx */
-                        while (hi - lo > 1) {
-                            const u32 mid = (lo + hi) >> 1;
-                            if (s_occ_excl[mid] <= idx) lo = mid;
-                            else hi = mid;
+                        u32 lo;
+                        if (base == 0)
+                            lo = __popcll(startmask & (lane_mask_lt() | (1ull << lane))) - 1u;
+                        else {
+                            lo = 0;
+                            u32 hi = nne; /* largest o with excl[o] <= idx */
+                            while (hi - lo > 1) {
+                                const u32 mid = (lo + hi) >> 1;
+                                if (s_occ_excl[mid] <= idx) lo = mid;
+                                else hi = mid;
+                            }
                         }
                         pay = a.v.ent[s_occ_start[lo] + (idx - s_occ_excl[lo])];
                         oprel = (int)s_occ_prel[lo];
@@ -1461,6 +1484,9 @@ __device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
 }
 
 #define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
+/* slot of a node id (< 2^31) in the marking hash: one 32-bit multiply (disco_hash64 costs two 64-bit multiplies — eight
+ * quarter-rate 32-bit ones — and is evaluated for every entry of every swept row) */
+__device__ __forceinline__ u32 tr_hash(u64 id, u32 hmask) { return (((u32)id * 0x9E3779B1u) >> 10) & hmask; }
 
 template <bool N32>
 __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey, u8 *hstate, u32 *sent, u32 hmask, u32 lane)
@@ -1474,7 +1500,7 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
     __syncthreads();
     for (u32 s = lane; s < d; s += 64) { /* markedNodes->insert(dst, INPLAY) */
         u64 id = ADJ_DST(row[s]);
-        u32 idx = (u32)disco_hash64(id) & hmask;
+        u32 idx = tr_hash(id, hmask);
         for (;;) {
             u64 old = atomicCAS(&hkey[idx], TR_EMPTY, id);
             if (old == TR_EMPTY || old == id) break;
@@ -1508,7 +1534,7 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
                 const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
                 if (!ok) continue;
                 const u64 w = ADJ_DST(e2);
-                u32 idx = (u32)disco_hash64(w) & hmask;
+                u32 idx = tr_hash(w, hmask);
                 for (;;) {
                     u64 kk = hkey[idx];
                     if (kk == TR_EMPTY) break;
@@ -1590,7 +1616,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     u32 sent = 0;
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
         const u64 id = ADJ_DST(e);
-        u32 idx = (u32)disco_hash64(id) & hmask;
+        u32 idx = tr_hash(id, hmask);
         for (;;) {
             u64 old = atomicCAS(&hkey[idx], TR_EMPTY, id);
             if (old == TR_EMPTY || old == id) break;
@@ -1618,7 +1644,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
             const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
             if (!ok) return;
             const u64 w = ADJ_DST(e2);
-            u32 idx = (u32)disco_hash64(w) & hmask;
+            u32 idx = tr_hash(w, hmask);
             for (;;) {
                 const u64 kk = hkey[idx];
                 if (kk == TR_EMPTY) break;
