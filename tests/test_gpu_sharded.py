@@ -126,3 +126,35 @@ def test_sharded_many_survivor_nodes_take_the_flag_exchange(monkeypatch):
     ce, cc = canon_hip(edges, rows, fidx)
     gu.check_against_golden("mixed_4k", ce, cc)
     assert run_sharded.last_exchange == "rows64"  # the 4-byte attempt was abandoned after the marking
+
+
+def _repeat_reads(seed, n, lmin, lmax):
+    r3 = np.random.default_rng(seed + 1)
+    rep = "".join(r3.choice(list("ACGT"), int(r3.integers(60, 400))))
+    genome = "".join("".join(r3.choice(list("ACGT"), int(r3.integers(30, 300)))) + rep for _ in range(int(r3.integers(3, 40))))
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = []
+    for _ in range(n):
+        L = int(r3.integers(lmin, lmax + 1))
+        if L >= len(genome):
+            continue
+        p0 = int(r3.integers(0, len(genome) - L))
+        s0 = genome[p0:p0 + L]
+        reads.append(s0.translate(comp)[::-1] if r3.random() < 0.5 else s0)
+    return reads
+
+
+@pytest.mark.parametrize("G", [2, 3, 4])
+def test_sharded_notices_a_twin_missing_from_another_ranks_list(G):
+    """ONE cap-bound site on rank 0: the read that still holds the edge lives on another rank, whose one-sided pass is
+    unbalanced although none of ITS lists lacks a twin — it must report that (tools/fuzz_sharded.py, it1158)"""
+    from tests.util import run_hip_reads
+
+    reads = _repeat_reads(906630212, 1387, 60, 75)
+    e1, r1, c1 = run_hip_reads(reads, 50)
+    assert c1["asymmetric_pairs"] == 1 and c1["cap_bind_sites"] == 1
+    edges, rows, e_pre, asym = run_sharded(reads, 50, G)
+    assert (asym, e_pre) == (1, c1["e_pre"])
+    ce1, cc1 = canon_hip(e1, r1)
+    ce2, cc2 = canon_hip(edges, rows)
+    assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
