@@ -329,6 +329,10 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_adj_own, c->adj_cap);
     dev_free(c, &c->d_start_tmp, c->start_cap);
     c->start_cap = 0;
+    dev_free(c, &c->d_nref, c->nref_cap);
+    c->nref_cap = 0;
+    c->d_nadj32 = nullptr;
+    c->nbr32 = false;
     c->d_adj = nullptr;
     dev_free(c, &c->d_extra_cnt, c->n);
     dev_free(c, &c->d_extra_node, c->extra_cap);
