@@ -464,7 +464,6 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
             __syncthreads();
             for (u32 lb = 0; lb < nlead; lb += 64) {
                 const u32 li = lb + lane;
-                const u32 nocc = min(64u, nlead - lb);
                 u32 s = 0, cnt = 0;
                 if (li < nlead) {
                     const u32 prel = s_wp[s_lead[li]] & 0x7FFFu;
