@@ -158,3 +158,49 @@ def test_sharded_notices_a_twin_missing_from_another_ranks_list(G):
     ce1, cc1 = canon_hip(e1, r1)
     ce2, cc2 = canon_hip(edges, rows)
     assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
+
+
+def test_copying_import_of_a_node_ordered_adjacency():
+    """disco_export_adjacency + disco_import_adjacency (the copying form of the exchange: one compact node-ordered CSR instead
+    of the adopted rank-major padded buffer): two ranks' exports concatenated by hand, both contexts finish on the copy"""
+    reads, fidx, mo = gu.case_inputs("mixed_4k")
+    dev = torch.device("cuda", 0)
+    n = len(reads)
+    gs = [buildgraph.BuildGraph(min_overlap=mo, device=0) for _ in range(2)]
+    try:
+        engines = [distributed.HipEngine(g, dev) for g in gs]
+        parts = []
+        for r, (g, e) in enumerate(zip(gs, engines)):
+            g.upload_ascii(reads)
+            lo, hi = distributed.shard_range(n, r, 2)
+            e.build_index()
+            e.set_query_range(lo, hi)
+            e.probe()
+        keys = torch.minimum(engines[0].get_keys().clone(), engines[1].get_keys().clone())
+        for e in engines:
+            e.set_keys(keys.clone())
+            e.mark_contained()
+            e.select_edges()
+            parts.append(e.export_adjacency())
+        deg_all = torch.cat([p[0] for p in parts])
+        rows_all = torch.cat([p[1] for p in parts])
+        total = 0
+        for e in engines:
+            e.import_adjacency(deg_all, rows_all)
+            assert e.symmetrize(False) == 0
+            e.transitive_mark()
+        # survivors of all nodes: the flags of both ranks in the compact layout (slots of rank 0's nodes first)
+        f0, lo0, hi0, span = engines[0].get_flags()
+        f1, lo1, hi1, _ = engines[1].get_flags()
+        assert (lo0, hi0, lo1, hi1) == (0, int(parts[0][1].numel()), int(parts[0][1].numel()), span)
+        flags = torch.cat([f0, f1])
+        for e in engines:
+            e.set_flags(flags.clone())
+            total += e.emit_edges()
+        edges = np.concatenate([g.fetch_edges() for g in gs])
+        assert total == len(edges)
+        ce, cc = canon_hip(edges, gs[0].fetch_contained(), fidx)
+        gu.check_against_golden("mixed_4k", ce, cc)
+    finally:
+        for g in gs:
+            g.close()
