@@ -11,15 +11,18 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails = 0
 t0 = time.time()
 for it in range(iters):
-    lmin = int(rng.choice([45, 60, 80, 100, 150, 151, 168, 200, 256, 257, 300, 500, 1000]))
+    lmin = int(rng.choice([45, 60, 80, 100, 150, 151, 168, 200, 256, 257, 300, 500, 1000, 1025, 2000, 5000]))
     lmax = lmin if rng.random() < 0.4 else int(lmin + rng.integers(1, 2 * lmin))
     mo = int(rng.choice([31, 32, 33, 40, 41, 50, 64, 65]))
     if mo >= lmin:
         mo = max(31, lmin - 8)
-    cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700]))
-    n = int(rng.integers(300, 5000))
+    cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700, 1500]))
+    n = int(rng.integers(300, 9000))
     if cov >= 300:
         n = min(n, 2500)
+    if lmin >= 1000:
+        n = min(n, 1200)
+        cov = min(cov, 60.0)
     nc = int(rng.integers(1, 6))
     skew = int(rng.random() < 0.3)
     err = float(rng.choice([0, 0, 0, 0.002, 0.01]))
