@@ -46,6 +46,11 @@ const char *const kMotifs[] = {"AC", "AG", "AT", "CG", "CT", "GT", "AAT", "ATA",
 size_t covered_by(const char *s, size_t n, const char *motif, size_t m)
 {
     size_t hits = 0;
+    if (m == 2 && motif[0] != motif[1]) { /* occurrences of two different letters cannot overlap: a plain count */
+        const char x = motif[0], y = motif[1];
+        for (size_t p = 0; p + 1 < n; p++) hits += (size_t)((s[p] == x) & (s[p + 1] == y));
+        return hits * 2;
+    }
     for (size_t p = 0; p + m <= n;) { /* left-to-right, non-overlapping: BG/Common.h:173-183 */
         if (memcmp(s + p, motif, m) == 0) {
             hits++;
@@ -189,19 +194,56 @@ struct UpperTable {
 };
 const UpperTable kUpper;
 
-/* clean a record into buf (newlines dropped, upper case); returns the length */
-inline uint32_t clean(const char *d, const Rec &r, std::string &buf)
+/* base code of an (upper-case) character: A0 C1 G2 T3 (BG/HashTable.h:16-24), anything else 4 */
+struct CodeTable {
+    unsigned char t[256];
+    uint64_t inc[256]; /* one 16-bit counter per base in a 64-bit word (reads are shorter than 32768), other characters: 0 */
+    CodeTable()
+    {
+        for (int i = 0; i < 256; i++) {
+            t[i] = 4;
+            inc[i] = 0;
+        }
+        t['A'] = 0;
+        t['C'] = 1;
+        t['G'] = 2;
+        t['T'] = 3;
+        inc['A'] = 1ull;
+        inc['C'] = 1ull << 16;
+        inc['G'] = 1ull << 32;
+        inc['T'] = 1ull << 48;
+    }
+};
+const CodeTable kCode;
+
+/* clean a record into buf (newlines dropped, upper case) and count its bases on the way (cnt[4] = characters that are not
+ * ACGT); returns the length */
+inline uint32_t clean(const char *d, const Rec &r, std::string &buf, uint32_t cnt[5])
 {
     buf.resize(r.e - r.s);
     char *o = &buf[0];
     size_t m = 0, p = r.s;
+    uint64_t acc = 0; /* four 16-bit base counters; a record of 32768 or more characters is rejected by its length anyway */
     while (p < r.e) { /* copy line by line (BG/Dataset.cpp:276 removes the newlines) */
         const char *nl = (const char *)memchr(d + p, '\n', r.e - p);
         const size_t q = nl ? (size_t)(nl - d) : r.e;
-        for (size_t i = p; i < q; i++) o[m++] = (char)kUpper.t[(unsigned char)d[i]];
+        if (m + (q - p) < 32768) {
+            for (size_t i = p; i < q; i++) {
+                const unsigned char c = kUpper.t[(unsigned char)d[i]];
+                o[m++] = (char)c;
+                acc += kCode.inc[c];
+            }
+        } else {
+            for (size_t i = p; i < q; i++) o[m++] = (char)kUpper.t[(unsigned char)d[i]];
+        }
         p = q + 1;
     }
     buf.resize(m);
+    cnt[0] = (uint32_t)(acc & 0xFFFF);
+    cnt[1] = (uint32_t)((acc >> 16) & 0xFFFF);
+    cnt[2] = (uint32_t)((acc >> 32) & 0xFFFF);
+    cnt[3] = (uint32_t)(acc >> 48);
+    cnt[4] = (uint32_t)(m - std::min<size_t>(m, (size_t)cnt[0] + cnt[1] + cnt[2] + cnt[3])); /* characters that are not ACGT */
     return (uint32_t)m;
 }
 
@@ -234,41 +276,73 @@ bool fasta_starts_parallel(const Blob &b, int threads, std::vector<std::vector<s
 
 } // namespace
 
-bool test_read(const char *s, size_t n)
-{
-    if (n < 30) return false; /* MIN_READ_SIZE */
-    size_t cnt[4] = {0, 0, 0, 0};
-    for (size_t i = 0; i < n; i++) {
-        switch (s[i]) {
-        case 'A': cnt[0]++; break;
-        case 'C': cnt[1]++; break;
-        case 'G': cnt[2]++; break;
-        case 'T': cnt[3]++; break;
-        default: return false;
+/* the patterns of testRead prepared once: first 8 bytes of every end repeat as an integer (a read end is compared with the
+ * 38 integers, the 29-byte memcmp only runs on a match), base content and length of every motif */
+struct FilterTables {
+    uint64_t rep8[sizeof(kEndRepeats) / sizeof(kEndRepeats[0])];
+    struct Motif {
+        const char *s;
+        uint32_t len, need[4];
+    } motif[sizeof(kMotifs) / sizeof(kMotifs[0])];
+    FilterTables()
+    {
+        size_t i = 0;
+        for (const char *r : kEndRepeats) memcpy(&rep8[i++], r, 8);
+        i = 0;
+        for (const char *mo : kMotifs) {
+            Motif &m = motif[i++];
+            m.s = mo;
+            m.len = (uint32_t)strlen(mo);
+            m.need[0] = m.need[1] = m.need[2] = m.need[3] = 0;
+            for (uint32_t x = 0; x < m.len; x++) m.need[kCode.t[(unsigned char)mo[x]]]++;
         }
     }
+};
+const FilterTables kFilter;
+
+/* Dataset::testRead (BG/Dataset.cpp:403-452) on a cleaned read whose base counts are known (cnt[4] = non-ACGT characters) */
+bool test_read_counted(const char *s, size_t n, const uint32_t cnt[5])
+{
+    if (n < 30) return false; /* MIN_READ_SIZE */
+    if (cnt[4]) return false; /* :411 */
     size_t thr = (size_t)((double)n * .7);
-    for (size_t c : cnt)
-        if (c >= thr) return false;
-    for (const char *r : kEndRepeats) {
-        const size_t m = 29;
-        if (n < m) return false;
-        if ((s[0] == r[0] && memcmp(r, s, m) == 0) || (s[n - m] == r[0] && memcmp(r, s + n - m, m) == 0)) return false;
+    for (int b = 0; b < 4; b++)
+        if (cnt[b] >= thr) return false;
+    {
+        const size_t m = 29; /* n >= 30 > m */
+        uint64_t head, tail;
+        memcpy(&head, s, 8);
+        memcpy(&tail, s + n - m, 8);
+        size_t i = 0;
+        for (const char *r : kEndRepeats) {
+            const uint64_t r8 = kFilter.rep8[i++];
+            if ((head == r8 && memcmp(r, s, m) == 0) || (tail == r8 && memcmp(r, s + n - m, m) == 0)) return false;
+        }
     }
     thr = (size_t)((double)n * .5);
-    for (const char *mo : kMotifs) {
-        const size_t m = strlen(mo);
-        /* the non-overlapping occurrences of a motif cannot outnumber what the read's base counts allow: if even that bound
-         * stays under the threshold the scan is pointless (exact: an upper bound on countSubstring, BG/Common.h:173-183) */
-        size_t need[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < m; i++) need[mo[i] == 'A' ? 0 : mo[i] == 'C' ? 1 : mo[i] == 'G' ? 2 : 3]++;
-        size_t bound = n;
+    uint32_t q[7] = {0, 0, 0, 0, 0, 0, 0}; /* q[m] = ceil(thr / m) for the motif lengths 2, 3, 6 */
+    q[2] = (uint32_t)((thr + 1) / 2);
+    q[3] = (uint32_t)((thr + 2) / 3);
+    q[6] = (uint32_t)((thr + 5) / 6);
+    for (const FilterTables::Motif &mo : kFilter.motif) {
+        /* the non-overlapping occurrences of a motif cannot outnumber what the read's base counts allow
+         * (min_b floor(cnt[b] / need[b])): if even that bound times the motif length stays under the threshold the scan is
+         * pointless (exact: an upper bound on countSubstring, BG/Common.h:173-183). floor(c / d) < q  <=>  c < d q. */
+        const uint32_t qq = mo.len <= 6 ? q[mo.len] : (uint32_t)((thr + mo.len - 1) / mo.len);
+        bool skip = false;
         for (int b = 0; b < 4; b++)
-            if (need[b]) bound = std::min(bound, cnt[b] / need[b]);
-        if (bound * m < thr) continue;
-        if (covered_by(s, n, mo, m) >= thr) return false;
+            if (mo.need[b] && cnt[b] < mo.need[b] * qq) skip = true;
+        if (skip) continue;
+        if (covered_by(s, n, mo.s, mo.len) >= thr) return false;
     }
     return true;
+}
+
+bool test_read(const char *s, size_t n)
+{
+    uint32_t cnt[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) cnt[kCode.t[(unsigned char)s[i]]]++;
+    return test_read_counted(s, n, cnt);
 }
 
 bool load_reads(const std::vector<std::string> &pe, const std::vector<std::string> &se, uint32_t min_overlap, int threads,
@@ -342,16 +416,19 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
             for (int t = 0; t < threads; t++) {
                 std::vector<uint64_t> &ar = arenas[fi][t];
                 for (size_t i = nr0 * (size_t)t / threads; i < nr0 * (size_t)(t + 1) / threads; i++) {
-                    const uint32_t L = clean(b.data, R[i], buf);
-                    if (!(L > min_overlap && L <= 32767 && test_read(buf.data(), L))) continue; /* BG/Dataset.cpp:305 */
+                    uint32_t cnt[5];
+                    const uint32_t L = clean(b.data, R[i], buf, cnt);
+                    if (!(L > min_overlap && L <= 32767 && test_read_counted(buf.data(), L, cnt))) continue; /* BG/Dataset.cpp:305 */
                     G[i] = (uint16_t)L;
                     const size_t w0 = ar.size(), W = (L + 31) / 32;
                     ar.resize(w0 + W, 0);
                     uint64_t *w = &ar[w0];
-                    for (uint32_t x = 0; x < L; x++) {
-                        const char ch = buf[x];
-                        const uint64_t bb = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : 3;
-                        w[x >> 5] |= bb << (62 - 2 * (x & 31)); /* BG/HashTable.cpp:456-477 */
+                    const unsigned char *bs = (const unsigned char *)buf.data();
+                    for (uint32_t x0 = 0; x0 < L; x0 += 32) { /* MSB first, 2 bits per base: BG/HashTable.cpp:456-477 */
+                        const uint32_t nb = std::min<uint32_t>(32, L - x0);
+                        uint64_t acc = 0;
+                        for (uint32_t x = 0; x < nb; x++) acc = (acc << 2) | kCode.t[bs[x0 + x]];
+                        w[x0 >> 5] = acc << (2 * (32 - nb));
                     }
                 }
             }
