@@ -87,6 +87,7 @@ ABI = [
     ("disco_adopt_neighbours32", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
     ("disco_dropped_hits", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("disco_set_global_dropped", C.c_int, [_P, C.c_uint64]),
+    ("disco_fetch_edge_files", C.c_int64, [_P, C.c_uint32, _P, C.c_uint64]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
 ]
@@ -310,6 +311,13 @@ class BuildGraph:
 
     def set_global_dropped(self, n_all: int):
         self._chk(self.L.disco_set_global_dropped(self._h, n_all))
+
+    def fetch_edge_files(self, n_files: int):
+        """file index of every edge (order of fetch_edges): connected components dealt out to n_files files"""
+        n = int(self.L.disco_fetch_edges(self._h, None, 0))
+        out = np.zeros(max(n, 1), dtype=np.uint16)
+        self._chk(self.L.disco_fetch_edge_files(self._h, n_files, out.ctypes.data, n))
+        return out[:n]
 
     def measure_hbm(self, nbytes: int = 4 << 30, reps: int = 5) -> float:
         """attainable HBM bandwidth in GB/s (read + write bytes of a streaming copy kernel)"""

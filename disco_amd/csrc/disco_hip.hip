@@ -1512,6 +1512,85 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     return (int64_t)ne;
 }
 
+int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, uint64_t cap)
+{
+    if (!c || !out || n_files == 0 || n_files > 0xFFFEu) return DISCO_E_ARG;
+    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edge_files: run disco_transitive_reduce first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 ne = c->n_out, n = c->n;
+    if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edge_files: need room for %llu edges", (unsigned long long)ne);
+    if (ne == 0) return 0;
+    u32 *parent = nullptr, *cnt = nullptr, *d_nlist = nullptr;
+    u16 *cfile = nullptr, *efile = nullptr;
+    u64 *list = nullptr;
+    const u32 list_cap = n_files * 64 + 64;
+    int rc = DISCO_OK;
+    auto cleanup = [&]() {
+        dev_free(c, &parent, n);
+        dev_free(c, &cnt, n);
+        dev_free(c, &cfile, n);
+        dev_free(c, &efile, ne);
+        dev_free(c, &list, list_cap);
+        dev_free(c, &d_nlist, 1);
+    };
+#define PART_CHK(x)            \
+    do {                       \
+        rc = (x);              \
+        if (rc != DISCO_OK) {  \
+            cleanup();         \
+            return rc;         \
+        }                      \
+    } while (0)
+    PART_CHK(dev_alloc(c, &parent, n));
+    PART_CHK(dev_alloc(c, &cnt, n));
+    PART_CHK(dev_alloc(c, &cfile, n));
+    PART_CHK(dev_alloc(c, &efile, ne));
+    PART_CHK(dev_alloc(c, &list, list_cap));
+    PART_CHK(dev_alloc(c, &d_nlist, 1));
+    hipLaunchKernelGGL(uf_init_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, parent, n);
+    hipLaunchKernelGGL(uf_hook_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->out_used, parent);
+    hipLaunchKernelGGL(uf_compress_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, parent, n);
+    (void)hipMemsetAsync(cnt, 0, n * sizeof(u32), c->stream);
+    (void)hipMemsetAsync(cfile, 0xFF, n * sizeof(u16), c->stream);
+    (void)hipMemsetAsync(d_nlist, 0, sizeof(u32), c->stream);
+    hipLaunchKernelGGL(uf_count_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_valid, c->out_used, parent, cnt);
+    /* components of at least 1/(64 files) of the edges are dealt out by size, largest first to the lightest file; the rest
+     * (there can be millions of small ones) go by hash */
+    const u32 thr = (u32)std::max<u64>(ne / ((u64)n_files * 64), 1);
+    hipLaunchKernelGGL(uf_big_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, cnt, n, thr, list, d_nlist, list_cap);
+    u32 n_list = 0;
+    std::vector<u64> hl(list_cap);
+    if (hipMemcpyAsync(&n_list, d_nlist, sizeof(u32), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(hl.data(), list, list_cap * sizeof(u64), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        cleanup();
+        return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: %s", hipGetErrorString(hipGetLastError()));
+    }
+    n_list = std::min(n_list, list_cap);
+    hl.resize(n_list);
+    std::sort(hl.begin(), hl.end(), [](u64 a, u64 b) { return (u32)a != (u32)b ? (u32)a > (u32)b : a < b; }); /* by size, then root: deterministic */
+    std::vector<u64> load(n_files, 0);
+    for (u64 &e : hl) {
+        const u32 f = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[f] += (u32)e;
+        e = (e & 0xFFFFFFFF00000000ull) | f;
+    }
+    if (n_list) {
+        if (hipMemcpyAsync(list, hl.data(), n_list * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            cleanup();
+            return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: upload failed");
+        }
+        hipLaunchKernelGGL(uf_assign_kernel, dim3((n_list + 255) / 256), dim3(256), 0, c->stream, list, n_list, cfile);
+    }
+    hipLaunchKernelGGL(uf_edge_file_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_valid, c->d_out_pos, c->out_used, parent, cfile, n_files, efile);
+    hipError_t e1 = hipMemcpyAsync(out, efile, ne * sizeof(u16), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    cleanup();
+#undef PART_CHK
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: copy failed");
+    return (int64_t)ne;
+}
+
 int disco_phase_ms(disco_ctx *c, float *ms, int n)
 {
     if (!c || !ms) return DISCO_E_ARG;

@@ -1999,6 +1999,98 @@ __global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *
         }
 }
 
+/* ================================================================================================================
+ * file partition of the emitted edges by connected component (disco_partition_edges): the consumer pre-simplifies every
+ * edge file on its own and may only touch nodes ALL of whose edges are in that file (SG/OverlapGraphSimple.cpp:344,
+ * 636-644). The reference gets such files from the locality of its BFS batches; here the components of the reduced graph
+ * (concurrent union-find: hook the larger root under the smaller with a CAS, path halving) are dealt out to the files, so
+ * that every node has all its edges in one file.
+ * ============================================================================================================== */
+__device__ __forceinline__ u32 uf_find(u32 *parent, u32 x)
+{
+    for (;;) {
+        const u32 p = parent[x];
+        if (p == x) return x;
+        const u32 g = parent[p];
+        if (g != p) parent[x] = g; /* path halving; parents only ever decrease, so a lost race is harmless */
+        x = p;
+    }
+}
+
+__global__ void uf_init_kernel(u32 *parent, u64 n)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) parent[i] = (u32)i;
+}
+
+__global__ void uf_hook_kernel(const u64 *__restrict__ out_src, const u64 *__restrict__ out_ent, const u8 *__restrict__ valid, u64 n_slots, u32 *parent)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_slots; i += (u64)gridDim.x * blockDim.x) {
+        if (!valid[i]) continue;
+        u32 a = (u32)out_src[i], b = (u32)ADJ_DST(out_ent[i]);
+        for (;;) {
+            a = uf_find(parent, a);
+            b = uf_find(parent, b);
+            if (a == b) break;
+            if (a < b) {
+                const u32 t = a;
+                a = b;
+                b = t;
+            }
+            if (atomicCAS(&parent[a], a, b) == a) break; /* a was still a root: now it hangs under the smaller root */
+        }
+    }
+}
+
+__global__ void uf_compress_kernel(u32 *parent, u64 n)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u32 r = (u32)i;
+        while (parent[r] != r) r = parent[r];
+        parent[i] = r;
+    }
+}
+
+/* edges per component (at its root); parent is fully compressed */
+__global__ void uf_count_kernel(const u64 *__restrict__ out_src, const u8 *__restrict__ valid, u64 n_slots, const u32 *__restrict__ parent, u32 *cnt)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_slots; i += (u64)gridDim.x * blockDim.x)
+        if (valid[i]) atomicAdd(&cnt[parent[(u32)out_src[i]]], 1u);
+}
+
+/* components of at least thr edges -> list (dealt out by size on the host); cfile[root] = 0xFFFF: "by hash" */
+__global__ void uf_big_kernel(const u32 *__restrict__ cnt, u64 n, u32 thr, u64 *list, u32 *n_list, u32 cap)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (cnt[i] >= thr) {
+            const u32 k = atomicAdd(n_list, 1u);
+            if (k < cap) list[k] = (i << 32) | cnt[i];
+        }
+}
+
+__global__ void uf_assign_kernel(const u64 *__restrict__ pairs, u32 n_pairs, u16 *cfile)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) cfile[pairs[i] >> 32] = (u16)(pairs[i] & 0xFFFF);
+}
+
+__global__ void uf_edge_file_kernel(const u64 *__restrict__ out_src, const u8 *__restrict__ valid, const u64 *__restrict__ pos, u64 n_slots,
+                                    const u32 *__restrict__ parent, const u16 *__restrict__ cfile, u32 n_files, u16 *edge_file)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_slots; i += (u64)gridDim.x * blockDim.x)
+        if (valid[i]) {
+            const u32 r = parent[(u32)out_src[i]];
+            u16 f = cfile[r];
+            if (f == 0xFFFFu) f = (u16)(((u64)(r * 0x9E3779B1u) * n_files) >> 32); /* small components: spread by hash */
+            edge_file[pos[i]] = f;
+        }
+}
+
 /* how many items of [lo,hi) exceed a threshold: rows longer than ES_CAP (cnt = row_cnt) / nodes of degree above TR_CAP
  * (ref != null: degree field of the reference word) — sizes the big-item lists before the kernels that fill them */
 __global__ void count_above_kernel(const u32 *__restrict__ cnt, const u64 *__restrict__ ref, u64 lo, u64 hi, u32 thr, u64 *out)

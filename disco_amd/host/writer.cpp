@@ -132,7 +132,8 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
     return ok;
 }
 
-bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err)
+bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err,
+                 const uint16_t *edge_file)
 {
     const uint64_t n = rs.size();
     const size_t ne = edges.size();
@@ -143,8 +144,11 @@ bool write_edges(const std::string &prefix, int n_files, const std::vector<disco
     std::vector<int32_t> os(ne), od(ne);
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (size_t i = 0; i < ne; i++) {
-        os[i] = owner_of(edges[i].src, n, n_files);
-        od[i] = owner_of(edges[i].dst, n, n_files);
+        if (edge_file) os[i] = od[i] = std::min<int32_t>(edge_file[i], n_files - 1);
+        else {
+            os[i] = owner_of(edges[i].src, n, n_files);
+            od[i] = owner_of(edges[i].dst, n, n_files);
+        }
     }
     for (size_t i = 0; i < ne; i++) {
         cnt[os[i] + 1]++;

@@ -203,6 +203,11 @@ int disco_tr_flags(disco_ctx *ctx, void **d_flags, uint64_t *slot_lo, uint64_t *
 int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
 /* edges of the local query range (src < dst), in no particular order; returns count or negative error */
 int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
+/* one file index in [0, n_files) per edge, in the order of disco_fetch_edges: the connected components of the reduced graph
+ * dealt out to n_files files (large components by size, small ones by hash), so that every node has ALL its edges in one
+ * file — what lets the consumer pre-simplify the files independently (SG/OverlapGraphSimple.cpp:344,636-644; the reference
+ * gets it from the locality of its BFS batches, BG/OverlapGraph.cpp:100-325) */
+int64_t disco_fetch_edge_files(disco_ctx *ctx, uint32_t n_files, uint16_t *out, uint64_t cap);
 int disco_get_counters(disco_ctx *ctx, disco_counters *out);
 /* milliseconds of the last run of each phase, measured with HIP events on the stream the kernels were launched on
  * (index = DISCO_PH_*). DISCO_PH_PROBE_KERNEL brackets exactly one launch of the dominant kernel. */

@@ -143,3 +143,24 @@ def test_metagenome_like_abundances():
     spec = readgen.GenSpec.coverage(37, 12000, 100, 30.0, n_contigs=40, len_max=250, skew=1)
     c = assert_parity(readgen.generate_reads(spec), 40, "skew")
     assert c["e_out"] > 0 and c["n_contained"] > 0
+
+
+def test_edge_files_follow_connected_components():
+    """disco_fetch_edge_files: all edges of a node in ONE file (what the consumer's per-file pre-simplification needs), large
+    components dealt out by size"""
+    from disco_amd import buildgraph
+
+    spec = readgen.GenSpec.coverage(41, 30000, 150, 30.0, n_contigs=12)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        e = g.fetch_edges()
+        for nf in (1, 4, 7):
+            f = g.fetch_edge_files(nf)
+            assert len(f) == len(e) and f.max() < nf
+            node_file = {}
+            for a, b, t in zip(e["src"].tolist(), e["dst"].tolist(), f.tolist()):
+                assert node_file.setdefault(a, t) == t and node_file.setdefault(b, t) == t
+            if nf > 1:
+                load = np.bincount(f, minlength=nf)
+                assert load.min() > 0 and load.max() < 2.5 * load.mean()  # 12 contigs over 4 / 7 files

@@ -117,6 +117,10 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
                 marked.add(b)
         for v in marked:
             assert here[v] == all_edges[v]
+    # the files are cut along connected components: every edge is written once, with both ends marked
+    n_lines = sum(len(r) for r in per_file)
+    assert n_lines == len({e for es in all_edges.values() for e in es})
+    assert all(info.rsplit(",", 1)[1] == "2" for rows in per_file for _, _, info in rows)
     # contained rows of one containing read are contiguous (SG/DataSet.cpp:316-335)
     for t in range(threads):
         supers = [l.split("\t")[1] for l in open(f"{prefix}_{t}_containedReads.txt")]
