@@ -177,8 +177,12 @@ def test_files_load_in_the_reference_parsimplify(tmp_path):
     ours3 = str(tmp_path / "ours3")
     p = subprocess.run([os.path.join(BIN, "buildG"), "-se", fa, "-f", ours3, "-p", str(cfg), "-t", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0, p.stdout
+    parts = []
     for t in range(3):
-        _parsimplify(f"{ours3}_{t}_parGraph.txt", str(tmp_path / f"ours3_{t}.txt"), 40)
+        parts += _parsimplify(f"{ours3}_{t}_parGraph.txt", str(tmp_path / f"ours3_{t}.txt"), 40)
+    # the files are cut along connected components, so the per-file pre-simplification is complete: together the three files
+    # contract into exactly the composite edges of the single file
+    assert sorted(parts, key=lambda s: (len(s), min(s))) == a
 
 
 def test_input_stage_falls_back_on_awkward_fasta(tmp_path):
