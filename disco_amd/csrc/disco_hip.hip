@@ -1236,6 +1236,8 @@ int disco_transitive_mark(disco_ctx *c)
     a.wide_cap = c->wide_cap;
     a.nref = c->nbr32 ? c->d_nref : nullptr;
     a.nadj32 = c->nbr32 ? c->d_nadj32 : nullptr;
+    /* every row needs its flags whenever another rank may ask for them (any sharded flow) or there are no survivor lists */
+    a.all_flags = (c->adj_imported || c->nbr32 || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
     if (nq) {
         if (c->nbr32) hipLaunchKernelGGL((transitive_mark_kernel<false, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
@@ -1360,6 +1362,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.ref = c->d_adj_ref;
         a.adj = c->d_adj;
         a.hcnt = half_emit ? c->d_hcnt : nullptr;
+        a.half = half_emit ? c->d_half : nullptr;
         const bool listed = half_emit && c->n_wide <= c->wide_cap; /* else the list overflowed: scan the whole range */
         a.list = listed ? c->d_wide : nullptr;
         a.n_list = listed ? c->n_wide : 0;

@@ -1468,6 +1468,10 @@ struct TrArgs {
      * reference words; ref / adj above then hold the rank's own rows only */
     const u64 *nref;
     const u32 *nadj32;
+    /* 0: the transitive flag is written into the rows of nodes with more than HALF_CAP survivors only — everybody else's result
+     * IS its survivor list, and rewriting 34 of 36 entries per node was a quarter of this kernel's memory requests (single GPU
+     * with survivor lists); 1: every row gets its flags (sharded flows: the flag exchange may need all of them) */
+    u32 all_flags;
 };
 
 template <bool N32>
@@ -1675,8 +1679,8 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     }
     const bool fl = lane < d && hstate[sent];
     const bool fr = lane < d && !fl;
-    if (fl) a.adj[nd.vs + lane] = e | ADJ_FLAG;
     const u64 mk = __ballot(fr);
+    if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
     if (a.half && fr) {
         const u32 r = __popcll(mk & lane_mask_lt());
         if (r < HALF_CAP) a.half[nd.v * HALF_CAP + r] = e;
@@ -1827,6 +1831,8 @@ struct EmitArgs {
     const u64 *ref;
     const u64 *adj;
     const u32 *hcnt; /* non-null: only nodes with more than HALF_CAP survivors (the others went through emit_half_kernel) */
+    const u64 *half; /* with hcnt: survivor lists; a neighbour with at most HALF_CAP survivors is judged by its list (its row
+                        carries no flags then, see TrArgs.all_flags) */
     const u64 *list; /* non-null: the nodes to emit (n_list of them) instead of the whole query range */
     u64 n_list;
     u64 *out_src;
@@ -1867,10 +1873,16 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
                 if (v < w && !(e & ADJ_FLAG)) {
                     const u32 Lw = ADJ_DLEN(e);
                     const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
-                    const u64 rw = a.ref[w];
-                    const u64 *roww = a.adj + REF_POS(rw);
-                    const int ti = adj_find(roww, REF_DEG(rw), twin);
-                    keep = (ti >= 0) && !(roww[ti] & ADJ_FLAG);
+                    const u32 cw = a.hcnt ? a.hcnt[w] : HALF_CAP + 1;
+                    if (cw <= HALF_CAP) {
+                        const u64 *hw = a.half + w * HALF_CAP;
+                        for (u32 r = 0; r < cw; r++) keep |= (hw[r] == twin);
+                    } else {
+                        const u64 rw = a.ref[w];
+                        const u64 *roww = a.adj + REF_POS(rw);
+                        const int ti = adj_find(roww, REF_DEG(rw), twin);
+                        keep = (ti >= 0) && !(roww[ti] & ADJ_FLAG);
+                    }
                 }
             }
             const u64 mk = __ballot(keep);
