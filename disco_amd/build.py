@@ -36,7 +36,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(LIB, HIP_DEPS):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + HIP_SOURCES
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB] + HIP_SOURCES
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/disco_hip.h"
@@ -30,6 +31,22 @@
 static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
 
 static thread_local std::string g_create_error;
+
+/* host-side loops over tens of millions of results (struct conversion, random reads of the length table) */
+template <typename F>
+static void parallel_for(u64 n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("DISCO_HOST_THREADS")) nt = (unsigned)atoi(e);
+    nt = std::max(1u, std::min(nt, 16u));
+    if (n < (1u << 16) || nt == 1) {
+        f((u64)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([=]() { f(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th) x.join();
+}
 
 struct disco_ctx {
     int device = 0;
@@ -1464,20 +1481,24 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     dev_free(c, &pos, c->n + 1);
     dev_free(c, &ids, nc);
     dev_free(c, &keys, nc);
-    for (u64 i = 0; i < nc; i++) {
-        const u64 key = hkey[i];
-        disco_contained_row &r = out[i];
-        r.contained = hid[i];
-        r.super = CKEY_SUPER(key);
-        r.j = CKEY_J(key);
-        r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
-        r.len2 = c->h_len[r.contained];
-        r.len1 = c->h_len[r.super];
-        u32 orient, off;
-        disco_map_type(r.type, r.len1, (u32)c->k, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
-        r.orient = orient;
-        r.start = off;
-    }
+    const u16 *hlen = c->h_len.data();
+    const u32 kk = (u32)c->k;
+    parallel_for(nc, [&, hlen, kk](u64 b, u64 e_) {
+        for (u64 i = b; i < e_; i++) {
+            const u64 key = hkey[i];
+            disco_contained_row &r = out[i];
+            r.contained = hid[i];
+            r.super = CKEY_SUPER(key);
+            r.j = CKEY_J(key);
+            r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
+            r.len2 = hlen[r.contained];
+            r.len1 = hlen[r.super];
+            u32 orient, off;
+            disco_map_type(r.type, r.len1, kk, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
+            r.orient = orient;
+            r.start = off;
+        }
+    });
     return (int64_t)nc;
 }
 
@@ -1503,15 +1524,18 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     dev_free(c, &csrc, ne);
     dev_free(c, &cent, ne);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edges: copy failed");
-    for (u64 i = 0; i < ne; i++) {
-        disco_edge &e = out[i];
-        e.src = hs[i];
-        e.dst = ADJ_DST(he[i]);
-        e.orient = ADJ_ORI(he[i]);
-        e.offset = ADJ_OFF(he[i]);
-        e.len_src = c->h_len[e.src];
-        e.len_dst = ADJ_DLEN(he[i]);
-    }
+    const u16 *hlen = c->h_len.data();
+    parallel_for(ne, [&, hlen](u64 b, u64 e_) {
+        for (u64 i = b; i < e_; i++) {
+            disco_edge &e = out[i];
+            e.src = hs[i];
+            e.dst = ADJ_DST(he[i]);
+            e.orient = ADJ_ORI(he[i]);
+            e.offset = ADJ_OFF(he[i]);
+            e.len_src = hlen[e.src];
+            e.len_dst = ADJ_DLEN(he[i]);
+        }
+    });
     return (int64_t)ne;
 }
 
