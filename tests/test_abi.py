@@ -57,3 +57,33 @@ def test_no_product_code_touches_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "disco_oracle" in txt or "libdisco_oracle" in txt:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_a_plain_c_caller_compiles_links_and_runs(tmp_path):
+    """the boundary is a C ABI: a C99 program includes include/disco_hip.h, links libdisco_hip.so and calls the host-only entry
+    points (no GPU needed: version, packing, error text)"""
+    import subprocess
+
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "disco_hip.h"
+int main(void)
+{
+    uint64_t w[2] = {0, 0};
+    if (disco_abi_version() <= 0) return 2;
+    if (disco_pack_ascii("ACGTACGTACGTACGTACGTACGTACGTACGTA", 33, w) != 0) return 3; /* MSB first, A0 C1 G2 T3 */
+    if (w[0] != 0x1B1B1B1B1B1B1B1BULL || w[1] != 0) return 4;
+    if (disco_pack_ascii("ACGN", 4, w) == 0) return 5;                               /* non-ACGT is an error */
+    if (disco_last_error(NULL) == NULL) return 6;
+    printf("abi %d\n", disco_abi_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.join(ROOT, "disco_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src),
+                           "-L", libdir, "-ldisco_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("abi "), (out.returncode, out.stdout)
