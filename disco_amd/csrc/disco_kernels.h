@@ -2018,13 +2018,18 @@ __global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *
  * (concurrent union-find: hook the larger root under the smaller with a CAS, path halving) are dealt out to the files, so
  * that every node has all its edges in one file.
  * ============================================================================================================== */
+/* parent pointers are read and written by other workgroups DURING the kernel: plain loads may be served from this CU's vector
+ * L1 or this XCD's L2 for ever (neither is refreshed by other CUs' stores), and a wave retrying its CAS on a stale "root"
+ * would spin — every access goes to the coherence point (agent-scope atomics) */
+__device__ __forceinline__ u32 uf_load(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ u32 uf_find(u32 *parent, u32 x)
 {
     for (;;) {
-        const u32 p = parent[x];
+        const u32 p = uf_load(&parent[x]);
         if (p == x) return x;
-        const u32 g = parent[p];
-        if (g != p) parent[x] = g; /* path halving; parents only ever decrease, so a lost race is harmless */
+        const u32 g = uf_load(&parent[p]);
+        if (g != p) __hip_atomic_store(&parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* path halving; parents only ever decrease, so a lost race is harmless */
         x = p;
     }
 }
