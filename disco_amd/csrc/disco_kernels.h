@@ -598,7 +598,10 @@ __device__ __forceinline__ u64 uniform_u64(u64 x)
 }
 
 /* NW = 0: generic variant (any stride, rows read from global memory). NW = 5 / 8: staged variants for a row stride of
- * VERIFY_SW words whose reads have at most 32*NW bases (decided by the host): only the first NW words of a row are moved. */
+ * VERIFY_SW words whose reads have at most 32*NW bases (decided by the host): only the first NW words of a row are moved.
+ * NW = 16: staged variant for a row stride of 16 words (reads of 257..512 bases: 2 x 300 bp runs, merged pairs): the rows are
+ * too wide to be held in registers one read ahead, they are fetched when their read's turn comes (headers and candidate
+ * lists stay pipelined). */
 template <int NW>
 __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 {
@@ -606,16 +609,19 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
      * the zero word in front of the next lane's row), the read's own row and its reverse complement live in LDS with a
      * statically known address space; the zero words make the shifted extracts branch free */
     constexpr bool staged = NW != 0;
+    constexpr bool PREF = NW != 0 && NW <= VERIFY_SW; /* candidate rows prefetched into registers one read ahead */
+    constexpr int RW = PREF ? NW : 1;                  /* row words carried in the pipeline registers */
+    constexpr int SA = (NW > VERIFY_SW ? NW : VERIFY_SW) + 4;
     constexpr int BST = (NW + 3) | 1;
     __shared__ u64 s_b[staged ? 1 + 64 * BST : 1];
-    __shared__ u64 s_a[VERIFY_SW + 4];   /* [0] = 0, [1..NW] = the read's own row, zeros behind */
-    __shared__ u64 s_arc[VERIFY_SW + 4]; /* same layout: reverse complement of the read, left aligned */
+    __shared__ u64 s_a[SA];   /* [0] = 0, [1..NW] = the read's own row, zeros behind */
+    __shared__ u64 s_arc[SA]; /* same layout: reverse complement of the read, left aligned */
     const u32 lane = threadIdx.x;
-    const int S = staged ? VERIFY_SW : a.v.S, k = a.v.k;
+    const int S = !staged ? a.v.S : (NW > VERIFY_SW ? NW : VERIFY_SW), k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
     if (staged) {
         for (u32 i = lane; i < 1 + 64 * BST; i += 64) s_b[i] = 0;
-        if (lane < VERIFY_SW + 4) {
+        if (lane < (u32)SA) {
             s_a[lane] = 0;
             s_arc[lane] = 0;
         }
@@ -631,7 +637,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         u64 rs;
     };
     struct Rows {
-        u64 w[staged ? NW : 1];
+        u64 w[RW];
         u64 aw; /* lane < NW: word `lane` of the read's own row */
     };
     u64 cbeg = 0, cend = 0;
@@ -656,7 +662,14 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         return ok ? h : 0ull;
     };
     auto load_row = [&](u64 (&w)[staged ? NW : 1], const u64 *g) {
-        if (NW == 5) { /* 16 + 16 + 8 bytes */
+        if (NW > VERIFY_SW) {
+#pragma unroll
+            for (int t = 0; t < NW; t += 2) {
+                const ulonglong2 q = ((const ulonglong2 *)g)[t / 2];
+                w[t % (staged ? NW : 1)] = q.x;
+                w[(t + 1) % (staged ? NW : 1)] = q.y;
+            }
+        } else if (NW == 5) { /* 16 + 16 + 8 bytes */
             const ulonglong2 q0 = ((const ulonglong2 *)g)[0], q1 = ((const ulonglong2 *)g)[1];
             w[0] = q0.x; w[1] = q0.y; w[2 % (staged ? NW : 1)] = q1.x; w[3 % (staged ? NW : 1)] = q1.y; w[4 % (staged ? NW : 1)] = g[4];
         } else if (NW == 8) {
@@ -672,7 +685,12 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         if (staged) {
             const u64 *own = a.v.reads + (A < a.v.q_lo + cend ? A : a.v.q_lo + cend - 1) * S;
             r.aw = own[lane < (u32)NW ? lane : 0u];
-            load_row(r.w, lane < mt.c ? a.v.reads + HIT_ID(h) * S : own);
+            if (PREF) {
+                u64 w[staged ? NW : 1];
+                load_row(w, lane < mt.c ? a.v.reads + HIT_ID(h) * S : own);
+#pragma unroll
+                for (int t = 0; t < RW; t++) r.w[t] = w[t % (staged ? NW : 1)];
+            }
         }
         return r;
     };
@@ -798,7 +816,18 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
             };
             /* the first 64 candidates and their rows were prefetched; longer rows fetch the rest on the spot (kept out of the
              * first batch's code path: a load there would make the compiler drain the whole pipeline) */
-            batch(lane < c, h0, R0.w);
+            if (PREF) {
+                u64 w[staged ? NW : 1];
+#pragma unroll
+                for (int t = 0; t < (staged ? NW : 1); t++) w[t] = R0.w[t % RW];
+                batch(lane < c, h0, w);
+            } else { /* wide rows (and the generic variant): fetched now */
+                const bool act = lane < c;
+                u64 w[staged ? NW : 1];
+                w[0] = 0;
+                if (staged) load_row(w, act ? a.v.reads + HIT_ID(h0) * S : ga);
+                batch(act, h0, w);
+            }
             for (u32 i0 = 64; i0 < c; i0 += 64) {
                 const bool act = i0 + lane < c;
                 const u64 h = row[act ? i0 + lane : 0];
