@@ -733,6 +733,8 @@ int disco_probe(disco_ctx *c)
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<8>, dim3(wq_grid(c, verify_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == 16) hipLaunchKernelGGL(verify_kernel<16>, dim3(wq_grid(c, verify_kernel<16>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (c->S == 24) hipLaunchKernelGGL(verify_kernel<24>, dim3(wq_grid(c, verify_kernel<24>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (c->S == 32) hipLaunchKernelGGL(verify_kernel<32>, dim3(wq_grid(c, verify_kernel<32>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else hipLaunchKernelGGL(verify_kernel<0>, dim3(wq_grid(c, verify_kernel<0>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
             }
             ph_end(c, DISCO_PH_VERIFY);

@@ -599,9 +599,9 @@ __device__ __forceinline__ u64 uniform_u64(u64 x)
 
 /* NW = 0: generic variant (any stride, rows read from global memory). NW = 5 / 8: staged variants for a row stride of
  * VERIFY_SW words whose reads have at most 32*NW bases (decided by the host): only the first NW words of a row are moved.
- * NW = 16: staged variant for a row stride of 16 words (reads of 257..512 bases: 2 x 300 bp runs, merged pairs): the rows are
- * too wide to be held in registers one read ahead, they are fetched when their read's turn comes (headers and candidate
- * lists stay pipelined). */
+ * NW = 16 / 24 / 32: staged variants for a row stride of NW words (reads of 257..1024 bases: 2 x 300 bp runs, merged pairs,
+ * long amplicons): the rows are too wide to be held in registers one read ahead, they are fetched when their read's turn comes
+ * (headers and candidate lists stay pipelined). */
 template <int NW>
 __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 {

@@ -25,6 +25,8 @@ def _gen(seed, n, lmin, cov, lmax=None, contigs=1):
     (5, 2000, 300, 600, 20.0, 40),      # long reads, many words per row
     (43, 3000, 257, 512, 25.0, 40),     # 16-word rows: the staged verify variant for reads of 257..512 bases
     (47, 3000, 260, 500, 40.0, 65),     # the same at k = 64
+    (53, 1500, 520, 760, 25.0, 40),     # 24-word rows
+    (59, 1500, 800, 1024, 25.0, 50),    # 32-word rows (the widest staged variant; longer reads: generic variant)
     (17, 6000, 150, 150, 100.0, 40),    # 100x coverage: rows of 65..256 hits (wide-row paths of edge selection / marking)
     (19, 5000, 100, 250, 120.0, 40),    # the same with mixed lengths (containment inside wide rows)
     (29, 4000, 150, 150, 300.0, 40),    # 300x: rows of 257..1024 hits (edge_select_mid_kernel), big-node marking
