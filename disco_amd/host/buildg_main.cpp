@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -193,17 +194,17 @@ int main(int argc, char **argv)
     if (!disco::write_contained(prefix, threads, rows, rs, err)) return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
-    std::vector<disco_edge> edges(e_out);
-    if (e_out && disco_fetch_edges(ctx, edges.data(), e_out) < 0) return die(disco_last_error(ctx));
+    std::unique_ptr<disco_edge[]> edges(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
+    if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
     lap("fetch edges");
     /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
      * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
-    std::vector<uint16_t> edge_file(e_out);
-    if (e_out && disco_fetch_edge_files(ctx, (uint32_t)threads, edge_file.data(), e_out) < 0) return die(disco_last_error(ctx));
+    std::unique_ptr<uint16_t[]> edge_file(new uint16_t[std::max<uint64_t>(e_out, 1)]);
+    if (e_out && disco_fetch_edge_files(ctx, (uint32_t)threads, edge_file.get(), e_out) < 0) return die(disco_last_error(ctx));
     lap("partition edges into files");
     disco_destroy(ctx);
     lap("release GPU context");
-    if (!disco::write_edges(prefix, threads, edges, rs, threads, err, e_out ? edge_file.data() : nullptr)) return die(err);
+    if (!disco::write_edges(prefix, threads, edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr)) return die(err);
     lap("write edges");
     if (!disco::write_checkpoint(prefix, false, true, true, err)) return die(err);
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;

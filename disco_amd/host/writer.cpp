@@ -132,11 +132,11 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
     return ok;
 }
 
-bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err,
+bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const ReadSet &rs, int threads, std::string &err,
                  const uint16_t *edge_file)
 {
     const uint64_t n = rs.size();
-    const size_t ne = edges.size();
+    const size_t ne = n_edges;
     if (threads < 1) threads = 1;
     /* an edge goes to the file that owns its source and, if different, to the file that owns its destination: bucket the
      * (edge, file, flag) items by file with a counting sort, then format fixed-size chunks of items in parallel */

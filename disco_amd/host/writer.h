@@ -24,7 +24,7 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
 /* edge_file: file of every edge when both of its ends have ALL their edges there (disco_fetch_edge_files: connected components
  * dealt out to the files) — every line then carries flag 2; nullptr: files own contiguous id ranges, an edge between two
  * files is written to both with flags 0 / 1 */
-bool write_edges(const std::string &prefix, int n_files, const std::vector<disco_edge> &edges, const ReadSet &rs, int threads, std::string &err,
+bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const ReadSet &rs, int threads, std::string &err,
                  const uint16_t *edge_file = nullptr);
 bool write_checkpoint(const std::string &prefix, bool ccr, bool gc, bool append, std::string &err);
 void read_checkpoint(const std::string &prefix, bool &ccr, bool &gc);
