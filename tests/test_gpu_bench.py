@@ -1,0 +1,43 @@
+"""-m gpu : bench.py prints ONE JSON line, last on stdout, with the fields the driver reads (small workload so that it takes
+seconds); also through the sharded code path over RCCL with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "300000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000"] + extra
+    env = dict(os.environ, MASTER_PORT="29641")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.strip()]
+    return json.loads(lines[-1])  # the JSON line is the LAST line of stdout (RCCL's banner must not follow it)
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "overlaps/s" and d["higher_is_better"] is True
+    assert d["value"] > 1e8 and d["ms_per_step"] > 0 and "workload" in d["config"] and d["vs_baseline"] is None
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["value"] > 0
+    assert d["config"]["cap_bind_sites"] == 0 and d["config"]["asymmetric_pairs"] == 0
+
+
+def test_bench_sharded_code_path_with_one_rank():
+    d = _run(["--force-distributed", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["config"]["e_out"] > 0
