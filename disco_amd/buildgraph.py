@@ -88,6 +88,7 @@ ABI = [
     ("disco_dropped_hits", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("disco_set_global_dropped", C.c_int, [_P, C.c_uint64]),
     ("disco_fetch_edge_files", C.c_int64, [_P, C.c_uint32, _P, C.c_uint64]),
+    ("disco_set_query_order", C.c_int, [_P, _P]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
 ]
@@ -318,6 +319,9 @@ class BuildGraph:
         out = np.zeros(max(n, 1), dtype=np.uint16)
         self._chk(self.L.disco_fetch_edge_files(self._h, n_files, out.ctypes.data, n))
         return out[:n]
+
+    def set_query_order(self, d_order_ptr: int):
+        self._chk(self.L.disco_set_query_order(self._h, _P(d_order_ptr)))
 
     def measure_hbm(self, nbytes: int = 4 << 30, reps: int = 5) -> float:
         """attainable HBM bandwidth in GB/s (read + write bytes of a streaming copy kernel)"""

@@ -49,6 +49,8 @@ static void parallel_for(u64 n, F f)
     for (auto &x : th) x.join();
 }
 
+#define ORDER_BUCKETS (1ull << 23) /* values of the 23-bit order hash */
+
 struct disco_ctx {
     int device = 0;
     disco_params prm{};
@@ -98,6 +100,11 @@ struct disco_ctx {
     u32 *d_n_big = nullptr;
     u32 big_cap = 0;
     u64 big_rows = 0;
+    const u64 *d_order = nullptr; /* processing order of the query range (caller-owned or built by the context), or null */
+    bool order_external = false;
+    u32 *d_ocnt = nullptr, *d_okey = nullptr, *d_oslot = nullptr;
+    u64 *d_order_own = nullptr;
+    u64 okey_cap = 0, oslot_cap = 0, order_cap = 0;
     /* sharded flow, compact exchange: neighbour rows as 4-byte entries in a caller-owned gathered array */
     const u32 *d_nadj32 = nullptr;
     u64 *d_nref = nullptr;
@@ -349,6 +356,12 @@ static void free_graph_state(disco_ctx *c)
     c->start_cap = 0;
     dev_free(c, &c->d_nref, c->nref_cap);
     c->nref_cap = 0;
+    dev_free(c, &c->d_ocnt, ORDER_BUCKETS + 1);
+    dev_free(c, &c->d_okey, c->okey_cap);
+    dev_free(c, &c->d_oslot, c->oslot_cap);
+    dev_free(c, &c->d_order_own, c->order_cap);
+    c->okey_cap = c->oslot_cap = c->order_cap = 0;
+    if (!c->order_external) c->d_order = nullptr;
     c->d_nadj32 = nullptr;
     c->nbr32 = false;
     c->d_adj = nullptr;
@@ -702,6 +715,17 @@ int disco_probe(disco_ctx *c)
         if (!c->d_probe_rare) CHK(dev_alloc(c, &c->d_probe_rare, 1));
         HIPCHK(c, hipMemcpyAsync(c->d_probe_rare, &c->h_probe_rare, sizeof(ProbeRare), hipMemcpyHostToDevice, c->stream));
         a.rare = c->d_probe_rare;
+        /* grouping of the query range by read-level minimizer for the verify pass (DISCO_NO_ORDER=1: file order) */
+        const bool own_order = !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= 4096;
+        a.okey = nullptr;
+        if (own_order) {
+            if (!c->d_ocnt) CHK(dev_alloc(c, &c->d_ocnt, ORDER_BUCKETS + 1));
+            CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, nq));
+            CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nq));
+            CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, nq));
+            HIPCHK(c, hipMemsetAsync(c->d_okey, 0xFF, nq * sizeof(u32), c->stream));
+            a.okey = c->d_okey;
+        }
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {
@@ -729,6 +753,15 @@ int disco_probe(disco_ctx *c)
             va.hits = c->d_hits;
             va.row_start = c->d_row_start;
             va.row_cnt = c->d_row_cnt;
+            if (own_order) { /* keys -> counts (+ slots) -> starts -> order */
+                HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (ORDER_BUCKETS + 1) * sizeof(u32), c->stream));
+                hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, nq, c->d_ocnt, c->d_oslot);
+                CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, ORDER_BUCKETS + 1, c->d_ocnt, false, nullptr)));
+                hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, c->d_oslot, c->d_ocnt, c->q_lo, nq, c->d_order_own);
+                c->d_order = c->d_order_own;
+            } else if (!c->order_external)
+                c->d_order = nullptr;
+            va.order = c->d_order;
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
@@ -1621,6 +1654,14 @@ int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, ui
 #undef PART_CHK
     if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: copy failed");
     return (int64_t)ne;
+}
+
+int disco_set_query_order(disco_ctx *c, const void *d_order_u64)
+{
+    if (!c) return DISCO_E_ARG;
+    c->d_order = (const u64 *)d_order_u64;
+    c->order_external = d_order_u64 != nullptr;
+    return DISCO_OK;
 }
 
 int disco_phase_ms(disco_ctx *c, float *ms, int n)

@@ -297,10 +297,16 @@ struct ProbeArgs {
     u64 *row_start; /* [n]                                            */
     u32 *row_cnt;   /* [n]                                            */
     const ProbeRare *rare;
+    /* processing order for the later passes (or null): reads are grouped by their read-level minimizer — the smallest order
+     * hash among all m-mers of the read, which this kernel computes anyway. Reads of one group contain the same genome m-mer,
+     * so they overlap each other and fetch the same candidate rows; verify_kernel walks the groups one after the other and
+     * finds those rows in the cache. okey[read - q_lo] = that hash (23 bits); the grouping itself (count, scan, scatter) is done
+     * by order_count_kernel / order_scatter_kernel. */
+    u32 *okey;
 };
 
 #ifndef PROBE_WAVES_PER_SIMD
-#define PROBE_WAVES_PER_SIMD 8
+#define PROBE_WAVES_PER_SIMD 7
 #endif
 template <bool BIG, bool LDSROW>
 __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
@@ -412,12 +418,18 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
             /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
              *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
             __syncthreads();
+            u32 hmin = 0xFFFFFFFFu;
             for (int q = (int)lane; q < np; q += 64) {
                 const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
+                hmin = min(hmin, o >> 9);
                 s_first[q] = 0xFFFFFFFFu;
                 s_strand[q] = (u8)(o & 1u);
                 s_k1[q] = (o & ~0x1FFu) | (u32)q;
                 s_k2[q] = (o & ~0x1FFu) | (511u - (u32)q);
+            }
+            if (!BIG && a.okey) { /* read-level minimizer (smallest order hash of the read; okey starts at ~0): see ProbeArgs */
+                for (int o = 32; o > 0; o >>= 1) hmin = min(hmin, (u32)__shfl_xor(hmin, o));
+                if (lane == 0) atomicMin(&a.okey[A - a.v.q_lo], hmin);
             }
             __syncthreads();
             /* 2. minimum over [q, q + P) for every q by doubling, P = largest power of two <= nf; in place, ascending
@@ -579,6 +591,7 @@ struct VerifyArgs {
     u64 *hits;
     const u64 *row_start;
     u32 *row_cnt; /* in: candidates, out: verified overlap hits (row compacted in place) */
+    const u64 *order; /* [q_hi - q_lo] processing order (read ids), or null */
 };
 
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
@@ -589,6 +602,13 @@ __device__ __forceinline__ u64 extract32_padded(const u64 *row, int pos)
     const int w = pos >> 5, sh = (pos & 31) * 2;
     const u64 a = row[w], b = row[w + 1];
     return (a << sh) | ((b >> 1) >> (63 - sh));
+}
+
+__device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, (int)l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), (int)l);
+    return ((u64)hi << 32) | lo;
 }
 
 __device__ __forceinline__ u32 uniform_u32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
@@ -644,10 +664,15 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
     /* every pipelined load is UNCONDITIONAL (clamped address + select): a load under an exec-mask branch makes the number
      * of loads in flight unknown to the compiler, which then waits for (nearly) all of them at the next use and the
      * pipeline collapses into one exposed latency per stage */
-    auto load_meta = [&](u64 A) {
+    /* the reads of a chunk in processing order: position `it` of the query range holds read order[it] (a.order: reads that
+     * share their read-level minimizer are neighbours there, so that the candidate rows one of them fetches are still in the
+     * cache for the next ones), or simply read q_lo + it */
+    u64 ord_chunk = 0;
+    auto rid = [&](u64 it) { return readlane_u64(ord_chunk, (u32)((it < cend ? it : cend - 1) - cbeg)); };
+    auto load_meta = [&](u64 it) {
         Meta mt;
-        const bool ok = A < a.v.q_lo + cend;
-        const u64 Ac = ok ? A : a.v.q_lo + cend - 1;
+        const bool ok = it < cend;
+        const u64 Ac = rid(it);
         mt.c = a.row_cnt[Ac];
         mt.rs = a.row_start[Ac];
         mt.L = a.v.len[Ac];
@@ -683,7 +708,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         r.w[0] = 0;
         r.aw = 0;
         if (staged) {
-            const u64 *own = a.v.reads + (A < a.v.q_lo + cend ? A : a.v.q_lo + cend - 1) * S;
+            const u64 *own = a.v.reads + A * S;
             r.aw = own[lane < (u32)NW ? lane : 0u];
             if (PREF) {
                 u64 w[staged ? NW : 1];
@@ -695,15 +720,19 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         return r;
     };
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
-    const u64 A_first = a.v.q_lo + cbeg;
-    Meta m0 = load_meta(A_first), m1 = load_meta(A_first + 1), m2 = load_meta(A_first + 2);
-    u64 h0 = load_cands(m0, A_first), h1 = load_cands(m1, A_first + 1);
-    Rows R0 = load_rows(m0, h0, A_first);
+    {
+        const u64 i = cbeg + (lane < cend - cbeg ? lane : 0u); /* WQ_CHUNK <= 64: one lane per read of the chunk */
+        ord_chunk = a.order ? a.order[i] : a.v.q_lo + i;
+    }
+    Meta m0 = load_meta(cbeg), m1 = load_meta(cbeg + 1), m2 = load_meta(cbeg + 2);
+    u64 h0 = load_cands(m0, rid(cbeg)), h1 = load_cands(m1, rid(cbeg + 1));
+    Rows R0 = load_rows(m0, h0, rid(cbeg));
 
-    for (u64 A = A_first; A < a.v.q_lo + cend; A++) {
-        const Meta m3 = load_meta(A + 3);
-        const u64 h2 = load_cands(m2, A + 2);
-        const Rows R1 = load_rows(m1, h1, A + 1);
+    for (u64 it = cbeg; it < cend; it++) {
+        const u64 A = rid(it);
+        const Meta m3 = load_meta(it + 3);
+        const u64 h2 = load_cands(m2, rid(it + 2));
+        const Rows R1 = load_rows(m1, h1, rid(it + 1));
         const u32 c = uniform_u32(m0.c); /* wave uniform: scalar from here on (the loads themselves stay in flight as vectors) */
         if (c != 0) {
             u64 *row = a.hits + uniform_u64(m0.rs);
@@ -1619,13 +1648,6 @@ struct TrNodeRegs {
     u64 p0, p2; /* lane's entry of their rows */
 };
 
-__device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
-{
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, (int)l);
-    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), (int)l);
-    return ((u64)hi << 32) | lo;
-}
-
 template <bool N32>
 __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs &nd, u64 *hkey, u8 *hstate, u32 lane)
 {
@@ -2135,6 +2157,21 @@ __global__ void uf_edge_file_kernel(const u64 *__restrict__ out_src, const u8 *_
             if (f == 0xFFFFu) f = (u16)(((u64)(r * 0x9E3779B1u) * n_files) >> 32); /* small components: spread by hash */
             edge_file[pos[i]] = f;
         }
+}
+
+/* the query range grouped by read-level minimizer: count per hash value (the atomic hands every read its slot; the 32 MB of
+ * counters stay in the L2 / Infinity Cache), exclusive scan, then order[start[hash] + slot] = read */
+__global__ void order_count_kernel(const u32 *__restrict__ okey, u64 nq, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) oslot[i] = atomicAdd(&cnt[okey[i] & 0x7FFFFFu], 1u);
+}
+
+__global__ void order_scatter_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ oslot, const u32 *__restrict__ start, u64 lo, u64 nq,
+                                     u64 *__restrict__ order)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) order[(u64)start[okey[i] & 0x7FFFFFu] + oslot[i]] = lo + i;
 }
 
 /* how many items of [lo,hi) exceed a threshold: rows longer than ES_CAP (cnt = row_cnt) / nodes of degree above TR_CAP

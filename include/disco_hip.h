@@ -224,6 +224,10 @@ enum {
     DISCO_PH_COUNT
 };
 int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
+/* processing order of the query range for the verify pass: a device array of q_hi - q_lo read ids (a permutation of the
+ * range; caller-owned, must stay valid), or NULL for file order. Results do not depend on it; reads that overlap each other
+ * processed back to back find their candidates' rows in the cache. */
+int disco_set_query_order(disco_ctx *ctx, const void *d_order_u64);
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* attainable HBM bandwidth on this device (SURVEY.md §8d "Roofline that bounds the path": nominal AND measured): a
