@@ -716,7 +716,8 @@ int disco_probe(disco_ctx *c)
         HIPCHK(c, hipMemcpyAsync(c->d_probe_rare, &c->h_probe_rare, sizeof(ProbeRare), hipMemcpyHostToDevice, c->stream));
         a.rare = c->d_probe_rare;
         /* grouping of the query range by read-level minimizer for the verify pass (DISCO_NO_ORDER=1: file order) */
-        const bool own_order = !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= 4096;
+        const u64 order_min = getenv("DISCO_ORDER_MIN_READS") ? (u64)atoll(getenv("DISCO_ORDER_MIN_READS")) : 4096; /* tests: 1 */
+        const bool own_order = !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= order_min && nq > 0;
         a.okey = nullptr;
         if (own_order) {
             if (!c->d_ocnt) CHK(dev_alloc(c, &c->d_ocnt, ORDER_BUCKETS + 1));

@@ -168,3 +168,11 @@ def test_edge_files_follow_connected_components():
             if nf > 1:
                 load = np.bincount(f, minlength=nf)
                 assert load.min() > 0 and load.max() < 2.5 * load.mean()  # 12 contigs over 4 / 7 files
+
+
+def test_grouped_verify_order_on_small_inputs(monkeypatch):
+    """the processing order of the verify pass (reads grouped by read-level minimizer) is normally used from 4096 reads on;
+    forced here on small, ragged and multi-segment inputs — results must not depend on it"""
+    monkeypatch.setenv("DISCO_ORDER_MIN_READS", "1")
+    for seed, n, lmin, lmax, cov in ((61, 700, 150, 150, 30.0), (67, 1500, 100, 250, 60.0), (71, 300, 400, 900, 20.0), (73, 65, 150, 150, 10.0)):
+        assert_parity(_gen(seed, n, lmin, cov, lmax), 40, f"order{seed}")

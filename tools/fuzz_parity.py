@@ -1,6 +1,7 @@
 """differential fuzzing: HIP path (C-ABI) vs the CPU oracle on random generator settings.
    python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1]"""
-import sys, time, traceback
+import os, sys, time, traceback
+os.environ.setdefault('DISCO_ORDER_MIN_READS', '1')  # the grouped verify order on every data set, however small
 sys.path.insert(0, '.')
 import numpy as np
 from disco_amd import readgen

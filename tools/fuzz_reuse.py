@@ -1,6 +1,7 @@
 """one context reused for many data sets of different sizes / lengths / parameters (buffers kept across passes must be resized or
 rebuilt correctly): every pass is compared with a fresh context.   python tools/fuzz_reuse.py [ITERATIONS=40] [SEED=1]"""
-import sys
+import os, sys
+os.environ.setdefault('DISCO_ORDER_MIN_READS', '1')  # the grouped verify order on every data set, however small
 sys.path.insert(0, '.')
 import numpy as np
 from disco_amd import buildgraph, readgen

@@ -1,6 +1,7 @@
 """differential fuzzing of the sharded flow: G simulated ranks (threads on one GPU, real engine and kernels) vs the unsharded pass.
    python tools/fuzz_sharded.py [ITERATIONS=30] [SEED=1]"""
-import sys, time, traceback
+import os, sys, time, traceback
+os.environ.setdefault('DISCO_ORDER_MIN_READS', '1')  # the grouped verify order on every data set, however small
 sys.path.insert(0, '.')
 import numpy as np
 from disco_amd import readgen
