@@ -89,11 +89,12 @@ ABI = [
     ("disco_set_global_dropped", C.c_int, [_P, C.c_uint64]),
     ("disco_fetch_edge_files", C.c_int64, [_P, C.c_uint32, _P, C.c_uint64]),
     ("disco_set_query_order", C.c_int, [_P, _P]),
+    ("disco_get_query_order", C.c_int, [_P, C.POINTER(_P)]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
 ]
 
-PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit")
+PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit", "order")
 
 
 def lib_path() -> str:
@@ -319,6 +320,12 @@ class BuildGraph:
         out = np.zeros(max(n, 1), dtype=np.uint16)
         self._chk(self.L.disco_fetch_edge_files(self._h, n_files, out.ctypes.data, n))
         return out[:n]
+
+    def get_query_order(self) -> int:
+        """device pointer of the processing order the last probe used (0 = file order)"""
+        out = _P()
+        self._chk(self.L.disco_get_query_order(self._h, C.byref(out)))
+        return out.value or 0
 
     def set_query_order(self, d_order_ptr: int):
         self._chk(self.L.disco_set_query_order(self._h, _P(d_order_ptr)))

@@ -214,15 +214,26 @@ __device__ __forceinline__ u64 mmer_canonical(const u64 *p, int S, int pos, int 
  * position), the m-mer's strand in bit 0. Minimizers are chosen by the order hash. m <= 23, so the canonical m-mer has at
  * most 46 bits: two full-rate 24-bit multiplies fold it into 32 bits and one 32-bit multiply mixes the result (the order
  * only has to be strand symmetric and unrelated to the base composition; bucket keys use the bijective disco_hash64). */
+/* lane l's value of x (l wave-uniform) */
+__device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, (int)l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), (int)l);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u32 order_hash32(u64 c)
+{
+    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24), 0x85EBCBu) + 0x7F4A7C15u;
+    h ^= h >> 15;
+    return h * 0x2C1B3C6Du;
+}
 template <bool NB = false>
 __device__ __forceinline__ u32 mmer_order(const u64 *p, int S, int pos, int m)
 {
     u32 strand;
     const u64 c = mmer_canonical<NB>(p, S, pos, m, strand);
-    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24), 0x85EBCBu) + 0x7F4A7C15u;
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    return (h & ~0x1FFu) | strand;
+    return (order_hash32(c) & ~0x1FFu) | strand;
 }
 
 /* 64-bit bucket key of the m-mer at pos (bijective mix of the canonical m-mer: distinct m-mers never share a key) */

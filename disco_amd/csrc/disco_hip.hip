@@ -49,7 +49,6 @@ static void parallel_for(u64 n, F f)
     for (auto &x : th) x.join();
 }
 
-#define ORDER_BUCKETS (1ull << 23) /* values of the 23-bit order hash */
 
 struct disco_ctx {
     int device = 0;
@@ -104,7 +103,7 @@ struct disco_ctx {
     bool order_external = false;
     u32 *d_ocnt = nullptr, *d_okey = nullptr, *d_oslot = nullptr;
     u64 *d_order_own = nullptr;
-    u64 okey_cap = 0, oslot_cap = 0, order_cap = 0;
+    u64 okey_cap = 0, oslot_cap = 0, order_cap = 0, ocnt_cap = 0;
     /* sharded flow, compact exchange: neighbour rows as 4-byte entries in a caller-owned gathered array */
     const u32 *d_nadj32 = nullptr;
     u64 *d_nref = nullptr;
@@ -356,11 +355,11 @@ static void free_graph_state(disco_ctx *c)
     c->start_cap = 0;
     dev_free(c, &c->d_nref, c->nref_cap);
     c->nref_cap = 0;
-    dev_free(c, &c->d_ocnt, ORDER_BUCKETS + 1);
+    dev_free(c, &c->d_ocnt, c->ocnt_cap);
     dev_free(c, &c->d_okey, c->okey_cap);
     dev_free(c, &c->d_oslot, c->oslot_cap);
     dev_free(c, &c->d_order_own, c->order_cap);
-    c->okey_cap = c->oslot_cap = c->order_cap = 0;
+    c->okey_cap = c->oslot_cap = c->order_cap = c->ocnt_cap = 0;
     if (!c->order_external) c->d_order = nullptr;
     c->d_nadj32 = nullptr;
     c->nbr32 = false;
@@ -715,18 +714,32 @@ int disco_probe(disco_ctx *c)
         if (!c->d_probe_rare) CHK(dev_alloc(c, &c->d_probe_rare, 1));
         HIPCHK(c, hipMemcpyAsync(c->d_probe_rare, &c->h_probe_rare, sizeof(ProbeRare), hipMemcpyHostToDevice, c->stream));
         a.rare = c->d_probe_rare;
-        /* grouping of the query range by read-level minimizer for the verify pass (DISCO_NO_ORDER=1: file order) */
+        /* grouping of the query range by read-level minimizer for the probe and verify passes (DISCO_NO_ORDER=1: file order) */
         const u64 order_min = getenv("DISCO_ORDER_MIN_READS") ? (u64)atoll(getenv("DISCO_ORDER_MIN_READS")) : 4096; /* tests: 1 */
         const bool own_order = !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= order_min && nq > 0;
-        a.okey = nullptr;
+        a.order = nullptr;
+        int order_bits = 16; /* buckets of the grouping: about one per read (a group has ~13 reads at 30x: few groups share a bucket) */
+        while (order_bits < 27 && (1ull << order_bits) < nq) ++order_bits;
+        const u64 order_buckets = 1ull << order_bits;
         if (own_order) {
-            if (!c->d_ocnt) CHK(dev_alloc(c, &c->d_ocnt, ORDER_BUCKETS + 1));
+            CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
             CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, nq));
             CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nq));
             CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, nq));
-            HIPCHK(c, hipMemsetAsync(c->d_okey, 0xFF, nq * sizeof(u32), c->stream));
-            a.okey = c->d_okey;
-        }
+            /* keys -> counts (+ slots) -> starts -> order */
+            const u32 oshift = 32u - (u32)order_bits;
+            ph_begin(c, DISCO_PH_ORDER);
+            hipLaunchKernelGGL(read_key_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, view(c), c->d_okey);
+            HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
+            hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, nq, oshift, c->d_ocnt, c->d_oslot);
+            CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, c->d_oslot, c->d_ocnt, oshift, c->q_lo, nq, c->d_order_own);
+            ph_end(c, DISCO_PH_ORDER);
+            HIPCHK(c, hipGetLastError());
+            c->d_order = c->d_order_own;
+        } else if (!c->order_external)
+            c->d_order = nullptr;
+        a.order = c->d_order;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {
@@ -754,14 +767,6 @@ int disco_probe(disco_ctx *c)
             va.hits = c->d_hits;
             va.row_start = c->d_row_start;
             va.row_cnt = c->d_row_cnt;
-            if (own_order) { /* keys -> counts (+ slots) -> starts -> order */
-                HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (ORDER_BUCKETS + 1) * sizeof(u32), c->stream));
-                hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, nq, c->d_ocnt, c->d_oslot);
-                CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, ORDER_BUCKETS + 1, c->d_ocnt, false, nullptr)));
-                hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, c->d_oslot, c->d_ocnt, c->q_lo, nq, c->d_order_own);
-                c->d_order = c->d_order_own;
-            } else if (!c->order_external)
-                c->d_order = nullptr;
             va.order = c->d_order;
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
@@ -1662,6 +1667,13 @@ int disco_set_query_order(disco_ctx *c, const void *d_order_u64)
     if (!c) return DISCO_E_ARG;
     c->d_order = (const u64 *)d_order_u64;
     c->order_external = d_order_u64 != nullptr;
+    return DISCO_OK;
+}
+
+int disco_get_query_order(disco_ctx *c, const void **d_order_u64)
+{
+    if (!c || !d_order_u64) return DISCO_E_ARG;
+    *d_order_u64 = c->d_order;
     return DISCO_OK;
 }
 

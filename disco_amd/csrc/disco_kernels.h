@@ -297,12 +297,11 @@ struct ProbeArgs {
     u64 *row_start; /* [n]                                            */
     u32 *row_cnt;   /* [n]                                            */
     const ProbeRare *rare;
-    /* processing order for the later passes (or null): reads are grouped by their read-level minimizer — the smallest order
-     * hash among all m-mers of the read, which this kernel computes anyway. Reads of one group contain the same genome m-mer,
-     * so they overlap each other and fetch the same candidate rows; verify_kernel walks the groups one after the other and
-     * finds those rows in the cache. okey[read - q_lo] = that hash (23 bits); the grouping itself (count, scan, scatter) is done
-     * by order_count_kernel / order_scatter_kernel. */
-    u32 *okey;
+    /* processing order of the query range (or null: ascending id): reads grouped by their read-level minimizer, see
+     * read_key_kernel. Reads of one group contain the same genome m-mer: they look up the same buckets here and fetch the
+     * same candidate rows in verify_kernel, which walks the same order (so it also finds the wave's candidate lists one after
+     * the other in the hit buffer). */
+    const u64 *order;
 };
 
 #ifndef PROBE_WAVES_PER_SIMD
@@ -337,14 +336,20 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
     u64 pre_w = 0;
     int pre_len = 0;
     u64 cbeg = 0, cend = 0;
+    u64 ord_chunk = 0; /* lane i: the read the chunk's item i stands for (WQ_CHUNK == 64) */
+    auto rid = [&](u64 it) { return readlane_u64(ord_chunk, (u32)(it - cbeg)); };
     while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
+    if (!BIG) {
+        const u64 i = min(cbeg + lane, cend - 1);
+        ord_chunk = a.order ? a.order[i] : a.v.q_lo + i;
+    }
     if (!BIG && LDSROW) {
-        const u64 A0 = a.v.q_lo + cbeg;
+        const u64 A0 = rid(cbeg);
         pre_len = a.v.len[A0];
         if ((int)lane < S) pre_w = a.v.reads[A0 * S + lane];
     }
     for (u64 it = cbeg; it < cend; it++) {
-        const u64 A = BIG ? a.rare->big_list[it] : a.v.q_lo + it;
+        const u64 A = BIG ? a.rare->big_list[it] : rid(it);
         const u64 *ga = a.v.reads + A * S;
         int LA;
         __syncthreads();
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
             if ((int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? pre_w : 0ull;
             const u64 itn = it + 1;
             if (itn < cend) {
-                const u64 An = a.v.q_lo + itn;
+                const u64 An = rid(itn);
                 pre_len = a.v.len[An];
                 if ((int)lane < S) pre_w = a.v.reads[An * S + lane];
             }
@@ -418,18 +423,12 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
             /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
              *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
             __syncthreads();
-            u32 hmin = 0xFFFFFFFFu;
             for (int q = (int)lane; q < np; q += 64) {
                 const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
-                hmin = min(hmin, o >> 9);
                 s_first[q] = 0xFFFFFFFFu;
                 s_strand[q] = (u8)(o & 1u);
                 s_k1[q] = (o & ~0x1FFu) | (u32)q;
                 s_k2[q] = (o & ~0x1FFu) | (511u - (u32)q);
-            }
-            if (!BIG && a.okey) { /* read-level minimizer (smallest order hash of the read; okey starts at ~0): see ProbeArgs */
-                for (int o = 32; o > 0; o >>= 1) hmin = min(hmin, (u32)__shfl_xor(hmin, o));
-                if (lane == 0) atomicMin(&a.okey[A - a.v.q_lo], hmin);
             }
             __syncthreads();
             /* 2. minimum over [q, q + P) for every q by doubling, P = largest power of two <= nf; in place, ascending
@@ -602,13 +601,6 @@ __device__ __forceinline__ u64 extract32_padded(const u64 *row, int pos)
     const int w = pos >> 5, sh = (pos & 31) * 2;
     const u64 a = row[w], b = row[w + 1];
     return (a << sh) | ((b >> 1) >> (63 - sh));
-}
-
-__device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
-{
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, (int)l);
-    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), (int)l);
-    return ((u64)hi << 32) | lo;
 }
 
 __device__ __forceinline__ u32 uniform_u32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
@@ -2161,17 +2153,54 @@ __global__ void uf_edge_file_kernel(const u64 *__restrict__ out_src, const u8 *_
 
 /* the query range grouped by read-level minimizer: count per hash value (the atomic hands every read its slot; the 32 MB of
  * counters stay in the L2 / Infinity Cache), exclusive scan, then order[start[hash] + slot] = read */
-__global__ void order_count_kernel(const u32 *__restrict__ okey, u64 nq, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
+/* ================================================================================================================
+ * processing order of the probe and verify passes. Reads are grouped by their READ-LEVEL MINIMIZER: the smallest order
+ * hash among all m-mers of the read. Two reads with the same key contain the same genome m-mer (up to hash collisions), so
+ * they overlap each other: a group is ~13 reads at 30x, laid over ~2 read lengths of genome, and its members look up the
+ * same index buckets and gather the same candidate rows. Walking the groups one after the other turns most of those
+ * random fetches into cache hits. The key keeps all 32 bits of the hash: the smallest of ~128 hashes lies in the lowest
+ * 1/128 of the range, so the 23 bits the minimizer order keeps would leave ~10^5 distinct keys and lump unrelated loci together.
+ * One thread per read, rolling forward / reverse-complement m-mer (m <= 23: 46 bits).
+ * The order changes no result: every consumer is order independent per read (rows are keyed by read id).
+ * ============================================================================================================== */
+__global__ void __launch_bounds__(256) read_key_kernel(DiscoView v, u32 *__restrict__ okey)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < nq; i += (u64)gridDim.x * blockDim.x) oslot[i] = atomicAdd(&cnt[okey[i] & 0x7FFFFFu], 1u);
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= v.q_hi - v.q_lo) return;
+    const u64 A = v.q_lo + i;
+    const int L = v.len[A], m = v.m;
+    const u64 *__restrict__ row = v.reads + A * v.S;
+    const u64 mask = (1ull << (2 * m)) - 1ull;
+    const int rsh = 2 * (m - 1);
+    u64 f = 0, r = 0;
+    u32 best = 0xFFFFFFFFu;
+    int pos = 0;
+    for (int w = 0; pos < L; ++w) {
+        u64 word = row[w];
+        const int nb = min(32, L - pos);
+        for (int j = 0; j < nb; ++j, ++pos) {
+            const u32 b = (u32)(word >> 62);
+            word <<= 2;
+            f = ((f << 2) | b) & mask;
+            r = (r >> 2) | ((u64)(3u - b) << rsh);
+            if (pos >= m - 1) best = min(best, order_hash32(f < r ? f : r));
+        }
+    }
+    okey[i] = best;
 }
 
-__global__ void order_scatter_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ oslot, const u32 *__restrict__ start, u64 lo, u64 nq,
+#define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift))
+__global__ void order_count_kernel(const u32 *__restrict__ okey, u64 nq, u32 shift, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) oslot[i] = atomicAdd(&cnt[ORDER_BUCKET(okey[i], shift)], 1u);
+}
+
+__global__ void order_scatter_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ oslot, const u32 *__restrict__ start, u32 shift, u64 lo, u64 nq,
                                      u64 *__restrict__ order)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < nq; i += (u64)gridDim.x * blockDim.x) order[(u64)start[okey[i] & 0x7FFFFFu] + oslot[i]] = lo + i;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) order[(u64)start[ORDER_BUCKET(okey[i], shift)] + oslot[i]] = lo + i;
 }
 
 /* how many items of [lo,hi) exceed a threshold: rows longer than ES_CAP (cnt = row_cnt) / nodes of degree above TR_CAP

@@ -221,6 +221,7 @@ enum {
     DISCO_PH_TWIN,         /* twin_check_kernel                                  */
     DISCO_PH_TRMARK,       /* transitive_mark_kernel<false>                      */
     DISCO_PH_EMIT,         /* emit mark + scan + emit fill                       */
+    DISCO_PH_ORDER,        /* read_key_kernel + count + scan + scatter (grouped processing order) */
     DISCO_PH_COUNT
 };
 int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
@@ -228,6 +229,8 @@ int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
  * range; caller-owned, must stay valid), or NULL for file order. Results do not depend on it; reads that overlap each other
  * processed back to back find their candidates' rows in the cache. */
 int disco_set_query_order(disco_ctx *ctx, const void *d_order_u64);
+/* the order the last disco_probe used for its verify pass (device pointer to q_hi - q_lo read ids), NULL = file order */
+int disco_get_query_order(disco_ctx *ctx, const void **d_order_u64);
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* attainable HBM bandwidth on this device (SURVEY.md §8d "Roofline that bounds the path": nominal AND measured): a
