@@ -260,8 +260,9 @@ __host__ __device__ __forceinline__ int disco_minimizer_len(int k)
  *   - several positions tie (the same canonical m-mer twice, or an order-hash collision; rare): rev = 1 iff the reverse
  *     complement of the whole k-mer is the smaller integer (a palindrome has rev = 0, like BG/HashTable.cpp:539-549
  *     tries the forward match first), and the LEFTMOST tied position in the canonical orientation is taken.
- * Returns the chosen forward offset. Index and probe both call this, so a k-mer and its reverse complement always agree on
- * the minimizer and on its offset t = rev ? nf-1-f : f inside the canonical orientation. */
+ * Returns the chosen forward offset. This serial form STATES the rule; index_count_kernel (rolling pass, two running minima per
+ * end k-mer) and probe_kernel (range-minimum tables) each evaluate it their own way, so a k-mer and its reverse complement always
+ * agree on the minimizer and on its offset t = rev ? nf-1-f : f inside the canonical orientation. */
 template <bool NB = false, typename F>
 __device__ __forceinline__ int window_minimizer(F h, int nf, const u64 *p, int S, int j, int k, u32 &rev)
 {

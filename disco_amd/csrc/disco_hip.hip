@@ -646,7 +646,8 @@ int disco_build_index(disco_ctx *c)
     /* {key, record} of both end k-mers of every read, computed once by the count pass and re-read by the fill pass */
     CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
     ulonglong2 *rec = c->d_rec;
-    if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, v, c->d_bkt, rec);
+    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n)); /* grouping keys of all reads (disco_probe orders its query range by them) */
+    if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey);
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt, T + 1, c->d_bkt, false, nullptr)));
     if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
@@ -723,17 +724,15 @@ int disco_probe(disco_ctx *c)
         const u64 order_buckets = 1ull << order_bits;
         if (own_order) {
             CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
-            CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, nq));
             CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nq));
             CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, nq));
             /* keys -> counts (+ slots) -> starts -> order */
             const u32 oshift = 32u - (u32)order_bits;
             ph_begin(c, DISCO_PH_ORDER);
-            hipLaunchKernelGGL(read_key_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, view(c), c->d_okey);
             HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
-            hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, nq, oshift, c->d_ocnt, c->d_oslot);
+            hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, nq, oshift, c->d_ocnt, c->d_oslot);
             CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
-            hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey, c->d_oslot, c->d_ocnt, oshift, c->q_lo, nq, c->d_order_own);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, c->d_oslot, c->d_ocnt, oshift, c->q_lo, nq, c->d_order_own);
             ph_end(c, DISCO_PH_ORDER);
             HIPCHK(c, hipGetLastError());
             c->d_order = c->d_order_own;

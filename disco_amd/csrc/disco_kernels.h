@@ -142,32 +142,82 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * bkt has T+1 slots (T <= 2^32); counts go to bkt[b] (the counting atomic hands each record its slot inside the bucket);
  * after the in-place exclusive scan of bkt[0..T] bucket b is [bkt[b], bkt[b+1]) and the fill is a plain scatter.
  * ============================================================================================================== */
-/* index record of the end k-mer at base pos of read row p: key = minimizer key, t = minimizer offset in canonical orientation */
-__device__ __forceinline__ u64 end_kmer_record(const u64 *__restrict__ p, int S, int pos, int k, int m, u32 &t, u32 &rev)
-{
-    const int nf = k - m + 1;
-    const int f = window_minimizer([&](int x) { return mmer_order(p, S, pos + x, m); }, nf, p, S, pos, k, rev);
-    t = rev ? (u32)(nf - 1 - f) : (u32)f;
-    return mmer_key(p, S, pos + f, m);
-}
-
-__global__ void index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec)
+/* One thread per read, ONE rolling pass over the read's m-mers (forward and reverse-complement m-mer updated per base,
+ * m <= 23: 46 bits; every row word is loaded once). The first nf m-mers are the prefix k-mer's window, the last nf the suffix
+ * k-mer's: their minimizers come out of the pass with window_minimizer's rule (two running minima per window; the rare tie
+ * goes through kmer_is_rev as there). The same pass yields the read's grouping key for the probe / verify order:
+ * okey[i] = smallest 32-bit order hash among ALL m-mers of the read (see "processing order" below).
+ * (The previous version called the random-access mmer_order 34 times per read: 33 L2 requests per read, 10.2 ms at 50 M reads,
+ * plus a separate 4.2 ms pass for the keys.) */
+__global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey)
 {
     /* rec[2i], rec[2i+1] = {bucket << 32 | slot inside the bucket, record} of the prefix / suffix k-mer of read i: the slot is
      * what the counting atomic returns, so the fill pass needs no second round of atomics */
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < v.n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 *p = v.reads + i * v.S;
-        int L = v.len[i];
-        u32 tp, rp, ts, rs;
-        u64 kp = end_kmer_record(p, v.S, 0, v.k, v.m, tp, rp);
-        u64 ks = end_kmer_record(p, v.S, L - v.k, v.k, v.m, ts, rs);
-        const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
-        const u32 sp = atomicAdd(&bkt[bp], 1u);
-        const u32 ss = atomicAdd(&bkt[bs], 1u);
-        rec[2 * i] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
-        rec[2 * i + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= v.n) return;
+    const u64 *__restrict__ p = v.reads + i * v.S;
+    const int L = v.len[i], k = v.k, m = v.m, nf = k - m + 1;
+    const int nmm = L - m + 1; /* m-mer positions (L >= k: validate_len_kernel) */
+    const int sfx0 = nmm - nf; /* = L - k: first m-mer of the suffix k-mer */
+    const u64 mask = (1ull << (2 * m)) - 1ull;
+    const int rsh = 2 * (m - 1);
+    u64 f = 0, r = 0, word = 0;
+    int pos = 0; /* bases consumed */
+    auto next = [&]() {
+        if ((pos & 31) == 0) word = p[pos >> 5];
+        const u32 b = (u32)(word >> 62);
+        word <<= 2;
+        ++pos;
+        f = ((f << 2) | b) & mask;
+        r = (r >> 2) | ((u64)(3u - b) << rsh);
+    };
+    u32 best = 0xFFFFFFFFu;
+    auto order_word = [&]() { /* order word of the next m-mer (mmer_order's value) */
+        next();
+        const bool st = r < f;
+        const u32 h = order_hash32(st ? r : f);
+        best = min(best, h);
+        return (h & ~0x1FFu) | (u32)st;
+    };
+    for (int q = 0; q < m - 1; ++q) next();
+    u32 k1p = 0xFFFFFFFFu, k2p = 0xFFFFFFFFu, k1s = 0xFFFFFFFFu, k2s = 0xFFFFFFFFu;
+    int q = 0;
+    for (; q < nf; ++q) { /* prefix window (and the suffix window where the two overlap: L < k + nf) */
+        const u32 o = order_word();
+        k1p = min(k1p, o + ((u32)q << 1));
+        k2p = min(k2p, o + ((u32)(63 - q) << 1));
+        if (q >= sfx0) {
+            k1s = min(k1s, o + ((u32)(q - sfx0) << 1));
+            k2s = min(k2s, o + ((u32)(63 - (q - sfx0)) << 1));
+        }
     }
+    for (; q < sfx0; ++q) order_word();
+    for (; q < nmm; ++q) { /* suffix window */
+        const u32 o = order_word();
+        k1s = min(k1s, o + ((u32)(q - sfx0) << 1));
+        k2s = min(k2s, o + ((u32)(63 - (q - sfx0)) << 1));
+    }
+    if (okey) okey[i] = best;
+    auto resolve = [&](u32 k1, u32 k2, int j0, u32 &t, u32 &rev) {
+        const int ffirst = (int)((k1 >> 1) & 63u), flast = 63 - (int)((k2 >> 1) & 63u);
+        int fsel = ffirst;
+        if (ffirst == flast)
+            rev = k1 & 1u;
+        else {
+            rev = kmer_is_rev(p, v.S, j0, k);
+            fsel = rev ? flast : ffirst;
+        }
+        t = rev ? (u32)(nf - 1 - fsel) : (u32)fsel;
+        return mmer_key(p, v.S, j0 + fsel, m);
+    };
+    u32 tp, rp, ts, rs;
+    const u64 kp = resolve(k1p, k2p, 0, tp, rp);
+    const u64 ks = resolve(k1s, k2s, sfx0, ts, rs);
+    const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
+    const u32 sp = atomicAdd(&bkt[bp], 1u);
+    const u32 ss = atomicAdd(&bkt[bs], 1u);
+    rec[2 * i] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
+    rec[2 * i + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
 }
 
 /* bkt = exclusive scan of the counts: record goes to bkt[bucket] + slot */
@@ -298,7 +348,7 @@ struct ProbeArgs {
     u32 *row_cnt;   /* [n]                                            */
     const ProbeRare *rare;
     /* processing order of the query range (or null: ascending id): reads grouped by their read-level minimizer, see
-     * read_key_kernel. Reads of one group contain the same genome m-mer: they look up the same buckets here and fetch the
+     * "processing order" below. Reads of one group contain the same genome m-mer: they look up the same buckets here and fetch the
      * same candidate rows in verify_kernel, which walks the same order (so it also finds the wave's candidate lists one after
      * the other in the hit buffer). */
     const u64 *order;
@@ -2160,35 +2210,9 @@ __global__ void uf_edge_file_kernel(const u64 *__restrict__ out_src, const u8 *_
  * same index buckets and gather the same candidate rows. Walking the groups one after the other turns most of those
  * random fetches into cache hits. The key keeps all 32 bits of the hash: the smallest of ~128 hashes lies in the lowest
  * 1/128 of the range, so the 23 bits the minimizer order keeps would leave ~10^5 distinct keys and lump unrelated loci together.
- * One thread per read, rolling forward / reverse-complement m-mer (m <= 23: 46 bits).
+ * The keys come out of index_count_kernel's rolling pass over every read (okey[read]).
  * The order changes no result: every consumer is order independent per read (rows are keyed by read id).
  * ============================================================================================================== */
-__global__ void __launch_bounds__(256) read_key_kernel(DiscoView v, u32 *__restrict__ okey)
-{
-    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (i >= v.q_hi - v.q_lo) return;
-    const u64 A = v.q_lo + i;
-    const int L = v.len[A], m = v.m;
-    const u64 *__restrict__ row = v.reads + A * v.S;
-    const u64 mask = (1ull << (2 * m)) - 1ull;
-    const int rsh = 2 * (m - 1);
-    u64 f = 0, r = 0;
-    u32 best = 0xFFFFFFFFu;
-    int pos = 0;
-    for (int w = 0; pos < L; ++w) {
-        u64 word = row[w];
-        const int nb = min(32, L - pos);
-        for (int j = 0; j < nb; ++j, ++pos) {
-            const u32 b = (u32)(word >> 62);
-            word <<= 2;
-            f = ((f << 2) | b) & mask;
-            r = (r >> 2) | ((u64)(3u - b) << rsh);
-            if (pos >= m - 1) best = min(best, order_hash32(f < r ? f : r));
-        }
-    }
-    okey[i] = best;
-}
-
 #define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift))
 __global__ void order_count_kernel(const u32 *__restrict__ okey, u64 nq, u32 shift, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
 {

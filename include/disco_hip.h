@@ -221,7 +221,7 @@ enum {
     DISCO_PH_TWIN,         /* twin_check_kernel                                  */
     DISCO_PH_TRMARK,       /* transitive_mark_kernel<false>                      */
     DISCO_PH_EMIT,         /* emit mark + scan + emit fill                       */
-    DISCO_PH_ORDER,        /* read_key_kernel + count + scan + scatter (grouped processing order) */
+    DISCO_PH_ORDER,        /* count + scan + scatter of the grouped processing order (the keys come from the index pass) */
     DISCO_PH_COUNT
 };
 int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
