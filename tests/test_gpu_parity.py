@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from disco_amd import readgen
+from disco_amd import buildgraph, readgen
 from tests.util import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -176,3 +176,24 @@ def test_grouped_verify_order_on_small_inputs(monkeypatch):
     monkeypatch.setenv("DISCO_ORDER_MIN_READS", "1")
     for seed, n, lmin, lmax, cov in ((61, 700, 150, 150, 30.0), (67, 1500, 100, 250, 60.0), (71, 300, 400, 900, 20.0), (73, 65, 150, 150, 10.0)):
         assert_parity(_gen(seed, n, lmin, cov, lmax), 40, f"order{seed}")
+
+
+def test_processing_order_is_a_grouped_permutation():
+    """disco_get_query_order: the order the probe / verify passes walk is a permutation of the query range, and it keeps reads
+    from the same genome locus together (generator coordinates: most neighbours in the order overlap on the genome)"""
+    import torch
+    n = 60_000
+    spec = readgen.GenSpec.coverage(97, n, 150, 30.0, n_contigs=3)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        ptr = g.get_query_order()
+        assert ptr, "grouping is on from 4096 reads"
+        t = torch.empty(n, dtype=torch.int64, device="cuda")
+        g.memcpy_d2d(t.data_ptr(), ptr, n * 8)
+        g.synchronize()
+        order = t.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(n))
+    gpos, _, _ = readgen.read_locations(spec)
+    d = np.abs(np.diff(gpos[order].astype(np.int64)))
+    assert (d < 150).mean() > 0.8  # ~13 reads per group: 1 boundary in 13 neighbours (file order: 0.0002)
