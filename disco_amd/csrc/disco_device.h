@@ -99,6 +99,33 @@ __device__ __forceinline__ u64 lane_mask_lt()
     return l ? (~0ull >> (64 - l)) : 0ull;
 }
 
+/* inclusive minimum scans inside the 16-lane rows of a wavefront (DPP row shifts; a lane without a source keeps ~0):
+ * row_prefix_min: lane i gets the minimum over its row's lanes <= i; row_suffix_min: over its row's lanes >= i */
+__device__ __forceinline__ u32 row_prefix_min(u32 x)
+{
+    u32 y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    x = x < y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xF, 0xF, false);
+    x = x < y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xF, 0xF, false);
+    x = x < y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xF, 0xF, false);
+    return x < y ? x : y;
+}
+__device__ __forceinline__ u32 row_suffix_min(u32 x)
+{
+    u32 y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x101, 0xF, 0xF, false); /* row_shl:1 */
+    x = x < y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x102, 0xF, 0xF, false);
+    x = x < y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x104, 0xF, 0xF, false);
+    x = x < y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(-1, (int)x, 0x108, 0xF, 0xF, false);
+    return x < y ? x : y;
+}
+
 /* ascending bitonic sort of one u64 per lane across the wavefront (21 compare-exchange steps) */
 __device__ __forceinline__ u64 wave_bitonic_sort(u64 x, u32 lane)
 {

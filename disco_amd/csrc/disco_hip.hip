@@ -671,7 +671,20 @@ int disco_probe(disco_ctx *c)
     if (c->n) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, DISCO_NOKEY);
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
     const bool ldsrow = c->S <= PROBE_ACAP;
-    const int grid = ldsrow ? wq_grid(c, probe_kernel<false, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<false, false>, nq, "DISCO_PROBE_WAVES");
+    const bool row17 = c->k - view(c).m == 16 && !getenv("DISCO_NO_ROW17"); /* window = 17 m-mers: DPP row-scan variant */
+    const int grid = row17 ? (ldsrow ? wq_grid(c, probe_kernel<false, true, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<false, false, true>, nq, "DISCO_PROBE_WAVES"))
+                           : (ldsrow ? wq_grid(c, probe_kernel<false, true, false>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<false, false, false>, nq, "DISCO_PROBE_WAVES"));
+    auto launch_probe = [&](const ProbeArgs &a, bool big, int g) {
+#define DISCO_PROBE_LAUNCH(B, L, R) hipLaunchKernelGGL((probe_kernel<B, L, R>), dim3(g), dim3(64), 0, c->stream, a)
+        if (big) {
+            if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(true, true, true); else DISCO_PROBE_LAUNCH(true, true, false); }
+            else { if (row17) DISCO_PROBE_LAUNCH(true, false, true); else DISCO_PROBE_LAUNCH(true, false, false); }
+        } else {
+            if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(false, true, true); else DISCO_PROBE_LAUNCH(false, true, false); }
+            else { if (row17) DISCO_PROBE_LAUNCH(false, false, true); else DISCO_PROBE_LAUNCH(false, false, false); }
+        }
+#undef DISCO_PROBE_LAUNCH
+    };
     u64 want_hits = nq * 64 + (u64)grid * PROBE_CHUNK + (1u << 16);
     u32 want_big = (u32)std::min<u64>(nq, nq / 64 + 1024);
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -742,8 +755,7 @@ int disco_probe(disco_ctx *c)
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {
-            if (ldsrow) hipLaunchKernelGGL((probe_kernel<false, true>), dim3(grid), dim3(64), 0, c->stream, a);
-            else hipLaunchKernelGGL((probe_kernel<false, false>), dim3(grid), dim3(64), 0, c->stream, a);
+            launch_probe(a, false, grid);
         }
         ph_end(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipGetLastError());
@@ -753,8 +765,7 @@ int disco_probe(disco_ctx *c)
         if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
             int g2 = wave_grid(c, (n_big + WQ_CHUNK - 1) / WQ_CHUNK, 8);
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-            if (ldsrow) hipLaunchKernelGGL((probe_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
-            else hipLaunchKernelGGL((probe_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
+            launch_probe(a, true, g2);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));
         }

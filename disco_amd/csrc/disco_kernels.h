@@ -357,8 +357,10 @@ struct ProbeArgs {
 #ifndef PROBE_WAVES_PER_SIMD
 #define PROBE_WAVES_PER_SIMD 7
 #endif
-template <bool BIG, bool LDSROW>
-__global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
+/* ROW17: k - m = 16, the window minimum comes from DPP row scans (below); that variant keeps more values in registers and
+ * is built for one wave per SIMD fewer (at 7 it spilled 14 registers and ran 48 instead of 40 ms) */
+template <bool BIG, bool LDSROW, bool ROW17>
+__global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
 {
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
      * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
@@ -470,46 +472,94 @@ __global__ void __launch_bounds__(64, PROBE_WAVES_PER_SIMD) probe_kernel(ProbeAr
         for (int w0 = 0; w0 < npos; w0 += PROBE_SEGW) { /* segments of PROBE_SEGW windows (one for reads up to 256+k bp) */
             const int nw = min(PROBE_SEGW, npos - w0);
             const int np = nw + nf - 1; /* m-mer positions the segment's windows cover */
-            /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
-             *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
-            __syncthreads();
-            for (int q = (int)lane; q < np; q += 64) {
-                const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
-                s_first[q] = 0xFFFFFFFFu;
-                s_strand[q] = (u8)(o & 1u);
-                s_k1[q] = (o & ~0x1FFu) | (u32)q;
-                s_k2[q] = (o & ~0x1FFu) | (511u - (u32)q);
-            }
-            __syncthreads();
-            /* 2. minimum over [q, q + P) for every q by doubling, P = largest power of two <= nf; in place, ascending
-             *    passes (a pass reads only positions it has not written: d <= 32 < 64). Entries whose range leaves the
-             *    segment are never used by a window. Then every window w takes min(T[w], T[w + nf - P]) and so has its
-             *    minimizer occurrence and canonical strand (window_minimizer's rule, disco_device.h). */
-            int P = 1;
-            for (; 2 * P <= nf; P <<= 1)
-                for (int q0 = 0; q0 < np; q0 += 64) {
-                    const int q = min(q0 + (int)lane, np - 1);
-                    const u32 a1 = s_k1[q], b1 = s_k1[q + P], a2 = s_k2[q], b2 = s_k2[q + P];
-                    __syncthreads();
-                    s_k1[q] = a1 < b1 ? a1 : b1;
-                    s_k2[q] = a2 < b2 ? a2 : b2;
+            /* every window w: p1 / p2 = leftmost / rightmost position of the smallest order hash among its m-mers -> its
+             * minimizer occurrence and canonical strand (window_minimizer's rule, disco_device.h) */
+            auto choose = [&](int w, u32 m1, u32 m2) {
+                const u32 p1 = m1 & 511u, p2 = 511u - (m2 & 511u);
+                u32 rev_w, prel = p1;
+                if (p1 == p2)
+                    rev_w = s_strand[p1];
+                else { /* the smallest hash occurs more than once in the window */
+                    rev_w = kmer_is_rev<LDSROW>(pa, S, w0 + w, k);
+                    prel = rev_w ? p2 : p1;
                 }
+                s_wp[w] = (u16)(prel | (rev_w << 15));
+                atomicMin(&s_first[prel], (u32)w);
+            };
             __syncthreads();
-            for (int ws = 0; ws < nw; ws += 64) {
-                const int w = ws + (int)lane;
-                if (w < nw) {
-                    const int e = nf - P;
-                    const u32 a1 = s_k1[w], b1 = s_k1[w + e], a2 = s_k2[w], b2 = s_k2[w + e];
-                    const u32 p1 = (a1 < b1 ? a1 : b1) & 511u, p2 = 511u - ((a2 < b2 ? a2 : b2) & 511u);
-                    u32 rev_w, prel = p1;
-                    if (p1 == p2)
-                        rev_w = s_strand[p1];
-                    else { /* the smallest hash occurs more than once in the window */
-                        rev_w = kmer_is_rev<LDSROW>(pa, S, w0 + w, k);
-                        prel = rev_w ? p2 : p1;
+            if (ROW17) {
+                /* k - m = 16 (min-overlap 40): a window is 17 positions = the tail of one 16-lane row plus the head of the next
+                 * up to the same lane, so its minimum is min(suffix-min of the row at w, prefix-min of the next row at w + 16):
+                 * two 4-step DPP row scans per table and register instead of four doubling passes through LDS.
+                 * key1 = hash | position (smallest hash, then LEFTMOST), key2 = hash | 511 - position (then RIGHTMOST). */
+                u32 h[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const int q = (int)lane + 64 * r;
+                    h[r] = 0xFFFFFFFFu;
+                    if (q < np) { /* np <= 144; the third pass is empty for reads up to 150 bp */
+                        const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
+                        s_first[q] = 0xFFFFFFFFu;
+                        s_strand[q] = (u8)(o & 1u);
+                        h[r] = o & ~0x1FFu;
                     }
-                    s_wp[w] = (u16)(prel | (rev_w << 15));
-                    atomicMin(&s_first[prel], (u32)w);
+                }
+                u32 m1[2], m2[2];
+                const u32 src = (lane + 16u) & 63u;
+#pragma unroll
+                for (int t = 0; t < 2; t++) { /* table 1, table 2 */
+                    u32 pre[3], suf[2];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const u32 q = lane + 64u * r;
+                        const u32 key = h[r] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (h[r] | (t ? 511u - q : q));
+                        pre[r] = row_prefix_min(key);
+                        if (r < 2) suf[r] = row_suffix_min(key);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const u32 ya = (u32)__shfl((int)pre[r], (int)src), yb = (u32)__shfl((int)pre[r + 1], (int)src);
+                        const u32 y = lane < 48u ? ya : yb;
+                        (t ? m2 : m1)[r] = suf[r] < y ? suf[r] : y;
+                    }
+                }
+                __syncthreads(); /* s_first, s_strand */
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int w = (int)lane + 64 * r;
+                    if (w < nw) choose(w, m1[r], m2[r]);
+                }
+            } else {
+                /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
+                 *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
+                for (int q = (int)lane; q < np; q += 64) {
+                    const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
+                    s_first[q] = 0xFFFFFFFFu;
+                    s_strand[q] = (u8)(o & 1u);
+                    s_k1[q] = (o & ~0x1FFu) | (u32)q;
+                    s_k2[q] = (o & ~0x1FFu) | (511u - (u32)q);
+                }
+                __syncthreads();
+                /* 2. minimum over [q, q + P) for every q by doubling, P = largest power of two <= nf; in place, ascending
+                 *    passes (a pass reads only positions it has not written: d <= 32 < 64). Entries whose range leaves the
+                 *    segment are never used by a window. Then every window w takes min(T[w], T[w + nf - P]). */
+                int P = 1;
+                for (; 2 * P <= nf; P <<= 1)
+                    for (int q0 = 0; q0 < np; q0 += 64) {
+                        const int q = min(q0 + (int)lane, np - 1);
+                        const u32 a1 = s_k1[q], b1 = s_k1[q + P], a2 = s_k2[q], b2 = s_k2[q + P];
+                        __syncthreads();
+                        s_k1[q] = a1 < b1 ? a1 : b1;
+                        s_k2[q] = a2 < b2 ? a2 : b2;
+                    }
+                __syncthreads();
+                for (int ws = 0; ws < nw; ws += 64) {
+                    const int w = ws + (int)lane;
+                    if (w < nw) {
+                        const int e = nf - P;
+                        const u32 a1 = s_k1[w], b1 = s_k1[w + e], a2 = s_k2[w], b2 = s_k2[w + e];
+                        choose(w, a1 < b1 ? a1 : b1, a2 < b2 ? a2 : b2);
+                    }
                 }
             }
             __syncthreads();

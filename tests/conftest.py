@@ -19,3 +19,16 @@ def oracle():
 
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first(request):
+    """tests that hand device pointers between torch and the library (sharded flow, processing order) need torch's HIP runtime
+    initialised BEFORE libdisco_hip.so opens the device — afterwards torch reports "No HIP GPUs are available". Done once per
+    session whenever GPU tests are selected; a no-op on the CPU suite."""
+    if any(item.get_closest_marker("gpu") for item in request.session.items):
+        import torch
+
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    yield
