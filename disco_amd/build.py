@@ -34,12 +34,39 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def vgpr_spills(remarks: str) -> dict:
+    """kernel -> spilled vector registers, from hipcc's -Rpass-analysis=kernel-resource-usage remarks"""
+    out, name = {}, None
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[")[0].strip()
+        elif "VGPRs Spill:" in line and name:
+            n = int(line.split("VGPRs Spill:")[1].split("[")[0])
+            if n:
+                out[name] = n
+    return out
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """The wave-per-read kernels read values out of lanes that are inactive where the value was last written (v_readlane of
+    the chunk registers, DPP row scans). A vector register that is spilled and reloaded under a partial exec mask loses exactly
+    those lanes, so a spilling build computes WRONG graphs (measured: verify_kernel<5> forced to 6 waves per SIMD spilled 16
+    registers and returned 46.1 M instead of 45.3 M edges). The build therefore fails when any kernel spills vector registers
+    (DISCO_ALLOW_SPILLS=1 to experiment)."""
     if force or _stale(LIB, HIP_DEPS):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB] + HIP_SOURCES
+        tmp = LIB + ".tmp"
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Rpass-analysis=kernel-resource-usage",
+               "-o", tmp] + HIP_SOURCES
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis" not in l)[-4000:])
+        spills = vgpr_spills(r.stderr)
+        if spills and not os.environ.get("DISCO_ALLOW_SPILLS"):
+            os.unlink(tmp)
+            raise RuntimeError(f"kernels spill vector registers (cross-lane reads would return garbage): {spills}")
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -87,3 +87,19 @@ int main(void)
                            "-L", libdir, "-ldisco_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 0 and out.stdout.startswith("abi "), (out.returncode, out.stdout)
+
+
+def test_build_rejects_vector_register_spills():
+    """the kernels read lanes that are inactive where a value was written; a spilled vector register loses them, so
+    disco_amd/build.py refuses a build whose resource remarks report VGPR spills (parser check; the shipped build has none)"""
+    from disco_amd import build
+
+    remarks = "\n".join([
+        "x.h:1:1: remark: Function Name: _Z13verify_kernelILi5EEv10VerifyArgs [-Rpass-analysis=kernel-resource-usage]",
+        "x.h:1:1: remark:     VGPRs: 80 [-Rpass-analysis=kernel-resource-usage]",
+        "x.h:1:1: remark:     SGPRs Spill: 12 [-Rpass-analysis=kernel-resource-usage]",
+        "x.h:1:1: remark:     VGPRs Spill: 16 [-Rpass-analysis=kernel-resource-usage]",
+        "x.h:1:1: remark: Function Name: _Z12probe_kernelILb0ELb1ELb1EEv9ProbeArgs [-Rpass-analysis=kernel-resource-usage]",
+        "x.h:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]",
+    ])
+    assert build.vgpr_spills(remarks) == {"_Z13verify_kernelILi5EEv10VerifyArgs": 16}
