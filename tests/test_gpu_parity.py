@@ -197,3 +197,15 @@ def test_processing_order_is_a_grouped_permutation():
     gpos, _, _ = readgen.read_locations(spec)
     d = np.abs(np.diff(gpos[order].astype(np.int64)))
     assert (d < 150).mean() > 0.8  # ~13 reads per group: 1 boundary in 13 neighbours (file order: 0.0002)
+
+
+def test_probe_window_minimum_variants_agree(monkeypatch):
+    """min-overlap 40 makes a window 17 m-mers and selects the DPP row-scan variant of probe_kernel; DISCO_NO_ROW17=1 forces the
+    LDS range-minimum tables on the same data. Both must match the oracle (single- and multi-segment reads, > 128 windows)."""
+    monkeypatch.setenv("DISCO_ORDER_MIN_READS", "1")
+    cases = ((101, 900, 150, 150, 30.0), (103, 500, 100, 400, 40.0), (107, 200, 600, 1100, 15.0))
+    for seed, n, lmin, lmax, cov in cases:
+        assert_parity(_gen(seed, n, lmin, cov, lmax), 40, f"row17-{seed}")
+    monkeypatch.setenv("DISCO_NO_ROW17", "1")
+    for seed, n, lmin, lmax, cov in cases:
+        assert_parity(_gen(seed, n, lmin, cov, lmax), 40, f"lds-{seed}")
