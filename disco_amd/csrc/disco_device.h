@@ -280,45 +280,20 @@ __host__ __device__ __forceinline__ int disco_minimizer_len(int k)
     return m < 1 ? 1 : m;
 }
 
-/* Minimizer of the k-mer window at base j from the order hashes h(0..nf-1) of its m-mers (forward offsets).
- * The window's CANONICAL ORIENTATION and the chosen occurrence are defined together, strand-symmetrically:
- *   - unique smallest order hash (25 bits): that m-mer is the minimizer; the window is "reversed" (rev = 1) iff the
+/* THE WINDOW-MINIMIZER RULE ("window_minimizer's rule" elsewhere). For the k-mer window at base j with the order words
+ * h(0..nf-1) of its m-mers (forward offsets), the window's CANONICAL ORIENTATION and the chosen occurrence are defined
+ * together, strand-symmetrically:
+ *   - unique smallest order hash (23 bits): that m-mer is the minimizer; the window is "reversed" (rev = 1) iff the
  *     m-mer sits on its non-canonical strand. (A k-mer and its reverse complement contain the same physical m-mer on opposite strands.)
  *   - several positions tie (the same canonical m-mer twice, or an order-hash collision; rare): rev = 1 iff the reverse
- *     complement of the whole k-mer is the smaller integer (a palindrome has rev = 0, like BG/HashTable.cpp:539-549
- *     tries the forward match first), and the LEFTMOST tied position in the canonical orientation is taken.
- * Returns the chosen forward offset. This serial form STATES the rule; index_count_kernel (rolling pass, two running minima per
- * end k-mer) and probe_kernel (range-minimum tables) each evaluate it their own way, so a k-mer and its reverse complement always
- * agree on the minimizer and on its offset t = rev ? nf-1-f : f inside the canonical orientation. */
-template <bool NB = false, typename F>
-__device__ __forceinline__ int window_minimizer(F h, int nf, const u64 *p, int S, int j, int k, u32 &rev)
-{
-    /* two running minima over keys  order hash | offset << 1 | strand : k1 carries the offset f (smallest hash, then
-     * LEFTMOST position), k2 carries 63 - f (smallest hash, then RIGHTMOST position). Branch-free, eight order words
-     * at a time. nf <= 64. (The probe computes the same choice for all windows of a read at once with a range-minimum
-     * table, probe_kernel step 2; this serial form serves the two end k-mers of the index.) */
-    u32 k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-    for (int f0 = 0; f0 < nf; f0 += 8) {
-        u32 x[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = h(f0 + i < nf ? f0 + i : nf - 1);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int f = f0 + i;
-            const u32 a = (f < nf) ? x[i] + ((u32)f << 1) : 0xFFFFFFFFu;
-            const u32 b = (f < nf) ? x[i] + ((u32)(63 - f) << 1) : 0xFFFFFFFFu;
-            k1 = a < k1 ? a : k1;
-            k2 = b < k2 ? b : k2;
-        }
-    }
-    const int ffirst = (int)((k1 >> 1) & 63u), flast = 63 - (int)((k2 >> 1) & 63u);
-    if (ffirst == flast) {
-        rev = k1 & 1u;
-        return ffirst;
-    }
-    rev = kmer_is_rev<NB>(p, S, j, k);
-    return rev ? flast : ffirst;
-}
+ *     complement of the whole k-mer is the smaller integer (kmer_is_rev; a palindrome has rev = 0, like BG/HashTable.cpp:539-549
+ *     tries the forward match first), and the LEFTMOST tied position in the canonical orientation is taken (leftmost forward
+ *     offset when rev = 0, rightmost when rev = 1).
+ * A record stores the offset t = rev ? nf-1-f : f of the chosen forward offset f inside the canonical orientation, so a k-mer
+ * and its reverse complement always agree on minimizer and offset. Two evaluations exist, both through two running minima
+ * over keys (hash | leftmost-first) and (hash | rightmost-first), whose agreement means "unique":
+ *   index_count_kernel — serial, over the first / last nf m-mers of its rolling pass (the two end k-mers of a read);
+ *   probe_kernel       — all windows of a read at once (DPP row scans or range-minimum tables in LDS). */
 
 /* A[a0 .. a0+m) == s2[b0 .. b0+m) where s2 = B (rev = 0) or revcomp(B) (rev = 1); LB = length of B */
 template <bool NB = false>
