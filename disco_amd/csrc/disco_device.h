@@ -126,6 +126,22 @@ __device__ __forceinline__ u32 row_suffix_min(u32 x)
     return x < y ? x : y;
 }
 
+/* x of lane (lane ^ j), j a compile-time power of two (the sorts below unroll completely): strides 1 and 2 are DPP quad
+ * permutes, 8 is a rotation inside the 16-lane row — register-to-register moves with a few cycles of latency where
+ * ds_bpermute goes through the LDS pipe; a bitonic network is one long dependency chain, so the latency is what counts.
+ * (Strides 4, 16 and 32 can be had without LDS too — two bank-masked row rotations, v_permlane16/32_swap plus a row-masked
+ * move; verified on the device, but edge_select_kernel ran 25.8 vs 25.7 ms with them, so they keep the plain shuffle.) */
+__device__ __forceinline__ u32 lane_xor32(u32 x, int j)
+{
+    switch (j) {
+    case 1: return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  /* quad_perm [1,0,3,2] */
+    case 2: return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);  /* quad_perm [2,3,0,1] */
+    case 8: return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); /* row_ror:8 */
+    default: return (u32)__shfl_xor((int)x, j);
+    }
+}
+__device__ __forceinline__ u64 lane_xor64(u64 x, int j) { return ((u64)lane_xor32((u32)(x >> 32), j) << 32) | lane_xor32((u32)x, j); }
+
 /* ascending bitonic sort of one u64 per lane across the wavefront (21 compare-exchange steps) */
 __device__ __forceinline__ u64 wave_bitonic_sort(u64 x, u32 lane)
 {
@@ -133,11 +149,11 @@ __device__ __forceinline__ u64 wave_bitonic_sort(u64 x, u32 lane)
     for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            const u64 y = __shfl_xor(x, j2);
+            const u64 y = lane_xor64(x, j2);
             const bool up = (lane & k2) == 0;
             const bool lower = (lane & j2) == 0;
             const bool take_min = (up == lower);
-            x = take_min ? (x < y ? x : y) : (x < y ? y : x);
+            x = ((x < y) == take_min) ? x : y; /* one compare; the lane masks are wave constants (scalar registers) */
         }
     }
     return x;
@@ -150,11 +166,11 @@ __device__ __forceinline__ u32 wave_bitonic_sort32(u32 x, u32 lane)
     for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            const u32 y = __shfl_xor(x, j2);
+            const u32 y = lane_xor32(x, j2);
             const bool up = (lane & k2) == 0;
             const bool lower = (lane & j2) == 0;
             const bool take_min = (up == lower);
-            x = take_min ? (x < y ? x : y) : (x < y ? y : x);
+            x = ((x < y) == take_min) ? x : y; /* one compare; the lane masks are wave constants (scalar registers) */
         }
     }
     return x;
