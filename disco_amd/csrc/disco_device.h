@@ -126,6 +126,20 @@ __device__ __forceinline__ u32 row_suffix_min(u32 x)
     return x < y ? x : y;
 }
 
+/* inclusive prefix sum across the wavefront, all in DPP adds: four row_shr steps inside the 16-lane rows, then row_bcast:15
+ * into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (six instructions; the shuffle form is six ds_bpermute round trips in a
+ * dependency chain) */
+__device__ __forceinline__ u32 wave_inclusive_add(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 /* x of lane (lane ^ j), j a compile-time power of two (the sorts below unroll completely): strides 1 and 2 are DPP quad
  * permutes, 8 is a rotation inside the 16-lane row — register-to-register moves with a few cycles of latency where
  * ds_bpermute goes through the LDS pipe; a bitonic network is one long dependency chain, so the latency is what counts.

@@ -585,12 +585,8 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                     s_occ_fp[lane] = KEY_FP(key);
                     s_occ_prel[lane] = (u16)prel;
                 }
-                u32 incl = cnt;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const u32 y = __shfl_up(incl, o);
-                    if ((int)lane >= o) incl += y;
-                }
-                const u32 total = __shfl(incl, 63);
+                const u32 incl = wave_inclusive_add(cnt);
+                const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
                 /* only the buckets that hold records keep a slot (compacted): their start offsets in the concatenated record
                  * list are then strictly increasing, and a byte mark at every start turns "which bucket owns record i" into a
                  * ballot and a population count for the first 64 records (a binary search for the rest) */
