@@ -210,7 +210,7 @@ int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
 int64_t disco_fetch_edge_files(disco_ctx *ctx, uint32_t n_files, uint16_t *out, uint64_t cap);
 int disco_get_counters(disco_ctx *ctx, disco_counters *out);
 /* milliseconds of the last run of each phase, measured with HIP events on the stream the kernels were launched on
- * (index = DISCO_PH_*). DISCO_PH_PROBE_KERNEL brackets exactly one launch of the dominant kernel. */
+ * (index = DISCO_PH_*). DISCO_PH_PROBE_KERNEL / DISCO_PH_VERIFY each bracket exactly one launch of the two longest kernels. */
 enum {
     DISCO_PH_INDEX = 0,    /* memset + count + scan + fill                       */
     DISCO_PH_PROBE_KERNEL, /* one launch of probe_kernel<false> (candidate generation) */
@@ -225,11 +225,12 @@ enum {
     DISCO_PH_COUNT
 };
 int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
-/* processing order of the query range for the verify pass: a device array of q_hi - q_lo read ids (a permutation of the
- * range; caller-owned, must stay valid), or NULL for file order. Results do not depend on it; reads that overlap each other
- * processed back to back find their candidates' rows in the cache. */
+/* processing order of the query range for the probe and verify passes: a device array of q_hi - q_lo read ids (a permutation
+ * of the range; caller-owned, must stay valid), or NULL: the library's own grouping (reads with the same read-level minimizer
+ * next to each other; file order for small inputs or with DISCO_NO_ORDER=1). Results do not depend on it; reads that overlap
+ * each other processed back to back find the same index buckets and candidate rows in the cache. */
 int disco_set_query_order(disco_ctx *ctx, const void *d_order_u64);
-/* the order the last disco_probe used for its verify pass (device pointer to q_hi - q_lo read ids), NULL = file order */
+/* the order the last disco_probe walked (device pointer to q_hi - q_lo read ids, owned by the context), NULL = file order */
 int disco_get_query_order(disco_ctx *ctx, const void **d_order_u64);
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
