@@ -104,6 +104,8 @@ struct disco_ctx {
     u32 *d_ocnt = nullptr, *d_okey = nullptr, *d_oslot = nullptr;
     u64 *d_order_own = nullptr;
     u64 okey_cap = 0, oslot_cap = 0, order_cap = 0, ocnt_cap = 0;
+    ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
+    u64 meta_cap = 0;
     /* sharded flow, compact exchange: neighbour rows as 4-byte entries in a caller-owned gathered array */
     const u32 *d_nadj32 = nullptr;
     u64 *d_nref = nullptr;
@@ -357,6 +359,8 @@ static void free_graph_state(disco_ctx *c)
     c->nref_cap = 0;
     dev_free(c, &c->d_ocnt, c->ocnt_cap);
     dev_free(c, &c->d_okey, c->okey_cap);
+    dev_free(c, &c->d_meta_ord, c->meta_cap);
+    c->meta_cap = 0;
     dev_free(c, &c->d_oslot, c->oslot_cap);
     dev_free(c, &c->d_order_own, c->order_cap);
     c->okey_cap = c->oslot_cap = c->order_cap = c->ocnt_cap = 0;
@@ -728,6 +732,8 @@ int disco_probe(disco_ctx *c)
         if (!c->d_probe_rare) CHK(dev_alloc(c, &c->d_probe_rare, 1));
         HIPCHK(c, hipMemcpyAsync(c->d_probe_rare, &c->h_probe_rare, sizeof(ProbeRare), hipMemcpyHostToDevice, c->stream));
         a.rare = c->d_probe_rare;
+        CHK(ensure_cap(c, &c->d_meta_ord, &c->meta_cap, std::max<u64>(nq, 1)));
+        a.meta_ord = c->d_meta_ord;
         /* grouping of the query range by read-level minimizer for the probe and verify passes (DISCO_NO_ORDER=1: file order) */
         const u64 order_min = getenv("DISCO_ORDER_MIN_READS") ? (u64)atoll(getenv("DISCO_ORDER_MIN_READS")) : 4096; /* tests: 1 */
         const bool own_order = !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= order_min && nq > 0;
@@ -778,6 +784,7 @@ int disco_probe(disco_ctx *c)
             va.row_start = c->d_row_start;
             va.row_cnt = c->d_row_cnt;
             va.order = c->d_order;
+            va.meta_ord = c->d_meta_ord;
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
