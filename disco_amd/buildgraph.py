@@ -322,7 +322,7 @@ class BuildGraph:
         return out[:n]
 
     def get_query_order(self) -> int:
-        """device pointer of the processing order the last probe used (0 = file order)"""
+        """device pointer of the processing order the last probe walked (0 = file order); entries: read id | length << 32"""
         out = _P()
         self._chk(self.L.disco_get_query_order(self._h, C.byref(out)))
         return out.value or 0

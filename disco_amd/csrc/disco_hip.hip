@@ -99,7 +99,8 @@ struct disco_ctx {
     u32 *d_n_big = nullptr;
     u32 big_cap = 0;
     u64 big_rows = 0;
-    const u64 *d_order = nullptr; /* processing order of the query range (caller-owned or built by the context), or null */
+    const u64 *d_order = nullptr; /* a caller's processing order of the query range (plain read ids), or null */
+    const u64 *d_order_used = nullptr; /* what the last probe walked: packed entries (ORDER_MAKE) in d_order_own, or null = file order */
     bool order_external = false;
     u32 *d_ocnt = nullptr, *d_okey = nullptr, *d_oslot = nullptr;
     u64 *d_order_own = nullptr;
@@ -364,7 +365,7 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_oslot, c->oslot_cap);
     dev_free(c, &c->d_order_own, c->order_cap);
     c->okey_cap = c->oslot_cap = c->order_cap = c->ocnt_cap = 0;
-    if (!c->order_external) c->d_order = nullptr;
+    c->d_order_used = nullptr;
     c->d_nadj32 = nullptr;
     c->nbr32 = false;
     c->d_adj = nullptr;
@@ -751,13 +752,18 @@ int disco_probe(disco_ctx *c)
             HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
             hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, nq, oshift, c->d_ocnt, c->d_oslot);
             CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
-            hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, c->d_oslot, c->d_ocnt, oshift, c->q_lo, nq, c->d_order_own);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, c->d_oslot, c->d_ocnt, oshift, c->q_lo, nq, c->d_len, c->d_order_own);
             ph_end(c, DISCO_PH_ORDER);
             HIPCHK(c, hipGetLastError());
-            c->d_order = c->d_order_own;
-        } else if (!c->order_external)
-            c->d_order = nullptr;
-        a.order = c->d_order;
+            c->d_order_used = c->d_order_own;
+        } else if (c->order_external && nq) {
+            CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, nq));
+            hipLaunchKernelGGL(order_pack_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_order, nq, c->d_len, c->d_order_own);
+            HIPCHK(c, hipGetLastError());
+            c->d_order_used = c->d_order_own;
+        } else
+            c->d_order_used = nullptr;
+        a.order = c->d_order_used;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {
@@ -783,7 +789,7 @@ int disco_probe(disco_ctx *c)
             va.hits = c->d_hits;
             va.row_start = c->d_row_start;
             va.row_cnt = c->d_row_cnt;
-            va.order = c->d_order;
+            va.order = c->d_order_used;
             va.meta_ord = c->d_meta_ord;
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
@@ -1690,7 +1696,7 @@ int disco_set_query_order(disco_ctx *c, const void *d_order_u64)
 int disco_get_query_order(disco_ctx *c, const void **d_order_u64)
 {
     if (!c || !d_order_u64) return DISCO_E_ARG;
-    *d_order_u64 = c->d_order;
+    *d_order_u64 = c->d_order_used;
     return DISCO_OK;
 }
 

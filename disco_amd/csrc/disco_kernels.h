@@ -63,6 +63,11 @@ enum {
  * not depend on how many workgroups happen to be resident (a static blockIdx-strided loop ran 30-40 % slower whenever
  * the grid was not a multiple of the resident workgroups) */
 #define WQ_CHUNK 64
+/* entry of the processing order: read id | length << 32 — the length travels with the id, so the probe does not fetch len[id]
+ * (a random 64-byte line per read) for reads it takes out of order */
+#define ORDER_MAKE(id, l) ((u64)(id) | ((u64)(l) << 32))
+#define ORDER_ID(o) ((o) & 0xFFFFFFFFull)
+#define ORDER_LEN(o) ((int)((o) >> 32))
 template <u32 CHUNK = WQ_CHUNK>
 __device__ __forceinline__ bool wq_grab(u64 *counter, u64 n, u64 &beg, u64 &end)
 {
@@ -393,20 +398,22 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
     int pre_len = 0;
     u64 cbeg = 0, cend = 0;
     u64 ord_chunk = 0; /* lane i: the read the chunk's item i stands for (WQ_CHUNK == 64) */
-    auto rid = [&](u64 it) { return readlane_u64(ord_chunk, (u32)(it - cbeg)); };
+    auto rid = [&](u64 it) { return readlane_u64(ord_chunk, (u32)(it - cbeg)); }; /* packed: ORDER_ID / ORDER_LEN */
     while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
     if (!BIG) {
         const u64 i = min(cbeg + lane, cend - 1);
-        ord_chunk = a.order ? a.order[i] : a.v.q_lo + i;
+        ord_chunk = a.order ? a.order[i] : ORDER_MAKE(a.v.q_lo + i, a.v.len[a.v.q_lo + i]);
     }
     if (!BIG && LDSROW) {
-        const u64 A0 = rid(cbeg);
-        pre_len = a.v.len[A0];
+        const u64 o0 = rid(cbeg);
+        const u64 A0 = ORDER_ID(o0);
+        pre_len = ORDER_LEN(o0);
         if ((int)lane < S) pre_w = a.v.reads[A0 * S + lane];
     }
     for (u64 it = cbeg; it < cend; it++) {
         const u64 bl = BIG ? a.rare->big_list[it] : 0ull; /* read id | position in the order << 32 */
-        const u64 A = BIG ? (bl & 0xFFFFFFFFull) : rid(it);
+        const u64 oe = BIG ? 0ull : rid(it);
+        const u64 A = BIG ? (bl & 0xFFFFFFFFull) : ORDER_ID(oe);
         const u64 opos = BIG ? (bl >> 32) : it;
         const u64 *ga = a.v.reads + A * S;
         int LA;
@@ -416,12 +423,13 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
             if ((int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? pre_w : 0ull;
             const u64 itn = it + 1;
             if (itn < cend) {
-                const u64 An = rid(itn);
-                pre_len = a.v.len[An];
+                const u64 on = rid(itn);
+                const u64 An = ORDER_ID(on);
+                pre_len = ORDER_LEN(on);
                 if ((int)lane < S) pre_w = a.v.reads[An * S + lane];
             }
         } else {
-            LA = a.v.len[A];
+            LA = BIG ? (int)a.v.len[A] : ORDER_LEN(oe);
             if (LDSROW && (int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? ga[lane] : 0ull;
         }
         const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
@@ -768,7 +776,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
      * share their read-level minimizer are neighbours there, so that the candidate rows one of them fetches are still in the
      * cache for the next ones), or simply read q_lo + it */
     u64 ord_chunk = 0;
-    auto rid = [&](u64 it) { return readlane_u64(ord_chunk, (u32)((it < cend ? it : cend - 1) - cbeg)); };
+    auto rid = [&](u64 it) { return ORDER_ID(readlane_u64(ord_chunk, (u32)((it < cend ? it : cend - 1) - cbeg))); };
     ulonglong2 meta_chunk = make_ulonglong2(0, 0); /* lane i: header of the chunk's read i (probe_kernel's meta_ord) */
     auto load_meta = [&](u64 it) {
         Meta mt;
@@ -2281,10 +2289,17 @@ __global__ void order_count_kernel(const u32 *__restrict__ okey, u64 nq, u32 shi
 }
 
 __global__ void order_scatter_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ oslot, const u32 *__restrict__ start, u32 shift, u64 lo, u64 nq,
-                                     u64 *__restrict__ order)
+                                     const u16 *__restrict__ len, u64 *__restrict__ order)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < nq; i += (u64)gridDim.x * blockDim.x) order[(u64)start[ORDER_BUCKET(okey[i], shift)] + oslot[i]] = lo + i;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) order[(u64)start[ORDER_BUCKET(okey[i], shift)] + oslot[i]] = ORDER_MAKE(lo + i, len[lo + i]);
+}
+
+/* a caller's order (plain read ids) in the packed form the kernels walk */
+__global__ void order_pack_kernel(const u64 *__restrict__ ids, u64 nq, const u16 *__restrict__ len, u64 *__restrict__ order)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) order[i] = ORDER_MAKE(ids[i], len[ids[i]]);
 }
 
 /* how many items of [lo,hi) exceed a threshold: rows longer than ES_CAP (cnt = row_cnt) / nodes of degree above TR_CAP

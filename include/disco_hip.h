@@ -230,7 +230,8 @@ int disco_phase_ms(disco_ctx *ctx, float *ms, int n);
  * next to each other; file order for small inputs or with DISCO_NO_ORDER=1). Results do not depend on it; reads that overlap
  * each other processed back to back find the same index buckets and candidate rows in the cache. */
 int disco_set_query_order(disco_ctx *ctx, const void *d_order_u64);
-/* the order the last disco_probe walked (device pointer to q_hi - q_lo read ids, owned by the context), NULL = file order */
+/* the order the last disco_probe walked: device pointer to q_hi - q_lo entries owned by the context, read id in bits 31..0 and
+ * the read's length in bits 47..32 (the kernels carry the length with the id); NULL = file order */
 int disco_get_query_order(disco_ctx *ctx, const void **d_order_u64);
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);

@@ -192,7 +192,9 @@ def test_processing_order_is_a_grouped_permutation():
         t = torch.empty(n, dtype=torch.int64, device="cuda")
         g.memcpy_d2d(t.data_ptr(), ptr, n * 8)
         g.synchronize()
-        order = t.cpu().numpy()
+        packed = t.cpu().numpy()
+    order = packed & 0xFFFFFFFF  # entries carry the read's length in bits 47..32
+    assert np.array_equal(packed >> 32, np.full(n, 150))
     assert np.array_equal(np.sort(order), np.arange(n))
     gpos, _, _ = readgen.read_locations(spec)
     d = np.abs(np.diff(gpos[order].astype(np.int64)))
@@ -209,3 +211,29 @@ def test_probe_window_minimum_variants_agree(monkeypatch):
     monkeypatch.setenv("DISCO_NO_ROW17", "1")
     for seed, n, lmin, lmax, cov in cases:
         assert_parity(_gen(seed, n, lmin, cov, lmax), 40, f"lds-{seed}")
+
+
+def test_caller_supplied_order_changes_nothing():
+    """disco_set_query_order: any permutation of the query range (plain read ids) gives the same graph"""
+    import torch
+    n = 20_000
+    spec = readgen.GenSpec.coverage(131, n, 100, 30.0, n_contigs=2, len_max=220)
+    res = []
+    for mode in ("own", "random", "reversed"):
+        with buildgraph.BuildGraph(min_overlap=40) as g:
+            g.generate_reads(spec)
+            if mode == "random":
+                perm = torch.randperm(n, dtype=torch.int64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+            elif mode == "reversed":
+                perm = torch.arange(n - 1, -1, -1, dtype=torch.int64, device="cuda")
+            if mode != "own":
+                torch.cuda.synchronize()
+                g.set_query_order(perm.data_ptr())
+            g.run_graph()
+            cnt = g.counters()
+            e = np.sort(g.fetch_edges(), order=("src", "dst", "orient", "offset"))
+            r = np.sort(g.fetch_contained(), order=("contained",))
+            res.append((cnt["e_pre"], cnt["e_out"], cnt["n_contained"], cnt["kmer_hits"], e, r))
+    for x in res[1:]:
+        assert x[:4] == res[0][:4]
+        assert np.array_equal(x[4], res[0][4]) and np.array_equal(x[5], res[0][5])
