@@ -132,11 +132,37 @@ def cpu_baseline(args, spec_full):
     return dict(value=e_pre / t, unit="overlaps/s", cores=1, kind="port", sample=sample + f"; C restatement {t:.2f} s")
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD torch.distributed.run (this
+    process has not touched the GPU and never will — no exec of a GPU-initialised process), relay its output and exit code.
+    Replaces mpirun of the reference's multi-process binaries (MPI/main.cpp:29-37)."""
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this machine has {have} GPU(s); one rank per GPU is required "
+                         f"(refusing to print a {args.gpus}-GPU line measured on fewer)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     import torch
     import torch.distributed as dist
 
@@ -151,7 +177,6 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     genome = int(args.reads * args.read_len / args.coverage)
     n_contigs = max(1, genome // 5_000_000)  # 5 Mbp contigs, reads never span contigs

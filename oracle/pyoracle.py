@@ -203,7 +203,17 @@ def canonical_edges_large(src_f, dst_f, orient, offset, len_src, len_dst):
     la = np.where(swap, l2, l1)
     lb = np.where(swap, l1, l2)
     t = np.stack([a, b, o2, la - off2, la, off2, lb], axis=1)
-    order = np.lexsort((t[:, 6], t[:, 5], t[:, 4], t[:, 3], t[:, 2], t[:, 1], t[:, 0]))
+    # one edge per read pair is the rule: then (a, b) alone decides the order and one 64-bit key sort does it (seconds at
+    # 45 M edges, where the 7-key lexsort takes minutes); pairs that occur twice fall back to the full lexsort
+    order = None
+    if len(t) and a.min() >= 0 and b.min() >= 0 and a.max() < (1 << 31) and b.max() < (1 << 32):
+        key = (a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        if len(ks) > 1 and np.any(ks[1:] == ks[:-1]):
+            order = None
+    if order is None:
+        order = np.lexsort((t[:, 6], t[:, 5], t[:, 4], t[:, 3], t[:, 2], t[:, 1], t[:, 0]))
     t = t[order]
     if len(t) > 1:
         keep = np.ones(len(t), dtype=bool)

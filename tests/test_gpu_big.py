@@ -1,7 +1,7 @@
 """-m gpu : BASELINE-size parity. Reads are generated on the device from the committed generator parameters; the canonical
 edge list and contained rows of the HIP path must hash to the digests of the files the REAL reference buildG wrote for the
-same reads (tests/golden/make_big_digest.py, run once in the build container). Cases above 2 M reads only run with
-DISCO_RUN_BIG=1 (the canonicalisation of 45 M edges takes minutes of host time)."""
+same reads (tests/golden/make_big_digest.py, run once in the build container). All cases — including BASELINE config 3,
+50 M reads, the configuration bench.py reports — run in the default -m gpu suite."""
 import json
 import os
 
@@ -19,8 +19,6 @@ CASES = json.load(open(os.path.join(HERE, "golden", "cases_big.json")))
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_digest_matches_reference_files(name):
     c = CASES[name]
-    if c["reads"] > 2_000_000 and not os.environ.get("DISCO_RUN_BIG"):
-        pytest.skip("set DISCO_RUN_BIG=1 to run the full-size parity check")
     spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"],
                                     len_max=c.get("len_max", c["read_len"]))
     with buildgraph.BuildGraph(min_overlap=c["min_overlap"]) as g:
