@@ -4,8 +4,9 @@
 A step = one pass of the hot path (index build -> fused probe+verify -> containment -> edge selection -> twin check ->
 transitive reduction -> emission) over reads that are already resident in HBM, results left in HBM.
   N = 1 : the whole pass on one MI355X.
-  N > 1 : strong scaling — the same reads on every GPU, query reads range-partitioned, three RCCL collectives
-          (disco_amd/distributed.py).  value = E_pre of the whole job / max-over-ranks time.
+  N > 1 : strong scaling — the same job, reads and graph nodes range-partitioned over the ranks (one per GPU), every exchange an
+          RCCL collective inside libdisco_hip.so (disco_dist_run_graph).  value = E_pre of the whole job / max-over-ranks time.
+          `python bench.py --gpus N` without a launcher starts its own N ranks (a child torch.distributed.run).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -37,7 +38,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)  # = BASELINE config 2
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-distributed", action="store_true", help="run the sharded code path (RCCL collectives) even with one rank")
+    ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path (RCCL communicator, every exchange) even with one rank")
     return ap.parse_args()
 
 
@@ -166,45 +167,47 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from disco_amd import buildgraph, distributed, readgen
+    from disco_amd import buildgraph, readgen
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    torch.zeros(1, device=device)  # torch's HIP runtime opens the device before libdisco_hip.so does (tests/conftest.py)
     sharded = world > 1 or args.force_distributed
-    if sharded:
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
-
     genome = int(args.reads * args.read_len / args.coverage)
     n_contigs = max(1, genome // 5_000_000)  # 5 Mbp contigs, reads never span contigs
     spec = readgen.GenSpec.coverage(args.seed, args.reads, args.read_len, args.coverage, n_contigs=n_contigs)
     g = buildgraph.BuildGraph(min_overlap=args.min_overlap, device=local_rank)
-    g.generate_reads(spec)  # inputs resident in HBM before the timed region
-    engine = distributed.HipEngine(g, device)
-
-    info = {}
-    dist_timing = {} if os.environ.get("DISCO_DIST_TIMING") else None
+    if sharded:
+        # control plane: gloo (rendezvous, barrier, max over ranks). Data plane: RCCL inside libdisco_hip.so — the unique id of
+        # its communicator travels over the control plane, as MPI_Bcast would carry it (disco_comm_init)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("gloo")
+        uid = [buildgraph.BuildGraph.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        g.comm_init(uid[0], world, rank)
+        g.dist_generate_reads(spec)  # every rank generates ITS range of the reads: the inputs are range-partitioned in HBM
+    else:
+        g.generate_reads(spec)  # inputs resident in HBM before the timed region
 
     def step():
         if not sharded:
             g.run_graph()
         else:
-            info.update(distributed.distributed_step(engine, timing=dist_timing))
+            g.dist_run_graph(gather_reads=True)  # every pass starts from the range-partitioned reads: the all-gather is timed
 
     def fence():
         g.synchronize()
         torch.cuda.synchronize(device)
         if sharded:
             dist.barrier()
+        g.synchronize()
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         step()
-    if dist_timing is not None:
-        dist_timing.clear()
     kern_ms = {"probe_kernel": [], "verify_kernel": []}
     fence()
     t0 = time.perf_counter()
@@ -216,20 +219,20 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
 
     cnt = g.counters()
     phases = g.phase_ms()
-    e_pre = cnt["e_pre"] if not sharded else info["e_pre"]
-    e_out = cnt["e_out"] if not sharded else info["e_out"]
+    info = g.dist_info() if sharded else None
+    e_pre = info["e_pre"] if sharded else cnt["e_pre"]
+    e_out = info["e_out"] if sharded else cnt["e_out"]
     words_mean = float((args.read_len + 31) // 32)  # W of SURVEY.md §8: packed words per read (device rows are padded to 64 B)
-    if world > 1:  # probe counters are per shard: sum them for the roofline bookkeeping
-        v = torch.tensor([cnt["probes"], cnt["kmer_hits"]], dtype=torch.int64, device=device)
-        dist.all_reduce(v)
-        cnt_all = dict(cnt, probes=int(v[0]), kmer_hits=int(v[1]), e_pre=e_pre, e_out=e_out)
+    if sharded:  # whole-job counters from the pass itself
+        cnt_all = dict(cnt, probes=info["probes"], kmer_hits=info["kmer_hits"], e_pre=e_pre, e_out=e_out, n_contained=info["n_contained"],
+                       cap_bind_sites=info["cap_bind_sites"], asymmetric_pairs=info["asymmetric_pairs"])
     else:
         cnt_all = cnt
     total_b, kern_b = algorithmic_bytes(cnt_all, args.reads, words_mean)
@@ -280,9 +283,11 @@ def main():
                         f"uniform-random contigs, both strands, error-free, min-overlap {args.min_overlap} (k={args.min_overlap - 1}), "
                         f"transitive reduction on, seed {args.seed}",
             "reads": args.reads, "read_len": args.read_len, "min_overlap": args.min_overlap,
-            "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: reads replicated, queries range-partitioned, 3 RCCL collectives",
-            "e_pre": e_pre, "e_out": e_out, "n_contained": cnt["n_contained"],
-            "cap_bind_sites": cnt["cap_bind_sites"], "asymmetric_pairs": cnt["asymmetric_pairs"],
+            "parallelism": "1 GPU" if not sharded else (
+                f"{world} GPU(s), one rank each: reads and graph nodes range-partitioned, index built hash-partitioned (all-to-all of "
+                f"records, all-gather of shards), neighbour rows on request, survivor push; RCCL inside libdisco_hip.so"),
+            "e_pre": e_pre, "e_out": e_out, "n_contained": cnt_all["n_contained"],
+            "cap_bind_sites": cnt_all["cap_bind_sites"], "asymmetric_pairs": cnt_all["asymmetric_pairs"],
             "probes": cnt_all["probes"], "kmer_hits": cnt_all["kmer_hits"],
             "reads_per_s": args.reads / (ms_per_step * 1e-3),
             "phase_ms_rank0": {k: round(v, 3) for k, v in phases.items()},
@@ -292,6 +297,11 @@ def main():
         "roofline": roof(dominant),
         "roofline_other": [roof(k) for k in avg_ms if k != dominant],
     }
+    if sharded:  # rank 0's view of the exchanges of the last pass
+        out["config"]["exchanges_rank0"] = {"regime": "regular" if info["regime"] == 0 else "order-dependent (adjacency gathered)",
+                                            "tr_rounds": info["tr_rounds"], "tr_deferred": info["tr_deferred"],
+                                            "bytes_sent": info["bytes_sent"], "ms": {k: round(v, 3) for k, v in info["ms"].items()},
+                                            "ms_pass": round(info["ms_total"], 3)}
     g.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -302,8 +312,6 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if dist_timing:
-            print("[dist timing, rank 0, ms summed over all steps]", {k: round(v, 1) for k, v in dist_timing.items()}, file=sys.stderr)
         try:  # RCCL writes its version banner through C stdio, which is flushed at exit: push it out before the JSON line
             import ctypes
             ctypes.CDLL(None).fflush(None)

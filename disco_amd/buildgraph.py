@@ -70,29 +70,43 @@ ABI = [
     ("disco_transitive_mark", C.c_int, [_P]),
     ("disco_emit_edges", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("disco_run_graph", C.c_int, [_P]),
-    ("disco_contain_keys", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("disco_adjacency_size", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("disco_export_adjacency", C.c_int, [_P, _P, _P]),
     ("disco_import_adjacency", C.c_int, [_P, _P, _P, C.c_uint64]),
-    ("disco_adopt_adjacency", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
-    ("disco_half_lists", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint64)]),
-    ("disco_half_complete", C.c_int, [_P, C.c_int]),
-    ("disco_tr_flags", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("disco_fetch_contained", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_fetch_edges", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
     ("disco_phase_ms", C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
-    ("disco_export_adjacency32", C.c_int, [_P, _P, _P]),
-    ("disco_adopt_neighbours32", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
-    ("disco_dropped_hits", C.c_int, [_P, C.POINTER(C.c_uint64)]),
-    ("disco_set_global_dropped", C.c_int, [_P, C.c_uint64]),
     ("disco_fetch_edge_files", C.c_int64, [_P, C.c_uint32, _P, C.c_uint64]),
     ("disco_set_query_order", C.c_int, [_P, _P]),
     ("disco_get_query_order", C.c_int, [_P, C.POINTER(_P)]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+    ("disco_comm_unique_id", C.c_int, [_P, C.c_size_t]),
+    ("disco_comm_init", C.c_int, [_P, _P, C.c_int, C.c_int]),
+    ("disco_comm_init_local", C.c_int, [C.POINTER(_P), C.c_int]),
+    ("disco_comm_rank", C.c_int, [_P]),
+    ("disco_comm_world", C.c_int, [_P]),
+    ("disco_dist_range", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("disco_dist_upload_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
+    ("disco_dist_generate_reads", C.c_int, [_P, C.POINTER(GenSpecABI)]),
+    ("disco_dist_run_graph", C.c_int, [_P, C.c_uint32]),
+    ("disco_dist_get_info", C.c_int, [_P, _P]),
 ]
+
+XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency")
+UNIQUE_ID_BYTES = 128
+DIST_GATHER_READS = 1
+
+
+class DistInfo(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("n_reads", C.c_uint64), ("own_lo", C.c_uint64), ("own_hi", C.c_uint64),
+                ("n_contained", C.c_uint64), ("e_pre", C.c_uint64), ("e_out", C.c_uint64), ("e_out_local", C.c_uint64),
+                ("n_contained_local", C.c_uint64), ("cap_bind_sites", C.c_uint64), ("asymmetric_pairs", C.c_uint64),
+                ("dropped_hits", C.c_uint64), ("probes", C.c_uint64), ("kmer_hits", C.c_uint64), ("regime", C.c_uint32),
+                ("tr_rounds", C.c_uint32), ("tr_deferred", C.c_uint64), ("bytes_sent", C.c_uint64 * len(XCHG)),
+                ("ms", C.c_float * len(XCHG)), ("ms_total", C.c_float)]
 
 PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit", "order")
 
@@ -247,12 +261,7 @@ class BuildGraph:
     def run_graph(self):
         self._chk(self.L.disco_run_graph(self._h))
 
-    # -- multi-GPU exchange points -------------------------------------------------------------------------------
-    def contain_keys(self):
-        p, n = _P(), C.c_uint64()
-        self._chk(self.L.disco_contain_keys(self._h, C.byref(p), C.byref(n)))
-        return p.value, n.value
-
+    # -- adjacency in / out ----------------------------------------------------------------------------------------
     def adjacency_size(self) -> int:
         n = C.c_uint64()
         self._chk(self.L.disco_adjacency_size(self._h, C.byref(n)))
@@ -263,22 +272,6 @@ class BuildGraph:
 
     def import_adjacency(self, d_deg_all_ptr: int, d_entries_all_ptr: int, n_entries: int):
         self._chk(self.L.disco_import_adjacency(self._h, _P(d_deg_all_ptr), _P(d_entries_all_ptr), n_entries))
-
-    def adopt_adjacency(self, d_deg_all_ptr: int, d_rows_padded_ptr: int, per_rank_nodes: int, max_per_rank: int, world: int):
-        self._chk(self.L.disco_adopt_adjacency(self._h, _P(d_deg_all_ptr), _P(d_rows_padded_ptr), per_rank_nodes, max_per_rank, world))
-
-    def half_lists(self):
-        h, c, w = _P(), _P(), C.c_uint64()
-        self._chk(self.L.disco_half_lists(self._h, C.byref(h), C.byref(c), C.byref(w)))
-        return h.value, c.value, w.value
-
-    def half_complete(self, complete: bool = True):
-        self._chk(self.L.disco_half_complete(self._h, 1 if complete else 0))
-
-    def tr_flags(self):
-        p, lo, hi, tot = _P(), C.c_uint64(), C.c_uint64(), C.c_uint64()
-        self._chk(self.L.disco_tr_flags(self._h, C.byref(p), C.byref(lo), C.byref(hi), C.byref(tot)))
-        return p.value, lo.value, hi.value, tot.value
 
     # -- results -----------------------------------------------------------------------------------------------
     def fetch_contained(self) -> np.ndarray:
@@ -299,20 +292,6 @@ class BuildGraph:
         a = (C.c_float * len(PHASES))()
         self._chk(self.L.disco_phase_ms(self._h, a, len(PHASES)))
         return {n: float(a[i]) for i, n in enumerate(PHASES)}
-
-    def export_adjacency32(self, deg_ptr: int, rows32_ptr: int):
-        self._chk(self.L.disco_export_adjacency32(self._h, _P(deg_ptr), _P(rows32_ptr)))
-
-    def adopt_neighbours32(self, deg_all_ptr: int, rows32_ptr: int, per: int, mx: int, world: int):
-        self._chk(self.L.disco_adopt_neighbours32(self._h, _P(deg_all_ptr), _P(rows32_ptr), per, mx, world))
-
-    def dropped_hits(self) -> int:
-        out = C.c_uint64(0)
-        self._chk(self.L.disco_dropped_hits(self._h, C.byref(out)))
-        return out.value
-
-    def set_global_dropped(self, n_all: int):
-        self._chk(self.L.disco_set_global_dropped(self._h, n_all))
 
     def fetch_edge_files(self, n_files: int):
         """file index of every edge (order of fetch_edges): connected components dealt out to n_files files"""
@@ -344,6 +323,75 @@ class BuildGraph:
 
     def memcpy_d2d(self, dst_ptr: int, src_ptr: int, nbytes: int):
         self._chk(self.L.disco_memcpy_d2d(self._h, _P(dst_ptr), _P(src_ptr), nbytes))
+
+    # -- multi-GPU flow (one BuildGraph per rank; every call below is collective) ---------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = load().disco_comm_unique_id(buf, UNIQUE_ID_BYTES)
+        if rc != 0:
+            raise DiscoError(f"disco_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, world: int, rank: int):
+        """join the RCCL communicator (one rank per GPU)"""
+        self._chk(self.L.disco_comm_init(self._h, C.c_char_p(unique_id), world, rank))
+
+    @staticmethod
+    def comm_init_local(graphs):
+        """the ranks are the given contexts of this process, one host thread each (single-GPU boxes, tests)"""
+        arr = (_P * len(graphs))(*[g._h for g in graphs])
+        rc = load().disco_comm_init_local(arr, len(graphs))
+        if rc != 0:
+            raise DiscoError(f"disco_comm_init_local failed ({rc})")
+
+    @property
+    def rank(self) -> int:
+        return int(self.L.disco_comm_rank(self._h))
+
+    @property
+    def world(self) -> int:
+        return int(self.L.disco_comm_world(self._h))
+
+    def dist_range(self, n_total: int):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.disco_dist_range(self._h, n_total, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def dist_upload_reads(self, packed_own: np.ndarray, lens_own: np.ndarray, n_total: int, stride_words: int | None = None):
+        packed_own = np.ascontiguousarray(packed_own, dtype=np.uint64)
+        lens_own = np.ascontiguousarray(lens_own, dtype=np.uint16)
+        self._keep = (packed_own, lens_own)
+        stride = int(stride_words if stride_words is not None else packed_own.shape[1])
+        self._chk(self.L.disco_dist_upload_reads(self._h, packed_own.ctypes.data, stride, lens_own.ctypes.data, n_total))
+
+    def dist_upload_ascii(self, reads):
+        """every rank passes ALL reads of the job; only its own range is packed and uploaded"""
+        n = len(reads)
+        lo, hi = self.dist_range(n)
+        stride = int((max((len(r) for r in reads), default=1) + 31) // 32)
+        packed = np.zeros((hi - lo, stride), dtype=np.uint64)
+        lens = np.fromiter((len(r) for r in reads[lo:hi]), dtype=np.uint16, count=hi - lo)
+        for i, r in enumerate(reads[lo:hi]):
+            b = r.encode()
+            if self.L.disco_pack_ascii(b, len(b), packed[i].ctypes.data) != 0:
+                raise DiscoError(f"read {lo + i} contains a non-ACGT base")
+        self.dist_upload_reads(packed, lens, n, stride)
+
+    def dist_generate_reads(self, spec):
+        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
+        self._chk(self.L.disco_dist_generate_reads(self._h, C.byref(s)))
+
+    def dist_run_graph(self, gather_reads: bool = True):
+        self._chk(self.L.disco_dist_run_graph(self._h, DIST_GATHER_READS if gather_reads else 0))
+
+    def dist_info(self) -> dict:
+        d = DistInfo()
+        self._chk(self.L.disco_dist_get_info(self._h, C.byref(d)))
+        out = {n: getattr(d, n) for n, _ in DistInfo._fields_ if n not in ("bytes_sent", "ms")}
+        out["bytes_sent"] = {x: int(d.bytes_sent[i]) for i, x in enumerate(XCHG)}
+        out["ms"] = {x: float(d.ms[i]) for i, x in enumerate(XCHG)}
+        return out
 
     def counters(self) -> dict:
         c = Counters()

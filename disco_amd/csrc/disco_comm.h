@@ -1,0 +1,307 @@
+/*
+ * disco_comm.h — the exchange layer of the multi-GPU BuildGraph flow (host side, part of libdisco_hip.so).
+ *
+ * Replaces the communication of the reference's two multi-process binaries:
+ *   buildG-MPI    : MPI_Isend / MPI_Recv gossip of marked and contained read ids (MPI/OverlapGraph.cpp:218-246,473-506)
+ *   buildG-MPIRMA : one MPI_Get per hash bucket out of an MPI-3 RMA window over the sharded hashData
+ *                   (RMA/HashTable.cpp:422-435 window, :644-653,694-705 gets)
+ * with BULK collectives on device buffers: all-to-all-v (grouped ncclSend / ncclRecv: on the xGMI mesh every peer pair has its
+ * own link, so all 7 links of a GPU carry a slice at once), all-gather(-v) and reduce-scatter(MIN).
+ *
+ * Two transports behind one interface:
+ *   RcclComm : one rank per GPU over RCCL (the product path; processes under torchrun / mpirun-like launchers, or one host
+ *              thread per GPU inside buildG --gpus N)
+ *   LoopComm : ranks = host threads of ONE process whose contexts live on the same device (or on peers that can address each
+ *              other): the collectives are device-to-device copies between the ranks' buffers, fenced by host barriers.
+ *              RCCL refuses two ranks on one GPU; this is what lets the exact multi-rank code path run on the 1-GPU test
+ *              boxes (tests/test_gpu_dist.py, buildG --gpus N --same-device).
+ * All byte counts are size_t; every call is collective (all ranks, same order) and returns DISCO_OK or a negative code.
+ */
+#ifndef DISCO_COMM_H_
+#define DISCO_COMM_H_
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/disco_hip.h"
+
+struct DiscoComm {
+    int rank = 0, world = 1;
+    std::string err;
+    virtual ~DiscoComm() {}
+    virtual const char *kind() const = 0;
+    /* every rank contributes `bytes` at send; rank p's block lands at recv + p * bytes (in place when send == recv + rank * bytes) */
+    virtual int all_gather(const void *send, void *recv, size_t bytes, hipStream_t s) = 0;
+    /* blocks of different sizes: rank p's block (cnt[p] bytes) lands at recv + off[p]; send may alias recv + off[rank] */
+    virtual int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) = 0;
+    /* block for rank p = send + soff[p] (scnt[p] bytes); the block from rank p lands at recv + roff[p] (rcnt[p] bytes) */
+    virtual int all_to_all_v(const void *send, const size_t *soff, const size_t *scnt, void *recv, const size_t *roff, const size_t *rcnt,
+                             hipStream_t s) = 0;
+    /* buf = world blocks of `per` int64 values; afterwards block `rank` of this rank's buf holds the element-wise minimum of
+     * that block over all ranks (the other blocks are unspecified) */
+    virtual int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) = 0;
+    /* control plane: n host values per rank -> all[world * n], rank-major (synchronises the stream) */
+    virtual int host_all_gather(const unsigned long long *mine, int n, unsigned long long *all, hipStream_t s) = 0;
+    virtual int barrier(hipStream_t s) = 0;
+};
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+#define DISCO_NCCL(call)                                                                     \
+    do {                                                                                     \
+        ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess) {                                                             \
+            err = std::string(#call) + ": " + ncclGetErrorString(r_);                        \
+            return DISCO_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+#define DISCO_COMM_HIP(call)                                                                 \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return DISCO_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+struct RcclComm final : DiscoComm {
+    ncclComm_t comm = nullptr;
+    unsigned long long *d_small = nullptr; /* staging of host_all_gather */
+    size_t small_cap = 0;
+    const char *kind() const override { return "rccl"; }
+    int init(const void *unique_id, int nranks, int rk)
+    {
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof id);
+        rank = rk;
+        world = nranks;
+        DISCO_NCCL(ncclCommInitRank(&comm, nranks, id, rk));
+        return DISCO_OK;
+    }
+    ~RcclComm() override
+    {
+        if (d_small) (void)hipFree(d_small);
+        if (comm) (void)ncclCommDestroy(comm);
+    }
+    int all_gather(const void *send, void *recv, size_t bytes, hipStream_t s) override
+    {
+        if (bytes == 0) return DISCO_OK;
+        DISCO_NCCL(ncclAllGather(send, recv, bytes, ncclInt8, comm, s));
+        return DISCO_OK;
+    }
+    int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
+    {
+        DISCO_NCCL(ncclGroupStart());
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            if (cnt[rank]) DISCO_NCCL(ncclSend(send, cnt[rank], ncclInt8, p, comm, s));
+            if (cnt[p]) DISCO_NCCL(ncclRecv((char *)recv + off[p], cnt[p], ncclInt8, p, comm, s));
+        }
+        DISCO_NCCL(ncclGroupEnd());
+        if (cnt[rank] && send != (const char *)recv + off[rank])
+            DISCO_COMM_HIP(hipMemcpyAsync((char *)recv + off[rank], send, cnt[rank], hipMemcpyDeviceToDevice, s));
+        return DISCO_OK;
+    }
+    int all_to_all_v(const void *send, const size_t *soff, const size_t *scnt, void *recv, const size_t *roff, const size_t *rcnt,
+                     hipStream_t s) override
+    {
+        DISCO_NCCL(ncclGroupStart());
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            if (scnt[p]) DISCO_NCCL(ncclSend((const char *)send + soff[p], scnt[p], ncclInt8, p, comm, s));
+            if (rcnt[p]) DISCO_NCCL(ncclRecv((char *)recv + roff[p], rcnt[p], ncclInt8, p, comm, s));
+        }
+        DISCO_NCCL(ncclGroupEnd());
+        if (scnt[rank]) /* the block a rank keeps never touches a link */
+            DISCO_COMM_HIP(hipMemcpyAsync((char *)recv + roff[rank], (const char *)send + soff[rank], scnt[rank], hipMemcpyDeviceToDevice, s));
+        return DISCO_OK;
+    }
+    int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) override
+    {
+        if (per == 0) return DISCO_OK;
+        DISCO_NCCL(ncclReduceScatter(buf, (long long *)buf + (size_t)rank * per, per, ncclInt64, ncclMin, comm, s));
+        return DISCO_OK;
+    }
+    int host_all_gather(const unsigned long long *mine, int n, unsigned long long *all, hipStream_t s) override
+    {
+        const size_t need = (size_t)(world + 1) * n;
+        if (need > small_cap) {
+            if (d_small) (void)hipFree(d_small);
+            d_small = nullptr;
+            DISCO_COMM_HIP(hipMalloc((void **)&d_small, need * 8));
+            small_cap = need;
+        }
+        unsigned long long *d_mine = d_small + (size_t)world * n;
+        DISCO_COMM_HIP(hipMemcpyAsync(d_mine, mine, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        DISCO_NCCL(ncclAllGather(d_mine, d_small, (size_t)n * 8, ncclInt8, comm, s));
+        DISCO_COMM_HIP(hipMemcpyAsync(all, d_small, (size_t)world * n * 8, hipMemcpyDeviceToHost, s));
+        DISCO_COMM_HIP(hipStreamSynchronize(s));
+        return DISCO_OK;
+    }
+    int barrier(hipStream_t s) override
+    {
+        unsigned long long x = 0;
+        std::vector<unsigned long long> all((size_t)world);
+        return host_all_gather(&x, 1, all.data(), s);
+    }
+};
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+__global__ void loop_min_i64_kernel(long long *__restrict__ dst, const long long *const *__restrict__ srcs, int world, size_t off, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        long long m = srcs[0][off + i];
+        for (int p = 1; p < world; p++) {
+            const long long x = srcs[p][off + i];
+            m = x < m ? x : m;
+        }
+        dst[off + i] = m;
+    }
+}
+
+/* state shared by the ranks (threads) of one in-process group */
+struct LoopGroup {
+    int world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long gen = 0;
+    bool aborted = false;
+    std::vector<const void *> ptr;                /* per rank: published buffer                */
+    std::vector<std::vector<size_t>> off, cnt;    /* per rank: published per-peer offsets/counts */
+    std::vector<unsigned long long> host;         /* host_all_gather scratch                   */
+    explicit LoopGroup(int w) : world(w), ptr((size_t)w), off((size_t)w), cnt((size_t)w) {}
+    bool wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
+        const unsigned long g = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lk, [&] { return gen != g || aborted; });
+        return !aborted;
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+
+struct LoopComm final : DiscoComm {
+    std::shared_ptr<LoopGroup> g;
+    const long long **d_srcs = nullptr;
+    const char *kind() const override { return "loop"; }
+    LoopComm(std::shared_ptr<LoopGroup> grp, int rk) : g(std::move(grp))
+    {
+        rank = rk;
+        world = g->world;
+    }
+    ~LoopComm() override
+    {
+        if (d_srcs) (void)hipFree(d_srcs);
+    }
+#define LOOP_WAIT()                                           \
+    do {                                                      \
+        if (!g->wait()) {                                     \
+            err = "loop communicator aborted by another rank"; \
+            return DISCO_E_STATE;                             \
+        }                                                     \
+    } while (0)
+    int fail_abort(int rc)
+    {
+        g->abort();
+        return rc;
+    }
+    int all_gather(const void *send, void *recv, size_t bytes, hipStream_t s) override
+    {
+        std::vector<size_t> off((size_t)world), cnt((size_t)world, bytes);
+        for (int p = 0; p < world; p++) off[(size_t)p] = (size_t)p * bytes;
+        return all_gather_v(send, recv, off.data(), cnt.data(), s);
+    }
+    int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
+    {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP); /* my block is complete */
+        g->ptr[(size_t)rank] = send;
+        LOOP_WAIT();
+        for (int p = 0; p < world; p++) {
+            char *dst = (char *)recv + off[p];
+            if (cnt[p] && dst != g->ptr[(size_t)p])
+                if (hipMemcpyAsync(dst, g->ptr[(size_t)p], cnt[p], hipMemcpyDeviceToDevice, s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LOOP_WAIT(); /* nobody reuses its send block before every peer has pulled it */
+        return DISCO_OK;
+    }
+    int all_to_all_v(const void *send, const size_t *soff, const size_t *scnt, void *recv, const size_t *roff, const size_t *rcnt,
+                     hipStream_t s) override
+    {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        g->ptr[(size_t)rank] = send;
+        g->off[(size_t)rank].assign(soff, soff + world);
+        g->cnt[(size_t)rank].assign(scnt, scnt + world);
+        LOOP_WAIT();
+        for (int p = 0; p < world; p++) {
+            const size_t n = g->cnt[(size_t)p][(size_t)rank];
+            if (n != rcnt[p]) {
+                err = "all_to_all_v: receive count does not match the peer's send count";
+                return fail_abort(DISCO_E_ARG);
+            }
+            if (n && hipMemcpyAsync((char *)recv + roff[p], (const char *)g->ptr[(size_t)p] + g->off[(size_t)p][(size_t)rank], n, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return fail_abort(DISCO_E_HIP);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LOOP_WAIT();
+        return DISCO_OK;
+    }
+    int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) override
+    {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        g->ptr[(size_t)rank] = buf;
+        LOOP_WAIT();
+        if (per) {
+            if (!d_srcs && hipMalloc((void **)&d_srcs, sizeof(void *) * (size_t)world) != hipSuccess) return fail_abort(DISCO_E_NOMEM);
+            if (hipMemcpyAsync(d_srcs, g->ptr.data(), sizeof(void *) * (size_t)world, hipMemcpyHostToDevice, s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+            /* reads block `rank` of every rank's buffer, writes block `rank` of mine: nobody else touches those */
+            hipLaunchKernelGGL(loop_min_i64_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 4096)), dim3(256), 0, s, (long long *)buf, d_srcs, world,
+                               (size_t)rank * per, per);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LOOP_WAIT();
+        return DISCO_OK;
+    }
+    int host_all_gather(const unsigned long long *mine, int n, unsigned long long *all, hipStream_t s) override
+    {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            if (g->host.size() < (size_t)world * n) g->host.resize((size_t)world * n);
+        }
+        LOOP_WAIT(); /* the scratch has its final size before anybody writes */
+        for (int i = 0; i < n; i++) g->host[(size_t)rank * n + i] = mine[i];
+        LOOP_WAIT();
+        for (size_t i = 0; i < (size_t)world * n; i++) all[i] = g->host[i];
+        LOOP_WAIT();
+        return DISCO_OK;
+    }
+    int barrier(hipStream_t s) override
+    {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LOOP_WAIT();
+        return DISCO_OK;
+    }
+#undef LOOP_WAIT
+};
+
+#endif /* DISCO_COMM_H_ */

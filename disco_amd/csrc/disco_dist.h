@@ -1,0 +1,398 @@
+/*
+ * disco_dist.h — kernels of the multi-GPU BuildGraph flow (gfx950): routing of items to the rank that owns them, the
+ * hash-partitioned index build, on-request exchange of neighbour rows for the transitive reduction, and the push of
+ * surviving half-edges for the emission. Host orchestration: disco_hip.hip ("multi-GPU flow"), transport: disco_comm.h.
+ *
+ * Ownership (both replace RMA/HashTable.cpp:95-116, the range split of hashData, and :1066-1087, needsProcessing):
+ *   reads / graph nodes : rank r owns ids [r * per, (r + 1) * per), per = ceil(n / G) rounded up to a multiple of 64
+ *   index buckets       : rank r owns the buckets b with (b * G) >> log2(T) == r — a contiguous range of the bucket table
+ */
+#ifndef DISCO_DIST_H_
+#define DISCO_DIST_H_
+
+#include "disco_kernels.h"
+
+#define DIST_MAX_WORLD 64
+
+/* ---- routing: partition a flat list into one contiguous segment per destination rank --------------------------------- */
+struct RouteByBucket { /* index records {bucket << 32 | slot, record} */
+    int logT;
+    u32 G;
+    __device__ __forceinline__ u32 operator()(const ulonglong2 &r) const { return (u32)(((r.x >> 32) * (u64)G) >> logT); }
+};
+struct RouteByRowRequest { /* u << 1 | cls */
+    u64 per;
+    __device__ __forceinline__ u32 operator()(const u32 &r) const { return (u32)((u64)(r >> 1) / per); }
+};
+struct RouteByNode { /* {node id, payload} */
+    u64 per;
+    __device__ __forceinline__ u32 operator()(const ulonglong2 &r) const { return (u32)(r.x / per); }
+};
+
+#define ROUTE_ITEMS 8 /* items per thread and tile */
+template <typename T, typename F>
+__global__ void __launch_bounds__(256) route_count_kernel(const T *__restrict__ items, u64 n, F owner, u32 G, u64 *__restrict__ cnt)
+{
+    __shared__ u32 s_h[DIST_MAX_WORLD];
+    if (threadIdx.x < DIST_MAX_WORLD) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&s_h[owner(items[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < G && s_h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (u64)s_h[threadIdx.x]);
+}
+
+/* cursor[g] starts at the first slot of segment g; a tile reserves its share of every segment with one atomic per segment */
+template <typename T, typename F>
+__global__ void __launch_bounds__(256) route_scatter_kernel(const T *__restrict__ items, u64 n, F owner, u32 G, u64 *__restrict__ cursor, T *__restrict__ out)
+{
+    __shared__ u32 s_h[DIST_MAX_WORLD];
+    __shared__ u64 s_base[DIST_MAX_WORLD];
+    const u64 tile = (u64)256 * ROUTE_ITEMS;
+    for (u64 t0 = (u64)blockIdx.x * tile; t0 < n; t0 += (u64)gridDim.x * tile) {
+        if (threadIdx.x < DIST_MAX_WORLD) s_h[threadIdx.x] = 0;
+        __syncthreads();
+        T my[ROUTE_ITEMS];
+        u32 o[ROUTE_ITEMS], r[ROUTE_ITEMS];
+#pragma unroll
+        for (int q = 0; q < ROUTE_ITEMS; q++) {
+            const u64 i = t0 + (u64)q * 256 + threadIdx.x;
+            o[q] = 0xFFFFFFFFu;
+            if (i < n) {
+                my[q] = items[i];
+                o[q] = owner(my[q]);
+                r[q] = atomicAdd(&s_h[o[q]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < G) s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (u64)s_h[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ROUTE_ITEMS; q++)
+            if (o[q] != 0xFFFFFFFFu) out[s_base[o[q]] + r[q]] = my[q];
+        __syncthreads();
+    }
+}
+
+/* ---- hash-partitioned index build (the owner's side) ------------------------------------------------------------------ */
+/* records received from all ranks: count per bucket of this rank's range; the atomic hands every record its slot */
+__global__ void shard_count_kernel(ulonglong2 *__restrict__ rec, u64 n, u32 *__restrict__ bkt)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 b = rec[i].x >> 32;
+        rec[i].x = (b << 32) | atomicAdd(&bkt[b], 1u);
+    }
+}
+
+__global__ void add_u32_kernel(u32 *__restrict__ p, u64 n, u32 val)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] += val;
+}
+
+/* ---- neighbour rows on request (transitive reduction) -------------------------------------------------------------- */
+/* both reference words of the rank's own nodes point at the node's exported row (all entries: the sweep filters by type) */
+__global__ void nref_local_kernel(const u64 *__restrict__ start, const u32 *__restrict__ deg, u64 lo, u64 nloc, u64 *__restrict__ nref)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nloc; i += (u64)gridDim.x * blockDim.x) {
+        const u64 r = REF_MAKE(start[i], deg[i]);
+        nref[2 * (lo + i)] = r;
+        nref[2 * (lo + i) + 1] = r;
+    }
+}
+
+/* append the lanes' requests (0xFFFFFFFF = none) to the list: one atomic per wavefront */
+__device__ __forceinline__ void request_append(u32 rq, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+{
+    const bool has = rq != 0xFFFFFFFFu;
+    const u64 mk = __ballot(has);
+    if (!mk) return;
+    u64 base = 0;
+    const u32 leader = (u32)__ffsll((long long)mk) - 1u;
+    if ((threadIdx.x & 63) == leader) base = atomicAdd(n_list, (u64)__popcll(mk));
+    base = readlane_u64(base, leader);
+    if (has) {
+        const u64 pos = base + __popcll(mk & lane_mask_lt());
+        if (pos < cap) list[pos] = rq;
+        else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+    }
+}
+
+/* the (u, cls) a sweep from this entry needs, if u is remote and nobody on this rank has asked for it yet */
+__device__ __forceinline__ u32 request_for(u64 e, u64 lo, u64 hi, u64 *__restrict__ nref)
+{
+    const u64 u = ADJ_DST(e);
+    if (u >= lo && u < hi) return 0xFFFFFFFFu;
+    const u32 cls = (~ADJ_ORI(e)) & 1u;
+    if (atomicCAS(&nref[2 * u + cls], TR_UNAVAIL, TR_REQUESTED) != TR_UNAVAIL) return 0xFFFFFFFFu;
+    return ((u32)u << 1) | cls;
+}
+
+/* round 1: every register-resident node (degree <= 64) asks for the two rows its marking sweeps for certain — slot 0 and the
+ * first slot on the other side of the node (exactly transitive_mark_kernel's speculative pair) */
+__global__ void __launch_bounds__(256) tr_request_first_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, u64 lo, u64 hi,
+                                                               u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+{
+    const u64 nloc = hi - lo;
+    const u64 n64 = (nloc + 63) & ~63ull;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n64; i += (u64)gridDim.x * blockDim.x) {
+        u32 rq0 = 0xFFFFFFFFu, rq2 = 0xFFFFFFFFu;
+        if (i < nloc) {
+            const u64 rv = ref[lo + i];
+            const u32 d = REF_DEG(rv);
+            if (d != 0 && d <= 64) {
+                const u64 *row = adj + REF_POS(rv);
+                const u64 e0 = row[0];
+                const u32 side0 = ADJ_ORI(e0) >> 1;
+                u64 e2 = 0;
+                bool has2 = false;
+                for (u32 s = 1; s < d; s++) {
+                    const u64 e = row[s];
+                    if ((ADJ_ORI(e) >> 1) != side0) {
+                        e2 = e;
+                        has2 = true;
+                        break;
+                    }
+                }
+                rq0 = request_for(e0, lo, hi, nref);
+                if (has2) rq2 = request_for(e2, lo, hi, nref);
+            }
+        }
+        request_append(rq0, list, n_list, cap, ctr);
+        request_append(rq2, list, n_list, cap, ctr);
+    }
+}
+
+/* sum of the degrees of the listed nodes (upper bound of what the request-all round can ask for) */
+__global__ void list_degree_sum_kernel(const u64 *__restrict__ list, u64 n_list, const u64 *__restrict__ ref, u64 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s = 0;
+    for (; i < n_list; i += (u64)gridDim.x * blockDim.x) s += REF_DEG(ref[list[i]]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+__global__ void list_max_degree_kernel(const u64 *__restrict__ list, u64 n_list, const u64 *__restrict__ ref, u64 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 m = 0;
+    for (; i < n_list; i += (u64)gridDim.x * blockDim.x) m = max(m, REF_DEG(ref[list[i]]));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, (u64)m);
+}
+
+/* sum of len[i] - k over the reads [lo, hi): the k-mer probes of the range (disco_counters.probes) */
+__global__ void probes_sum_kernel(const u16 *__restrict__ len, u64 lo, u64 hi, u32 k, u64 *__restrict__ out)
+{
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s = 0;
+    for (; i < hi; i += (u64)gridDim.x * blockDim.x) s += (u64)len[i] - k;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+/* round 2: the listed nodes (deferred by round 1, or beyond the register path) ask for every row they do not have */
+__global__ void __launch_bounds__(64) tr_request_all_kernel(const u64 *__restrict__ nodes, u64 n_nodes, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
+                                                            u64 lo, u64 hi, u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+{
+    for (u64 it = blockIdx.x; it < n_nodes; it += gridDim.x) {
+        const u64 rv = ref[nodes[it]];
+        const u32 d = REF_DEG(rv);
+        const u64 *row = adj + REF_POS(rv);
+        for (u32 s0 = 0; s0 < d; s0 += 64) {
+            const u32 s = s0 + threadIdx.x;
+            u32 rq = 0xFFFFFFFFu;
+            if (s < d) rq = request_for(row[s], lo, hi, nref);
+            request_append(rq, list, n_list, cap, ctr);
+        }
+    }
+}
+
+/* the owner's side: entries of row(u) a sweep of class cls uses (BG/OverlapGraph.cpp:705-708: cls 1 -> types 0/1, cls 0 ->
+ * types 2/3), counted (FILL = false) or written as 4-byte entries at out + pos[i] (FILL = true); one wavefront per request */
+template <bool FILL>
+__global__ void __launch_bounds__(64) tr_respond_kernel(const u32 *__restrict__ req, u64 n_req, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
+                                                        u32 *__restrict__ deg, const u64 *__restrict__ pos, u32 *__restrict__ out)
+{
+    for (u64 i = blockIdx.x; i < n_req; i += gridDim.x) {
+        const u32 rq = req[i];
+        const u64 rv = ref[rq >> 1];
+        const u32 cls = rq & 1u, d = REF_DEG(rv);
+        const u64 *row = adj + REF_POS(rv);
+        u32 n = 0;
+        const u64 base = FILL ? pos[i] : 0ull;
+        for (u32 s0 = 0; s0 < d; s0 += 64) {
+            const u32 s = s0 + threadIdx.x;
+            u64 e = 0;
+            bool ok = false;
+            if (s < d) {
+                e = row[s];
+                ok = (ADJ_ORI(e) >> 1) != cls;
+            }
+            const u64 mk = __ballot(ok);
+            if (FILL && ok) out[base + n + __popcll(mk & lane_mask_lt())] = NBR32_MAKE(e);
+            n += __popcll(mk);
+        }
+        if (!FILL && threadIdx.x == 0) deg[i] = n;
+    }
+}
+
+/* the requester's side: reference words of the rows that came back (pos = exclusive scan of the received degrees) */
+__global__ void nref_remote_kernel(const u32 *__restrict__ req, u64 n_req, const u32 *__restrict__ deg, const u64 *__restrict__ pos, u64 base,
+                                   u64 *__restrict__ nref)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_req; i += (u64)gridDim.x * blockDim.x) nref[2 * (u64)(req[i] >> 1) + (req[i] & 1u)] = REF_MAKE(base + pos[i], deg[i]);
+}
+
+/* ---- emission: surviving half-edges pushed to the owner of the smaller endpoint -------------------------------------- */
+/* An edge (a, b), a < b, is emitted by the owner of a, and survives iff it is unflagged from both ends (BG/OverlapGraph.cpp:
+ * 717-718). The owner of b pushes {a, twin} for each of b's unflagged entries (b -> a) with a on a lower rank; twin = the entry
+ * (a -> b) as it stands in a's own list, so the receiver only has to look it up among a's survivors. Lane = own node b.
+ * FILL = false counts the items. */
+template <bool FILL>
+__global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u64 *__restrict__ half,
+                                                        const u32 *__restrict__ hcnt, const u16 *__restrict__ len, u64 lo, u64 hi,
+                                                        ulonglong2 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+{
+    const u64 nloc = hi - lo;
+    const u64 n64 = (nloc + 63) & ~63ull;
+    const u32 lane = threadIdx.x & 63u;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 mine = 0;
+    /* one candidate per lane and call: the wavefront's items are appended with one atomic */
+    auto push = [&](bool have, u64 e, u64 b, u32 Lb) {
+        const bool take = have && ADJ_DST(e) < lo; /* else: a > b, or a on this rank (judged locally) */
+        const u64 mk = __ballot(take);
+        if (!mk) return;
+        if (!FILL) {
+            if (lane == 0) mine += __popcll(mk);
+            return;
+        }
+        const u32 leader = (u32)__ffsll((long long)mk) - 1u;
+        u64 base = 0;
+        if (lane == leader) base = atomicAdd(n_list, (u64)__popcll(mk));
+        base = readlane_u64(base, leader);
+        if (take) {
+            const u64 p = base + __popcll(mk & lane_mask_lt());
+            if (p < cap) list[p] = make_ulonglong2(ADJ_DST(e), ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lb, b, disco_twin_orient(ADJ_ORI(e)), Lb));
+            else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+        }
+    };
+    for (; i < n64; i += (u64)gridDim.x * blockDim.x) {
+        const bool live = i < nloc;
+        const u64 b = lo + (live ? i : 0);
+        const u32 cnt = live ? hcnt[b] : 0u, Lb = live ? (u32)len[b] : 0u;
+        const bool narrow = cnt <= HALF_CAP;
+#pragma unroll
+        for (u32 r = 0; r < HALF_CAP; r++) {
+            const bool have = narrow && r < cnt;
+            push(have, have ? half[b * HALF_CAP + r] : 0ull, b, Lb);
+        }
+        /* many survivors (rare): the row carries the flags; the wavefront walks the rows of its wide lanes one after the other */
+        u64 wide = __ballot(!narrow);
+        while (wide) {
+            const u32 l = (u32)__ffsll((long long)wide) - 1u;
+            wide &= wide - 1;
+            const u64 bw = readlane_u64(b, l);
+            const u32 Lw = (u32)__builtin_amdgcn_readlane((int)Lb, (int)l);
+            const u64 rv = ref[bw];
+            const u64 *row = adj + REF_POS(rv);
+            const u32 d = REF_DEG(rv);
+            for (u32 s0 = 0; s0 < d; s0 += 64) {
+                const u32 sl = s0 + lane;
+                const u64 e = sl < d ? row[sl] : ADJ_FLAG;
+                push(!(e & ADJ_FLAG), e & ~ADJ_FLAG, bw, Lw);
+            }
+        }
+    }
+    if (!FILL && lane == 0 && mine) atomicAdd(n_list, mine);
+}
+
+/* the receiver: item {a, twin} -> the edge (a, twin) is emitted iff twin is among the survivors of a. Output through the same
+ * wave-private chunks as emit_half_kernel. */
+struct EmitRecvArgs {
+    const ulonglong2 *items;
+    u64 n_items;
+    const u64 *ref;
+    const u64 *adj;
+    const u64 *half;
+    const u32 *hcnt;
+    u64 *out_src;
+    u64 *out_ent;
+    u64 out_cap;
+    u64 *bump;
+    u64 *wq;
+};
+
+__global__ void __launch_bounds__(64) emit_push_recv_kernel(EmitRecvArgs a)
+{
+    const u32 lane = threadIdx.x;
+    u64 chunk_base = 0;
+    u32 chunk_used = EMIT_CHUNK;
+    bool have_chunk = false;
+    auto close_chunk = [&]() {
+        if (have_chunk)
+            for (u32 i = chunk_used + lane; i < EMIT_CHUNK; i += 64)
+                if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
+    };
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.wq, (a.n_items + 63) / 64, cbeg, cend))
+        for (u64 blk = cbeg; blk < cend; blk++) {
+            const u64 i = blk * 64 + lane;
+            bool keep = false;
+            u64 v = 0, twin = 0;
+            if (i < a.n_items) {
+                const ulonglong2 it = a.items[i];
+                v = it.x;
+                twin = it.y;
+                const u32 cw = a.hcnt[v];
+                if (cw <= HALF_CAP) {
+                    const u64 *hw = a.half + v * HALF_CAP;
+                    for (u32 r = 0; r < cw; r++) keep |= (hw[r] == twin);
+                } else {
+                    const u64 rw = a.ref[v];
+                    const u64 *roww = a.adj + REF_POS(rw);
+                    const int ti = adj_find(roww, REF_DEG(rw), twin);
+                    keep = (ti >= 0) && !(roww[ti] & ADJ_FLAG);
+                }
+            }
+            const u64 mk = __ballot(keep);
+            const u32 kc = __popcll(mk);
+            if (kc) {
+                if (chunk_used + kc > EMIT_CHUNK) {
+                    close_chunk();
+                    u64 base = 0;
+                    if (lane == 0) base = atomicAdd(a.bump, (u64)EMIT_CHUNK);
+                    chunk_base = __shfl(base, 0);
+                    chunk_used = 0;
+                    have_chunk = true;
+                }
+                if (keep) {
+                    const u64 pos = chunk_base + chunk_used + __popcll(mk & lane_mask_lt());
+                    if (pos < a.out_cap) {
+                        a.out_src[pos] = v;
+                        a.out_ent[pos] = twin;
+                    }
+                }
+                chunk_used += kc;
+            }
+        }
+    close_chunk();
+}
+
+/* u8 flags of the own range only: everything outside [lo, hi) is not this rank's business (fetch_contained scans all n) */
+__global__ void sum_u32_kernel(const u32 *__restrict__ p, u64 n, u64 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s = 0;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) s += p[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+#endif /* DISCO_DIST_H_ */

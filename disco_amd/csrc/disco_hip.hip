@@ -28,6 +28,8 @@
 
 #include "../../include/disco_hip.h"
 #include "disco_kernels.h"
+#include "disco_dist.h"
+#include "disco_comm.h"
 
 static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
 
@@ -107,12 +109,9 @@ struct disco_ctx {
     u64 okey_cap = 0, oslot_cap = 0, order_cap = 0, ocnt_cap = 0;
     ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
     u64 meta_cap = 0;
-    /* sharded flow, compact exchange: neighbour rows as 4-byte entries in a caller-owned gathered array */
-    const u32 *d_nadj32 = nullptr;
-    u64 *d_nref = nullptr;
+    u64 *d_nref = nullptr; /* multi-GPU flow: reference words nref[2u + cls] of the neighbour-row store */
     u64 nref_cap = 0;
-    bool nbr32 = false;
-    u64 dropped_local = 0, adj_total_global = 0;
+    u64 dropped_local = 0;
     ProbeRare h_probe_rare;
     ProbeRare *d_probe_rare = nullptr;
     u32 max_len = 0; /* longest read (validate_reads) */
@@ -162,6 +161,30 @@ struct disco_ctx {
     float ph_ms[DISCO_PH_COUNT] = {0};
 
     int phase = 0; /* 0 none, 1 reads, 2 index, 3 probe, 4 contained, 5 edges selected, 6 symmetrized, 7 marked, 8 emitted */
+
+    /* multi-GPU flow (disco_comm_* / disco_dist_*): one context per rank */
+    DiscoComm *comm = nullptr;
+    u64 per = 0;        /* nodes per rank: ceil(n / world) rounded up to a multiple of 64 */
+    u64 n_alloc = 0;    /* rows of the per-read tables (n on one GPU, world * per in the multi-GPU flow) */
+    bool dist_reads = false;   /* the read table was set through disco_dist_*: rows [q_lo, q_hi) are this rank's */
+    bool dist_active = false;  /* the current pass is a multi-GPU pass in the regular regime (emission judges local pairs only) */
+    u64 *d_route = nullptr;    /* [2 * DIST_MAX_WORLD] counters / cursors of the routing kernels */
+    ulonglong2 *d_x16a = nullptr, *d_x16b = nullptr; /* 16-byte items: send (partitioned) / receive */
+    u64 x16a_cap = 0, x16b_cap = 0;
+    u32 *d_req_flat = nullptr, *d_req_s = nullptr, *d_req_r = nullptr; /* row requests: flat list, partitioned, received */
+    u64 req_flat_cap = 0, req_s_cap = 0, req_r_cap = 0;
+    u32 *d_rdeg_s = nullptr, *d_rdeg_r = nullptr, *d_rdata_s = nullptr; /* responses: degrees out / back, entries out */
+    u64 rdeg_s_cap = 0, rdeg_r_cap = 0, rdata_s_cap = 0;
+    u64 *d_rpos = nullptr;
+    u64 rpos_cap = 0;
+    u32 *d_nadj32_own = nullptr; /* neighbour-row store: own rows | rows fetched in round 1 | round 2 */
+    u64 nadj_cap = 0, nadj_used = 0;
+    u32 *d_deg_tmp = nullptr;
+    u64 deg_tmp_cap = 0;
+    u64 *d_list_n = nullptr; /* length of the flat list being built */
+    ulonglong2 *d_push_r = nullptr; /* received half-edge pushes (alias of d_x16b while a pass is in flight) */
+    u64 n_push_r = 0;
+    disco_dist_info dinfo{};
 };
 
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -342,7 +365,7 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_ent, c->ent_cap);
     dev_free(c, &c->d_rec, c->rec_cap);
     c->bkt_cap = c->ent_cap = c->rec_cap = 0;
-    dev_free(c, &c->d_best, c->n);
+    dev_free(c, &c->d_best, c->n_alloc);
     dev_free(c, &c->d_hits, c->hits_cap);
     c->hits_cap = 0;
     dev_free(c, &c->d_row_start, c->n);
@@ -350,8 +373,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_big_list, c->big_cap);
     dev_free(c, &c->d_big_cnt, c->big_cap);
     c->big_cap = 0;
-    dev_free(c, &c->d_contained, c->n);
-    dev_free(c, &c->d_cbits, c->n / 64 + 1);
+    dev_free(c, &c->d_contained, c->n_alloc);
+    dev_free(c, &c->d_cbits, c->n_alloc / 64 + 1);
     dev_free(c, &c->d_adj_ref, c->n);
     dev_free(c, &c->d_adj_own, c->adj_cap);
     dev_free(c, &c->d_start_tmp, c->start_cap);
@@ -366,8 +389,6 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_order_own, c->order_cap);
     c->okey_cap = c->oslot_cap = c->order_cap = c->ocnt_cap = 0;
     c->d_order_used = nullptr;
-    c->d_nadj32 = nullptr;
-    c->nbr32 = false;
     c->d_adj = nullptr;
     dev_free(c, &c->d_extra_cnt, c->n);
     dev_free(c, &c->d_extra_node, c->extra_cap);
@@ -388,13 +409,28 @@ static void free_graph_state(disco_ctx *c)
     c->flags_pending = false;
     c->adj_imported = false;
     c->T = 0;
+    dev_free(c, &c->d_x16a, c->x16a_cap);
+    dev_free(c, &c->d_x16b, c->x16b_cap);
+    dev_free(c, &c->d_req_flat, c->req_flat_cap);
+    dev_free(c, &c->d_req_s, c->req_s_cap);
+    dev_free(c, &c->d_req_r, c->req_r_cap);
+    dev_free(c, &c->d_rdeg_s, c->rdeg_s_cap);
+    dev_free(c, &c->d_rdeg_r, c->rdeg_r_cap);
+    dev_free(c, &c->d_rdata_s, c->rdata_s_cap);
+    dev_free(c, &c->d_rpos, c->rpos_cap);
+    dev_free(c, &c->d_nadj32_own, c->nadj_cap);
+    dev_free(c, &c->d_deg_tmp, c->deg_tmp_cap);
+    c->x16a_cap = c->x16b_cap = c->req_flat_cap = c->req_s_cap = c->req_r_cap = c->rdeg_s_cap = c->rdeg_r_cap = c->rdata_s_cap = 0;
+    c->rpos_cap = c->nadj_cap = c->nadj_used = c->deg_tmp_cap = 0;
+    c->d_push_r = nullptr;
+    c->n_push_r = 0;
 }
 
 static void free_reads(disco_ctx *c)
 {
     if (c->reads_owned) {
-        dev_free(c, &c->d_reads, c->n * (u64)c->S);
-        dev_free(c, &c->d_len, c->n);
+        dev_free(c, &c->d_reads, c->n_alloc * (u64)c->S);
+        dev_free(c, &c->d_len, c->n_alloc);
     }
     c->d_reads = nullptr;
     c->d_len = nullptr;
@@ -469,6 +505,10 @@ void disco_destroy(disco_ctx *c)
     (void)hipFree(c->d_n_big);
     (void)hipFree(c->d_n_extra);
     dev_free(c, &c->d_probe_rare, 1);
+    dev_free(c, &c->d_route, 2 * DIST_MAX_WORLD);
+    dev_free(c, &c->d_list_n, 1);
+    delete c->comm;
+    c->comm = nullptr;
     for (int i = 0; i < DISCO_PH_COUNT; i++) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -533,6 +573,9 @@ static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride)
     free_graph_state(c);
     free_reads(c);
     c->n = n;
+    c->n_alloc = n;
+    c->dist_reads = false;
+    c->dist_active = false;
     c->S = (int)stride;
     c->q_lo = 0;
     c->q_hi = n;
@@ -596,7 +639,7 @@ int disco_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
     c->reads_owned = true;
     disco_genspec g;
     memcpy(&g, s, sizeof g);
-    if (c->n) hipLaunchKernelGGL(generate_reads_kernel, dim3(flat_grid(c, c->n * stride)), dim3(256), 0, c->stream, g, c->d_reads, c->d_len, (int)stride);
+    if (c->n) hipLaunchKernelGGL(generate_reads_kernel, dim3(flat_grid(c, c->n * stride)), dim3(256), 0, c->stream, g, c->d_reads, c->d_len, (int)stride, (u64)0, c->n);
     HIPCHK(c, hipGetLastError());
     return validate_reads(c);
 }
@@ -652,7 +695,7 @@ int disco_build_index(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
     ulonglong2 *rec = c->d_rec;
     CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n)); /* grouping keys of all reads (disco_probe orders its query range by them) */
-    if (c->n) hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey);
+    if (c->n) hipLaunchKernelGGL(index_count_kernel<true>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, (u64)0, c->n);
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt, T + 1, c->d_bkt, false, nullptr)));
     if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
@@ -669,11 +712,11 @@ int disco_probe(disco_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
     if (!c->d_best) {
-        CHK(dev_alloc(c, &c->d_best, c->n));
+        CHK(dev_alloc(c, &c->d_best, c->n_alloc));
         CHK(dev_alloc(c, &c->d_row_start, c->n));
         CHK(dev_alloc(c, &c->d_row_cnt, c->n));
     }
-    if (c->n) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, DISCO_NOKEY);
+    if (c->n_alloc) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n_alloc)), dim3(256), 0, c->stream, c->d_best, c->n_alloc, DISCO_NOKEY);
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
     const bool ldsrow = c->S <= PROBE_ACAP;
     const bool row17 = c->k - view(c).m == 16 && !getenv("DISCO_NO_ROW17"); /* window = 17 m-mers: DPP row-scan variant */
@@ -818,22 +861,14 @@ int disco_probe(disco_ctx *c)
     return fail(c, DISCO_E_CAPACITY, "disco_probe: hit buffer could not be sized");
 }
 
-int disco_contain_keys(disco_ctx *c, void **d_keys, uint64_t *n)
-{
-    if (!c || !d_keys || !n) return DISCO_E_ARG;
-    if (c->phase < 3) return fail(c, DISCO_E_STATE, "disco_contain_keys: run disco_probe first");
-    *d_keys = c->d_best;
-    *n = c->n;
-    return DISCO_OK;
-}
 
 int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
 {
     if (!c) return DISCO_E_ARG;
     if (c->phase < 3) return fail(c, DISCO_E_STATE, "disco_mark_contained: run disco_probe first");
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n));
-    if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n / 64 + 1));
+    if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
+    if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
     CHK(zero_counter(c, CTR_N_CONTAINED));
     ph_begin(c, DISCO_PH_CONTAIN);
     if (c->n) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
@@ -925,7 +960,6 @@ static int select_edges(disco_ctx *c)
         CHK(rc);
     }
     c->dropped = c->dropped_local = c->h_ctr[CTR_DROPPED];
-    c->nbr32 = false;
     if (getenv("DISCO_VERBOSE"))
         fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
                 (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
@@ -1143,68 +1177,9 @@ int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
     return DISCO_OK;
 }
 
-int disco_export_adjacency32(disco_ctx *c, void *d_deg_u32, void *d_entries_u32)
-{
-    if (!c || !d_deg_u32) return DISCO_E_ARG;
-    if (c->phase < 5 || c->adj_imported) return fail(c, DISCO_E_STATE, "disco_export_adjacency32: needs the locally selected edges");
-    if (c->n >= (1ull << 30)) return fail(c, DISCO_E_ARG, "disco_export_adjacency32: needs fewer than 2^30 reads");
-    HIPCHK(c, hipSetDevice(c->device));
-    const u64 nq = c->q_hi - c->q_lo;
-    ph_begin(c, DISCO_PH_CSR);
-    if (nq) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_adj_ref, c->q_lo, c->q_hi, (u32 *)d_deg_u32);
-    HIPCHK(c, hipGetLastError());
-    if (nq && c->adj_total && d_entries_u32) {
-        CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, c->n + 1));
-        u64 total = 0;
-        int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32, nq, c->d_start_tmp, true, &total);
-        if (rc == DISCO_OK && total != c->adj_total) rc = fail(c, DISCO_E_STATE, "disco_export_adjacency32: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
-        if (rc == DISCO_OK) hipLaunchKernelGGL(rows_gather32_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, c->q_lo, c->q_hi, c->d_start_tmp, (u32 *)d_entries_u32);
-        hipError_t e = hipStreamSynchronize(c->stream);
-        CHK(rc);
-        if (e != hipSuccess) return fail(c, DISCO_E_HIP, "disco_export_adjacency32: %s", hipGetErrorString(e));
-    }
-    ph_end(c, DISCO_PH_CSR);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    ph_collect(c);
-    return DISCO_OK;
-}
 
-int disco_adopt_neighbours32(disco_ctx *c, const void *d_deg_u32_all, const void *d_rows_u32_padded, uint64_t per_rank_nodes, uint64_t max_per_rank, uint32_t world)
-{
-    if (!c || !d_deg_u32_all || !world || !per_rank_nodes) return DISCO_E_ARG;
-    if (c->phase < 5 || c->adj_imported) return fail(c, DISCO_E_STATE, "disco_adopt_neighbours32: needs the locally selected edges");
-    if ((u64)world * per_rank_nodes < c->n) return fail(c, DISCO_E_ARG, "disco_adopt_neighbours32: world*per (%llu) < reads (%llu)", (unsigned long long)((u64)world * per_rank_nodes), (unsigned long long)c->n);
-    HIPCHK(c, hipSetDevice(c->device));
-    const u64 slots = (u64)world * per_rank_nodes;
-    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, slots + 1));
-    CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, c->n + 1));
-    u64 total = 0;
-    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, slots, c->d_start_tmp, true, &total)));
-    if (c->n) hipLaunchKernelGGL(ref_from_padded_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_start_tmp, (const u32 *)d_deg_u32_all, c->n, per_rank_nodes, max_per_rank, c->d_nref);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->d_nadj32 = (const u32 *)d_rows_u32_padded;
-    c->nbr32 = true;
-    c->adj_total_global = total;
-    c->half_complete = false;
-    return DISCO_OK;
-}
 
-int disco_dropped_hits(disco_ctx *c, uint64_t *n_local)
-{
-    if (!c || !n_local) return DISCO_E_ARG;
-    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_dropped_hits: select edges first");
-    *n_local = c->dropped_local;
-    return DISCO_OK;
-}
 
-int disco_set_global_dropped(disco_ctx *c, uint64_t n_all_ranks)
-{
-    if (!c) return DISCO_E_ARG;
-    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_set_global_dropped: select edges first");
-    c->dropped = n_all_ranks;
-    return DISCO_OK;
-}
 
 int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all)
 {
@@ -1231,53 +1206,8 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     return DISCO_OK;
 }
 
-/* Sharded flow without copies: the caller all-gathers the shards IN PLACE into rank-major padded device buffers and the
- * context addresses them where they lie. d_deg_u32_all[v] = degree of node v (world*per entries, v = r*per + i);
- * d_rows_u64_padded[r*max_per_rank ...] = rows of rank r's nodes in node order. The buffers stay the caller's and must
- * live until the pass is over; transitive marking sets flag bits in them. */
-int disco_adopt_adjacency(disco_ctx *c, const void *d_deg_u32_all, void *d_rows_u64_padded, uint64_t per_rank_nodes, uint64_t max_per_rank, uint32_t world)
-{
-    if (!c || !d_deg_u32_all || !world || !per_rank_nodes) return DISCO_E_ARG;
-    if (c->phase < 5) return fail(c, DISCO_E_STATE, "disco_adopt_adjacency: select edges first");
-    if ((u64)world * per_rank_nodes < c->n) return fail(c, DISCO_E_ARG, "disco_adopt_adjacency: world*per (%llu) < reads (%llu)", (unsigned long long)((u64)world * per_rank_nodes), (unsigned long long)c->n);
-    HIPCHK(c, hipSetDevice(c->device));
-    const u64 slots = (u64)world * per_rank_nodes;
-    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, slots + 1));
-    u64 total = 0;
-    CHK((scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32_all, slots, c->d_start_tmp, true, &total)));
-    if (c->n) hipLaunchKernelGGL(ref_from_padded_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_start_tmp, (const u32 *)d_deg_u32_all, c->n, per_rank_nodes, max_per_rank, c->d_adj_ref);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->d_adj = (u64 *)d_rows_u64_padded;
-    c->adj_total = total;
-    c->adj_span = (u64)world * max_per_rank;
-    c->adj_imported = true;
-    c->nbr32 = false;
-    c->half_complete = false;
-    c->phase = 5;
-    return DISCO_OK;
-}
 
-/* survivor lists of disco_transitive_mark: half = u64[n][4] (first 4 unflagged entries of a node in list order),
- * hcnt = u32[n]; n_wide = nodes of the local range with more than 4. In the sharded flow ranks all-gather their ranges of
- * both arrays and then call disco_half_complete(ctx, 1); the emission then needs neither rows nor flags of other ranks. */
-int disco_half_lists(disco_ctx *c, void **d_half, void **d_hcnt, uint64_t *n_wide)
-{
-    if (!c || !d_half || !d_hcnt || !n_wide) return DISCO_E_ARG;
-    if (c->phase < 7 || !c->use_half) return fail(c, DISCO_E_STATE, "disco_half_lists: run disco_transitive_mark first (survivor lists enabled)");
-    *d_half = c->d_half;
-    *d_hcnt = c->d_hcnt;
-    *n_wide = c->n_wide;
-    return DISCO_OK;
-}
 
-int disco_half_complete(disco_ctx *c, int complete)
-{
-    if (!c) return DISCO_E_ARG;
-    if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_half_complete: run disco_transitive_mark first");
-    c->half_complete = complete != 0;
-    return DISCO_OK;
-}
 
 /* ---------------------------------------------------------------------------------------------------------------- */
 int disco_transitive_mark(disco_ctx *c)
@@ -1317,15 +1247,12 @@ int disco_transitive_mark(disco_ctx *c)
     a.wide_list = c->d_wide;
     a.n_wide = c->d_n_wide;
     a.wide_cap = c->wide_cap;
-    a.nref = c->nbr32 ? c->d_nref : nullptr;
-    a.nadj32 = c->nbr32 ? c->d_nadj32 : nullptr;
-    /* every row needs its flags whenever another rank may ask for them (any sharded flow) or there are no survivor lists */
-    a.all_flags = (c->adj_imported || c->nbr32 || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
+    a.nref = nullptr;
+    a.nadj32 = nullptr;
+    /* every row needs its flags when the emission cannot rely on the survivor lists alone */
+    a.all_flags = (c->adj_imported || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
-    if (nq) {
-        if (c->nbr32) hipLaunchKernelGGL((transitive_mark_kernel<false, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
-    }
+    if (nq) hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
@@ -1353,8 +1280,7 @@ int disco_transitive_mark(disco_ctx *c)
         a.scratch = (u64 *)scratch;
         a.hcap = hcap;
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-        if (c->nbr32) hipLaunchKernelGGL((transitive_mark_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL((transitive_mark_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL((transitive_mark_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
         hipError_t e2 = hipStreamSynchronize(c->stream);
         dev_free(c, &scratch, (u64)g2 * per);
@@ -1369,37 +1295,6 @@ int disco_transitive_mark(disco_ctx *c)
     return DISCO_OK;
 }
 
-/* Sharded flow only (adjacency imported): the transitive flags of this rank's slots [slot_lo, slot_hi) of the gathered CSR
- * are extracted into a byte array of `total` slots; ranks all-gather those byte ranges in place, then disco_emit_edges
- * ORs the complete array back into the entries. */
-int disco_tr_flags(disco_ctx *c, void **d_flags, uint64_t *slot_lo, uint64_t *slot_hi, uint64_t *total)
-{
-    if (!c || !d_flags || !slot_lo || !slot_hi || !total) return DISCO_E_ARG;
-    if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_tr_flags: run disco_transitive_mark first");
-    if (!c->adj_imported) return fail(c, DISCO_E_STATE, "disco_tr_flags: only meaningful after disco_import_adjacency (the flags of a single-GPU run live in the entries)");
-    HIPCHK(c, hipSetDevice(c->device));
-    /* the local rows are contiguous in both sharded layouts: from the first local node's position to the end of the last one */
-    u64 lo = 0, hi = 0, r = 0;
-    if (c->q_lo < c->q_hi) {
-        HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + c->q_lo, 8, hipMemcpyDeviceToHost));
-        lo = REF_POS(r);
-        HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + (c->q_hi - 1), 8, hipMemcpyDeviceToHost));
-        hi = REF_POS(r) + REF_DEG(r);
-    }
-    CHK(ensure_cap(c, &c->d_flag, &c->flag_cap, c->adj_span));
-    if (!c->flags_pending) {
-        HIPCHK(c, hipMemsetAsync(c->d_flag, 0, std::max<u64>(c->adj_span, 1), c->stream));
-        if (hi > lo) hipLaunchKernelGGL(flags_extract_kernel, dim3(flat_grid(c, hi - lo)), dim3(256), 0, c->stream, c->d_adj, lo, hi, c->d_flag);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->flags_pending = true;
-    }
-    *d_flags = c->d_flag;
-    *slot_lo = lo;
-    *slot_hi = hi;
-    *total = c->adj_span;
-    return DISCO_OK;
-}
 
 int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
 {
@@ -1408,13 +1303,11 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
     HIPCHK(c, hipSetDevice(c->device));
     const u64 nq = c->q_hi - c->q_lo;
     ph_begin(c, DISCO_PH_EMIT);
-    if (c->flags_pending) { /* gathered flags of all ranks -> entries */
-        if (c->adj_span) hipLaunchKernelGGL(flags_apply_kernel, dim3(flat_grid(c, c->adj_span)), dim3(256), 0, c->stream, c->d_adj, c->adj_span, c->d_flag);
-        c->flags_pending = false;
-    }
     const int grid = wq_grid(c, emit_kernel, nq, "DISCO_EMIT_WAVES");
-    const u64 nwaves = (u64)grid * 2; /* emit_half_kernel + emit_kernel */
-    u64 want = std::max<u64>(2 * nq, 1024) + nwaves * EMIT_CHUNK;
+    const u64 n_push = c->dist_active ? c->n_push_r : 0; /* multi-GPU flow: survivors pushed by the owners of the larger endpoints */
+    const int grid_push = (int)std::max<u64>(std::min<u64>((n_push + 63) / 64, (u64)c->n_cu * 16), 1);
+    const u64 nwaves = (u64)grid * 2 + (n_push ? (u64)grid_push : 0); /* emit_half_kernel + emit_kernel (+ emit_push_recv_kernel) */
+    u64 want = std::max<u64>(2 * nq, 1024) + n_push + nwaves * EMIT_CHUNK;
     for (int attempt = 0; attempt < 6; attempt++) {
         if (!c->d_out_src || want > c->out_cap) {
             dev_free(c, &c->d_out_src, c->out_cap);
@@ -1437,6 +1330,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             h.out_ent = c->d_out_ent;
             h.out_cap = c->out_cap;
             h.bump = c->d_bump;
+            h.local_only = c->dist_active ? 1u : 0u;
             const int gh = wq_grid(c, emit_half_kernel, (nq + 63) / 64, "DISCO_EMIT_WAVES");
             hipLaunchKernelGGL(emit_half_kernel, dim3(gh), dim3(64), 0, c->stream, h);
         }
@@ -1453,8 +1347,25 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.out_ent = c->d_out_ent;
         a.out_cap = c->out_cap;
         a.bump = c->d_bump;
+        a.local_only = c->dist_active ? 1u : 0u;
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq && !(listed && c->n_wide == 0)) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(64), 0, c->stream, a);
+        if (n_push) {
+            EmitRecvArgs pr;
+            pr.items = c->d_push_r;
+            pr.n_items = n_push;
+            pr.ref = c->d_adj_ref;
+            pr.adj = c->d_adj;
+            pr.half = c->d_half;
+            pr.hcnt = c->d_hcnt;
+            pr.out_src = c->d_out_src;
+            pr.out_ent = c->d_out_ent;
+            pr.out_cap = c->out_cap;
+            pr.bump = c->d_bump;
+            pr.wq = c->d_wq;
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL(emit_push_recv_kernel, dim3(grid_push), dim3(64), 0, c->stream, pr);
+        }
         HIPCHK(c, hipGetLastError());
         u64 used = 0;
         HIPCHK(c, hipMemcpyAsync(&used, c->d_bump, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -1807,6 +1718,727 @@ int disco_get_counters(disco_ctx *c, disco_counters *o)
     o->big_rows = c->big_rows;
     o->index_buckets = c->T;
     o->hbm_bytes = c->hbm_bytes;
+    return DISCO_OK;
+}
+
+} /* extern "C" */
+
+/* ================================================================================================================
+ * multi-GPU flow (include/disco_hip.h "multi-GPU flow"; kernels: disco_dist.h; transport: disco_comm.h)
+ *
+ * One pass on rank r of G (own = [r*per, (r+1)*per) ∩ [0, n)):
+ *   0. [flag] all-gather of the packed reads               every rank verifies candidates against any read
+ *   1. index records of the OWN reads (no atomics)  →  all-to-all to the owner of their bucket range  →  the owner counts,
+ *      scans and fills its shard straight into its slice of the global table  →  all-gather-v of the bkt / ent slices
+ *   2. grouping + probe + verify of the own reads (unchanged kernels)
+ *   3. reduce-scatter(MIN) of the containment keys, flags of the own range, all-gather of the bitmap
+ *   4. edge selection of the own reads
+ *   5. regular regime (no rank dropped a verified hit): rows of the neighbours a node's marking sweeps are requested from
+ *      their owners, class-filtered 4-byte entries come back; marking; nodes that needed a row nobody had asked for are redone
+ *      after a second, request-everything round
+ *   6. surviving half-edges pushed to the owner of the smaller endpoint; emission
+ *   order-dependent regime (some rank dropped a hit: per-k-mer cap, second hit to a destination): the whole adjacency is
+ *   gathered and every rank completes, marks and judges all lists itself (exact, not scalable; never on BASELINE data)
+ * ============================================================================================================== */
+using HClock = std::chrono::steady_clock;
+static float ms_since(HClock::time_point t0) { return std::chrono::duration<float, std::milli>(HClock::now() - t0).count(); }
+
+#define COMM_CHK(c, expr)                                                                        \
+    do {                                                                                         \
+        int rc_ = (expr);                                                                        \
+        if (rc_ != DISCO_OK) return fail((c), rc_, "%s: %s", #expr, (c)->comm->err.c_str());    \
+    } while (0)
+
+/* grow-only buffer that keeps its first `used` elements */
+template <typename T>
+static int ensure_cap_keep(disco_ctx *c, T **p, u64 *cap, u64 need, u64 used)
+{
+    if (*p && need <= *cap) return DISCO_OK;
+    T *q = nullptr;
+    const u64 ncap = std::max<u64>(need + need / 8, 1);
+    CHK(dev_alloc(c, &q, ncap));
+    if (*p && used) HIPCHK(c, hipMemcpyAsync(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c, p, *cap);
+    *p = q;
+    *cap = ncap;
+    return DISCO_OK;
+}
+
+static void dist_range(const disco_ctx *c, u64 n, u64 *per, u64 *lo, u64 *hi)
+{
+    const u64 G = c->comm ? (u64)c->comm->world : 1, r = c->comm ? (u64)c->comm->rank : 0;
+    u64 p = (n + G - 1) / G;
+    p = (p + 63) & ~63ull;
+    if (p == 0) p = 64;
+    *per = p;
+    *lo = std::min(r * p, n);
+    *hi = std::min(*lo + p, n);
+}
+
+/* partition items[0..n) into one segment per destination rank: out = segments in rank order, cnt[g] = items for rank g */
+template <typename T, typename F>
+static int route_items(disco_ctx *c, const T *items, u64 n, F owner, T *out, std::vector<u64> &cnt)
+{
+    const u32 G = (u32)c->comm->world;
+    cnt.assign(G, 0);
+    if (!c->d_route) CHK(dev_alloc(c, &c->d_route, 2 * DIST_MAX_WORLD));
+    HIPCHK(c, hipMemsetAsync(c->d_route, 0, 2 * DIST_MAX_WORLD * sizeof(u64), c->stream));
+    if (n) hipLaunchKernelGGL((route_count_kernel<T, F>), dim3(flat_grid(c, n)), dim3(256), 0, c->stream, items, n, owner, G, c->d_route);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_route, G * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 cur[DIST_MAX_WORLD], acc = 0;
+    for (u32 g = 0; g < G; g++) {
+        cur[g] = acc;
+        acc += cnt[g];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_route + DIST_MAX_WORLD, cur, G * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    if (n) hipLaunchKernelGGL((route_scatter_kernel<T, F>), dim3(flat_grid(c, (n + ROUTE_ITEMS - 1) / ROUTE_ITEMS)), dim3(256), 0, c->stream, items, n, owner, G,
+                              c->d_route + DIST_MAX_WORLD, out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* `cur` is a stack array */
+    return DISCO_OK;
+}
+
+/* rcnt[p] = what rank p sends to this rank, from everybody's send counts */
+static int exchange_counts(disco_ctx *c, const std::vector<u64> &scnt, std::vector<u64> &rcnt, std::vector<u64> *matrix = nullptr)
+{
+    const int G = c->comm->world;
+    std::vector<u64> all((size_t)G * G);
+    COMM_CHK(c, c->comm->host_all_gather((const unsigned long long *)scnt.data(), G, (unsigned long long *)all.data(), c->stream));
+    rcnt.resize((size_t)G);
+    for (int p = 0; p < G; p++) rcnt[(size_t)p] = all[(size_t)p * G + c->comm->rank];
+    if (matrix) *matrix = std::move(all);
+    return DISCO_OK;
+}
+
+/* all-to-all of item segments (elem bytes per item), both sides compact in rank order */
+static int a2a_items(disco_ctx *c, int xid, const void *send, const std::vector<u64> &scnt, void *recv, const std::vector<u64> &rcnt, size_t elem)
+{
+    const int G = c->comm->world;
+    std::vector<size_t> so((size_t)G), sc((size_t)G), ro((size_t)G), rc((size_t)G);
+    size_t a = 0, b = 0;
+    for (int p = 0; p < G; p++) {
+        so[(size_t)p] = a;
+        sc[(size_t)p] = scnt[(size_t)p] * elem;
+        a += sc[(size_t)p];
+        ro[(size_t)p] = b;
+        rc[(size_t)p] = rcnt[(size_t)p] * elem;
+        b += rc[(size_t)p];
+        if (p != c->comm->rank) c->dinfo.bytes_sent[xid] += sc[(size_t)p];
+    }
+    const auto t0 = HClock::now();
+    COMM_CHK(c, c->comm->all_to_all_v(send, so.data(), sc.data(), recv, ro.data(), rc.data(), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->dinfo.ms[xid] += ms_since(t0);
+    return DISCO_OK;
+}
+
+static u64 vsum(const std::vector<u64> &v)
+{
+    u64 s = 0;
+    for (u64 x : v) s += x;
+    return s;
+}
+
+/* sum / max of a few host values over all ranks */
+static int host_reduce(disco_ctx *c, u64 *vals, int n, bool take_max = false)
+{
+    const int G = c->comm->world;
+    std::vector<u64> all((size_t)G * n);
+    COMM_CHK(c, c->comm->host_all_gather((const unsigned long long *)vals, n, (unsigned long long *)all.data(), c->stream));
+    for (int i = 0; i < n; i++) {
+        u64 a = 0;
+        for (int p = 0; p < G; p++) a = take_max ? std::max(a, all[(size_t)p * n + i]) : a + all[(size_t)p * n + i];
+        vals[i] = a;
+    }
+    return DISCO_OK;
+}
+
+/* ---- 1. hash-partitioned index build ------------------------------------------------------------------------------- */
+static int dist_build_index(disco_ctx *c)
+{
+    const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    const u64 nloc = c->q_hi - c->q_lo;
+    u64 T = 1024;
+    int logT = 10;
+    double tscale = 2.0;
+    if (const char *e = getenv("DISCO_BUCKET_SCALE")) tscale = atof(e);
+    while ((double)T < tscale * (double)c->n && logT < 32) {
+        T <<= 1;
+        logT++;
+    }
+    c->T = T;
+    c->bshift = 64 - logT;
+    CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
+    CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
+    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n));
+    CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, std::max<u64>(2 * nloc, 1)));
+    c->adj_imported = false;
+    ph_begin(c, DISCO_PH_INDEX);
+    DiscoView v = view(c);
+    if (nloc) hipLaunchKernelGGL(index_count_kernel<false>, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, c->stream, v, c->d_bkt, c->d_rec, c->d_okey, c->q_lo, c->q_hi);
+    HIPCHK(c, hipGetLastError());
+    /* records -> owner of their bucket range */
+    CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nloc, 1)));
+    std::vector<u64> scnt, rcnt, matrix;
+    RouteByBucket f{logT, G};
+    CHK(route_items(c, c->d_rec, 2 * nloc, f, c->d_x16a, scnt));
+    CHK(exchange_counts(c, scnt, rcnt, &matrix));
+    const u64 nrec = vsum(rcnt);
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nrec, 1)));
+    CHK(a2a_items(c, DISCO_X_INDEX_RECORDS, c->d_x16a, scnt, c->d_x16b, rcnt, sizeof(ulonglong2)));
+    /* my bucket range and the position of my records in the global record array (shards in rank order) */
+    auto blo_of = [&](u64 g) { return (g * T + G - 1) / G; };
+    const u64 blo = blo_of(r), bhi = blo_of(r + 1);
+    std::vector<u64> shard((size_t)G, 0);
+    for (u32 p = 0; p < G; p++)
+        for (u32 q = 0; q < G; q++) shard[q] += matrix[(size_t)p * G + q];
+    u64 base = 0;
+    for (u32 q = 0; q < r; q++) base += shard[q];
+    if (shard[r] != nrec) return fail(c, DISCO_E_STATE, "index shard: %llu records received, %llu announced", (unsigned long long)nrec, (unsigned long long)shard[r]);
+    if (vsum(shard) != 2 * c->n) return fail(c, DISCO_E_STATE, "index: %llu records over all ranks, expected %llu", (unsigned long long)vsum(shard), (unsigned long long)(2 * c->n));
+    if (bhi > blo) HIPCHK(c, hipMemsetAsync(c->d_bkt + blo, 0, (bhi - blo) * sizeof(u32), c->stream));
+    if (nrec) hipLaunchKernelGGL(shard_count_kernel, dim3(flat_grid(c, nrec)), dim3(256), 0, c->stream, c->d_x16b, nrec, c->d_bkt);
+    if (bhi > blo) {
+        CHK((scan_exclusive<u32, u32>(c, c->d_bkt + blo, bhi - blo, c->d_bkt + blo, false, nullptr)));
+        if (base) hipLaunchKernelGGL(add_u32_kernel, dim3(flat_grid(c, bhi - blo)), dim3(256), 0, c->stream, c->d_bkt + blo, bhi - blo, (u32)base);
+    }
+    if (nrec) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, nrec)), dim3(256), 0, c->stream, nrec, c->d_x16b, c->d_bkt, c->d_ent);
+    const u32 total = (u32)(2 * c->n);
+    HIPCHK(c, hipMemcpyAsync(c->d_bkt + T, &total, sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* shards -> everybody (in place: every rank wrote its slices where they belong) */
+    {
+        std::vector<size_t> off((size_t)G), cnt((size_t)G);
+        const auto t0 = HClock::now();
+        for (u32 p = 0; p < G; p++) {
+            off[p] = blo_of(p) * sizeof(u32);
+            cnt[p] = (blo_of(p + 1) - blo_of(p)) * sizeof(u32);
+            if (p != r) c->dinfo.bytes_sent[DISCO_X_INDEX_SHARDS] += cnt[r];
+        }
+        COMM_CHK(c, c->comm->all_gather_v(c->d_bkt + blo, c->d_bkt, off.data(), cnt.data(), c->stream));
+        size_t a = 0;
+        for (u32 p = 0; p < G; p++) {
+            off[p] = a;
+            cnt[p] = shard[p] * sizeof(u64);
+            a += cnt[p];
+            if (p != r) c->dinfo.bytes_sent[DISCO_X_INDEX_SHARDS] += cnt[r];
+        }
+        COMM_CHK(c, c->comm->all_gather_v(c->d_ent + base, c->d_ent, off.data(), cnt.data(), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->dinfo.ms[DISCO_X_INDEX_SHARDS] += ms_since(t0);
+    }
+    ph_end(c, DISCO_PH_INDEX);
+    c->phase = 2;
+    return DISCO_OK;
+}
+
+/* ---- 3. containment: smallest key wins across ranks, flags of the own range, bitmap to everybody -------------------- */
+static int dist_mark_contained(disco_ctx *c)
+{
+    const u32 G = (u32)c->comm->world;
+    const u64 lo = c->q_lo, nloc = c->q_hi - c->q_lo, per = c->per;
+    if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
+    if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
+    const auto t0 = HClock::now();
+    COMM_CHK(c, c->comm->reduce_scatter_min_i64(c->d_best, per, c->stream));
+    c->dinfo.bytes_sent[DISCO_X_CONTAIN] += (u64)(G - 1) * per * 8;
+    CHK(zero_counter(c, CTR_N_CONTAINED));
+    ph_begin(c, DISCO_PH_CONTAIN);
+    HIPCHK(c, hipMemsetAsync(c->d_contained, 0, std::max<u64>(c->n_alloc, 1), c->stream));
+    const u64 r = (u64)c->comm->rank;
+    HIPCHK(c, hipMemsetAsync(c->d_cbits + r * per / 64, 0, per / 8, c->stream));
+    if (nloc) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_best + lo, nloc, c->d_contained + lo, c->d_cbits + lo / 64, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    COMM_CHK(c, c->comm->all_gather(c->d_cbits + r * per / 64, c->d_cbits, per / 8, c->stream));
+    c->dinfo.bytes_sent[DISCO_X_CONTAIN] += (u64)(G - 1) * per / 8;
+    ph_end(c, DISCO_PH_CONTAIN);
+    CHK(read_counters(c));
+    ph_collect(c);
+    c->dinfo.ms[DISCO_X_CONTAIN] += ms_since(t0);
+    c->n_contained = c->h_ctr[CTR_N_CONTAINED]; /* own range: what disco_fetch_contained returns */
+    c->phase = 4;
+    return DISCO_OK;
+}
+
+/* ---- 5. neighbour rows on request ------------------------------------------------------------------------------------ */
+/* one request round: the flat list of (u, cls) requests in d_req_flat -> rows appended to the neighbour-row store, nref set */
+static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
+{
+    const u32 G = (u32)c->comm->world;
+    std::vector<u64> scnt, rcnt;
+    CHK(ensure_cap(c, &c->d_req_s, &c->req_s_cap, std::max<u64>(n_flat, 1)));
+    RouteByRowRequest f{c->per};
+    CHK(route_items(c, c->d_req_flat, n_flat, f, c->d_req_s, scnt));
+    CHK(exchange_counts(c, scnt, rcnt));
+    const u64 nrq = vsum(rcnt);
+    CHK(ensure_cap(c, &c->d_req_r, &c->req_r_cap, std::max<u64>(nrq, 1)));
+    CHK(a2a_items(c, DISCO_X_ROW_REQUESTS, c->d_req_s, scnt, c->d_req_r, rcnt, sizeof(u32)));
+    /* the owner's side: class-filtered degree of every requested row, positions, entries */
+    CHK(ensure_cap(c, &c->d_rdeg_s, &c->rdeg_s_cap, std::max<u64>(nrq, 1)));
+    CHK(ensure_cap(c, &c->d_rpos, &c->rpos_cap, std::max<u64>(std::max(nrq, n_flat), 1) + 1));
+    const int rgrid = (int)std::max<u64>(std::min<u64>(nrq, (u64)c->n_cu * 32), 1);
+    if (nrq) hipLaunchKernelGGL(tr_respond_kernel<false>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, c->d_rdeg_s, (const u64 *)nullptr, (u32 *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    u64 total_s = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_s, nrq, c->d_rpos, true, &total_s)));
+    std::vector<u64> ecnt_s((size_t)G, 0), ecnt_r;
+    {   /* entries per requester = differences of the positions at the segment boundaries */
+        std::vector<u64> bpos((size_t)G + 1, 0);
+        u64 a = 0;
+        for (u32 p = 0; p < G; p++) {
+            if (nrq) HIPCHK(c, hipMemcpyAsync(&bpos[p], c->d_rpos + a, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            a += rcnt[p];
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bpos[G] = total_s;
+        for (u32 p = 0; p < G; p++) ecnt_s[p] = bpos[p + 1] - bpos[p];
+    }
+    CHK(ensure_cap(c, &c->d_rdata_s, &c->rdata_s_cap, std::max<u64>(total_s, 1)));
+    if (nrq) hipLaunchKernelGGL(tr_respond_kernel<true>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, (u32 *)nullptr, c->d_rpos, c->d_rdata_s);
+    HIPCHK(c, hipGetLastError());
+    /* degrees back (same segmentation as the requests, reversed), then the entries */
+    CHK(ensure_cap(c, &c->d_rdeg_r, &c->rdeg_r_cap, std::max<u64>(n_flat, 1)));
+    CHK(a2a_items(c, DISCO_X_ROW_REQUESTS, c->d_rdeg_s, rcnt, c->d_rdeg_r, scnt, sizeof(u32)));
+    CHK(exchange_counts(c, ecnt_s, ecnt_r));
+    const u64 total_r = vsum(ecnt_r);
+    CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, c->nadj_used + total_r + 1, c->nadj_used));
+    CHK(a2a_items(c, DISCO_X_ROW_DATA, c->d_rdata_s, ecnt_s, c->d_nadj32_own + c->nadj_used, ecnt_r, sizeof(u32)));
+    u64 chk = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_r, n_flat, c->d_rpos, true, &chk)));
+    if (chk != total_r) return fail(c, DISCO_E_STATE, "row exchange: %llu entries announced, %llu received", (unsigned long long)chk, (unsigned long long)total_r);
+    if (n_flat) hipLaunchKernelGGL(nref_remote_kernel, dim3(flat_grid(c, n_flat)), dim3(256), 0, c->stream, c->d_req_s, n_flat, c->d_rdeg_r, c->d_rpos, c->nadj_used, c->d_nref);
+    HIPCHK(c, hipGetLastError());
+    c->nadj_used += total_r;
+    return DISCO_OK;
+}
+
+static int dist_transitive_mark(disco_ctx *c)
+{
+    const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
+    /* own rows as 4-byte entries at the head of the neighbour-row store */
+    CHK(ensure_cap(c, &c->d_deg_tmp, &c->deg_tmp_cap, std::max<u64>(nloc, 1)));
+    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, c->n + 1));
+    CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, 2 * c->n + 2));
+    ph_begin(c, DISCO_PH_CSR);
+    HIPCHK(c, hipMemsetAsync(c->d_nref, 0xFF, (2 * c->n + 2) * sizeof(u64), c->stream));
+    if (nloc) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, lo, hi, c->d_deg_tmp);
+    u64 total = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_deg_tmp, nloc, c->d_start_tmp, true, &total)));
+    if (total != c->adj_total) return fail(c, DISCO_E_STATE, "own rows: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
+    c->nadj_used = 0;
+    CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, total + 1, 0));
+    if (nloc && total) hipLaunchKernelGGL(rows_gather32_kernel, dim3(wave_grid(c, nloc, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, lo, hi, c->d_start_tmp, c->d_nadj32_own);
+    if (nloc) hipLaunchKernelGGL(nref_local_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_start_tmp, c->d_deg_tmp, lo, nloc, c->d_nref);
+    HIPCHK(c, hipGetLastError());
+    c->nadj_used = total;
+    ph_end(c, DISCO_PH_CSR);
+    /* round 1: slot 0 and the first slot on the other side of every register-resident node */
+    if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
+    CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, 2 * nloc + 64));
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    CHK(zero_counter(c, CTR_OVERFLOW));
+    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, lo, hi, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    u64 n_flat = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "row requests: list overflow");
+    CHK(dist_fetch_rows(c, n_flat));
+    c->dinfo.tr_rounds = 1;
+
+    /* marking of the own nodes; nodes beyond the register path or short of a row land in big_list */
+    const u64 need_big = nloc + 1024;
+    if (need_big > c->big_cap) {
+        dev_free(c, &c->d_big_list, c->big_cap);
+        dev_free(c, &c->d_big_cnt, c->big_cap);
+        c->big_cap = 0;
+        CHK(dev_alloc(c, &c->d_big_list, need_big));
+        CHK(dev_alloc(c, &c->d_big_cnt, need_big));
+        c->big_cap = (u32)need_big;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
+    TrArgs a;
+    a.v = view(c);
+    a.ref = c->d_adj_ref;
+    a.adj = c->d_adj;
+    a.big_list = c->d_big_list;
+    a.n_big = c->d_n_big;
+    a.big_cap = c->big_cap;
+    a.scratch = nullptr;
+    a.hcap = 0;
+    c->use_half = true;
+    if (!c->d_half) CHK(dev_alloc(c, &c->d_half, c->n * HALF_CAP));
+    if (!c->d_hcnt) CHK(dev_alloc(c, &c->d_hcnt, c->n));
+    HIPCHK(c, hipMemsetAsync(c->d_hcnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
+    if (!c->d_wide) {
+        c->wide_cap = (u32)std::min<u64>(c->n, c->n / 32 + 4096);
+        CHK(dev_alloc(c, &c->d_wide, c->wide_cap));
+        CHK(dev_alloc(c, &c->d_n_wide, 1));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_n_wide, 0, sizeof(u32), c->stream));
+    a.half = c->d_half;
+    a.hcnt = c->d_hcnt;
+    a.wide_list = c->d_wide;
+    a.n_wide = c->d_n_wide;
+    a.wide_cap = c->wide_cap;
+    a.nref = c->d_nref;
+    a.nadj32 = c->d_nadj32_own;
+    a.all_flags = 1u;
+    ph_begin(c, DISCO_PH_TRMARK);
+    if (nloc) hipLaunchKernelGGL((transitive_mark_kernel<false, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    ph_end(c, DISCO_PH_TRMARK);
+    HIPCHK(c, hipGetLastError());
+    u32 n_big = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    CHK(read_counters(c));
+    ph_collect(c);
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking: deferred-node list overflow (%u nodes)", n_big);
+    u64 any = n_big;
+    CHK(host_reduce(c, &any, 1));
+    c->dinfo.tr_deferred = any;
+    if (any) { /* round 2 (collective): the listed nodes ask for every row they lack, then take the generic path */
+        c->dinfo.tr_rounds = 2;
+        u64 bound = 0, maxd = 0;
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        if (n_big) hipLaunchKernelGGL(list_degree_sum_kernel, dim3(flat_grid(c, n_big)), dim3(256), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_list_n);
+        HIPCHK(c, hipMemcpyAsync(&bound, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, bound + 64));
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        if (n_big) hipLaunchKernelGGL(tr_request_all_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_adj, lo, hi, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        CHK(read_counters(c));
+        if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "row requests (round 2): list overflow");
+        CHK(dist_fetch_rows(c, n_flat));
+        if (n_big) {
+            CHK(zero_counter(c, CTR_MAX_DEG));
+            hipLaunchKernelGGL(list_max_degree_kernel, dim3(flat_grid(c, n_big)), dim3(256), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_ctr + CTR_MAX_DEG);
+            CHK(read_counters(c));
+            maxd = c->h_ctr[CTR_MAX_DEG];
+            u64 hcap = 64;
+            while (hcap < 2 * maxd) hcap <<= 1;
+            const int g2 = (int)std::min<u64>(n_big, (u64)c->n_cu * 8);
+            const u64 perb = hcap * 8 + hcap * 4 + hcap;
+            u8 *scratch = nullptr;
+            CHK(dev_alloc(c, &scratch, (u64)g2 * perb));
+            a.scratch = (u64 *)scratch;
+            a.hcap = hcap;
+            a.nadj32 = c->d_nadj32_own; /* the store may have moved */
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL((transitive_mark_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
+            hipError_t e = hipGetLastError();
+            int rc = read_counters(c);
+            dev_free(c, &scratch, (u64)g2 * perb);
+            if (e != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel (second round): %s", hipGetErrorString(e));
+            CHK(rc);
+            if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "transitive marking: a row was still missing after the request-all round");
+        }
+    }
+    c->n_wide = 0;
+    HIPCHK(c, hipMemcpy(&c->n_wide, c->d_n_wide, sizeof(u32), hipMemcpyDeviceToHost));
+    c->flags_pending = false;
+    c->phase = 7;
+    return DISCO_OK;
+}
+
+/* ---- 6. surviving half-edges to the owner of the smaller endpoint ---------------------------------------------------- */
+static int dist_push_survivors(disco_ctx *c)
+{
+    const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
+    u64 n_items = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    if (nloc) hipLaunchKernelGGL(emit_push_kernel<false>, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(n_items, 1)));
+    CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(n_items, 1)));
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    CHK(zero_counter(c, CTR_OVERFLOW));
+    if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, c->d_x16b, c->d_list_n, n_items, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "survivor push: the fill pass produced more items than the count pass");
+    std::vector<u64> scnt, rcnt;
+    RouteByNode f{c->per};
+    CHK(route_items(c, c->d_x16b, n_items, f, c->d_x16a, scnt));
+    CHK(exchange_counts(c, scnt, rcnt));
+    const u64 nr = vsum(rcnt);
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nr, 1)));
+    CHK(a2a_items(c, DISCO_X_PUSH, c->d_x16a, scnt, c->d_x16b, rcnt, sizeof(ulonglong2)));
+    c->d_push_r = c->d_x16b;
+    c->n_push_r = nr;
+    return DISCO_OK;
+}
+
+/* ---- order-dependent regime: everybody gets the whole adjacency and finishes the pass on its own --------------------- */
+static int dist_irregular(disco_ctx *c, const std::vector<u64> &adj_totals)
+{
+    const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo, per = c->per;
+    u32 *deg_all = nullptr;
+    u64 *rows_all = nullptr;
+    const u64 total = vsum(adj_totals);
+    CHK(dev_alloc(c, &deg_all, (u64)G * per));
+    CHK(dev_alloc(c, &rows_all, std::max<u64>(total, 1)));
+    u64 base = 0;
+    for (u32 p = 0; p < r; p++) base += adj_totals[p];
+    int rc = DISCO_OK;
+    const auto t0 = HClock::now();
+    do {
+        if ((rc = hipMemsetAsync(deg_all + (u64)r * per, 0, per * sizeof(u32), c->stream) == hipSuccess ? DISCO_OK : DISCO_E_HIP) != DISCO_OK) break;
+        if ((rc = disco_export_adjacency(c, deg_all + (u64)r * per, rows_all + base)) != DISCO_OK) break;
+        if ((rc = c->comm->all_gather(deg_all + (u64)r * per, deg_all, per * sizeof(u32), c->stream)) != DISCO_OK) break;
+        std::vector<size_t> off((size_t)G), cnt((size_t)G);
+        size_t a = 0;
+        for (u32 p = 0; p < G; p++) {
+            off[p] = a;
+            cnt[p] = adj_totals[p] * sizeof(u64);
+            a += cnt[p];
+            if (p != r) c->dinfo.bytes_sent[DISCO_X_ADJACENCY] += cnt[r] + per * sizeof(u32);
+        }
+        if ((rc = c->comm->all_gather_v(rows_all + base, rows_all, off.data(), cnt.data(), c->stream)) != DISCO_OK) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = DISCO_E_HIP;
+            break;
+        }
+        c->dinfo.ms[DISCO_X_ADJACENCY] += ms_since(t0);
+        (void)nloc;
+        if ((rc = disco_import_adjacency(c, deg_all, rows_all, total)) != DISCO_OK) break;
+    } while (0);
+    dev_free(c, &deg_all, (u64)G * per);
+    dev_free(c, &rows_all, std::max<u64>(total, 1));
+    if (rc != DISCO_OK) return c->err.empty() ? fail(c, rc, "adjacency exchange: %s", c->comm->err.c_str()) : rc;
+    CHK(disco_symmetrize(c, 1, nullptr));
+    CHK(merge_extras(c));
+    c->q_lo = 0;
+    c->q_hi = c->n;
+    rc = disco_transitive_mark(c);
+    c->q_lo = lo;
+    c->q_hi = hi;
+    CHK(rc);
+    c->half_complete = true; /* every node was marked here */
+    c->dist_active = false;  /* nothing is pushed: every pair is judged locally */
+    c->n_push_r = 0;
+    return DISCO_OK;
+}
+
+extern "C" {
+
+int disco_comm_unique_id(void *out, size_t cap)
+{
+    if (!out || cap < DISCO_UNIQUE_ID_BYTES) return DISCO_E_ARG;
+    static_assert(sizeof(ncclUniqueId) == DISCO_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return fail(nullptr, DISCO_E_HIP, "ncclGetUniqueId failed");
+    memcpy(out, &id, sizeof id);
+    return DISCO_OK;
+}
+
+static int comm_attach(disco_ctx *c, DiscoComm *cm)
+{
+    delete c->comm;
+    c->comm = cm;
+    return DISCO_OK;
+}
+
+int disco_comm_init(disco_ctx *c, const void *unique_id, int nranks, int rank)
+{
+    if (!c || !unique_id || nranks < 1 || nranks > DIST_MAX_WORLD || rank < 0 || rank >= nranks) return c ? fail(c, DISCO_E_ARG, "disco_comm_init: bad argument") : DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    RcclComm *cm = new (std::nothrow) RcclComm();
+    if (!cm) return fail(c, DISCO_E_NOMEM, "disco_comm_init: out of host memory");
+    const int rc = cm->init(unique_id, nranks, rank);
+    if (rc != DISCO_OK) {
+        fail(c, rc, "disco_comm_init: %s", cm->err.c_str());
+        delete cm;
+        return rc;
+    }
+    return comm_attach(c, cm);
+}
+
+int disco_comm_init_local(disco_ctx *const *ctxs, int nranks)
+{
+    if (!ctxs || nranks < 1 || nranks > DIST_MAX_WORLD) return DISCO_E_ARG;
+    for (int r = 0; r < nranks; r++)
+        if (!ctxs[r]) return DISCO_E_ARG;
+    auto grp = std::make_shared<LoopGroup>(nranks);
+    for (int r = 0; r < nranks; r++) comm_attach(ctxs[r], new LoopComm(grp, r));
+    return DISCO_OK;
+}
+
+int disco_comm_rank(const disco_ctx *c) { return (c && c->comm) ? c->comm->rank : 0; }
+int disco_comm_world(const disco_ctx *c) { return (c && c->comm) ? c->comm->world : 1; }
+
+int disco_dist_range(const disco_ctx *c, uint64_t n_total, uint64_t *lo, uint64_t *hi)
+{
+    if (!c || !lo || !hi) return DISCO_E_ARG;
+    u64 per, l, h;
+    dist_range(c, n_total, &per, &l, &h);
+    *lo = l;
+    *hi = h;
+    return DISCO_OK;
+}
+
+/* table of world * per rows; the own range is filled by the caller / generator, the rest by the all-gather of the pass */
+static int dist_set_reads(disco_ctx *c, u64 n_total, uint32_t dstride)
+{
+    if (!c->comm) return fail(c, DISCO_E_STATE, "no communicator: call disco_comm_init / disco_comm_init_local first");
+    CHK(set_reads_common(c, n_total, dstride));
+    u64 per, lo, hi;
+    dist_range(c, n_total, &per, &lo, &hi);
+    c->per = per;
+    c->n_alloc = per * (u64)c->comm->world;
+    c->q_lo = lo;
+    c->q_hi = hi;
+    CHK(dev_alloc(c, &c->d_reads, c->n_alloc * (u64)dstride));
+    CHK(dev_alloc(c, &c->d_len, c->n_alloc));
+    c->reads_owned = true;
+    c->dist_reads = true;
+    return DISCO_OK;
+}
+
+static int dist_validate(disco_ctx *c)
+{
+    const u64 nloc = c->q_hi - c->q_lo;
+    CHK(zero_counter(c, CTR_BAD_LEN));
+    CHK(zero_counter(c, CTR_MAX_LEN));
+    if (nloc) hipLaunchKernelGGL(validate_len_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_len + c->q_lo, nloc, c->S, (int)c->prm.min_overlap, c->d_ctr);
+    CHK(read_counters(c));
+    u64 bad = c->h_ctr[CTR_BAD_LEN], mx = c->h_ctr[CTR_MAX_LEN];
+    CHK(host_reduce(c, &bad, 1));
+    CHK(host_reduce(c, &mx, 1, true));
+    if (bad) return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)bad, c->prm.min_overlap);
+    c->max_len = (u32)mx;
+    c->phase = 1;
+    return DISCO_OK;
+}
+
+int disco_dist_upload_reads(disco_ctx *c, const uint64_t *packed_own, uint32_t stride_words, const uint16_t *len_own, uint64_t n_total)
+{
+    if (!c) return DISCO_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t dstride = (stride_words + 7u) & ~7u;
+    CHK(dist_set_reads(c, n_total, dstride));
+    const u64 nloc = c->q_hi - c->q_lo;
+    if (nloc && (!packed_own || !len_own)) return fail(c, DISCO_E_ARG, "disco_dist_upload_reads: null argument");
+    if (nloc) {
+        u64 *dst = c->d_reads + c->q_lo * (u64)dstride;
+        if (dstride != stride_words) HIPCHK(c, hipMemsetAsync(dst, 0, nloc * (u64)dstride * 8, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dstride * 8, packed_own, (size_t)stride_words * 8, (size_t)stride_words * 8, nloc, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_len + c->q_lo, len_own, nloc * 2, hipMemcpyHostToDevice, c->stream));
+    }
+    return dist_validate(c);
+}
+
+int disco_dist_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
+{
+    if (!c || !s) return c ? fail(c, DISCO_E_ARG, "disco_dist_generate_reads: null argument") : DISCO_E_ARG;
+    if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
+        return fail(c, DISCO_E_ARG, "disco_dist_generate_reads: bad spec");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t stride = (((s->len_max + 31) / 32) + 7u) & ~7u;
+    CHK(dist_set_reads(c, s->n_reads, stride));
+    disco_genspec g;
+    memcpy(&g, s, sizeof g);
+    const u64 nloc = c->q_hi - c->q_lo;
+    if (nloc) hipLaunchKernelGGL(generate_reads_kernel, dim3(flat_grid(c, nloc * stride)), dim3(256), 0, c->stream, g, c->d_reads, c->d_len, (int)stride, c->q_lo, c->q_hi);
+    HIPCHK(c, hipGetLastError());
+    return dist_validate(c);
+}
+
+int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
+{
+    if (!c) return DISCO_E_ARG;
+    if (!c->comm) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: no communicator");
+    if (!c->dist_reads || c->phase < 1) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: set the reads with disco_dist_upload_reads / disco_dist_generate_reads");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    const auto t_pass = HClock::now();
+    disco_dist_info &di = c->dinfo;
+    memset(&di, 0, sizeof di);
+    di.world = G;
+    di.rank = r;
+    di.n_reads = c->n;
+    di.own_lo = c->q_lo;
+    di.own_hi = c->q_hi;
+    c->dist_active = true;
+    c->n_push_r = 0;
+    c->h_len.clear();
+    /* 0. everybody gets every read */
+    if ((flags & DISCO_DIST_GATHER_READS) && G > 1) {
+        const auto t0 = HClock::now();
+        const u64 row_bytes = (u64)c->S * 8;
+        COMM_CHK(c, c->comm->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, c->stream));
+        COMM_CHK(c, c->comm->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (row_bytes + 2);
+        di.ms[DISCO_X_READS] += ms_since(t0);
+    }
+    CHK(dist_build_index(c));
+    CHK(disco_probe(c));
+    CHK(dist_mark_contained(c));
+    CHK(select_edges(c));
+    /* whole-job figures and the regime decision */
+    u64 probes = 0;
+    if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    if (c->q_hi > c->q_lo) hipLaunchKernelGGL(probes_sum_kernel, dim3(flat_grid(c, c->q_hi - c->q_lo)), dim3(256), 0, c->stream, c->d_len, c->q_lo, c->q_hi, (u32)c->k, c->d_list_n);
+    HIPCHK(c, hipMemcpyAsync(&probes, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 g[8] = {c->adj_total, c->dropped_local, c->n_contained, c->h_ctr[CTR_CAP_SITES], c->h_ctr[CTR_KMER_HITS], probes, 0, 0};
+    {
+        constexpr int NV = 6;
+        std::vector<u64> all((size_t)G * NV);
+        COMM_CHK(c, c->comm->host_all_gather((const unsigned long long *)g, NV, (unsigned long long *)all.data(), c->stream));
+        std::vector<u64> adj_totals((size_t)G);
+        u64 sum[NV] = {0, 0, 0, 0, 0, 0};
+        for (u32 p = 0; p < G; p++) {
+            adj_totals[p] = all[(size_t)p * NV];
+            for (int i = 0; i < NV; i++) sum[i] += all[(size_t)p * NV + i];
+        }
+        di.probes = sum[5];
+        di.dropped_hits = sum[1];
+        di.n_contained = sum[2];
+        di.n_contained_local = c->n_contained;
+        di.cap_bind_sites = sum[3];
+        di.kmer_hits = sum[4];
+        di.e_pre = sum[0] / 2;
+        c->dropped = sum[1];
+        const bool irregular = sum[1] != 0 || c->n >= (1ull << 30) || getenv("DISCO_DIST_FORCE_GATHER");
+        if (irregular) {
+            di.regime = 1;
+            CHK(dist_irregular(c, adj_totals));
+            di.e_pre = c->adj_total / 2;
+            di.asymmetric_pairs = c->asym_local;
+        } else {
+            c->phase = 6; /* nobody dropped a hit: the lists are symmetric by construction (twin_check's argument) */
+            c->n_extra = 0;
+            c->asym_local = 0;
+            c->ph_ms[DISCO_PH_TWIN] = 0;
+            CHK(dist_transitive_mark(c));
+            CHK(dist_push_survivors(c));
+        }
+    }
+    uint64_t n_out = 0;
+    CHK(disco_emit_edges(c, &n_out));
+    u64 tot[1] = {(u64)n_out};
+    CHK(host_reduce(c, tot, 1));
+    di.e_out = tot[0];
+    di.e_out_local = n_out;
+    di.ms_total = ms_since(t_pass);
+    return DISCO_OK;
+}
+
+int disco_dist_get_info(disco_ctx *c, disco_dist_info *out)
+{
+    if (!c || !out) return DISCO_E_ARG;
+    *out = c->dinfo;
     return DISCO_OK;
 }
 

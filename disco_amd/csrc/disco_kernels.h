@@ -99,10 +99,11 @@ struct DiscoView {
 /* ================================================================================================================
  * synthetic reads straight into HBM (bench / tests) — twin of readgen.h / readgen.py
  * ============================================================================================================== */
-__global__ void generate_reads_kernel(disco_genspec spec, u64 *__restrict__ reads, u16 *__restrict__ len, int S)
+/* rows [r_lo, r_hi) of the table (the whole table on one GPU, the rank's own range in the multi-GPU flow) */
+__global__ void generate_reads_kernel(disco_genspec spec, u64 *__restrict__ reads, u16 *__restrict__ len, int S, u64 r_lo, u64 r_hi)
 {
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 total = spec.n_reads * (u64)S;
+    u64 gid = r_lo * (u64)S + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 total = r_hi * (u64)S;
     for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
         u64 r = gid / S;
         int w = (int)(gid % S);
@@ -154,12 +155,16 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * okey[i] = smallest 32-bit order hash among ALL m-mers of the read (see "processing order" below).
  * (The previous version called the random-access mmer_order 34 times per read: 33 L2 requests per read, 10.2 ms at 50 M reads,
  * plus a separate 4.2 ms pass for the keys.) */
-__global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey)
+/* Reads [lo, hi) (the whole table on one GPU, the rank's own range in the multi-GPU flow); rec is indexed from lo. COUNT = false
+ * (multi-GPU): no counting atomics — the records are routed to the rank that owns their bucket range first and counted there
+ * (shard_count_kernel), which is what replaces the range-partitioned hashData of RMA/HashTable.cpp:95-116. */
+template <bool COUNT>
+__global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi)
 {
     /* rec[2i], rec[2i+1] = {bucket << 32 | slot inside the bucket, record} of the prefix / suffix k-mer of read i: the slot is
      * what the counting atomic returns, so the fill pass needs no second round of atomics */
-    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (i >= v.n) return;
+    const u64 i = lo + (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= hi) return;
     const u64 *__restrict__ p = v.reads + i * v.S;
     const int L = v.len[i], k = v.k, m = v.m, nf = k - m + 1;
     const int nmm = L - m + 1; /* m-mer positions (L >= k: validate_len_kernel) */
@@ -219,10 +224,10 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
     const u64 kp = resolve(k1p, k2p, 0, tp, rp);
     const u64 ks = resolve(k1s, k2s, sfx0, ts, rs);
     const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
-    const u32 sp = atomicAdd(&bkt[bp], 1u);
-    const u32 ss = atomicAdd(&bkt[bs], 1u);
-    rec[2 * i] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
-    rec[2 * i + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
+    const u32 sp = COUNT ? atomicAdd(&bkt[bp], 1u) : 0u;
+    const u32 ss = COUNT ? atomicAdd(&bkt[bs], 1u) : 0u;
+    rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
+    rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
 }
 
 /* bkt = exclusive scan of the counts: record goes to bkt[bucket] + slot */
@@ -1435,17 +1440,6 @@ __global__ void ref_from_start_kernel(const u64 *__restrict__ start, const u32 *
     for (; i < n; i += (u64)gridDim.x * blockDim.x) ref[i] = REF_MAKE(start[i], deg[i]);
 }
 
-/* rank-major padded adjacency (sharded flow): the rows of rank r = nodes [r*per, (r+1)*per) sit in node order at
- * rows[r*mx ...]; gstart = exclusive scan of the degrees over all world*per node slots */
-__global__ void ref_from_padded_kernel(const u64 *__restrict__ gstart, const u32 *__restrict__ deg, u64 n, u64 per, u64 mx, u64 *__restrict__ ref)
-{
-    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; v < n; v += (u64)gridDim.x * blockDim.x) {
-        const u64 r = v / per;
-        ref[v] = REF_MAKE(r * mx + (gstart[v] - gstart[r * per]), deg[v]);
-    }
-}
-
 /* rows of the nodes [lo,hi) copied into node order: dst[dst_start[v-lo] + i] (export for the all-gather; flags stripped) */
 __global__ void __launch_bounds__(64) rows_gather_kernel(const u64 *__restrict__ adj, const u64 *__restrict__ ref, u64 lo, u64 hi,
                                                          const u64 *__restrict__ dst_start, u64 *__restrict__ dst)
@@ -1632,8 +1626,11 @@ struct TrArgs {
     u32 big_cap;
     u64 *scratch;  /* BIG variant: per block hkey[hcap] | ent(u32)[hcap] | state(u8)[hcap] */
     u64 hcap;      /* power of two >= 2 * max degree */
-    /* N32 variants (sharded flow): the rows of the NEIGHBOURS come from an all-gathered array of 4-byte entries with its own
-     * reference words; ref / adj above then hold the rank's own rows only */
+    /* N32 variants (multi-GPU flow): the rows of the NEIGHBOURS come from a store of 4-byte entries with its own reference
+     * words nref[2u + cls], cls = which half of u's row the sweep from v uses (1: v enters u reversed, types 0/1 of u's entries
+     * count; 0: types 2/3). The rank's own nodes have their whole row behind both words; a remote (u, cls) has the entries of
+     * that class only, fetched on request from u's owner (tr_request_*_kernel), or TR_UNAVAIL: not fetched. A node whose sweep
+     * needs an unavailable row goes to big_list and is redone after the second request round. ref / adj hold the own rows. */
     const u64 *nref;
     const u32 *nadj32;
     /* 0: the transitive flag is written into the rows of nodes with more than HALF_CAP survivors only — everybody else's result
@@ -1642,8 +1639,11 @@ struct TrArgs {
     u32 all_flags;
 };
 
+#define TR_UNAVAIL 0xFFFFFFFFFFFFFFFFull   /* nref word: row not fetched (degree field 0xFFFFFF, never a real degree) */
+#define TR_REQUESTED 0xFFFFFFFFFFFFFFFEull /* nref word: requested in the current round                              */
+#define TR_NODEG 0xFFFFFFu
 template <bool N32>
-__device__ __forceinline__ u64 tr_nref(const TrArgs &a, u64 u) { return N32 ? a.nref[u] : a.ref[u]; }
+__device__ __forceinline__ u64 tr_nref(const TrArgs &a, u64 u, u32 cls) { return N32 ? a.nref[2 * u + cls] : a.ref[u]; }
 template <bool N32>
 __device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
 {
@@ -1695,10 +1695,14 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
             const u64 e1 = row[i];
             const u64 u = ADJ_DST(e1);
             const u32 type1 = ADJ_ORI(e1);
-            const u64 ru = tr_nref<N32>(a, u);
-            const u64 us = REF_POS(ru);
-            const u32 du = REF_DEG(ru);
             const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
+            const u64 ru = tr_nref<N32>(a, u, in1 ? 1u : 0u);
+            const u64 us = REF_POS(ru);
+            u32 du = REF_DEG(ru);
+            if (N32 && du == TR_NODEG) { /* cannot happen after the request-all round: fail loudly */
+                if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                du = 0;
+            }
             for (u32 t = lane; t < du; t += 64) {        /* :698 */
                 const u64 e2 = tr_nent<N32>(a, us + t);
                 const u32 type2 = ADJ_ORI(e2);
@@ -1774,8 +1778,9 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     const u32 s2 = nd.s2;
     const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
     const u32 d0 = REF_DEG(nd.r0), d2 = REF_DEG(nd.r2);
-    const u64 p0 = (lane < d0) ? (N32 ? NBR32_ENTRY((u32)nd.p0) : nd.p0) : 0ull;
-    const u64 p2 = (lane < d2) ? (N32 ? NBR32_ENTRY((u32)nd.p2) : nd.p2) : 0ull;
+    const u64 p0 = (lane < d0 && d0 != TR_NODEG) ? (N32 ? NBR32_ENTRY((u32)nd.p0) : nd.p0) : 0ull;
+    const u64 p2 = (lane < d2 && d2 != TR_NODEG) ? (N32 ? NBR32_ENTRY((u32)nd.p2) : nd.p2) : 0ull;
+    bool deferred = false;
     __syncthreads();
     u32 sent = 0;
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
@@ -1826,17 +1831,38 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         };
         /* three copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
          * lands on the common path and drains the kernel's prefetch pipeline */
-        if (i == 0)
+        if (i == 0) {
+            if (N32 && d0 == TR_NODEG) {
+                deferred = true;
+                break;
+            }
             sweep(st0, d0, p0);
-        else if (i == s2)
+        } else if (i == s2) {
+            if (N32 && d2 == TR_NODEG) {
+                deferred = true;
+                break;
+            }
             sweep(st2, d2, p2);
-        else {
-            const u64 ru = tr_nref<N32>(a, ADJ_DST(e1));
+        } else {
+            const u64 ru = tr_nref<N32>(a, ADJ_DST(e1), in1 ? 1u : 0u);
             const u64 us = REF_POS(ru);
             const u32 du = REF_DEG(ru);
+            if (N32 && du == TR_NODEG) { /* a third sweep whose row was not requested: redo the node after the second round */
+                deferred = true;
+                break;
+            }
             sweep(us, du, (lane < du) ? tr_nent<N32>(a, us + lane) : 0ull);
         }
         __syncthreads();
+    }
+    if (N32 && deferred) {
+        if (lane == 0) {
+            const u32 idx = atomicAdd(a.n_big, 1u);
+            if (idx < a.big_cap) a.big_list[idx] = nd.v;
+            else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+        }
+        __syncthreads();
+        return;
     }
     const bool fl = lane < d && hstate[sent];
     const bool fr = lane < d && !fl;
@@ -1905,14 +1931,15 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         const u32 side0 = ADJ_ORI(readlane_u64(r.e, 0)) >> 1;
         const u64 om = __ballot(lane < r.d && (ADJ_ORI(r.e) >> 1) != side0);
         r.s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
-        const u64 u0 = r.d ? ADJ_DST(readlane_u64(r.e, 0)) : r.v, u2 = r.d ? ADJ_DST(readlane_u64(r.e, r.s2)) : r.v;
-        r.r0 = tr_nref<N32>(a, u0 < n_nodes ? u0 : r.v);
-        r.r2 = tr_nref<N32>(a, u2 < n_nodes ? u2 : r.v);
+        const u64 e0 = readlane_u64(r.e, 0), e2 = readlane_u64(r.e, r.s2);
+        const u64 u0 = r.d ? ADJ_DST(e0) : r.v, u2 = r.d ? ADJ_DST(e2) : r.v;
+        r.r0 = tr_nref<N32>(a, u0 < n_nodes ? u0 : r.v, (~ADJ_ORI(e0)) & 1u); /* cls = 1 for types 0 and 2 */
+        r.r2 = tr_nref<N32>(a, u2 < n_nodes ? u2 : r.v, (~ADJ_ORI(e2)) & 1u);
     };
     auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 (broadcast loads: scalar from here on) */
         r.r0 = uniform_u64(r.r0);
         r.r2 = uniform_u64(r.r2);
-        const u32 d0 = r.d ? REF_DEG(r.r0) : 0u, d2 = r.d ? REF_DEG(r.r2) : 0u;
+        const u32 d0 = (r.d && REF_DEG(r.r0) != TR_NODEG) ? REF_DEG(r.r0) : 0u, d2 = (r.d && REF_DEG(r.r2) != TR_NODEG) ? REF_DEG(r.r2) : 0u;
         /* raw words only: N32 entries are expanded where they are consumed (nothing is computed from a loaded value in the
          * iteration that issues the load) */
         if (N32) {
@@ -1949,7 +1976,7 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         if (n0.d != 0)
             tr_node_small<N32>(a, n0, s_hkey, s_state, lane);
         else if (n0.dfull != 0) {
-            if (n0.dfull <= TR_CAP) {
+            if (!N32 && n0.dfull <= TR_CAP) { /* multi-GPU: every node beyond the register path waits for the request-all round */
                 u32 hc = 64;
                 while (hc < 2 * n0.dfull) hc <<= 1;
                 tr_node<N32>(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
@@ -1964,20 +1991,6 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         n2 = n3;
     }
     }
-}
-
-/* sharded flow: transitive flags of the slots [lo,hi) of the gathered CSR as bytes (export) / OR them back in (import) */
-__global__ void flags_extract_kernel(const u64 *__restrict__ adj, u64 lo, u64 hi, u8 *__restrict__ flag)
-{
-    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < hi; i += (u64)gridDim.x * blockDim.x) flag[i] = (adj[i] & ADJ_FLAG) ? 1 : 0;
-}
-
-__global__ void flags_apply_kernel(u64 *__restrict__ adj, u64 total, const u8 *__restrict__ flag)
-{
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < total; i += (u64)gridDim.x * blockDim.x)
-        if (flag[i] & 1) adj[i] |= ADJ_FLAG;
 }
 
 /* ================================================================================================================
@@ -2000,6 +2013,9 @@ struct EmitArgs {
     u64 *out_ent;
     u64 out_cap;
     u64 *bump;
+    /* multi-GPU flow: only pairs whose larger endpoint is owned by this rank too are judged here (the survivors of a remote w
+     * are not on this rank: its owner pushes them, emit_push_recv_kernel) */
+    u32 local_only;
 };
 
 __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
@@ -2031,7 +2047,7 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
             if (s < d) {
                 e = a.adj[vs + s];
                 const u64 w = ADJ_DST(e);
-                if (v < w && !(e & ADJ_FLAG)) {
+                if (v < w && !(e & ADJ_FLAG) && (!a.local_only || w < a.v.q_hi)) {
                     const u32 Lw = ADJ_DLEN(e);
                     const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
                     const u32 cw = a.hcnt ? a.hcnt[w] : HALF_CAP + 1;
@@ -2085,6 +2101,7 @@ struct EmitHalfArgs {
     u64 *out_ent;
     u64 out_cap;
     u64 *bump;
+    u32 local_only; /* see EmitArgs */
 };
 
 __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
@@ -2114,7 +2131,7 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
             if (cnt <= HALF_CAP && r < cnt) { /* wide nodes (cnt > HALF_CAP) are emitted by emit_kernel */
                 e = a.half[v * HALF_CAP + r];
                 const u64 w = ADJ_DST(e);
-                if (v < w) {
+                if (v < w && (!a.local_only || w < a.v.q_hi)) {
                     const u64 twin = ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
                     const u32 cw = a.hcnt[w];
                     if (cw <= HALF_CAP) {

@@ -153,50 +153,68 @@ int disco_emit_edges(disco_ctx *ctx, uint64_t *n_out);
 /* all five phases back to back on the context's stream */
 int disco_run_graph(disco_ctx *ctx);
 
-/* ---- multi-GPU exchange points (the collectives themselves are the caller's: RCCL via torch.distributed) -------- */
-/* device pointer to the per-read containment keys (uint64[n], smaller = better, INT64_MAX = not contained). Ranks
- * combine them with an all-reduce(MIN) between disco_probe and disco_mark_contained
- * (replaces the contained-read exchange MPI/OverlapGraph.cpp:480-506,559-588). */
-int disco_contain_keys(disco_ctx *ctx, void **d_keys, uint64_t *n);
-/* adjacency of the local query range after disco_build_edges: deg[i] (uint32) for i in [lo,hi) and the concatenated
- * rows (uint64 entries).  Exported to caller-provided device buffers / imported from the gathered ones so that the
- * transitive reduction of a shard can see the lists of neighbours owned by other ranks
+/* ---- adjacency in and out (order-dependent regime of the multi-GPU flow; tools) ------------------------------------ */
+/* adjacency of the local query range after disco_select_edges: deg[i] (uint32) for i in [lo,hi) and the concatenated
+ * rows (uint64 entries), exported to caller-provided device buffers / imported from arrays covering ALL nodes
  * (replaces the full-replica partial graphs of MPI/OverlapGraph.cpp:244-279). */
 int disco_adjacency_size(disco_ctx *ctx, uint64_t *n_entries);
 int disco_export_adjacency(disco_ctx *ctx, void *d_deg_u32, void *d_entries_u64);
 int disco_import_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, const void *d_entries_u64_all, uint64_t n_entries_all);
-/* sharded flow without copies: the caller all-gathers the shards IN PLACE into rank-major padded device buffers
- * (d_deg_u32_all[v], v = r*per_rank_nodes + i; rows of rank r in node order at d_rows_u64_padded[r*max_per_rank ...]) and the
- * context addresses them where they lie (caller-owned, must outlive the pass; marking sets flag bits in them). */
-int disco_adopt_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, void *d_rows_u64_padded, uint64_t per_rank_nodes,
-                          uint64_t max_per_rank, uint32_t world);
-/* Compact form of the exchange for the regular regime (no read dropped a verified hit anywhere, fewer than 2^30 reads):
- * the transitive marking reads only (destination, orientation) of a NEIGHBOUR's row (BG/OverlapGraph.cpp:698-708), so the
- * rows travel as 4-byte entries dst(30) | orient(2) << 30 — half the bytes of disco_export_adjacency, and the all-gather of
- * the rows is what bounds the sharded flow on xGMI. disco_export_adjacency32 writes this rank's degrees and rows (node
- * order), disco_adopt_neighbours32 makes the context read neighbour rows from the gathered, rank-major padded array
- * (layout of disco_adopt_adjacency) while its own rows stay where edge selection left them. The survivor lists
- * (disco_half_lists) then carry the result; with wide nodes the caller falls back to the 8-byte exchange. */
-int disco_export_adjacency32(disco_ctx *ctx, void *d_deg_u32, void *d_entries_u32);
-int disco_adopt_neighbours32(disco_ctx *ctx, const void *d_deg_u32_all, const void *d_rows_u32_padded, uint64_t per_rank_nodes,
-                             uint64_t max_per_rank, uint32_t world);
-/* verified hits that edge selection did not turn into an edge on THIS rank (second hit to a destination, per-k-mer cap);
- * lists can be asymmetric only if some rank dropped one, so the sharded caller sums the counts over all ranks and hands the
- * total back before disco_symmetrize (the twin search is skipped only when nobody dropped anything) */
-int disco_dropped_hits(disco_ctx *ctx, uint64_t *n_local);
-int disco_set_global_dropped(disco_ctx *ctx, uint64_t n_all_ranks);
-/* survivor lists written by disco_transitive_mark: half = uint64[n][4] (the first 4 edges of a node not flagged from its own
- * end, list order), hcnt = uint32[n] (how many there are), n_wide = local nodes with more than 4. Ranks all-gather their
- * node ranges of both arrays into these buffers and call disco_half_complete(ctx, 1): the emission then needs neither the
- * rows nor the flags of other ranks (an edge survives iff it is among the survivors of BOTH ends). If any rank has wide
- * nodes, exchange the flags instead (disco_tr_flags). */
-int disco_half_lists(disco_ctx *ctx, void **d_half, void **d_hcnt, uint64_t *n_wide);
-int disco_half_complete(disco_ctx *ctx, int complete);
-/* sharded flow only (after disco_import_adjacency / disco_adopt_adjacency): transitive flags as uint8 per slot of the gathered adjacency (`total`
- * slots). This rank computed [slot_lo, slot_hi); ranks all-gather those byte ranges in place between
- * disco_transitive_mark and disco_emit_edges, because an edge survives only if it is flagged from neither end
- * (BG/OverlapGraph.cpp:717-718 flags the twin too). On a single GPU the flag is a bit of the entry and nothing is exchanged. */
-int disco_tr_flags(disco_ctx *ctx, void **d_flags, uint64_t *slot_lo, uint64_t *slot_hi, uint64_t *total);
+
+/* ---- multi-GPU flow: one context per GPU (rank), RCCL underneath ------------------------------------------------------
+ * Replaces buildG-MPI / buildG-MPIRMA (MPI/main.cpp:29-37 MPI_Init_thread + rank ranges, RMA/HashTable.cpp:95-116 range split of
+ * hashData, :422-435 RMA window, :644-653,694-705 MPI_Get per bucket, :1066-1087 needsProcessing ownership,
+ * MPI/OverlapGraph.cpp:218-246,473-506 gossip of marked / contained ids). Reads and graph nodes are range-partitioned
+ * (rank r owns ids [r*per, (r+1)*per)), the index is BUILT hash-partitioned (records routed by all-to-all to the owner of their
+ * bucket range) and its shards exchanged; containment keys are min-reduced to the owner; the transitive reduction fetches the
+ * two or three neighbour rows a node's marking sweeps ON REQUEST from their owners (all-to-all), and surviving half-edges are
+ * pushed to the owner of the smaller endpoint. Every call below is COLLECTIVE: all ranks, same order. */
+#define DISCO_UNIQUE_ID_BYTES 128
+enum { /* exchanges of one pass (disco_dist_info.bytes_sent) */
+    DISCO_X_READS = 0,     /* all-gather of the packed reads (only with DISCO_DIST_GATHER_READS)      */
+    DISCO_X_INDEX_RECORDS, /* all-to-all: index records to the owner of their bucket range            */
+    DISCO_X_INDEX_SHARDS,  /* all-gather-v: built bucket-table and record shards                       */
+    DISCO_X_CONTAIN,       /* reduce-scatter(MIN) of the containment keys + all-gather of the bitmap   */
+    DISCO_X_ROW_REQUESTS,  /* all-to-all: (node, class) row requests + degrees back                    */
+    DISCO_X_ROW_DATA,      /* all-to-all: the requested neighbour rows, 4-byte entries                 */
+    DISCO_X_PUSH,          /* all-to-all: surviving half-edges to the owner of the smaller endpoint    */
+    DISCO_X_ADJACENCY,     /* order-dependent regime only: all-gather of the whole adjacency            */
+    DISCO_X_COUNT
+};
+enum { DISCO_DIST_GATHER_READS = 1 }; /* disco_dist_run_graph flags: the pass starts from range-partitioned reads */
+typedef struct disco_dist_info {
+    uint32_t world, rank;
+    uint64_t n_reads, own_lo, own_hi;
+    uint64_t n_contained, e_pre, e_out;       /* whole job                                                    */
+    uint64_t e_out_local;                     /* edges this rank emitted (disco_fetch_edges)                  */
+    uint64_t n_contained_local;               /* contained rows this rank holds (disco_fetch_contained)       */
+    uint64_t cap_bind_sites, asymmetric_pairs, dropped_hits, probes, kmer_hits; /* whole job                  */
+    uint32_t regime;                          /* 0: regular (rows on request); 1: order-dependent (adjacency gathered) */
+    uint32_t tr_rounds;                       /* request rounds of the transitive reduction (1 or 2)         */
+    uint64_t tr_deferred;                     /* nodes redone after the second round, whole job               */
+    uint64_t bytes_sent[DISCO_X_COUNT];       /* this rank's payload bytes to OTHER ranks, last pass          */
+    float ms[DISCO_X_COUNT];                  /* host wall time of each exchange on this rank, last pass      */
+    float ms_total;
+} disco_dist_info;
+/* fills out[0..DISCO_UNIQUE_ID_BYTES) on ONE rank (ncclGetUniqueId); the caller hands it to the others (MPI_Bcast-like, any
+ * side channel) */
+int disco_comm_unique_id(void *out, size_t cap);
+/* joins the RCCL communicator of nranks ranks (ncclCommInitRank on the context's device) */
+int disco_comm_init(disco_ctx *ctx, const void *unique_id, int nranks, int rank);
+/* the ranks are contexts of THIS process driven by one host thread each, on one device or on peers: collectives become
+ * device-to-device copies fenced by host barriers (RCCL refuses two ranks on one GPU; this runs the identical multi-rank
+ * code path on a single-GPU box: tests, buildG --gpus N --same-device) */
+int disco_comm_init_local(disco_ctx *const *ctxs, int nranks);
+int disco_comm_rank(const disco_ctx *ctx);  /* 0 without a communicator */
+int disco_comm_world(const disco_ctx *ctx); /* 1 without a communicator */
+/* id range this rank owns of n_total reads */
+int disco_dist_range(const disco_ctx *ctx, uint64_t n_total, uint64_t *lo, uint64_t *hi);
+/* this rank's reads = rows [lo, hi) of the job's n_total reads (replaces the per-rank file pass of MPI/Dataset.cpp:153-170) */
+int disco_dist_upload_reads(disco_ctx *ctx, const uint64_t *packed_own, uint32_t stride_words, const uint16_t *len_own, uint64_t n_total);
+int disco_dist_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
+/* one whole pass; afterwards disco_fetch_edges / disco_fetch_contained / disco_fetch_edge_files return THIS rank's share */
+int disco_dist_run_graph(disco_ctx *ctx, uint32_t flags);
+int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
 
 /* ---- results --------------------------------------------------------------------------------------------------- */
 /* rows in ascending contained-read id; returns the number of rows written, or a negative error */

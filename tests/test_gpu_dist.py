@@ -1,0 +1,95 @@
+"""-m gpu : the multi-GPU flow (range-partitioned reads, hash-partitioned index build, rows on request, survivor push) with
+G = 1..4 ranks on ONE GPU (tests/dist_util.py). The canonical output must be identical for every G and equal to the REAL
+reference's (SURVEY.md §8e 'parity across GPU counts')."""
+import numpy as np
+import pytest
+
+from disco_amd import readgen
+from tests import golden_util as gu
+from tests.dist_util import run_ranks, run_ranks_reads
+from tests.util import canon_hip, run_hip_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["u150_5k", "mixed_4k", "k30_6k", "long_2k"])
+@pytest.mark.parametrize("G", [1, 2, 3, 4])
+def test_ranks_equal_reference(name, G):
+    """regular regime: neighbour rows fetched on request"""
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden(name, ce, cc)
+    assert info["regime"] == 0 and info["asymmetric_pairs"] == 0 and info["world"] == G
+    if G > 1:
+        assert sum(i["bytes_sent"]["index_records"] for i in infos) > 0
+        assert sum(i["bytes_sent"]["row_data"] for i in infos) > 0
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_ranks_forced_adjacency_gather_equals_reference(G, monkeypatch):
+    """the order-dependent regime's path (whole adjacency gathered, every rank finishes on its own), forced on regular data"""
+    monkeypatch.setenv("DISCO_DIST_FORCE_GATHER", "1")
+    reads, fidx, mo = gu.case_inputs("mixed_4k")
+    edges, rows, info, _ = run_ranks_reads(reads, mo, G)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden("mixed_4k", ce, cc)
+    assert info["regime"] == 1
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_ranks_order_dependent_regime_equals_single_gpu(G):
+    """repeats: the cap binds, pairs are found from one side only -> adjacency gathered; result = the single-GPU pass = the oracle"""
+    from oracle import pyoracle
+
+    reads, fidx, mo = gu.case_inputs("repeats_8k")
+    edges, rows, info, _ = run_ranks_reads(reads, mo, G)
+    ce, cc = canon_hip(edges, rows, fidx)
+    oce, occ, ocnt = pyoracle.oracle_canonical(reads, fidx, mo)
+    assert info["regime"] == 1 and info["dropped_hits"] > 0
+    assert info["asymmetric_pairs"] == ocnt["asymmetric_pairs"] and info["e_pre"] == ocnt["e_pre"]
+    assert np.array_equal(cc, occ) and np.array_equal(ce, oce)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_ranks_generated_reads_match_single_gpu(G):
+    """reads generated on the device, range by range; counters of the whole job equal the single-GPU pass"""
+    from disco_amd import buildgraph
+
+    spec = readgen.GenSpec.coverage(seed=7, n_reads=200_000, read_len=150, cov=30.0)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        e1, r1, c1 = g.fetch_edges(), g.fetch_contained(), g.counters()
+    edges, rows, info, infos = run_ranks(G, 40, lambda g: g.dist_generate_reads(spec), passes=2)
+    for key in ("e_pre", "e_out", "n_contained", "probes", "kmer_hits", "cap_bind_sites"):
+        assert info[key] == c1[key], (key, info[key], c1[key])
+    ce1, cc1 = canon_hip(e1, r1)
+    ce2, cc2 = canon_hip(edges, rows)
+    assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
+    assert info["tr_rounds"] >= 1
+
+
+def test_ranks_with_empty_ranges():
+    """fewer reads than ranks x 64: some ranks own nothing and still take part in every collective"""
+    reads, fidx, mo = gu.case_inputs("ref_10reads_containedReads")
+    edges, rows, info, _ = run_ranks_reads(reads, mo, 3)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden("ref_10reads_containedReads", ce, cc)
+
+
+def test_third_sweeps_take_the_second_round():
+    """reads of very different lengths over a repeat-free genome with both strands: some nodes sweep a third neighbour whose
+    row round 1 did not fetch; they are redone after the request-all round and the result does not change"""
+    spec = readgen.GenSpec.coverage(seed=11, n_reads=60_000, read_len=100, cov=40.0, len_max=250)
+    from disco_amd import buildgraph
+
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        e1, r1, c1 = g.fetch_edges(), g.fetch_contained(), g.counters()
+    edges, rows, info, _ = run_ranks(3, 40, lambda g: g.dist_generate_reads(spec))
+    ce1, cc1 = canon_hip(e1, r1)
+    ce2, cc2 = canon_hip(edges, rows)
+    assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
+    assert info["e_pre"] == c1["e_pre"]

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""multi-GPU flow on ONE GPU: G ranks = G host threads over the in-process communicator; prints every rank's exchange
+volumes and timings. usage: dist_probe.py G N_READS [len_min len_max cov passes]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from disco_amd import readgen  # noqa: E402
+from tests.dist_util import run_ranks  # noqa: E402
+
+G, n = int(sys.argv[1]), int(sys.argv[2])
+lmin = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+lmax = int(sys.argv[4]) if len(sys.argv) > 4 else lmin
+cov = float(sys.argv[5]) if len(sys.argv) > 5 else 30.0
+passes = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+genome = int(n * (lmin + lmax) / 2 / cov)
+spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=max(1, genome // 5_000_000), len_max=lmax)
+t0 = time.time()
+edges, rows, info, infos = run_ranks(G, 40, lambda g: g.dist_generate_reads(spec), passes=passes)
+print(f"wall {time.time() - t0:.2f} s; e_pre {info['e_pre']} e_out {info['e_out']} contained {info['n_contained']} regime {info['regime']} "
+      f"tr_rounds {info['tr_rounds']} deferred {info['tr_deferred']}")
+for i in infos:
+    print(json.dumps({"rank": i["rank"], "ms_total": round(i["ms_total"], 2), "MB_sent": {k: round(v / 1e6, 2) for k, v in i["bytes_sent"].items()},
+                      "ms": {k: round(v, 2) for k, v in i["ms"].items()}}))
