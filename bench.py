@@ -165,9 +165,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     import torch
-    import torch.distributed as dist
 
-    from disco_amd import buildgraph, readgen
+    from disco_amd import buildgraph, launch, readgen
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
@@ -179,15 +178,12 @@ def main():
     n_contigs = max(1, genome // 5_000_000)  # 5 Mbp contigs, reads never span contigs
     spec = readgen.GenSpec.coverage(args.seed, args.reads, args.read_len, args.coverage, n_contigs=n_contigs)
     g = buildgraph.BuildGraph(min_overlap=args.min_overlap, device=local_rank)
+    cp = None
     if sharded:
         # control plane: gloo (rendezvous, barrier, max over ranks). Data plane: RCCL inside libdisco_hip.so — the unique id of
         # its communicator travels over the control plane, as MPI_Bcast would carry it (disco_comm_init)
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("gloo")
-        uid = [buildgraph.BuildGraph.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        g.comm_init(uid[0], world, rank)
+        cp = launch.ControlPlane("gloo")
+        g.comm_init(cp.broadcast_unique_id(buildgraph.BuildGraph.comm_unique_id), world, rank)
         g.dist_generate_reads(spec)  # every rank generates ITS range of the reads: the inputs are range-partitioned in HBM
     else:
         g.generate_reads(spec)  # inputs resident in HBM before the timed region
@@ -202,7 +198,7 @@ def main():
         g.synchronize()
         torch.cuda.synchronize(device)
         if sharded:
-            dist.barrier()
+            cp.barrier()
         g.synchronize()
         torch.cuda.synchronize(device)
 
@@ -219,9 +215,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = cp.max_over_ranks(elapsed)
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
 
     cnt = g.counters()
@@ -309,8 +303,7 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never lose the bench line over it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e}"}
     if sharded:
-        dist.barrier()
-        dist.destroy_process_group()
+        cp.close()
     if rank == 0:
         try:  # RCCL writes its version banner through C stdio, which is flushed at exit: push it out before the JSON line
             import ctypes

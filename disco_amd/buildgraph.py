@@ -79,6 +79,7 @@ ABI = [
     ("disco_phase_ms", C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("disco_fetch_edge_files", C.c_int64, [_P, C.c_uint32, _P, C.c_uint64]),
+    ("disco_partition_edges", C.c_int64, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     ("disco_set_query_order", C.c_int, [_P, _P]),
     ("disco_get_query_order", C.c_int, [_P, C.POINTER(_P)]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
@@ -299,6 +300,13 @@ class BuildGraph:
         out = np.zeros(max(n, 1), dtype=np.uint16)
         self._chk(self.L.disco_fetch_edge_files(self._h, n_files, out.ctypes.data, n))
         return out[:n]
+
+    def partition_edges(self, edges: np.ndarray, n_nodes: int, n_files: int):
+        """file index of every edge of a host array (EDGE_DTYPE): connected components dealt out to n_files files"""
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        out = np.zeros(max(len(edges), 1), dtype=np.uint16)
+        self._chk(self.L.disco_partition_edges(self._h, edges.ctypes.data, len(edges), n_nodes, n_files, out.ctypes.data))
+        return out[:len(edges)]
 
     def get_query_order(self) -> int:
         """device pointer of the processing order the last probe walked (0 = file order); entries: read id | length << 32"""

@@ -1517,14 +1517,11 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     return (int64_t)ne;
 }
 
-int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, uint64_t cap)
+/* connected components of the edges in the slots [0, n_slots) (valid[i] != 0; pos[i] = rank of the edge among the valid ones)
+ * dealt out to n_files files: out[pos[i]] = file of edge i */
+static int64_t partition_edges(disco_ctx *c, const u64 *d_src, const u64 *d_ent, const u8 *d_valid, const u64 *d_pos, u64 n_slots, u64 ne, u64 n,
+                               uint32_t n_files, uint16_t *out)
 {
-    if (!c || !out || n_files == 0 || n_files > 0xFFFEu) return DISCO_E_ARG;
-    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edge_files: run disco_transitive_reduce first");
-    HIPCHK(c, hipSetDevice(c->device));
-    const u64 ne = c->n_out, n = c->n;
-    if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edge_files: need room for %llu edges", (unsigned long long)ne);
-    if (ne == 0) return 0;
     u32 *parent = nullptr, *cnt = nullptr, *d_nlist = nullptr;
     u16 *cfile = nullptr, *efile = nullptr;
     u64 *list = nullptr;
@@ -1553,12 +1550,12 @@ int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, ui
     PART_CHK(dev_alloc(c, &list, list_cap));
     PART_CHK(dev_alloc(c, &d_nlist, 1));
     hipLaunchKernelGGL(uf_init_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, parent, n);
-    hipLaunchKernelGGL(uf_hook_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->out_used, parent);
+    hipLaunchKernelGGL(uf_hook_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, d_src, d_ent, d_valid, n_slots, parent);
     hipLaunchKernelGGL(uf_compress_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, parent, n);
     (void)hipMemsetAsync(cnt, 0, n * sizeof(u32), c->stream);
     (void)hipMemsetAsync(cfile, 0xFF, n * sizeof(u16), c->stream);
     (void)hipMemsetAsync(d_nlist, 0, sizeof(u32), c->stream);
-    hipLaunchKernelGGL(uf_count_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_valid, c->out_used, parent, cnt);
+    hipLaunchKernelGGL(uf_count_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, d_src, d_valid, n_slots, parent, cnt);
     /* components of at least 1/(64 files) of the edges are dealt out by size, largest first to the lightest file; the rest
      * (there can be millions of small ones) go by hash */
     const u32 thr = (u32)std::max<u64>(ne / ((u64)n_files * 64), 1);
@@ -1569,7 +1566,7 @@ int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, ui
         hipMemcpyAsync(hl.data(), list, list_cap * sizeof(u64), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
         cleanup();
-        return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: %s", hipGetErrorString(hipGetLastError()));
+        return fail(c, DISCO_E_HIP, "edge partition: %s", hipGetErrorString(hipGetLastError()));
     }
     n_list = std::min(n_list, list_cap);
     hl.resize(n_list);
@@ -1583,17 +1580,70 @@ int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, ui
     if (n_list) {
         if (hipMemcpyAsync(list, hl.data(), n_list * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
             cleanup();
-            return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: upload failed");
+            return fail(c, DISCO_E_HIP, "edge partition: upload failed");
         }
         hipLaunchKernelGGL(uf_assign_kernel, dim3((n_list + 255) / 256), dim3(256), 0, c->stream, list, n_list, cfile);
     }
-    hipLaunchKernelGGL(uf_edge_file_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_valid, c->d_out_pos, c->out_used, parent, cfile, n_files, efile);
+    hipLaunchKernelGGL(uf_edge_file_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, d_src, d_valid, d_pos, n_slots, parent, cfile, n_files, efile);
     hipError_t e1 = hipMemcpyAsync(out, efile, ne * sizeof(u16), hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipStreamSynchronize(c->stream);
     cleanup();
 #undef PART_CHK
-    if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edge_files: copy failed");
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "edge partition: copy failed");
     return (int64_t)ne;
+}
+
+int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, uint64_t cap)
+{
+    if (!c || !out || n_files == 0) return DISCO_E_ARG;
+    if (n_files > 0xFFFEu) return fail(c, DISCO_E_ARG, "disco_fetch_edge_files: at most 65534 files (%u asked for)", n_files);
+    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edge_files: run disco_transitive_reduce first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 ne = c->n_out;
+    if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edge_files: need room for %llu edges", (unsigned long long)ne);
+    if (ne == 0) return 0;
+    return partition_edges(c, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos, c->out_used, ne, c->n, n_files, out);
+}
+
+/* the same partition for edges held by the HOST (buildG --gpus N: the edges of all ranks, concatenated): src / dst are read ids
+ * below n_nodes */
+int64_t disco_partition_edges(disco_ctx *c, const disco_edge *edges, uint64_t n_edges, uint64_t n_nodes, uint32_t n_files, uint16_t *out)
+{
+    if (!c || !out || n_files == 0 || (n_edges && !edges)) return DISCO_E_ARG;
+    if (n_files > 0xFFFEu) return fail(c, DISCO_E_ARG, "disco_partition_edges: at most 65534 files (%u asked for)", n_files);
+    if (n_nodes >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "disco_partition_edges: more than 2^31 nodes");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_edges == 0) return 0;
+    u64 *d_src = nullptr, *d_ent = nullptr, *d_pos = nullptr;
+    u8 *d_valid = nullptr;
+    std::unique_ptr<u64[]> hs(new u64[n_edges]), he(new u64[n_edges]);
+    parallel_for(n_edges, [&](u64 b, u64 e_) {
+        for (u64 i = b; i < e_; i++) {
+            hs[i] = edges[i].src;
+            he[i] = ADJ_MAKE(0u, edges[i].dst, 0u, 0u);
+        }
+    });
+    int rc = DISCO_OK;
+    int64_t res = 0;
+    do {
+        if ((rc = dev_alloc(c, &d_src, n_edges)) != DISCO_OK) break;
+        if ((rc = dev_alloc(c, &d_ent, n_edges)) != DISCO_OK) break;
+        if ((rc = dev_alloc(c, &d_pos, n_edges)) != DISCO_OK) break;
+        if ((rc = dev_alloc(c, &d_valid, n_edges)) != DISCO_OK) break;
+        if (hipMemcpyAsync(d_src, hs.get(), n_edges * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_ent, he.get(), n_edges * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemsetAsync(d_valid, 1, n_edges, c->stream) != hipSuccess) {
+            rc = fail(c, DISCO_E_HIP, "disco_partition_edges: upload failed");
+            break;
+        }
+        hipLaunchKernelGGL(iota_u64_kernel, dim3(flat_grid(c, n_edges)), dim3(256), 0, c->stream, d_pos, n_edges);
+        res = partition_edges(c, d_src, d_ent, d_valid, d_pos, n_edges, n_edges, n_nodes, n_files, out);
+    } while (0);
+    dev_free(c, &d_src, n_edges);
+    dev_free(c, &d_ent, n_edges);
+    dev_free(c, &d_pos, n_edges);
+    dev_free(c, &d_valid, n_edges);
+    return rc != DISCO_OK ? rc : res;
 }
 
 int disco_set_query_order(disco_ctx *c, const void *d_order_u64)

@@ -2367,6 +2367,12 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const ulonglong2 *__re
     if (acc == 0x1234567ull) sink[0] = acc; /* keeps the loads alive */
 }
 
+__global__ void iota_u64_kernel(u64 *p, u64 n)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = i;
+}
+
 __global__ void fill_u64_kernel(u64 *p, u64 n, u64 val)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -4,14 +4,23 @@
  * Same command line and the same output files as the reference (/root/reference/src/BuildGraph/src/main.cpp:79-150,
  * runDisco.sh:200-245), so runDisco.sh works unmodified when this binary sits next to it:
  *     buildG [-pe f1,f2,...] [-se f1,...] -f <out prefix> -p <disco.cfg> [-t threads] [-m GB] [-w n] [--gpu id]
+ *            [--gpus N [--same-device] [--mpi-names]]
  * -t sets the host thread count AND the number of <prefix>_<t>_parGraph.txt / _containedReads.txt files, as in the
- * reference. The graph itself is built on the GPU through the C-ABI of libdisco_hip.so (include/disco_hip.h).
+ * reference. The graph itself is built on the GPU(s) through the C-ABI of libdisco_hip.so (include/disco_hip.h).
+ * --gpus N is the replacement of buildG-MPI / buildG-MPIRMA (MPI/main.cpp:29-37, runDisco-MPI.sh:214-258): one rank per GPU
+ * (a host thread each), reads and graph nodes range-partitioned, RCCL collectives inside the library; with --mpi-names the
+ * files carry the <prefix>_<rank>_<thread>_ names those binaries write (MPI/OverlapGraph.cpp:127,370,419,518).
  */
 #include <omp.h>
 
+#include <unistd.h>
+
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -33,9 +42,12 @@ static void usage()
               << "  -se\tcomma separated single-end read files, fasta/fastq[.gz]\n"
               << "  -f\tprefix of all output files\n"
               << "  -p\tparameter file (MinOverlap4BuildGraph is read from it)\n"
-              << "  -t\thost threads = number of partial graph files (default: all cores)\n"
+              << "  -t\thost threads = number of partial graph files (default: all cores, at most 65534)\n"
               << "  -m\tmaximum host memory in GB (accepted for compatibility)\n"
-              << "  --gpu\tGPU to use (default 0)\n";
+              << "  --gpu\tfirst GPU to use (default 0)\n"
+              << "  --gpus\tnumber of GPUs = ranks (default 1): reads and graph partitioned over them, RCCL exchanges\n"
+              << "  --same-device\tall ranks on the GPU given by --gpu (in-process exchanges; single-GPU boxes)\n"
+              << "  --mpi-names\tfile names <prefix>_<rank>_<thread>_... as written by buildG-MPI / buildG-MPIRMA (runDisco-MPI.sh)\n";
 }
 
 static std::vector<std::string> split(const std::string &s, char d)
@@ -53,8 +65,19 @@ static std::string trim(const std::string &s)
     return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
 }
 
+/* whole-string unsigned number (decimal, 0x, 0 prefixes like the reference's stoull(..., 0)); false on anything else */
+static bool parse_u64(const std::string &s, unsigned long long &out)
+{
+    const std::string t = trim(s);
+    if (t.empty() || t[0] == '-') return false;
+    errno = 0;
+    char *end = nullptr;
+    out = strtoull(t.c_str(), &end, 0);
+    return errno == 0 && end && *end == '\0';
+}
+
 /* BG/main.cpp:152-176 : key = value lines; default 30 */
-static bool read_min_overlap(const std::string &path, uint32_t &mo)
+static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string &err)
 {
     std::ifstream f(path);
     if (!f.is_open()) return false;
@@ -65,7 +88,14 @@ static bool read_min_overlap(const std::string &path, uint32_t &mo)
         if (eq == std::string::npos) continue;
         auto tok = split(line, '=');
         if (tok.size() < 2) continue;
-        if (trim(tok[0]) == "MinOverlap4BuildGraph") mo = (uint32_t)std::stoull(trim(tok[1]), nullptr, 0);
+        if (trim(tok[0]) == "MinOverlap4BuildGraph") {
+            unsigned long long v = 0;
+            if (!parse_u64(tok[1], v) || v > 0xFFFFFFFFull) {
+                err = "MinOverlap4BuildGraph = '" + trim(tok[1]) + "' in " + path + " is not a number";
+                return true;
+            }
+            mo = (uint32_t)v;
+        }
     }
     return true;
 }
@@ -81,14 +111,22 @@ static int die(const std::string &msg)
         if ((expr) < 0) return die(std::string(#expr " : ") + disco_last_error(ctx));      \
     } while (0)
 
+struct RankResult {
+    std::vector<disco_contained_row> rows;
+    std::unique_ptr<disco_edge[]> edges;
+    uint64_t n_edges = 0;
+    disco_dist_info info{};
+    std::string err;
+};
+
 int main(int argc, char **argv)
 {
     std::cout << "Software: Disco Assembler BuildGraph, MI355X-native drop-in (disco_amd)\n";
     auto t_main = Clock::now();
     std::vector<std::string> pe, se;
     std::string prefix, cfg;
-    int threads = omp_get_max_threads(), gpu = 0;
-    unsigned long long mem_gb = 0, wsize = 0;
+    int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
+    bool same_device = false, mpi_names = false;
     std::cout << "PRINTING ARGUMENTS\n";
     for (int i = 0; i < argc; i++) std::cout << argv[i] << ' ';
     std::cout << std::endl;
@@ -98,29 +136,52 @@ int main(int argc, char **argv)
     }
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
-        auto next = [&]() -> std::string { return (i + 1 < argc) ? argv[++i] : std::string(); };
+        bool bad = false;
+        auto next = [&]() -> std::string {
+            if (i + 1 < argc) return argv[++i];
+            bad = true;
+            return std::string();
+        };
+        auto num = [&](unsigned long long lo, unsigned long long hi) -> unsigned long long {
+            unsigned long long v = 0;
+            const std::string t = next();
+            if (bad || !parse_u64(t, v) || v < lo || v > hi) {
+                bad = true;
+                std::cerr << "Option " << a << " needs a number in [" << lo << ", " << hi << "]" << (t.empty() ? "" : ", got '" + t + "'") << "\n";
+            }
+            return v;
+        };
         if (a == "-pe") for (auto &f : split(next(), ',')) pe.push_back(f);
         else if (a == "-se") for (auto &f : split(next(), ',')) se.push_back(f);
         else if (a == "-f") prefix = next();
-        else if (a == "-t") threads = (int)std::stoull(next(), nullptr, 0);
-        else if (a == "-w") wsize = std::stoull(next(), nullptr, 0);
-        else if (a == "-m") mem_gb = std::stoull(next(), nullptr, 0);
+        else if (a == "-t") threads = (int)num(1, 65534); /* one partial graph file per thread: 16-bit file index */
+        else if (a == "-w") (void)num(0, ~0ull);
+        else if (a == "-m") (void)num(0, ~0ull);
         else if (a == "-p") cfg = next();
-        else if (a == "--gpu") gpu = (int)std::stoull(next(), nullptr, 0);
+        else if (a == "--gpu") gpu = (int)num(0, 1023);
+        else if (a == "--gpus") gpus = (int)num(1, 64);
+        else if (a == "--same-device") same_device = true;
+        else if (a == "--mpi-names") mpi_names = true;
         else {
             usage();
             if (a == "-h" || a == "--help") return 0;
             std::cerr << "Unknown option: " << a << "\n\n";
             return 1; /* BG/main.cpp:133-148 */
         }
+        if (bad) {
+            usage();
+            return 1;
+        }
     }
-    (void)mem_gb;
-    (void)wsize;
-    if (threads < 1) threads = 1;
     uint32_t min_overlap = 30;
-    if (!read_min_overlap(cfg, min_overlap)) {
+    std::string cfg_err;
+    if (!read_min_overlap(cfg, min_overlap, cfg_err)) {
         std::cerr << "Unable to open parameter file: " << cfg << std::endl;
         return 1; /* BG/main.cpp:157-160 */
+    }
+    if (!cfg_err.empty()) {
+        std::cerr << cfg_err << std::endl;
+        return 1;
     }
     std::cout << "MinOverlap4BuildGraph = " << min_overlap << std::endl;
 
@@ -145,66 +206,162 @@ int main(int argc, char **argv)
                   << (fr.good + fr.bad) << " total reads in current dataset.\n";
     }
     std::cout << "Shortest read length in all datasets: " << rs.shortest << "\n Longest read length in all datasets: " << rs.longest << std::endl;
+    if (rs.too_long)
+        std::cout << "Warning: " << rs.too_long << " reads longer than 32767 bp were dropped (15-bit length field of the index records, "
+                  << "BG/HashTable.cpp:531); the reference would keep them." << std::endl;
     if (rs.size() == 0) return die("No reads found in the read files provided! Please check if the filename(s) and path(s) are correct.");
     if (!disco::write_read_id_map(prefix, rs, err)) return die(err);
     const double t_parse = secs(t0);
     std::cout << "Function readDataset() finished in " << t_parse << " Seconds." << std::endl;
 
-    /* ---- graph on the GPU ----------------------------------------------------------------------------------------- */
-    t0 = Clock::now();
-    disco_params prm{min_overlap, 4, 0, 0};
-    disco_ctx *ctx = nullptr;
-    if (disco_create(gpu, &prm, &ctx) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
-    DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed, rs.stride_words, rs.len.data(), rs.size()));
-    const double t_h2d = secs(t0);
-    t0 = Clock::now();
-    DISCO_CALL(ctx, disco_build_index(ctx));
-    DISCO_CALL(ctx, disco_probe(ctx));
-    uint64_t n_cont = 0, e_pre = 0, e_out = 0;
-    DISCO_CALL(ctx, disco_mark_contained(ctx, &n_cont));
-    std::cout << "\n" << (rs.size() - n_cont) << " Non-contained reads. (Keep as is)\n"
-              << n_cont << " contained reads. (Need to change their mate-pair information)" << std::endl;
-    DISCO_CALL(ctx, disco_build_edges(ctx, &e_pre));
-    DISCO_CALL(ctx, disco_transitive_reduce(ctx, &e_out));
-    const double t_graph = secs(t0);
-    disco_counters cn;
-    DISCO_CALL(ctx, disco_get_counters(ctx, &cn));
-    std::cout << "Graph construction complete.\n"
-              << "  overlaps (pre-reduction) : " << e_pre << "\n  edges after reduction    : " << e_out << "\n  k-mer probes             : " << cn.probes
-              << "\n  k-mer hits               : " << cn.kmer_hits << "\n  cap_bind_sites           : " << cn.cap_bind_sites
-              << "\n  asymmetric_pairs         : " << cn.asymmetric_pairs << "\n"
-              << "Function buildOverlapGraph() [GPU] finished in " << t_graph << " Seconds (" << (t_graph > 0 ? e_pre / t_graph : 0)
-              << " overlaps/s); host->device " << t_h2d << " Seconds." << std::endl;
-    if (cn.cap_bind_sites || cn.asymmetric_pairs)
-        std::cout << "Note: this input is in the order-dependent regime of the reference (edge cap per k-mer reached or overlaps found from one "
-                     "side only); the reference's own result varies with its thread count here."
-                  << std::endl;
-
-    /* ---- outputs -------------------------------------------------------------------------------------------------- */
-    t0 = Clock::now();
+    /* ---- graph on the GPU(s) ---------------------------------------------------------------------------------------- */
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
+    disco_params prm{min_overlap, 4, 0, 0};
+    uint64_t n_cont = 0, e_pre = 0, e_out = 0;
+    std::vector<disco_contained_row> rows;
+    std::unique_ptr<disco_edge[]> edges;
+    std::unique_ptr<uint16_t[]> edge_file;
+    const int n_edge_files = mpi_names ? gpus * std::max(threads - 1, 1) : threads;
+    double t_graph = 0, t_h2d = 0;
+    t0 = Clock::now();
     auto t1 = Clock::now();
     auto lap = [&](const char *what) {
         if (verbose) fprintf(stderr, "[disco host] %-28s %.3f s\n", what, secs(t1));
         t1 = Clock::now();
     };
-    std::vector<disco_contained_row> rows(n_cont);
-    if (n_cont && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
-    lap("fetch contained rows");
-    if (!disco::write_contained(prefix, threads, rows, rs, err)) return die(err);
+    if (gpus == 1) {
+        disco_ctx *ctx = nullptr;
+        if (disco_create(gpu, &prm, &ctx) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
+        DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed, rs.stride_words, rs.len.data(), rs.size()));
+        t_h2d = secs(t0);
+        t0 = Clock::now();
+        DISCO_CALL(ctx, disco_build_index(ctx));
+        DISCO_CALL(ctx, disco_probe(ctx));
+        DISCO_CALL(ctx, disco_mark_contained(ctx, &n_cont));
+        std::cout << "\n" << (rs.size() - n_cont) << " Non-contained reads. (Keep as is)\n"
+                  << n_cont << " contained reads. (Need to change their mate-pair information)" << std::endl;
+        DISCO_CALL(ctx, disco_build_edges(ctx, &e_pre));
+        DISCO_CALL(ctx, disco_transitive_reduce(ctx, &e_out));
+        t_graph = secs(t0);
+        disco_counters cn;
+        DISCO_CALL(ctx, disco_get_counters(ctx, &cn));
+        std::cout << "Graph construction complete.\n"
+                  << "  overlaps (pre-reduction) : " << e_pre << "\n  edges after reduction    : " << e_out << "\n  k-mer probes             : " << cn.probes
+                  << "\n  k-mer hits               : " << cn.kmer_hits << "\n  cap_bind_sites           : " << cn.cap_bind_sites
+                  << "\n  asymmetric_pairs         : " << cn.asymmetric_pairs << "\n"
+                  << "Function buildOverlapGraph() [GPU] finished in " << t_graph << " Seconds (" << (t_graph > 0 ? e_pre / t_graph : 0)
+                  << " overlaps/s); host->device " << t_h2d << " Seconds." << std::endl;
+        if (cn.cap_bind_sites || cn.asymmetric_pairs)
+            std::cout << "Note: this input is in the order-dependent regime of the reference (edge cap per k-mer reached or overlaps found from one "
+                         "side only); the reference's own result varies with its thread count here."
+                      << std::endl;
+        t0 = Clock::now();
+        t1 = Clock::now();
+        rows.resize(n_cont);
+        if (n_cont && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
+        lap("fetch contained rows");
+        edges.reset(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
+        if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
+        lap("fetch edges");
+        /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
+         * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
+        edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
+        if (e_out && disco_fetch_edge_files(ctx, (uint32_t)n_edge_files, edge_file.get(), e_out) < 0) return die(disco_last_error(ctx));
+        lap("partition edges into files");
+        disco_destroy(ctx);
+        lap("release GPU context");
+    } else {
+        /* one rank per GPU, one host thread per rank (replaces mpirun -np N of runDisco-MPI.sh:214-258): rank r holds the reads
+         * [r*per, (r+1)*per), every exchange is an RCCL collective inside libdisco_hip.so */
+        std::vector<disco_ctx *> ctx((size_t)gpus, nullptr);
+        for (int r = 0; r < gpus; r++)
+            if (disco_create(same_device ? gpu : gpu + r, &prm, &ctx[(size_t)r]) < 0)
+                return die(std::string("disco_create (rank ") + std::to_string(r) + "): " + disco_last_error(nullptr) +
+                           (same_device ? "" : " — one GPU per rank is needed; --same-device runs all ranks on one GPU"));
+        unsigned char uid[DISCO_UNIQUE_ID_BYTES];
+        if (same_device) {
+            if (disco_comm_init_local(ctx.data(), gpus) < 0) return die("disco_comm_init_local failed");
+        } else if (disco_comm_unique_id(uid, sizeof uid) < 0)
+            return die(std::string("disco_comm_unique_id: ") + disco_last_error(nullptr));
+        std::vector<RankResult> res((size_t)gpus);
+        std::vector<std::thread> th;
+        for (int r = 0; r < gpus; r++)
+            th.emplace_back([&, r]() {
+                RankResult &R = res[(size_t)r];
+                disco_ctx *c = ctx[(size_t)r];
+                auto bail = [&](const char *what) {
+                    R.err = std::string(what) + ": " + disco_last_error(c);
+                    /* the other ranks wait for this one inside a collective: there is nothing to unwind to */
+                    std::cout << "\nError (rank " << r << "): " << R.err << std::endl;
+                    _exit(2);
+                };
+                if (!same_device && disco_comm_init(c, uid, gpus, r) < 0) bail("disco_comm_init");
+                uint64_t lo = 0, hi = 0;
+                if (disco_dist_range(c, rs.size(), &lo, &hi) < 0) bail("disco_dist_range");
+                if (disco_dist_upload_reads(c, rs.packed + lo * rs.stride_words, rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
+                if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS) < 0) bail("disco_dist_run_graph");
+                if (disco_dist_get_info(c, &R.info) < 0) bail("disco_dist_get_info");
+                R.rows.resize(R.info.n_contained_local);
+                if (R.info.n_contained_local && disco_fetch_contained(c, R.rows.data(), R.info.n_contained_local) < 0) bail("disco_fetch_contained");
+                R.n_edges = R.info.e_out_local;
+                R.edges.reset(new disco_edge[std::max<uint64_t>(R.n_edges, 1)]);
+                if (R.n_edges && disco_fetch_edges(c, R.edges.get(), R.n_edges) < 0) bail("disco_fetch_edges");
+            });
+        for (auto &t : th) t.join();
+        t_graph = secs(t0);
+        const disco_dist_info &di = res[0].info;
+        n_cont = di.n_contained;
+        e_pre = di.e_pre;
+        e_out = di.e_out;
+        std::cout << "\n" << (rs.size() - n_cont) << " Non-contained reads. (Keep as is)\n"
+                  << n_cont << " contained reads. (Need to change their mate-pair information)" << std::endl;
+        std::cout << "Graph construction complete on " << gpus << " ranks" << (same_device ? " (one device, in-process exchanges)" : " (RCCL)") << ".\n"
+                  << "  overlaps (pre-reduction) : " << e_pre << "\n  edges after reduction    : " << e_out << "\n  k-mer probes             : " << di.probes
+                  << "\n  k-mer hits               : " << di.kmer_hits << "\n  cap_bind_sites           : " << di.cap_bind_sites
+                  << "\n  asymmetric_pairs         : " << di.asymmetric_pairs << "\n  regime                   : "
+                  << (di.regime ? "order-dependent (adjacency gathered)" : "regular (neighbour rows on request)") << "\n"
+                  << "Function buildOverlapGraph() [" << gpus << " GPU ranks] finished in " << t_graph << " Seconds incl. upload (" << (t_graph > 0 ? e_pre / t_graph : 0)
+                  << " overlaps/s); last pass " << di.ms_total * 1e-3 << " Seconds on rank 0." << std::endl;
+        if (di.cap_bind_sites || di.asymmetric_pairs)
+            std::cout << "Note: this input is in the order-dependent regime of the reference (edge cap per k-mer reached or overlaps found from one "
+                         "side only); the reference's own result varies with its thread count here."
+                      << std::endl;
+        t0 = Clock::now();
+        t1 = Clock::now();
+        /* the ranks' shares side by side: contained rows of rank r's reads, edges whose smaller endpoint rank r owns */
+        uint64_t nr = 0, ne = 0;
+        for (auto &R : res) {
+            nr += R.rows.size();
+            ne += R.n_edges;
+        }
+        if (nr != n_cont || ne != e_out) return die("the ranks' shares do not add up to the job's totals");
+        rows.reserve(nr);
+        for (auto &R : res) {
+            rows.insert(rows.end(), R.rows.begin(), R.rows.end());
+            std::vector<disco_contained_row>().swap(R.rows);
+        }
+        edges.reset(new disco_edge[std::max<uint64_t>(ne, 1)]);
+        uint64_t at = 0;
+        for (auto &R : res) {
+            if (R.n_edges) memcpy(edges.get() + at, R.edges.get(), R.n_edges * sizeof(disco_edge));
+            at += R.n_edges;
+            R.edges.reset();
+        }
+        lap("gather the ranks' shares");
+        edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
+        if (e_out && disco_partition_edges(ctx[0], edges.get(), e_out, rs.size(), (uint32_t)n_edge_files, edge_file.get()) < 0) return die(disco_last_error(ctx[0]));
+        lap("partition edges into files");
+        for (auto c : ctx) disco_destroy(c);
+        lap("release GPU contexts");
+    }
+
+    /* ---- outputs -------------------------------------------------------------------------------------------------- */
+    disco::FileTags etags = mpi_names ? disco::FileTags::mpi_edges(gpus, threads) : disco::FileTags::plain(threads);
+    disco::FileTags ctags = mpi_names ? disco::FileTags::mpi_contained(gpus, threads) : disco::FileTags::plain(threads);
+    if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags)) return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
-    std::unique_ptr<disco_edge[]> edges(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
-    if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
-    lap("fetch edges");
-    /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
-     * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
-    std::unique_ptr<uint16_t[]> edge_file(new uint16_t[std::max<uint64_t>(e_out, 1)]);
-    if (e_out && disco_fetch_edge_files(ctx, (uint32_t)threads, edge_file.get(), e_out) < 0) return die(disco_last_error(ctx));
-    lap("partition edges into files");
-    disco_destroy(ctx);
-    lap("release GPU context");
-    if (!disco::write_edges(prefix, threads, edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr)) return die(err);
+    if (!disco::write_edges(prefix, (int)etags.tag.size(), edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr, &etags)) return die(err);
     lap("write edges");
     if (!disco::write_checkpoint(prefix, false, true, true, err)) return die(err);
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;

@@ -418,7 +418,14 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
                 for (size_t i = nr0 * (size_t)t / threads; i < nr0 * (size_t)(t + 1) / threads; i++) {
                     uint32_t cnt[5];
                     const uint32_t L = clean(b.data, R[i], buf, cnt);
-                    if (!(L > min_overlap && L <= 32767 && test_read_counted(buf.data(), L, cnt))) continue; /* BG/Dataset.cpp:305 */
+                    if (L > 32767) { /* the packed layout has the reference's 15-bit length field; the reference itself keeps such reads */
+                        if (L > min_overlap && test_read_counted(buf.data(), L, cnt)) {
+#pragma omp atomic
+                            out.too_long++;
+                        }
+                        continue;
+                    }
+                    if (!(L > min_overlap && test_read_counted(buf.data(), L, cnt))) continue; /* BG/Dataset.cpp:305 */
                     G[i] = (uint16_t)L;
                     const size_t w0 = ar.size(), W = (L + 31) / 32;
                     ar.resize(w0 + W, 0);

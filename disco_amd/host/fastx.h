@@ -43,6 +43,7 @@ struct ReadSet {
     std::vector<uint64_t> file_index; /* [n] 1-based index over all records   */
     std::vector<FileRange> files;
     uint64_t total_records = 0;
+    uint64_t too_long = 0; /* otherwise good reads dropped only because they exceed 32767 bp (counted among the bad ones) */
     uint32_t shortest = 0, longest = 0;
     uint64_t size() const { return n_reads; }
     ReadSet() = default;

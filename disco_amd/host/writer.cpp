@@ -57,7 +57,33 @@ bool write_read_id_map(const std::string &prefix, const ReadSet &rs, std::string
     return flush(prefix + "_ReadIDMap.txt", s, err);
 }
 
-bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err)
+FileTags FileTags::plain(int n_files)
+{
+    FileTags t;
+    for (int i = 0; i < n_files; i++) t.tag.push_back(std::to_string(i));
+    return t;
+}
+
+FileTags FileTags::mpi_edges(int ranks, int threads)
+{
+    FileTags t;
+    for (int r = 0; r < ranks; r++)
+        for (int i = (threads > 1 ? 1 : 0); i < std::max(threads, 1); i++) t.tag.push_back(std::to_string(r) + "_" + std::to_string(i));
+    return t;
+}
+
+FileTags FileTags::mpi_contained(int ranks, int threads)
+{
+    FileTags t;
+    for (int r = 0; r < ranks; r++)
+        for (int i = 0; i < std::max(threads, 1); i++) t.tag.push_back(std::to_string(r) + "_" + std::to_string(i));
+    return t;
+}
+
+static std::string tag_of(const FileTags *tags, int t) { return (tags && (size_t)t < tags->tag.size()) ? tags->tag[(size_t)t] : std::to_string(t); }
+
+bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err,
+                     const FileTags *tags)
 {
     /* rows of one containing read must be contiguous (SG/DataSet.cpp:316-335); the reference emits them per super read in
      * (j, bucket order) = ascending (j, contained id, record kind) */
@@ -115,7 +141,7 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
     bool ok = true;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int t = 0; t < n_files; t++) {
-        const std::string path = prefix + "_" + std::to_string(t) + "_containedReads.txt";
+        const std::string path = prefix + "_" + tag_of(tags, t) + "_containedReads.txt";
         FILE *f = fopen(path.c_str(), "wb");
         bool good = f != nullptr;
         for (size_t c = first_chunk[t]; good && c < first_chunk[t + 1]; c++)
@@ -133,7 +159,7 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
 }
 
 bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const ReadSet &rs, int threads, std::string &err,
-                 const uint16_t *edge_file)
+                 const uint16_t *edge_file, const FileTags *tags)
 {
     const uint64_t n = rs.size();
     const size_t ne = n_edges;
@@ -211,7 +237,7 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
     bool ok = true;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(threads, n_files))
     for (int t = 0; t < n_files; t++) {
-        const std::string path = prefix + "_" + std::to_string(t) + "_parGraph.txt";
+        const std::string path = prefix + "_" + tag_of(tags, t) + "_parGraph.txt";
         FILE *f = fopen(path.c_str(), "wb");
         bool good = f != nullptr;
         for (size_t c = first_chunk[t]; good && c < first_chunk[t + 1]; c++)
@@ -227,7 +253,7 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
         /* layout compatibility: one start id per file (BG/OverlapGraph.cpp:211) */
         std::string e2;
         uint64_t first = n_files ? (uint64_t)(((__uint128_t)n * (unsigned)t + n_files - 1) / n_files) + 1 : 1;
-        flush(prefix + "_" + std::to_string(t) + "_startRead.txt", std::to_string(first) + "\n", e2);
+        flush(prefix + "_" + tag_of(tags, t) + "_startRead.txt", std::to_string(first) + "\n", e2);
     }
     return ok;
 }

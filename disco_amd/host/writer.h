@@ -18,14 +18,25 @@
 
 namespace disco {
 
+/* the "<t>" of <prefix>_<t>_parGraph.txt for every file: "0", "1", ... (buildG, BG/OverlapGraph.cpp:385,899) or "<rank>_<thread>"
+ * (the multi-process binaries, MPI/OverlapGraph.cpp:127,370,419,518; runDisco-MPI.sh:165-186 lists edge files for threads
+ * 1..t-1 of every rank — thread 0 is the communication thread there — and contained-read files for threads 0..t-1) */
+struct FileTags {
+    std::vector<std::string> tag;
+    static FileTags plain(int n_files);
+    static FileTags mpi_edges(int ranks, int threads);     /* ranks * max(threads - 1, 1) files */
+    static FileTags mpi_contained(int ranks, int threads); /* ranks * threads files             */
+};
+
 bool write_read_id_map(const std::string &prefix, const ReadSet &rs, std::string &err);
-/* every t in [0, n_files) gets a file, empty ones included (the consumer aborts on a missing file) */
-bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err);
+/* every file gets written, empty ones included (the consumer aborts on a missing file) */
+bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err,
+                     const FileTags *tags = nullptr);
 /* edge_file: file of every edge when both of its ends have ALL their edges there (disco_fetch_edge_files: connected components
  * dealt out to the files) — every line then carries flag 2; nullptr: files own contiguous id ranges, an edge between two
  * files is written to both with flags 0 / 1 */
 bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const ReadSet &rs, int threads, std::string &err,
-                 const uint16_t *edge_file = nullptr);
+                 const uint16_t *edge_file = nullptr, const FileTags *tags = nullptr);
 bool write_checkpoint(const std::string &prefix, bool ccr, bool gc, bool append, std::string &err);
 void read_checkpoint(const std::string &prefix, bool &ccr, bool &gc);
 

@@ -226,6 +226,9 @@ int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
  * file — what lets the consumer pre-simplify the files independently (SG/OverlapGraphSimple.cpp:344,636-644; the reference
  * gets it from the locality of its BFS batches, BG/OverlapGraph.cpp:100-325) */
 int64_t disco_fetch_edge_files(disco_ctx *ctx, uint32_t n_files, uint16_t *out, uint64_t cap);
+/* the same partition for edges the HOST holds (buildG --gpus N: the edges all ranks emitted, concatenated; n_nodes = reads of
+ * the whole job): out[i] = file of edges[i]. Any context will do; its graph state is not touched. */
+int64_t disco_partition_edges(disco_ctx *ctx, const disco_edge *edges, uint64_t n_edges, uint64_t n_nodes, uint32_t n_files, uint16_t *out);
 int disco_get_counters(disco_ctx *ctx, disco_counters *out);
 /* milliseconds of the last run of each phase, measured with HIP events on the stream the kernels were launched on
  * (index = DISCO_PH_*). DISCO_PH_PROBE_KERNEL / DISCO_PH_VERIFY each bracket exactly one launch of the two longest kernels. */

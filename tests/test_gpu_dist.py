@@ -93,3 +93,42 @@ def test_third_sweeps_take_the_second_round():
     ce2, cc2 = canon_hip(edges, rows)
     assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
     assert info["e_pre"] == c1["e_pre"]
+
+
+def test_ownership_arithmetic_matches_the_library():
+    from disco_amd import buildgraph, launch
+
+    gs = [buildgraph.BuildGraph(min_overlap=40) for _ in range(3)]
+    try:
+        buildgraph.BuildGraph.comm_init_local(gs)
+        for n in (0, 1, 64, 65, 1000, 12345677):
+            for r, g in enumerate(gs):
+                assert g.dist_range(n) == launch.owner_range(n, r, 3)
+                assert (g.rank, g.world) == (r, 3)
+    finally:
+        for g in gs:
+            g.close()
+
+
+def test_partition_of_host_edges_keeps_components_together():
+    """disco_partition_edges (buildG --gpus N): the edges of all ranks, held by the host, dealt to files by component"""
+    from disco_amd import buildgraph
+
+    rng = np.random.default_rng(5)
+    n, ncomp = 20000, 400
+    comp = rng.integers(0, ncomp, n)
+    order = np.argsort(comp, kind="stable")
+    e = np.zeros(0, dtype=buildgraph.EDGE_DTYPE)
+    src, dst = [], []
+    for c in range(ncomp):  # a path through every component
+        ids = order[comp[order] == c]
+        src += list(ids[:-1])
+        dst += list(ids[1:])
+    e = np.zeros(len(src), dtype=buildgraph.EDGE_DTYPE)
+    e["src"], e["dst"] = np.minimum(src, dst), np.maximum(src, dst)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        f = g.partition_edges(e, n, 7)
+    assert f.max() < 7 and len(np.unique(f)) == 7
+    file_of_comp = {}
+    for s, fi in zip(e["src"], f):
+        assert file_of_comp.setdefault(int(comp[s]), int(fi)) == int(fi)

@@ -73,10 +73,37 @@ def test_cli_usage_and_unknown_flag():
     assert p.returncode == 1 and "Unable to open parameter file" in p.stderr
 
 
+def test_cli_rejects_malformed_numbers(tmp_path):
+    """a missing or non-numeric value prints the usage and exits 1 (the reference's stoull would abort the process)"""
+    build.build_host()
+    exe = os.path.join(BIN, "buildG")
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\n")
+    for argv in (["-se", "x.fa", "-f", "g", "-p", str(cfg), "-t"], ["-se", "x.fa", "-f", "g", "-p", str(cfg), "-t", "four"],
+                 ["-se", "x.fa", "-f", "g", "-p", str(cfg), "-t", "70000"], ["-se", "x.fa", "-f", "g", "-p", str(cfg), "-m", "-3"],
+                 ["-se", "x.fa", "-f", "g", "-p", str(cfg), "--gpus", "0"]):
+        p = subprocess.run([exe] + argv, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        assert p.returncode == 1 and "Usage: buildG" in p.stderr and "needs a number" in p.stderr, (argv, p.stderr)
+    bad = tmp_path / "bad.cfg"
+    bad.write_text("MinOverlap4BuildGraph = abc\n")
+    p = subprocess.run([exe, "-se", "x.fa", "-f", "g", "-p", str(bad)], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 1 and "is not a number" in p.stderr
+
+
+def _file_tags(threads, gpus, mpi_names):
+    """(edge-file tags, contained-file tags) the run must produce"""
+    if not mpi_names:
+        t = [str(i) for i in range(threads)]
+        return t, t
+    first = 1 if threads > 1 else 0  # runDisco-MPI.sh:165-186: edge files of threads 1..t-1, contained files of threads 0..t-1
+    return ([f"{r}_{i}" for r in range(gpus) for i in range(first, threads)], [f"{r}_{i}" for r in range(gpus) for i in range(threads)])
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads", [1, 4])
-def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
-    """whole drop-in: argv in, files out; canonical content identical to the real reference's files"""
+@pytest.mark.parametrize("threads,gpus,mpi_names", [(1, 1, False), (4, 1, False), (3, 2, False), (3, 2, True), (2, 3, True), (1, 2, True)])
+def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_names):
+    """whole drop-in: argv in, files out; canonical content identical to the real reference's files — on one GPU and with
+    --gpus N ranks (here all on one device: --same-device), plain and buildG-MPI file names"""
     build.build_host()
     c = gu.CASES["multifile"]
     cfg = tmp_path / "disco.cfg"
@@ -85,10 +112,18 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
     pe = ",".join(os.path.join(gu.GOLD, f) for f in c["pe"])
     se = ",".join(os.path.join(gu.GOLD, f) for f in c["se"])
     cmd = [os.path.join(BIN, "buildG"), "-pe", pe, "-se", se, "-f", prefix, "-p", str(cfg), "-t", str(threads), "-m", "8"]
+    if gpus > 1:
+        cmd += ["--gpus", str(gpus), "--same-device"]
+    if mpi_names:
+        cmd += ["--mpi-names"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0, p.stdout
-    for t in range(threads):  # every file must exist, empty or not (SG/DataSet.cpp:294-295)
-        assert os.path.exists(f"{prefix}_{t}_parGraph.txt") and os.path.exists(f"{prefix}_{t}_containedReads.txt")
+    etags, ctags = _file_tags(threads, gpus, mpi_names)
+    for t in etags:  # every file must exist, empty or not (SG/DataSet.cpp:294-295)
+        assert os.path.exists(f"{prefix}_{t}_parGraph.txt"), t
+    for t in ctags:
+        assert os.path.exists(f"{prefix}_{t}_containedReads.txt"), t
+    assert len(glob.glob(prefix + "_*_parGraph.txt")) == len(etags) and len(glob.glob(prefix + "_*_containedReads.txt")) == len(ctags)
     edges = refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt")))
     cont = refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt")))
     gu.check_against_golden("multifile", edges, cont)
@@ -98,7 +133,7 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
     # flag rule: a node flagged as marked in file t has ALL its edges in file t
     all_edges = {}
     per_file = []
-    for t in range(threads):
+    for t in etags:
         rows = [l.rstrip("\n").split("\t") for l in open(f"{prefix}_{t}_parGraph.txt")]
         per_file.append(rows)
         for a, b, info in rows:
@@ -122,7 +157,7 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads):
     assert n_lines == len({e for es in all_edges.values() for e in es})
     assert all(info.rsplit(",", 1)[1] == "2" for rows in per_file for _, _, info in rows)
     # contained rows of one containing read are contiguous (SG/DataSet.cpp:316-335)
-    for t in range(threads):
+    for t in ctags:
         supers = [l.split("\t")[1] for l in open(f"{prefix}_{t}_containedReads.txt")]
         seen, prev = set(), None
         for s in supers:
