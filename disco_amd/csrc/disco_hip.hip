@@ -929,6 +929,8 @@ static int select_edges(disco_ctx *c)
     a.big_cap = c->big_cap;
     a.scratch = nullptr;
     a.scratch_cap = 0;
+    a.order = c->d_order_used; /* the headers in meta_ord are by position in THIS order */
+    a.meta_ord = c->d_meta_ord;
     ph_begin(c, DISCO_PH_SELECT);
     if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);

@@ -711,7 +711,8 @@ struct VerifyArgs {
     const u64 *row_start;
     u32 *row_cnt; /* in: candidates, out: verified overlap hits (row compacted in place) */
     const u64 *order; /* [q_hi - q_lo] processing order (read ids), or null */
-    const ulonglong2 *meta_ord; /* [q_hi - q_lo] headers by position in the order (written by probe_kernel) */
+    ulonglong2 *meta_ord; /* [q_hi - q_lo] headers by position in the order (written by probe_kernel); out: the count becomes the
+                             number of verified overlap hits — edge_select_kernel walks the same order and reads it here */
 };
 
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
@@ -839,6 +840,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         ord_chunk = a.order ? a.order[i] : a.v.q_lo + i;
         meta_chunk = a.meta_ord[i];
     }
+    u32 nk_chunk = 0; /* lane i: verified hits of the chunk's read i (0 for reads without candidates) */
     Meta m0 = load_meta(cbeg), m1 = load_meta(cbeg + 1), m2 = load_meta(cbeg + 2);
     u64 h0 = load_cands(m0, rid(cbeg)), h1 = load_cands(m1, rid(cbeg + 1));
     Rows R0 = load_rows(m0, h0, rid(cbeg));
@@ -984,6 +986,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                 a.row_cnt[A] = nkeep;
                 my_raw += nkeep;
             }
+            if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
         }
         m0 = m1;
         m1 = m2;
@@ -992,6 +995,8 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         h1 = h2;
         R0 = R1;
     }
+    /* the counts of the whole chunk in one coalesced store: {row start, verified hits | length << 32} by position in the order */
+    if (lane < (u32)(cend - cbeg)) a.meta_ord[cbeg + lane].y = (u64)nk_chunk | (meta_chunk.y & 0xFFFFFFFF00000000ull);
     }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {
@@ -1058,6 +1063,11 @@ struct EdgeSelArgs {
     u32 big_cap;
     u64 *scratch;  /* BIG: gridDim.x * 2 * scratch_cap entries   */
     u64 scratch_cap;
+    /* the reads are taken in the processing order of probe / verify (or ascending id when order is null), headers by position:
+     * {row start, verified hits | length << 32}. Reads of one locus come back to back, so the bitmap words of their (shared)
+     * destinations are still in the L2 for the next read — in file order 16 of a read's 44 bitmap gathers missed it */
+    const u64 *order;
+    const ulonglong2 *meta_ord;
 };
 
 /* stable-free rank sort of m distinct keys from src into dst (wave cooperative) */
@@ -1322,13 +1332,17 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
         u32 c, LA, cw; /* raw: candidates, length, bitmap word holding the read's own contained bit */
         u64 rs;
     };
-    auto read_of = [&](u64 it) { return a.v.q_lo + (it < cend ? it : cend - 1); };
+    u64 ord_chunk = 0;                             /* lane i: read of the chunk's position i (WQ_CHUNK == 64) */
+    ulonglong2 meta_chunk = make_ulonglong2(0, 0); /* lane i: its header                                      */
+    auto read_of = [&](u64 it) { return ORDER_ID(readlane_u64(ord_chunk, (u32)((it < cend ? it : cend - 1) - cbeg))); };
     auto ld_meta = [&](u64 it) {
         SelMeta m;
-        const u64 A = read_of(it);
-        m.c = a.row_cnt[A];
-        m.rs = a.row_start[A];
-        m.LA = a.v.len[A];
+        const u32 i = (u32)((it < cend ? it : cend - 1) - cbeg);
+        const u64 A = ORDER_ID(readlane_u64(ord_chunk, i));
+        const u64 w = readlane_u64(meta_chunk.y, i);
+        m.c = (u32)w;
+        m.LA = (u32)(w >> 32);
+        m.rs = readlane_u64(meta_chunk.x, i);
         m.cw = ((const u32 *)a.contained)[A >> 5];
         return m;
     };
@@ -1351,6 +1365,11 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             }
             continue;
         }
+        {
+            const u64 i = cbeg + (lane < cend - cbeg ? lane : 0u);
+            ord_chunk = a.order ? a.order[i] : a.v.q_lo + i;
+            meta_chunk = a.meta_ord[i];
+        }
         /* stages: meta of read it+3 | hit row of it+2 | bitmap gather of it+1 | selection of it */
         SelMeta m0 = ld_meta(cbeg), m1 = ld_meta(cbeg + 1), m2 = ld_meta(cbeg + 2);
         u32 c0 = fin_meta(m0, cbeg), c1 = fin_meta(m1, cbeg + 1);
@@ -1366,7 +1385,7 @@ __global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
             const u64 h1 = fin_row(c1, r1);
             const u32 w1 = ld_gather(h1, it + 1);
             const u64 g0 = fin_gather(h0, w0);
-            const u64 A = a.v.q_lo + it;
+            const u64 A = read_of(it);
             if (c0 == 0) {
                 if (lane == 0) a.ref[A] = 0;
             } else if (c0 > ES_CAP) {
