@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)  # = BASELINE config 2
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-buffers-in / host-structs-out pass")
+    ap.add_argument("--no-stage", action="store_true", help="skip the stage wall (FASTA -> files through disco_amd/bin/buildG) at the benched config")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path (RCCL communicator, every exchange) even with one rank")
     return ap.parse_args()
 
@@ -55,6 +57,37 @@ def algorithmic_bytes(cnt, n_reads, words_mean):
     total = N * R + 2 * N * 16 + N * R + Q * 8 + H * R + E_pre * 16 + 2 * E_pre * 16 + E_out * 16 + C * 16
     per_kernel = {"probe_kernel": N * R + Q * 8, "verify_kernel": H * R + E_pre * 16}
     return total, per_kernel
+
+
+KERNEL_SOURCES = ("disco_amd/csrc/disco_kernels.h", "disco_amd/csrc/disco_device.h", "disco_amd/csrc/disco_dist.h", "disco_amd/csrc/disco_hip.hip")
+
+
+def kernels_sha16():
+    """fingerprint of the kernel sources: profiles/probe_traffic.json carries the one it was measured with, and its counter
+    figures are only quoted for exactly these kernels"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def reference_at_config3():
+    """the REAL reference's run on BASELINE config 3 (50 M x 150 bp), done once in the build container and recorded in
+    tests/golden/u150_50m.reference_run.txt (it takes 78 minutes; the GPU box's baseline leg samples config 2 instead)"""
+    path = os.path.join(ROOT, "tests", "golden", "u150_50m.reference_run.txt")
+    try:
+        txt = open(path).read()
+        t = sum(float(re.search(r"Function %s\(\) finished in ([0-9.eE+-]+) Seconds" % fn, txt).group(1)) for fn in ("insertDataset", "buildOverlapGraphFromHashTable"))
+        wall = float(re.search(r"Function main\(\) finished in ([0-9.eE+-]+) Seconds", txt).group(1))
+        cases = json.load(open(os.path.join(ROOT, "tests", "golden", "cases_big.json")))
+        e_pre = 903_537_181  # = the HIP path's count on the same (digest-checked) reads; the reference does not print it
+        return {"overlaps_per_s": e_pre / t, "graph_s": t, "whole_process_s": wall, "threads": 7, "where": "build container, 8 vCPU",
+                "edges": cases["u150_50m"]["n_edges"], "source": "tests/golden/u150_50m.reference_run.txt"}
+    except Exception:
+        return None
 
 
 def usable_cores():
@@ -131,6 +164,51 @@ def cpu_baseline(args, spec_full):
     pyoracle.build_graph(codes, off, args.min_overlap)
     t = time.perf_counter() - t0
     return dict(value=e_pre / t, unit="overlaps/s", cores=1, kind="port", sample=sample + f"; C restatement {t:.2f} s")
+
+
+def stage_wall(args, spec, e_pre):
+    """SURVEY.md §8(d) 'stage' wall at the BENCHED configuration: the FASTA of the same reads (disco_amd/bin/readgen) through the
+    drop-in executable, process start to files closed — parse + filter + pack on the host cores, upload, graph on the GPU,
+    fetch, text output. What the reference's 'Function main() finished in' line measures."""
+    import shutil
+
+    gen = os.path.join(ROOT, "disco_amd", "bin", "readgen")
+    exe = os.path.join(ROOT, "disco_amd", "bin", "buildG")
+    if not (os.path.exists(gen) and os.path.exists(exe)):
+        return {"skipped": "disco_amd/bin/readgen or buildG not built"}
+    need = args.reads * (args.read_len + 12) * 1.5 + (1 << 30)
+    d = tempfile.mkdtemp(prefix="disco_stage_")
+    try:
+        if shutil.disk_usage(d).free < need:
+            return {"skipped": "not enough free disk for the FASTA and the edge files (%.1f GB needed)" % (need / 1e9)}
+        fa = os.path.join(d, "reads.fasta")
+        t0 = time.perf_counter()
+        subprocess.run([gen, fa, str(args.reads), str(args.read_len), repr(float(args.coverage)), str(args.seed), str(args.read_len), "5000000"],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_gen = time.perf_counter() - t0
+        with open(os.path.join(d, "disco.cfg"), "w") as f:
+            f.write(f"MinOverlap4BuildGraph = {args.min_overlap}\n")
+        cores = usable_cores()
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "-se", fa, "-f", os.path.join(d, "g"), "-p", os.path.join(d, "disco.cfg"), "-t", str(cores)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"))
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"failed": p.stdout[-500:]}
+        parts = {}
+        for key, pat in (("parse_filter_pack_s", r"Function readDataset\(\) finished in ([0-9.eE+-]+)"), ("graph_s", r"\[GPU\] finished in ([0-9.eE+-]+)"),
+                         ("upload_s", r"host->device ([0-9.eE+-]+)"), ("fetch_and_write_s", r"Function saveParGraphToFile\(\) finished in ([0-9.eE+-]+)")):
+            m = re.search(pat, p.stdout)
+            if m:
+                parts[key] = float(m.group(1))
+        m = re.search(r"overlaps \(pre-reduction\) : (\d+)", p.stdout)
+        same = (int(m.group(1)) == e_pre) if m else None
+        out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("g_"))
+        return {"wall_s": round(wall, 3), "overlaps_per_s": e_pre / wall, "host_threads": cores, "fasta_bytes": os.path.getsize(fa), "output_bytes": out_bytes,
+                "same_overlap_count_as_the_bench_pass": same, "fasta_generation_s": round(t_gen, 2), **parts,
+                "what": "disco_amd/bin/buildG on the FASTA of the benched reads, process start to files closed (the reference's main() timer)"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def spawn_ranks(args):
@@ -232,13 +310,18 @@ def main():
     total_b, kern_b = algorithmic_bytes(cnt_all, args.reads, words_mean)
     avg_ms = {k: sum(v) / max(len(v), 1) for k, v in kern_ms.items()}
     dominant = max(avg_ms, key=lambda k: avg_ms[k])  # the longest kernel of the pass
-    tj = {}
+    tj, traffic_note = {}, "no counter profile for this workload"
     tfile = os.path.join(ROOT, "profiles", "probe_traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             if tj.get("reads") != args.reads or tj.get("gpus", 1) != world:
-                tj = {}
+                tj, traffic_note = {}, "profiles/probe_traffic.json was taken on another workload"
+            elif tj.get("kernels_sha16") != kernels_sha16():
+                tj, traffic_note = {}, ("profiles/probe_traffic.json was taken with other kernel sources (%s, now %s): re-run profiles/prof_pmc.sh"
+                                        % (tj.get("kernels_sha16"), kernels_sha16()))
+            else:
+                traffic_note = "FETCH_SIZE + WRITE_SIZE of profiles/probe_traffic.json (rocprofv3 --pmc, same kernel sources: %s)" % tj["kernels_sha16"]
         except Exception:
             tj = {}
 
@@ -257,7 +340,8 @@ def main():
         ach = b_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "peak_measured_copy": hbm_measured, "peak_measured_row_gather": gather_measured,
-                "traffic": tj.get("kernels", {}).get(kname), "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": ms}
+                "traffic": tj.get("kernels", {}).get(kname), "traffic_source": traffic_note, "algorithmic_bytes_per_launch": b_launch,
+                "avg_launch_ms": ms}
 
     out = {
         "metric": "overlaps/sec (BuildGraph stage), 150 bp reads",
@@ -291,6 +375,16 @@ def main():
         "roofline": roof(dominant),
         "roofline_other": [roof(k) for k in avg_ms if k != dominant],
     }
+    if not sharded and not args.no_host_to_host:
+        # SURVEY.md §8(d) 'graph' wall: host buffers in, host structs out (the HBM-resident `value` never includes the copies)
+        try:
+            h2h = g.host_to_host_pass()
+            h2h["overlaps_per_s"] = e_pre / (h2h["total_ms"] * 1e-3)
+            h2h["what"] = ("pinned packed reads in host memory -> disco_upload_reads -> whole pass (first pass: pays its allocations) -> "
+                           "disco_fetch_contained + disco_fetch_edges into host structs")
+            out["graph_host_to_host"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in h2h.items()}
+        except Exception as e:
+            out["graph_host_to_host"] = {"failed": str(e)}
     if sharded:  # rank 0's view of the exchanges of the last pass
         out["config"]["exchanges_rank0"] = {"regime": "regular" if info["regime"] == 0 else "order-dependent (adjacency gathered)",
                                             "tr_rounds": info["tr_rounds"], "tr_deferred": info["tr_deferred"],
@@ -302,6 +396,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, spec)
         except Exception as e:  # the baseline is a reported extra; never lose the bench line over it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e}"}
+        if args.reads == 50_000_000 and args.read_len == 150 and args.min_overlap == 40 and args.seed == 42:
+            ref3 = reference_at_config3()
+            if ref3:
+                out["cpu_baseline"]["reference_at_benched_config"] = ref3
+    if rank == 0 and world == 1 and not args.no_stage:
+        try:
+            out["stage_drop_in"] = stage_wall(args, spec, e_pre)
+        except Exception as e:
+            out["stage_drop_in"] = {"failed": str(e)}
     if sharded:
         cp.close()
     if rank == 0:

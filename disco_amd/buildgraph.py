@@ -401,6 +401,44 @@ class BuildGraph:
         out["ms"] = {x: float(d.ms[i]) for i, x in enumerate(XCHG)}
         return out
 
+    def host_to_host_pass(self) -> dict:
+        """SURVEY.md §8(d) 'graph' wall: packed reads in (pinned) HOST memory -> upload -> whole graph pass -> contained rows and
+        edges in HOST structs. Uses the reads the context currently holds: they are downloaded first (untimed) into pinned
+        memory, then everything device-side is dropped and rebuilt from the host copy (so the pass pays its allocations, like a
+        real single-shot run). Returns milliseconds per part."""
+        import time
+
+        n, s = self.num_reads, self.stride_words
+        nbytes = max(n * s * 8, 8)
+        p = self.L.disco_host_alloc(nbytes)
+        if not p:
+            raise DiscoError("disco_host_alloc failed")
+        try:
+            lens = np.zeros(n, dtype=np.uint16)
+            self._chk(self.L.disco_download_reads(self._h, p, lens.ctypes.data))
+            t0 = time.perf_counter()
+            self._chk(self.L.disco_upload_reads(self._h, p, s, lens.ctypes.data, n))
+            self.synchronize()
+            t1 = time.perf_counter()
+            self.run_graph()
+            self.synchronize()
+            t2 = time.perf_counter()
+            nc = self._chk(self.L.disco_fetch_contained(self._h, None, 0))
+            ne = self._chk(self.L.disco_fetch_edges(self._h, None, 0))
+            rows = np.empty(max(nc, 1), dtype=CONTAINED_DTYPE)
+            edges = np.empty(max(ne, 1), dtype=EDGE_DTYPE)
+            t3 = time.perf_counter()
+            if nc:
+                self._chk(self.L.disco_fetch_contained(self._h, rows.ctypes.data, nc))
+            if ne:
+                self._chk(self.L.disco_fetch_edges(self._h, edges.ctypes.data, ne))
+            t4 = time.perf_counter()
+            return {"upload_ms": (t1 - t0) * 1e3, "graph_ms": (t2 - t1) * 1e3, "fetch_ms": (t4 - t3) * 1e3,
+                    "total_ms": (t2 - t0 + t4 - t3) * 1e3, "upload_bytes": int(n * s * 8), "fetch_bytes": int(nc * 40 + ne * 32),
+                    "n_contained": int(nc), "e_out": int(ne)}
+        finally:
+            self.L.disco_host_free(p)
+
     def counters(self) -> dict:
         c = Counters()
         self._chk(self.L.disco_get_counters(self._h, C.byref(c)))

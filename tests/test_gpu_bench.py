@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "300000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "300000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000", "--no-stage"] + extra
     env = dict(os.environ, MASTER_PORT="29641")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -36,6 +36,29 @@ def test_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0
     assert d["config"]["cap_bind_sites"] == 0 and d["config"]["asymmetric_pairs"] == 0
+    h = d["graph_host_to_host"]  # host buffers in, host structs out
+    assert h["e_out"] == d["config"]["e_out"] and h["total_ms"] > 0 and h["upload_bytes"] > 0
+    assert "traffic_source" in r
+
+
+def test_bench_stage_wall_through_the_drop_in_executable():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "200000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-to-host"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.strip().split("\n") if l.strip()][-1])
+    s = d["stage_drop_in"]
+    assert s.get("same_overlap_count_as_the_bench_pass") is True and s["wall_s"] > 0 and s["output_bytes"] > 0, s
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`--gpus 2` on a 1-GPU box must fail loudly instead of printing a line measured on one GPU"""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has 2 GPUs")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "300000", "--steps", "1", "--warmup", "0"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 2" in p.stderr and not p.stdout.strip()
 
 
 def test_bench_sharded_code_path_with_one_rank():
