@@ -164,6 +164,10 @@ struct disco_ctx {
 
     /* multi-GPU flow (disco_comm_* / disco_dist_*): one context per rank */
     DiscoComm *comm = nullptr;
+    DiscoComm *comm_bulk = nullptr;   /* a second communicator for the all-gather of the reads: it runs on bulk_stream while the */
+    hipStream_t bulk_stream = nullptr; /* index is built and the own reads are probed (only verify needs the other ranks' rows)  */
+    hipEvent_t ev_bulk = nullptr;
+    bool wait_bulk_before_verify = false;
     u64 per = 0;        /* nodes per rank: ceil(n / world) rounded up to a multiple of 64 */
     u64 n_alloc = 0;    /* rows of the per-read tables (n on one GPU, world * per in the multi-GPU flow) */
     bool dist_reads = false;   /* the read table was set through disco_dist_*: rows [q_lo, q_hi) are this rank's */
@@ -507,8 +511,11 @@ void disco_destroy(disco_ctx *c)
     dev_free(c, &c->d_probe_rare, 1);
     dev_free(c, &c->d_route, 2 * DIST_MAX_WORLD);
     dev_free(c, &c->d_list_n, 1);
+    delete c->comm_bulk;
     delete c->comm;
-    c->comm = nullptr;
+    c->comm = c->comm_bulk = nullptr;
+    if (c->bulk_stream) (void)hipStreamDestroy(c->bulk_stream);
+    if (c->ev_bulk) (void)hipEventDestroy(c->ev_bulk);
     for (int i = 0; i < DISCO_PH_COUNT; i++) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -834,6 +841,10 @@ int disco_probe(disco_ctx *c)
             va.row_cnt = c->d_row_cnt;
             va.order = c->d_order_used;
             va.meta_ord = c->d_meta_ord;
+            if (c->wait_bulk_before_verify) { /* multi-GPU flow: the candidate rows of other ranks' reads arrive on bulk_stream */
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bulk, 0));
+                c->wait_bulk_before_verify = false;
+            }
             ph_begin(c, DISCO_PH_VERIFY);
             if (nq) {
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
@@ -2292,10 +2303,15 @@ int disco_comm_unique_id(void *out, size_t cap)
     return DISCO_OK;
 }
 
-static int comm_attach(disco_ctx *c, DiscoComm *cm)
+static int comm_attach(disco_ctx *c, DiscoComm *cm, DiscoComm *bulk)
 {
     delete c->comm;
+    delete c->comm_bulk;
     c->comm = cm;
+    c->comm_bulk = bulk;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, DISCO_E_HIP, "hipSetDevice failed");
+    if (!c->bulk_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->bulk_stream, hipStreamNonBlocking));
+    if (!c->ev_bulk) HIPCHK(c, hipEventCreateWithFlags(&c->ev_bulk, hipEventDisableTiming));
     return DISCO_OK;
 }
 
@@ -2304,14 +2320,35 @@ int disco_comm_init(disco_ctx *c, const void *unique_id, int nranks, int rank)
     if (!c || !unique_id || nranks < 1 || nranks > DIST_MAX_WORLD || rank < 0 || rank >= nranks) return c ? fail(c, DISCO_E_ARG, "disco_comm_init: bad argument") : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     RcclComm *cm = new (std::nothrow) RcclComm();
-    if (!cm) return fail(c, DISCO_E_NOMEM, "disco_comm_init: out of host memory");
-    const int rc = cm->init(unique_id, nranks, rank);
-    if (rc != DISCO_OK) {
-        fail(c, rc, "disco_comm_init: %s", cm->err.c_str());
+    RcclComm *bulk = new (std::nothrow) RcclComm();
+    if (!cm || !bulk) {
         delete cm;
+        delete bulk;
+        return fail(c, DISCO_E_NOMEM, "disco_comm_init: out of host memory");
+    }
+    int rc = cm->init(unique_id, nranks, rank);
+    if (rc == DISCO_OK) { /* the id of the second communicator travels over the first one */
+        ncclUniqueId id2;
+        memset(&id2, 0, sizeof id2);
+        void *d_id = nullptr;
+        if (rank == 0 && ncclGetUniqueId(&id2) != ncclSuccess) rc = DISCO_E_HIP;
+        if (rc == DISCO_OK && hipMalloc(&d_id, sizeof id2) != hipSuccess) rc = DISCO_E_NOMEM;
+        if (rc == DISCO_OK && (hipMemcpyAsync(d_id, &id2, sizeof id2, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                               ncclBroadcast(d_id, d_id, sizeof id2, ncclInt8, 0, cm->comm, c->stream) != ncclSuccess ||
+                               hipMemcpyAsync(&id2, d_id, sizeof id2, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                               hipStreamSynchronize(c->stream) != hipSuccess))
+            rc = DISCO_E_HIP;
+        if (d_id) (void)hipFree(d_id);
+        if (rc == DISCO_OK) rc = bulk->init(&id2, nranks, rank);
+        else cm->err = "exchange of the second communicator's id failed";
+    }
+    if (rc != DISCO_OK) {
+        fail(c, rc, "disco_comm_init: %s %s", cm->err.c_str(), bulk->err.c_str());
+        delete cm;
+        delete bulk;
         return rc;
     }
-    return comm_attach(c, cm);
+    return comm_attach(c, cm, bulk);
 }
 
 int disco_comm_init_local(disco_ctx *const *ctxs, int nranks)
@@ -2319,8 +2356,11 @@ int disco_comm_init_local(disco_ctx *const *ctxs, int nranks)
     if (!ctxs || nranks < 1 || nranks > DIST_MAX_WORLD) return DISCO_E_ARG;
     for (int r = 0; r < nranks; r++)
         if (!ctxs[r]) return DISCO_E_ARG;
-    auto grp = std::make_shared<LoopGroup>(nranks);
-    for (int r = 0; r < nranks; r++) comm_attach(ctxs[r], new LoopComm(grp, r));
+    auto grp = std::make_shared<LoopGroup>(nranks), grp2 = std::make_shared<LoopGroup>(nranks);
+    for (int r = 0; r < nranks; r++) {
+        const int rc = comm_attach(ctxs[r], new LoopComm(grp, r), new LoopComm(grp2, r));
+        if (rc != DISCO_OK) return rc;
+    }
     return DISCO_OK;
 }
 
@@ -2422,15 +2462,24 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
     c->dist_active = true;
     c->n_push_r = 0;
     c->h_len.clear();
-    /* 0. everybody gets every read */
-    if ((flags & DISCO_DIST_GATHER_READS) && G > 1) {
+    /* 0. everybody gets every read — on the second communicator and stream: the index build and the probe of the own reads
+     *    need nothing of it, verify waits for it (disco_probe) */
+    if (flags & DISCO_DIST_GATHER_READS) {
         const auto t0 = HClock::now();
         const u64 row_bytes = (u64)c->S * 8;
-        COMM_CHK(c, c->comm->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, c->stream));
-        COMM_CHK(c, c->comm->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* the own rows are in place */
+#define BULK_CHK(expr)                                                                                        \
+    do {                                                                                                      \
+        int rc_ = (expr);                                                                                     \
+        if (rc_ != DISCO_OK) return fail(c, rc_, "%s: %s", #expr, c->comm_bulk->err.c_str());                 \
+    } while (0)
+        BULK_CHK(c->comm_bulk->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, c->bulk_stream));
+        BULK_CHK(c->comm_bulk->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, c->bulk_stream));
+#undef BULK_CHK
+        HIPCHK(c, hipEventRecord(c->ev_bulk, c->bulk_stream));
+        c->wait_bulk_before_verify = true;
         di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (row_bytes + 2);
-        di.ms[DISCO_X_READS] += ms_since(t0);
+        di.ms[DISCO_X_READS] += ms_since(t0); /* time to ISSUE it (RCCL: asynchronous; in-process transport: the copies themselves) */
     }
     CHK(dist_build_index(c));
     CHK(disco_probe(c));

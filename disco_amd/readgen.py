@@ -132,3 +132,24 @@ def pack_reads(codes, off, stride_words: int | None = None):
     vals = codes.astype(np.uint64) << sh
     np.bitwise_or.at(packed, (rid, i >> 5), vals)
     return packed, length.astype(np.uint16)
+
+
+def generate_pairs(seed: int, n_pairs: int, genome_len: int, len_min: int, len_max: int, ins_min: int = 600, ins_max: int = 900):
+    """interleaved paired-end reads of one uniform-random genome (BASELINE config 1's stand-in for test/Ecoli_250_500_test.fna,
+    which the reference does not ship): read 2i from the forward strand at the fragment's start, read 2i+1 the
+    reverse complement of the fragment's end. numpy's PCG64 with the given seed: bit-reproducible."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+    for _ in range(n_pairs):
+        ins = int(rng.integers(ins_min, ins_max + 1))
+        p = int(rng.integers(0, genome_len - ins))
+        l1, l2 = int(rng.integers(len_min, len_max + 1)), int(rng.integers(len_min, len_max + 1))
+        l1, l2 = min(l1, ins), min(l2, ins)
+        r1 = genome[p:p + l1]
+        r2 = comp[genome[p + ins - l2:p + ins]][::-1]
+        reads.append(letters[r1].tobytes().decode())
+        reads.append(letters[r2].tobytes().decode())
+    return reads
