@@ -59,10 +59,11 @@ class GenSpec:
         return GenSpec(seed, n_reads, max(total // n_contigs, len_max + 1), n_contigs, read_len, len_max, skew)
 
 
-def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None):
+def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None, ids=None):
+    """(genome position, length, strand) of the reads r0..r1, or of the given read ids"""
     r1 = spec.n_reads if r1 is None else r1
     with np.errstate(over="ignore"):
-        r = np.arange(r0, r1, dtype=np.uint64)
+        r = np.arange(r0, r1, dtype=np.uint64) if ids is None else np.asarray(ids, dtype=np.uint64)
         sr = np.uint64(spec.seed) ^ np.uint64(0xA5A5A5A55A5A5A5A)
         h0 = mix64(sr + np.uint64(4) * r)
         h1 = mix64(sr + np.uint64(4) * r + np.uint64(1))
@@ -78,9 +79,9 @@ def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None):
     return gpos, length.astype(np.uint32), strand
 
 
-def generate_codes(spec: GenSpec, r0: int = 0, r1: int | None = None):
-    """returns (codes uint8 [sum len], off uint64 [n+1]) — base codes of reads r0..r1."""
-    gpos, length, strand = read_locations(spec, r0, r1)
+def generate_codes(spec: GenSpec, r0: int = 0, r1: int | None = None, ids=None):
+    """returns (codes uint8 [sum len], off uint64 [n+1]) — base codes of reads r0..r1, or of the given read ids."""
+    gpos, length, strand = read_locations(spec, r0, r1, ids)
     n = len(gpos)
     off = np.zeros(n + 1, dtype=np.uint64)
     np.cumsum(length, out=off[1:])
