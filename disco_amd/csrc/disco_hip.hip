@@ -759,6 +759,7 @@ int disco_probe(disco_ctx *c)
         if (want_big > c->big_cap) {
             dev_free(c, &c->d_big_list, c->big_cap);
             dev_free(c, &c->d_big_cnt, c->big_cap);
+            c->big_cap = 0;
             CHK(dev_alloc(c, &c->d_big_list, want_big));
             CHK(dev_alloc(c, &c->d_big_cnt, want_big));
             c->big_cap = want_big;
@@ -1080,34 +1081,41 @@ static int merge_extras(disco_ctx *c)
     if (c->n_extra == 0) return DISCO_OK;
     u32 *new_deg = nullptr, *fill = nullptr;
     u64 *new_start = nullptr, *new_adj = nullptr, *scratch = nullptr;
-    CHK(dev_alloc(c, &new_deg, c->n));
-    CHK(dev_alloc(c, &fill, c->n));
-    CHK(dev_alloc(c, &new_start, c->n + 1));
-    hipLaunchKernelGGL(merge_deg_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, new_deg);
-    u64 total = 0;
-    CHK((scan_exclusive<u32, u64>(c, new_deg, c->n, new_start, true, &total)));
-    CHK(dev_alloc(c, &new_adj, total));
-    HIPCHK(c, hipMemsetAsync(fill, 0, c->n * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(merge_copy_kernel, dim3(wave_grid(c, c->n, 16)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, new_start, new_adj, c->n);
-    hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_ref, new_start, fill, new_adj);
-    /* row scratch: the longest merged row */
-    u64 maxdeg = 0;
-    {
-        std::vector<u32> h(c->n);
-        HIPCHK(c, hipMemcpyAsync(h.data(), new_deg, c->n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    u64 total = 0, scratch_n = 0;
+    auto body = [&]() -> int {
+        CHK(dev_alloc(c, &new_deg, c->n));
+        CHK(dev_alloc(c, &fill, c->n));
+        CHK(dev_alloc(c, &new_start, c->n + 1));
+        hipLaunchKernelGGL(merge_deg_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, new_deg);
+        CHK((scan_exclusive<u32, u64>(c, new_deg, c->n, new_start, true, &total)));
+        CHK(dev_alloc(c, &new_adj, total));
+        HIPCHK(c, hipMemsetAsync(fill, 0, c->n * sizeof(u32), c->stream));
+        hipLaunchKernelGGL(merge_copy_kernel, dim3(wave_grid(c, c->n, 16)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, new_start, new_adj, c->n);
+        hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_ref, new_start, fill, new_adj);
+        /* row scratch: the longest merged row (reduced on the device) */
+        CHK(zero_counter(c, CTR_MAX_DEG));
+        hipLaunchKernelGGL(max_u32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, new_deg, c->n, c->d_ctr + CTR_MAX_DEG);
+        HIPCHK(c, hipGetLastError());
+        CHK(read_counters(c));
+        const u64 maxdeg = c->h_ctr[CTR_MAX_DEG];
+        const int g = (int)std::min<u64>(c->n, 256);
+        scratch_n = (u64)g * (maxdeg + 1);
+        CHK(dev_alloc(c, &scratch, scratch_n));
+        hipLaunchKernelGGL(merge_sort_kernel, dim3(g), dim3(64), 0, c->stream, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);
+        hipLaunchKernelGGL(ref_from_start_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, new_start, new_deg, c->n, c->d_adj_ref);
+        HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (u32 d : h) maxdeg = std::max<u64>(maxdeg, d);
-    }
-    int g = (int)std::min<u64>(c->n, 256);
-    CHK(dev_alloc(c, &scratch, (u64)g * (maxdeg + 1)));
-    hipLaunchKernelGGL(merge_sort_kernel, dim3(g), dim3(64), 0, c->stream, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);
-    hipLaunchKernelGGL(ref_from_start_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, new_start, new_deg, c->n, c->d_adj_ref);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    dev_free(c, &scratch, (u64)g * (maxdeg + 1));
+        return DISCO_OK;
+    };
+    const int rc = body();
+    dev_free(c, &scratch, scratch_n);
     dev_free(c, &new_deg, c->n);
     dev_free(c, &fill, c->n);
     dev_free(c, &new_start, c->n + 1);
+    if (rc != DISCO_OK) {
+        dev_free(c, &new_adj, total);
+        return rc;
+    }
     dev_free(c, &c->d_adj_own, c->adj_cap);
     c->d_adj_own = new_adj;
     c->d_adj = new_adj;
@@ -1274,16 +1282,12 @@ int disco_transitive_mark(disco_ctx *c)
     ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking: big-node list overflow (%u nodes)", n_big);
     if (n_big) {
-        /* longest list among the big nodes bounds the hash size */
-        std::vector<u64> big(n_big);
-        HIPCHK(c, hipMemcpyAsync(big.data(), c->d_big_list, n_big * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        u64 maxd = 0;
-        for (u64 v : big) {
-            u64 r = 0;
-            HIPCHK(c, hipMemcpy(&r, c->d_adj_ref + v, 8, hipMemcpyDeviceToHost));
-            maxd = std::max<u64>(maxd, REF_DEG(r));
-        }
+        /* longest list among the big nodes bounds the hash size: one reduction on the device, one read-back */
+        CHK(zero_counter(c, CTR_MAX_DEG));
+        hipLaunchKernelGGL(list_max_degree_kernel, dim3(flat_grid(c, n_big)), dim3(256), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_ctr + CTR_MAX_DEG);
+        HIPCHK(c, hipGetLastError());
+        CHK(read_counters(c));
+        const u64 maxd = c->h_ctr[CTR_MAX_DEG];
         u64 hcap = 64;
         while (hcap < 2 * maxd) hcap <<= 1;
         int g2 = (int)std::min<u64>(n_big, (u64)c->n_cu * 8);
@@ -1295,9 +1299,11 @@ int disco_transitive_mark(disco_ctx *c)
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         hipLaunchKernelGGL((transitive_mark_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
-        hipError_t e2 = hipStreamSynchronize(c->stream);
+        const int rc2 = read_counters(c); /* synchronises; the big pass may have raised CTR_OVERFLOW */
         dev_free(c, &scratch, (u64)g2 * per);
-        if (e != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel (big nodes): %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        if (e != hipSuccess) return fail(c, DISCO_E_HIP, "transitive_mark_kernel (big nodes): %s", hipGetErrorString(e));
+        CHK(rc2);
+        if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking (big nodes): list overflow");
     }
     c->n_wide = 0;
     if (c->use_half) {
@@ -1459,18 +1465,23 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     if (nc == 0) return 0;
     CHK(ensure_host_len(c));
     u64 *pos = nullptr, *ids = nullptr, *keys = nullptr;
-    CHK(dev_alloc(c, &pos, c->n + 1));
-    CHK(dev_alloc(c, &ids, nc));
-    CHK(dev_alloc(c, &keys, nc));
-    CHK((scan_exclusive<u8, u64>(c, c->d_contained, c->n, pos, false, nullptr)));
-    hipLaunchKernelGGL(contain_rows_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->d_contained, pos, c->n, ids, keys);
     std::vector<u64> hid(nc), hkey(nc);
-    HIPCHK(c, hipMemcpyAsync(hid.data(), ids, nc * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hkey.data(), keys, nc * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto gather = [&]() -> int {
+        CHK(dev_alloc(c, &pos, c->n + 1));
+        CHK(dev_alloc(c, &ids, nc));
+        CHK(dev_alloc(c, &keys, nc));
+        CHK((scan_exclusive<u8, u64>(c, c->d_contained, c->n, pos, false, nullptr)));
+        hipLaunchKernelGGL(contain_rows_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->d_contained, pos, c->n, ids, keys);
+        HIPCHK(c, hipMemcpyAsync(hid.data(), ids, nc * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hkey.data(), keys, nc * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return DISCO_OK;
+    };
+    const int grc = gather();
     dev_free(c, &pos, c->n + 1);
     dev_free(c, &ids, nc);
     dev_free(c, &keys, nc);
+    CHK(grc);
     const u16 *hlen = c->h_len.data();
     const u32 kk = (u32)c->k;
     parallel_for(nc, [&, hlen, kk](u64 b, u64 e_) {

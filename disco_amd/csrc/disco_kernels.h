@@ -2386,6 +2386,15 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const ulonglong2 *__re
     if (acc == 0x1234567ull) sink[0] = acc; /* keeps the loads alive */
 }
 
+__global__ void max_u32_kernel(const u32 *__restrict__ p, u64 n, u64 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 m = 0;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) m = max(m, p[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, (u64)m);
+}
+
 __global__ void iota_u64_kernel(u64 *p, u64 n)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
