@@ -12,8 +12,8 @@ from tests.util import canon_hip, run_hip_reads
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["u150_5k", "mixed_4k", "k30_6k", "long_2k"])
-@pytest.mark.parametrize("G", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,G", [(n, g) for n in ("u150_5k", "mixed_4k", "k30_6k", "long_2k") for g in (1, 2, 3, 4)] +
+                         [("u150_5k", 8), ("mixed_4k", 8), ("contigs_20k", 8), ("k64_3k", 5)])
 def test_ranks_equal_reference(name, G):
     """regular regime: neighbour rows fetched on request"""
     reads, fidx, mo = gu.case_inputs(name)
