@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libdisco_hip.so")
+_LIBPATH = os.environ.get("DISCO_LIB") or os.path.join(_HERE, "libdisco_hip.so")  # DISCO_LIB: an experimental build (tools/ab_build.py)
 _lib = None
 
 

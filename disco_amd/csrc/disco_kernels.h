@@ -1673,6 +1673,11 @@ __device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
     return a.adj[pos];
 }
 
+#ifndef TR_HASH_LOAD
+#define TR_HASH_LOAD 4 /* slots per neighbour in the marking hash of the register path: fewer probe-loop trips (each trip of a
+                          divergent loop is a dozen scalar exec-mask instructions, and this kernel is bound by its SCALAR unit) */
+#endif
+static_assert(TR_HASH_LOAD * 64 < 2 * TR_CAP, "the register path's table (at most TR_HASH_LOAD x 64 slots) must leave the last slot of s_state free: it takes the stores of the lanes without a hit");
 #define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
 /* slot of a node id (< 2^31) in the marking hash: one 32-bit multiply (disco_hash64 costs two 64-bit multiplies — eight
  * quarter-rate 32-bit ones — and is evaluated for every entry of every swept row) */
@@ -1787,7 +1792,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     const u32 d = nd.d;
     const u64 e = nd.e;
     u32 hc = 64;
-    while (hc < 2 * d) hc <<= 1;
+    while (hc < TR_HASH_LOAD * d) hc <<= 1; /* d <= 64: at most 4 * 64 of the 2 * TR_CAP slots */
     const u32 hmask = hc - 1;
     for (u32 i = lane; i <= hmask; i += 64) {
         hkey[i] = TR_EMPTY;
@@ -1827,26 +1832,29 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         const u64 e1 = readlane_u64(e, i);
         const u32 type1 = ADJ_ORI(e1);
         const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
-        auto mark = [&](u64 e2) {
+        /* every lane calls: the probe loop is wave-uniform (one trip for nearly every entry at four slots per neighbour), the
+         * ELIMINATED store goes to a spare slot for the lanes without a hit — a divergent loop with early exits costs a dozen
+         * scalar exec-mask instructions per trip, and the scalar unit is what this kernel runs out of */
+        auto mark = [&](bool act, u64 e2) {
             const u32 type2 = ADJ_ORI(e2);
-            const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
-            if (!ok) return;
-            const u64 w = ADJ_DST(e2);
+            bool pend = act && ((type2 >> 1) == (in1 ? 0u : 1u)); /* :705-708: in1 -> types 0/1, else types 2/3 */
+            const u32 w = (u32)ADJ_DST(e2); /* ids are below 2^31: the low word of a slot identifies the node, 0xFFFFFFFF = empty */
             u32 idx = tr_hash(w, hmask);
-            for (;;) {
-                const u64 kk = hkey[idx];
-                if (kk == TR_EMPTY) break;
-                if (kk == w) {
-                    hstate[idx] = 1; /* ELIMINATED */
-                    break;
-                }
+            do {
+                const u32 kk = ((const u32 *)hkey)[2 * idx];
+                const bool hit = pend && kk == w;
+                hstate[hit ? idx : (2u * TR_CAP - 1u)] = 1; /* ELIMINATED; the last slot is never a table slot (hc <= 256) */
+                pend = pend && !hit && kk != 0xFFFFFFFFu;
                 idx = (idx + 1) & hmask;
-            }
+            } while (__any(pend));
         };
         auto sweep = [&](u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
-            if (lane < du) mark(pre);
+            mark(lane < du, pre);
             if (du > 64)
-                for (u32 t = 64 + lane; t < du; t += 64) mark(tr_nent<N32>(a, us + t));
+                for (u32 t0 = 64; t0 < du; t0 += 64) {
+                    const bool act = t0 + lane < du;
+                    mark(act, act ? tr_nent<N32>(a, us + t0 + lane) : 0ull);
+                }
         };
         /* three copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
          * lands on the common path and drains the kernel's prefetch pipeline */
