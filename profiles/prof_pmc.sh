@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pmc}; mkdir -p $O
 N=${2:-20000000}
-B="python3 $R/bench.py --reads $N --steps 1 --warmup 0 --no-cpu-baseline"
+B="python3 $R/bench.py --reads $N --steps 1 --warmup 0 --no-cpu-baseline --no-stage --no-host-to-host"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/sq -o p -- $B > /dev/null 2>&1

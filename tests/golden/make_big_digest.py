@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--len-max", type=int, default=0, help="longest read (uniform lengths in [len, len-max]); 0 = fixed length")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--min-overlap", type=int, default=40)
+    ap.add_argument("--skew", type=int, default=0, help="1: metagenome-like contig abundances (readgen's skew)")
     a = ap.parse_args()
     # edge line: src dst orient,ovl,0,0,len1,start1,stop1,len2,0,stop2,NA[,flag] -> columns 0 1 2 | 7 (start1) 6 (len1) 9 (len2)
     e = np.concatenate([read_cols(f"{a.prefix}_{t}_parGraph.txt", [0, 1, 2, 7, 6, 9]) for t in range(a.threads)])
@@ -61,7 +62,7 @@ def main():
     assert len(np.unique(cc[:, 0])) == len(cc), "a contained read is listed twice"
     out = os.path.join(HERE, "cases_big.json")
     cases = json.load(open(out)) if os.path.exists(out) else {}
-    cases[a.name] = dict(kind="generated", seed=a.seed, reads=a.reads, read_len=a.len, len_max=a.len_max or a.len, coverage=a.coverage, n_contigs=a.contigs,
+    cases[a.name] = dict(kind="generated", seed=a.seed, reads=a.reads, read_len=a.len, len_max=a.len_max or a.len, coverage=a.coverage, n_contigs=a.contigs, skew=a.skew,
                          min_overlap=a.min_overlap, n_edges=int(len(ce)), n_contained=int(len(cc)),
                          edges_sha256=pyoracle.digest_array(ce), contained_sha256=pyoracle.digest_array(cc),
                          reference="oracle/_ref/buildG_ref -se <generated fasta> -t %d" % a.threads)

@@ -20,7 +20,7 @@ CASES = json.load(open(os.path.join(HERE, "golden", "cases_big.json")))
 def test_hip_digest_matches_reference_files(name):
     c = CASES[name]
     spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"],
-                                    len_max=c.get("len_max", c["read_len"]))
+                                    len_max=c.get("len_max", c["read_len"]), skew=c.get("skew", 0))
     with buildgraph.BuildGraph(min_overlap=c["min_overlap"]) as g:
         g.generate_reads(spec)
         g.run_graph()
