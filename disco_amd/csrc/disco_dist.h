@@ -92,12 +92,13 @@ __global__ void add_u32_kernel(u32 *__restrict__ p, u64 n, u32 val)
 }
 
 /* ---- neighbour rows on request (transitive reduction) -------------------------------------------------------------- */
-/* both reference words of the rank's own nodes point at the node's exported row (all entries: the sweep filters by type) */
-__global__ void nref_local_kernel(const u64 *__restrict__ start, const u32 *__restrict__ deg, u64 lo, u64 nloc, u64 *__restrict__ nref)
+/* both reference words of the rank's own nodes address the node's row where edge selection left it (TR_LOCAL: 8-byte entries in
+ * adj; the sweep filters by type itself) */
+__global__ void nref_local_kernel(const u64 *__restrict__ ref, u64 lo, u64 nloc, u64 *__restrict__ nref)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < nloc; i += (u64)gridDim.x * blockDim.x) {
-        const u64 r = REF_MAKE(start[i], deg[i]);
+        const u64 r = ref[lo + i] | TR_LOCAL;
         nref[2 * (lo + i)] = r;
         nref[2 * (lo + i) + 1] = r;
     }

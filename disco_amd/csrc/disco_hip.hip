@@ -2093,22 +2093,14 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
 static int dist_transitive_mark(disco_ctx *c)
 {
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
-    /* own rows as 4-byte entries at the head of the neighbour-row store */
-    CHK(ensure_cap(c, &c->d_deg_tmp, &c->deg_tmp_cap, std::max<u64>(nloc, 1)));
-    CHK(ensure_cap(c, &c->d_start_tmp, &c->start_cap, c->n + 1));
+    /* reference words: everything "not fetched", the own nodes' rows in place */
     CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, 2 * c->n + 2));
     ph_begin(c, DISCO_PH_CSR);
     HIPCHK(c, hipMemsetAsync(c->d_nref, 0xFF, (2 * c->n + 2) * sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(deg_from_ref_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, lo, hi, c->d_deg_tmp);
-    u64 total = 0;
-    CHK((scan_exclusive<u32, u64>(c, c->d_deg_tmp, nloc, c->d_start_tmp, true, &total)));
-    if (total != c->adj_total) return fail(c, DISCO_E_STATE, "own rows: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
-    c->nadj_used = 0;
-    CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, total + 1, 0));
-    if (nloc && total) hipLaunchKernelGGL(rows_gather32_kernel, dim3(wave_grid(c, nloc, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, lo, hi, c->d_start_tmp, c->d_nadj32_own);
-    if (nloc) hipLaunchKernelGGL(nref_local_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_start_tmp, c->d_deg_tmp, lo, nloc, c->d_nref);
+    if (nloc) hipLaunchKernelGGL(nref_local_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, lo, nloc, c->d_nref);
     HIPCHK(c, hipGetLastError());
-    c->nadj_used = total;
+    c->nadj_used = 0; /* the neighbour-row store holds fetched rows only */
+    CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, 1u << 16, 0)); /* idle lanes of the row prefetch read its first 64 K entries */
     ph_end(c, DISCO_PH_CSR);
     /* round 1: slot 0 and the first slot on the other side of every register-resident node */
     if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));

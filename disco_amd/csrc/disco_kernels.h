@@ -543,6 +543,10 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                     }
                 }
                 __syncthreads(); /* s_first, s_strand */
+#if defined(PROBE_STOP) && PROBE_STOP <= 1 /* timing attribution builds (tools/ab_build.py): hashing + window minima only */
+                if (m1[0] + m1[1] + m2[0] + m2[1] == 12345u) nrow++;
+                continue;
+#endif
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const int w = (int)lane + 64 * r;
@@ -582,6 +586,10 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                 }
             }
             __syncthreads();
+#if defined(PROBE_STOP) && PROBE_STOP <= 2 /* ... + choose */
+            if (s_wp[lane] == 0xABCDu) nrow++;
+            continue;
+#endif
             /* 3. the first window of every occurrence leads one bucket lookup */
             u32 nlead = 0;
             for (int ws = 0; ws < nw; ws += 64) {
@@ -592,6 +600,10 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                 nlead += __popcll(lm);
             }
             __syncthreads();
+#if defined(PROBE_STOP) && PROBE_STOP <= 3 /* ... + lead detection */
+            if (s_lead[lane] == 0xABCDu) nrow++;
+            continue;
+#endif
             for (u32 lb = 0; lb < nlead; lb += 64) {
                 const u32 li = lb + lane;
                 u32 s = 0, cnt = 0;
@@ -625,6 +637,10 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                 }
                 __syncthreads();
                 const u64 startmask = __ballot(s_mark[lane] != 0);
+#if defined(PROBE_STOP) && PROBE_STOP <= 4 /* ... + bucket lookups, no record walk */
+                if (startmask == 0x123456789ull) nrow++;
+                continue;
+#endif
                 /* 4. all records of all led buckets, lane = record: a record names the window(s) it can match through its
                  *    minimizer offset t; the window's own (occurrence, strand) must agree */
                 for (u32 base = 0; base < total; base += 64) {
@@ -1663,10 +1679,15 @@ struct TrArgs {
 #define TR_NODEG 0xFFFFFFu
 template <bool N32>
 __device__ __forceinline__ u64 tr_nref(const TrArgs &a, u64 u, u32 cls) { return N32 ? a.nref[2 * u + cls] : a.ref[u]; }
+/* N32: a reference word with TR_LOCAL set addresses the rank's OWN row in adj (8-byte entries, read in place: exporting the own
+ * rows into the 4-byte store cost more than the marking of a whole rank at 8 GPUs); without it, a fetched row in nadj32 */
+#define TR_LOCAL (1ull << 39)
+#define TR_LOCAL_POS(pos) ((pos) & (TR_LOCAL - 1ull))
 template <bool N32>
 __device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
 {
     if (N32) {
+        if (pos & TR_LOCAL) return a.adj[TR_LOCAL_POS(pos)];
         const u32 x = a.nadj32[pos];
         return NBR32_ENTRY(x);
     }
@@ -1802,8 +1823,8 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     const u32 s2 = nd.s2;
     const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
     const u32 d0 = REF_DEG(nd.r0), d2 = REF_DEG(nd.r2);
-    const u64 p0 = (lane < d0 && d0 != TR_NODEG) ? (N32 ? NBR32_ENTRY((u32)nd.p0) : nd.p0) : 0ull;
-    const u64 p2 = (lane < d2 && d2 != TR_NODEG) ? (N32 ? NBR32_ENTRY((u32)nd.p2) : nd.p2) : 0ull;
+    const u64 p0 = (lane < d0 && d0 != TR_NODEG) ? ((N32 && !(st0 & TR_LOCAL)) ? NBR32_ENTRY((u32)nd.p0) : nd.p0) : 0ull;
+    const u64 p2 = (lane < d2 && d2 != TR_NODEG) ? ((N32 && !(st2 & TR_LOCAL)) ? NBR32_ENTRY((u32)nd.p2) : nd.p2) : 0ull;
     bool deferred = false;
     __syncthreads();
     u32 sent = 0;
@@ -1970,8 +1991,13 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         /* raw words only: N32 entries are expanded where they are consumed (nothing is computed from a loaded value in the
          * iteration that issues the load) */
         if (N32) {
-            r.p0 = a.nadj32[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : 0];
-            r.p2 = a.nadj32[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : 0];
+            /* wave-uniform choice (r0 / r2 are scalars): exactly one load per row on either side of the branch, so the number of
+             * loads in flight stays known */
+            const u64 q0 = REF_POS(r.r0), q2 = REF_POS(r.r2);
+            if (d0 && (q0 & TR_LOCAL)) r.p0 = a.adj[TR_LOCAL_POS(q0) + (lane < d0 ? lane : 0u)];
+            else r.p0 = a.nadj32[d0 ? q0 + (lane < d0 ? lane : 0u) : (r.vs & 0xFFFFull)];
+            if (d2 && (q2 & TR_LOCAL)) r.p2 = a.adj[TR_LOCAL_POS(q2) + (lane < d2 ? lane : 0u)];
+            else r.p2 = a.nadj32[d2 ? q2 + (lane < d2 ? lane : 0u) : (r.vs & 0xFFFFull)];
         } else {
             r.p0 = a.adj[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : r.vs];
             r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
