@@ -96,6 +96,7 @@ ABI = [
     ("disco_dist_get_info", C.c_int, [_P, _P]),
 ]
 
+FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
 XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency")
 UNIQUE_ID_BYTES = 128
 DIST_GATHER_READS = 1
@@ -135,11 +136,11 @@ def load():
 class BuildGraph:
     """One context = one GPU. Phases in the order the reference's main() runs them."""
 
-    def __init__(self, min_overlap: int = 40, device: int = 0, max_edges_per_kmer: int = 4):
+    def __init__(self, min_overlap: int = 40, device: int = 0, max_edges_per_kmer: int = 4, flags: int = 0):
         self.L = load()
         self.min_overlap = min_overlap
         self._h = _P()
-        p = Params(min_overlap, max_edges_per_kmer, 0, 0)
+        p = Params(min_overlap, max_edges_per_kmer, flags, 0)
         rc = self.L.disco_create(device, C.byref(p), C.byref(self._h))
         if rc != 0:
             raise DiscoError(f"disco_create failed ({rc}): {self.L.disco_last_error(None).decode()}")

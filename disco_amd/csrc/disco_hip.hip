@@ -114,7 +114,8 @@ struct disco_ctx {
     u64 dropped_local = 0;
     ProbeRare h_probe_rare;
     ProbeRare *d_probe_rare = nullptr;
-    u32 max_len = 0; /* longest read (validate_reads) */
+    u32 max_len = 0, min_len = 0; /* longest / shortest read (validate_reads) */
+    bool two_pass_last = false;    /* the last probe verified in two passes */
 
     /* containment */
     u8 *d_contained = nullptr;
@@ -594,8 +595,10 @@ static int validate_reads(disco_ctx *c)
 {
     CHK(zero_counter(c, CTR_BAD_LEN));
     CHK(zero_counter(c, CTR_MAX_LEN));
+    CHK(zero_counter(c, CTR_MIN_LEN));
     if (c->n) hipLaunchKernelGGL(validate_len_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_len, c->n, c->S, (int)c->prm.min_overlap, c->d_ctr);
     CHK(read_counters(c));
+    c->min_len = 0xFFFFu - (u32)c->h_ctr[CTR_MIN_LEN];
     if (c->h_ctr[CTR_BAD_LEN])
         return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)c->h_ctr[CTR_BAD_LEN], c->prm.min_overlap);
     c->max_len = (u32)c->h_ctr[CTR_MAX_LEN];
@@ -846,8 +849,26 @@ int disco_probe(disco_ctx *c)
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bulk, 0));
                 c->wait_bulk_before_verify = false;
             }
+            /* two passes (containment-type candidates, flags, overlap-type candidates of non-contained reads) where most reads
+             * can be contained: only on request (the kmer_hits counter then counts the compared candidates only), reads of mixed
+             * length, rows of the 64-byte staged variants, and not inside a multi-GPU pass (its flags need an exchange in between) */
+            const bool two_pass = (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && !c->dist_active && c->S == VERIFY_SW && nq &&
+                                  (u64)c->min_len * 10 < (u64)c->max_len * 9 && !getenv("DISCO_NO_TWO_PASS");
+            c->two_pass_last = two_pass;
             ph_begin(c, DISCO_PH_VERIFY);
-            if (nq) {
+            if (two_pass) {
+                if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
+                if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
+                va.cbits = c->d_cbits;
+                const bool short_rows = c->max_len <= 160;
+                if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 1>), dim3(wq_grid(c, verify_kernel<5, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else hipLaunchKernelGGL((verify_kernel<8, 1>), dim3(wq_grid(c, verify_kernel<8, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                CHK(zero_counter(c, CTR_N_CONTAINED));
+                hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
+                if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 2>), dim3(wq_grid(c, verify_kernel<5, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else hipLaunchKernelGGL((verify_kernel<8, 2>), dim3(wq_grid(c, verify_kernel<8, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+            } else if (nq) {
+                va.cbits = nullptr;
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<8>, dim3(wq_grid(c, verify_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == 16) hipLaunchKernelGGL(verify_kernel<16>, dim3(wq_grid(c, verify_kernel<16>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);

@@ -56,6 +56,7 @@ enum {
     CTR_ADJ_TOTAL, /* directed edges selected (sum of degrees of the query range) */
     CTR_MAX_LEN, /* longest read */
     CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
+    CTR_MIN_LEN, /* ~shortest read (stored complemented so that atomicMax finds the minimum from a zeroed counter) */
     CTR_COUNT
 };
 
@@ -123,15 +124,22 @@ __global__ void generate_reads_kernel(disco_genspec spec, u64 *__restrict__ read
 __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, int min_overlap, u64 *ctr)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 bad = 0, mx = 0;
+    u32 bad = 0, mx = 0, mn = 0xFFFFu;
     for (; i < n; i += (u64)gridDim.x * blockDim.x) {
         u32 L = len[i];
         if (L <= (u32)min_overlap || L > 32767u || L > (u32)S * 32u) bad++;
         mx = L > mx ? L : mx;
+        mn = L < mn ? L : mn;
     }
     if (bad) atomicAdd(&ctr[CTR_BAD_LEN], (u64)bad);
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (u32)__shfl_down(mx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&ctr[CTR_MAX_LEN], (u64)mx);
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (u32)__shfl_down(mx, o));
+        mn = min(mn, (u32)__shfl_down(mn, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&ctr[CTR_MAX_LEN], (u64)mx);
+        atomicMax(&ctr[CTR_MIN_LEN], (u64)(0xFFFFu - mn));
+    }
 }
 
 /* ================================================================================================================
@@ -729,6 +737,7 @@ struct VerifyArgs {
     const u64 *order; /* [q_hi - q_lo] processing order (read ids), or null */
     ulonglong2 *meta_ord; /* [q_hi - q_lo] headers by position in the order (written by probe_kernel); out: the count becomes the
                              number of verified overlap hits — edge_select_kernel walks the same order and reads it here */
+    const u64 *cbits;     /* MODE 2: contained bitmap (complete: the containment pass has run)                            */
 };
 
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
@@ -752,7 +761,13 @@ __device__ __forceinline__ u64 uniform_u64(u64 x)
  * NW = 16 / 24 / 32: staged variants for a row stride of NW words (reads of 257..1024 bases: 2 x 300 bp runs, merged pairs,
  * long amplicons): the rows are too wide to be held in registers one read ahead, they are fetched when their read's turn comes
  * (headers and candidate lists stay pipelined). */
-template <int NW>
+/* MODE 0: everything in one pass (exact kmer_hits counter). MODE 1 / 2: the two-pass form for read sets in which most reads are
+ * contained (metagenomes: 3/4 of the reads). Whether a candidate is containment-type follows from (j, lengths, record kind) BEFORE
+ * its row is fetched, and a containment-type candidate can never become an edge between two non-contained reads (if its compare
+ * holds, one of the two reads is contained). MODE 1 fetches and compares the containment-type candidates only (best[]); the host
+ * then fixes the contained flags; MODE 2 skips contained query reads altogether and fetches rows for the overlap-type candidates
+ * of the others. Rows fetched: about half instead of all; kmer_hits then counts the compared candidates only (disco_params.flags). */
+template <int NW, int MODE = 0>
 __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
 {
     /* staged: the candidate rows (one per lane, NW words + zero words behind; odd stride; the last zero word of a lane is
@@ -800,6 +815,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
     u64 ord_chunk = 0;
     auto rid = [&](u64 it) { return ORDER_ID(readlane_u64(ord_chunk, (u32)((it < cend ? it : cend - 1) - cbeg))); };
     ulonglong2 meta_chunk = make_ulonglong2(0, 0); /* lane i: header of the chunk's read i (probe_kernel's meta_ord) */
+    u32 skip_chunk = 0; /* MODE 2, lane i: read i of the chunk is contained (nothing to do for it) */
     auto load_meta = [&](u64 it) {
         Meta mt;
         const bool ok = it < cend;
@@ -808,7 +824,15 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         mt.rs = readlane_u64(meta_chunk.x, i);
         mt.L = (int)(w >> 32);
         mt.c = ok ? (u32)w : 0u;
+        if (MODE == 2 && __builtin_amdgcn_readlane((int)skip_chunk, (int)i)) mt.c = 0u;
         return mt;
+    };
+    /* is the candidate of this pass? containment-type <=> s2 lies inside A (BG/OverlapGraph.cpp:532,547); an overlap needs j >= 1 */
+    auto in_pass = [&](u64 h, int LA) -> bool {
+        if (MODE == 0) return true;
+        const int j = (int)HIT_J(h), LB = (int)HIT_LEN(h);
+        const bool contain = (HIT_SUFFIX(h) == HIT_REV(h)) ? (LA - j >= LB) : (j + k - LB >= 0);
+        return MODE == 1 ? contain : (!contain && j >= 1);
     };
     /* idle lanes load something the wave touches anyway (never one fixed address: with every wave of the chip doing that,
      * the line's L2 channel becomes a hot spot) */
@@ -843,7 +867,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
             r.aw = own[lane < (u32)NW ? lane : 0u];
             if (PREF) {
                 u64 w[staged ? NW : 1];
-                load_row(w, lane < mt.c ? a.v.reads + HIT_ID(h) * S : own);
+                load_row(w, (lane < mt.c && in_pass(h, mt.L)) ? a.v.reads + HIT_ID(h) * S : own);
 #pragma unroll
                 for (int t = 0; t < RW; t++) r.w[t] = w[t % (staged ? NW : 1)];
             }
@@ -855,6 +879,10 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         const u64 i = cbeg + (lane < cend - cbeg ? lane : 0u); /* WQ_CHUNK <= 64: one lane per read of the chunk */
         ord_chunk = a.order ? a.order[i] : a.v.q_lo + i;
         meta_chunk = a.meta_ord[i];
+        if (MODE == 2) {
+            const u64 id = ORDER_ID(ord_chunk);
+            skip_chunk = (((const u32 *)a.cbits)[id >> 5] >> (id & 31)) & 1u;
+        }
     }
     u32 nk_chunk = 0; /* lane i: verified hits of the chunk's read i (0 for reads without candidates) */
     Meta m0 = load_meta(cbeg), m1 = load_meta(cbeg + 1), m2 = load_meta(cbeg + 2);
@@ -884,7 +912,8 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
             }
             u32 nkeep = 0;
             /* one batch of 64 candidates: lane = candidate h with its row words w (staged variants) */
-            auto batch = [&](const bool act, const u64 h, const u64 (&w)[staged ? NW : 1]) {
+            auto batch = [&](const bool act0, const u64 h, const u64 (&w)[staged ? NW : 1]) {
+                const bool act = act0 && in_pass(h, LA);
                 bool ov = false;
                 const int j = (int)HIT_J(h);
                 const u64 B = HIT_ID(h);
@@ -971,9 +1000,11 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                     }
                 }
                 /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
-                const u64 mk = __ballot(ov);
-                if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
-                nkeep += __popcll(mk);
+                if (MODE != 1) { /* the containment pass leaves the candidate list as it is */
+                    const u64 mk = __ballot(ov);
+                    if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+                    nkeep += __popcll(mk);
+                }
                 __syncthreads();
             };
             /* the first 64 candidates and their rows were prefetched; longer rows fetch the rest on the spot (kept out of the
@@ -987,7 +1018,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                 const bool act = lane < c;
                 u64 w[staged ? NW : 1];
                 w[0] = 0;
-                if (staged) load_row(w, act ? a.v.reads + HIT_ID(h0) * S : ga);
+                if (staged) load_row(w, (act && in_pass(h0, LA)) ? a.v.reads + HIT_ID(h0) * S : ga);
                 batch(act, h0, w);
             }
             for (u32 i0 = 64; i0 < c; i0 += 64) {
@@ -995,14 +1026,16 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
                 const u64 h = row[act ? i0 + lane : 0];
                 u64 w[staged ? NW : 1];
                 w[0] = 0;
-                if (staged) load_row(w, act ? a.v.reads + HIT_ID(h) * S : ga);
+                if (staged) load_row(w, (act && in_pass(h, LA)) ? a.v.reads + HIT_ID(h) * S : ga);
                 batch(act, act ? h : 0ull, w);
             }
-            if (lane == 0) {
-                a.row_cnt[A] = nkeep;
-                my_raw += nkeep;
+            if (MODE != 1) {
+                if (lane == 0) {
+                    a.row_cnt[A] = nkeep;
+                    my_raw += nkeep;
+                }
+                if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
             }
-            if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
         }
         m0 = m1;
         m1 = m2;
@@ -1012,7 +1045,7 @@ __global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
         R0 = R1;
     }
     /* the counts of the whole chunk in one coalesced store: {row start, verified hits | length << 32} by position in the order */
-    if (lane < (u32)(cend - cbeg)) a.meta_ord[cbeg + lane].y = (u64)nk_chunk | (meta_chunk.y & 0xFFFFFFFF00000000ull);
+    if (MODE != 1 && lane < (u32)(cend - cbeg)) a.meta_ord[cbeg + lane].y = (u64)nk_chunk | (meta_chunk.y & 0xFFFFFFFF00000000ull);
     }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {

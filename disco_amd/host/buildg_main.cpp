@@ -216,7 +216,9 @@ int main(int argc, char **argv)
 
     /* ---- graph on the GPU(s) ---------------------------------------------------------------------------------------- */
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
-    disco_params prm{min_overlap, 4, 0, 0};
+    /* two-pass verify for read sets of mixed lengths (metagenomes: most reads contained): same files, fewer candidate-row fetches;
+     * only the diagnostic k-mer-hit count in the log then counts the compared candidates */
+    disco_params prm{min_overlap, 4, getenv("DISCO_EXACT_COUNTERS") ? 0u : DISCO_FLAG_TWO_PASS_VERIFY, 0};
     uint64_t n_cont = 0, e_pre = 0, e_out = 0;
     std::vector<disco_contained_row> rows;
     std::unique_ptr<disco_edge[]> edges;

@@ -41,12 +41,19 @@ enum {
     DISCO_E_UNSUPPORTED = -6
 };
 
+/* disco_params.flags */
+#define DISCO_FLAG_TWO_PASS_VERIFY 1u /* read sets of mixed lengths (shortest < 0.9 x longest), single-GPU passes: verify the
+                                         containment-type candidates first, fix the contained flags, then fetch rows only for the
+                                         overlap-type candidates of non-contained reads — about half the row fetches where most
+                                         reads are contained (metagenomes). Results are unchanged; disco_counters.kmer_hits and
+                                         .raw_hits then count the compared candidates only (the reference has no such counters) */
+
 typedef struct disco_ctx disco_ctx;
 
 typedef struct disco_params {
     uint32_t min_overlap;        /* MinOverlap4BuildGraph (disco.cfg:9); k = min_overlap - 1 (BG/HashTable.cpp:50) */
     uint32_t max_edges_per_kmer; /* MAX_EDGE_PER_KMER (BG/Common.h:62); 0 -> 4                                       */
-    uint32_t flags;              /* reserved, 0                                                                      */
+    uint32_t flags;              /* DISCO_FLAG_*                                                                     */
     uint32_t reserved;
 } disco_params;
 

@@ -16,12 +16,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = json.load(open(os.path.join(HERE, "golden", "cases_big.json")))
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
-def test_hip_digest_matches_reference_files(name):
+def _cases():
+    """every pinned case, and the mixed-length ones once more through the two-pass verify (DISCO_FLAG_TWO_PASS_VERIFY)"""
+    out = [(n, 0) for n in sorted(CASES)]
+    return out + [(n, buildgraph.FLAG_TWO_PASS_VERIFY) for n in sorted(CASES) if CASES[n].get("len_max", CASES[n]["read_len"]) > CASES[n]["read_len"]]
+
+
+@pytest.mark.parametrize("name,flags", _cases())
+def test_hip_digest_matches_reference_files(name, flags):
     c = CASES[name]
     spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"],
                                     len_max=c.get("len_max", c["read_len"]), skew=c.get("skew", 0))
-    with buildgraph.BuildGraph(min_overlap=c["min_overlap"]) as g:
+    with buildgraph.BuildGraph(min_overlap=c["min_overlap"], flags=flags) as g:
         g.generate_reads(spec)
         g.run_graph()
         cnt = g.counters()

@@ -9,7 +9,8 @@ genome = int(n * (lmin + lmax) / 2 / cov)
 skew = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 nc = int(sys.argv[6]) if len(sys.argv) > 6 else max(1, genome // 5_000_000)
 spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
-g = buildgraph.BuildGraph(min_overlap=40, device=0)
+import os
+g = buildgraph.BuildGraph(min_overlap=40, device=0, flags=buildgraph.FLAG_TWO_PASS_VERIFY if os.environ.get("TWO_PASS") else 0)
 g.generate_reads(spec)
 for r in range(2):
     t0 = time.perf_counter(); g.run_graph(); g.synchronize(); t = time.perf_counter() - t0
