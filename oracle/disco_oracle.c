@@ -3,7 +3,7 @@
  *
  * TEST INFRASTRUCTURE ONLY: the checker for the HIP path, never the thing measured or shipped.
  * Parity status: PINNED against the reference golden vector and against the real reference binary
- * (tests/test_oracle_vs_reference.py, tests/golden/).
+ * (tests/test_oracle_golden.py, tests/golden/).
  *
  * Plain C99, one base per byte, no bit tricks: deliberately a different style from the HIP kernels
  * so that the two implementations do not share bugs.  BG/ = /root/reference/src/BuildGraph/src/.

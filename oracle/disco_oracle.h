@@ -5,7 +5,7 @@
  * execute this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
  * only as the checker.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks this restatement against
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement against
  *   (1) the reference's only in-tree golden vector, src/BuildGraph/bench_test_0_parGraph.txt, and
  *   (2) outputs of the real reference `buildG` (oracle/_ref/buildG_ref, built from
  *       /root/reference by oracle/Makefile) on seeded inputs, committed under tests/golden/.

@@ -7,11 +7,6 @@ from tests.util import assert_parity
 
 pytestmark = pytest.mark.gpu
 
-REF_FASTA = {
-    # the two in-tree FASTAs of the reference, restated as data (sequences only) in tests/golden
-}
-
-
 def _gen(seed, n, lmin, cov, lmax=None, contigs=1):
     spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=contigs, len_max=lmax)
     return readgen.generate_reads(spec)
