@@ -116,6 +116,7 @@ struct disco_ctx {
     ProbeRare *d_probe_rare = nullptr;
     u32 max_len = 0, min_len = 0; /* longest / shortest read (validate_reads) */
     bool two_pass_last = false;    /* the last probe verified in two passes */
+    bool contained_done = false;   /* multi-GPU pass: the containment exchange already ran between the two verify passes */
 
     /* containment */
     u8 *d_contained = nullptr;
@@ -443,6 +444,8 @@ static void free_reads(disco_ctx *c)
     c->h_len.clear();
     c->n = 0;
 }
+
+static int dist_mark_contained(disco_ctx *c); /* multi-GPU flow, below */
 
 /* ================================================================================================================ */
 extern "C" {
@@ -852,7 +855,8 @@ int disco_probe(disco_ctx *c)
             /* two passes (containment-type candidates, flags, overlap-type candidates of non-contained reads) where most reads
              * can be contained: only on request (the kmer_hits counter then counts the compared candidates only), reads of mixed
              * length, rows of the 64-byte staged variants, and not inside a multi-GPU pass (its flags need an exchange in between) */
-            const bool two_pass = (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && !c->dist_active && c->S == VERIFY_SW && nq &&
+            /* (multi-GPU pass: every rank takes the same branch — min / max length are the job's, nq plays no part) */
+            const bool two_pass = (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && c->S == VERIFY_SW && (nq || c->dist_active) &&
                                   (u64)c->min_len * 10 < (u64)c->max_len * 9 && !getenv("DISCO_NO_TWO_PASS");
             c->two_pass_last = two_pass;
             ph_begin(c, DISCO_PH_VERIFY);
@@ -861,12 +865,21 @@ int disco_probe(disco_ctx *c)
                 if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
                 va.cbits = c->d_cbits;
                 const bool short_rows = c->max_len <= 160;
-                if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 1>), dim3(wq_grid(c, verify_kernel<5, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
-                else hipLaunchKernelGGL((verify_kernel<8, 1>), dim3(wq_grid(c, verify_kernel<8, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
-                CHK(zero_counter(c, CTR_N_CONTAINED));
-                hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
-                if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 2>), dim3(wq_grid(c, verify_kernel<5, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
-                else hipLaunchKernelGGL((verify_kernel<8, 2>), dim3(wq_grid(c, verify_kernel<8, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                if (nq) {
+                    if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 1>), dim3(wq_grid(c, verify_kernel<5, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                    else hipLaunchKernelGGL((verify_kernel<8, 1>), dim3(wq_grid(c, verify_kernel<8, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                }
+                if (c->dist_active) { /* the keys of other ranks' containing reads count too: exchange, then the flags (collective) */
+                    CHK(dist_mark_contained(c));
+                    c->contained_done = true;
+                } else {
+                    CHK(zero_counter(c, CTR_N_CONTAINED));
+                    hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
+                }
+                if (nq) {
+                    if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 2>), dim3(wq_grid(c, verify_kernel<5, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                    else hipLaunchKernelGGL((verify_kernel<8, 2>), dim3(wq_grid(c, verify_kernel<8, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                }
             } else if (nq) {
                 va.cbits = nullptr;
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
@@ -2506,8 +2519,9 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
         di.ms[DISCO_X_READS] += ms_since(t0); /* time to ISSUE it (RCCL: asynchronous; in-process transport: the copies themselves) */
     }
     CHK(dist_build_index(c));
+    c->contained_done = false;
     CHK(disco_probe(c));
-    CHK(dist_mark_contained(c));
+    if (!c->contained_done) CHK(dist_mark_contained(c));
     CHK(select_edges(c));
     /* whole-job figures and the regime decision */
     u64 probes = 0;

@@ -10,10 +10,10 @@ import numpy as np
 from disco_amd import buildgraph
 
 
-def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1):
+def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flags=0):
     """setup(g) puts this rank's reads into context g (collective calls allowed). Returns (edges of all ranks, contained
     rows of all ranks, info of rank 0, infos)"""
-    gs = [buildgraph.BuildGraph(min_overlap=min_overlap, device=device) for _ in range(G)]
+    gs = [buildgraph.BuildGraph(min_overlap=min_overlap, device=device, flags=flags) for _ in range(G)]
     buildgraph.BuildGraph.comm_init_local(gs)
     out, errors = [None] * G, []
 

@@ -33,6 +33,12 @@ def test_config5_shape_at_full_size(monkeypatch):
     if _host_gb() < 96:  # 1.5 x 10^8 contained rows and 5 x 10^7 edges come back to the host
         n = min(n, 50_000_000)
     spec = readgen.GenSpec.coverage(42, n, 100, 30.0, n_contigs=100, len_max=250, skew=1)
+    # first pass: the two-pass verify (what buildG uses on read sets of mixed length); second pass, on a fresh context: the
+    # single-pass verify with the full twin search forced — every result counter must agree
+    with buildgraph.BuildGraph(min_overlap=40, flags=buildgraph.FLAG_TWO_PASS_VERIFY) as g2:
+        g2.generate_reads(spec)
+        g2.run_graph()
+        c0 = g2.counters()
     with buildgraph.BuildGraph(min_overlap=40) as g:
         g.generate_reads(spec)
         g.run_graph()
@@ -45,6 +51,8 @@ def test_config5_shape_at_full_size(monkeypatch):
         r = g.fetch_contained()
     for k in ("n_reads", "probes", "kmer_hits", "n_contained", "raw_hits", "e_pre", "e_out", "cap_bind_sites", "asymmetric_pairs"):
         assert c1[k] == c2[k], k
+    for k in ("n_reads", "probes", "n_contained", "e_pre", "e_out", "cap_bind_sites", "asymmetric_pairs"):
+        assert c0[k] == c1[k], ("two-pass verify", k)
     assert c1["n_reads"] == n and c1["asymmetric_pairs"] == 0 and len(e) == c1["e_out"] and len(r) == c1["n_contained"]
     assert 0.6 * n < c1["n_contained"] < 0.9 * n and c1["e_out"] > 0.1 * n  # the heavy-containment regime
     assert np.all(e["src"] < e["dst"])

@@ -132,3 +132,15 @@ def test_partition_of_host_edges_keeps_components_together():
     file_of_comp = {}
     for s, fi in zip(e["src"], f):
         assert file_of_comp.setdefault(int(comp[s]), int(fi)) == int(fi)
+
+
+@pytest.mark.parametrize("name,G", [("mixed_4k", 2), ("mixed_4k", 3), ("k30_6k", 4), ("contigs_20k", 2)])
+def test_ranks_two_pass_verify_equal_reference(name, G):
+    """DISCO_FLAG_TWO_PASS_VERIFY inside a multi-rank pass: the containment exchange moves between the two verify passes"""
+    from disco_amd import buildgraph
+
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, _ = run_ranks_reads(reads, mo, G, flags=buildgraph.FLAG_TWO_PASS_VERIFY)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden(name, ce, cc)
+    assert info["regime"] == 0
