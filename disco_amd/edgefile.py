@@ -1,0 +1,57 @@
+"""reader of buildG's binary side output (--binary-out; layout: disco_amd/host/writer.h) and its conversion back into the text
+files of the stage (BG/OverlapGraph.cpp:438-447 contained rows, :808-867 edge lines) — what a SimplifyGraph loader patched to read
+the binary form would do in memory instead (SG/OverlapGraphSimple.cpp:535-650, SG/DataSet.cpp:284-343)."""
+from __future__ import annotations
+
+import numpy as np
+
+HEADER = np.dtype([("magic", "S8"), ("version", "<u4"), ("record_bytes", "<u4"), ("n_records", "<u8"), ("n_files", "<u4"), ("reserved", "<u4")])
+EDGE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("orient", "<u4"), ("offset", "<u4"), ("len_src", "<u4"), ("len_dst", "<u4"), ("file", "<u2"),
+                 ("flag", "<u2"), ("pad", "<u4")])
+CONTAINED = np.dtype([("contained", "<u8"), ("super", "<u8"), ("orient", "<u4"), ("len2", "<u4"), ("len1", "<u4"), ("start", "<u4"),
+                      ("file", "<u2"), ("pad0", "<u2"), ("pad1", "<u4")])
+
+
+def _read(path, magic, dtype):
+    with open(path, "rb") as f:
+        h = np.frombuffer(f.read(HEADER.itemsize), dtype=HEADER)[0]
+        if h["magic"] != magic or h["version"] != 1 or h["record_bytes"] != dtype.itemsize:
+            raise ValueError(f"{path}: not a {magic.decode()} v1 file")
+        rec = np.frombuffer(f.read(), dtype=dtype)
+    if len(rec) != h["n_records"]:
+        raise ValueError(f"{path}: {len(rec)} records, header says {h['n_records']}")
+    return rec, int(h["n_files"])
+
+
+def read_edges(path):
+    return _read(path, b"DISCOEDG", EDGE)
+
+
+def read_contained(path):
+    return _read(path, b"DISCOCON", CONTAINED)
+
+
+def edge_lines(rec):
+    """the text lines of the records, in record order"""
+    for r in rec:
+        ovl = int(r["len_src"]) - int(r["offset"])
+        yield (f"{r['src']}\t{r['dst']}\t{r['orient']},{ovl},0,0,{r['len_src']},{r['offset']},{int(r['len_src']) - 1},{r['len_dst']},0,{ovl - 1},NA,{r['flag']}\n")
+
+
+def contained_lines(rec):
+    for r in rec:
+        yield (f"{r['contained']}\t{r['super']}\t{r['orient']},{r['len2']},0,0,{r['len2']},0,{r['len2']},{r['len1']},{r['start']},"
+               f"{int(r['start']) + int(r['len2'])}\n")
+
+
+def text_files(prefix, tags=None):
+    """{file name: text} of every <prefix>_<t>_parGraph.txt / _containedReads.txt the binary pair stands for (tags: the "<t>"
+    of every file, default "0", "1", …; the same tags for both kinds)"""
+    e, ne = read_edges(prefix + "_edges.bin")
+    c, nc = read_contained(prefix + "_contained.bin")
+    out = {}
+    for rec, nfiles, lines, suffix in ((e, ne, edge_lines, "parGraph"), (c, nc, contained_lines, "containedReads")):
+        for t in range(nfiles):
+            tag = tags[t] if tags else str(t)
+            out[f"{prefix}_{tag}_{suffix}.txt"] = "".join(lines(rec[rec["file"] == t]))
+    return out

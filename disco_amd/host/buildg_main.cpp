@@ -47,7 +47,9 @@ static void usage()
               << "  --gpu\tfirst GPU to use (default 0)\n"
               << "  --gpus\tnumber of GPUs = ranks (default 1): reads and graph partitioned over them, RCCL exchanges\n"
               << "  --same-device\tall ranks on the GPU given by --gpu (in-process exchanges; single-GPU boxes)\n"
-              << "  --mpi-names\tfile names <prefix>_<rank>_<thread>_... as written by buildG-MPI / buildG-MPIRMA (runDisco-MPI.sh)\n";
+              << "  --mpi-names\tfile names <prefix>_<rank>_<thread>_... as written by buildG-MPI / buildG-MPIRMA (runDisco-MPI.sh)\n"
+              << "  --binary-out\talso write <prefix>_edges.bin / <prefix>_contained.bin (fixed 40-byte records, disco_amd/host/writer.h)\n"
+              << "  --no-text\tbinary output only: leave the text edge / contained files empty (a consumer with the loader patch)\n";
 }
 
 static std::vector<std::string> split(const std::string &s, char d)
@@ -126,7 +128,7 @@ int main(int argc, char **argv)
     std::vector<std::string> pe, se;
     std::string prefix, cfg;
     int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
-    bool same_device = false, mpi_names = false;
+    bool same_device = false, mpi_names = false, binary_out = false, no_text = false;
     std::cout << "PRINTING ARGUMENTS\n";
     for (int i = 0; i < argc; i++) std::cout << argv[i] << ' ';
     std::cout << std::endl;
@@ -162,6 +164,8 @@ int main(int argc, char **argv)
         else if (a == "--gpus") gpus = (int)num(1, 64);
         else if (a == "--same-device") same_device = true;
         else if (a == "--mpi-names") mpi_names = true;
+        else if (a == "--binary-out") binary_out = true;
+        else if (a == "--no-text") binary_out = no_text = true;
         else {
             usage();
             if (a == "-h" || a == "--help") return 0;
@@ -360,6 +364,14 @@ int main(int argc, char **argv)
     /* ---- outputs -------------------------------------------------------------------------------------------------- */
     disco::FileTags etags = mpi_names ? disco::FileTags::mpi_edges(gpus, threads) : disco::FileTags::plain(threads);
     disco::FileTags ctags = mpi_names ? disco::FileTags::mpi_contained(gpus, threads) : disco::FileTags::plain(threads);
+    if (binary_out) {
+        if (!disco::write_binary(prefix, (int)etags.tag.size(), (int)ctags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rows, rs, err)) return die(err);
+        lap("write binary side output");
+    }
+    if (no_text) { /* the file lists of the scripts still exist (the consumer aborts on a missing file), empty */
+        rows.clear();
+        e_out = 0;
+    }
     if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags)) return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);

@@ -258,6 +258,94 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
     return ok;
 }
 
+namespace {
+struct BinHeader {
+    char magic[8];
+    uint32_t version, record_bytes;
+    uint64_t n_records;
+    uint32_t n_files, reserved;
+};
+struct BinEdge {
+    uint64_t src, dst;
+    uint32_t orient, offset, len_src, len_dst;
+    uint16_t file, flag;
+    uint32_t pad;
+};
+struct BinContained {
+    uint64_t contained, super;
+    uint32_t orient, len2, len1, start;
+    uint16_t file, pad0;
+    uint32_t pad1;
+};
+static_assert(sizeof(BinHeader) == 32 && sizeof(BinEdge) == 40 && sizeof(BinContained) == 40, "binary side-output layout");
+
+template <typename R>
+bool write_records(const std::string &path, const char *magic, const std::vector<R> &rec, int n_files, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) {
+        err = "Unable to open file: " + path;
+        return false;
+    }
+    BinHeader h;
+    memcpy(h.magic, magic, 8);
+    h.version = 1;
+    h.record_bytes = (uint32_t)sizeof(R);
+    h.n_records = rec.size();
+    h.n_files = (uint32_t)n_files;
+    h.reserved = 0;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (rec.empty() || fwrite(rec.data(), sizeof(R), rec.size(), f) == rec.size());
+    fclose(f);
+    if (!ok) err = "Short write: " + path;
+    return ok;
+}
+} // namespace
+
+bool write_binary(const std::string &prefix, int n_edge_files, int n_contained_files, const disco_edge *edges, size_t n_edges, const uint16_t *edge_file,
+                  std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err)
+{
+    const uint64_t n = rs.size();
+    std::vector<BinEdge> be(n_edges);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n_edges; i++) {
+        const disco_edge &e = edges[i];
+        BinEdge &o = be[i];
+        o.src = rs.file_index[e.src];
+        o.dst = rs.file_index[e.dst];
+        o.orient = e.orient;
+        o.offset = e.offset;
+        o.len_src = e.len_src;
+        o.len_dst = e.len_dst;
+        o.file = edge_file ? (uint16_t)std::min<int>(edge_file[i], n_edge_files - 1) : (uint16_t)owner_of(e.src, n, n_edge_files);
+        o.flag = 2; /* the files are cut along connected components: both ends have all their edges in this file */
+        o.pad = 0;
+    }
+    if (!write_records(prefix + "_edges.bin", "DISCOEDG", be, n_edge_files, err)) return false;
+    std::vector<BinEdge>().swap(be);
+    /* same order as the text files: by containing read, then (j, contained id) */
+    std::sort(rows.begin(), rows.end(), [](const disco_contained_row &a, const disco_contained_row &b) {
+        if (a.super != b.super) return a.super < b.super;
+        if (a.j != b.j) return a.j < b.j;
+        return a.contained < b.contained;
+    });
+    std::vector<BinContained> bc(rows.size());
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < rows.size(); i++) {
+        const disco_contained_row &r = rows[i];
+        BinContained &o = bc[i];
+        o.contained = rs.file_index[r.contained];
+        o.super = rs.file_index[r.super];
+        o.orient = r.orient;
+        o.len2 = r.len2;
+        o.len1 = r.len1;
+        o.start = r.start;
+        o.file = (uint16_t)owner_of(r.super, n, n_contained_files);
+        o.pad0 = 0;
+        o.pad1 = 0;
+    }
+    return write_records(prefix + "_contained.bin", "DISCOCON", bc, n_contained_files, err);
+}
+
 bool write_checkpoint(const std::string &prefix, bool ccr, bool gc, bool append, std::string &err)
 {
     std::ofstream f(prefix + "_CheckpointInfo.txt", append ? std::ios::app : std::ios::trunc);

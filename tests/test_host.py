@@ -170,6 +170,42 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_nam
     assert p2.returncode == 0 and "Graph already exists" in p2.stdout
 
 
+@pytest.mark.gpu
+def test_binary_side_output_stands_for_the_text_files(tmp_path):
+    """--binary-out writes fixed-size records beside the text files; converted back (disco_amd/edgefile.py) they ARE
+    the text files, line for line per file (lines of a file sorted: the text writer groups by file in chunks, the binary file
+    keeps the edges in fetch order)"""
+    from disco_amd import edgefile
+
+    build.build_host()
+    c = gu.CASES["multifile"]
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text(f"MinOverlap4BuildGraph = {c['min_overlap']}\n")
+    prefix = str(tmp_path / "g")
+    pe = ",".join(os.path.join(gu.GOLD, f) for f in c["pe"])
+    se = ",".join(os.path.join(gu.GOLD, f) for f in c["se"])
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-pe", pe, "-se", se, "-f", prefix, "-p", str(cfg), "-t", "3", "--binary-out"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    texts = edgefile.text_files(prefix)
+    assert len(texts) == 6
+    for path, text in texts.items():
+        assert sorted(open(path).read().splitlines()) == sorted(text.splitlines()), path
+    assert "".join(texts[f"{prefix}_{t}_containedReads.txt"] for t in range(3)) == "".join(open(f"{prefix}_{t}_containedReads.txt").read() for t in range(3))
+    # --no-text: the file lists still exist, empty; the binary pair carries everything
+    prefix2 = str(tmp_path / "h")
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-pe", pe, "-se", se, "-f", prefix2, "-p", str(cfg), "-t", "3", "--no-text"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    assert all(os.path.getsize(f"{prefix2}_{t}_parGraph.txt") == 0 and os.path.getsize(f"{prefix2}_{t}_containedReads.txt") == 0 for t in range(3))
+    e2, _ = edgefile.read_edges(prefix2 + "_edges.bin")
+    e1, _ = edgefile.read_edges(prefix + "_edges.bin")
+    key = lambda r: np.sort(r[["src", "dst", "orient", "offset", "len_src", "len_dst"]], order=["src", "dst"])  # noqa: E731
+    assert np.array_equal(key(e1), key(e2))
+    edges = refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt")))
+    assert len(e1) == len(edges) == c["n_edges"]
+
+
 def _parsimplify(edge_file, out_file, min_ovl):
     exe = os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref")
     p = subprocess.run([exe, edge_file, out_file, str(min_ovl), "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
