@@ -1,0 +1,84 @@
+"""differential fuzzing of the multi-GPU flow and of the two-pass verify: random generator settings (the recipe of fuzz_parity.py:
+lengths 45-5000, k = 30-64, coverage 3-1500x, contigs, abundance skew, substitution errors, exact / reverse-complement duplicates,
+repeat genomes that bind the cap), every case through
+   (a) the single-GPU pass,  (b) the single-GPU pass with DISCO_FLAG_TWO_PASS_VERIFY,  (c) G = 2..5 ranks on one GPU (in-process
+   transport), two-pass flag at random
+and (a) is checked against the CPU oracle (tests.util.assert_parity); (b) and (c) must equal (a) bit for bit.
+   python tools/fuzz_dist.py [ITERATIONS=50] [SEED=1]"""
+import os
+import sys
+import time
+import traceback
+
+os.environ.setdefault('DISCO_ORDER_MIN_READS', '1')
+sys.path.insert(0, '.')
+import numpy as np  # noqa: E402
+
+from disco_amd import buildgraph, readgen  # noqa: E402
+from tests.dist_util import run_ranks_reads  # noqa: E402
+from tests.util import assert_parity, canon_hip, run_hip_reads  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fails = 0
+t0 = time.time()
+for it in range(iters):
+    lmin = int(rng.choice([45, 60, 80, 100, 150, 151, 168, 200, 256, 257, 300, 500, 1000, 1025, 2000]))
+    lmax = lmin if rng.random() < 0.3 else int(lmin + rng.integers(1, 2 * lmin))
+    mo = int(rng.choice([31, 32, 33, 40, 41, 50, 64, 65]))
+    if mo >= lmin:
+        mo = max(31, lmin - 8)
+    cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700]))
+    n = int(rng.integers(100, 7000))
+    if cov >= 300:
+        n = min(n, 2000)
+    if lmin >= 1000:
+        n = min(n, 1000)
+        cov = min(cov, 60.0)
+    nc = int(rng.integers(1, 6))
+    skew = int(rng.random() < 0.3)
+    seed = int(rng.integers(1, 1 << 30))
+    G = int(rng.integers(2, 6))
+    tp = buildgraph.FLAG_TWO_PASS_VERIFY if rng.random() < 0.5 else 0
+    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} G={G} two_pass_in_ranks={tp}"
+    try:
+        spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
+        reads = list(readgen.generate_reads(spec))
+        if rng.random() < 0.25:  # repeats: the cap binds, one-sided pairs -> the order-dependent regime (adjacency gathered)
+            r3 = np.random.default_rng(seed + 1)
+            rep = "".join(r3.choice(list("ACGT"), int(r3.integers(60, 400))))
+            genome = "".join("".join(r3.choice(list("ACGT"), int(r3.integers(30, 300)))) + rep for _ in range(int(r3.integers(3, 40))))
+            comp0 = str.maketrans("ACGT", "TGCA")
+            reads = []
+            for _ in range(n):
+                L = int(r3.integers(lmin, lmax + 1))
+                if L >= len(genome):
+                    continue
+                p0 = int(r3.integers(0, len(genome) - L))
+                s0 = genome[p0:p0 + L]
+                reads.append(s0.translate(comp0)[::-1] if r3.random() < 0.5 else s0)
+            label += " repeats"
+            if len(reads) < 8:
+                continue
+        if rng.random() < 0.2:
+            comp = str.maketrans("ACGT", "TGCA")
+            reads += [reads[i] if rng.random() < 0.5 else reads[i].translate(comp)[::-1] for i in rng.integers(0, len(reads), max(len(reads) // 10, 1))]
+        c = assert_parity(reads, mo, label)  # (a) vs the oracle
+        e1, r1, _ = run_hip_reads(reads, mo)
+        ce1, cc1 = canon_hip(e1, r1)
+        e2, r2, c2 = run_hip_reads(reads, mo, flags=buildgraph.FLAG_TWO_PASS_VERIFY)  # (b)
+        ce2, cc2 = canon_hip(e2, r2)
+        assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2), "two-pass verify differs"
+        e3, r3_, info, _ = run_ranks_reads(reads, mo, G, flags=tp)  # (c)
+        ce3, cc3 = canon_hip(e3, r3_)
+        assert np.array_equal(cc1, cc3), f"{G} ranks: contained rows differ ({len(cc1)} vs {len(cc3)})"
+        assert np.array_equal(ce1, ce3), f"{G} ranks: edges differ ({len(ce1)} vs {len(ce3)})"
+        assert info["e_pre"] == c["e_pre"] and info["asymmetric_pairs"] == c["asymmetric_pairs"] and info["cap_bind_sites"] == c["cap_bind_sites"], (info, c)
+        print("ok  ", label, "e_pre", c["e_pre"], "e_out", c["e_out"], "contained", c["n_contained"], "regime", info["regime"], "rounds", info["tr_rounds"],
+              "deferred", info["tr_deferred"], flush=True)
+    except Exception as e:
+        fails += 1
+        print("FAIL", label, repr(e)[:300], flush=True)
+        traceback.print_exc()
+print(f"{iters - fails}/{iters} ok in {time.time() - t0:.0f} s")
+sys.exit(1 if fails else 0)
