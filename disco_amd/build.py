@@ -17,7 +17,7 @@ BUILDG = os.path.join(HERE, "bin", "buildG")
 HIP_SOURCES = [os.path.join(HERE, "csrc", "disco_hip.hip")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(HERE, "csrc", f) for f in ("disco_kernels.h", "disco_device.h", "readgen.h", "disco_dist.h", "disco_comm.h")] + [
     os.path.join(ROOT, "include", "disco_hip.h")]
-HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("buildg_main.cpp", "fastx.cpp", "writer.cpp")]
+HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("buildg_main.cpp", "fastx.cpp", "writer.cpp", "parsimple.cpp")]
 
 
 def _hipcc() -> str:
@@ -86,6 +86,13 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     dsrc = [os.path.join(HERE, "host", "fastx_dump.cpp"), os.path.join(HERE, "host", "fastx.cpp")]
     if force or _stale(dump, dsrc + [os.path.join(HERE, "host", "fastx.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", "-o", dump] + dsrc + ["-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    ps = os.path.join(HERE, "bin", "parsimplify")
+    psrc = [os.path.join(HERE, "host", f) for f in ("parsimplify_main.cpp", "parsimple.cpp", "fastx.cpp", "writer.cpp")]
+    if force or _stale(ps, psrc + [os.path.join(HERE, "host", f) for f in ("parsimple.h", "writer.h", "fastx.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", ps] + psrc + ["-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

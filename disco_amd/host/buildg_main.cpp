@@ -13,6 +13,7 @@
  */
 #include <omp.h>
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -30,6 +31,7 @@
 
 #include "disco_hip.h"
 #include "fastx.h"
+#include "parsimple.h"
 #include "writer.h"
 
 using Clock = std::chrono::steady_clock;
@@ -48,6 +50,9 @@ static void usage()
               << "  --gpus\tnumber of GPUs = ranks (default 1): reads and graph partitioned over them, RCCL exchanges\n"
               << "  --same-device\tall ranks on the GPU given by --gpu (in-process exchanges; single-GPU boxes)\n"
               << "  --mpi-names\tfile names <prefix>_<rank>_<thread>_... as written by buildG-MPI / buildG-MPIRMA (runDisco-MPI.sh)\n"
+              << "  --par-simple\tprefix: also write <prefix>_<i>_ParSimpleEdges.txt, the output of the reference's parsimplify step on\n"
+              << "\t\tevery edge file (fullsimplify then skips that step); DISCO_PAR_SIMPLE=1 in the environment derives the prefix\n"
+              << "\t\tfrom -f the way runDisco.sh lays its directories out (<out>/graph/<name> -> <out>/assembly/<name>)\n"
               << "  --binary-out\talso write <prefix>_edges.bin / <prefix>_contained.bin (fixed 40-byte records, disco_amd/host/writer.h)\n"
               << "  --no-text\tbinary output only: leave the text edge / contained files empty (a consumer with the loader patch)\n";
 }
@@ -79,11 +84,12 @@ static bool parse_u64(const std::string &s, unsigned long long &out)
 }
 
 /* BG/main.cpp:152-176 : key = value lines; default 30 */
-static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string &err)
+static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string &err, uint32_t *mo_simplify = nullptr)
 {
     std::ifstream f(path);
     if (!f.is_open()) return false;
     mo = 30;
+    if (mo_simplify) *mo_simplify = 0; /* SG/Config.cpp: minOvl defaults to 0 */
     std::string line;
     while (std::getline(f, line)) {
         size_t eq = line.find('=');
@@ -97,6 +103,10 @@ static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string 
                 return true;
             }
             mo = (uint32_t)v;
+        }
+        if (mo_simplify && trim(tok[0]) == "MinOverlap4SimplifyGraph") {
+            unsigned long long v = 0;
+            if (parse_u64(tok[1], v) && v <= 0xFFFFFFFFull) *mo_simplify = (uint32_t)v;
         }
     }
     return true;
@@ -129,6 +139,7 @@ int main(int argc, char **argv)
     std::string prefix, cfg;
     int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
     bool same_device = false, mpi_names = false, binary_out = false, no_text = false;
+    std::string par_simple; /* prefix of the <prefix>_<i>_ParSimpleEdges.txt files, or empty */
     std::cout << "PRINTING ARGUMENTS\n";
     for (int i = 0; i < argc; i++) std::cout << argv[i] << ' ';
     std::cout << std::endl;
@@ -164,6 +175,7 @@ int main(int argc, char **argv)
         else if (a == "--gpus") gpus = (int)num(1, 64);
         else if (a == "--same-device") same_device = true;
         else if (a == "--mpi-names") mpi_names = true;
+        else if (a == "--par-simple") par_simple = next();
         else if (a == "--binary-out") binary_out = true;
         else if (a == "--no-text") binary_out = no_text = true;
         else {
@@ -177,9 +189,9 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    uint32_t min_overlap = 30;
+    uint32_t min_overlap = 30, min_overlap_simplify = 0;
     std::string cfg_err;
-    if (!read_min_overlap(cfg, min_overlap, cfg_err)) {
+    if (!read_min_overlap(cfg, min_overlap, cfg_err, &min_overlap_simplify)) {
         std::cerr << "Unable to open parameter file: " << cfg << std::endl;
         return 1; /* BG/main.cpp:157-160 */
     }
@@ -367,6 +379,23 @@ int main(int argc, char **argv)
     if (binary_out) {
         if (!disco::write_binary(prefix, (int)etags.tag.size(), (int)ctags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rows, rs, err)) return die(err);
         lap("write binary side output");
+    }
+    if (par_simple.empty() && getenv("DISCO_PAR_SIMPLE")) { /* runDisco.sh:166-167: <out>/graph/<name> and <out>/assembly/<name> */
+        const size_t at = prefix.rfind("/graph/");
+        if (at != std::string::npos) {
+            par_simple = prefix.substr(0, at) + "/assembly/" + prefix.substr(at + 7);
+            const std::string dir = prefix.substr(0, at) + "/assembly";
+            (void)mkdir(dir.c_str(), 0777); /* runDisco.sh keeps an existing assembly directory ("Will continue previous run") */
+        }
+    }
+    if (!par_simple.empty() && !mpi_names) {
+        disco::ParSimpleStats ps;
+        if (!disco::write_par_simple(par_simple, (int)etags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rs, min_overlap_simplify, threads, err, &ps))
+            return die(err);
+        std::cout << "Partial simplification (the reference's parsimplify step) on the resident graph: " << ps.edges_in << " edges -> " << ps.edges_out << " ("
+                  << ps.nodes_absorbed << " nodes absorbed into composite edges, " << ps.dead_end_nodes << " dead-end nodes, " << ps.rounds << " rounds); files "
+                  << par_simple << "_<i>_ParSimpleEdges.txt" << std::endl;
+        lap("partial simplification");
     }
     if (no_text) { /* the file lists of the scripts still exist (the consumer aborts on a missing file), empty */
         rows.clear();

@@ -1,0 +1,330 @@
+/* parsimple.cpp — see parsimple.h */
+#include "parsimple.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace disco {
+
+namespace {
+
+/* one simple overlap along the direction an edge is stored in: from the previous node of the path to `to` */
+struct Link {
+    uint32_t to;
+    uint32_t offset;
+    uint8_t orient; /* bit 1: strand of the link's source, bit 0: strand of its destination (SG/OverlapGraphSimple.cpp:600-609) */
+};
+
+struct PEdge {
+    uint32_t a, b;             /* stored direction a -> b                                                         */
+    uint32_t offset;           /* sum of the links' offsets                                                       */
+    uint8_t orient;            /* (first link & 2) | (last link & 1): mergedEdgeOrientation, SG/EdgeSimple.cpp:272 */
+    uint8_t unknown_len = 0;   /* DISCO_PARSIMPLE_EMULATE_UNINIT only — bit 0 / 1: the reference would hold an uninitialised length for a / b */
+    std::vector<Link> links;   /* empty: a simple edge (one implicit link a -> b with orient / offset)            */
+};
+
+inline uint8_t twin(uint8_t o) { return (uint8_t)(((o >> 1) ^ 1) | (((o & 1) ^ 1) << 1)); } /* get_twin_orient, SG/EdgeSimple.cpp:277 */
+
+struct Graph {
+    const uint16_t *len;       /* read length by id */
+    std::vector<PEdge> e;
+    /* half-edge h = 2 * edge + dir (dir 1: the reverse b -> a) */
+    uint32_t src(uint64_t h) const { return (h & 1) ? e[h >> 1].b : e[h >> 1].a; }
+    uint32_t dst(uint64_t h) const { return (h & 1) ? e[h >> 1].a : e[h >> 1].b; }
+    uint8_t orient(uint64_t h) const { return (h & 1) ? twin(e[h >> 1].orient) : e[h >> 1].orient; }
+    /* reverse offset: dstLen + offset - srcLen (make_nonComposite_reverseEdge, SG/EdgeSimple.cpp:119-120; telescopes for composites) */
+    bool dst_len_unknown(uint64_t h) const { return (e[h >> 1].unknown_len >> ((h & 1) ? 0 : 1)) & 1; }
+    bool src_len_unknown(uint64_t h) const { return (e[h >> 1].unknown_len >> ((h & 1) ? 1 : 0)) & 1; }
+    uint32_t offset(uint64_t h) const
+    {
+        const PEdge &x = e[h >> 1];
+        return (h & 1) ? (uint32_t)((int64_t)len[x.b] + x.offset - len[x.a]) : x.offset;
+    }
+    /* the links of half-edge h in ITS direction, appended to out (prev = the node the walk comes from) */
+    void append_links(uint64_t h, std::vector<Link> &out) const
+    {
+        const PEdge &x = e[h >> 1];
+        if (!(h & 1)) {
+            if (x.links.empty()) out.push_back(Link{x.b, x.offset, x.orient});
+            else out.insert(out.end(), x.links.begin(), x.links.end());
+            return;
+        }
+        if (x.links.empty()) {
+            out.push_back(Link{x.a, (uint32_t)((int64_t)len[x.b] + x.offset - len[x.a]), twin(x.orient)});
+            return;
+        }
+        /* reverse a path a -> v1 -> ... -> b : links b -> vk, ..., v1 -> a */
+        const size_t k = x.links.size();
+        for (size_t i = k; i-- > 0;) {
+            const uint32_t from = i ? x.links[i - 1].to : x.a, to = x.links[i].to; /* forward link from -> to */
+            out.push_back(Link{from, (uint32_t)((int64_t)len[to] + x.links[i].offset - len[from]), twin(x.links[i].orient)});
+        }
+    }
+};
+
+} // namespace
+
+bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const uint16_t *edge_file, const ReadSet &rs,
+                      uint32_t min_ovl_simplify, int threads, std::string &err, ParSimpleStats *stats, const FileTags *tags,
+                      const std::vector<std::string> *paths, const uint8_t *marked)
+{
+    const uint64_t n = rs.size();
+    if (threads < 1) threads = 1;
+    Graph g;
+    g.len = rs.len.data();
+    std::vector<uint16_t> node_file(n, 0);
+    g.e.reserve(n_edges);
+    for (size_t i = 0; i < n_edges; i++) {
+        const disco_edge &x = edges[i];
+        const uint16_t f = edge_file ? (uint16_t)std::min<int>(edge_file[i], n_files - 1) : 0;
+        node_file[x.src] = node_file[x.dst] = f;
+        if (x.len_src - x.offset < min_ovl_simplify) continue; /* SG/OverlapGraphSimple.cpp:589 */
+        PEdge p;
+        p.a = (uint32_t)x.src;
+        p.b = (uint32_t)x.dst;
+        p.offset = x.offset;
+        p.orient = (uint8_t)x.orient;
+        g.e.push_back(std::move(p));
+    }
+    ParSimpleStats st{};
+    st.edges_in = g.e.size();
+    /* thresholds of the stand-alone parsimplify (it reads no cfg: the compiled defaults, SG/Config.cpp:43-44) */
+    const size_t kMinReads = 5;
+    const uint32_t kMinLength = 500;
+    /* The reference's first, parallel contraction round copies the two edges of the node it starts a chain from with a copy
+     * constructor that leaves BOTH read lengths uninitialised (SG/EdgeSimple.cpp:50-79; the chain starts at its smallest absorbable
+     * node, SG/OverlapGraphSimple.cpp:339-346,468-480): an end of the chain that is adjacent to that node then carries a garbage
+     * length — zero on a fresh heap — into the edge length its dead-end test compares with 500 bp. This implementation uses the
+     * true lengths. DISCO_PARSIMPLE_EMULATE_UNINIT=1 reproduces the reference's zero instead, which is how tests/test_host.py shows
+     * that this is the ONLY difference between the two. */
+    const bool emulate_uninit = getenv("DISCO_PARSIMPLE_EMULATE_UNINIT") != nullptr;
+
+    std::vector<uint64_t> start; /* CSR over half-edges by source */
+    std::vector<uint64_t> half;
+    auto build_csr = [&]() {
+        start.assign(n + 1, 0);
+        for (const PEdge &x : g.e) {
+            start[x.a + 1]++;
+            start[x.b + 1]++;
+        }
+        for (uint64_t v = 0; v < n; v++) start[v + 1] += start[v];
+        half.resize(2 * g.e.size());
+        std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+        for (uint64_t i = 0; i < g.e.size(); i++) {
+            half[cur[g.e[i].a]++] = 2 * i;
+            half[cur[g.e[i].b]++] = 2 * i + 1;
+        }
+    };
+    auto deg = [&](uint32_t v) { return start[v + 1] - start[v]; };
+
+    for (;;) {
+        st.rounds++;
+        /* ---- contraction (contractParCompositeEdges + _Serial, SG/OverlapGraphSimple.cpp:69-109,313-500): a node with exactly two
+         * edges that leave it from opposite ends (is_mergeable, SG/EdgeSimple.cpp:254-270), neither of them a loop, is absorbed;
+         * every maximal chain of such nodes becomes ONE composite edge between its two other nodes ------------------------------- */
+        build_csr();
+        std::vector<uint8_t> internal(n, 0);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (uint64_t v = 0; v < n; v++) {
+            if (deg((uint32_t)v) != 2) continue;
+            const uint64_t h0 = half[start[v]], h1 = half[start[v] + 1];
+            if ((h0 >> 1) == (h1 >> 1)) continue; /* the two ends of one loop edge */
+            if (g.e[h0 >> 1].a == g.e[h0 >> 1].b || g.e[h1 >> 1].a == g.e[h1 >> 1].b) continue;
+            /* "all three nodes must be marked" (SG/OverlapGraphSimple.cpp:87,358-360): marked = all of the node's edges are in this file */
+            if (marked && !(marked[v] && marked[g.dst(h0)] && marked[g.dst(h1)])) continue;
+            if (((g.orient(h0) >> 1) & 1) != ((g.orient(h1) >> 1) & 1)) internal[v] = 1;
+        }
+        std::vector<uint8_t> dead_edge(g.e.size(), 0), seen(n, 0);
+        std::vector<PEdge> fresh;
+        uint64_t merged = 0;
+        auto walk = [&](uint64_t h, PEdge &out, uint64_t &last_half) { /* from a non-internal (or anchor) node through internal ones */
+            out.a = g.src(h);
+            out.links.clear();
+            uint64_t cur = h;
+            for (;;) {
+                g.append_links(cur, out.links);
+                const uint32_t v = g.dst(cur);
+                if (!internal[v] || v == out.a) break;
+                const uint64_t h0 = half[start[v]], h1 = half[start[v] + 1];
+                cur = ((h0 ^ 1) == cur) ? h1 : h0; /* the half-edge of v that is not the way back */
+            }
+            last_half = cur;
+            out.b = g.dst(cur);
+            out.offset = 0;
+            for (const Link &l : out.links) out.offset += l.offset;
+            out.orient = (uint8_t)((out.links.front().orient & 2) | (out.links.back().orient & 1));
+            out.unknown_len = (uint8_t)((g.src_len_unknown(h) ? 1 : 0) | (g.dst_len_unknown(cur) ? 2 : 0)); /* what Add() hands on */
+            if (emulate_uninit && st.rounds == 1) {
+                /* internal nodes of the chain = the link targets but the last; the smallest one is where the reference starts */
+                const size_t k = out.links.size() - 1;
+                size_t at = 0;
+                for (size_t i = 1; i < k; i++)
+                    if (out.links[i].to < out.links[at].to) at = i;
+                if (at == 0) out.unknown_len |= 1;
+                if (at + 1 == k) out.unknown_len |= 2;
+            }
+        };
+#pragma omp parallel num_threads(threads)
+        {
+            std::vector<PEdge> mine;
+            uint64_t my_merged = 0;
+#pragma omp for schedule(dynamic, 4096)
+            for (uint64_t v = 0; v < n; v++) {
+                if (internal[v]) continue;
+                for (uint64_t q = start[v]; q < start[v + 1]; q++) {
+                    const uint64_t h = half[q];
+                    if (!internal[g.dst(h)]) continue;
+                    PEdge c;
+                    uint64_t last;
+                    walk(h, c, last);
+                    if (h > (last ^ 1)) continue; /* the same chain walked from its other end */
+                    uint64_t cur = h; /* retire what the chain is made of */
+                    for (;;) {
+                        dead_edge[cur >> 1] = 1;
+                        const uint32_t x = g.dst(cur);
+                        if (!internal[x] || x == c.a) break;
+                        seen[x] = 1;
+                        const uint64_t h0 = half[start[x]], h1 = half[start[x] + 1];
+                        cur = ((h0 ^ 1) == cur) ? h1 : h0;
+                        my_merged++;
+                    }
+                    mine.push_back(std::move(c));
+                }
+            }
+#pragma omp critical
+            {
+                merged += my_merged;
+                for (PEdge &c : mine) fresh.push_back(std::move(c));
+            }
+        }
+        /* rings made of absorbable nodes only: the reference's sweep in ascending id leaves the largest id holding a loop */
+        for (uint64_t v = n; v-- > 0;) {
+            if (!internal[v] || seen[v]) continue;
+            internal[v] = 0; /* anchor */
+            PEdge c;
+            uint64_t last;
+            walk(half[start[v]], c, last);
+            uint64_t cur = half[start[v]];
+            for (;;) {
+                dead_edge[cur >> 1] = 1;
+                const uint32_t x = g.dst(cur);
+                if (x == (uint32_t)v) break;
+                seen[x] = 1;
+                const uint64_t h0 = half[start[x]], h1 = half[start[x] + 1];
+                cur = ((h0 ^ 1) == cur) ? h1 : h0;
+                merged++;
+            }
+            seen[v] = 1;
+            fresh.push_back(std::move(c));
+        }
+        if (merged) {
+            std::vector<PEdge> next;
+            next.reserve(g.e.size() - merged + fresh.size());
+            for (uint64_t i = 0; i < g.e.size(); i++)
+                if (!dead_edge[i]) next.push_back(std::move(g.e[i]));
+            for (PEdge &c : fresh) next.push_back(std::move(c));
+            g.e.swap(next);
+            st.nodes_absorbed += merged;
+        }
+        /* ---- dead ends (removeParDeadEndNodes, SG/OverlapGraphSimple.cpp:136-221): a node all of whose edges are weak — fewer than
+         * 5 reads inside, shorter than 500 bp, not a loop — and all enter it or all leave it loses its edges ------------------------ */
+        build_csr();
+        std::vector<uint8_t> dead_node(n, 0);
+        uint64_t n_dead = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_dead) num_threads(threads)
+        for (uint64_t v = 0; v < n; v++) {
+            if (start[v + 1] == start[v] || (marked && !marked[v])) continue;
+            bool weak = true;
+            uint64_t in = 0, out = 0;
+            for (uint64_t q = start[v]; q < start[v + 1] && weak; q++) {
+                const uint64_t h = half[q];
+                const PEdge &x = g.e[h >> 1];
+                const uint32_t dlen = g.dst_len_unknown(h) ? 0u : g.len[g.dst(h)];
+                if ((marked && !marked[g.dst(h)]) || x.links.size() >= kMinReads + 1 || g.offset(h) + dlen >= kMinLength || x.a == x.b) weak = false;
+                else if ((g.orient(h) >> 1) & 1) out++;
+                else in++;
+            }
+            if (weak && in * out == 0 && in + out > 0) {
+                dead_node[v] = 1;
+                n_dead++;
+            }
+        }
+        uint64_t removed = 0;
+        if (n_dead) {
+            std::vector<PEdge> next;
+            next.reserve(g.e.size());
+            for (PEdge &x : g.e) {
+                if (dead_node[x.a] || dead_node[x.b]) removed++;
+                else next.push_back(std::move(x));
+            }
+            g.e.swap(next);
+            st.dead_end_nodes += n_dead;
+            st.dead_end_edges += removed;
+        }
+        if (!merged && !removed) break;
+    }
+    st.edges_out = g.e.size();
+    if (stats) *stats = st;
+
+    /* ---- <prefix>_<t>_ParSimpleEdges.txt (printEdge, SG/OverlapGraphSimple.cpp:658-690): the direction with source < destination --- */
+    std::vector<std::vector<uint64_t>> by_file((size_t)n_files);
+    for (uint64_t i = 0; i < g.e.size(); i++) by_file[node_file[g.e[i].a]].push_back(i);
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(threads, n_files))
+    for (int t = 0; t < n_files; t++) {
+        std::vector<uint64_t> &ids = by_file[(size_t)t];
+        auto key = [&](uint64_t i) {
+            const PEdge &x = g.e[i];
+            return std::make_pair(std::min(x.a, x.b), std::max(x.a, x.b));
+        };
+        std::sort(ids.begin(), ids.end(), [&](uint64_t p, uint64_t q) {
+            const auto kp = key(p), kq = key(q);
+            if (kp != kq) return kp < kq;
+            const PEdge &x = g.e[p], &y = g.e[q]; /* parallel edges between the same two nodes: by content, not by the order the threads made them */
+            if (x.offset != y.offset) return x.offset < y.offset;
+            if (x.links.size() != y.links.size()) return x.links.size() < y.links.size();
+            return x.orient < y.orient;
+        });
+        const std::string path = (paths && (size_t)t < paths->size()) ? (*paths)[(size_t)t]
+                                 : prefix + "_" + ((tags && (size_t)t < tags->tag.size()) ? tags->tag[(size_t)t] : std::to_string(t)) + "_ParSimpleEdges.txt";
+        FILE *f = fopen(path.c_str(), "wb");
+        bool good = f != nullptr;
+        std::string line;
+        std::vector<Link> links;
+        char buf[96];
+        for (size_t k = 0; good && k < ids.size(); k++) {
+            const PEdge &x = g.e[ids[k]];
+            const uint64_t h = 2 * ids[k] + (x.a <= x.b ? 0 : 1);
+            links.clear();
+            g.append_links(h, links);
+            const uint32_t s = g.src(h), d = g.dst(h), off = g.offset(h);
+            snprintf(buf, sizeof buf, "%llu\t%llu\t%u,%u,%u,0,0\t", (unsigned long long)rs.file_index[s], (unsigned long long)rs.file_index[d], (unsigned)g.orient(h), off,
+                     off + (g.dst_len_unknown(h) ? 0u : g.len[d]));
+            line.assign(buf);
+            /* inner reads: the common node of consecutive links with the orientation bit and the offset of the link INTO it
+             * (mergeList, SG/EdgeSimple.cpp:214-246) */
+            for (size_t i = 0; i + 1 < links.size(); i++) {
+                snprintf(buf, sizeof buf, "(%llu,%u,%u)", (unsigned long long)rs.file_index[links[i].to], (unsigned)(links[i].orient & 1), links[i].offset);
+                line += buf;
+            }
+            line += '\n';
+            good = fwrite(line.data(), 1, line.size(), f) == line.size();
+        }
+        if (f) fclose(f);
+        if (!good) {
+#pragma omp critical
+            {
+                ok = false;
+                err = "Unable to write file: " + path;
+            }
+        }
+    }
+    return ok;
+}
+
+} // namespace disco

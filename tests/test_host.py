@@ -313,3 +313,61 @@ def test_read_filter_matches_oracle_on_adversarial_reads(tmp_path):
     assert total == wtotal == len(reads)
     assert np.array_equal(fidx, wfidx) and got == want
     assert 1000 < len(got) < 5000  # both outcomes are well represented
+
+
+def _par_lines(path):
+    """lines of a ParSimpleEdges file without the edge-length column: the reference's parallel contraction copies edges with a
+    copy constructor that leaves both read lengths uninitialised (SG/EdgeSimple.cpp:50-79), so that column is offset + garbage for
+    some composite edges there; fullsimplify never reads it (SG/OverlapGraph.cpp:2028-2094 takes fields 0, 1 and 5)"""
+    out = []
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        info = f[2].split(",")
+        out.append("\t".join(f[:2] + [",".join(info[:2] + info[3:])] + f[3:]))
+    return sorted(out)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref")),
+                    reason="prebuilt reference parsimplify (make -C oracle ref_parsimplify) not present")
+@pytest.mark.parametrize("name", ["u150_5k", "mixed_4k", "k30_6k", "k64_3k", "long_2k", "multifile"])
+@pytest.mark.parametrize("split", [False, True])
+def test_partial_simplification_equals_the_reference_parsimplify(tmp_path, name, split):
+    """disco_amd/bin/parsimplify (= the code behind buildG --par-simple) against the REAL parsimplify on the same
+    edge file: the same set of (composite) edges, inner read lists included. split: a file that owns only the lower half of the
+    nodes, edges to the other half carrying flags 0 / 1 — nodes that are not marked must neither be absorbed nor removed"""
+    build.build_host()
+    src = os.path.join(gu.GOLD, name + ".edges.txt")
+    lines = [l.rstrip("\n") for l in open(src) if l.strip()]
+    ids = sorted({int(x) for l in lines for x in l.split("\t")[:2]})
+    cut = ids[len(ids) // 2]
+    edge_file = tmp_path / "in_parGraph.txt"
+    with open(edge_file, "w") as f:
+        for l in lines:
+            a, b = (int(x) for x in l.split("\t")[:2])
+            if not split:
+                f.write(l + ",2\n")
+            elif a < cut or b < cut:
+                f.write(l + ("," + ("2" if (a < cut and b < cut) else "0" if a < cut else "1")) + "\n")
+    ours, ref = str(tmp_path / "ours.txt"), str(tmp_path / "ref.txt")
+    p = subprocess.run([os.path.join(BIN, "parsimplify"), str(edge_file), ours, "30", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    p = subprocess.run([os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref"), str(edge_file), ref, "30", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout[-2000:]
+    a, b = _par_lines(ours), _par_lines(ref)
+    if a != b:
+        # the one known difference: the reference's dead-end test reads uninitialised read lengths on some composite edges
+        # (parsimple.cpp, DISCO_PARSIMPLE_EMULATE_UNINIT); with that reproduced the two agree again
+        p = subprocess.run([os.path.join(BIN, "parsimplify"), str(edge_file), ours, "30", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, DISCO_PARSIMPLE_EMULATE_UNINIT="1"))
+        assert p.returncode == 0, p.stdout
+        a2 = _par_lines(ours)
+        assert a2 == b
+        assert len(set(a) ^ set(b)) <= max(4, len(b) // 50)
+        return
+    assert len(a) < len(lines)  # something was contracted
+    # the column the reference gets wrong on some lines is offset + length of the destination here
+    for line in open(ours):
+        f = line.split("\t")
+        info = f[2].split(",")
+        assert int(info[2]) > int(info[1])

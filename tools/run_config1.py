@@ -10,7 +10,9 @@ reads from one 0.6 Mbp uniform-random genome (25x; at the 3x of a 4.6 Mbp genome
                                   parsimplify (oracle/_ref, built by oracle/Makefile), whole pipeline to scaffolds
   ours DIR GRAPHDIR (container) : the same directory layout with the drop-in's graph files put where buildG writes them, then
                                   runDisco.sh -osg: the reference's fullsimplify / parsimplify consume the drop-in's files
-  fixture REFDIR OURSDIR        : canonical digests of both graphs + scaffold statistics of both runs -> tests/golden/config1.json
+  ours-simple DIR GRAPHDIR      : as `ours`, with the drop-in's <out>/assembly/disco_<i>_ParSimpleEdges.txt in place too (buildG under
+                                  DISCO_PAR_SIMPLE=1): fullsimplify loads them and never starts parsimplify
+  fixture REFDIR OURSDIR [OURSSIMPLEDIR] : canonical digests of both graphs + scaffold statistics of both runs -> tests/golden/config1.json
 """
 import glob
 import hashlib
@@ -91,8 +93,11 @@ def main():
         sha = write_reads(os.path.join(d, "reads.fasta"))
         open(os.path.join(d, "disco.cfg"), "w").write(f"MinOverlap4BuildGraph = {MIN_OVERLAP}\n")
         log = os.path.join(d, "out", "disco.log")
+        # DISCO_PAR_SIMPLE=1: buildG also leaves <out>/assembly/disco_<i>_ParSimpleEdges.txt — fullsimplify then skips its parsimplify
+        # step (SG/OverlapGraph.cpp:1027-1049); the `ours-simple` run below checks that the pipeline ends in the same scaffold
         rc = subprocess.call([os.path.join(ROOT, "disco_amd", "bin", "buildG"), "-pe", os.path.join(d, "reads.fasta"), "-f", os.path.join(d, "out", "graph", "disco"),
-                              "-p", os.path.join(d, "disco.cfg"), "-t", str(THREADS), "-m", "8"], stdout=open(log, "w"), stderr=subprocess.STDOUT)
+                              "-p", os.path.join(d, "disco.cfg"), "-t", str(THREADS), "-m", "8"], stdout=open(log, "w"), stderr=subprocess.STDOUT,
+                             env=dict(os.environ, DISCO_PAR_SIMPLE="1"))
         print("buildG rc", rc, "reads sha256", sha, graph_digests(os.path.join(d, "out", "graph", "disco")))
         os.remove(os.path.join(d, "reads.fasta"))  # regenerated where it is needed
         sys.exit(rc)
@@ -104,15 +109,24 @@ def main():
         rc = subprocess.call([os.path.join(b, "runDisco.sh"), "-inP", os.path.join(d, "reads.fasta"), "-d", os.path.join(d, "out"), "-n", str(THREADS), "-m", "8"], cwd=d)
         print("runDisco.sh rc", rc, seq_stats(os.path.join(d, "out", "disco_scaffoldsFinalCombined.fasta")))
         sys.exit(rc)
-    if cmd == "ours":
+    if cmd in ("ours", "ours-simple"):
         d, graph = os.path.abspath(sys.argv[2]), os.path.abspath(sys.argv[3])
         os.makedirs(os.path.join(d, "out", "graph"), exist_ok=True)
         write_reads(os.path.join(d, "reads.fasta"))
         for f in glob.glob(os.path.join(graph, "disco_*")):
             shutil.copy(f, os.path.join(d, "out", "graph"))
+        if cmd == "ours-simple":  # the partial simplification the drop-in did on the resident graph, where fullsimplify looks for it
+            os.makedirs(os.path.join(d, "out", "assembly"), exist_ok=True)
+            n = 0
+            for f in glob.glob(os.path.join(os.path.dirname(graph), "assembly", "disco_*_ParSimpleEdges.txt")):
+                shutil.copy(f, os.path.join(d, "out", "assembly"))
+                n += 1
+            assert n == THREADS, n
         b = stage_dir(d, os.path.join(ROOT, "disco_amd", "bin", "buildG"))  # present beside the script, not run: -osg
         rc = subprocess.call([os.path.join(b, "runDisco.sh"), "-inP", os.path.join(d, "reads.fasta"), "-d", os.path.join(d, "out"), "-n", str(THREADS), "-m", "8", "-osg"], cwd=d)
-        print("runDisco.sh -osg rc", rc, seq_stats(os.path.join(d, "out", "disco_scaffoldsFinalCombined.fasta")))
+        log = open(os.path.join(d, "out", "disco.log")).read()
+        print("runDisco.sh -osg rc", rc, seq_stats(os.path.join(d, "out", "disco_scaffoldsFinalCombined.fasta")),
+              "| parsimplify step skipped:", "Partial graphs already exist" in log)
         sys.exit(rc)
     if cmd == "fixture":
         refd, oursd = os.path.abspath(sys.argv[2]), os.path.abspath(sys.argv[3])
@@ -133,6 +147,9 @@ def main():
               "graph_reference": g_ref, "graph_drop_in": g_ours,
               "scaffolds_reference": seq_stats(os.path.join(refd, "out", "disco_scaffoldsFinalCombined.fasta")),
               "scaffolds_drop_in": seq_stats(os.path.join(oursd, "out", "disco_scaffoldsFinalCombined.fasta")),
+              **({"scaffolds_drop_in_with_its_own_partial_simplification": seq_stats(os.path.join(os.path.abspath(sys.argv[4]), "out", "disco_scaffoldsFinalCombined.fasta")),
+                  "scaffold_sequences_identical": open(os.path.join(os.path.abspath(sys.argv[4]), "out", "disco_scaffoldsFinalCombined.fasta")).read().split("\n", 1)[1:] ==
+                  open(os.path.join(refd, "out", "disco_scaffoldsFinalCombined.fasta")).read().split("\n", 1)[1:]} if len(sys.argv) > 4 else {}),
               "how": "tools/run_config1.py: ref = runDisco.sh with the real buildG / fullsimplify / parsimplify; drop-in = disco_amd/bin/buildG on the MI355X "
                      "(the command runDisco.sh:200 issues) + runDisco.sh -osg with the real fullsimplify / parsimplify on its files"}
         json.dump(fx, open(os.path.join(ROOT, "tests", "golden", "config1.json"), "w"), indent=1, sort_keys=True)
