@@ -24,7 +24,6 @@ struct PEdge {
     uint32_t a, b;             /* stored direction a -> b                                                         */
     uint32_t offset;           /* sum of the links' offsets                                                       */
     uint8_t orient;            /* (first link & 2) | (last link & 1): mergedEdgeOrientation, SG/EdgeSimple.cpp:272 */
-    uint8_t unknown_len = 0;   /* DISCO_PARSIMPLE_EMULATE_UNINIT only — bit 0 / 1: the reference would hold an uninitialised length for a / b */
     std::vector<Link> links;   /* empty: a simple edge (one implicit link a -> b with orient / offset)            */
 };
 
@@ -38,8 +37,6 @@ struct Graph {
     uint32_t dst(uint64_t h) const { return (h & 1) ? e[h >> 1].a : e[h >> 1].b; }
     uint8_t orient(uint64_t h) const { return (h & 1) ? twin(e[h >> 1].orient) : e[h >> 1].orient; }
     /* reverse offset: dstLen + offset - srcLen (make_nonComposite_reverseEdge, SG/EdgeSimple.cpp:119-120; telescopes for composites) */
-    bool dst_len_unknown(uint64_t h) const { return (e[h >> 1].unknown_len >> ((h & 1) ? 0 : 1)) & 1; }
-    bool src_len_unknown(uint64_t h) const { return (e[h >> 1].unknown_len >> ((h & 1) ? 1 : 0)) & 1; }
     uint32_t offset(uint64_t h) const
     {
         const PEdge &x = e[h >> 1];
@@ -96,13 +93,10 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
     /* thresholds of the stand-alone parsimplify (it reads no cfg: the compiled defaults, SG/Config.cpp:43-44) */
     const size_t kMinReads = 5;
     const uint32_t kMinLength = 500;
-    /* The reference's first, parallel contraction round copies the two edges of the node it starts a chain from with a copy
-     * constructor that leaves BOTH read lengths uninitialised (SG/EdgeSimple.cpp:50-79; the chain starts at its smallest absorbable
-     * node, SG/OverlapGraphSimple.cpp:339-346,468-480): an end of the chain that is adjacent to that node then carries a garbage
-     * length — zero on a fresh heap — into the edge length its dead-end test compares with 500 bp. This implementation uses the
-     * true lengths. DISCO_PARSIMPLE_EMULATE_UNINIT=1 reproduces the reference's zero instead, which is how tests/test_host.py shows
-     * that this is the ONLY difference between the two. */
-    const bool emulate_uninit = getenv("DISCO_PARSIMPLE_EMULATE_UNINIT") != nullptr;
+    /* NB the stock reference executable is not deterministic here: EdgeSimple::copyEdge (SG/EdgeSimple.cpp:50-71) copies every member
+     * but the two read lengths, so the composite edges its parallel contraction round builds from copies carry uninitialised
+     * lengths into this test (2 M-edge file: 571 of 6 000 output lines differ between its -t 1 and -t 8 runs). With that one
+     * defect repaired (oracle/Makefile: parsimplify_ref_initlen) it writes exactly the lines this function writes. */
 
     std::vector<uint64_t> start; /* CSR over half-edges by source */
     std::vector<uint64_t> half;
@@ -158,16 +152,6 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             out.offset = 0;
             for (const Link &l : out.links) out.offset += l.offset;
             out.orient = (uint8_t)((out.links.front().orient & 2) | (out.links.back().orient & 1));
-            out.unknown_len = (uint8_t)((g.src_len_unknown(h) ? 1 : 0) | (g.dst_len_unknown(cur) ? 2 : 0)); /* what Add() hands on */
-            if (emulate_uninit && st.rounds == 1) {
-                /* internal nodes of the chain = the link targets but the last; the smallest one is where the reference starts */
-                const size_t k = out.links.size() - 1;
-                size_t at = 0;
-                for (size_t i = 1; i < k; i++)
-                    if (out.links[i].to < out.links[at].to) at = i;
-                if (at == 0) out.unknown_len |= 1;
-                if (at + 1 == k) out.unknown_len |= 2;
-            }
         };
 #pragma omp parallel num_threads(threads)
         {
@@ -244,8 +228,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             for (uint64_t q = start[v]; q < start[v + 1] && weak; q++) {
                 const uint64_t h = half[q];
                 const PEdge &x = g.e[h >> 1];
-                const uint32_t dlen = g.dst_len_unknown(h) ? 0u : g.len[g.dst(h)];
-                if ((marked && !marked[g.dst(h)]) || x.links.size() >= kMinReads + 1 || g.offset(h) + dlen >= kMinLength || x.a == x.b) weak = false;
+                if ((marked && !marked[g.dst(h)]) || x.links.size() >= kMinReads + 1 || g.offset(h) + g.len[g.dst(h)] >= kMinLength || x.a == x.b) weak = false;
                 else if ((g.orient(h) >> 1) & 1) out++;
                 else in++;
             }
@@ -304,7 +287,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             g.append_links(h, links);
             const uint32_t s = g.src(h), d = g.dst(h), off = g.offset(h);
             snprintf(buf, sizeof buf, "%llu\t%llu\t%u,%u,%u,0,0\t", (unsigned long long)rs.file_index[s], (unsigned long long)rs.file_index[d], (unsigned)g.orient(h), off,
-                     off + (g.dst_len_unknown(h) ? 0u : g.len[d]));
+                     off + g.len[d]);
             line.assign(buf);
             /* inner reads: the common node of consecutive links with the orientation bit and the offset of the link INTO it
              * (mergeList, SG/EdgeSimple.cpp:214-246) */

@@ -315,26 +315,36 @@ def test_read_filter_matches_oracle_on_adversarial_reads(tmp_path):
     assert 1000 < len(got) < 5000  # both outcomes are well represented
 
 
-def _par_lines(path):
-    """lines of a ParSimpleEdges file without the edge-length column: the reference's parallel contraction copies edges with a
-    copy constructor that leaves both read lengths uninitialised (SG/EdgeSimple.cpp:50-79), so that column is offset + garbage for
-    some composite edges there; fullsimplify never reads it (SG/OverlapGraph.cpp:2028-2094 takes fields 0, 1 and 5)"""
+REF_PS = os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref")
+REF_PS_INITLEN = REF_PS + "_initlen"  # the reference with EdgeSimple::copyEdge copying the two read lengths too (oracle/Makefile)
+
+
+def _par_lines(path, drop_length=False):
+    """sorted lines of a ParSimpleEdges file; drop_length: without the edge-length column (offset + length of the destination),
+    which the STOCK reference fills from uninitialised members on some composite edges (SG/EdgeSimple.cpp:50-71); fullsimplify never
+    reads that column (SG/OverlapGraph.cpp:2028-2094 takes fields 0, 1 and 5)"""
     out = []
     for line in open(path):
         f = line.rstrip("\n").split("\t")
         info = f[2].split(",")
-        out.append("\t".join(f[:2] + [",".join(info[:2] + info[3:])] + f[3:]))
+        out.append("\t".join(f[:2] + [",".join(info[:2] + info[3:]) if drop_length else f[2]] + f[3:]))
     return sorted(out)
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref")),
-                    reason="prebuilt reference parsimplify (make -C oracle ref_parsimplify) not present")
+def _run_ps(exe, edge_file, out, min_ovl, threads):
+    p = subprocess.run([exe, str(edge_file), out, str(min_ovl), str(threads)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout[-2000:]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PS_INITLEN), reason="prebuilt reference parsimplify (make -C oracle ref_parsimplify) not present")
 @pytest.mark.parametrize("name", ["u150_5k", "mixed_4k", "k30_6k", "k64_3k", "long_2k", "multifile"])
 @pytest.mark.parametrize("split", [False, True])
 def test_partial_simplification_equals_the_reference_parsimplify(tmp_path, name, split):
     """disco_amd/bin/parsimplify (= the code behind buildG --par-simple) against the REAL parsimplify on the same
-    edge file: the same set of (composite) edges, inner read lists included. split: a file that owns only the lower half of the
-    nodes, edges to the other half carrying flags 0 / 1 — nodes that are not marked must neither be absorbed nor removed"""
+    edge file: the same lines — every (composite) edge, inner read lists and lengths included. split: a file that owns only the
+    lower half of the nodes, edges to the other half carrying flags 0 / 1 — nodes that are not marked must neither be absorbed
+    nor removed. The comparator is the reference with its uninitialised-length defect repaired (deterministic); the stock binary
+    must agree too up to the lines that defect decides."""
     build.build_host()
     src = os.path.join(gu.GOLD, name + ".edges.txt")
     lines = [l.rstrip("\n") for l in open(src) if l.strip()]
@@ -348,26 +358,69 @@ def test_partial_simplification_equals_the_reference_parsimplify(tmp_path, name,
                 f.write(l + ",2\n")
             elif a < cut or b < cut:
                 f.write(l + ("," + ("2" if (a < cut and b < cut) else "0" if a < cut else "1")) + "\n")
-    ours, ref = str(tmp_path / "ours.txt"), str(tmp_path / "ref.txt")
-    p = subprocess.run([os.path.join(BIN, "parsimplify"), str(edge_file), ours, "30", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert p.returncode == 0, p.stdout
-    p = subprocess.run([os.path.join(os.path.dirname(refrun.REF_BIN), "parsimplify_ref"), str(edge_file), ref, "30", "1"], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True)
-    assert p.returncode == 0, p.stdout[-2000:]
+    ours, ref, stock = str(tmp_path / "ours.txt"), str(tmp_path / "ref.txt"), str(tmp_path / "stock.txt")
+    _run_ps(os.path.join(BIN, "parsimplify"), edge_file, ours, 30, 4)
+    _run_ps(REF_PS_INITLEN, edge_file, ref, 30, 2)
     a, b = _par_lines(ours), _par_lines(ref)
-    if a != b:
-        # the one known difference: the reference's dead-end test reads uninitialised read lengths on some composite edges
-        # (parsimple.cpp, DISCO_PARSIMPLE_EMULATE_UNINIT); with that reproduced the two agree again
-        p = subprocess.run([os.path.join(BIN, "parsimplify"), str(edge_file), ours, "30", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                           env=dict(os.environ, DISCO_PARSIMPLE_EMULATE_UNINIT="1"))
-        assert p.returncode == 0, p.stdout
-        a2 = _par_lines(ours)
-        assert a2 == b
-        assert len(set(a) ^ set(b)) <= max(4, len(b) // 50)
-        return
+    assert a == b
     assert len(a) < len(lines)  # something was contracted
-    # the column the reference gets wrong on some lines is offset + length of the destination here
-    for line in open(ours):
-        f = line.split("\t")
-        info = f[2].split(",")
-        assert int(info[2]) > int(info[1])
+    _run_ps(REF_PS, edge_file, stock, 30, 1)
+    s1, a1 = _par_lines(stock, True), _par_lines(ours, True)
+    assert len(set(s1) ^ set(a1)) <= max(4, len(a1) // 50)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_PS_INITLEN), reason="prebuilt reference parsimplify (make -C oracle ref_parsimplify) not present")
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_buildg_par_simple_equals_parsimplify_on_its_edge_files(tmp_path, gpus):
+    """buildG --par-simple: the files fullsimplify would otherwise make by running parsimplify on every edge file — written from
+    the edges while they are in memory. Each must hold the same (composite) edges as the REAL parsimplify run on the edge file of
+    the same run."""
+    from disco_amd import readgen
+
+    build.build_host()
+    spec = readgen.GenSpec.coverage(seed=5, n_reads=30000, read_len=110, cov=20.0, n_contigs=6, len_max=190)
+    fa = str(tmp_path / "r.fasta")
+    readgen.write_fasta(fa, readgen.generate_reads(spec))
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\nMinOverlap4SimplifyGraph = 40\n")
+    os.makedirs(tmp_path / "graph")
+    prefix = str(tmp_path / "graph" / "asm")
+    cmd = [os.path.join(BIN, "buildG"), "-se", fa, "-f", prefix, "-p", str(cfg), "-t", "3"] + (["--gpus", str(gpus), "--same-device"] if gpus > 1 else [])
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_PAR_SIMPLE="1"))
+    assert p.returncode == 0 and "Partial simplification" in p.stdout, p.stdout
+    total = 0
+    for t in range(3):
+        mine = str(tmp_path / "assembly" / f"asm_{t}_ParSimpleEdges.txt")  # runDisco.sh's layout: <out>/graph/<name> -> <out>/assembly/<name>
+        assert os.path.exists(mine)
+        ref = str(tmp_path / f"ref_{t}.txt")
+        _run_ps(REF_PS_INITLEN, f"{prefix}_{t}_parGraph.txt", ref, 40, 2)
+        a, b = _par_lines(mine), _par_lines(ref)
+        assert a == b, (t, len(a), len(b))
+        total += len(a)
+    assert 0 < total < 3000  # 6 contigs, mixed lengths: a few hundred composite edges, not 25 000 simple ones
+
+
+@pytest.mark.gpu
+def test_buildg_par_simple_at_scale_equals_the_reference(tmp_path):
+    """10 M metagenome-like reads (BASELINE config 5's generator settings): the partial simplification buildG leaves beside its
+    graph must hash like the output of the REAL parsimplify (length defect repaired, oracle/Makefile) on the edge file the REAL
+    buildG wrote for the same reads — both halves of that reference run were done once in the build container
+    (tests/golden/cases_big.json: s100_250_10m)."""
+    import hashlib
+    import json
+
+    build.build_host()
+    c = json.load(open(os.path.join(gu.GOLD, "cases_big.json")))["s100_250_10m"]
+    fa = str(tmp_path / "r.fasta")
+    subprocess.run([os.path.join(BIN, "readgen"), fa, str(c["reads"]), str(c["read_len"]), repr(float(c["coverage"])), str(c["seed"]), str(c["len_max"]), "583333", "1"],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\nMinOverlap4SimplifyGraph = 30\n")
+    os.makedirs(tmp_path / "graph")
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-se", fa, "-f", str(tmp_path / "graph" / "x"), "-p", str(cfg), "-t", "1", "--no-text"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_PAR_SIMPLE="1"))
+    assert p.returncode == 0, p.stdout[-2000:]
+    lines = sorted(open(tmp_path / "assembly" / "x_0_ParSimpleEdges.txt").read().splitlines())
+    assert len(lines) == c["par_simple_lines"]
+    assert hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest() == c["par_simple_sha256"]
