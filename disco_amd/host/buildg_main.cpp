@@ -382,11 +382,21 @@ int main(int argc, char **argv)
     }
     if (par_simple.empty() && getenv("DISCO_PAR_SIMPLE")) { /* runDisco.sh:166-167: <out>/graph/<name> and <out>/assembly/<name> */
         const size_t at = prefix.rfind("/graph/");
+        std::string base, name;
+        bool found = false;
         if (at != std::string::npos) {
-            par_simple = prefix.substr(0, at) + "/assembly/" + prefix.substr(at + 7);
-            const std::string dir = prefix.substr(0, at) + "/assembly";
-            (void)mkdir(dir.c_str(), 0777); /* runDisco.sh keeps an existing assembly directory ("Will continue previous run") */
+            base = prefix.substr(0, at + 1);
+            name = prefix.substr(at + 7);
+            found = true;
+        } else if (prefix.compare(0, 6, "graph/") == 0) { /* relative to the output directory itself */
+            name = prefix.substr(6);
+            found = true;
         }
+        if (found) {
+            par_simple = base + "assembly/" + name;
+            (void)mkdir((base + "assembly").c_str(), 0777); /* runDisco.sh keeps an existing assembly directory ("Will continue previous run") */
+        } else
+            std::cout << "DISCO_PAR_SIMPLE: the output prefix is not <out>/graph/<name>; use --par-simple <prefix>" << std::endl;
     }
     if (!par_simple.empty() && !mpi_names) {
         disco::ParSimpleStats ps;

@@ -90,6 +90,13 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
     }
     ParSimpleStats st{};
     st.edges_in = g.e.size();
+    const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
+    double t_last = omp_get_wtime();
+    auto lap = [&](const char *what) {
+        if (verbose) fprintf(stderr, "[disco host]   parsimple %-24s %.3f s\n", what, omp_get_wtime() - t_last);
+        t_last = omp_get_wtime();
+    };
+    lap("load");
     /* thresholds of the stand-alone parsimplify (it reads no cfg: the compiled defaults, SG/Config.cpp:43-44) */
     const size_t kMinReads = 5;
     const uint32_t kMinLength = 500;
@@ -100,19 +107,26 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
 
     std::vector<uint64_t> start; /* CSR over half-edges by source */
     std::vector<uint64_t> half;
+    std::vector<uint32_t> cnt;
     auto build_csr = [&]() {
-        start.assign(n + 1, 0);
-        for (const PEdge &x : g.e) {
-            start[x.a + 1]++;
-            start[x.b + 1]++;
+        const uint64_t ne = g.e.size();
+        cnt.assign(n, 0);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (uint64_t i = 0; i < ne; i++) {
+            __atomic_fetch_add(&cnt[g.e[i].a], 1u, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&cnt[g.e[i].b], 1u, __ATOMIC_RELAXED);
         }
-        for (uint64_t v = 0; v < n; v++) start[v + 1] += start[v];
-        half.resize(2 * g.e.size());
-        std::vector<uint64_t> cur(start.begin(), start.end() - 1);
-        for (uint64_t i = 0; i < g.e.size(); i++) {
-            half[cur[g.e[i].a]++] = 2 * i;
-            half[cur[g.e[i].b]++] = 2 * i + 1;
+        start.resize(n + 1);
+        start[0] = 0;
+        for (uint64_t v = 0; v < n; v++) start[v + 1] = start[v] + cnt[v];
+        half.resize(2 * ne);
+        std::fill(cnt.begin(), cnt.end(), 0u);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (uint64_t i = 0; i < ne; i++) {
+            half[start[g.e[i].a] + __atomic_fetch_add(&cnt[g.e[i].a], 1u, __ATOMIC_RELAXED)] = 2 * i;
+            half[start[g.e[i].b] + __atomic_fetch_add(&cnt[g.e[i].b], 1u, __ATOMIC_RELAXED)] = 2 * i + 1;
         }
+        /* the order of a node's half-edges decides nothing below (a node's two half-edges are told apart by "not the way back") */
     };
     auto deg = [&](uint32_t v) { return start[v + 1] - start[v]; };
 
@@ -122,6 +136,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
          * edges that leave it from opposite ends (is_mergeable, SG/EdgeSimple.cpp:254-270), neither of them a loop, is absorbed;
          * every maximal chain of such nodes becomes ONE composite edge between its two other nodes ------------------------------- */
         build_csr();
+        lap("csr");
         std::vector<uint8_t> internal(n, 0);
 #pragma omp parallel for schedule(static) num_threads(threads)
         for (uint64_t v = 0; v < n; v++) {
@@ -136,14 +151,17 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
         std::vector<uint8_t> dead_edge(g.e.size(), 0), seen(n, 0);
         std::vector<PEdge> fresh;
         uint64_t merged = 0;
-        auto walk = [&](uint64_t h, PEdge &out, uint64_t &last_half) { /* from a non-internal (or anchor) node through internal ones */
+        auto walk = [&](uint64_t h, PEdge &out, uint64_t &last_half, bool retire) { /* from a non-internal (or anchor) node through internal ones */
             out.a = g.src(h);
             out.links.clear();
+            out.links.reserve(64);
             uint64_t cur = h;
             for (;;) {
                 g.append_links(cur, out.links);
+                if (retire) dead_edge[cur >> 1] = 1;
                 const uint32_t v = g.dst(cur);
                 if (!internal[v] || v == out.a) break;
+                if (retire) seen[v] = 1;
                 const uint64_t h0 = half[start[v]], h1 = half[start[v] + 1];
                 cur = ((h0 ^ 1) == cur) ? h1 : h0; /* the half-edge of v that is not the way back */
             }
@@ -163,20 +181,17 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
                 for (uint64_t q = start[v]; q < start[v + 1]; q++) {
                     const uint64_t h = half[q];
                     if (!internal[g.dst(h)]) continue;
-                    PEdge c;
-                    uint64_t last;
-                    walk(h, c, last);
-                    if (h > (last ^ 1)) continue; /* the same chain walked from its other end */
-                    uint64_t cur = h; /* retire what the chain is made of */
+                    uint64_t last = h; /* follow the chain to its other end first: each chain is found from both ends, built from one */
                     for (;;) {
-                        dead_edge[cur >> 1] = 1;
-                        const uint32_t x = g.dst(cur);
-                        if (!internal[x] || x == c.a) break;
-                        seen[x] = 1;
+                        const uint32_t x = g.dst(last);
+                        if (!internal[x] || x == (uint32_t)v) break;
                         const uint64_t h0 = half[start[x]], h1 = half[start[x] + 1];
-                        cur = ((h0 ^ 1) == cur) ? h1 : h0;
-                        my_merged++;
+                        last = ((h0 ^ 1) == last) ? h1 : h0;
                     }
+                    if (h > (last ^ 1)) continue; /* the walk from the other end builds it */
+                    PEdge c;
+                    walk(h, c, last, true); /* builds the composite and retires what the chain is made of */
+                    my_merged += c.links.size() - 1;
                     mine.push_back(std::move(c));
                 }
             }
@@ -186,23 +201,15 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
                 for (PEdge &c : mine) fresh.push_back(std::move(c));
             }
         }
+        lap("chains");
         /* rings made of absorbable nodes only: the reference's sweep in ascending id leaves the largest id holding a loop */
         for (uint64_t v = n; v-- > 0;) {
             if (!internal[v] || seen[v]) continue;
             internal[v] = 0; /* anchor */
             PEdge c;
             uint64_t last;
-            walk(half[start[v]], c, last);
-            uint64_t cur = half[start[v]];
-            for (;;) {
-                dead_edge[cur >> 1] = 1;
-                const uint32_t x = g.dst(cur);
-                if (x == (uint32_t)v) break;
-                seen[x] = 1;
-                const uint64_t h0 = half[start[x]], h1 = half[start[x] + 1];
-                cur = ((h0 ^ 1) == cur) ? h1 : h0;
-                merged++;
-            }
+            walk(half[start[v]], c, last, true);
+            merged += c.links.size() - 1;
             seen[v] = 1;
             fresh.push_back(std::move(c));
         }
@@ -215,6 +222,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             g.e.swap(next);
             st.nodes_absorbed += merged;
         }
+        lap("rings + rebuild");
         /* ---- dead ends (removeParDeadEndNodes, SG/OverlapGraphSimple.cpp:136-221): a node all of whose edges are weak — fewer than
          * 5 reads inside, shorter than 500 bp, not a loop — and all enter it or all leave it loses its edges ------------------------ */
         build_csr();
@@ -249,6 +257,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             st.dead_end_nodes += n_dead;
             st.dead_end_edges += removed;
         }
+        lap("dead ends");
         if (!merged && !removed) break;
     }
     st.edges_out = g.e.size();
@@ -277,26 +286,42 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
                                  : prefix + "_" + ((tags && (size_t)t < tags->tag.size()) ? tags->tag[(size_t)t] : std::to_string(t)) + "_ParSimpleEdges.txt";
         FILE *f = fopen(path.c_str(), "wb");
         bool good = f != nullptr;
-        std::string line;
         std::vector<Link> links;
-        char buf[96];
+        std::vector<char> text;
+        auto put = [](char *p, uint64_t v) {
+            char tmp[24];
+            int m = 0;
+            do {
+                tmp[m++] = (char)('0' + v % 10);
+                v /= 10;
+            } while (v);
+            while (m) *p++ = tmp[--m];
+            return p;
+        };
         for (size_t k = 0; good && k < ids.size(); k++) {
             const PEdge &x = g.e[ids[k]];
             const uint64_t h = 2 * ids[k] + (x.a <= x.b ? 0 : 1);
             links.clear();
             g.append_links(h, links);
             const uint32_t s = g.src(h), d = g.dst(h), off = g.offset(h);
-            snprintf(buf, sizeof buf, "%llu\t%llu\t%u,%u,%u,0,0\t", (unsigned long long)rs.file_index[s], (unsigned long long)rs.file_index[d], (unsigned)g.orient(h), off,
-                     off + g.len[d]);
-            line.assign(buf);
+            text.resize(160 + links.size() * 36);
+            char *p = text.data();
+            p = put(p, rs.file_index[s]); *p++ = '\t';
+            p = put(p, rs.file_index[d]); *p++ = '\t';
+            p = put(p, g.orient(h)); *p++ = ',';
+            p = put(p, off); *p++ = ',';
+            p = put(p, (uint64_t)off + g.len[d]);
+            memcpy(p, ",0,0\t", 5); p += 5;
             /* inner reads: the common node of consecutive links with the orientation bit and the offset of the link INTO it
              * (mergeList, SG/EdgeSimple.cpp:214-246) */
             for (size_t i = 0; i + 1 < links.size(); i++) {
-                snprintf(buf, sizeof buf, "(%llu,%u,%u)", (unsigned long long)rs.file_index[links[i].to], (unsigned)(links[i].orient & 1), links[i].offset);
-                line += buf;
+                *p++ = '(';
+                p = put(p, rs.file_index[links[i].to]); *p++ = ',';
+                *p++ = (char)('0' + (links[i].orient & 1)); *p++ = ',';
+                p = put(p, links[i].offset); *p++ = ')';
             }
-            line += '\n';
-            good = fwrite(line.data(), 1, line.size(), f) == line.size();
+            *p++ = '\n';
+            good = fwrite(text.data(), 1, (size_t)(p - text.data()), f) == (size_t)(p - text.data());
         }
         if (f) fclose(f);
         if (!good) {
@@ -307,6 +332,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             }
         }
     }
+    lap("write");
     return ok;
 }
 
