@@ -377,10 +377,12 @@ struct ProbeArgs {
 };
 
 #ifndef PROBE_WAVES_PER_SIMD
-#define PROBE_WAVES_PER_SIMD 7
+#define PROBE_WAVES_PER_SIMD 8
 #endif
 /* ROW17: k - m = 16, the window minimum comes from DPP row scans (below); that variant keeps more values in registers and
- * is built for one wave per SIMD fewer (at 7 it spilled 14 registers and ran 48 instead of 40 ms) */
+ * is built for one wave per SIMD fewer. Round 2: 8 / 7 waves per SIMD instead of 7 / 6 — the kernel as it stands now fits 73
+ * registers without spilling (round 1's did not: 14 spilled registers, 48 instead of 40 ms) and the seventh wave hides more of the
+ * bucket and record fetches: 38.9 -> 36.5 ms, A/B in one box (tools/ab_build.py); at 9 / 8 it spills 12 registers (40.4 ms) */
 template <bool BIG, bool LDSROW, bool ROW17>
 __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
 {

@@ -3,7 +3,7 @@
 import collections, csv, glob, json, sys
 src, out = sys.argv[1], sys.argv[2]
 res = collections.defaultdict(dict)
-for d in ("fetch", "write", "sq", "sq2", "tcc"):
+for d in ("fetch", "write", "sq", "sq2", "tcc", "lanes"):
     for f in glob.glob(f"{src}/{d}/*counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         meta = {}
