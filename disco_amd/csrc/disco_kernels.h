@@ -769,8 +769,11 @@ __device__ __forceinline__ u64 uniform_u64(u64 x)
  * holds, one of the two reads is contained). MODE 1 fetches and compares the containment-type candidates only (best[]); the host
  * then fixes the contained flags; MODE 2 skips contained query reads altogether and fetches rows for the overlap-type candidates
  * of the others. Rows fetched: about half instead of all; kmer_hits then counts the compared candidates only (disco_params.flags). */
+#ifndef VERIFY_WAVES_PER_SIMD
+#define VERIFY_WAVES_PER_SIMD 1 /* no register cap beyond what the compiler chooses */
+#endif
 template <int NW, int MODE = 0>
-__global__ void __launch_bounds__(64) verify_kernel(VerifyArgs a)
+__global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(VerifyArgs a)
 {
     /* staged: the candidate rows (one per lane, NW words + zero words behind; odd stride; the last zero word of a lane is
      * the zero word in front of the next lane's row), the read's own row and its reverse complement live in LDS with a
@@ -1356,8 +1359,11 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
     return true;
 }
 
+#ifndef SELECT_WAVES_PER_SIMD
+#define SELECT_WAVES_PER_SIMD 1
+#endif
 template <bool BIG>
-__global__ void __launch_bounds__(64) edge_select_kernel(EdgeSelArgs a)
+__global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(EdgeSelArgs a)
 {
     __shared__ u64 s_h[BIG ? 1 : ES_CAP];
     __shared__ u64 s_t[BIG ? 1 : ES_CAP];

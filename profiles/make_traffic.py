@@ -14,7 +14,7 @@ src, reads = sys.argv[1], int(sys.argv[2])
 pmc = json.load(open(src))
 kern = {}
 for k, v in pmc.items():
-    base = k.split("<")[0]
+    base = k.split("<")[0].strip()
     if base in ("probe_kernel", "verify_kernel", "edge_select_kernel", "transitive_mark_kernel", "index_count_kernel"):
         kern[base] = kern.get(base, 0.0) + (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
 out = {"reads": reads, "gpus": 1, "kernels": kern, "kernels_sha16": bench.kernels_sha16(),
