@@ -51,15 +51,23 @@ for it in range(iters):
         open(cfg, "w").write("MinOverlap4BuildGraph = %d\n" % mo)
         threads = int(rng.choice([1, 2, 5]))
 
+        # the drop-in also as N ranks on the one GPU (in-process exchanges), at random; with and without buildG-MPI's file names
+        extra = []
+        if rng.random() < 0.5:
+            extra = ["--gpus", str(int(rng.integers(2, 5))), "--same-device"] + (["--mpi-names"] if rng.random() < 0.3 else [])
+
         def run(exe, prefix, t):
             cmd = [exe] + (["-pe", ",".join(pe)] if pe else []) + (["-se", ",".join(se)] if se else []) + ["-f", prefix, "-p", cfg, "-t", str(t), "-m", "8"]
+            if exe == MINE:
+                cmd += extra
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             return p.returncode, p.stdout
 
         os.makedirs(os.path.join(d, "ref")); os.makedirs(os.path.join(d, "mine"))
         rc1, log1 = run(refrun.REF_BIN, os.path.join(d, "ref", "g"), 1)
         rc2, log2 = run(MINE, os.path.join(d, "mine", "g"), threads)
-        label = "it%d n=%d len=%d-%d mo=%d cov=%g files=%s t=%d" % (it, n, lmin, lmax, mo, cov, [k + ":" + os.path.basename(f) for f, k in zip(files, kinds)], threads)
+        label = "it%d n=%d len=%d-%d mo=%d cov=%g files=%s t=%d %s" % (it, n, lmin, lmax, mo, cov, [k + ":" + os.path.basename(f) for f, k in zip(files, kinds)], threads,
+                                                                        " ".join(extra))
         try:
             assert rc2 == 0, log2[-500:]
             e1 = refrun.parse_pargraph(sorted(glob.glob(os.path.join(d, "ref", "g_*_parGraph.txt"))))
