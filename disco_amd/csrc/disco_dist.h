@@ -74,6 +74,27 @@ __global__ void __launch_bounds__(256) route_scatter_kernel(const T *__restrict_
     }
 }
 
+/* ---- reads: rows travel at the words they use, not at the 64-byte stride of the table ---------------------------------- */
+/* rows [r0, r0 + nrows) of the S-stride table <-> a dense array of W words per row (W = words of the longest read of the job) */
+__global__ void pack_rows_kernel(const u64 *__restrict__ table, int S, int W, u64 r0, u64 nrows, u64 *__restrict__ dense)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = nrows * (u64)W;
+    for (; i < total; i += (u64)gridDim.x * blockDim.x) dense[i] = table[(r0 + i / W) * S + i % W];
+}
+
+/* all rows but [skip_lo, skip_hi) (the rank's own, already in place); the words beyond W stay zero (the table was cleared once) */
+__global__ void unpack_rows_kernel(const u64 *__restrict__ dense, int S, int W, u64 nrows, u64 skip_lo, u64 skip_hi, u64 *__restrict__ table)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = nrows * (u64)W;
+    for (; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 r = i / W;
+        if (r >= skip_lo && r < skip_hi) continue;
+        table[r * S + i % W] = dense[i];
+    }
+}
+
 /* ---- hash-partitioned index build (the owner's side) ------------------------------------------------------------------ */
 /* records received from all ranks: count per bucket of this rank's range; the atomic hands every record its slot */
 __global__ void shard_count_kernel(ulonglong2 *__restrict__ rec, u64 n, u32 *__restrict__ bkt)

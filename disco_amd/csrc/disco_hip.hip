@@ -188,6 +188,8 @@ struct disco_ctx {
     u32 *d_deg_tmp = nullptr;
     u64 deg_tmp_cap = 0;
     u64 *d_list_n = nullptr; /* length of the flat list being built */
+    u64 *d_dense = nullptr; /* the job's reads at W words per row, for the all-gather (rows of the table are padded to 64 bytes) */
+    u64 dense_cap = 0;
     ulonglong2 *d_push_r = nullptr; /* received half-edge pushes (alias of d_x16b while a pass is in flight) */
     u64 n_push_r = 0;
     disco_dist_info dinfo{};
@@ -426,6 +428,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_rpos, c->rpos_cap);
     dev_free(c, &c->d_nadj32_own, c->nadj_cap);
     dev_free(c, &c->d_deg_tmp, c->deg_tmp_cap);
+    dev_free(c, &c->d_dense, c->dense_cap);
+    c->dense_cap = 0;
     c->x16a_cap = c->x16b_cap = c->req_flat_cap = c->req_s_cap = c->req_r_cap = c->rdeg_s_cap = c->rdeg_r_cap = c->rdata_s_cap = 0;
     c->rpos_cap = c->nadj_cap = c->nadj_used = c->deg_tmp_cap = 0;
     c->d_push_r = nullptr;
@@ -2427,6 +2431,8 @@ static int dist_set_reads(disco_ctx *c, u64 n_total, uint32_t dstride)
     c->q_hi = hi;
     CHK(dev_alloc(c, &c->d_reads, c->n_alloc * (u64)dstride));
     CHK(dev_alloc(c, &c->d_len, c->n_alloc));
+    /* unused words of a row are zero (disco_device.h): the other ranks' rows arrive at their used words only */
+    HIPCHK(c, hipMemsetAsync(c->d_reads, 0, c->n_alloc * (u64)dstride * 8, c->stream));
     c->reads_owned = true;
     c->dist_reads = true;
     return DISCO_OK;
@@ -2510,12 +2516,27 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
         int rc_ = (expr);                                                                                     \
         if (rc_ != DISCO_OK) return fail(c, rc_, "%s: %s", #expr, c->comm_bulk->err.c_str());                 \
     } while (0)
-        BULK_CHK(c->comm_bulk->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, c->bulk_stream));
+        const int W = (int)((c->max_len + 31) / 32); /* words the longest read of the job uses (150 bp: 5 of the 8-word stride) */
+        u64 sent_row_bytes = row_bytes;
+        if (W < c->S && !getenv("DISCO_DIST_FULL_ROWS")) {
+            /* pack the own rows, all-gather the dense array, spread the other ranks' rows back over the table: 37 % fewer bytes
+             * on the links at 150 bp, paid with two streaming passes on the second stream while the index is being built */
+            const u64 total_rows = c->per * (u64)G;
+            CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, total_rows * (u64)W));
+            u64 *mine = c->d_dense + (u64)r * c->per * W;
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(flat_grid(c, c->per * W)), dim3(256), 0, c->bulk_stream, c->d_reads, c->S, W, (u64)r * c->per, c->per, mine);
+            BULK_CHK(c->comm_bulk->all_gather(mine, c->d_dense, c->per * (u64)W * 8, c->bulk_stream));
+            hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, total_rows * W)), dim3(256), 0, c->bulk_stream, c->d_dense, c->S, W, total_rows, (u64)r * c->per,
+                               (u64)(r + 1) * c->per, c->d_reads);
+            HIPCHK(c, hipGetLastError());
+            sent_row_bytes = (u64)W * 8;
+        } else
+            BULK_CHK(c->comm_bulk->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, c->bulk_stream));
         BULK_CHK(c->comm_bulk->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, c->bulk_stream));
 #undef BULK_CHK
         HIPCHK(c, hipEventRecord(c->ev_bulk, c->bulk_stream));
         c->wait_bulk_before_verify = true;
-        di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (row_bytes + 2);
+        di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (sent_row_bytes + 2);
         di.ms[DISCO_X_READS] += ms_since(t0); /* time to ISSUE it (RCCL: asynchronous; in-process transport: the copies themselves) */
     }
     CHK(dist_build_index(c));
