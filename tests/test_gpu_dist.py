@@ -144,3 +144,50 @@ def test_ranks_two_pass_verify_equal_reference(name, G):
     ce, cc = canon_hip(edges, rows, fidx)
     gu.check_against_golden(name, ce, cc)
     assert info["regime"] == 0
+
+
+def test_config4_reads_through_8_ranks_hash_like_the_reference():
+    """BASELINE config 4's data — the 50 M x 150 bp reads of config 3 — through the 8-rank flow (here: 8 contexts on ONE GPU over the
+    in-process transport; RCCL refuses two ranks per device): the union of the ranks' edges and contained rows must hash to the
+    digests of the files the REAL reference wrote for these reads (tests/golden/cases_big.json: u150_50m)."""
+    import json
+    import os
+
+    from oracle import pyoracle
+
+    c = json.load(open(os.path.join(gu.GOLD, "cases_big.json")))["u150_50m"]
+    spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"])
+    e, r, info, infos = run_ranks(8, c["min_overlap"], lambda g: g.dist_generate_reads(spec))
+    assert info["regime"] == 0 and info["asymmetric_pairs"] == 0 and info["cap_bind_sites"] == 0
+    assert (info["e_out"], info["n_contained"]) == (c["n_edges"], c["n_contained"])
+    one = np.int64(1)
+    ce = pyoracle.canonical_edges_large(e["src"].astype(np.int64) + one, e["dst"].astype(np.int64) + one, e["orient"], e["offset"], e["len_src"], e["len_dst"])
+    del e
+    assert pyoracle.digest_array(ce) == c["edges_sha256"]
+    cc = np.stack([r["contained"].astype(np.int64) + one, r["super"].astype(np.int64) + one] + [np.asarray(r[k], dtype=np.int64) for k in ("orient", "len2", "len1", "start")], axis=1)
+    cc = cc[np.lexsort(tuple(cc[:, i] for i in range(5, -1, -1)))]
+    assert pyoracle.digest_array(cc) == c["contained_sha256"]
+    # every exchange of the north-star design moved bytes, none of them the order-dependent regime's
+    sent = {k: sum(i["bytes_sent"][k] for i in infos) for k in infos[0]["bytes_sent"]}
+    assert all(sent[k] > 0 for k in ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push")) and sent["adjacency"] == 0
+
+
+def test_config5_shape_through_8_ranks_equals_reference():
+    """BASELINE config 5's generator settings (metagenome-like, 100-250 bp, 79 % of the reads contained) at the 10 M reads the REAL
+    reference was run on, through 8 ranks with the two-pass verify (the containment exchange between its passes): same digests"""
+    import json
+    import os
+
+    from disco_amd import buildgraph
+    from oracle import pyoracle
+
+    c = json.load(open(os.path.join(gu.GOLD, "cases_big.json")))["s100_250_10m"]
+    spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c["n_contigs"], len_max=c["len_max"], skew=c["skew"])
+    e, r, info, _ = run_ranks(8, c["min_overlap"], lambda g: g.dist_generate_reads(spec), flags=buildgraph.FLAG_TWO_PASS_VERIFY)
+    assert info["regime"] == 0 and (info["e_out"], info["n_contained"]) == (c["n_edges"], c["n_contained"])
+    one = np.int64(1)
+    ce = pyoracle.canonical_edges_large(e["src"].astype(np.int64) + one, e["dst"].astype(np.int64) + one, e["orient"], e["offset"], e["len_src"], e["len_dst"])
+    assert pyoracle.digest_array(ce) == c["edges_sha256"]
+    cc = np.stack([r["contained"].astype(np.int64) + one, r["super"].astype(np.int64) + one] + [np.asarray(r[k], dtype=np.int64) for k in ("orient", "len2", "len1", "start")], axis=1)
+    cc = cc[np.lexsort(tuple(cc[:, i] for i in range(5, -1, -1)))]
+    assert pyoracle.digest_array(cc) == c["contained_sha256"]
