@@ -21,7 +21,7 @@ class DiscoError(RuntimeError):
 
 
 class Params(C.Structure):
-    _fields_ = [("min_overlap", C.c_uint32), ("max_edges_per_kmer", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("min_overlap", C.c_uint32), ("max_edges_per_kmer", C.c_uint32), ("flags", C.c_uint32), ("max_substitutions", C.c_uint32)]
 
 
 class GenSpecABI(C.Structure):
@@ -75,6 +75,7 @@ ABI = [
     ("disco_import_adjacency", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("disco_fetch_contained", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_fetch_edges", C.c_int64, [_P, _P, C.c_uint64]),
+    ("disco_fetch_edge_substitutions", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
     ("disco_phase_ms", C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
@@ -136,11 +137,11 @@ def load():
 class BuildGraph:
     """One context = one GPU. Phases in the order the reference's main() runs them."""
 
-    def __init__(self, min_overlap: int = 40, device: int = 0, max_edges_per_kmer: int = 4, flags: int = 0):
+    def __init__(self, min_overlap: int = 40, device: int = 0, max_edges_per_kmer: int = 4, flags: int = 0, max_substitutions: int = 0):
         self.L = load()
         self.min_overlap = min_overlap
         self._h = _P()
-        p = Params(min_overlap, max_edges_per_kmer, flags, 0)
+        p = Params(min_overlap, max_edges_per_kmer, flags, max_substitutions)
         rc = self.L.disco_create(device, C.byref(p), C.byref(self._h))
         if rc != 0:
             raise DiscoError(f"disco_create failed ({rc}): {self.L.disco_last_error(None).decode()}")
@@ -288,6 +289,14 @@ class BuildGraph:
         out = np.zeros(n, dtype=EDGE_DTYPE)
         if n:
             self._chk(self.L.disco_fetch_edges(self._h, out.ctypes.data, n))
+        return out
+
+    def fetch_edge_substitutions(self) -> np.ndarray:
+        """substitutions of every edge's overlap, in the order of fetch_edges (all 0 unless max_substitutions > 0)"""
+        n = self._chk(self.L.disco_fetch_edge_substitutions(self._h, None, 0))
+        out = np.zeros(n, dtype=np.uint16)
+        if n:
+            self._chk(self.L.disco_fetch_edge_substitutions(self._h, out.ctypes.data, n))
         return out
 
     def phase_ms(self) -> dict:

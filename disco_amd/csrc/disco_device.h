@@ -349,5 +349,32 @@ __device__ __forceinline__ bool seg_equal(const u64 *pa, const u64 *pb, int S, i
     return true;
 }
 
+/* bases that differ between two packed words (2 bits per base) */
+__device__ __forceinline__ u32 base_mismatches(u64 x) { return (u32)__popcll((x | (x >> 1)) & 0x5555555555555555ull); }
+
+/* number of positions at which A[a0 .. a0+m) and s2[b0 .. b0+m) differ (seg_equal's geometry) */
+template <bool NB = false>
+__device__ __forceinline__ u32 seg_mismatches(const u64 *pa, const u64 *pb, int S, int LB, int a0, int b0, int m, u32 rev)
+{
+    u32 c = 0;
+    for (int i = 0; i < m; i += 32) {
+        int n = m - i;
+        if (n > 32) n = 32;
+        u64 wa = extract32<NB>(pa, S, a0 + i);
+        u64 wb;
+        if (!rev) {
+            wb = extract32<NB>(pb, S, b0 + i);
+        } else {
+            int q = LB - b0 - i - n;
+            u64 x = extract32<NB>(pb, S, q);
+            wb = rev2_64(~x);
+            if (n < 32) wb <<= 2 * (32 - n);
+        }
+        u64 mask = (n == 32) ? ~0ull : (~0ull << (64 - 2 * n));
+        c += base_mismatches((wa ^ wb) & mask);
+    }
+    return c;
+}
+
 #endif /* __HIPCC__ */
 #endif /* DISCO_DEVICE_H_ */

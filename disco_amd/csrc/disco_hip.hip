@@ -470,6 +470,7 @@ int disco_create(int device, const disco_params *p, disco_ctx **out)
     c->device = device;
     c->prm = *p;
     if (c->prm.max_edges_per_kmer == 0) c->prm.max_edges_per_kmer = 4;
+    if (c->prm.max_substitutions > 32767) c->prm.max_substitutions = 32767; /* no read is longer (15-bit length field) */
     c->k = (int)p->min_overlap - 1;
 #define CREATE_CHK(call)                                                                              \
     do {                                                                                              \
@@ -860,7 +861,9 @@ int disco_probe(disco_ctx *c)
              * can be contained: only on request (the kmer_hits counter then counts the compared candidates only), reads of mixed
              * length, rows of the 64-byte staged variants, and not inside a multi-GPU pass (its flags need an exchange in between) */
             /* (multi-GPU pass: every rank takes the same branch — min / max length are the job's, nq plays no part) */
-            const bool two_pass = (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && c->S == VERIFY_SW && (nq || c->dist_active) &&
+            const bool inexact = c->prm.max_substitutions != 0; /* single pass: the extension is not tuned for metagenomes */
+            va.max_subs = c->prm.max_substitutions;
+            const bool two_pass = !inexact && (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && c->S == VERIFY_SW && (nq || c->dist_active) &&
                                   (u64)c->min_len * 10 < (u64)c->max_len * 9 && !getenv("DISCO_NO_TWO_PASS");
             c->two_pass_last = two_pass;
             ph_begin(c, DISCO_PH_VERIFY);
@@ -884,6 +887,16 @@ int disco_probe(disco_ctx *c)
                     if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 2>), dim3(wq_grid(c, verify_kernel<5, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                     else hipLaunchKernelGGL((verify_kernel<8, 2>), dim3(wq_grid(c, verify_kernel<8, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 }
+            } else if (nq && inexact) {
+                va.cbits = nullptr;
+#define VERIFY_INEXACT(NW) hipLaunchKernelGGL((verify_kernel<NW, 0, true>), dim3(wq_grid(c, verify_kernel<NW, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va)
+                if (c->S == VERIFY_SW && c->max_len <= 160) VERIFY_INEXACT(5);
+                else if (c->S == VERIFY_SW) VERIFY_INEXACT(8);
+                else if (c->S == 16) VERIFY_INEXACT(16);
+                else if (c->S == 24) VERIFY_INEXACT(24);
+                else if (c->S == 32) VERIFY_INEXACT(32);
+                else VERIFY_INEXACT(0);
+#undef VERIFY_INEXACT
             } else if (nq) {
                 va.cbits = nullptr;
                 if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
@@ -1035,7 +1048,8 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
      * region. A find can therefore miss its twin only if the twin's owner DROPPED a verified hit (second hit to the same
      * destination, BG/OverlapGraph.cpp:656, or the per-k-mer cap, :645). If no read of the target range dropped anything,
      * every list in the range already holds all twins and nothing needs to be searched. */
-    if (c->dropped == 0 && lo >= c->q_lo && hi <= c->q_hi && !getenv("DISCO_FORCE_TWIN_CHECK")) {
+    /* (inexact mode: a substitution inside one read's end k-mer hides the pair from the other side — always search) */
+    if (c->dropped == 0 && c->prm.max_substitutions == 0 && lo >= c->q_lo && hi <= c->q_hi && !getenv("DISCO_FORCE_TWIN_CHECK")) {
         c->n_extra = 0;
         c->asym_local = 0;
         c->ph_ms[DISCO_PH_TWIN] = 0;
@@ -1576,6 +1590,30 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
             e.len_dst = ADJ_DLEN(hep[i]);
         }
     });
+    return (int64_t)ne;
+}
+
+int64_t disco_fetch_edge_substitutions(disco_ctx *c, uint16_t *out, uint64_t cap)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edge_substitutions: run disco_transitive_reduce first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 ne = c->n_out;
+    if (!out) return (int64_t)ne;
+    if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edge_substitutions: need room for %llu edges", (unsigned long long)ne);
+    if (ne == 0) return 0;
+    if (c->prm.max_substitutions == 0) { /* exact overlaps: nothing to count */
+        memset(out, 0, ne * sizeof(uint16_t));
+        return (int64_t)ne;
+    }
+    u16 *subs = nullptr;
+    CHK(dev_alloc(c, &subs, ne));
+    hipLaunchKernelGGL(edge_subs_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos,
+                       c->out_used, c->d_reads, c->d_len, c->S, subs);
+    hipError_t e1 = hipMemcpyAsync(out, subs, ne * sizeof(u16), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    dev_free(c, &subs, ne);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edge_substitutions: copy failed");
     return (int64_t)ne;
 }
 
@@ -2570,7 +2608,7 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
         di.kmer_hits = sum[4];
         di.e_pre = sum[0] / 2;
         c->dropped = sum[1];
-        const bool irregular = sum[1] != 0 || c->n >= (1ull << 30) || getenv("DISCO_DIST_FORCE_GATHER");
+        const bool irregular = sum[1] != 0 || c->n >= (1ull << 30) || c->prm.max_substitutions != 0 || getenv("DISCO_DIST_FORCE_GATHER");
         if (irregular) {
             di.regime = 1;
             CHK(dist_irregular(c, adj_totals));

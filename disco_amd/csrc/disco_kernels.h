@@ -740,6 +740,7 @@ struct VerifyArgs {
     ulonglong2 *meta_ord; /* [q_hi - q_lo] headers by position in the order (written by probe_kernel); out: the count becomes the
                              number of verified overlap hits — edge_select_kernel walks the same order and reads it here */
     const u64 *cbits;     /* MODE 2: contained bitmap (complete: the containment pass has run)                            */
+    u32 max_subs;         /* INEXACT: substitutions an aligned region may carry (disco_params.max_substitutions)          */
 };
 
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
@@ -772,7 +773,10 @@ __device__ __forceinline__ u64 uniform_u64(u64 x)
 #ifndef VERIFY_WAVES_PER_SIMD
 #define VERIFY_WAVES_PER_SIMD 1 /* no register cap beyond what the compiler chooses */
 #endif
-template <int NW, int MODE = 0>
+/* INEXACT (an extension: the reference writes 0 into the substitutions column, BG/OverlapGraph.cpp:815-816):
+ * the aligned region may differ in up to a.max_subs bases — the XOR words are counted instead of OR-ed; the seed k-mer must
+ * still match exactly (it is what made the pair a hit of getListOfReads), so its compare runs for every candidate. */
+template <int NW, int MODE = 0, bool INEXACT = false>
 __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(VerifyArgs a)
 {
     /* staged: the candidate rows (one per lane, NW words + zero words behind; odd stride; the last zero word of a lane is
@@ -961,26 +965,28 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                         return xt;
                     };
                     u64 diff = 0, blo = 0;
+                    u32 nsub = 0;
                     if (act) blo = bp[0];
 #pragma unroll
                     for (int t = 0; t < NW; t++) {
                         if (!__any(t <= nl)) continue;
                         if (t <= nl) {
                             const u64 bhi = bp[t + 1];
-                            diff |= xor_word(t, blo, bhi);
+                            if (INEXACT) nsub += base_mismatches(xor_word(t, blo, bhi));
+                            else diff |= xor_word(t, blo, bhi);
                             blo = bhi;
                         }
                     }
-                    const bool full_ok = act && diff == 0;
-                    bool kmer_ok = full_ok; /* the k-mer lies inside the aligned region */
-                    if (__any(act && !full_ok)) {
+                    const bool region_ok = act && (INEXACT ? nsub <= a.max_subs : diff == 0);
+                    bool kmer_ok = region_ok; /* exact compare: the k-mer lies inside the aligned region */
+                    if (__any(act && (INEXACT || !region_ok))) {
                         /* the exact k-mer compare on its own (what makes a candidate a hit of getListOfReads), over the same
                          * XOR words: k-mer region [K0, K1) in T coordinates */
                         const int K0 = rev ? LA - j - k : j, K1 = K0 + k;
                         const int kw0 = (K0 >> 5) - w0, kw1 = ((K1 - 1) >> 5) - w0;
                         const u64 kfirst = ~0ull >> (2 * (K0 & 31)), klast = ~0ull << (62 - 2 * ((K1 - 1) & 31));
                         u64 kd = 0;
-                        if (act && !full_ok)
+                        if (act && (INEXACT || !region_ok))
                             for (int t = kw0; t <= kw1; t++) {
                                 u64 xt = xor_word(t, bp[t], bp[t + 1]);
                                 if (t == kw0) xt &= kfirst;
@@ -989,6 +995,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                             }
                         kmer_ok = act && kd == 0;
                     }
+                    const bool full_ok = region_ok && kmer_ok;
                     if (kmer_ok) my_khits++;
                     if (full_ok) {
                         if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
@@ -998,7 +1005,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                     const u64 *gb = a.v.reads + B * S;
                     if (seg_equal<false>(ga, gb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
                         my_khits++;
-                        if (seg_equal<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev)) {
+                        if (INEXACT ? seg_mismatches<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev) <= a.max_subs
+                                    : seg_equal<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev)) {
                             if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                             ov = overlap;
                         }
@@ -2128,6 +2136,9 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
     while (wq_grab(a.v.wq, a.list ? a.n_list : a.v.q_hi - a.v.q_lo, cbeg, cend))
     for (u64 it = cbeg; it < cend; it++) {
         const u64 v = a.list ? a.list[it] : a.v.q_lo + it;
+        /* the list can name nodes of other ranks' ranges: the order-dependent regime of the multi-GPU flow marks ALL nodes on every
+         * rank (and lists their wide ones) but emits its own range only */
+        if (v < a.v.q_lo || v >= a.v.q_hi) continue;
         if (a.hcnt && a.hcnt[v] <= HALF_CAP) continue;
         const u64 rv = a.ref[v];
         const u32 d = REF_DEG(rv);
@@ -2280,6 +2291,25 @@ __global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *
         if (valid[i]) {
             dst_src[pos[i]] = out_src[i];
             dst_ent[pos[i]] = out_ent[i];
+        }
+}
+
+/* substitutions of the overlap every emitted edge stands for (the third column of an edge line; 0 by construction unless the
+ * inexact mode is on), from the edge's geometry: orient 2,3 — string2 starts at `offset` of the source; orient 0,1 — string2 ends
+ * where the first len_src - offset bases of the source end; string2 = the destination (0,3) or its reverse complement (1,2)
+ * (BG/Edge.h:30-34, BG/OverlapGraph.cpp:614-626,660-666) */
+__global__ void edge_subs_kernel(const u64 *__restrict__ out_src, const u64 *__restrict__ out_ent, const u8 *__restrict__ valid,
+                                 const u64 *__restrict__ pos, u64 n, const u64 *__restrict__ reads, const u16 *__restrict__ len, int S,
+                                 u16 *__restrict__ subs)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (valid[i]) {
+            const u64 src = out_src[i], e = out_ent[i];
+            const int l1 = (int)len[src], l2 = (int)ADJ_DLEN(e), off = (int)ADJ_OFF(e), ovl = l1 - off;
+            const u32 o = ADJ_ORI(e);
+            const u32 rev = (o == 1 || o == 2);
+            subs[pos[i]] = (u16)seg_mismatches<false>(reads + src * S, reads + ADJ_DST(e) * S, S, l2, o >= 2 ? off : 0, o >= 2 ? 0 : l2 - ovl, ovl, rev);
         }
 }
 

@@ -54,7 +54,10 @@ typedef struct disco_params {
     uint32_t min_overlap;        /* MinOverlap4BuildGraph (disco.cfg:9); k = min_overlap - 1 (BG/HashTable.cpp:50) */
     uint32_t max_edges_per_kmer; /* MAX_EDGE_PER_KMER (BG/Common.h:62); 0 -> 4                                       */
     uint32_t flags;              /* DISCO_FLAG_*                                                                     */
-    uint32_t reserved;
+    uint32_t max_substitutions;  /* 0 = the reference: exact overlaps. > 0 = EXTENSION (the reference always writes
+                                    0 into the substitutions column, BG/OverlapGraph.cpp:815-816): a candidate seeded by an exact
+                                    end-k-mer hit is an overlap / a containment if its aligned region differs in at most this many
+                                    bases; pairs found from one side only are completed by the twin pass (order-dependent regime) */
 } disco_params;
 
 /* synthetic reads, see disco_amd/csrc/readgen.h (replaces bbmap/randomreads.sh for the BASELINE configs) */
@@ -228,6 +231,10 @@ int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
 int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
 /* edges of the local query range (src < dst), in no particular order; returns count or negative error */
 int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
+/* substitutions of every edge's overlap, in the order of disco_fetch_edges — the third number of an edge line, "no substitutions"
+ * in the reference (BG/OverlapGraph.cpp:815); all 0 unless disco_params.max_substitutions > 0. Computed on the device from the
+ * packed reads and the edge geometry. */
+int64_t disco_fetch_edge_substitutions(disco_ctx *ctx, uint16_t *out, uint64_t cap);
 /* one file index in [0, n_files) per edge, in the order of disco_fetch_edges: the connected components of the reduced graph
  * dealt out to n_files files (large components by size, small ones by hash), so that every node has ALL its edges in one
  * file — what lets the consumer pre-simplify the files independently (SG/OverlapGraphSimple.cpp:344,636-644; the reference

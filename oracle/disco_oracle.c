@@ -173,6 +173,7 @@ typedef struct oracle_index {
     uint64_t *start;   /* nbuckets + 1 */
     uint64_t *rec;     /* 2n records: id << 1 | isSuffix */
     uint64_t *super;   /* superReadID per read, NONE = not contained (BG/Read.h:24) */
+    uint32_t max_subs; /* 0 = the reference (exact compares); > 0 = the inexact-overlap EXTENSION, see disco_oracle.h */
 } oracle_index;
 
 static uint64_t mix64(uint64_t z)
@@ -236,6 +237,19 @@ static int eq_rev(const uint8_t *a, const uint8_t *b, uint32_t n)
     return 1;
 }
 
+/* the compare of checkOverlap* : memcmp in the reference; with the extension, at most max_subs differing bases */
+static uint32_t mismatches(const uint8_t *a, const uint8_t *b, uint32_t n)
+{
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < n; i++) c += a[i] != b[i];
+    return c;
+}
+static int same(const oracle_index *ix, const uint8_t *a, const uint8_t *b, uint32_t n)
+{
+    if (ix->max_subs == 0) return memcmp(a, b, n) == 0;
+    return mismatches(a, b, n) <= ix->max_subs;
+}
+
 /* getListOfReads — BG/HashTable.cpp:521-571.  Appends readID | type << 62 in bucket order. */
 static void list_of_reads(const oracle_index *ix, const uint8_t *q, vec64 *hits, int skip_contained)
 {
@@ -276,10 +290,10 @@ static int check_contained(const oracle_index *ix, const uint8_t *read1, uint32_
     oriented(ix, read2, orient, buf);
     if (orient == 0 || orient == 2) {
         uint32_t rem1 = len1 - start - k, rem2 = len2 - k;
-        if (rem1 >= rem2) return memcmp(read1 + start + k, buf + k, rem2) == 0;
+        if (rem1 >= rem2) return same(ix, read1 + start + k, buf + k, rem2);
     } else {
         uint32_t rem1 = start, rem2 = len2 - k;
-        if (rem1 >= rem2) return memcmp(read1 + start - rem2, buf, rem2) == 0;
+        if (rem1 >= rem2) return same(ix, read1 + start - rem2, buf, rem2);
     }
     return 0;
 }
@@ -292,10 +306,10 @@ static int check_overlap(const oracle_index *ix, const uint8_t *read1, uint32_t 
     oriented(ix, read2, orient, buf);
     if (orient == 0 || orient == 2) {
         if (len1 - start - k >= len2 - k) return 0; /* :579 */
-        return memcmp(read1 + start + k, buf + k, len1 - (start + k)) == 0;
+        return same(ix, read1 + start + k, buf + k, len1 - (start + k));
     } else {
         if (len2 - k < start) return 0; /* :591 */
-        return memcmp(read1, buf + (len2 - k - start), start) == 0;
+        return same(ix, read1, buf + (len2 - k - start), start);
     }
 }
 
@@ -323,11 +337,14 @@ static void mark_contained(oracle_index *ix, uint32_t maxlen, oracle_result *out
     size_t cap = 0, n = 0;
     oracle_contained_row *rows = NULL;
     for (uint64_t i = 0; i < ix->n; i++) {          /* :391 */
-        if (ix->super[i] != NONE) continue;          /* :395 */
+        /* extension only: with substitutions containment is not transitive, so which reads are contained would depend on the
+         * order in which containers are themselves marked; the extension defines the order-free form — a read is contained
+         * iff ANY read contains it within the threshold, recorded with its first container in (read, j, bucket) order */
+        if (ix->max_subs == 0 && ix->super[i] != NONE) continue; /* :395 */
         const uint8_t *read1 = read_ptr(ix, i);
         uint32_t len1 = read_len(ix, i);
         for (uint32_t j = 0; j < len1 - ix->k; j++) { /* :401 */
-            list_of_reads(ix, read1 + j, &hits, 1);  /* :404 */
+            list_of_reads(ix, read1 + j, &hits, ix->max_subs == 0);  /* :404 */
             for (size_t h = 0; h < hits.n; h++) {    /* :407 */
                 uint64_t read2 = hits.p[h] & 0x3FFFFFFFFFFFFFFFull;
                 uint32_t type = (uint32_t)(hits.p[h] >> 62);
@@ -433,11 +450,30 @@ static int cmp_edge(const void *a, const void *b)
 /* ------------------------------------------------------------------------------------------------
  * the whole path
  * ---------------------------------------------------------------------------------------------- */
+/* extension: substitutions of the overlap an edge stands for, from the edge's geometry alone (BG/Edge.h:30-34 orientations,
+ * offsets as insertEdge stores them, BG/OverlapGraph.cpp:614-626): orient 2,3 — string2 starts at `offset` of src;
+ * orient 0,1 — string2 ends where the first len_src - offset bases of src end; string2 = dst (0,3) or its reverse complement */
+static uint32_t edge_substitutions(const oracle_index *ix, uint64_t src, uint64_t dst, uint32_t orient, uint32_t offset, uint8_t *buf)
+{
+    uint32_t l1 = read_len(ix, src), l2 = read_len(ix, dst), ovl = l1 - offset;
+    const uint8_t *a = read_ptr(ix, src);
+    oriented(ix, dst, (orient == 0 || orient == 3) ? 0 : 2, buf);
+    if (orient >= 2) return mismatches(a + offset, buf, ovl);
+    return mismatches(a, buf + (l2 - ovl), ovl);
+}
+
 int oracle_build_graph(const uint8_t *codes, const uint64_t *off, uint64_t n_reads, uint32_t min_overlap,
                        uint32_t flags, oracle_result *out)
 {
+    return oracle_build_graph_inexact(codes, off, n_reads, min_overlap, flags, 0, out);
+}
+
+int oracle_build_graph_inexact(const uint8_t *codes, const uint64_t *off, uint64_t n_reads, uint32_t min_overlap,
+                               uint32_t flags, uint32_t max_subs, oracle_result *out)
+{
     oracle_index ix;
     uint32_t maxlen = 0;
+    int geometry_errors = 0;
     if (!out || min_overlap < 2) return -1;
     memset(out, 0, sizeof *out);
     memset(&ix, 0, sizeof ix);
@@ -445,6 +481,7 @@ int oracle_build_graph(const uint8_t *codes, const uint64_t *off, uint64_t n_rea
     ix.off = off;
     ix.n = n_reads;
     ix.k = min_overlap - 1; /* hashStringLength, BG/HashTable.cpp:50 */
+    ix.max_subs = max_subs;
     out->c.n_reads = n_reads;
     for (uint64_t i = 0; i < n_reads; i++) {
         uint64_t L = off[i + 1] - off[i];
@@ -569,6 +606,15 @@ int oracle_build_graph(const uint8_t *codes, const uint64_t *off, uint64_t n_rea
         if (n) qsort(E, n, sizeof *E, cmp_edge);
         out->edges = E;
         out->c.e_out = n;
+        out->edge_subs = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+        if (max_subs) {
+            uint8_t *buf = (uint8_t *)malloc(maxlen + 1);
+            for (size_t t = 0; t < n; t++) {
+                out->edge_subs[t] = edge_substitutions(&ix, E[t].src, E[t].dst, E[t].orient, E[t].offset, buf);
+                if (out->edge_subs[t] > max_subs) geometry_errors++; /* an edge is an accepted find or its twin */
+            }
+            free(buf);
+        }
     }
     for (uint64_t v = 0; v < n_reads; v++) {
         free(F[v].p);
@@ -581,7 +627,7 @@ int oracle_build_graph(const uint8_t *codes, const uint64_t *off, uint64_t n_rea
     free(ix.start);
     free(ix.rec);
     free(ix.super);
-    return 0;
+    return geometry_errors ? -2 : 0;
 }
 
 void oracle_free_result(oracle_result *r)
@@ -589,6 +635,8 @@ void oracle_free_result(oracle_result *r)
     if (!r) return;
     free(r->contained);
     free(r->edges);
+    free(r->edge_subs);
     r->contained = NULL;
     r->edges = NULL;
+    r->edge_subs = NULL;
 }

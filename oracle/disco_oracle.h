@@ -59,6 +59,7 @@ typedef struct oracle_result {
     oracle_contained_row *contained;  /* discovery order: super ascending, then j, bucket order */
     oracle_edge *edges;               /* sorted by (src, dst, orient, offset), unique           */
     oracle_counters c;
+    uint32_t *edge_subs;              /* per edge: substitutions of its overlap (all 0 unless the extension below is on) */
 } oracle_result;
 
 enum { ORACLE_COUNT_HITS = 1 };
@@ -85,6 +86,17 @@ long oracle_parse_records(const char *buf, size_t n,
  * Returns 0, or -1 on bad arguments.  Free with oracle_free_result. */
 int oracle_build_graph(const uint8_t *codes, const uint64_t *off, uint64_t n_reads,
                        uint32_t min_overlap, uint32_t flags, oracle_result *out);
+
+/* EXTENSION, not a restatement: the reference compares exactly and writes 0 into the substitutions column
+ * (BG/OverlapGraph.cpp:815-816).  With max_subs > 0 the two compares of checkOverlapForContainedRead / checkOverlap accept up to
+ * max_subs differing bases outside the seed k-mer (the seed itself is still an exact hash-table hit); everything else follows
+ * the reference, except that containment is taken in its order-free form (a read is contained iff any read contains it within
+ * the threshold — with substitutions containment is not transitive, so the reference's skip of already-contained containers,
+ * :395, would make the result depend on the processing order).  Pairs whose seed k-mer carries a substitution on one side are
+ * found from the other side only; insertEdge's twin (:614-626) completes them, as it does for cap-bound pairs.
+ * max_subs = 0 is oracle_build_graph.  Returns -2 if an emitted edge's overlap has more than max_subs substitutions. */
+int oracle_build_graph_inexact(const uint8_t *codes, const uint64_t *off, uint64_t n_reads,
+                               uint32_t min_overlap, uint32_t flags, uint32_t max_subs, oracle_result *out);
 
 void oracle_free_result(oracle_result *r);
 

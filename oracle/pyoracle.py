@@ -31,7 +31,8 @@ class Counters(C.Structure):
 
 
 class Result(C.Structure):
-    _fields_ = [("contained", C.POINTER(ContainedRow)), ("edges", C.POINTER(Edge)), ("c", Counters)]
+    _fields_ = [("contained", C.POINTER(ContainedRow)), ("edges", C.POINTER(Edge)), ("c", Counters),
+                ("edge_subs", C.POINTER(C.c_uint32))]
 
 
 CONTAINED_DTYPE = np.dtype([("contained", "<u8"), ("super", "<u8"), ("orient", "<u4"), ("len2", "<u4"),
@@ -54,6 +55,8 @@ def lib():
         L = C.CDLL(build())
         L.oracle_build_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(Result)]
         L.oracle_build_graph.restype = C.c_int
+        L.oracle_build_graph_inexact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Result)]
+        L.oracle_build_graph_inexact.restype = C.c_int
         L.oracle_free_result.argtypes = [C.POINTER(Result)]
         L.oracle_test_read.argtypes = [C.c_char_p, C.c_size_t]
         L.oracle_test_read.restype = C.c_int
@@ -118,23 +121,33 @@ def encode_reads(reads):
     return np.ascontiguousarray(codes), off
 
 
-def build_graph(codes, off, min_overlap: int, count_hits: bool = False):
+def build_graph_inexact(codes, off, min_overlap: int, max_subs: int):
+    """the inexact-overlap EXTENSION (disco_oracle.h; the reference has no such mode): (rows, edges, counters, substitutions per edge)"""
+    return build_graph(codes, off, min_overlap, max_subs=max_subs, with_subs=True)
+
+
+def build_graph(codes, off, min_overlap: int, count_hits: bool = False, max_subs: int = 0, with_subs: bool = False):
     """returns (contained rows [CONTAINED_DTYPE], edges [EDGE_DTYPE], counters dict); ids are 0-based good-read ranks."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     res = Result()
-    rc = lib().oracle_build_graph(codes.ctypes.data, off.ctypes.data, len(off) - 1, min_overlap,
-                                  1 if count_hits else 0, C.byref(res))
+    if max_subs:
+        rc = lib().oracle_build_graph_inexact(codes.ctypes.data, off.ctypes.data, len(off) - 1, min_overlap,
+                                              1 if count_hits else 0, max_subs, C.byref(res))
+    else:
+        rc = lib().oracle_build_graph(codes.ctypes.data, off.ctypes.data, len(off) - 1, min_overlap,
+                                      1 if count_hits else 0, C.byref(res))
     if rc != 0:
-        raise ValueError("oracle_build_graph: bad arguments")
+        raise ValueError(f"oracle_build_graph: {'bad arguments' if rc == -1 else 'an edge exceeds the substitution threshold'}")
     nc, ne = res.c.n_contained, res.c.e_out
     rows = np.ctypeslib.as_array(C.cast(res.contained, C.POINTER(C.c_uint8)), (nc * C.sizeof(ContainedRow),)).copy().view(
         CONTAINED_DTYPE) if nc else np.zeros(0, CONTAINED_DTYPE)
     edges = np.ctypeslib.as_array(C.cast(res.edges, C.POINTER(C.c_uint8)), (ne * C.sizeof(Edge),)).copy().view(
         EDGE_DTYPE) if ne else np.zeros(0, EDGE_DTYPE)
     counters = {n: int(getattr(res.c, n)) for n, _ in Counters._fields_}
+    subs = np.ctypeslib.as_array(res.edge_subs, (ne,)).copy() if ne else np.zeros(0, np.uint32)
     lib().oracle_free_result(C.byref(res))
-    return rows, edges, counters
+    return (rows, edges, counters, subs) if with_subs else (rows, edges, counters)
 
 
 # ----------------------------------------------------------------------------------------------------------------

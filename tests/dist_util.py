@@ -10,10 +10,10 @@ import numpy as np
 from disco_amd import buildgraph
 
 
-def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flags=0):
+def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flags=0, max_substitutions=0, subs_out=None):
     """setup(g) puts this rank's reads into context g (collective calls allowed). Returns (edges of all ranks, contained
-    rows of all ranks, info of rank 0, infos)"""
-    gs = [buildgraph.BuildGraph(min_overlap=min_overlap, device=device, flags=flags) for _ in range(G)]
+    rows of all ranks, info of rank 0, infos); subs_out: a list that receives the substitutions of the edges, in their order"""
+    gs = [buildgraph.BuildGraph(min_overlap=min_overlap, device=device, flags=flags, max_substitutions=max_substitutions) for _ in range(G)]
     buildgraph.BuildGraph.comm_init_local(gs)
     out, errors = [None] * G, []
 
@@ -23,7 +23,7 @@ def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flag
             setup(g)
             for _ in range(passes):
                 g.dist_run_graph(gather_reads)
-            out[r] = (g.fetch_edges(), g.fetch_contained(), g.dist_info())
+            out[r] = (g.fetch_edges(), g.fetch_contained(), g.dist_info(), g.fetch_edge_substitutions() if subs_out is not None else None)
         except Exception as e:  # pragma: no cover
             errors.append((r, repr(e)))
 
@@ -38,6 +38,8 @@ def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flag
         edges = np.concatenate([o[0] for o in out])
         rows = np.concatenate([o[1] for o in out])
         infos = [o[2] for o in out]
+        if subs_out is not None:
+            subs_out.append(np.concatenate([o[3] for o in out]))
         assert sum(i["e_out_local"] for i in infos) == len(edges) == infos[0]["e_out"]
         assert sum(i["n_contained_local"] for i in infos) == len(rows) == infos[0]["n_contained"]
         return edges, rows, infos[0], infos
