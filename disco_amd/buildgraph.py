@@ -55,6 +55,7 @@ ABI = [
     ("disco_upload_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
     ("disco_adopt_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
     ("disco_generate_reads", C.c_int, [_P, C.POINTER(GenSpecABI)]),
+    ("disco_substitute_bases", C.c_int, [_P, C.c_uint64, C.c_uint32]),
     ("disco_download_reads", C.c_int, [_P, _P, _P]),
     ("disco_stride_words", C.c_uint32, [_P]),
     ("disco_num_reads", C.c_uint64, [_P]),
@@ -201,6 +202,10 @@ class BuildGraph:
     def generate_reads(self, spec):
         s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
         self._chk(self.L.disco_generate_reads(self._h, C.byref(s)))
+
+    def substitute_bases(self, seed: int, rate_ppm: int):
+        """substitution errors into the resident reads (readgen.substitute is the numpy twin)"""
+        self._chk(self.L.disco_substitute_bases(self._h, seed, rate_ppm))
 
     def download_reads(self):
         n, s = self.num_reads, self.stride_words

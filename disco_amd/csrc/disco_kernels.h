@@ -120,6 +120,27 @@ __global__ void generate_reads_kernel(disco_genspec spec, u64 *__restrict__ read
     }
 }
 
+/* substitution errors into resident reads (disco_substitute_bases) */
+__global__ void substitute_bases_kernel(u64 seed, u32 rate_ppm, u64 *__restrict__ reads, const u16 *__restrict__ len, int S, u64 r_lo, u64 r_hi)
+{
+    u64 gid = r_lo * (u64)S + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = r_hi * (u64)S;
+    for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
+        const u64 r = gid / S;
+        const int base0 = (int)(gid % S) * 32, L = (int)len[r];
+        if (base0 >= L) continue;
+        const u64 word = reads[gid];
+        u64 out = 0;
+        for (int i = 0; i < 32; i++) {
+            u32 b = (u32)(word >> (62 - 2 * i)) & 3u;
+            if (base0 + i < L) b = disco_substituted_base(seed, rate_ppm, r, (u32)(base0 + i), b);
+            else b = 0;
+            out |= (u64)b << (62 - 2 * i);
+        }
+        reads[gid] = out;
+    }
+}
+
 /* reads must satisfy min_overlap < len <= 32767 (BG/Dataset.cpp:305, BG/HashTable.cpp:531) and fit the stride */
 __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, int min_overlap, u64 *ctr)
 {
@@ -1130,6 +1151,7 @@ struct EdgeSelArgs {
      * destinations are still in the L2 for the next read — in file order 16 of a read's 44 bitmap gathers missed it */
     const u64 *order;
     const ulonglong2 *meta_ord;
+    u64 *dropbits; /* out: one bit per read whose selection dropped a verified hit (only those lists can lack a twin: twin_check) */
 };
 
 /* stable-free rank sort of m distinct keys from src into dst (wave cooperative) */
@@ -1275,6 +1297,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
     n_edges += nacc;
     dropped += m - nacc;
+    if (lane == 0 && m != nacc) atomicOr(&a.dropbits[A >> 6], 1ull << (A & 63));
     __syncthreads();
 }
 
@@ -1317,6 +1340,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
     n_edges += nacc;
     dropped += m - nacc; /* second and later hits to a destination already linked (BG/OverlapGraph.cpp:656) */
+    if (lane == 0 && m != nacc) atomicOr(&a.dropbits[A >> 6], 1ull << (A & 63));
     return true;
 }
 
@@ -1581,6 +1605,9 @@ struct TwinArgs {
     u64 *extra_key;
     u32 *n_extra;
     u32 extra_cap;
+    const u64 *dropbits; /* or null. Bit w set: the selection of w dropped a verified hit. With exact overlaps the twin of a find
+                            u -> w can be missing from w's list only then (twin_check in disco_hip.hip has the argument), so every
+                            other find needs no search */
     int up_only;    /* 1: search only finds with src < dst and count both kinds; equality of the two counts plus no
                        missing twin proves symmetry (the up-finds inject into the down-finds); no extras recorded */
 };
@@ -1610,6 +1637,7 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
                 n_up++;
             } else if (w < a.lo || w >= a.hi)
                 continue;
+            if (a.dropbits && !((a.dropbits[w >> 6] >> (w & 63)) & 1ull)) continue;
             const u32 Lw = ADJ_DLEN(ent);
             const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent)), Lu); /* :617-619 */
             const u64 rw = a.ref[w];
@@ -1669,6 +1697,49 @@ __global__ void merge_scatter_kernel(const u64 *__restrict__ extra_node, const u
         u32 d = REF_DEG(old_ref[w]);
         u32 slot = atomicAdd(&fill[w], 1u);
         new_adj[new_start[w] + d + slot] = extra_key[i];
+    }
+}
+
+/* few extras (the ordinary case on real reads: a few repeats bind the cap): only the rows that receive extras move — each gets
+ * 2 x (deg + extras) fresh slots behind the used part of the entry buffer: merged unsorted in the upper half, rank-sorted into the
+ * lower half, which becomes the row. merge_need_kernel sizes the space first; the old rows are simply abandoned. */
+__global__ void merge_need_kernel(const u64 *__restrict__ ref, const u32 *__restrict__ extra_cnt, u64 n, u64 *__restrict__ need)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (extra_cnt[i]) atomicAdd(need, 2ull * (REF_DEG(ref[i]) + extra_cnt[i]));
+}
+
+__global__ void __launch_bounds__(64) merge_sparse_kernel(const u64 *__restrict__ extra_node, const u64 *__restrict__ extra_key, u32 n_extra,
+                                                          const u32 *__restrict__ extra_cnt, u64 *__restrict__ ref, u64 *__restrict__ adj, u64 free_base,
+                                                          u64 *__restrict__ bump)
+{
+    const u32 lane = threadIdx.x;
+    for (u32 i = blockIdx.x; i < n_extra; i += gridDim.x) {
+        const u64 v = extra_node[i];
+        /* the node is handled by the wave that holds its FIRST extra */
+        bool earlier = false;
+        for (u32 t = lane; t < i; t += 64) earlier |= extra_node[t] == v;
+        if (__any(earlier)) continue;
+        const u64 r = ref[v];
+        const u32 d = REF_DEG(r), nd = d + extra_cnt[v];
+        u64 p = 0;
+        if (lane == 0) p = free_base + atomicAdd(bump, 2ull * nd);
+        p = __shfl(p, 0);
+        u64 *lo = adj + p, *up = adj + p + nd;
+        for (u32 t = lane; t < d; t += 64) up[t] = adj[REF_POS(r) + t] & ~ADJ_FLAG;
+        u32 at = d;
+        for (u32 t0 = i; t0 < n_extra; t0 += 64) {
+            const u32 t = t0 + lane;
+            const bool mine = t < n_extra && extra_node[t] == v;
+            const u64 mk = __ballot(mine);
+            if (mine) up[at + __popcll(mk & lane_mask_lt())] = extra_key[t];
+            at += __popcll(mk);
+        }
+        __syncthreads();
+        wave_rank_sort(up, lo, nd, lane);
+        __syncthreads();
+        if (lane == 0) ref[v] = REF_MAKE(p, nd);
     }
 }
 

@@ -89,4 +89,13 @@ DISCO_HD uint32_t disco_read_base(const disco_genspec *s, const disco_readloc *l
     return 3u - disco_genome_base(s->seed, loc->gpos + (loc->len - 1 - i));
 }
 
+/* sequencing-error model for the inexact-overlap extension (bench / tests): base p of read r is substituted with probability
+ * rate_ppm / 10^6, by one of the three other bases — a pure function of (seed, r, p), like everything above */
+DISCO_HD uint32_t disco_substituted_base(uint64_t seed, uint32_t rate_ppm, uint64_t r, uint32_t p, uint32_t base)
+{
+    const uint64_t h = disco_mix64((seed * 0x9FB21C651E98DF25ull) ^ ((r << 15) | p));
+    if ((uint32_t)(h % 1000000u) >= rate_ppm) return base;
+    return (base + 1u + (uint32_t)((h >> 40) % 3u)) & 3u;
+}
+
 #endif /* DISCO_READGEN_H_ */

@@ -7,7 +7,7 @@ import numpy as np
 
 HEADER = np.dtype([("magic", "S8"), ("version", "<u4"), ("record_bytes", "<u4"), ("n_records", "<u8"), ("n_files", "<u4"), ("reserved", "<u4")])
 EDGE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("orient", "<u4"), ("offset", "<u4"), ("len_src", "<u4"), ("len_dst", "<u4"), ("file", "<u2"),
-                 ("flag", "<u2"), ("pad", "<u4")])
+                 ("flag", "<u2"), ("substitutions", "<u4")])
 CONTAINED = np.dtype([("contained", "<u8"), ("super", "<u8"), ("orient", "<u4"), ("len2", "<u4"), ("len1", "<u4"), ("start", "<u4"),
                       ("file", "<u2"), ("pad0", "<u2"), ("pad1", "<u4")])
 
@@ -35,7 +35,7 @@ def edge_lines(rec):
     """the text lines of the records, in record order"""
     for r in rec:
         ovl = int(r["len_src"]) - int(r["offset"])
-        yield (f"{r['src']}\t{r['dst']}\t{r['orient']},{ovl},0,0,{r['len_src']},{r['offset']},{int(r['len_src']) - 1},{r['len_dst']},0,{ovl - 1},NA,{r['flag']}\n")
+        yield (f"{r['src']}\t{r['dst']}\t{r['orient']},{ovl},{r['substitutions']},0,{r['len_src']},{r['offset']},{int(r['len_src']) - 1},{r['len_dst']},0,{ovl - 1},NA,{r['flag']}\n")
 
 
 def contained_lines(rec):

@@ -53,6 +53,8 @@ static void usage()
               << "  --par-simple\tprefix: also write <prefix>_<i>_ParSimpleEdges.txt, the output of the reference's parsimplify step on\n"
               << "\t\tevery edge file (fullsimplify then skips that step); DISCO_PAR_SIMPLE=1 in the environment derives the prefix\n"
               << "\t\tfrom -f the way runDisco.sh lays its directories out (<out>/graph/<name> -> <out>/assembly/<name>)\n"
+              << "  --max-substitutions N\textension: accept overlaps / containments with up to N differing bases around an exact end-k-mer seed and\n"
+              << "\t\twrite the count into the substitutions column (default 0 = the reference; parameter file key MaxSubstitutions4BuildGraph)\n"
               << "  --binary-out\talso write <prefix>_edges.bin / <prefix>_contained.bin (fixed 40-byte records, disco_amd/host/writer.h)\n"
               << "  --no-text\tbinary output only: leave the text edge / contained files empty (a consumer with the loader patch)\n";
 }
@@ -84,7 +86,7 @@ static bool parse_u64(const std::string &s, unsigned long long &out)
 }
 
 /* BG/main.cpp:152-176 : key = value lines; default 30 */
-static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string &err, uint32_t *mo_simplify = nullptr)
+static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string &err, uint32_t *mo_simplify = nullptr, uint32_t *max_subs = nullptr)
 {
     std::ifstream f(path);
     if (!f.is_open()) return false;
@@ -103,6 +105,15 @@ static bool read_min_overlap(const std::string &path, uint32_t &mo, std::string 
                 return true;
             }
             mo = (uint32_t)v;
+        }
+        /* extension key: the reference's parser looks for its own keys only and skips this line */
+        if (max_subs && trim(tok[0]) == "MaxSubstitutions4BuildGraph") {
+            unsigned long long v = 0;
+            if (!parse_u64(tok[1], v) || v > 32767) {
+                err = "MaxSubstitutions4BuildGraph = '" + trim(tok[1]) + "' in " + path + " is not a number in [0, 32767]";
+                return true;
+            }
+            *max_subs = (uint32_t)v;
         }
         if (mo_simplify && trim(tok[0]) == "MinOverlap4SimplifyGraph") {
             unsigned long long v = 0;
@@ -126,6 +137,7 @@ static int die(const std::string &msg)
 struct RankResult {
     std::vector<disco_contained_row> rows;
     std::unique_ptr<disco_edge[]> edges;
+    std::unique_ptr<uint16_t[]> subs; /* inexact mode only */
     uint64_t n_edges = 0;
     disco_dist_info info{};
     std::string err;
@@ -140,6 +152,7 @@ int main(int argc, char **argv)
     int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
     bool same_device = false, mpi_names = false, binary_out = false, no_text = false;
     std::string par_simple; /* prefix of the <prefix>_<i>_ParSimpleEdges.txt files, or empty */
+    long long max_subs_cli = -1; /* --max-substitutions (overrides MaxSubstitutions4BuildGraph of the parameter file) */
     std::cout << "PRINTING ARGUMENTS\n";
     for (int i = 0; i < argc; i++) std::cout << argv[i] << ' ';
     std::cout << std::endl;
@@ -176,6 +189,7 @@ int main(int argc, char **argv)
         else if (a == "--same-device") same_device = true;
         else if (a == "--mpi-names") mpi_names = true;
         else if (a == "--par-simple") par_simple = next();
+        else if (a == "--max-substitutions") max_subs_cli = (long long)num(0, 32767);
         else if (a == "--binary-out") binary_out = true;
         else if (a == "--no-text") binary_out = no_text = true;
         else {
@@ -189,9 +203,9 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    uint32_t min_overlap = 30, min_overlap_simplify = 0;
+    uint32_t min_overlap = 30, min_overlap_simplify = 0, max_subs = 0;
     std::string cfg_err;
-    if (!read_min_overlap(cfg, min_overlap, cfg_err, &min_overlap_simplify)) {
+    if (!read_min_overlap(cfg, min_overlap, cfg_err, &min_overlap_simplify, &max_subs)) {
         std::cerr << "Unable to open parameter file: " << cfg << std::endl;
         return 1; /* BG/main.cpp:157-160 */
     }
@@ -200,6 +214,10 @@ int main(int argc, char **argv)
         return 1;
     }
     std::cout << "MinOverlap4BuildGraph = " << min_overlap << std::endl;
+    if (max_subs_cli >= 0) max_subs = (uint32_t)max_subs_cli;
+    if (max_subs)
+        std::cout << "MaxSubstitutions4BuildGraph = " << max_subs << " (extension: overlaps and containments may differ in that many bases around an exact "
+                  << "end-k-mer seed; the reference compares exactly)" << std::endl;
 
     bool ccr = false, gc = false;
     disco::read_checkpoint(prefix, ccr, gc);
@@ -234,7 +252,8 @@ int main(int argc, char **argv)
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
     /* two-pass verify for read sets of mixed lengths (metagenomes: most reads contained): same files, fewer candidate-row fetches;
      * only the diagnostic k-mer-hit count in the log then counts the compared candidates */
-    disco_params prm{min_overlap, 4, getenv("DISCO_EXACT_COUNTERS") ? 0u : DISCO_FLAG_TWO_PASS_VERIFY, 0};
+    disco_params prm{min_overlap, 4, getenv("DISCO_EXACT_COUNTERS") ? 0u : DISCO_FLAG_TWO_PASS_VERIFY, max_subs};
+    std::unique_ptr<uint16_t[]> edge_subs; /* substitutions per edge (third number of an edge line); stays null with exact overlaps */
     uint64_t n_cont = 0, e_pre = 0, e_out = 0;
     std::vector<disco_contained_row> rows;
     std::unique_ptr<disco_edge[]> edges;
@@ -269,7 +288,7 @@ int main(int argc, char **argv)
                   << "\n  asymmetric_pairs         : " << cn.asymmetric_pairs << "\n"
                   << "Function buildOverlapGraph() [GPU] finished in " << t_graph << " Seconds (" << (t_graph > 0 ? e_pre / t_graph : 0)
                   << " overlaps/s); host->device " << t_h2d << " Seconds." << std::endl;
-        if (cn.cap_bind_sites || cn.asymmetric_pairs)
+        if (!max_subs && (cn.cap_bind_sites || cn.asymmetric_pairs))
             std::cout << "Note: this input is in the order-dependent regime of the reference (edge cap per k-mer reached or overlaps found from one "
                          "side only); the reference's own result varies with its thread count here."
                       << std::endl;
@@ -280,6 +299,10 @@ int main(int argc, char **argv)
         lap("fetch contained rows");
         edges.reset(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
         if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
+        if (max_subs) {
+            edge_subs.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
+            if (e_out && disco_fetch_edge_substitutions(ctx, edge_subs.get(), e_out) < 0) return die(disco_last_error(ctx));
+        }
         lap("fetch edges");
         /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
          * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
@@ -324,6 +347,10 @@ int main(int argc, char **argv)
                 R.n_edges = R.info.e_out_local;
                 R.edges.reset(new disco_edge[std::max<uint64_t>(R.n_edges, 1)]);
                 if (R.n_edges && disco_fetch_edges(c, R.edges.get(), R.n_edges) < 0) bail("disco_fetch_edges");
+                if (max_subs) {
+                    R.subs.reset(new uint16_t[std::max<uint64_t>(R.n_edges, 1)]);
+                    if (R.n_edges && disco_fetch_edge_substitutions(c, R.subs.get(), R.n_edges) < 0) bail("disco_fetch_edge_substitutions");
+                }
             });
         for (auto &t : th) t.join();
         t_graph = secs(t0);
@@ -340,7 +367,7 @@ int main(int argc, char **argv)
                   << (di.regime ? "order-dependent (adjacency gathered)" : "regular (neighbour rows on request)") << "\n"
                   << "Function buildOverlapGraph() [" << gpus << " GPU ranks] finished in " << t_graph << " Seconds incl. upload (" << (t_graph > 0 ? e_pre / t_graph : 0)
                   << " overlaps/s); last pass " << di.ms_total * 1e-3 << " Seconds on rank 0." << std::endl;
-        if (di.cap_bind_sites || di.asymmetric_pairs)
+        if (!max_subs && (di.cap_bind_sites || di.asymmetric_pairs))
             std::cout << "Note: this input is in the order-dependent regime of the reference (edge cap per k-mer reached or overlaps found from one "
                          "side only); the reference's own result varies with its thread count here."
                       << std::endl;
@@ -359,11 +386,14 @@ int main(int argc, char **argv)
             std::vector<disco_contained_row>().swap(R.rows);
         }
         edges.reset(new disco_edge[std::max<uint64_t>(ne, 1)]);
+        if (max_subs) edge_subs.reset(new uint16_t[std::max<uint64_t>(ne, 1)]);
         uint64_t at = 0;
         for (auto &R : res) {
             if (R.n_edges) memcpy(edges.get() + at, R.edges.get(), R.n_edges * sizeof(disco_edge));
+            if (R.n_edges && max_subs) memcpy(edge_subs.get() + at, R.subs.get(), R.n_edges * sizeof(uint16_t));
             at += R.n_edges;
             R.edges.reset();
+            R.subs.reset();
         }
         lap("gather the ranks' shares");
         edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
@@ -377,7 +407,7 @@ int main(int argc, char **argv)
     disco::FileTags etags = mpi_names ? disco::FileTags::mpi_edges(gpus, threads) : disco::FileTags::plain(threads);
     disco::FileTags ctags = mpi_names ? disco::FileTags::mpi_contained(gpus, threads) : disco::FileTags::plain(threads);
     if (binary_out) {
-        if (!disco::write_binary(prefix, (int)etags.tag.size(), (int)ctags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rows, rs, err)) return die(err);
+        if (!disco::write_binary(prefix, (int)etags.tag.size(), (int)ctags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rows, rs, err, edge_subs.get())) return die(err);
         lap("write binary side output");
     }
     if (par_simple.empty() && getenv("DISCO_PAR_SIMPLE")) { /* runDisco.sh:166-167: <out>/graph/<name> and <out>/assembly/<name> */
@@ -414,7 +444,7 @@ int main(int argc, char **argv)
     if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags)) return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
-    if (!disco::write_edges(prefix, (int)etags.tag.size(), edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr, &etags)) return die(err);
+    if (!disco::write_edges(prefix, (int)etags.tag.size(), edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr, &etags, edge_subs.get())) return die(err);
     lap("write edges");
     if (!disco::write_checkpoint(prefix, false, true, true, err)) return die(err);
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;

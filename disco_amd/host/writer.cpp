@@ -159,7 +159,7 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
 }
 
 bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const ReadSet &rs, int threads, std::string &err,
-                 const uint16_t *edge_file, const FileTags *tags)
+                 const uint16_t *edge_file, const FileTags *tags, const uint16_t *edge_subs)
 {
     const uint64_t n = rs.size();
     const size_t ne = n_edges;
@@ -219,7 +219,8 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
             p = put_u64(p, rs.file_index[e.src]); *p++ = '\t';
             p = put_u64(p, rs.file_index[e.dst]); *p++ = '\t';
             p = put_u64(p, e.orient); *p++ = ',';
-            p = put_u64(p, ovl); memcpy(p, ",0,0,", 5); p += 5;
+            p = put_u64(p, ovl); *p++ = ',';
+            p = put_u64(p, edge_subs ? edge_subs[item[k] >> 2] : 0); memcpy(p, ",0,", 3); p += 3; /* :815-816 substitutions, edits */
             p = put_u64(p, e.len_src); *p++ = ',';
             p = put_u64(p, e.offset); *p++ = ',';
             p = put_u64(p, e.len_src - 1); *p++ = ',';
@@ -269,7 +270,7 @@ struct BinEdge {
     uint64_t src, dst;
     uint32_t orient, offset, len_src, len_dst;
     uint16_t file, flag;
-    uint32_t pad;
+    uint32_t subs;
 };
 struct BinContained {
     uint64_t contained, super;
@@ -302,7 +303,7 @@ bool write_records(const std::string &path, const char *magic, const std::vector
 } // namespace
 
 bool write_binary(const std::string &prefix, int n_edge_files, int n_contained_files, const disco_edge *edges, size_t n_edges, const uint16_t *edge_file,
-                  std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err)
+                  std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err, const uint16_t *edge_subs)
 {
     const uint64_t n = rs.size();
     std::vector<BinEdge> be(n_edges);
@@ -318,7 +319,7 @@ bool write_binary(const std::string &prefix, int n_edge_files, int n_contained_f
         o.len_dst = e.len_dst;
         o.file = edge_file ? (uint16_t)std::min<int>(edge_file[i], n_edge_files - 1) : (uint16_t)owner_of(e.src, n, n_edge_files);
         o.flag = 2; /* the files are cut along connected components: both ends have all their edges in this file */
-        o.pad = 0;
+        o.subs = edge_subs ? edge_subs[i] : 0;
     }
     if (!write_records(prefix + "_edges.bin", "DISCOEDG", be, n_edge_files, err)) return false;
     std::vector<BinEdge>().swap(be);

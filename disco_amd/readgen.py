@@ -96,6 +96,20 @@ def generate_codes(spec: GenSpec, r0: int = 0, r1: int | None = None, ids=None):
     return b, off
 
 
+def substitute(codes, off, seed: int, rate_ppm: int, r0: int = 0):
+    """numpy twin of disco_substituted_base (csrc/readgen.h): base p of read r0 + i is replaced with probability rate_ppm / 10^6"""
+    n = len(off) - 1
+    length = (off[1:] - off[:-1]).astype(np.int64)
+    rid = np.repeat(np.arange(n, dtype=np.uint64) + np.uint64(r0), length)
+    p = (np.arange(int(off[-1]), dtype=np.int64) - off[:-1].astype(np.int64)[np.repeat(np.arange(n), length)]).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        h = mix64((np.uint64(seed) * np.uint64(0x9FB21C651E98DF25)) ^ ((rid << np.uint64(15)) | p))
+    hit = (h % np.uint64(1000000)) < np.uint64(rate_ppm)
+    out = np.asarray(codes, dtype=np.uint8).copy()
+    out[hit] = ((out[hit].astype(np.uint64) + np.uint64(1) + (h[hit] >> np.uint64(40)) % np.uint64(3)) & np.uint64(3)).astype(np.uint8)
+    return out
+
+
 _ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 

@@ -127,6 +127,10 @@ int disco_upload_reads(disco_ctx *ctx, const uint64_t *packed, uint32_t stride_w
 int disco_adopt_reads(disco_ctx *ctx, const void *d_packed, uint32_t stride_words, const void *d_len, uint64_t n);
 /* generate synthetic reads directly in HBM (bench / tests) */
 int disco_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
+/* substitution errors into the resident reads, in place (bench / tests of the inexact-overlap extension): every base of this
+ * context's reads — of the rank's own range in the multi-GPU flow — is replaced by another one with probability rate_ppm / 10^6,
+ * a pure function of (seed, read, position) (csrc/readgen.h; numpy twin: disco_amd/readgen.py). Before disco_build_index. */
+int disco_substitute_bases(disco_ctx *ctx, uint64_t seed, uint32_t rate_ppm);
 /* copy the packed reads / lengths back to the host (tests, writer) */
 int disco_download_reads(disco_ctx *ctx, uint64_t *packed, uint16_t *len);
 uint32_t disco_stride_words(const disco_ctx *ctx);

@@ -124,3 +124,70 @@ def test_inexact_through_three_ranks():
     assert info["regime"] == 1
     assert np.array_equal(_subs_by_edge(edges, subs[0]), _subs_by_edge(he, hs))
     assert np.array_equal(canon_hip(edges, rows)[1], canon_hip(he, hr)[1])
+
+
+@pytest.mark.parametrize("how", ["cli", "cfg", "two_ranks"])
+def test_buildg_writes_the_substitutions_column(tmp_path, how):
+    """the drop-in's files in inexact mode: every edge line of the oracle's rule, with its count in the third number of the info
+    column (where the reference writes "no substitutions", BG/OverlapGraph.cpp:815), text and binary side output alike"""
+    import os
+    import subprocess
+
+    from disco_amd import build, edgefile
+
+    build.build_host()
+    codes, off = _mutated(121, 3000, 100, 220, 30.0, 0.005)
+    reads = readgen.codes_to_reads(codes, off)
+    fa = tmp_path / "r.fasta"
+    readgen.write_fasta(str(fa), reads)
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\n" + ("MaxSubstitutions4BuildGraph = 2\n" if how == "cfg" else ""))
+    prefix = str(tmp_path / "g")
+    cmd = [os.path.join(os.path.dirname(build.HERE), "disco_amd", "bin", "buildG"), "-se", str(fa), "-f", prefix, "-p", str(cfg), "-t", "2", "--binary-out"]
+    if how != "cfg":
+        cmd += ["--max-substitutions", "2"]
+    if how == "two_ranks":
+        cmd += ["--gpus", "2", "--same-device"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    assert "MaxSubstitutions4BuildGraph = 2" in p.stdout
+    got = []
+    for t in range(2):
+        for line in open(f"{prefix}_{t}_parGraph.txt"):
+            a, b, info = line.rstrip("\n").split("\t")
+            f = info.split(",")
+            assert f[3] == "0"  # edits
+            got.append((int(a) - 1, int(b) - 1, int(f[0]), int(f[5]), int(f[2])))  # src, dst, orient, start1 = offset, substitutions
+    got = np.array(sorted(got), dtype=np.int64)
+    orows, oe, oc, osubs = pyoracle.build_graph_inexact(codes, off, 40, 2)
+    assert np.array_equal(got, _subs_by_edge(oe, osubs))
+    assert got[:, 4].max() == 2
+    rec, _ = edgefile.read_edges(prefix + "_edges.bin")
+    binr = np.stack([rec["src"].astype(np.int64) - 1, rec["dst"].astype(np.int64) - 1, rec["orient"].astype(np.int64), rec["offset"].astype(np.int64),
+                     rec["substitutions"].astype(np.int64)], axis=1)
+    assert np.array_equal(binr[np.lexsort((binr[:, 3], binr[:, 2], binr[:, 1], binr[:, 0]))], got)
+    texts = edgefile.text_files(prefix)
+    for t in range(2):
+        path = f"{prefix}_{t}_parGraph.txt"
+        assert sorted(open(path).read().splitlines()) == sorted(texts[path].splitlines())
+    n_rows = sum(1 for t in range(2) for _ in open(f"{prefix}_{t}_containedReads.txt"))
+    assert n_rows == oc["n_contained"]
+
+
+def test_device_error_model_equals_its_numpy_twin():
+    """disco_substitute_bases (the error model of the bench / scale probes) against readgen.substitute, and the graph of such reads
+    against the oracle"""
+    spec = readgen.GenSpec.coverage(131, 3000, 100, 30.0, len_max=170)
+    codes, off = readgen.generate_codes(spec)
+    mut = readgen.substitute(codes, off, 9, 5000)
+    assert 0.003 < (mut != codes).mean() < 0.007
+    packed, lens = readgen.pack_reads(mut, off)
+    with buildgraph.BuildGraph(min_overlap=40, max_substitutions=2) as g:
+        g.generate_reads(spec)
+        g.substitute_bases(9, 5000)
+        dp, dl = g.download_reads()
+        assert np.array_equal(dl, lens) and np.array_equal(dp[:, :packed.shape[1]], packed) and not dp[:, packed.shape[1]:].any()
+        g.run_graph()
+        he, hs, hc = g.fetch_edges(), g.fetch_edge_substitutions(), g.counters()
+    orows, oe, oc, osubs = pyoracle.build_graph_inexact(mut, off, 40, 2)
+    assert np.array_equal(_subs_by_edge(he, hs), _subs_by_edge(oe, osubs)) and hc["n_contained"] == oc["n_contained"]

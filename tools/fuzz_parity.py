@@ -1,5 +1,7 @@
 """differential fuzzing: HIP path (C-ABI) vs the CPU oracle on random generator settings.
-   python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1]"""
+   python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1] [inexact]
+   with "inexact": every data set gets sequencing errors and a random substitution threshold (the f-4 extension, checked against
+   the oracle's statement of the same rule, substitutions per edge included)"""
 import os, sys, time, traceback
 os.environ.setdefault('DISCO_ORDER_MIN_READS', '1')  # the grouped verify order on every data set, however small
 sys.path.insert(0, '.')
@@ -9,6 +11,7 @@ from tests.util import assert_parity
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+inexact = len(sys.argv) > 3 and sys.argv[3] == "inexact"
 fails = 0
 t0 = time.time()
 for it in range(iters):
@@ -27,8 +30,12 @@ for it in range(iters):
     nc = int(rng.integers(1, 6))
     skew = int(rng.random() < 0.3)
     err = float(rng.choice([0, 0, 0, 0.002, 0.01]))
+    tsub = 0
+    if inexact:
+        err = float(rng.choice([0.001, 0.003, 0.006, 0.012]))
+        tsub = int(rng.choice([1, 2, 3, 5, 9, 40]))
     seed = int(rng.integers(1, 1 << 30))
-    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} err={err}"
+    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} err={err} tsub={tsub}"
     try:
         spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
         reads = list(readgen.generate_reads(spec))
@@ -58,7 +65,7 @@ for it in range(iters):
         if rng.random() < 0.2:  # exact and reverse-complement duplicates
             comp = str.maketrans("ACGT", "TGCA")
             reads += [reads[i] if rng.random() < 0.5 else reads[i].translate(comp)[::-1] for i in rng.integers(0, len(reads), len(reads) // 10)]
-        c = assert_parity(reads, mo, label)
+        c = assert_parity(reads, mo, label, max_substitutions=tsub)
         print("ok  ", label, "e_pre", c["e_pre"], "e_out", c["e_out"], "contained", c["n_contained"], "cap", c["cap_bind_sites"], "asym", c["asymmetric_pairs"], flush=True)
     except Exception as e:
         fails += 1
