@@ -386,7 +386,7 @@ def main():
         except Exception as e:
             out["graph_host_to_host"] = {"failed": str(e)}
     if sharded:  # rank 0's view of the exchanges of the last pass
-        out["config"]["exchanges_rank0"] = {"regime": "regular" if info["regime"] == 0 else "order-dependent (adjacency gathered)",
+        out["config"]["exchanges_rank0"] = {"regime": {0: "regular", 2: "regular after twin completion across ranks"}.get(info["regime"], "order-dependent (adjacency gathered)"),
                                             "tr_rounds": info["tr_rounds"], "tr_deferred": info["tr_deferred"],
                                             "bytes_sent": info["bytes_sent"], "ms": {k: round(v, 3) for k, v in info["ms"].items()},
                                             "ms_pass": round(info["ms_total"], 3)}

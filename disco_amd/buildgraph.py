@@ -99,7 +99,7 @@ ABI = [
 ]
 
 FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
-XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency")
+XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins")
 UNIQUE_ID_BYTES = 128
 DIST_GATHER_READS = 1
 

@@ -271,6 +271,68 @@ __global__ void nref_remote_kernel(const u32 *__restrict__ req, u64 n_req, const
     for (; i < n_req; i += (u64)gridDim.x * blockDim.x) nref[2 * (u64)(req[i] >> 1) + (req[i] & 1u)] = REF_MAKE(base + pos[i], deg[i]);
 }
 
+/* ---- twin completion across ranks (some read dropped a verified hit: real data at their repeats) --------------------------- */
+/* insertEdge puts the twin of every find into the other read's list (BG/OverlapGraph.cpp:614-626). A list can lack a twin only if
+ * its read dropped a hit (twin_check in disco_hip.hip); the drop bitmap is all-gathered, every rank sends {w, twin} for its finds
+ * u -> w into such reads w of OTHER ranks, the owner looks the twin up and appends what is missing to its extras. Wave per own
+ * node; FILL = false counts the items. */
+template <bool FILL>
+__global__ void __launch_bounds__(256) twin_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u16 *__restrict__ len, u64 lo, u64 hi,
+                                                        const u64 *__restrict__ dropbits, ulonglong2 *__restrict__ list, u64 *__restrict__ n_list, u64 cap,
+                                                        u64 *ctr)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    u64 mine = 0;
+    for (u64 u = lo + wave; u < hi; u += nwaves) {
+        const u64 ru = ref[u];
+        const u32 du = REF_DEG(ru), Lu = len[u];
+        for (u32 p0 = 0; p0 < du; p0 += 64) {
+            const u32 p = p0 + lane;
+            const u64 e = p < du ? adj[REF_POS(ru) + p] & ~ADJ_FLAG : 0ull;
+            const u64 w = ADJ_DST(e);
+            const bool take = p < du && (w < lo || w >= hi) && ((dropbits[w >> 6] >> (w & 63)) & 1ull);
+            const u64 mk = __ballot(take);
+            if (!mk) continue;
+            if (!FILL) {
+                mine += __popcll(mk);
+                continue;
+            }
+            const u32 leader = (u32)__ffsll((long long)mk) - 1u;
+            u64 base = 0;
+            if (lane == leader) base = atomicAdd(n_list, (u64)__popcll(mk));
+            base = readlane_u64(base, leader);
+            if (take) {
+                const u64 q = base + __popcll(mk & lane_mask_lt());
+                if (q < cap) list[q] = make_ulonglong2(w, ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lu, u, disco_twin_orient(ADJ_ORI(e)), Lu));
+                else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+            }
+        }
+    }
+    if (!FILL && lane == 0 && mine) atomicAdd(n_list, mine);
+}
+
+/* the owner's side: item {w, twin}; the twin is missing from w's list <=> the pair was found from the other side only */
+__global__ void twin_recv_kernel(const ulonglong2 *__restrict__ items, u64 n_items, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
+                                 u64 *__restrict__ extra_node, u64 *__restrict__ extra_key, u32 *__restrict__ extra_cnt, u32 *__restrict__ n_extra,
+                                 u32 extra_cap, u64 *ctr)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_items; i += (u64)gridDim.x * blockDim.x) {
+        const u64 w = items[i].x, twin = items[i].y;
+        const u64 rw = ref[w];
+        if (adj_find(adj + REF_POS(rw), REF_DEG(rw), twin) >= 0) continue;
+        atomicAdd(&ctr[CTR_ASYM], 1ull);
+        const u32 idx = atomicAdd(n_extra, 1u);
+        if (idx < extra_cap) {
+            extra_node[idx] = w;
+            extra_key[idx] = twin;
+            atomicAdd(&extra_cnt[w], 1u);
+        } else
+            atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+    }
+}
+
 /* ---- emission: surviving half-edges pushed to the owner of the smaller endpoint -------------------------------------- */
 /* An edge (a, b), a < b, is emitted by the owner of a, and survives iff it is unflagged from both ends (BG/OverlapGraph.cpp:
  * 717-718). The owner of b pushes {a, twin} for each of b's unflagged entries (b -> a) with a on a lower rank; twin = the entry

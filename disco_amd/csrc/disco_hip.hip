@@ -2366,6 +2366,89 @@ static int dist_push_survivors(disco_ctx *c)
     return DISCO_OK;
 }
 
+/* ---- some reads dropped a hit (real data: repeats): complete the lists across ranks, then carry on in the regular regime ------ */
+/* Collective. *done = false: too many twins are missing somewhere (or a rank's rows cannot grow in place) — nothing was changed
+ * on any rank and the caller gathers the adjacency instead. */
+static int dist_complete_twins(disco_ctx *c, bool *done, u64 *asym_total)
+{
+    const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo, per = c->per;
+    *done = false;
+    const auto t0 = HClock::now();
+    COMM_CHK(c, c->comm->all_gather(c->d_dropbits + (u64)r * per / 64, c->d_dropbits, per / 8, c->stream));
+    c->dinfo.bytes_sent[DISCO_X_TWINS] += (u64)(G - 1) * (per / 8);
+    c->drop_lo = 0;
+    c->drop_hi = c->n;
+    /* pairs inside the rank: finds of the own nodes into own nodes that dropped something */
+    CHK(twin_check(c, lo, hi));
+    u64 asym = c->h_ctr[CTR_ASYM];
+    /* pairs across ranks: {w, twin} to the owner of w */
+    u64 n_items = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    if (nloc) hipLaunchKernelGGL(twin_push_kernel<false>, dim3(flat_grid(c, nloc * 64)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_len, lo, hi, c->d_dropbits,
+                                 (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(n_items, 1)));
+    CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(n_items, 1)));
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    CHK(zero_counter(c, CTR_OVERFLOW));
+    if (nloc) hipLaunchKernelGGL(twin_push_kernel<true>, dim3(flat_grid(c, nloc * 64)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_len, lo, hi, c->d_dropbits,
+                                 c->d_x16b, c->d_list_n, n_items, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "twin push: the fill pass produced more items than the count pass");
+    std::vector<u64> scnt, rcnt;
+    RouteByNode f{per};
+    CHK(route_items(c, c->d_x16b, n_items, f, c->d_x16a, scnt));
+    CHK(exchange_counts(c, scnt, rcnt));
+    const u64 nr = vsum(rcnt);
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nr, 1)));
+    CHK(a2a_items(c, DISCO_X_TWINS, c->d_x16a, scnt, c->d_x16b, rcnt, sizeof(ulonglong2)));
+    /* room for every received item to turn out missing, behind the extras of the local check */
+    const u64 want = (u64)c->n_extra + nr + 1;
+    if (want > 0xFFFFFFFFull) return fail(c, DISCO_E_CAPACITY, "twin completion: more than 2^32 extras on one rank");
+    if (want > c->extra_cap) {
+        u64 cap_n = c->extra_cap, cap_k = c->extra_cap;
+        CHK(ensure_cap_keep(c, &c->d_extra_node, &cap_n, want, c->n_extra));
+        CHK(ensure_cap_keep(c, &c->d_extra_key, &cap_k, want, c->n_extra));
+        if (cap_n != cap_k) return fail(c, DISCO_E_STATE, "twin completion: extras arrays out of step");
+        c->extra_cap = (u32)std::min<u64>(cap_n, 0xFFFFFFFFull);
+    }
+    CHK(zero_counter(c, CTR_ASYM));
+    CHK(zero_counter(c, CTR_OVERFLOW));
+    if (nr) hipLaunchKernelGGL(twin_recv_kernel, dim3(flat_grid(c, nr)), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_x16b, nr, c->d_adj_ref, c->d_adj, c->d_extra_node,
+                               c->d_extra_key, c->d_extra_cnt, c->d_n_extra, c->extra_cap, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    u32 ne = 0;
+    HIPCHK(c, hipMemcpyAsync(&ne, c->d_n_extra, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    CHK(read_counters(c));
+    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "twin completion: extras list overflow");
+    asym += c->h_ctr[CTR_ASYM];
+    c->n_extra = ne;
+    /* can every rank grow its few rows in place? (merge_extras' sparse path; otherwise nothing has been changed yet) */
+    u64 need = 0;
+    if (ne) {
+        HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(merge_need_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, c->d_bump);
+        HIPCHK(c, hipMemcpyAsync(&need, c->d_bump, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const bool fits = c->d_adj == c->d_hits && ne <= 16384 && c->hits_used + need <= c->hits_cap && !getenv("DISCO_MERGE_REBUILD");
+    u64 v[2] = {fits ? 0ull : 1ull, asym};
+    CHK(host_reduce(c, v, 2));
+    c->dinfo.ms[DISCO_X_TWINS] += ms_since(t0);
+    *asym_total = v[1];
+    if (v[0]) {
+        c->n_extra = 0; /* the gathered adjacency is checked again as a whole */
+        return DISCO_OK;
+    }
+    CHK(merge_extras(c));
+    *done = true;
+    return DISCO_OK;
+}
+
 /* ---- order-dependent regime: everybody gets the whole adjacency and finishes the pass on its own --------------------- */
 static int dist_irregular(disco_ctx *c, const std::vector<u64> &adj_totals)
 {
@@ -2661,17 +2744,32 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
         di.kmer_hits = sum[4];
         di.e_pre = sum[0] / 2;
         c->dropped = sum[1];
-        const bool irregular = sum[1] != 0 || c->n >= (1ull << 30) || c->prm.max_substitutions != 0 || getenv("DISCO_DIST_FORCE_GATHER");
+        bool irregular = c->n >= (1ull << 30) || c->prm.max_substitutions != 0 || getenv("DISCO_DIST_FORCE_GATHER");
+        u64 asym_total = 0;
+        if (!irregular && sum[1] != 0) {
+            /* somebody dropped a hit (per-k-mer cap, second hit to a destination: real data do at their repeats). Only the lists of
+             * the reads that dropped something can lack a twin: complete those across ranks, then the regular regime applies */
+            bool done = false;
+            if (!getenv("DISCO_DIST_NO_TWIN_PUSH")) CHK(dist_complete_twins(c, &done, &asym_total));
+            irregular = !done;
+            if (done) {
+                u64 t[1] = {c->adj_total};
+                CHK(host_reduce(c, t, 1));
+                di.e_pre = t[0] / 2;
+                di.regime = 2;
+            }
+        }
         if (irregular) {
             di.regime = 1;
             CHK(dist_irregular(c, adj_totals));
             di.e_pre = c->adj_total / 2;
             di.asymmetric_pairs = c->asym_local;
         } else {
-            c->phase = 6; /* nobody dropped a hit: the lists are symmetric by construction (twin_check's argument) */
+            c->phase = 6; /* nobody dropped a hit, or the lists have just been completed: they are symmetric (twin_check's argument) */
             c->n_extra = 0;
-            c->asym_local = 0;
-            c->ph_ms[DISCO_PH_TWIN] = 0;
+            c->asym_local = asym_total;
+            di.asymmetric_pairs = asym_total;
+            if (di.regime == 0) c->ph_ms[DISCO_PH_TWIN] = 0;
             CHK(dist_transitive_mark(c));
             CHK(dist_push_survivors(c));
         }

@@ -364,7 +364,10 @@ int main(int argc, char **argv)
                   << "  overlaps (pre-reduction) : " << e_pre << "\n  edges after reduction    : " << e_out << "\n  k-mer probes             : " << di.probes
                   << "\n  k-mer hits               : " << di.kmer_hits << "\n  cap_bind_sites           : " << di.cap_bind_sites
                   << "\n  asymmetric_pairs         : " << di.asymmetric_pairs << "\n  regime                   : "
-                  << (di.regime ? "order-dependent (adjacency gathered)" : "regular (neighbour rows on request)") << "\n"
+                  << (di.regime == 0   ? "regular (neighbour rows on request)"
+                      : di.regime == 2 ? "regular after completing the lists of the reads that dropped a hit across ranks"
+                                       : "order-dependent (adjacency gathered)")
+                  << "\n"
                   << "Function buildOverlapGraph() [" << gpus << " GPU ranks] finished in " << t_graph << " Seconds incl. upload (" << (t_graph > 0 ? e_pre / t_graph : 0)
                   << " overlaps/s); last pass " << di.ms_total * 1e-3 << " Seconds on rank 0." << std::endl;
         if (!max_subs && (di.cap_bind_sites || di.asymmetric_pairs))

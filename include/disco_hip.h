@@ -192,7 +192,8 @@ enum { /* exchanges of one pass (disco_dist_info.bytes_sent) */
     DISCO_X_ROW_REQUESTS,  /* all-to-all: (node, class) row requests + degrees back                    */
     DISCO_X_ROW_DATA,      /* all-to-all: the requested neighbour rows, 4-byte entries                 */
     DISCO_X_PUSH,          /* all-to-all: surviving half-edges to the owner of the smaller endpoint    */
-    DISCO_X_ADJACENCY,     /* order-dependent regime only: all-gather of the whole adjacency            */
+    DISCO_X_ADJACENCY,     /* regime 1 only: all-gather of the whole adjacency                          */
+    DISCO_X_TWINS,         /* regime 2 only: drop bitmap all-gather + all-to-all of {node, twin entry} into reads that dropped a hit */
     DISCO_X_COUNT
 };
 enum { DISCO_DIST_GATHER_READS = 1 }; /* disco_dist_run_graph flags: the pass starts from range-partitioned reads */
@@ -203,7 +204,10 @@ typedef struct disco_dist_info {
     uint64_t e_out_local;                     /* edges this rank emitted (disco_fetch_edges)                  */
     uint64_t n_contained_local;               /* contained rows this rank holds (disco_fetch_contained)       */
     uint64_t cap_bind_sites, asymmetric_pairs, dropped_hits, probes, kmer_hits; /* whole job                  */
-    uint32_t regime;                          /* 0: regular (rows on request); 1: order-dependent (adjacency gathered) */
+    uint32_t regime;                          /* 0: regular (rows on request); 2: the same after completing the lists of the reads
+                                                 that dropped a hit across ranks (per-k-mer cap, second hit to a destination: real
+                                                 data at their repeats); 1: adjacency gathered, every rank finishes on its own
+                                                 (too many one-sided pairs for 2, inexact overlaps, >= 2^30 reads) */
     uint32_t tr_rounds;                       /* request rounds of the transitive reduction (1 or 2)         */
     uint64_t tr_deferred;                     /* nodes redone after the second round, whole job               */
     uint64_t bytes_sent[DISCO_X_COUNT];       /* this rank's payload bytes to OTHER ranks, last pass          */

@@ -37,18 +37,26 @@ def test_ranks_forced_adjacency_gather_equals_reference(G, monkeypatch):
     assert info["regime"] == 1
 
 
-@pytest.mark.parametrize("G", [2, 3])
-def test_ranks_order_dependent_regime_equals_single_gpu(G):
-    """repeats: the cap binds, pairs are found from one side only -> adjacency gathered; result = the single-GPU pass = the oracle"""
+@pytest.mark.parametrize("G,how", [(2, "twins"), (3, "twins"), (5, "twins"), (2, "gather"), (3, "gather"), (3, "rebuild")])
+def test_ranks_order_dependent_regime_equals_single_gpu(G, how, monkeypatch):
+    """repeats: the cap binds, pairs are found from one side only. The lists of the reads that dropped a hit are completed across
+    the ranks and the pass carries on in the regular regime (2); without that exchange — or when a rank's rows cannot grow in
+    place — the adjacency is gathered (1). Result = the single-GPU pass = the oracle, either way"""
     from oracle import pyoracle
 
+    if how == "gather":
+        monkeypatch.setenv("DISCO_DIST_NO_TWIN_PUSH", "1")
+    if how == "rebuild":
+        monkeypatch.setenv("DISCO_MERGE_REBUILD", "1")
     reads, fidx, mo = gu.case_inputs("repeats_8k")
     edges, rows, info, _ = run_ranks_reads(reads, mo, G)
     ce, cc = canon_hip(edges, rows, fidx)
     oce, occ, ocnt = pyoracle.oracle_canonical(reads, fidx, mo)
-    assert info["regime"] == 1 and info["dropped_hits"] > 0
-    assert info["asymmetric_pairs"] == ocnt["asymmetric_pairs"] and info["e_pre"] == ocnt["e_pre"]
+    assert info["regime"] == (2 if how == "twins" else 1) and info["dropped_hits"] > 0
+    assert info["asymmetric_pairs"] == ocnt["asymmetric_pairs"] > 0 and info["e_pre"] == ocnt["e_pre"]
     assert np.array_equal(cc, occ) and np.array_equal(ce, oce)
+    if how == "twins":
+        assert info["bytes_sent"]["twins"] > 0 and info["bytes_sent"]["adjacency"] == 0 and info["bytes_sent"]["row_data"] > 0
 
 
 @pytest.mark.parametrize("G", [2, 4])

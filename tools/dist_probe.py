@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """multi-GPU flow on ONE GPU: G ranks = G host threads over the in-process communicator; prints every rank's exchange
-volumes and timings. usage: dist_probe.py G N_READS [len_min len_max cov passes]"""
+volumes and timings. usage: dist_probe.py G N_READS [len_min len_max cov passes]
+env ERRORS_PPM=n: substitution errors per 10^6 bases (the reads then drop hits at chance repeats: regime 2)"""
 import json
 import os
 import sys
@@ -18,9 +19,18 @@ passes = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 genome = int(n * (lmin + lmax) / 2 / cov)
 spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=max(1, genome // 5_000_000), len_max=lmax)
 t0 = time.time()
-edges, rows, info, infos = run_ranks(G, 40, lambda g: g.dist_generate_reads(spec), passes=passes)
+ppm = int(os.environ.get("ERRORS_PPM", "0"))
+
+
+def setup(g):
+    g.dist_generate_reads(spec)
+    if ppm:
+        g.substitute_bases(7, ppm)
+
+
+edges, rows, info, infos = run_ranks(G, 40, setup, passes=passes)
 print(f"wall {time.time() - t0:.2f} s; e_pre {info['e_pre']} e_out {info['e_out']} contained {info['n_contained']} regime {info['regime']} "
-      f"tr_rounds {info['tr_rounds']} deferred {info['tr_deferred']}")
+      f"tr_rounds {info['tr_rounds']} deferred {info['tr_deferred']} asymmetric_pairs {info['asymmetric_pairs']} dropped {info['dropped_hits']}")
 for i in infos:
     print(json.dumps({"rank": i["rank"], "ms_total": round(i["ms_total"], 2), "MB_sent": {k: round(v / 1e6, 2) for k, v in i["bytes_sent"].items()},
                       "ms": {k: round(v, 2) for k, v in i["ms"].items()}}))
