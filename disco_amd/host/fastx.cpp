@@ -247,6 +247,74 @@ inline uint32_t clean(const char *d, const Rec &r, std::string &buf, uint32_t cn
     return (uint32_t)m;
 }
 
+/* ---- the common record — one line of upper-case ACGT — without the byte-at-a-time passes (x86-64 with AVX2 + BMI2, chosen at run
+ * time; anything else, and every record that is not of that form, takes clean() and the table-driven packer) ---------------------- */
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define DISCO_FAST_RECORDS 1
+/* base counts of d[s, e) if every byte is one of ACGT; false otherwise (newline inside, lower case, N, ...). Reads up to 31 bytes
+ * beyond e: the caller guarantees they exist. */
+__attribute__((target("avx2,bmi2,popcnt"))) inline bool count_acgt(const char *d, size_t s, size_t e, uint32_t cnt[5])
+{
+    const __m256i vA = _mm256_set1_epi8('A'), vC = _mm256_set1_epi8('C'), vG = _mm256_set1_epi8('G'), vT = _mm256_set1_epi8('T');
+    uint32_t a = 0, c = 0, g = 0, t = 0;
+    for (size_t p = s; p < e; p += 32) {
+        const __m256i x = _mm256_loadu_si256((const __m256i *)(d + p));
+        const uint32_t in = e - p >= 32 ? 0xFFFFFFFFu : ((1u << (e - p)) - 1u);
+        const uint32_t ma = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vA)) & in, mc = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vC)) & in;
+        const uint32_t mg = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vG)) & in, mt = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vT)) & in;
+        if ((ma | mc | mg | mt) != in) return false;
+        a += (uint32_t)_mm_popcnt_u32(ma);
+        c += (uint32_t)_mm_popcnt_u32(mc);
+        g += (uint32_t)_mm_popcnt_u32(mg);
+        t += (uint32_t)_mm_popcnt_u32(mt);
+    }
+    cnt[0] = a;
+    cnt[1] = c;
+    cnt[2] = g;
+    cnt[3] = t;
+    cnt[4] = 0;
+    return true;
+}
+
+/* 2-bit packing of L upper-case ACGT characters, MSB first (BG/HashTable.cpp:456-477): eight characters per step — (c >> 1) & 3 is
+ * A0 C1 T2 G3, one xor swaps the last two — gathered with pext. Reads up to 31 bytes beyond the read. */
+__attribute__((target("avx2,bmi2,popcnt"))) inline void pack_acgt(const char *sq, uint32_t L, uint64_t *w)
+{
+    for (uint32_t x0 = 0; x0 < L; x0 += 32) {
+        uint64_t acc = 0;
+        for (int q = 0; q < 4; q++) {
+            uint64_t x;
+            memcpy(&x, sq + x0 + 8 * q, 8);
+            x = __builtin_bswap64(x);
+            uint64_t t = (x >> 1) & 0x0303030303030303ull;
+            t ^= (t >> 1) & 0x0101010101010101ull;
+            acc = (acc << 16) | _pext_u64(t, 0x0303030303030303ull);
+        }
+        const uint32_t nb = std::min<uint32_t>(32, L - x0);
+        if (nb < 32) acc &= ~0ull << (2 * (32 - nb)); /* what lies behind the read */
+        w[x0 >> 5] = acc;
+    }
+}
+/* positions p < n - 1 with s[p] == x and s[p + 1] == y (the occurrences of a motif of two different letters cannot overlap: a plain
+ * count, BG/Common.h:173-183); reads up to 32 bytes beyond s + n */
+__attribute__((target("avx2,bmi2,popcnt"))) inline size_t dimer_hits_padded(const char *s, size_t n, char x, char y)
+{
+    const __m256i vx = _mm256_set1_epi8(x), vy = _mm256_set1_epi8(y);
+    size_t hits = 0;
+    for (size_t p = 0; p + 1 < n; p += 32) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(s + p)), b = _mm256_loadu_si256((const __m256i *)(s + p + 1));
+        uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpeq_epi8(a, vx), _mm256_cmpeq_epi8(b, vy)));
+        const size_t left = n - 1 - p; /* pairs that start in this block and end inside the read */
+        if (left < 32) m &= (1u << left) - 1u;
+        hits += (size_t)_mm_popcnt_u32(m);
+    }
+    return hits;
+}
+#else
+#define DISCO_FAST_RECORDS 0
+#endif
+
 /* record starts of a FASTA blob whose every '>' begins a line, found in parallel; false if the precondition fails */
 bool fasta_starts_parallel(const Blob &b, int threads, std::vector<std::vector<size_t>> &starts)
 {
@@ -301,7 +369,7 @@ struct FilterTables {
 const FilterTables kFilter;
 
 /* Dataset::testRead (BG/Dataset.cpp:403-452) on a cleaned read whose base counts are known (cnt[4] = non-ACGT characters) */
-bool test_read_counted(const char *s, size_t n, const uint32_t cnt[5])
+bool test_read_counted(const char *s, size_t n, const uint32_t cnt[5], bool padded)
 {
     if (n < 30) return false; /* MIN_READ_SIZE */
     if (cnt[4]) return false; /* :411 */
@@ -333,6 +401,12 @@ bool test_read_counted(const char *s, size_t n, const uint32_t cnt[5])
         for (int b = 0; b < 4; b++)
             if (mo.need[b] && cnt[b] < mo.need[b] * qq) skip = true;
         if (skip) continue;
+#if DISCO_FAST_RECORDS
+        if (padded && mo.len == 2 && mo.s[0] != mo.s[1]) { /* 32 readable bytes behind the read: the dimer count 32 positions at a time */
+            if (dimer_hits_padded(s, n, mo.s[0], mo.s[1]) * 2 >= thr) return false;
+            continue;
+        }
+#endif
         if (covered_by(s, n, mo.s, mo.len) >= thr) return false;
     }
     return true;
@@ -342,7 +416,7 @@ bool test_read(const char *s, size_t n)
 {
     uint32_t cnt[5] = {0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; i++) cnt[kCode.t[(unsigned char)s[i]]]++;
-    return test_read_counted(s, n, cnt);
+    return test_read_counted(s, n, cnt, false);
 }
 
 bool load_reads(const std::vector<std::string> &pe, const std::vector<std::string> &se, uint32_t min_overlap, int threads,
@@ -356,6 +430,9 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
         if (verbose) fprintf(stderr, "[disco host] %-28s %.3f s\n", what, t - t_last);
         t_last = t;
     };
+#if DISCO_FAST_RECORDS
+    const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !getenv("DISCO_NO_FAST_RECORDS");
+#endif
     std::vector<std::pair<std::string, bool>> inputs;
     for (auto &f : pe) inputs.push_back({f, true});
     for (auto &f : se) inputs.push_back({f, false});
@@ -417,20 +494,42 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
                 std::vector<uint64_t> &ar = arenas[fi][t];
                 for (size_t i = nr0 * (size_t)t / threads; i < nr0 * (size_t)(t + 1) / threads; i++) {
                     uint32_t cnt[5];
-                    const uint32_t L = clean(b.data, R[i], buf, cnt);
+                    uint32_t L = 0;
+                    const char *seq = nullptr;
+                    bool fast_rec = false;
+#if DISCO_FAST_RECORDS
+                    if (fast) { /* one line of upper-case ACGT, used where it lies in the file */
+                        const size_t rs0 = R[i].s, re0 = (R[i].e > rs0 && b.data[R[i].e - 1] == '\n') ? R[i].e - 1 : R[i].e;
+                        if (re0 - rs0 <= 32767 && re0 + 32 <= b.n && count_acgt(b.data, rs0, re0, cnt)) {
+                            L = (uint32_t)(re0 - rs0);
+                            seq = b.data + rs0;
+                            fast_rec = true;
+                        }
+                    }
+#endif
+                    if (!fast_rec) {
+                        L = clean(b.data, R[i], buf, cnt);
+                        seq = buf.data();
+                    }
                     if (L > 32767) { /* the packed layout has the reference's 15-bit length field; the reference itself keeps such reads */
-                        if (L > min_overlap && test_read_counted(buf.data(), L, cnt)) {
+                        if (L > min_overlap && test_read_counted(seq, L, cnt, fast_rec)) {
 #pragma omp atomic
                             out.too_long++;
                         }
                         continue;
                     }
-                    if (!(L > min_overlap && test_read_counted(buf.data(), L, cnt))) continue; /* BG/Dataset.cpp:305 */
+                    if (!(L > min_overlap && test_read_counted(seq, L, cnt, fast_rec))) continue; /* BG/Dataset.cpp:305 */
                     G[i] = (uint16_t)L;
                     const size_t w0 = ar.size(), W = (L + 31) / 32;
                     ar.resize(w0 + W, 0);
                     uint64_t *w = &ar[w0];
-                    const unsigned char *bs = (const unsigned char *)buf.data();
+#if DISCO_FAST_RECORDS
+                    if (fast_rec) {
+                        pack_acgt(seq, L, w);
+                        continue;
+                    }
+#endif
+                    const unsigned char *bs = (const unsigned char *)seq;
                     for (uint32_t x0 = 0; x0 < L; x0 += 32) { /* MSB first, 2 bits per base: BG/HashTable.cpp:456-477 */
                         const uint32_t nb = std::min<uint32_t>(32, L - x0);
                         uint64_t acc = 0;
