@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -12,16 +13,57 @@ namespace disco {
 
 namespace {
 
+/* decimal digits two at a time, written in place (the edge files are 2.5 GB of numbers at 45 M edges) */
+struct DigitPairs {
+    char t[200];
+    DigitPairs()
+    {
+        for (int i = 0; i < 100; i++) {
+            t[2 * i] = (char)('0' + i / 10);
+            t[2 * i + 1] = (char)('0' + i % 10);
+        }
+    }
+};
+const DigitPairs kPairs;
+
 inline char *put_u64(char *p, uint64_t v)
 {
-    char tmp[24];
-    int n = 0;
-    do {
-        tmp[n++] = (char)('0' + v % 10);
-        v /= 10;
-    } while (v);
-    while (n) *p++ = tmp[--n];
-    return p;
+    if (v < 10) {
+        *p++ = (char)('0' + v);
+        return p;
+    }
+    if (v < 100) {
+        memcpy(p, kPairs.t + 2 * v, 2);
+        return p + 2;
+    }
+    if (v < 1000) {
+        const uint32_t x = (uint32_t)v;
+        *p = (char)('0' + x / 100);
+        memcpy(p + 1, kPairs.t + 2 * (x % 100), 2);
+        return p + 3;
+    }
+    int n = 4;
+    for (uint64_t x = v / 10000; x; x /= 10) n++;
+    char *q = p + n;
+    if (v <= 0xFFFFFFFFull) { /* 32-bit divisions */
+        uint32_t x = (uint32_t)v;
+        while (x >= 100) {
+            q -= 2;
+            memcpy(q, kPairs.t + 2 * (x % 100), 2);
+            x /= 100;
+        }
+        if (x >= 10) memcpy(q - 2, kPairs.t + 2 * x, 2);
+        else *(q - 1) = (char)('0' + x);
+        return p + n;
+    }
+    while (v >= 100) {
+        q -= 2;
+        memcpy(q, kPairs.t + 2 * (v % 100), 2);
+        v /= 100;
+    }
+    if (v >= 10) memcpy(q - 2, kPairs.t + 2 * v, 2);
+    else *(q - 1) = (char)('0' + v);
+    return p + n;
 }
 
 /* node v belongs to file owner(v): contiguous id ranges. A node is "marked" in its owner's file, where ALL its edges are
@@ -164,6 +206,12 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
     const uint64_t n = rs.size();
     const size_t ne = n_edges;
     if (threads < 1) threads = 1;
+    const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
+    double t_last = omp_get_wtime();
+    auto lap = [&](const char *what) {
+        if (verbose) fprintf(stderr, "[disco host]   write_edges %-22s %.3f s\n", what, omp_get_wtime() - t_last);
+        t_last = omp_get_wtime();
+    };
     /* an edge goes to the file that owns its source and, if different, to the file that owns its destination: bucket the
      * (edge, file, flag) items by file with a counting sort, then format fixed-size chunks of items in parallel */
     std::vector<uint64_t> cnt((size_t)n_files + 1, 0);
@@ -194,6 +242,7 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
             }
         }
     }
+    lap("bucket by file");
     const uint64_t CH = 1 << 16;
     const uint64_t n_chunks = (n_items + CH - 1) / CH;
     std::vector<std::string> text(n_chunks);
@@ -212,6 +261,11 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
         o.reserve((range[c].second - range[c].first) * 56);
         char buf[200];
         for (uint64_t k = range[c].first; k < range[c].second; k++) {
+            if (k + 16 < range[c].second) { /* the destination's file index is a random 8-byte fetch out of 8 n bytes */
+                const disco_edge &nx = edges[item[k + 16] >> 2];
+                __builtin_prefetch(&rs.file_index[nx.dst]);
+                __builtin_prefetch(&rs.file_index[nx.src]);
+            }
             const disco_edge &e = edges[item[k] >> 2];
             const int flag = (int)(item[k] & 3);
             const uint64_t ovl = (uint64_t)e.len_src - e.offset; /* :814 */
@@ -230,6 +284,7 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
             o.append(buf, (size_t)(p - buf));
         }
     }
+    lap("format");
     /* one writer per file, chunks in order */
     std::vector<size_t> first_chunk((size_t)n_files + 1, 0);
     for (size_t c = 0; c < chunk_file.size(); c++) first_chunk[chunk_file[c] + 1] = c + 1;
@@ -256,6 +311,7 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
         uint64_t first = n_files ? (uint64_t)(((__uint128_t)n * (unsigned)t + n_files - 1) / n_files) + 1 : 1;
         flush(prefix + "_" + tag_of(tags, t) + "_startRead.txt", std::to_string(first) + "\n", e2);
     }
+    lap("write");
     return ok;
 }
 
