@@ -1091,7 +1091,9 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
      * every list (real data always drop something at their repeats: 95 -> 5 ms at 50 M reads with 0.3 % errors) */
     const bool by_bitmap = c->prm.max_substitutions == 0 && c->d_dropbits && lo >= c->drop_lo && hi <= c->drop_hi && !getenv("DISCO_FORCE_TWIN_CHECK");
     a.dropbits = by_bitmap ? c->d_dropbits : nullptr;
-    if (!by_bitmap) {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
+    /* (inexact overlaps: one-sided pairs are the rule — a substitution inside an end k-mer hides the pair from the other read —
+     * so the proof of symmetry is not attempted) */
+    if (!by_bitmap && c->prm.max_substitutions == 0) {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
         CHK(zero_counter(c, CTR_ASYM));
         CHK(zero_counter(c, CTR_TW_UP));
         CHK(zero_counter(c, CTR_TW_DOWN));
@@ -1115,7 +1117,7 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
             return DISCO_OK;
         }
     }
-    u32 want = 4096;
+    u32 want = std::max<u32>(4096, c->extra_cap); /* the lists kept from the last pass are the best guess */
     for (int attempt = 0; attempt < 6; attempt++) {
         if (want > c->extra_cap) {
             dev_free(c, &c->d_extra_node, c->extra_cap);
@@ -1198,7 +1200,7 @@ static int merge_extras(disco_ctx *c)
         HIPCHK(c, hipGetLastError());
         CHK(read_counters(c));
         const u64 maxdeg = c->h_ctr[CTR_MAX_DEG];
-        const int g = (int)std::min<u64>(c->n, 256);
+        const int g = (int)std::min<u64>(c->n, (u64)c->n_cu * 32); /* one wavefront per row at a time */
         scratch_n = (u64)g * (maxdeg + 1);
         CHK(dev_alloc(c, &scratch, scratch_n));
         hipLaunchKernelGGL(merge_sort_kernel, dim3(g), dim3(64), 0, c->stream, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);

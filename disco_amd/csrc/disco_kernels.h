@@ -1625,33 +1625,46 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
         const u64 s = REF_POS(ru);
         const u32 Lu = a.v.len[u];
         const bool u_in = (u >= a.lo && u < a.hi);
-        for (u32 p = lane; p < du; p += 64) {
-            const u64 ent = a.adj[s + p] & ~ADJ_FLAG;
+        for (u32 p0 = 0; p0 < du; p0 += 64) { /* wave-uniform trips: the missing twins of a trip are appended with ONE atomic */
+            const u32 p = p0 + lane;
+            bool search = p < du;
+            const u64 ent = search ? a.adj[s + p] & ~ADJ_FLAG : 0ull;
             const u64 w = ADJ_DST(ent);
-            if (a.up_only) {
+            if (search && a.up_only) {
                 if (w < u) { /* a down-find, counted at its source */
                     n_down += u_in ? 1u : 0u;
-                    continue;
+                    search = false;
+                } else if (w < a.lo || w >= a.hi)
+                    search = false;
+                else
+                    n_up++;
+            } else if (search && (w < a.lo || w >= a.hi))
+                search = false;
+            if (search && a.dropbits && !((a.dropbits[w >> 6] >> (w & 63)) & 1ull)) search = false;
+            bool miss = false;
+            u64 twin = 0;
+            if (search) {
+                const u32 Lw = ADJ_DLEN(ent);
+                twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent)), Lu); /* :617-619 */
+                const u64 rw = a.ref[w];
+                miss = adj_find(a.adj + REF_POS(rw), REF_DEG(rw), twin) < 0;
+            }
+            asym += miss ? 1u : 0u;
+            const u64 mk = __ballot(miss && !a.up_only);
+            if (mk) {
+                const u32 leader = (u32)__ffsll((long long)mk) - 1u;
+                u32 base = 0;
+                if (lane == leader) base = atomicAdd(a.n_extra, (u32)__popcll(mk));
+                base = (u32)__builtin_amdgcn_readlane((int)base, (int)leader);
+                const u32 idx = base + (u32)__popcll(mk & lane_mask_lt());
+                const bool put = miss && !a.up_only;
+                if (put && idx < a.extra_cap) {
+                    a.extra_node[idx] = w;
+                    a.extra_key[idx] = twin;
+                    atomicAdd(&a.extra_cnt[w], 1u);
                 }
-                if (w < a.lo || w >= a.hi) continue;
-                n_up++;
-            } else if (w < a.lo || w >= a.hi)
-                continue;
-            if (a.dropbits && !((a.dropbits[w >> 6] >> (w & 63)) & 1ull)) continue;
-            const u32 Lw = ADJ_DLEN(ent);
-            const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(ent) - Lu, u, disco_twin_orient(ADJ_ORI(ent)), Lu); /* :617-619 */
-            const u64 rw = a.ref[w];
-            if (adj_find(a.adj + REF_POS(rw), REF_DEG(rw), twin) < 0) {
-                asym++;
-                if (!a.up_only) {
-                    u32 idx = atomicAdd(a.n_extra, 1u);
-                    if (idx < a.extra_cap) {
-                        a.extra_node[idx] = w;
-                        a.extra_key[idx] = twin;
-                        atomicAdd(&a.extra_cnt[w], 1u);
-                    } else
-                        atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-                }
+                const u64 over = __ballot(put && idx >= a.extra_cap); /* the sizing pass overflows by design: one atomic per trip */
+                if (over && lane == leader) atomicAdd(&a.v.ctr[CTR_OVERFLOW], (u64)__popcll(over));
             }
         }
     }
@@ -1743,18 +1756,25 @@ __global__ void __launch_bounds__(64) merge_sparse_kernel(const u64 *__restrict_
     }
 }
 
-/* sort (ascending) the rows that received extras through a global scratch row */
+/* sort (ascending) the rows that received extras: up to 64 entries in registers (one bitonic network), longer rows through a global
+ * scratch row */
 __global__ void __launch_bounds__(64) merge_sort_kernel(const u32 *__restrict__ extra_cnt, const u64 *__restrict__ new_start,
                                                         u64 *__restrict__ new_adj, u64 n, u64 *__restrict__ scratch, u64 scratch_cap)
 {
     u64 *tmp = scratch + (u64)blockIdx.x * scratch_cap;
+    const u32 lane = threadIdx.x;
     for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
         if (!extra_cnt[v]) continue;
         u64 s = new_start[v];
         u32 d = (u32)(new_start[v + 1] - s);
-        wave_rank_sort(new_adj + s, tmp, d, threadIdx.x);
+        if (d <= 64) {
+            const u64 x = wave_bitonic_sort(lane < d ? new_adj[s + lane] : ~0ull, lane); /* entries are < ~0: the padding sorts behind them */
+            if (lane < d) new_adj[s + lane] = x;
+            continue;
+        }
+        wave_rank_sort(new_adj + s, tmp, d, lane);
         __syncthreads();
-        for (u32 i = threadIdx.x; i < d; i += 64) new_adj[s + i] = tmp[i];
+        for (u32 i = lane; i < d; i += 64) new_adj[s + i] = tmp[i];
         __syncthreads();
     }
 }
