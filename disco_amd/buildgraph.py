@@ -82,6 +82,9 @@ ABI = [
     ("disco_memcpy_d2d", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("disco_fetch_edge_files", C.c_int64, [_P, C.c_uint32, _P, C.c_uint64]),
     ("disco_partition_edges", C.c_int64, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    ("disco_contract_chains", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("disco_contract_chains_of", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("disco_fetch_chains", C.c_int, [_P, _P, _P, _P]),
     ("disco_set_query_order", C.c_int, [_P, _P]),
     ("disco_get_query_order", C.c_int, [_P, C.POINTER(_P)]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
@@ -102,6 +105,10 @@ FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
 XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins")
 UNIQUE_ID_BYTES = 128
 DIST_GATHER_READS = 1
+
+
+CHAIN_EDGE_DTYPE = np.dtype([("a", "<u8"), ("b", "<u8"), ("offset", "<u8"), ("orient", "<u4"), ("n_links", "<u4"), ("first_link", "<u8")])
+CHAIN_LINK_DTYPE = np.dtype([("to", "<u4"), ("offset", "<u4"), ("orient", "<u4")])
 
 
 class DistInfo(C.Structure):
@@ -295,6 +302,24 @@ class BuildGraph:
         if n:
             self._chk(self.L.disco_fetch_edges(self._h, out.ctypes.data, n))
         return out
+
+    def contract_chains(self, min_overlap_simplify: int = 0, edges=None):
+        """chains of the reduced graph as composite edges (disco_contract_chains; with `edges`: disco_contract_chains_of on that array).
+        Returns (composite edges [CHAIN_EDGE_DTYPE], links [CHAIN_LINK_DTYPE], absorbed flag per edge)"""
+        nc, nl = C.c_uint64(), C.c_uint64()
+        if edges is None:
+            self._chk(self.L.disco_contract_chains(self._h, min_overlap_simplify, C.byref(nc), C.byref(nl)))
+            ne = int(self.L.disco_fetch_edges(self._h, None, 0))
+        else:
+            edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+            self._chk(self.L.disco_contract_chains_of(self._h, edges.ctypes.data, len(edges), min_overlap_simplify, C.byref(nc), C.byref(nl)))
+            ne = len(edges)
+        comp = np.zeros(nc.value, dtype=CHAIN_EDGE_DTYPE)
+        links = np.zeros(nl.value, dtype=CHAIN_LINK_DTYPE)
+        absorbed = np.zeros(ne, dtype=np.uint8)
+        self._chk(self.L.disco_fetch_chains(self._h, comp.ctypes.data if len(comp) else None, links.ctypes.data if len(links) else None,
+                                            absorbed.ctypes.data if ne else None))
+        return comp, links, absorbed
 
     def fetch_edge_substitutions(self) -> np.ndarray:
         """substitutions of every edge's overlap, in the order of fetch_edges (all 0 unless max_substitutions > 0)"""

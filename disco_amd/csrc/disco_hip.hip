@@ -29,6 +29,7 @@
 #include "../../include/disco_hip.h"
 #include "disco_kernels.h"
 #include "disco_dist.h"
+#include "disco_chains.h"
 #include "disco_comm.h"
 
 static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
@@ -156,6 +157,12 @@ struct disco_ctx {
     u32 wide_cap = 0, n_wide = 0;
     u8 *d_out_valid = nullptr;
     u64 *d_out_pos = nullptr;
+    /* chain contraction (disco_contract_chains): composite edges, their links, absorbed flag per edge in fetch order */
+    ChainEdgeOut *d_ch_comp = nullptr;
+    ChainLinkOut *d_ch_links = nullptr;
+    u8 *d_ch_dead = nullptr;
+    u64 ch_comp_n = 0, ch_links_n = 0, ch_edges_n = 0, ch_comp_cap = 0, ch_links_cap = 0, ch_dead_cap = 0;
+    bool ch_ready = false;
     u64 *d_out_src = nullptr, *d_out_ent = nullptr;
     u64 out_used = 0; /* chunk slots written by the emission (survivors + ~0 tails) */
     u64 n_out = 0;
@@ -414,6 +421,11 @@ static void free_graph_state(disco_ctx *c)
     c->wide_cap = 0;
     c->adj_total = c->adj_cap = c->flag_cap = 0;
     dev_free(c, &c->d_out_valid, c->valid_cap);
+    dev_free(c, &c->d_ch_comp, c->ch_comp_cap);
+    dev_free(c, &c->d_ch_links, c->ch_links_cap);
+    dev_free(c, &c->d_ch_dead, c->ch_dead_cap);
+    c->ch_comp_cap = c->ch_links_cap = c->ch_dead_cap = 0;
+    c->ch_ready = false;
     dev_free(c, &c->d_out_pos, c->valid_cap + 1);
     dev_free(c, &c->d_out_src, c->out_cap);
     dev_free(c, &c->d_out_ent, c->out_cap);
@@ -1794,6 +1806,160 @@ int64_t disco_partition_edges(disco_ctx *c, const disco_edge *edges, uint64_t n_
     dev_free(c, &d_pos, n_edges);
     dev_free(c, &d_valid, n_edges);
     return rc != DISCO_OK ? rc : res;
+}
+
+/* ---- chains of the reduced graph as composite edges (kernels and the argument: disco_chains.h) ------------- */
+static int contract_chains(disco_ctx *c, const u64 *d_src, const u64 *d_ent, const u8 *d_valid, const u64 *d_pos, u64 n_slots, u64 ne, u64 n, u32 min_ovl)
+{
+    c->ch_ready = false;
+    if (n_slots >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "chain contraction: more than 2^31 edge slots");
+    ChainView g;
+    g.src = d_src;
+    g.ent = d_ent;
+    g.valid = d_valid;
+    g.pos = d_pos;
+    g.len = c->d_len;
+    g.n_slots = n_slots;
+    g.min_ovl = min_ovl;
+    u32 *deg = nullptr, *he = nullptr, *links_of = nullptr, *live = nullptr;
+    u8 *internal = nullptr, *is_head = nullptr;
+    ChRank *ra = nullptr, *rb = nullptr;
+    u64 *comp_id = nullptr, *link_start = nullptr;
+    const u64 n_half = 2 * n_slots;
+    int rc = DISCO_OK;
+    auto body = [&]() -> int {
+        CHK(dev_alloc(c, &deg, n));
+        CHK(dev_alloc(c, &he, 2 * n));
+        CHK(dev_alloc(c, &internal, n));
+        CHK(dev_alloc(c, &ra, n_half));
+        CHK(dev_alloc(c, &rb, n_half));
+        CHK(dev_alloc(c, &live, 1));
+        HIPCHK(c, hipMemsetAsync(deg, 0, n * sizeof(u32), c->stream));
+        hipLaunchKernelGGL(ch_degree_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, g, deg, he);
+        hipLaunchKernelGGL(ch_internal_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, g, deg, he, n, internal);
+        hipLaunchKernelGGL(ch_init_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, g, internal, he, ra);
+        HIPCHK(c, hipGetLastError());
+        /* a chain of L half-edges is ranked after ceil(log2 L) rounds; rings never finish: 32 rounds bound every list of < 2^32 elements */
+        for (int round = 0; round < 32; round++) {
+            u32 h_live = 0;
+            HIPCHK(c, hipMemsetAsync(live, 0, sizeof(u32), c->stream));
+            hipLaunchKernelGGL(ch_jump_kernel, dim3(flat_grid(c, n_half)), dim3(256), 0, c->stream, ra, rb, n_half, live);
+            HIPCHK(c, hipMemcpyAsync(&h_live, live, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::swap(ra, rb);
+            if (!h_live) break;
+        }
+        dev_free(c, &rb, n_half);
+        dev_free(c, &deg, n);
+        CHK(dev_alloc(c, &is_head, n_slots));
+        CHK(dev_alloc(c, &links_of, n_slots));
+        CHK(ensure_cap(c, &c->d_ch_dead, &c->ch_dead_cap, std::max<u64>(ne, 1)));
+        HIPCHK(c, hipMemsetAsync(c->d_ch_dead, 0, std::max<u64>(ne, 1), c->stream));
+        hipLaunchKernelGGL(ch_heads_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, g, internal, ra, is_head, links_of, c->d_ch_dead);
+        CHK(dev_alloc(c, &comp_id, n_slots + 1));
+        CHK(dev_alloc(c, &link_start, n_slots + 1));
+        u64 n_comp = 0, n_links = 0;
+        CHK((scan_exclusive<u8, u64>(c, is_head, n_slots, comp_id, false, &n_comp)));
+        CHK((scan_exclusive<u32, u64>(c, links_of, n_slots, link_start, false, &n_links)));
+        CHK(ensure_cap(c, &c->d_ch_comp, &c->ch_comp_cap, std::max<u64>(n_comp, 1)));
+        CHK(ensure_cap(c, &c->d_ch_links, &c->ch_links_cap, std::max<u64>(n_links, 1)));
+        hipLaunchKernelGGL(ch_emit_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, g, internal, ra, comp_id, link_start, c->d_ch_comp, c->d_ch_links);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->ch_comp_n = n_comp;
+        c->ch_links_n = n_links;
+        c->ch_edges_n = ne;
+        c->ch_ready = true;
+        return DISCO_OK;
+    };
+    rc = body();
+    dev_free(c, &deg, n);
+    dev_free(c, &he, 2 * n);
+    dev_free(c, &internal, n);
+    dev_free(c, &ra, n_half);
+    dev_free(c, &rb, n_half);
+    dev_free(c, &live, 1);
+    dev_free(c, &is_head, n_slots);
+    dev_free(c, &links_of, n_slots);
+    dev_free(c, &comp_id, n_slots + 1);
+    dev_free(c, &link_start, n_slots + 1);
+    return rc;
+}
+
+int disco_contract_chains(disco_ctx *c, uint32_t min_overlap_simplify, uint64_t *n_composite, uint64_t *n_links)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_contract_chains: run disco_transitive_reduce first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_out == 0) {
+        c->ch_comp_n = c->ch_links_n = c->ch_edges_n = 0;
+        c->ch_ready = true;
+    } else
+        CHK(contract_chains(c, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos, c->out_used, c->n_out, c->n, min_overlap_simplify));
+    if (n_composite) *n_composite = c->ch_comp_n;
+    if (n_links) *n_links = c->ch_links_n;
+    return DISCO_OK;
+}
+
+int disco_contract_chains_of(disco_ctx *c, const disco_edge *edges, uint64_t n_edges, uint32_t min_overlap_simplify, uint64_t *n_composite, uint64_t *n_links)
+{
+    if (!c || (n_edges && !edges)) return DISCO_E_ARG;
+    if (c->phase < 1) return fail(c, DISCO_E_STATE, "disco_contract_chains_of: the context holds no reads (their lengths are needed)");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ch_ready = false;
+    if (n_edges == 0) {
+        c->ch_comp_n = c->ch_links_n = c->ch_edges_n = 0;
+        c->ch_ready = true;
+    } else {
+        u64 *d_src = nullptr, *d_ent = nullptr, *d_pos = nullptr;
+        u8 *d_valid = nullptr;
+        std::unique_ptr<u64[]> hs(new u64[n_edges]), he(new u64[n_edges]);
+        bool bad = false;
+        parallel_for(n_edges, [&](u64 b, u64 e_) {
+            for (u64 i = b; i < e_; i++) {
+                if (edges[i].src >= c->n || edges[i].dst >= c->n) bad = true;
+                hs[i] = edges[i].src;
+                he[i] = ADJ_MAKE(edges[i].offset, edges[i].dst, edges[i].orient, edges[i].len_dst);
+            }
+        });
+        if (bad) return fail(c, DISCO_E_ARG, "disco_contract_chains_of: an edge names a read the context does not hold");
+        int rc = DISCO_OK;
+        do {
+            if ((rc = dev_alloc(c, &d_src, n_edges)) != DISCO_OK) break;
+            if ((rc = dev_alloc(c, &d_ent, n_edges)) != DISCO_OK) break;
+            if ((rc = dev_alloc(c, &d_pos, n_edges)) != DISCO_OK) break;
+            if ((rc = dev_alloc(c, &d_valid, n_edges)) != DISCO_OK) break;
+            if (hipMemcpyAsync(d_src, hs.get(), n_edges * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(d_ent, he.get(), n_edges * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemsetAsync(d_valid, 1, n_edges, c->stream) != hipSuccess) {
+                rc = fail(c, DISCO_E_HIP, "disco_contract_chains_of: upload failed");
+                break;
+            }
+            hipLaunchKernelGGL(iota_u64_kernel, dim3(flat_grid(c, n_edges)), dim3(256), 0, c->stream, d_pos, n_edges);
+            rc = contract_chains(c, d_src, d_ent, d_valid, d_pos, n_edges, n_edges, c->n, min_overlap_simplify);
+        } while (0);
+        dev_free(c, &d_src, n_edges);
+        dev_free(c, &d_ent, n_edges);
+        dev_free(c, &d_pos, n_edges);
+        dev_free(c, &d_valid, n_edges);
+        if (rc != DISCO_OK) return rc;
+    }
+    if (n_composite) *n_composite = c->ch_comp_n;
+    if (n_links) *n_links = c->ch_links_n;
+    return DISCO_OK;
+}
+
+int disco_fetch_chains(disco_ctx *c, disco_chain_edge *comp, disco_chain_link *links, uint8_t *edge_absorbed)
+{
+    if (!c) return DISCO_E_ARG;
+    if (!c->ch_ready) return fail(c, DISCO_E_STATE, "disco_fetch_chains: run disco_contract_chains first");
+    HIPCHK(c, hipSetDevice(c->device));
+    static_assert(sizeof(disco_chain_edge) == sizeof(ChainEdgeOut) && sizeof(disco_chain_link) == sizeof(ChainLinkOut), "chain records");
+    if (comp && c->ch_comp_n) HIPCHK(c, hipMemcpyAsync(comp, c->d_ch_comp, c->ch_comp_n * sizeof(ChainEdgeOut), hipMemcpyDeviceToHost, c->stream));
+    if (links && c->ch_links_n) HIPCHK(c, hipMemcpyAsync(links, c->d_ch_links, c->ch_links_n * sizeof(ChainLinkOut), hipMemcpyDeviceToHost, c->stream));
+    if (edge_absorbed && c->ch_edges_n) HIPCHK(c, hipMemcpyAsync(edge_absorbed, c->d_ch_dead, c->ch_edges_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DISCO_OK;
 }
 
 int disco_set_query_order(disco_ctx *c, const void *d_order_u64)

@@ -248,6 +248,29 @@ int main(int argc, char **argv)
     const double t_parse = secs(t0);
     std::cout << "Function readDataset() finished in " << t_parse << " Seconds." << std::endl;
 
+    if (par_simple.empty() && getenv("DISCO_PAR_SIMPLE")) { /* runDisco.sh:166-167: <out>/graph/<name> and <out>/assembly/<name> */
+        const size_t at = prefix.rfind("/graph/");
+        std::string base, name;
+        bool found = false;
+        if (at != std::string::npos) {
+            base = prefix.substr(0, at + 1);
+            name = prefix.substr(at + 7);
+            found = true;
+        } else if (prefix.compare(0, 6, "graph/") == 0) { /* relative to the output directory itself */
+            name = prefix.substr(6);
+            found = true;
+        }
+        if (found) {
+            par_simple = base + "assembly/" + name;
+            (void)mkdir((base + "assembly").c_str(), 0777); /* runDisco.sh keeps an existing assembly directory ("Will continue previous run") */
+        } else
+            std::cout << "DISCO_PAR_SIMPLE: the output prefix is not <out>/graph/<name>; use --par-simple <prefix>" << std::endl;
+    }
+    /* chains of the reduced graph contracted while it is still on the GPU (the consumer's parsimplify step, --par-simple) */
+    const bool gpu_chains = !par_simple.empty() && !mpi_names && !getenv("DISCO_PAR_SIMPLE_HOST");
+    std::vector<disco_chain_edge> ch_comp;
+    std::unique_ptr<disco_chain_link[]> ch_links;
+    std::unique_ptr<uint8_t[]> ch_absorbed;
     /* ---- graph on the GPU(s) ---------------------------------------------------------------------------------------- */
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
     /* two-pass verify for read sets of mixed lengths (metagenomes: most reads contained): same files, fewer candidate-row fetches;
@@ -309,6 +332,15 @@ int main(int argc, char **argv)
         edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
         if (e_out && disco_fetch_edge_files(ctx, (uint32_t)n_edge_files, edge_file.get(), e_out) < 0) return die(disco_last_error(ctx));
         lap("partition edges into files");
+        if (gpu_chains && e_out) {
+            uint64_t nc = 0, nl = 0;
+            DISCO_CALL(ctx, disco_contract_chains(ctx, min_overlap_simplify, &nc, &nl));
+            ch_comp.resize(nc);
+            ch_links.reset(new disco_chain_link[std::max<uint64_t>(nl, 1)]);
+            ch_absorbed.reset(new uint8_t[e_out]);
+            DISCO_CALL(ctx, disco_fetch_chains(ctx, ch_comp.data(), ch_links.get(), ch_absorbed.get()));
+            lap("contract chains on the GPU");
+        }
         disco_destroy(ctx);
         lap("release GPU context");
     } else {
@@ -402,6 +434,15 @@ int main(int argc, char **argv)
         edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
         if (e_out && disco_partition_edges(ctx[0], edges.get(), e_out, rs.size(), (uint32_t)n_edge_files, edge_file.get()) < 0) return die(disco_last_error(ctx[0]));
         lap("partition edges into files");
+        if (gpu_chains && e_out) { /* the ranks' edges lie on the host: rank 0's context, which holds every read's length, contracts them */
+            uint64_t nc = 0, nl = 0;
+            DISCO_CALL(ctx[0], disco_contract_chains_of(ctx[0], edges.get(), e_out, min_overlap_simplify, &nc, &nl));
+            ch_comp.resize(nc);
+            ch_links.reset(new disco_chain_link[std::max<uint64_t>(nl, 1)]);
+            ch_absorbed.reset(new uint8_t[e_out]);
+            DISCO_CALL(ctx[0], disco_fetch_chains(ctx[0], ch_comp.data(), ch_links.get(), ch_absorbed.get()));
+            lap("contract chains on the GPU");
+        }
         for (auto c : ctx) disco_destroy(c);
         lap("release GPU contexts");
     }
@@ -413,27 +454,17 @@ int main(int argc, char **argv)
         if (!disco::write_binary(prefix, (int)etags.tag.size(), (int)ctags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rows, rs, err, edge_subs.get())) return die(err);
         lap("write binary side output");
     }
-    if (par_simple.empty() && getenv("DISCO_PAR_SIMPLE")) { /* runDisco.sh:166-167: <out>/graph/<name> and <out>/assembly/<name> */
-        const size_t at = prefix.rfind("/graph/");
-        std::string base, name;
-        bool found = false;
-        if (at != std::string::npos) {
-            base = prefix.substr(0, at + 1);
-            name = prefix.substr(at + 7);
-            found = true;
-        } else if (prefix.compare(0, 6, "graph/") == 0) { /* relative to the output directory itself */
-            name = prefix.substr(6);
-            found = true;
-        }
-        if (found) {
-            par_simple = base + "assembly/" + name;
-            (void)mkdir((base + "assembly").c_str(), 0777); /* runDisco.sh keeps an existing assembly directory ("Will continue previous run") */
-        } else
-            std::cout << "DISCO_PAR_SIMPLE: the output prefix is not <out>/graph/<name>; use --par-simple <prefix>" << std::endl;
-    }
     if (!par_simple.empty() && !mpi_names) {
         disco::ParSimpleStats ps;
-        if (!disco::write_par_simple(par_simple, (int)etags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rs, min_overlap_simplify, threads, err, &ps))
+        disco::ChainSeed seed;
+        if (ch_absorbed) {
+            seed.comp = ch_comp.data();
+            seed.n_comp = ch_comp.size();
+            seed.links = ch_links.get();
+            seed.absorbed = ch_absorbed.get();
+        }
+        if (!disco::write_par_simple(par_simple, (int)etags.tag.size(), edges.get(), e_out, e_out ? edge_file.get() : nullptr, rs, min_overlap_simplify, threads, err, &ps,
+                                     nullptr, nullptr, nullptr, ch_absorbed ? &seed : nullptr))
             return die(err);
         std::cout << "Partial simplification (the reference's parsimplify step) on the resident graph: " << ps.edges_in << " edges -> " << ps.edges_out << " ("
                   << ps.nodes_absorbed << " nodes absorbed into composite edges, " << ps.dead_end_nodes << " dead-end nodes, " << ps.rounds << " rounds); files "

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <tuple>
 
 namespace disco {
 
@@ -69,8 +70,9 @@ struct Graph {
 
 bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const uint16_t *edge_file, const ReadSet &rs,
                       uint32_t min_ovl_simplify, int threads, std::string &err, ParSimpleStats *stats, const FileTags *tags,
-                      const std::vector<std::string> *paths, const uint8_t *marked)
+                      const std::vector<std::string> *paths, const uint8_t *marked, const ChainSeed *seed)
 {
+    if (marked) seed = nullptr;
     const uint64_t n = rs.size();
     if (threads < 1) threads = 1;
     const double t_begin = omp_get_wtime();
@@ -84,13 +86,14 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             const int t = omp_get_thread_num(), nt = omp_get_num_threads();
             const size_t lo = n_edges * (size_t)t / nt, hi = n_edges * (size_t)(t + 1) / nt;
             uint64_t c = 0;
-            for (size_t i = lo; i < hi; i++) c += edges[i].len_src - edges[i].offset >= min_ovl_simplify; /* SG/OverlapGraphSimple.cpp:589 */
+            for (size_t i = lo; i < hi; i++)
+                c += edges[i].len_src - edges[i].offset >= min_ovl_simplify && !(seed && seed->absorbed[i]); /* SG/OverlapGraphSimple.cpp:589 */
             first[(size_t)t + 1] = c;
 #pragma omp barrier
 #pragma omp single
             {
                 for (int k = 0; k < nt; k++) first[(size_t)k + 1] += first[(size_t)k];
-                g.e.resize(first[(size_t)nt]);
+                g.e.resize(first[(size_t)nt] + (seed ? seed->n_comp : 0));
             }
             uint64_t at = first[(size_t)t];
             for (size_t i = lo; i < hi; i++) {
@@ -98,7 +101,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
                 /* all edges of a node lie in one file (connected components), so concurrent writers agree */
                 const uint16_t f = edge_file ? (uint16_t)std::min<int>(edge_file[i], n_files - 1) : 0;
                 node_file[x.src] = node_file[x.dst] = f;
-                if (x.len_src - x.offset < min_ovl_simplify) continue;
+                if (x.len_src - x.offset < min_ovl_simplify || (seed && seed->absorbed[i])) continue;
                 PEdge &p = g.e[at++];
                 p.a = (uint32_t)x.src;
                 p.b = (uint32_t)x.dst;
@@ -109,6 +112,27 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
     }
     ParSimpleStats st{};
     st.edges_in = g.e.size();
+    if (seed && seed->n_comp) { /* the chains arrive contracted: the composite edges behind the simple ones */
+        const uint64_t base = g.e.size() - seed->n_comp;
+        uint64_t absorbed_edges = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : absorbed_edges) num_threads(threads)
+        for (uint64_t k = 0; k < seed->n_comp; k++) {
+            const disco_chain_edge &ce = seed->comp[k];
+            PEdge &p = g.e[base + k];
+            p.a = (uint32_t)ce.a;
+            p.b = (uint32_t)ce.b;
+            p.offset = (uint32_t)ce.offset;
+            p.orient = (uint8_t)ce.orient;
+            p.links.resize(ce.n_links);
+            for (uint32_t i = 0; i < ce.n_links; i++) {
+                const disco_chain_link &l = seed->links[ce.first_link + i];
+                p.links[i] = Link{l.to, l.offset, (uint8_t)l.orient};
+            }
+            absorbed_edges += ce.n_links;
+        }
+        st.edges_in += absorbed_edges - seed->n_comp; /* as loaded by the stand-alone step: every simple edge */
+        st.nodes_absorbed += absorbed_edges - seed->n_comp;
+    }
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
     double t_last = t_begin;
     auto lap = [&](const char *what) {
@@ -240,7 +264,7 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
                     if (h > (last ^ 1)) continue; /* the walk from the other end builds it */
                     PEdge c;
                     compose(path, c);
-                    my_merged += c.links.size() - 1;
+                    my_merged += path.size() - 1; /* nodes absorbed NOW: the edges of the chain minus one (their links may hold nodes of earlier rounds) */
                     mine.push_back(std::move(c));
                 }
             }
@@ -257,15 +281,23 @@ bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *
             internal[v] = 0; /* anchor */
             PEdge c;
             std::vector<uint64_t> path;
-            trace(half[start[v]], (uint32_t)v, &path);
+            /* which way round: the reference decides by comparing pointers (SG/OverlapGraphSimple.cpp:456-470), i.e. arbitrarily; here by
+             * the CONTENT of the anchor's two half-edges, so that the order in which the edges arrived (threads, GPU-contracted chains
+             * or not) cannot show in the files */
+            uint64_t h_first = half[start[v]], h_other = half[start[v] + 1];
+            {
+                auto key = [&](uint64_t h) { return std::make_tuple(g.dst(h), g.offset(h), g.orient(h), g.e[h >> 1].links.size()); };
+                if (key(h_other) < key(h_first)) std::swap(h_first, h_other);
+            }
+            trace(h_first, (uint32_t)v, &path);
             compose(path, c);
-            merged += c.links.size() - 1;
+            merged += path.size() - 1;
             seen[v] = 1;
             fresh.push_back(std::move(c));
         }
         if (merged) {
             std::vector<PEdge> next;
-            next.reserve(g.e.size() - merged + fresh.size());
+            next.reserve(g.e.size() - merged); /* the chains' edges (merged + one per chain) go, one composite edge per chain comes */
             for (uint64_t i = 0; i < g.e.size(); i++)
                 if (!dead_edge[i]) next.push_back(std::move(g.e[i]));
             for (PEdge &c : fresh) next.push_back(std::move(c));

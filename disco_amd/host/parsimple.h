@@ -30,13 +30,23 @@ struct ParSimpleStats {
     uint64_t edges_in, edges_out, nodes_absorbed, dead_end_nodes, dead_end_edges, rounds;
 };
 
+/* the chains of the graph already contracted on the GPU (disco_contract_chains + disco_fetch_chains): the edges flagged in
+ * `absorbed` are not loaded, the composite edges are; what remains for the host is the rings, the dead ends and the later rounds */
+struct ChainSeed {
+    const disco_chain_edge *comp = nullptr;
+    uint64_t n_comp = 0;
+    const disco_chain_link *links = nullptr;
+    const uint8_t *absorbed = nullptr; /* [n_edges] */
+};
+
 /* edges / edge_file as for write_edges (file = connected component set, so no chain crosses files); min_ovl_simplify =
  * MinOverlap4SimplifyGraph (disco.cfg:38; edges below it are dropped at load, SG/OverlapGraphSimple.cpp:589) */
 bool write_par_simple(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const uint16_t *edge_file, const ReadSet &rs,
                       uint32_t min_ovl_simplify, int threads, std::string &err, ParSimpleStats *stats = nullptr, const FileTags *tags = nullptr,
                       const std::vector<std::string> *paths = nullptr /* explicit output file names, one per file */,
                       const uint8_t *marked = nullptr /* [n reads] nodes all of whose edges are in their file (flags 0 / 1 / 2 of the edge
-                                                         lines, SG/OverlapGraphSimple.cpp:591-644); null: every node, as in buildG's files */);
+                                                         lines, SG/OverlapGraphSimple.cpp:591-644); null: every node, as in buildG's files */,
+                      const ChainSeed *seed = nullptr /* only with marked == null (the GPU contraction knows no marks) */);
 
 } // namespace disco
 #endif

@@ -276,6 +276,31 @@ int disco_set_query_order(disco_ctx *ctx, const void *d_order_u64);
 /* the order the last disco_probe walked: device pointer to q_hi - q_lo entries owned by the context, read id in bits 31..0 and
  * the read's length in bits 47..32 (the kernels carry the length with the id); NULL = file order */
 int disco_get_query_order(disco_ctx *ctx, const void **d_order_u64);
+/* ---- chains of the reduced graph as composite edges ---------------------------------------------------- */
+/* The consumer's first step on the files this stage writes is parsimplify: every maximal chain of nodes with exactly two edges that
+ * leave them from opposite ends becomes one composite edge carrying the reads inside it (contractParCompositeEdges,
+ * SG/OverlapGraphSimple.cpp:69-109,313-500; is_mergeable / mergeEdges, SG/EdgeSimple.cpp:214-272). disco_contract_chains does that
+ * contraction on the edges still resident after disco_transitive_reduce — by ranking the chains (pointer jumping), not by walking
+ * them — for the overlaps of at least min_overlap_simplify bases (the consumer's load filter, SG/OverlapGraphSimple.cpp:589).
+ * Rings made of such nodes only are left alone. disco_amd/host/parsimple.cpp takes the result as its starting point. */
+typedef struct disco_chain_edge {
+    uint64_t a, b;       /* end nodes (read ids), stored direction a -> b                                  */
+    uint64_t offset;     /* sum of the links' offsets                                                      */
+    uint32_t orient;     /* (first link & 2) | (last link & 1): mergedEdgeOrientation, SG/EdgeSimple.cpp:272 */
+    uint32_t n_links;    /* >= 2                                                                           */
+    uint64_t first_link; /* its links are links[first_link .. first_link + n_links)                        */
+} disco_chain_edge;
+typedef struct disco_chain_link { /* one simple overlap of the chain, in its direction: into read `to` */
+    uint32_t to, offset, orient;
+} disco_chain_link;
+int disco_contract_chains(disco_ctx *ctx, uint32_t min_overlap_simplify, uint64_t *n_composite, uint64_t *n_links);
+/* the same for edges held by the host (buildG --gpus N: all ranks' edges, concatenated); the context must hold the reads */
+int disco_contract_chains_of(disco_ctx *ctx, const disco_edge *edges, uint64_t n_edges, uint32_t min_overlap_simplify, uint64_t *n_composite,
+                             uint64_t *n_links);
+/* composite edges, their links, and one byte per edge — in the order of disco_fetch_edges, or of the array given to
+ * disco_contract_chains_of — that is 1 if the edge went into a composite edge; null pointers skip an output */
+int disco_fetch_chains(disco_ctx *ctx, disco_chain_edge *comp, disco_chain_link *links, uint8_t *edge_absorbed);
+
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* attainable HBM bandwidth on this device (SURVEY.md §8d "Roofline that bounds the path": nominal AND measured): a

@@ -424,3 +424,46 @@ def test_buildg_par_simple_at_scale_equals_the_reference(tmp_path):
     lines = sorted(open(tmp_path / "assembly" / "x_0_ParSimpleEdges.txt").read().splitlines())
     assert len(lines) == c["par_simple_lines"]
     assert hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest() == c["par_simple_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus,shape", [(1, "uniform"), (1, "metagenome"), (2, "metagenome"), (1, "errors")])
+def test_chains_contracted_on_the_gpu_equal_the_host_walk(tmp_path, gpus, shape):
+    """--par-simple starts from the chains the GPU has contracted by RANKING them (disco_contract_chains, pointer jumping; with
+    several ranks disco_contract_chains_of on the gathered edges); DISCO_PAR_SIMPLE_HOST=1 walks them on the host as the
+    reference does. Same files, line for line — on one long chain per contig, on the ragged graph of a metagenome and on reads
+    with errors (tips, bubbles, dead ends: several rounds)"""
+    from disco_amd import readgen
+
+    build.build_host()
+    if shape == "uniform":
+        spec = readgen.GenSpec.coverage(seed=15, n_reads=400_000, read_len=150, cov=30.0, n_contigs=4)
+    else:
+        spec = readgen.GenSpec.coverage(seed=16, n_reads=400_000, read_len=100, cov=25.0, n_contigs=40, len_max=250, skew=1 if shape == "metagenome" else 0)
+    codes, off = readgen.generate_codes(spec)
+    if shape == "errors":
+        codes = readgen.substitute(codes, off, 3, 2000)
+    fa = str(tmp_path / "r.fasta")
+    readgen.write_fasta(fa, readgen.codes_to_reads(codes, off))
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\nMinOverlap4SimplifyGraph = 45\n")  # a filter that bites: some edges are not loaded
+    out = {}
+    for how in ("gpu", "host"):
+        prefix = str(tmp_path / f"g_{how}")
+        cmd = [os.path.join(BIN, "buildG"), "-se", fa, "-f", prefix, "-p", str(cfg), "-t", "4", "--par-simple", str(tmp_path / f"s_{how}"), "--no-text"]
+        if gpus > 1:
+            cmd += ["--gpus", str(gpus), "--same-device"]
+        env = dict(os.environ, DISCO_VERBOSE="1")
+        if how == "host":
+            env["DISCO_PAR_SIMPLE_HOST"] = "1"
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+        assert p.returncode == 0, p.stdout
+        assert ("contract chains on the GPU" in p.stdout) == (how == "gpu")
+        out[how] = [sorted(open(str(tmp_path / f"s_{how}_{t}_ParSimpleEdges.txt")).read().splitlines()) for t in range(4)]
+        stats = [l for l in p.stdout.splitlines() if l.startswith("Partial simplification")][0]
+        out[how + "_stats"] = stats.split("files")[0].replace(" 1 rounds", " R rounds").replace(" 2 rounds", " R rounds")
+    assert out["gpu"] == out["host"]
+    assert sum(len(x) for x in out["gpu"]) > 0
+    # the same edges in, out and absorbed (the round count differs by the round the GPU did)
+    import re
+    assert re.sub(r"\d+ rounds", "R rounds", out["gpu_stats"]) == re.sub(r"\d+ rounds", "R rounds", out["host_stats"])
