@@ -214,6 +214,7 @@ int main(int argc, char **argv)
         return 1;
     }
     std::cout << "MinOverlap4BuildGraph = " << min_overlap << std::endl;
+    disco::set_writer_threads(threads);
     if (max_subs_cli >= 0) max_subs = (uint32_t)max_subs_cli;
     if (max_subs)
         std::cout << "MaxSubstitutions4BuildGraph = " << max_subs << " (extension: overlaps and containments may differ in that many bases around an exact "

@@ -28,6 +28,8 @@ struct FileTags {
     static FileTags mpi_contained(int ranks, int threads); /* ranks * threads files             */
 };
 
+/* threads of the writer's loops that take no count of their own (buildG: -t) */
+void set_writer_threads(int n);
 bool write_read_id_map(const std::string &prefix, const ReadSet &rs, std::string &err);
 /* every file gets written, empty ones included (the consumer aborts on a missing file) */
 bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err,
