@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-buffers-in / host-structs-out pass")
     ap.add_argument("--no-stage", action="store_true", help="skip the stage wall (FASTA -> files through disco_amd/bin/buildG) at the benched config")
+    ap.add_argument("--errors-ppm", type=int, default=0, help="per-base substitution rate in 10^-6 (SURVEY.md 8d: the optional Illumina-like variant, 1000; "
+                    "not a BASELINE config: implies --no-cpu-baseline --no-stage --no-host-to-host)")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path (RCCL communicator, every exchange) even with one rank")
     return ap.parse_args()
 
@@ -234,6 +236,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse_args()
+    if args.errors_ppm:
+        args.no_cpu_baseline = args.no_stage = args.no_host_to_host = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -265,6 +269,8 @@ def main():
         g.dist_generate_reads(spec)  # every rank generates ITS range of the reads: the inputs are range-partitioned in HBM
     else:
         g.generate_reads(spec)  # inputs resident in HBM before the timed region
+    if args.errors_ppm:
+        g.substitute_bases(args.seed + 1, args.errors_ppm)  # every rank: its own range of the table
 
     def step():
         if not sharded:
@@ -358,7 +364,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.reads} x {args.read_len} bp synthetic reads, {args.coverage:g}x of {n_contigs} x {spec.contig_len} bp "
-                        f"uniform-random contigs, both strands, error-free, min-overlap {args.min_overlap} (k={args.min_overlap - 1}), "
+                        f"uniform-random contigs, both strands, {'error-free' if not args.errors_ppm else f'{args.errors_ppm} substitutions per 10^6 bases (NOT a BASELINE config)'}, min-overlap {args.min_overlap} (k={args.min_overlap - 1}), "
                         f"transitive reduction on, seed {args.seed}",
             "reads": args.reads, "read_len": args.read_len, "min_overlap": args.min_overlap,
             "parallelism": "1 GPU" if not sharded else (

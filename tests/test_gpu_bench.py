@@ -64,3 +64,13 @@ def test_bench_refuses_more_ranks_than_gpus():
 def test_bench_sharded_code_path_with_one_rank():
     d = _run(["--force-distributed", "--no-cpu-baseline"])
     assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["config"]["e_out"] > 0
+
+
+def test_bench_illumina_like_variant():
+    """the optional variant with substitution errors (not a BASELINE config) — fewer overlaps survive the exact
+    compare, and the line says what it was measured on"""
+    clean = _run(["--no-cpu-baseline", "--no-host-to-host"])
+    d = _run(["--errors-ppm", "1000"])
+    assert "1000 substitutions per 10^6 bases" in d["config"]["workload"] and "cpu_baseline" not in d
+    assert 0.5 * clean["config"]["e_pre"] < d["config"]["e_pre"] < clean["config"]["e_pre"]
+    assert d["config"]["e_out"] > clean["config"]["e_out"]  # broken transitivity leaves more edges
