@@ -10,6 +10,10 @@
  *   (2) outputs of the real reference `buildG` (oracle/_ref/buildG_ref, built from
  *       /root/reference by oracle/Makefile) on seeded inputs, committed under tests/golden/.
  *
+ * The inexact-overlap entry point at the end (oracle_build_graph_inexact, max_subs > 0) is an EXTENSION with no counterpart in the
+ * reference: for that mode parity with the reference is UNPINNED by construction (there is no reference output to pin it to); what
+ * pins it is max_subs = 0 being the pinned restatement and tests/test_oracle_inexact.py (a brute-force statement of the rule).
+ *
  * Every function cites the reference file:line it follows (BG/ = src/BuildGraph/src/).
  * Read IDs here are 0-based ranks among good reads in file order (reference readNumber - 1).
  */
