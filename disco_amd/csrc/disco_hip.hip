@@ -157,6 +157,8 @@ struct disco_ctx {
     u32 wide_cap = 0, n_wide = 0;
     u8 *d_out_valid = nullptr;
     u64 *d_out_pos = nullptr;
+    u64 *h_stage = nullptr; /* pinned: two halves of {sources, entries} for the chunked copy-out of disco_fetch_edges */
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
     /* chain contraction (disco_contract_chains): composite edges, their links, absorbed flag per edge in fetch order */
     ChainEdgeOut *d_ch_comp = nullptr;
     ChainLinkOut *d_ch_links = nullptr;
@@ -531,6 +533,9 @@ void disco_destroy(disco_ctx *c)
     (void)hipFree(c->d_total);
     (void)hipFree(c->d_wq);
     (void)hipFree(c->d_bump);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int i = 0; i < 2; i++)
+        if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     (void)hipFree(c->d_n_big);
     (void)hipFree(c->d_n_extra);
     dev_free(c, &c->d_probe_rare, 1);
@@ -598,10 +603,33 @@ void disco_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride)
+/* keep != null: the caller owns-and-fills the table itself (upload, generator). If the context already holds an owned table of exactly
+ * this shape, NOTHING is freed — table, index, hit buffer, lists all keep their size and the next pass finds them as a repeated pass
+ * does (*keep = true); dropping and re-allocating tens of GB per read set cost 60 ms at best and, on some boxes, 1.2–1.9 s in the
+ * first allocation afterwards */
+static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride, bool *keep = nullptr)
 {
     if (n >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "more than 2^31 reads per context are not supported");
     if (stride == 0 || stride > 1024) return fail(c, DISCO_E_ARG, "stride_words %u out of range", stride);
+    if (keep) {
+        *keep = c->reads_owned && !c->dist_reads && !c->comm && c->d_reads && c->d_len && n > 0 && c->n == n && c->n_alloc == n && c->S == (int)stride &&
+                !getenv("DISCO_NO_BUFFER_REUSE");
+        if (*keep) {
+            c->h_len.clear();
+            c->n_out = c->out_used = 0;
+            c->adj_total = 0;
+            c->flags_pending = false;
+            c->adj_imported = false;
+            c->ch_ready = false;
+            c->d_adj = nullptr;
+            c->d_order_used = nullptr;
+            c->dist_active = false;
+            c->q_lo = 0;
+            c->q_hi = n;
+            c->phase = 0;
+            return DISCO_OK;
+        }
+    }
     free_graph_state(c);
     free_reads(c);
     c->n = n;
@@ -636,13 +664,32 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
     HIPCHK(c, hipSetDevice(c->device));
     /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
     const uint32_t dstride = (stride_words + 7u) & ~7u;
-    CHK(set_reads_common(c, n, dstride));
-    CHK(dev_alloc(c, &c->d_reads, n * (u64)dstride));
-    CHK(dev_alloc(c, &c->d_len, n));
+    bool kept = false;
+    CHK(set_reads_common(c, n, dstride, &kept));
+    if (!kept) {
+        CHK(dev_alloc(c, &c->d_reads, n * (u64)dstride));
+        CHK(dev_alloc(c, &c->d_len, n));
+    }
     c->reads_owned = true;
     if (n) {
-        if (dstride != stride_words) HIPCHK(c, hipMemsetAsync(c->d_reads, 0, n * (u64)dstride * 8, c->stream));
-        HIPCHK(c, hipMemcpy2DAsync(c->d_reads, (size_t)dstride * 8, packed, (size_t)stride_words * 8, (size_t)stride_words * 8, n, hipMemcpyHostToDevice, c->stream));
+        if (dstride != stride_words) {
+            /* narrower host rows (150 bp: 5 of the 8 words): ONE dense copy at the link's rate and a kernel that spreads the rows over the
+             * table — a 2-D copy of 40-byte rows ran at 8.7 GB/s (buildG, config 3: 0.23 s for 2 GB) */
+            u64 *dense = nullptr;
+            HIPCHK(c, hipMemsetAsync(c->d_reads, 0, n * (u64)dstride * 8, c->stream));
+            if (dev_alloc(c, &dense, n * (u64)stride_words) == DISCO_OK) {
+                hipError_t e1 = hipMemcpyAsync(dense, packed, n * (u64)stride_words * 8, hipMemcpyHostToDevice, c->stream);
+                hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, n * (u64)stride_words)), dim3(256), 0, c->stream, dense, (int)dstride, (int)stride_words, (u64)n, (u64)0,
+                                   (u64)0, c->d_reads);
+                hipError_t e2 = hipStreamSynchronize(c->stream);
+                dev_free(c, &dense, n * (u64)stride_words);
+                if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_upload_reads: copy failed");
+            } else { /* no room for the staging copy next to the table: row by row */
+                c->err.clear();
+                HIPCHK(c, hipMemcpy2DAsync(c->d_reads, (size_t)dstride * 8, packed, (size_t)stride_words * 8, (size_t)stride_words * 8, n, hipMemcpyHostToDevice, c->stream));
+            }
+        } else /* (a 2-D copy whose width equals both pitches still ran at a third of this one's rate: 181 against 61 ms for 3.2 GB) */
+            HIPCHK(c, hipMemcpyAsync(c->d_reads, packed, n * (u64)dstride * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_len, len, n * 2, hipMemcpyHostToDevice, c->stream));
     }
     c->h_len.assign(len, len + n);
@@ -667,9 +714,12 @@ int disco_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
         return fail(c, DISCO_E_ARG, "disco_generate_reads: bad spec");
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t stride = (((s->len_max + 31) / 32) + 7u) & ~7u; /* 64-B aligned rows */
-    CHK(set_reads_common(c, s->n_reads, stride));
-    CHK(dev_alloc(c, &c->d_reads, c->n * (u64)stride));
-    CHK(dev_alloc(c, &c->d_len, c->n));
+    bool kept = false;
+    CHK(set_reads_common(c, s->n_reads, stride, &kept));
+    if (!kept) {
+        CHK(dev_alloc(c, &c->d_reads, c->n * (u64)stride));
+        CHK(dev_alloc(c, &c->d_len, c->n));
+    }
     c->reads_owned = true;
     disco_genspec g;
     memcpy(&g, s, sizeof g);
@@ -1627,31 +1677,61 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edges: need room for %llu edges", (unsigned long long)ne);
     if (ne == 0) return 0;
     CHK(ensure_host_len(c));
-    /* drop the unused chunk tails of the emission, then copy out */
+    /* drop the unused chunk tails of the emission, then copy out: chunk k travels into pinned staging memory (kept by the context) while
+     * the host threads turn chunk k - 1 into disco_edge records — a copy into pageable memory ran at a third of the link's rate */
     u64 *csrc = nullptr, *cent = nullptr;
     CHK(dev_alloc(c, &csrc, ne));
     CHK(dev_alloc(c, &cent, ne));
     hipLaunchKernelGGL(emit_compact_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos, c->out_used, csrc, cent);
-    std::unique_ptr<u64[]> hs(new u64[ne]), he(new u64[ne]); /* not zero-filled: 0.7 GB at 45 M edges */
-    hipError_t e1 = hipMemcpyAsync(hs.get(), csrc, ne * 8, hipMemcpyDeviceToHost, c->stream);
-    hipError_t e2 = hipMemcpyAsync(he.get(), cent, ne * 8, hipMemcpyDeviceToHost, c->stream);
-    hipError_t e3 = hipStreamSynchronize(c->stream);
+    const u64 CHUNK = 1ull << 22; /* 4 M edges: 2 x 32 MB per buffer */
+    if (!c->h_stage) {
+        if (hipHostMalloc((void **)&c->h_stage, 4 * CHUNK * sizeof(u64)) != hipSuccess) c->h_stage = nullptr;
+        for (int i = 0; i < 2 && c->h_stage; i++)
+            if (hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipHostFree(c->h_stage);
+                c->h_stage = nullptr;
+            }
+    }
+    const u16 *hlen = c->h_len.data();
+    auto convert = [&](const u64 *hsp, const u64 *hep, u64 base, u64 cnt) {
+        parallel_for(cnt, [&, hlen, hsp, hep, base](u64 b, u64 e_) {
+            for (u64 i = b; i < e_; i++) {
+                disco_edge &e = out[base + i];
+                e.src = hsp[i];
+                e.dst = ADJ_DST(hep[i]);
+                e.orient = ADJ_ORI(hep[i]);
+                e.offset = ADJ_OFF(hep[i]);
+                e.len_src = hlen[e.src];
+                e.len_dst = ADJ_DLEN(hep[i]);
+            }
+        });
+    };
+    bool ok = true;
+    if (c->h_stage) {
+        const u64 nch = (ne + CHUNK - 1) / CHUNK;
+        auto issue = [&](u64 k) {
+            u64 *hs = c->h_stage + (k & 1) * 2 * CHUNK, *he = hs + CHUNK;
+            const u64 cnt = std::min(CHUNK, ne - k * CHUNK);
+            ok = ok && hipMemcpyAsync(hs, csrc + k * CHUNK, cnt * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                 hipMemcpyAsync(he, cent + k * CHUNK, cnt * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                 hipEventRecord(c->ev_stage[k & 1], c->stream) == hipSuccess;
+        };
+        issue(0);
+        for (u64 k = 0; k < nch && ok; k++) {
+            ok = hipEventSynchronize(c->ev_stage[k & 1]) == hipSuccess;
+            if (k + 1 < nch) issue(k + 1); /* into the other half, converted one iteration ago */
+            if (ok) convert(c->h_stage + (k & 1) * 2 * CHUNK, c->h_stage + (k & 1) * 2 * CHUNK + CHUNK, k * CHUNK, std::min(CHUNK, ne - k * CHUNK));
+        }
+        ok = (hipStreamSynchronize(c->stream) == hipSuccess) && ok;
+    } else { /* no pinned memory to be had: one pageable copy */
+        std::unique_ptr<u64[]> hs(new u64[ne]), he(new u64[ne]); /* not zero-filled: 0.7 GB at 45 M edges */
+        ok = hipMemcpyAsync(hs.get(), csrc, ne * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+             hipMemcpyAsync(he.get(), cent, ne * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        if (ok) convert(hs.get(), he.get(), 0, ne);
+    }
     dev_free(c, &csrc, ne);
     dev_free(c, &cent, ne);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_fetch_edges: copy failed");
-    const u16 *hlen = c->h_len.data();
-    const u64 *hsp = hs.get(), *hep = he.get();
-    parallel_for(ne, [&, hlen, hsp, hep](u64 b, u64 e_) {
-        for (u64 i = b; i < e_; i++) {
-            disco_edge &e = out[i];
-            e.src = hsp[i];
-            e.dst = ADJ_DST(hep[i]);
-            e.orient = ADJ_ORI(hep[i]);
-            e.offset = ADJ_OFF(hep[i]);
-            e.len_src = hlen[e.src];
-            e.len_dst = ADJ_DLEN(hep[i]);
-        }
-    });
+    if (!ok) return fail(c, DISCO_E_HIP, "disco_fetch_edges: copy failed");
     return (int64_t)ne;
 }
 

@@ -274,3 +274,31 @@ def test_two_pass_verify_on_repeats_equals_oracle():
     oce, occ, ocnt = pyoracle.oracle_canonical(reads, fidx, mo)
     assert np.array_equal(cc, occ) and np.array_equal(ce, oce)
     assert c["e_pre"] == ocnt["e_pre"] and c["asymmetric_pairs"] == ocnt["asymmetric_pairs"]
+
+
+def test_read_sets_of_the_same_shape_reuse_the_buffers():
+    """a context that gets another read set of the same (n, stride) keeps every buffer (disco_upload_reads / disco_generate_reads:
+    nothing freed, nothing re-allocated) — the results must be those of a fresh context, also when the new set needs MORE room
+    (ten times the coverage: the hit buffer overflows and is regrown) and when it comes from the other entry point"""
+    from tests.util import canon_hip
+
+    n = 20_000
+    specs = [readgen.GenSpec.coverage(61, n, 150, 20.0), readgen.GenSpec.coverage(62, n, 150, 200.0), readgen.GenSpec.coverage(63, n, 100, 30.0, len_max=250),
+             readgen.GenSpec.coverage(64, n, 150, 30.0, n_contigs=3)]
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        for i, spec in enumerate(specs):
+            if i % 2 == 0:
+                g.generate_reads(spec)
+            else:
+                g.upload_ascii(readgen.generate_reads(spec))
+            g.run_graph()
+            got = canon_hip(g.fetch_edges(), g.fetch_contained())
+            cnt = g.counters()
+            with buildgraph.BuildGraph(min_overlap=40) as f:
+                f.generate_reads(spec)
+                f.run_graph()
+                want = canon_hip(f.fetch_edges(), f.fetch_contained())
+                wcnt = f.counters()
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), i
+            for k in ("e_pre", "e_out", "n_contained", "kmer_hits", "probes"):
+                assert cnt[k] == wcnt[k], (i, k)
