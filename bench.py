@@ -386,7 +386,7 @@ def main():
         try:
             h2h = g.host_to_host_pass()
             h2h["overlaps_per_s"] = e_pre / (h2h["total_ms"] * 1e-3)
-            h2h["what"] = ("pinned packed reads in host memory -> disco_upload_reads -> whole pass (first pass: pays its allocations) -> "
+            h2h["what"] = ("pinned packed reads in host memory -> disco_upload_reads -> whole pass (the context keeps its buffers for a read set of the same shape) -> "
                            "disco_fetch_contained + disco_fetch_edges into host structs")
             out["graph_host_to_host"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in h2h.items()}
         except Exception as e:

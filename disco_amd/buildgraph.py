@@ -444,8 +444,8 @@ class BuildGraph:
     def host_to_host_pass(self) -> dict:
         """SURVEY.md §8(d) 'graph' wall: packed reads in (pinned) HOST memory -> upload -> whole graph pass -> contained rows and
         edges in HOST structs. Uses the reads the context currently holds: they are downloaded first (untimed) into pinned
-        memory, then everything device-side is dropped and rebuilt from the host copy (so the pass pays its allocations, like a
-        real single-shot run). Returns milliseconds per part."""
+        memory and uploaded again (a read set of the same shape: the context keeps its buffers, as a service that processes one
+        sample after the other would). Returns milliseconds per part."""
         import time
 
         n, s = self.num_reads, self.stride_words
