@@ -572,8 +572,8 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
     out.packed = nullptr;
     if (alloc.alloc) out.packed = (uint64_t *)alloc.alloc(std::max<size_t>(words, 1) * 8);
     if (!out.packed) {
-        out.packed_fallback.assign(std::max<size_t>(words, 1), 0);
-        out.packed = out.packed_fallback.data();
+        out.packed_fallback.reset(new uint64_t[std::max<size_t>(words, 1)]);
+        out.packed = out.packed_fallback.get();
         out.alloc = HostAlloc{};
     }
     out.len.resize(n);
@@ -621,7 +621,7 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
 
 ReadSet::~ReadSet()
 {
-    if (packed && alloc.free && packed != packed_fallback.data()) alloc.free(packed);
+    if (packed && alloc.free && packed != packed_fallback.get()) alloc.free(packed);
 }
 
 } // namespace disco

@@ -14,6 +14,7 @@
 #define DISCO_FASTX_H_
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -37,7 +38,7 @@ struct ReadSet {
     uint32_t stride_words = 0;
     uint64_t n_reads = 0;
     uint64_t *packed = nullptr;       /* [n][stride_words], from `alloc` or packed_fallback */
-    std::vector<uint64_t> packed_fallback;
+    std::unique_ptr<uint64_t[]> packed_fallback; /* NOT zero-filled: the packer writes every word of every row */
     HostAlloc alloc;
     std::vector<uint16_t> len;        /* [n]                                  */
     std::vector<uint64_t> file_index; /* [n] 1-based index over all records   */
