@@ -30,6 +30,7 @@
 #include "disco_kernels.h"
 #include "disco_dist.h"
 #include "disco_chains.h"
+#include "disco_text.h"
 #include "disco_comm.h"
 
 static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
@@ -165,6 +166,8 @@ struct disco_ctx {
     u8 *d_ch_dead = nullptr;
     u64 ch_comp_n = 0, ch_links_n = 0, ch_edges_n = 0, ch_comp_cap = 0, ch_links_cap = 0, ch_dead_cap = 0;
     bool ch_ready = false;
+    char *d_text = nullptr; /* disco_format_edges: the edge lines of all files, file after file */
+    u64 text_cap = 0, text_bytes = 0;
     u64 *d_out_src = nullptr, *d_out_ent = nullptr;
     u64 out_used = 0; /* chunk slots written by the emission (survivors + ~0 tails) */
     u64 n_out = 0;
@@ -426,6 +429,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_ch_comp, c->ch_comp_cap);
     dev_free(c, &c->d_ch_links, c->ch_links_cap);
     dev_free(c, &c->d_ch_dead, c->ch_dead_cap);
+    dev_free(c, &c->d_text, c->text_cap);
+    c->text_cap = c->text_bytes = 0;
     c->ch_comp_cap = c->ch_links_cap = c->ch_dead_cap = 0;
     c->ch_ready = false;
     dev_free(c, &c->d_out_pos, c->valid_cap + 1);
@@ -1886,6 +1891,82 @@ int64_t disco_partition_edges(disco_ctx *c, const disco_edge *edges, uint64_t n_
     dev_free(c, &d_pos, n_edges);
     dev_free(c, &d_valid, n_edges);
     return rc != DISCO_OK ? rc : res;
+}
+
+/* ---- the edge lines of the text files, formatted where the edges are (disco_text.h) ------------------------------------------ */
+int64_t disco_format_edges(disco_ctx *c, uint32_t n_files, const uint16_t *edge_file, const uint64_t *file_index, uint64_t *file_offsets)
+{
+    if (!c || !file_offsets || n_files == 0) return DISCO_E_ARG;
+    if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_format_edges: run disco_transitive_reduce first");
+    if (n_files > 256) return fail(c, DISCO_E_UNSUPPORTED, "disco_format_edges: more than 256 files (one placement pass per file)");
+    if (c->prm.max_substitutions) return fail(c, DISCO_E_UNSUPPORTED, "disco_format_edges: the substitutions column is written by the host writer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 ne = c->n_out;
+    for (uint32_t f = 0; f <= n_files; f++) file_offsets[f] = 0;
+    c->text_bytes = 0;
+    if (ne == 0) return 0;
+    if (!edge_file && n_files > 1) return fail(c, DISCO_E_ARG, "disco_format_edges: the file of every edge is needed for more than one file");
+    TextView g;
+    g.src = c->d_out_src;
+    g.ent = c->d_out_ent;
+    g.valid = c->d_out_valid;
+    g.pos = c->d_out_pos;
+    g.len = c->d_len;
+    g.n_slots = c->out_used;
+    u64 *d_findex = nullptr, *within = nullptr, *place = nullptr;
+    u8 *bytes = nullptr, *sel = nullptr;
+    u16 *efile = nullptr;
+    auto body = [&]() -> int {
+        if (file_index) {
+            CHK(dev_alloc(c, &d_findex, c->n));
+            HIPCHK(c, hipMemcpyAsync(d_findex, file_index, c->n * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        g.file_index = d_findex;
+        CHK(dev_alloc(c, &bytes, ne));
+        CHK(dev_alloc(c, &sel, ne));
+        CHK(dev_alloc(c, &efile, ne));
+        CHK(dev_alloc(c, &within, ne + 1));
+        CHK(dev_alloc(c, &place, ne));
+        if (edge_file) HIPCHK(c, hipMemcpyAsync(efile, edge_file, ne * sizeof(u16), hipMemcpyHostToDevice, c->stream));
+        else HIPCHK(c, hipMemsetAsync(efile, 0, ne * sizeof(u16), c->stream));
+        hipLaunchKernelGGL(text_measure_kernel, dim3(flat_grid(c, g.n_slots)), dim3(256), 0, c->stream, g, bytes);
+        u64 base = 0;
+        for (uint32_t f = 0; f < n_files; f++) {
+            u64 total = 0;
+            hipLaunchKernelGGL(text_select_kernel, dim3(flat_grid(c, ne)), dim3(256), 0, c->stream, bytes, efile, ne, f, sel);
+            CHK((scan_exclusive<u8, u64>(c, sel, ne, within, false, &total)));
+            hipLaunchKernelGGL(text_place_kernel, dim3(flat_grid(c, ne)), dim3(256), 0, c->stream, within, efile, ne, f, base, place);
+            file_offsets[f] = base;
+            base += total;
+        }
+        file_offsets[n_files] = base;
+        CHK(ensure_cap(c, &c->d_text, &c->text_cap, std::max<u64>(base, 1)));
+        hipLaunchKernelGGL(text_write_kernel, dim3(flat_grid(c, g.n_slots)), dim3(256), 0, c->stream, g, place, c->d_text);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->text_bytes = base;
+        return DISCO_OK;
+    };
+    const int rc = body();
+    dev_free(c, &d_findex, c->n);
+    dev_free(c, &bytes, ne);
+    dev_free(c, &sel, ne);
+    dev_free(c, &efile, ne);
+    dev_free(c, &within, ne + 1);
+    dev_free(c, &place, ne);
+    return rc != DISCO_OK ? rc : (int64_t)c->text_bytes;
+}
+
+int disco_fetch_edge_text(disco_ctx *c, char *out, uint64_t cap)
+{
+    if (!c || (!out && c->text_bytes)) return DISCO_E_ARG;
+    if (cap < c->text_bytes) return fail(c, DISCO_E_ARG, "disco_fetch_edge_text: need room for %llu bytes", (unsigned long long)c->text_bytes);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->text_bytes) {
+        HIPCHK(c, hipMemcpyAsync(out, c->d_text, c->text_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return DISCO_OK;
 }
 
 /* ---- chains of the reduced graph as composite edges (kernels and the argument: disco_chains.h) ------------- */

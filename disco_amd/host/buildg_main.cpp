@@ -273,6 +273,8 @@ int main(int argc, char **argv)
     }
     /* chains of the reduced graph contracted while it is still on the GPU (the consumer's parsimplify step, --par-simple) */
     const bool gpu_chains = !par_simple.empty() && !mpi_names && !getenv("DISCO_PAR_SIMPLE_HOST");
+    std::unique_ptr<char[]> edge_text;      /* the edge lines, formatted on the GPU (single GPU, exact overlaps) */
+    std::vector<uint64_t> edge_text_off;
     std::vector<disco_chain_edge> ch_comp;
     std::unique_ptr<disco_chain_link[]> ch_links;
     std::unique_ptr<uint8_t[]> ch_absorbed;
@@ -337,6 +339,16 @@ int main(int argc, char **argv)
         edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
         if (e_out && disco_fetch_edge_files(ctx, (uint32_t)n_edge_files, edge_file.get(), e_out) < 0) return die(disco_last_error(ctx));
         lap("partition edges into files");
+        /* the edge lines of the text files formatted where the edges are (2.5 GB of numbers at config 3); DISCO_HOST_TEXT=1: by the host writer */
+        if (e_out && !no_text && !max_subs && n_edge_files <= 256 && !getenv("DISCO_HOST_TEXT")) {
+            const bool identity = rs.total_records == rs.size(); /* no record was filtered: file index = read id + 1 */
+            edge_text_off.assign((size_t)n_edge_files + 1, 0);
+            const int64_t nb = disco_format_edges(ctx, (uint32_t)n_edge_files, edge_file.get(), identity ? nullptr : rs.file_index.data(), edge_text_off.data());
+            if (nb < 0) return die(disco_last_error(ctx));
+            edge_text.reset(new char[std::max<int64_t>(nb, 1)]);
+            DISCO_CALL(ctx, disco_fetch_edge_text(ctx, edge_text.get(), (uint64_t)nb));
+            lap("format edge lines on the GPU");
+        }
         if (gpu_chains && e_out) {
             uint64_t nc = 0, nl = 0;
             DISCO_CALL(ctx, disco_contract_chains(ctx, min_overlap_simplify, &nc, &nl));
@@ -483,7 +495,10 @@ int main(int argc, char **argv)
     if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags)) return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
-    if (!disco::write_edges(prefix, (int)etags.tag.size(), edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr, &etags, edge_subs.get())) return die(err);
+    if (edge_text && !no_text) {
+        if (!disco::write_edge_text(prefix, (int)etags.tag.size(), edge_text.get(), edge_text_off.data(), rs.size(), err, &etags)) return die(err);
+    } else if (!disco::write_edges(prefix, (int)etags.tag.size(), edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr, &etags, edge_subs.get()))
+        return die(err);
     lap("write edges");
     if (!disco::write_checkpoint(prefix, false, true, true, err)) return die(err);
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;

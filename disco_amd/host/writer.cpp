@@ -369,6 +369,30 @@ bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges
     return ok;
 }
 
+bool write_edge_text(const std::string &prefix, int n_files, const char *text, const uint64_t *offsets, uint64_t n_reads, std::string &err, const FileTags *tags)
+{
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(writer_threads(), std::max(n_files, 1)))
+    for (int t = 0; t < n_files; t++) {
+        const std::string path = prefix + "_" + tag_of(tags, t) + "_parGraph.txt";
+        FILE *f = fopen(path.c_str(), "wb");
+        const uint64_t nb = offsets[t + 1] - offsets[t];
+        bool good = f != nullptr && (nb == 0 || fwrite(text + offsets[t], 1, nb, f) == nb);
+        if (f) fclose(f);
+        if (!good) {
+#pragma omp critical
+            {
+                ok = false;
+                err = "Unable to write file: " + path;
+            }
+        }
+        std::string e2; /* layout compatibility: one start id per file (BG/OverlapGraph.cpp:211) */
+        const uint64_t first = n_files ? (uint64_t)(((__uint128_t)n_reads * (unsigned)t + n_files - 1) / n_files) + 1 : 1;
+        flush(prefix + "_" + tag_of(tags, t) + "_startRead.txt", std::to_string(first) + "\n", e2);
+    }
+    return ok;
+}
+
 namespace {
 struct BinHeader {
     char magic[8];

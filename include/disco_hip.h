@@ -276,6 +276,16 @@ int disco_set_query_order(disco_ctx *ctx, const void *d_order_u64);
 /* the order the last disco_probe walked: device pointer to q_hi - q_lo entries owned by the context, read id in bits 31..0 and
  * the read's length in bits 47..32 (the kernels carry the length with the id); NULL = file order */
 int disco_get_query_order(disco_ctx *ctx, const void **d_order_u64);
+/* ---- the edge lines of the text files, formatted on the GPU ------------------------------------------------------------------ */
+/* saveParGraphToFile's lines (BG/OverlapGraph.cpp:808-867: "src \t dst \t orient,ovl,0,0,len1,start1,len1-1,len2,0,ovl-1,NA,flag") for the
+ * edges still resident after disco_transitive_reduce, file after file: edge_file = the file of every edge in the order of
+ * disco_fetch_edges (disco_fetch_edge_files; may be null for one file), file_index = the 1-based file index of every read (the
+ * ids of the text files, SG/DataSet.cpp:103-107; null: read id + 1), flag 2 on every line (the files are cut along connected
+ * components). The text of file t is bytes [file_offsets[t], file_offsets[t + 1]) of what disco_fetch_edge_text copies out; returns the
+ * total number of bytes. At most 256 files, exact overlaps only (otherwise DISCO_E_UNSUPPORTED: the host writer formats). */
+int64_t disco_format_edges(disco_ctx *ctx, uint32_t n_files, const uint16_t *edge_file, const uint64_t *file_index, uint64_t *file_offsets);
+int disco_fetch_edge_text(disco_ctx *ctx, char *out, uint64_t cap);
+
 /* ---- chains of the reduced graph as composite edges ---------------------------------------------------- */
 /* The consumer's first step on the files this stage writes is parsimplify: every maximal chain of nodes with exactly two edges that
  * leave them from opposite ends becomes one composite edge carrying the reads inside it (contractParCompositeEdges,

@@ -467,3 +467,38 @@ def test_chains_contracted_on_the_gpu_equal_the_host_walk(tmp_path, gpus, shape)
     # the same edges in, out and absorbed (the round count differs by the round the GPU did)
     import re
     assert re.sub(r"\d+ rounds", "R rounds", out["gpu_stats"]) == re.sub(r"\d+ rounds", "R rounds", out["host_stats"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,threads", [("multifile", 1), ("multifile", 4), ("generated", 16), ("generated", 3)])
+def test_edge_lines_formatted_on_the_gpu_are_the_host_writers_bytes(tmp_path, case, threads):
+    """the edge files are formatted where the edges are (disco_format_edges: one thread per line, a scan per file) — line for line, byte for byte,
+    what the host writer produces (DISCO_HOST_TEXT=1), with filtered records (file index != read id + 1) and without"""
+    from disco_amd import readgen
+
+    build.build_host()
+    if case == "multifile":
+        c = gu.CASES["multifile"]
+        inputs = ["-pe", ",".join(os.path.join(gu.GOLD, f) for f in c["pe"]), "-se", ",".join(os.path.join(gu.GOLD, f) for f in c["se"])]
+        mo = c["min_overlap"]
+    else:
+        fa = str(tmp_path / "r.fasta")
+        readgen.write_fasta(fa, readgen.generate_reads(readgen.GenSpec.coverage(seed=31, n_reads=200_000, read_len=100, cov=30.0, n_contigs=7, len_max=260)))
+        inputs, mo = ["-se", fa], 40
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text(f"MinOverlap4BuildGraph = {mo}\n")
+    files = {}
+    for how in ("gpu", "host"):
+        prefix = str(tmp_path / how)
+        env = dict(os.environ, DISCO_VERBOSE="1")
+        if how == "host":
+            env["DISCO_HOST_TEXT"] = "1"
+        p = subprocess.run([os.path.join(BIN, "buildG")] + inputs + ["-f", prefix, "-p", str(cfg), "-t", str(threads)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, env=env)
+        assert p.returncode == 0, p.stdout
+        assert ("format edge lines on the GPU" in p.stdout) == (how == "gpu")
+        # (the order of the edges inside a file is the order of the emission, which differs from run to run: lines compared sorted)
+        files[how] = [sorted(open(f"{prefix}_{t}_parGraph.txt", "rb").read().split(b"\n")) for t in range(threads)] + \
+                     [open(f"{prefix}_{t}_startRead.txt", "rb").read() for t in range(threads)]
+    assert files["gpu"] == files["host"]
+    assert sum(len(x) for x in files["gpu"][:threads]) > 200  # lines
