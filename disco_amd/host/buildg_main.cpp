@@ -327,13 +327,6 @@ int main(int argc, char **argv)
         rows.resize(n_cont);
         if (n_cont && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
         lap("fetch contained rows");
-        edges.reset(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
-        if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
-        if (max_subs) {
-            edge_subs.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
-            if (e_out && disco_fetch_edge_substitutions(ctx, edge_subs.get(), e_out) < 0) return die(disco_last_error(ctx));
-        }
-        lap("fetch edges");
         /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
          * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
         edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
@@ -348,6 +341,16 @@ int main(int argc, char **argv)
             edge_text.reset(new char[std::max<int64_t>(nb, 1)]);
             DISCO_CALL(ctx, disco_fetch_edge_text(ctx, edge_text.get(), (uint64_t)nb));
             lap("format edge lines on the GPU");
+        }
+        /* the edges as host records: only for what still works on them there (binary side output, partial simplification, host-formatted text) */
+        if (binary_out || !par_simple.empty() || (!edge_text && !no_text)) {
+            edges.reset(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
+            if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
+            if (max_subs) {
+                edge_subs.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
+                if (e_out && disco_fetch_edge_substitutions(ctx, edge_subs.get(), e_out) < 0) return die(disco_last_error(ctx));
+            }
+            lap("fetch edges");
         }
         if (gpu_chains && e_out) {
             uint64_t nc = 0, nl = 0;
