@@ -305,6 +305,16 @@ class BuildGraph:
             self._chk(self.L.disco_fetch_edges(self._h, out.ctypes.data, n))
         return out
 
+    def format_edges(self, n_files: int = 1, edge_file=None, file_index=None):
+        """the edge lines of the text files, formatted on the GPU (disco_format_edges): (text bytes, offsets [n_files + 1])"""
+        off = np.zeros(n_files + 1, dtype=np.uint64)
+        ef = None if edge_file is None else np.ascontiguousarray(edge_file, dtype=np.uint16)
+        fi = None if file_index is None else np.ascontiguousarray(file_index, dtype=np.uint64)
+        nb = self._chk(self.L.disco_format_edges(self._h, n_files, None if ef is None else ef.ctypes.data, None if fi is None else fi.ctypes.data, off.ctypes.data))
+        buf = np.empty(max(nb, 1), dtype=np.uint8)
+        self._chk(self.L.disco_fetch_edge_text(self._h, buf.ctypes.data, nb))
+        return buf[:nb].tobytes(), off
+
     def contract_chains(self, min_overlap_simplify: int = 0, edges=None):
         """chains of the reduced graph as composite edges (disco_contract_chains; with `edges`: disco_contract_chains_of on that array).
         Returns (composite edges [CHAIN_EDGE_DTYPE], links [CHAIN_LINK_DTYPE], absorbed flag per edge)"""
