@@ -147,7 +147,27 @@ struct Rec {
 };
 
 /* literal sequential splitter: the reference's getline calls (BG/Dataset.cpp:255-293) */
-bool split_sequential(const Blob &b, std::vector<Rec> &recs, std::string &err)
+/* a vector whose resize() does not zero-fill (50 M records are written right away by the threads that found them) */
+template <typename T>
+struct DefaultInit : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = DefaultInit<U>;
+    };
+    template <typename U>
+    void construct(U *p)
+    {
+        ::new ((void *)p) U;
+    }
+    template <typename U, typename... A>
+    void construct(U *p, A &&...a)
+    {
+        ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using RecVec = std::vector<Rec, DefaultInit<Rec>>;
+
+bool split_sequential(const Blob &b, RecVec &recs, std::string &err)
 {
     const char *d = b.data;
     const size_t n = b.n;
@@ -439,7 +459,7 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
 
     /* ---- pass A: records + (good, length) of every file ---------------------------------------------------------- */
     std::vector<Blob> blobs(inputs.size());
-    std::vector<std::vector<Rec>> recs(inputs.size());
+    std::vector<RecVec> recs(inputs.size());
     std::vector<std::vector<uint16_t>> glen(inputs.size()); /* 0 = rejected, else the read length */
     std::vector<std::vector<std::vector<uint64_t>>> arenas(inputs.size()); /* [file][thread] packed good reads */
     uint64_t total_records = 0;
@@ -447,26 +467,36 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
         Blob &b = blobs[fi];
         if (!load_blob(inputs[fi].first, b, err, threads)) return false;
         lap("read file");
-        std::vector<Rec> &R = recs[fi];
+        RecVec &R = recs[fi];
         bool done = false;
         if (b.n && b.data[0] == '>' && threads > 1) { /* FASTA fast path */
             std::vector<std::vector<size_t>> starts;
             if (fasta_starts_parallel(b, threads, starts)) {
-                size_t cnt = 0;
-                for (auto &v : starts) cnt += v.size();
-                std::vector<size_t> all;
-                all.reserve(cnt + 1);
-                for (auto &v : starts) all.insert(all.end(), v.begin(), v.end());
-                /* a '>' that is the very last byte starts nothing (the reference's next getline fails) unless it is the only
-                 * one; it still ends the sequence of the record before it */
-                const std::vector<size_t> orig = all;
-                if (all.size() > 1 && all.back() == b.n - 1) all.pop_back();
-                R.resize(all.size());
-#pragma omp parallel for schedule(static) num_threads(threads)
-                for (size_t i = 0; i < all.size(); i++) {
-                    const size_t end = (i + 1 < orig.size()) ? orig[i + 1] : b.n;
-                    const char *nl = (const char *)memchr(b.data + all[i], '\n', end - all[i]);
-                    R[i] = Rec{nl ? (size_t)(nl - b.data) + 1 : end, end};
+                /* every thread turns the starts it found into records, at their place in file order; the end of a record is the next
+                 * start, wherever it was found. A '>' that is the very last byte starts nothing (the reference's next getline fails)
+                 * unless it is the only one; it still ends the sequence of the record before it */
+                std::vector<size_t> base(starts.size() + 1, 0), next_first(starts.size() + 1, b.n);
+                for (size_t t = 0; t < starts.size(); t++) base[t + 1] = base[t] + starts[t].size();
+                for (size_t t = starts.size(); t-- > 0;) next_first[t] = starts[t].empty() ? next_first[t + 1] : starts[t][0];
+                const size_t total = base[starts.size()];
+                size_t last_start = 0;
+                for (size_t t = starts.size(); t-- > 0;)
+                    if (!starts[t].empty()) {
+                        last_start = starts[t].back();
+                        break;
+                    }
+                const size_t n_rec = (total > 1 && last_start == b.n - 1) ? total - 1 : total;
+                R.resize(n_rec);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+                for (size_t t = 0; t < starts.size(); t++) {
+                    const std::vector<size_t> &st = starts[t];
+                    for (size_t j = 0; j < st.size(); j++) {
+                        const size_t i = base[t] + j;
+                        if (i >= n_rec) break;
+                        const size_t end = (j + 1 < st.size()) ? st[j + 1] : next_first[t + 1];
+                        const char *nl = (const char *)memchr(b.data + st[j], '\n', end - st[j]);
+                        R[i] = Rec{nl ? (size_t)(nl - b.data) + 1 : end, end};
+                    }
                 }
                 done = true;
             }
@@ -583,7 +613,7 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
     /* ---- pass B: pack the good reads at their final place -------------------------------------------------------- */
     uint64_t id_base = 0, rec_base = 0;
     for (size_t fi = 0; fi < inputs.size(); fi++) {
-        const std::vector<Rec> &R = recs[fi];
+        const RecVec &R = recs[fi];
         const std::vector<uint16_t> &G = glen[fi];
         const int nt = threads;
         std::vector<uint64_t> tbase(nt + 1, 0);
