@@ -61,7 +61,7 @@ def algorithmic_bytes(cnt, n_reads, words_mean):
     return total, per_kernel
 
 
-KERNEL_SOURCES = ("disco_amd/csrc/disco_kernels.h", "disco_amd/csrc/disco_device.h", "disco_amd/csrc/disco_dist.h", "disco_amd/csrc/disco_hip.hip")
+KERNEL_SOURCES = tuple(sorted("disco_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "disco_amd", "csrc")) if f.endswith((".h", ".hip"))))
 
 
 def kernels_sha16():
@@ -219,9 +219,9 @@ def spawn_ranks(args):
     Replaces mpirun of the reference's multi-process binaries (MPI/main.cpp:29-37)."""
     import socket
 
-    import torch
+    from disco_amd import launch
 
-    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    have = launch.gpu_count()  # from the KFD topology in sysfs: this parent never opens the HIP runtime
     if have < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but this machine has {have} GPU(s); one rank per GPU is required "
                          f"(refusing to print a {args.gpus}-GPU line measured on fewer)")
@@ -393,7 +393,7 @@ def main():
             out["graph_host_to_host"] = {"failed": str(e)}
     if sharded:  # rank 0's view of the exchanges of the last pass
         out["config"]["exchanges_rank0"] = {"regime": {0: "regular", 2: "regular after twin completion across ranks"}.get(info["regime"], "order-dependent (adjacency gathered)"),
-                                            "tr_rounds": info["tr_rounds"], "tr_deferred": info["tr_deferred"],
+                                            "transport": g.transport, "tr_rounds": info["tr_rounds"], "tr_deferred": info["tr_deferred"],
                                             "bytes_sent": info["bytes_sent"], "ms": {k: round(v, 3) for k, v in info["ms"].items()},
                                             "ms_pass": round(info["ms_total"], 3)}
     g.close()

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libdisco_hip.so")
 BUILDG = os.path.join(HERE, "bin", "buildG")
 
 HIP_SOURCES = [os.path.join(HERE, "csrc", "disco_hip.hip")]
-HIP_DEPS = HIP_SOURCES + [os.path.join(HERE, "csrc", f) for f in ("disco_kernels.h", "disco_device.h", "readgen.h", "disco_dist.h", "disco_comm.h")] + [
+HIP_DEPS = HIP_SOURCES + [os.path.join(HERE, "csrc", f) for f in sorted(f for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))] + [
     os.path.join(ROOT, "include", "disco_hip.h")]
 HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("buildg_main.cpp", "fastx.cpp", "writer.cpp", "parsimple.cpp")]
 
@@ -56,7 +56,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(LIB, HIP_DEPS):
         tmp = LIB + ".tmp"
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Rpass-analysis=kernel-resource-usage",
-               "-o", tmp] + HIP_SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+               "-o", tmp] + HIP_SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -96,6 +96,7 @@ ABI = [
     ("disco_comm_init_local", C.c_int, [C.POINTER(_P), C.c_int]),
     ("disco_comm_rank", C.c_int, [_P]),
     ("disco_comm_world", C.c_int, [_P]),
+    ("disco_comm_kind", C.c_char_p, [_P]),
     ("disco_dist_range", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("disco_dist_upload_reads", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
     ("disco_dist_generate_reads", C.c_int, [_P, C.POINTER(GenSpecABI)]),
@@ -412,6 +413,11 @@ class BuildGraph:
     @property
     def world(self) -> int:
         return int(self.L.disco_comm_world(self._h))
+
+    @property
+    def transport(self) -> str:
+        """the transport behind the communicator: rccl, loop (ranks of one process sharing a device) or none"""
+        return self.L.disco_comm_kind(self._h).decode()
 
     def dist_range(self, n_total: int):
         lo, hi = C.c_uint64(), C.c_uint64()

@@ -60,6 +60,16 @@ struct DiscoComm {
             return DISCO_E_HIP;                                                              \
         }                                                                                    \
     } while (0)
+/* between ncclGroupStart and ncclGroupEnd: close the group before leaving on an error, or the communicator stays inside it */
+#define DISCO_NCCL_G(call)                                                                   \
+    do {                                                                                     \
+        ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess) {                                                             \
+            err = std::string(#call) + ": " + ncclGetErrorString(r_);                        \
+            (void)ncclGroupEnd();                                                            \
+            return DISCO_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
 #define DISCO_COMM_HIP(call)                                                                 \
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
@@ -99,8 +109,8 @@ struct RcclComm final : DiscoComm {
         DISCO_NCCL(ncclGroupStart());
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
-            if (cnt[rank]) DISCO_NCCL(ncclSend(send, cnt[rank], ncclInt8, p, comm, s));
-            if (cnt[p]) DISCO_NCCL(ncclRecv((char *)recv + off[p], cnt[p], ncclInt8, p, comm, s));
+            if (cnt[rank]) DISCO_NCCL_G(ncclSend(send, cnt[rank], ncclInt8, p, comm, s));
+            if (cnt[p]) DISCO_NCCL_G(ncclRecv((char *)recv + off[p], cnt[p], ncclInt8, p, comm, s));
         }
         DISCO_NCCL(ncclGroupEnd());
         if (cnt[rank] && send != (const char *)recv + off[rank])
@@ -113,8 +123,8 @@ struct RcclComm final : DiscoComm {
         DISCO_NCCL(ncclGroupStart());
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
-            if (scnt[p]) DISCO_NCCL(ncclSend((const char *)send + soff[p], scnt[p], ncclInt8, p, comm, s));
-            if (rcnt[p]) DISCO_NCCL(ncclRecv((char *)recv + roff[p], rcnt[p], ncclInt8, p, comm, s));
+            if (scnt[p]) DISCO_NCCL_G(ncclSend((const char *)send + soff[p], scnt[p], ncclInt8, p, comm, s));
+            if (rcnt[p]) DISCO_NCCL_G(ncclRecv((char *)recv + roff[p], rcnt[p], ncclInt8, p, comm, s));
         }
         DISCO_NCCL(ncclGroupEnd());
         if (scnt[rank]) /* the block a rank keeps never touches a link */

@@ -14,8 +14,10 @@
  *   flag       u8[E]          bit0 = transitive from this end, bit1 = survives (emitted from this end)
  */
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -36,6 +38,17 @@
 static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
 
 static thread_local std::string g_create_error;
+
+/* tracing hooks (the reference brackets its functions with CLOCKSTART / CLOCKSTOP, BG/Common.h:71-95): every
+ * phase of the path is a named roctx range, so `rocprofv3 --marker-trace --kernel-trace` shows the kernels under the C-ABI call
+ * and the phase that launched them; without a tool attached a range costs two calls into an empty library */
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { (void)roctxRangePushA(name); }
+    ~RoctxRange() { (void)roctxRangePop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+#define DISCO_TRACE(name) RoctxRange roctx_range_(name)
 
 /* host-side loops over tens of millions of results (struct conversion, random reads of the length table) */
 template <typename F>
@@ -665,6 +678,7 @@ static int validate_reads(disco_ctx *c)
 
 int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n)
 {
+    DISCO_TRACE("disco_upload_reads");
     if (!c || (n && (!packed || !len))) return c ? fail(c, DISCO_E_ARG, "disco_upload_reads: null argument") : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
@@ -714,6 +728,7 @@ int disco_adopt_reads(disco_ctx *c, const void *d_packed, uint32_t stride_words,
 
 int disco_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
 {
+    DISCO_TRACE("disco_generate_reads");
     if (!c || !s) return c ? fail(c, DISCO_E_ARG, "disco_generate_reads: null argument") : DISCO_E_ARG;
     if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
         return fail(c, DISCO_E_ARG, "disco_generate_reads: bad spec");
@@ -772,6 +787,7 @@ int disco_set_query_range(disco_ctx *c, uint64_t lo, uint64_t hi)
 /* ---------------------------------------------------------------------------------------------------------------- */
 int disco_build_index(disco_ctx *c)
 {
+    DISCO_TRACE("disco_build_index");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 1) return fail(c, DISCO_E_STATE, "disco_build_index: no reads");
     HIPCHK(c, hipSetDevice(c->device));
@@ -809,6 +825,7 @@ int disco_build_index(disco_ctx *c)
 /* ---------------------------------------------------------------------------------------------------------------- */
 int disco_probe(disco_ctx *c)
 {
+    DISCO_TRACE("disco_probe");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 2) return fail(c, DISCO_E_STATE, "disco_probe: build the index first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1012,6 +1029,7 @@ int disco_probe(disco_ctx *c)
 
 int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
 {
+    DISCO_TRACE("disco_mark_contained");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 3) return fail(c, DISCO_E_STATE, "disco_mark_contained: run disco_probe first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1054,6 +1072,7 @@ static int ensure_big_cap(disco_ctx *c, const u32 *cnt, const u64 *ref, u32 thr)
 
 static int select_edges(disco_ctx *c)
 {
+    DISCO_TRACE("select_edges");
     const u64 nq = c->q_hi - c->q_lo;
     if (!c->d_adj_ref) CHK(dev_alloc(c, &c->d_adj_ref, c->n));
     HIPCHK(c, hipMemsetAsync(c->d_adj_ref, 0, std::max<u64>(c->n, 1) * sizeof(u64), c->stream));
@@ -1132,6 +1151,7 @@ static int select_edges(disco_ctx *c)
 /* twin check over targets [lo,hi); collects extras, does not merge */
 static int twin_check(disco_ctx *c, u64 lo, u64 hi)
 {
+    DISCO_TRACE("twin_check");
     if (!c->d_extra_cnt) CHK(dev_alloc(c, &c->d_extra_cnt, c->n));
     /* After the contained filter the verified-hit relation is symmetric: a hit A->B at window j >= 1 of overlap length
      * ovl >= k+1 shows up from B's side at window ovl-k >= 1 against A's other end record, and verifies over the same
@@ -1227,6 +1247,7 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
 /* merge the collected extras into a node-ordered CSR (rare: only when pairs were found from one side only) */
 static int merge_extras(disco_ctx *c)
 {
+    DISCO_TRACE("merge_extras");
     if (c->n_extra == 0) return DISCO_OK;
     /* a handful of extras and the rows still where edge selection left them (one GPU): move only the rows that grow into the free
      * tail of the hit buffer — 84 ms of the 272 ms pass at 50 M reads with 0.3 % errors went into rebuilding all of it for 953 extras */
@@ -1402,6 +1423,7 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
 /* ---------------------------------------------------------------------------------------------------------------- */
 int disco_transitive_mark(disco_ctx *c)
 {
+    DISCO_TRACE("disco_transitive_mark");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 6) return fail(c, DISCO_E_STATE, "disco_transitive_mark: build edges first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1486,6 +1508,7 @@ int disco_transitive_mark(disco_ctx *c)
 
 int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
 {
+    DISCO_TRACE("disco_emit_edges");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 7) return fail(c, DISCO_E_STATE, "disco_emit_edges: run disco_transitive_mark first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1595,6 +1618,7 @@ int disco_transitive_reduce(disco_ctx *c, uint64_t *n_out)
 
 int disco_run_graph(disco_ctx *c)
 {
+    DISCO_TRACE("disco_run_graph");
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1625,6 +1649,7 @@ static int ensure_host_len(disco_ctx *c)
 
 int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t cap)
 {
+    DISCO_TRACE("disco_fetch_contained");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 4) return fail(c, DISCO_E_STATE, "disco_fetch_contained: run disco_mark_contained first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1674,6 +1699,7 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
 
 int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
 {
+    DISCO_TRACE("disco_fetch_edges");
     if (!c) return DISCO_E_ARG;
     if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edges: run disco_transitive_reduce first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1769,6 +1795,7 @@ int64_t disco_fetch_edge_substitutions(disco_ctx *c, uint16_t *out, uint64_t cap
 static int64_t partition_edges(disco_ctx *c, const u64 *d_src, const u64 *d_ent, const u8 *d_valid, const u64 *d_pos, u64 n_slots, u64 ne, u64 n,
                                uint32_t n_files, uint16_t *out)
 {
+    DISCO_TRACE("partition_edges");
     u32 *parent = nullptr, *cnt = nullptr, *d_nlist = nullptr;
     u16 *cfile = nullptr, *efile = nullptr;
     u64 *list = nullptr;
@@ -1842,6 +1869,7 @@ static int64_t partition_edges(disco_ctx *c, const u64 *d_src, const u64 *d_ent,
 
 int64_t disco_fetch_edge_files(disco_ctx *c, uint32_t n_files, uint16_t *out, uint64_t cap)
 {
+    DISCO_TRACE("disco_fetch_edge_files");
     if (!c || !out || n_files == 0) return DISCO_E_ARG;
     if (n_files > 0xFFFEu) return fail(c, DISCO_E_ARG, "disco_fetch_edge_files: at most 65534 files (%u asked for)", n_files);
     if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_fetch_edge_files: run disco_transitive_reduce first");
@@ -1896,6 +1924,7 @@ int64_t disco_partition_edges(disco_ctx *c, const disco_edge *edges, uint64_t n_
 /* ---- the edge lines of the text files, formatted where the edges are (disco_text.h) ------------------------------------------ */
 int64_t disco_format_edges(disco_ctx *c, uint32_t n_files, const uint16_t *edge_file, const uint64_t *file_index, uint64_t *file_offsets)
 {
+    DISCO_TRACE("disco_format_edges");
     if (!c || !file_offsets || n_files == 0) return DISCO_E_ARG;
     if (c->phase < 8) return fail(c, DISCO_E_STATE, "disco_format_edges: run disco_transitive_reduce first");
     if (n_files > 256) return fail(c, DISCO_E_UNSUPPORTED, "disco_format_edges: more than 256 files (one placement pass per file)");
@@ -1972,6 +2001,7 @@ int disco_fetch_edge_text(disco_ctx *c, char *out, uint64_t cap)
 /* ---- chains of the reduced graph as composite edges (kernels and the argument: disco_chains.h) ------------- */
 static int contract_chains(disco_ctx *c, const u64 *d_src, const u64 *d_ent, const u8 *d_valid, const u64 *d_pos, u64 n_slots, u64 ne, u64 n, u32 min_ovl)
 {
+    DISCO_TRACE("contract_chains");
     c->ch_ready = false;
     if (n_slots >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "chain contraction: more than 2^31 edge slots");
     ChainView g;
@@ -2000,8 +2030,12 @@ static int contract_chains(disco_ctx *c, const u64 *d_src, const u64 *d_ent, con
         hipLaunchKernelGGL(ch_internal_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, g, deg, he, n, internal);
         hipLaunchKernelGGL(ch_init_kernel, dim3(flat_grid(c, n_slots)), dim3(256), 0, c->stream, g, internal, he, ra);
         HIPCHK(c, hipGetLastError());
-        /* a chain of L half-edges is ranked after ceil(log2 L) rounds; rings never finish: 32 rounds bound every list of < 2^32 elements */
-        for (int round = 0; round < 32; round++) {
+        /* a chain of L half-edges is ranked after ceil(log2 L) rounds and no chain has more than n_half elements; a ring of
+         * absorbable nodes never finishes (its elements are discarded by ch_heads_kernel and left to the host pass), so the
+         * rounds stop at that bound instead of running while anything is live */
+        int max_rounds = 1;
+        while (max_rounds < 32 && (1ull << max_rounds) < n_half) ++max_rounds;
+        for (int round = 0; round < max_rounds; round++) {
             u32 h_live = 0;
             HIPCHK(c, hipMemsetAsync(live, 0, sizeof(u32), c->stream));
             hipLaunchKernelGGL(ch_jump_kernel, dim3(flat_grid(c, n_half)), dim3(256), 0, c->stream, ra, rb, n_half, live);
@@ -2075,10 +2109,10 @@ int disco_contract_chains_of(disco_ctx *c, const disco_edge *edges, uint64_t n_e
         u64 *d_src = nullptr, *d_ent = nullptr, *d_pos = nullptr;
         u8 *d_valid = nullptr;
         std::unique_ptr<u64[]> hs(new u64[n_edges]), he(new u64[n_edges]);
-        bool bad = false;
+        std::atomic<bool> bad{false};
         parallel_for(n_edges, [&](u64 b, u64 e_) {
             for (u64 i = b; i < e_; i++) {
-                if (edges[i].src >= c->n || edges[i].dst >= c->n) bad = true;
+                if (edges[i].src >= c->n || edges[i].dst >= c->n) bad.store(true, std::memory_order_relaxed);
                 hs[i] = edges[i].src;
                 he[i] = ADJ_MAKE(edges[i].offset, edges[i].dst, edges[i].orient, edges[i].len_dst);
             }
@@ -2386,6 +2420,7 @@ static int host_reduce(disco_ctx *c, u64 *vals, int n, bool take_max = false)
 /* ---- 1. hash-partitioned index build ------------------------------------------------------------------------------- */
 static int dist_build_index(disco_ctx *c)
 {
+    DISCO_TRACE("dist_build_index");
     const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
     const u64 nloc = c->q_hi - c->q_lo;
     u64 T = 1024;
@@ -2466,6 +2501,7 @@ static int dist_build_index(disco_ctx *c)
 /* ---- 3. containment: smallest key wins across ranks, flags of the own range, bitmap to everybody -------------------- */
 static int dist_mark_contained(disco_ctx *c)
 {
+    DISCO_TRACE("dist_mark_contained");
     const u32 G = (u32)c->comm->world;
     const u64 lo = c->q_lo, nloc = c->q_hi - c->q_lo, per = c->per;
     if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
@@ -2495,6 +2531,7 @@ static int dist_mark_contained(disco_ctx *c)
 /* one request round: the flat list of (u, cls) requests in d_req_flat -> rows appended to the neighbour-row store, nref set */
 static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
 {
+    DISCO_TRACE("dist_fetch_rows");
     const u32 G = (u32)c->comm->world;
     std::vector<u64> scnt, rcnt;
     CHK(ensure_cap(c, &c->d_req_s, &c->req_s_cap, std::max<u64>(n_flat, 1)));
@@ -2545,6 +2582,7 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
 
 static int dist_transitive_mark(disco_ctx *c)
 {
+    DISCO_TRACE("dist_transitive_mark");
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
     /* reference words: everything "not fetched", the own nodes' rows in place */
     CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, 2 * c->n + 2));
@@ -2668,6 +2706,7 @@ static int dist_transitive_mark(disco_ctx *c)
 /* ---- 6. surviving half-edges to the owner of the smaller endpoint ---------------------------------------------------- */
 static int dist_push_survivors(disco_ctx *c)
 {
+    DISCO_TRACE("dist_push_survivors");
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
     u64 n_items = 0;
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
@@ -2700,6 +2739,7 @@ static int dist_push_survivors(disco_ctx *c)
  * on any rank and the caller gathers the adjacency instead. */
 static int dist_complete_twins(disco_ctx *c, bool *done, u64 *asym_total)
 {
+    DISCO_TRACE("dist_complete_twins");
     const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo, per = c->per;
     *done = false;
@@ -2781,6 +2821,7 @@ static int dist_complete_twins(disco_ctx *c, bool *done, u64 *asym_total)
 /* ---- order-dependent regime: everybody gets the whole adjacency and finishes the pass on its own --------------------- */
 static int dist_irregular(disco_ctx *c, const std::vector<u64> &adj_totals)
 {
+    DISCO_TRACE("dist_irregular");
     const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo, per = c->per;
     u32 *deg_all = nullptr;
@@ -2910,6 +2951,7 @@ int disco_comm_init_local(disco_ctx *const *ctxs, int nranks)
 
 int disco_comm_rank(const disco_ctx *c) { return (c && c->comm) ? c->comm->rank : 0; }
 int disco_comm_world(const disco_ctx *c) { return (c && c->comm) ? c->comm->world : 1; }
+const char *disco_comm_kind(const disco_ctx *c) { return (c && c->comm) ? c->comm->kind() : "none"; }
 
 int disco_dist_range(const disco_ctx *c, uint64_t n_total, uint64_t *lo, uint64_t *hi)
 {
@@ -2946,19 +2988,24 @@ static int dist_validate(disco_ctx *c)
     const u64 nloc = c->q_hi - c->q_lo;
     CHK(zero_counter(c, CTR_BAD_LEN));
     CHK(zero_counter(c, CTR_MAX_LEN));
+    CHK(zero_counter(c, CTR_MIN_LEN));
     if (nloc) hipLaunchKernelGGL(validate_len_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_len + c->q_lo, nloc, c->S, (int)c->prm.min_overlap, c->d_ctr);
     CHK(read_counters(c));
-    u64 bad = c->h_ctr[CTR_BAD_LEN], mx = c->h_ctr[CTR_MAX_LEN];
+    /* the job's longest / shortest read (the shortest travels complemented, so both are a maximum over the ranks): every rank
+     * then takes the same two-pass decision in disco_probe whatever its own reads or its context's history look like */
+    u64 bad = c->h_ctr[CTR_BAD_LEN], ext[2] = {c->h_ctr[CTR_MAX_LEN], c->h_ctr[CTR_MIN_LEN]};
     CHK(host_reduce(c, &bad, 1));
-    CHK(host_reduce(c, &mx, 1, true));
+    CHK(host_reduce(c, ext, 2, true));
     if (bad) return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)bad, c->prm.min_overlap);
-    c->max_len = (u32)mx;
+    c->max_len = (u32)ext[0];
+    c->min_len = 0xFFFFu - (u32)ext[1];
     c->phase = 1;
     return DISCO_OK;
 }
 
 int disco_dist_upload_reads(disco_ctx *c, const uint64_t *packed_own, uint32_t stride_words, const uint16_t *len_own, uint64_t n_total)
 {
+    DISCO_TRACE("disco_dist_upload_reads");
     if (!c) return DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t dstride = (stride_words + 7u) & ~7u;
@@ -2976,6 +3023,7 @@ int disco_dist_upload_reads(disco_ctx *c, const uint64_t *packed_own, uint32_t s
 
 int disco_dist_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
 {
+    DISCO_TRACE("disco_dist_generate_reads");
     if (!c || !s) return c ? fail(c, DISCO_E_ARG, "disco_dist_generate_reads: null argument") : DISCO_E_ARG;
     if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
         return fail(c, DISCO_E_ARG, "disco_dist_generate_reads: bad spec");
@@ -2992,6 +3040,7 @@ int disco_dist_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
 
 int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
 {
+    DISCO_TRACE("disco_dist_run_graph");
     if (!c) return DISCO_E_ARG;
     if (!c->comm) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: no communicator");
     if (!c->dist_reads || c->phase < 1) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: set the reads with disco_dist_upload_reads / disco_dist_generate_reads");

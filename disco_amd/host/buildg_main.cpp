@@ -394,6 +394,7 @@ int main(int argc, char **argv)
                 if (disco_dist_upload_reads(c, rs.packed + lo * rs.stride_words, rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
                 if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS) < 0) bail("disco_dist_run_graph");
                 if (disco_dist_get_info(c, &R.info) < 0) bail("disco_dist_get_info");
+                if (verbose && r == 0) fprintf(stderr, "[disco host] transport %s, %d ranks\n", disco_comm_kind(c), gpus);
                 R.rows.resize(R.info.n_contained_local);
                 if (R.info.n_contained_local && disco_fetch_contained(c, R.rows.data(), R.info.n_contained_local) < 0) bail("disco_fetch_contained");
                 R.n_edges = R.info.e_out_local;

@@ -12,6 +12,31 @@ def rank_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def gpu_count() -> int:
+    """GPUs of this machine WITHOUT touching the HIP runtime: the KFD topology in sysfs lists every agent, a GPU is a node with
+    SIMDs. A launcher that only starts child ranks must not open /dev/kfd itself (torch.cuda.device_count() falls back to
+    hipGetDeviceCount — hipInit — on ROCm builds without amdsmi). HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the count
+    the way they narrow what the ranks will see."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def owner_range(n_total: int, rank: int, world: int):
     """[lo, hi) of the reads / graph nodes a rank owns: ceil(n / world) rounded up to a multiple of 64 per rank — the twin of
     disco_dist_range (include/disco_hip.h), checked against it by tests/test_gpu_dist.py"""

@@ -225,6 +225,8 @@ int disco_comm_init(disco_ctx *ctx, const void *unique_id, int nranks, int rank)
 int disco_comm_init_local(disco_ctx *const *ctxs, int nranks);
 int disco_comm_rank(const disco_ctx *ctx);  /* 0 without a communicator */
 int disco_comm_world(const disco_ctx *ctx); /* 1 without a communicator */
+/* the transport behind the context's communicator: "rccl" (disco_comm_init), "loop" (disco_comm_init_local) or "none" */
+const char *disco_comm_kind(const disco_ctx *ctx);
 /* id range this rank owns of n_total reads */
 int disco_dist_range(const disco_ctx *ctx, uint64_t n_total, uint64_t *lo, uint64_t *hi);
 /* this rank's reads = rows [lo, hi) of the job's n_total reads (replaces the per-rank file pass of MPI/Dataset.cpp:153-170) */

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # skip reasons and warnings belong in the record the driver keeps (it runs `pytest -x -q`): which size a memory-gated test ran
+    # at, why a multi-GPU test did not run on a 1-GPU box
+    if "s" not in (config.option.reportchars or ""):
+        config.option.reportchars = (config.option.reportchars or "") + "s"
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs the real reference binary oracle/_ref/buildG_ref")
 
