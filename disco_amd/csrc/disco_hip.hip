@@ -115,8 +115,16 @@ struct disco_ctx {
     u64 *d_big_list = nullptr;
     u32 *d_big_cnt = nullptr;
     u32 *d_n_big = nullptr;
+    /* minimizer runs of the reads [runs_lo, runs_lo + runs_n) (index_runs_kernel -> probe_runs_kernel): runs_lpr u32 words per read
+     * (16: up to 32 runs, reads of up to 128 windows; 32: up to 64 runs, 256 windows), 0 = the index pass left none */
+    u32 *d_runs = nullptr;
+    u64 runs_cap = 0, runs_lo = 0, runs_n = 0;
+    int runs_lpr = 0;
+    u64 *d_slow_list = nullptr; /* reads whose run list is unusable (ties, too many runs): probe_kernel<2> */
+    u32 *d_n_slow = nullptr;
+    u32 slow_cap = 0;
     u32 big_cap = 0;
-    u64 big_rows = 0;
+    u64 big_rows = 0, slow_rows = 0;
     const u64 *d_order = nullptr; /* a caller's processing order of the query range (plain read ids), or null */
     const u64 *d_order_used = nullptr; /* what the last probe walked: packed entries (ORDER_MAKE) in d_order_own, or null = file order */
     bool order_external = false;
@@ -409,6 +417,11 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_big_list, c->big_cap);
     dev_free(c, &c->d_big_cnt, c->big_cap);
     c->big_cap = 0;
+    dev_free(c, &c->d_slow_list, c->slow_cap);
+    c->slow_cap = 0;
+    dev_free(c, &c->d_runs, c->runs_cap);
+    c->runs_cap = c->runs_n = 0;
+    c->runs_lpr = 0;
     dev_free(c, &c->d_contained, c->n_alloc);
     dev_free(c, &c->d_cbits, c->n_alloc / 64 + 1);
     dev_free(c, &c->d_dropbits, c->n_alloc / 64 + 1);
@@ -485,6 +498,39 @@ static void free_reads(disco_ctx *c)
     c->n = 0;
 }
 
+/* the count pass of the index build over the reads [lo, hi): with the minimizer runs for probe_runs_kernel where the shape of the job
+ * allows them — a window of 17 m-mers (min-overlap 40, the default), 64-byte rows (reads up to 256 bases, so a read has at most 256
+ * windows), and memory for 64 / 128 bytes per read (DISCO_RUNS_MAX_GB, default 16: beyond that — config 5's 2 x 10^8 reads on ONE
+ * GPU — the buffer would crowd the hit buffer out of the 288 GB) — otherwise index_count_kernel and the wave-per-read probe_kernel. */
+template <bool COUNT>
+static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec, u64 lo, u64 hi)
+{
+    const u64 nloc = hi - lo;
+    c->runs_lpr = 0;
+    c->runs_n = 0;
+    int lpr = 0;
+    if (v.k - v.m + 1 == 17 && c->S == VERIFY_SW && c->max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
+        const u32 maxwin = c->max_len - (u32)c->k;
+        lpr = maxwin <= 128 ? 16 : (maxwin <= 256 ? 32 : 0);
+        const double max_gb = getenv("DISCO_RUNS_MAX_GB") ? atof(getenv("DISCO_RUNS_MAX_GB")) : 16.0;
+        if ((double)nloc * lpr * 4.0 > max_gb * 1e9) lpr = 0;
+    }
+    if (!nloc) return DISCO_OK;
+    const dim3 grid((unsigned)((nloc + 255) / 256));
+    if (lpr) {
+        CHK(ensure_cap(c, &c->d_runs, &c->runs_cap, nloc * (u64)lpr));
+        if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs);
+        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs);
+        c->runs_lpr = lpr;
+        c->runs_lo = lo;
+        c->runs_n = nloc;
+    } else
+        hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi);
+    HIPCHK(c, hipGetLastError());
+    return DISCO_OK;
+}
+
+
 static int dist_mark_contained(disco_ctx *c); /* multi-GPU flow, below */
 
 /* ================================================================================================================ */
@@ -529,6 +575,7 @@ int disco_create(int device, const disco_params *p, disco_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_wq, sizeof(u64)));
     CREATE_CHK(hipMalloc((void **)&c->d_bump, sizeof(u64)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_big, sizeof(u32)));
+    CREATE_CHK(hipMalloc((void **)&c->d_n_slow, sizeof(u32)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_extra, sizeof(u32)));
     for (int i = 0; i < DISCO_PH_COUNT; i++) {
         CREATE_CHK(hipEventCreate(&c->ev0[i]));
@@ -555,6 +602,7 @@ void disco_destroy(disco_ctx *c)
     for (int i = 0; i < 2; i++)
         if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     (void)hipFree(c->d_n_big);
+    (void)hipFree(c->d_n_slow);
     (void)hipFree(c->d_n_extra);
     dev_free(c, &c->d_probe_rare, 1);
     dev_free(c, &c->d_route, 2 * DIST_MAX_WORLD);
@@ -813,7 +861,7 @@ int disco_build_index(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
     ulonglong2 *rec = c->d_rec;
     CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n)); /* grouping keys of all reads (disco_probe orders its query range by them) */
-    if (c->n) hipLaunchKernelGGL(index_count_kernel<true>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, (u64)0, c->n);
+    CHK(launch_index_count<true>(c, v, rec, 0, c->n));
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt, T + 1, c->d_bkt, false, nullptr)));
     if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
@@ -839,20 +887,32 @@ int disco_probe(disco_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
     const bool ldsrow = c->S <= PROBE_ACAP;
     const bool row17 = c->k - view(c).m == 16 && !getenv("DISCO_NO_ROW17"); /* window = 17 m-mers: DPP row-scan variant */
-    const int grid = row17 ? (ldsrow ? wq_grid(c, probe_kernel<false, true, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<false, false, true>, nq, "DISCO_PROBE_WAVES"))
-                           : (ldsrow ? wq_grid(c, probe_kernel<false, true, false>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<false, false, false>, nq, "DISCO_PROBE_WAVES"));
-    auto launch_probe = [&](const ProbeArgs &a, bool big, int g) {
+    /* the index pass left the minimizer runs of the whole query range: probe_runs_kernel (several reads per wavefront, starts at the
+     * bucket lookups); probe_kernel then only does the reads it is handed (unusable run lists, rows that outgrew their chunk) */
+    const bool use_runs = c->runs_lpr != 0 && c->d_runs && c->q_lo >= c->runs_lo && c->q_hi <= c->runs_lo + c->runs_n;
+    const int grid = use_runs ? (c->runs_lpr == 16 ? wq_grid(c, probe_runs_kernel<16>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_runs_kernel<32>, nq, "DISCO_PROBE_WAVES"))
+                     : row17  ? (ldsrow ? wq_grid(c, probe_kernel<0, true, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<0, false, true>, nq, "DISCO_PROBE_WAVES"))
+                              : (ldsrow ? wq_grid(c, probe_kernel<0, true, false>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<0, false, false>, nq, "DISCO_PROBE_WAVES"));
+    /* mode 0: the query range, 1: big_list (rows of known size), 2: slow_list */
+    auto launch_probe = [&](const ProbeArgs &a, int mode, int g) {
 #define DISCO_PROBE_LAUNCH(B, L, R) hipLaunchKernelGGL((probe_kernel<B, L, R>), dim3(g), dim3(64), 0, c->stream, a)
-        if (big) {
-            if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(true, true, true); else DISCO_PROBE_LAUNCH(true, true, false); }
-            else { if (row17) DISCO_PROBE_LAUNCH(true, false, true); else DISCO_PROBE_LAUNCH(true, false, false); }
-        } else {
-            if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(false, true, true); else DISCO_PROBE_LAUNCH(false, true, false); }
-            else { if (row17) DISCO_PROBE_LAUNCH(false, false, true); else DISCO_PROBE_LAUNCH(false, false, false); }
-        }
+#define DISCO_PROBE_MODE(B)                                                                      \
+    do {                                                                                         \
+        if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(B, true, true); else DISCO_PROBE_LAUNCH(B, true, false); }   \
+        else { if (row17) DISCO_PROBE_LAUNCH(B, false, true); else DISCO_PROBE_LAUNCH(B, false, false); }        \
+    } while (0)
+        if (mode == 0 && use_runs) {
+            if (c->runs_lpr == 16) hipLaunchKernelGGL(probe_runs_kernel<16>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
+            else hipLaunchKernelGGL(probe_runs_kernel<32>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
+        } else if (mode == 0) DISCO_PROBE_MODE(0);
+        else if (mode == 1) DISCO_PROBE_MODE(1);
+        else DISCO_PROBE_LAUNCH(2, true, true); /* slow_list only exists next to probe_runs_kernel: 64-byte rows, windows of 17 */
+#undef DISCO_PROBE_MODE
 #undef DISCO_PROBE_LAUNCH
     };
-    u64 want_hits = nq * 64 + (u64)grid * PROBE_CHUNK + (1u << 16);
+    const u64 chunk_slots = use_runs ? PR_CHUNK : PROBE_CHUNK;
+    u64 want_hits = nq * 64 + (u64)grid * chunk_slots + (1u << 16);
+    u32 want_slow = use_runs ? (u32)std::min<u64>(nq, nq / 64 + 1024) : 1u;
     u32 want_big = (u32)std::min<u64>(nq, nq / 64 + 1024);
     for (int attempt = 0; attempt < 8; attempt++) {
         if (want_hits > c->hits_cap) {
@@ -862,11 +922,17 @@ int disco_probe(disco_ctx *c)
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
             if (want_hits * 8 > fr) {
                 u64 can = fr / 8 / 10 * 9;
-                if (can < (u64)grid * PROBE_CHUNK * 2) return fail(c, DISCO_E_NOMEM, "disco_probe: not enough HBM for the hit buffer (%llu entries wanted)", (unsigned long long)want_hits);
+                if (can < (u64)grid * chunk_slots * 2) return fail(c, DISCO_E_NOMEM, "disco_probe: not enough HBM for the hit buffer (%llu entries wanted)", (unsigned long long)want_hits);
                 want_hits = can;
             }
             CHK(dev_alloc(c, &c->d_hits, want_hits));
             c->hits_cap = want_hits;
+        }
+        if (want_slow > c->slow_cap) {
+            dev_free(c, &c->d_slow_list, c->slow_cap);
+            c->slow_cap = 0;
+            CHK(dev_alloc(c, &c->d_slow_list, want_slow));
+            c->slow_cap = want_slow;
         }
         if (want_big > c->big_cap) {
             dev_free(c, &c->d_big_list, c->big_cap);
@@ -878,6 +944,7 @@ int disco_probe(disco_ctx *c)
         }
         HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_n_slow, 0, sizeof(u32), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ctr + CTR_KMER_HITS, 0, sizeof(u64) * 4, c->stream)); /* KMER_HITS, RAW_HITS, HITS_NEEDED, OVERFLOW */
         CHK(zero_counter(c, CTR_MAX_ROW));
         ProbeArgs a;
@@ -891,7 +958,9 @@ int disco_probe(disco_ctx *c)
         c->h_probe_rare.big_cnt = c->d_big_cnt;
         c->h_probe_rare.n_big = c->d_n_big;
         c->h_probe_rare.big_cap = c->big_cap;
-        c->h_probe_rare.reserved = 0;
+        c->h_probe_rare.slow_cap = c->slow_cap;
+        c->h_probe_rare.slow_list = c->d_slow_list;
+        c->h_probe_rare.n_slow = c->d_n_slow;
         c->h_probe_rare.ctr = c->d_ctr;
         if (!c->d_probe_rare) CHK(dev_alloc(c, &c->d_probe_rare, 1));
         HIPCHK(c, hipMemcpyAsync(c->d_probe_rare, &c->h_probe_rare, sizeof(ProbeRare), hipMemcpyHostToDevice, c->stream));
@@ -930,17 +999,27 @@ int disco_probe(disco_ctx *c)
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq) {
-            launch_probe(a, false, grid);
+            launch_probe(a, 0, grid);
         }
         ph_end(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipGetLastError());
-        u32 n_big = 0;
+        u32 n_big = 0, n_slow = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_slow, c->d_n_slow, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
         CHK(read_counters(c));
+        if (!c->h_ctr[CTR_OVERFLOW] && n_slow) { /* reads without a usable run list, the long way (they may add big rows) */
+            int g2 = wave_grid(c, (n_slow + WQ_CHUNK - 1) / WQ_CHUNK, 24);
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            launch_probe(a, 2, g2);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            CHK(read_counters(c));
+        }
+        c->slow_rows = n_slow;
         if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
             int g2 = wave_grid(c, (n_big + WQ_CHUNK - 1) / WQ_CHUNK, 8);
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-            launch_probe(a, true, g2);
+            launch_probe(a, 1, g2);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));
         }
@@ -1020,8 +1099,9 @@ int disco_probe(disco_ctx *c)
                     (unsigned long long)c->hits_cap, (unsigned long long)c->h_ctr[CTR_HITS_NEEDED], n_big, c->big_cap, (unsigned long long)c->h_ctr[CTR_OVERFLOW]);
         /* something was too small: grow and redo the pass (atomicMin on best is idempotent) */
         if (n_big > c->big_cap) want_big = (u32)std::min<u64>(nq, (u64)n_big + n_big / 4 + 1024);
+        if (n_slow > c->slow_cap) want_slow = (u32)std::min<u64>(nq, (u64)n_slow + n_slow / 4 + 1024);
         u64 needed = c->h_ctr[CTR_HITS_NEEDED];
-        want_hits = std::max<u64>(c->hits_cap * 2, needed + needed / 4 + (u64)grid * PROBE_CHUNK);
+        want_hits = std::max<u64>(c->hits_cap * 2, needed + needed / 4 + (u64)grid * chunk_slots);
     }
     return fail(c, DISCO_E_CAPACITY, "disco_probe: hit buffer could not be sized");
 }
@@ -2440,8 +2520,7 @@ static int dist_build_index(disco_ctx *c)
     c->adj_imported = false;
     ph_begin(c, DISCO_PH_INDEX);
     DiscoView v = view(c);
-    if (nloc) hipLaunchKernelGGL(index_count_kernel<false>, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, c->stream, v, c->d_bkt, c->d_rec, c->d_okey, c->q_lo, c->q_hi);
-    HIPCHK(c, hipGetLastError());
+    CHK(launch_index_count<false>(c, v, c->d_rec, c->q_lo, c->q_hi));
     /* records -> owner of their bucket range */
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nloc, 1)));
     std::vector<u64> scnt, rcnt, matrix;

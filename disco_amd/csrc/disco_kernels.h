@@ -25,6 +25,7 @@
 #define ES_DUPTAB (1 << ES_DUPBITS)
 #define ES_CAP 256        /* edge_select: hits of one read sorted in LDS (longer rows: global-scratch variant)  */
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
+#define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
@@ -259,6 +260,151 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
     rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
 }
 
+/* ----------------------------------------------------------------------------------------------------------------
+ * index_runs_kernel — index_count_kernel's rolling pass, which additionally hands the probe every read's MINIMIZER RUNS, so
+ * that probe_runs_kernel starts at the bucket lookups instead of re-deriving, wave per read, what this pass walks anyway
+ * (hashing the m-mers and the window minima were half of probe_kernel's instructions: 200 of 421 vector instructions per read,
+ * against 31 per m-mer and THREAD here).
+ *
+ * Window minima, branch free (van Herk / Gil-Werman blocks): the m-mer positions are cut into blocks of NF = k - m + 1, the
+ * window length. The window at w = b NF + r is the tail [r, NF) of block b plus the head [0, r) of block b + 1, so its minimum is
+ * min(suffix-min of block b at r, prefix-min of block b + 1 at r - 1): per position one step of a running prefix minimum, one
+ * step of the backward suffix pass over the block's stored order words, and one combine — no rescan when the minimum leaves
+ * the window (the serial sliding minimum needs one at about every ninth position per thread, i.e. at nearly every position for
+ * SOME thread of a wavefront: index 11.4 -> 40.9 ms in round 1). Two keys per position as everywhere (window_minimizer's rule,
+ * disco_device.h): order hash | position (leftmost of equal hashes) and order hash | 127 - position (rightmost); positions are
+ * relative to the start of block b, the strand of the m-mer rides in bit 0. The two minima name the same position iff the
+ * smallest hash is unique in the window: m1 ^ m2 == 0xFE exactly then.
+ *
+ * A RUN is a maximal range of consecutive windows with the same minimizer occurrence. Without ties the occurrence of a window is
+ * the position of its unique smallest hash, which never moves left as the window slides: every occurrence has ONE run, runs are
+ * disjoint and ordered, and all windows of a run have the strand of the occurrence's m-mer. The read's runs go out as 16-bit
+ * entries  first window << 6 | (occurrence - first window) << 1 | strand  (windows < 256, NF <= 32), CAP = 32 NL of them per
+ * read, unused ones 0xFFFF. A read with a tie in any window (the same m-mer twice within NF positions, or a collision of the
+ * 23-bit order hash: about 2 reads in 10 000 on random sequence, many in low-complexity sequence) or with more than CAP runs
+ * is marked 0xFFFE in its first entry: probe_runs_kernel hands those to probe_kernel, which resolves ties the long way.
+ * The prefix / suffix k-mer records of the read are windows 0 and L - k of the same pass.
+ * The entries are staged in LDS (each thread its own CAP slots) and leave as one coalesced copy per block. */
+template <bool COUNT, int NF, int NL>
+__global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
+                                                         u32 *__restrict__ runs)
+{
+    constexpr int CAP = 32 * NL;
+    __shared__ u16 s_runs[256 * CAP];
+    const u32 tid = threadIdx.x;
+    for (u32 x = tid; x < 256u * CAP / 2u; x += 256u) ((u32 *)s_runs)[x] = 0xFFFFFFFFu;
+    __syncthreads();
+    const u64 i = lo + (u64)blockIdx.x * 256u + tid;
+    if (i < hi) {
+        const u64 *__restrict__ p = v.reads + i * v.S;
+        const int L = v.len[i], k = v.k, m = v.m;
+        const int nmm = L - m + 1; /* m-mer positions */
+        const int npos = nmm - NF; /* = L - k: the probe's windows are [0, npos), window npos is the suffix k-mer */
+        const u64 mask = (1ull << (2 * m)) - 1ull;
+        const int rsh = 2 * (m - 1);
+        u64 f = 0, r = 0, word = 0;
+        int pos = 0;
+        auto next = [&]() {
+            if ((pos & 31) == 0) word = p[pos >> 5];
+            const u32 b = (u32)(word >> 62);
+            word <<= 2;
+            ++pos;
+            f = ((f << 2) | b) & mask;
+            r = (r >> 2) | ((u64)(3u - b) << rsh);
+        };
+        u32 best = 0xFFFFFFFFu;
+        auto order_word = [&]() {
+            next();
+            const bool st = r < f;
+            const u32 h = order_hash32(st ? r : f);
+            best = min(best, h);
+            return (h & ~0x1FFu) | (u32)st;
+        };
+        for (int q = 0; q < m - 1; ++q) next();
+        u32 hc[NF], s1[NF], s2[NF];
+#pragma unroll
+        for (int t = 0; t < NF; ++t) s1[t] = s2[t] = 0xFFFFFFFFu;
+        u16 *my = s_runs + tid * CAP;
+        u32 cnt = 0, last = 0xFFFFFFFFu, tie = 0;
+        u32 P1 = 0, P2 = 0, X1 = 0, X2 = 0, Xbase = 0;
+        /* window w (wave uniform: every thread walks the same positions) with minima m1 / m2 over positions relative to `base` */
+        auto window = [&](int w, u32 m1, u32 m2, int base) {
+            if (w <= npos) {
+                if (w == npos) { /* the suffix k-mer: its record; not one of the probe's windows */
+                    X1 = m1;
+                    X2 = m2;
+                    Xbase = (u32)base;
+                } else {
+                    tie |= (m1 ^ m2) ^ 0xFEu;
+                    const u32 prel = (u32)base + ((m1 >> 1) & 0x7Fu);
+                    if (prel != last) {
+                        last = prel;
+                        if (cnt < (u32)CAP) my[cnt] = (u16)(((u32)w << 6) | ((prel - (u32)w) << 1) | (m1 & 1u));
+                        ++cnt;
+                    }
+                }
+            }
+        };
+        const int nblk = npos / NF + 2; /* window npos lies in block npos / NF and is complete once the next block has gone by */
+        int q = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const int base = (b - 1) * NF;
+            if (b >= 1) window(base, s1[0], s2[0], base); /* the window that IS block b - 1 */
+            if (b == 1) {
+                P1 = s1[0]; /* window 0: the prefix k-mer's record */
+                P2 = s2[0];
+            }
+            u32 p1 = 0xFFFFFFFFu, p2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                u32 o = 0xFFFFFFFFu; /* past the read: never a minimum (a window the probe uses never reaches there) */
+                if (q < nmm) o = order_word();
+                ++q;
+                hc[t] = o;
+                p1 = min(p1, o | ((u32)(NF + t) << 1));
+                p2 = min(p2, o | ((u32)(127 - (NF + t)) << 1));
+                if (t + 1 < NF && b >= 1) window(base + t + 1, min(s1[t + 1], p1), min(s2[t + 1], p2), base);
+            }
+            u32 a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int t = NF - 1; t >= 0; --t) {
+                a1 = min(a1, hc[t] | ((u32)t << 1));
+                a2 = min(a2, hc[t] | ((u32)(127 - t) << 1));
+                s1[t] = a1;
+                s2[t] = a2;
+            }
+        }
+        if (okey) okey[i] = best;
+        if ((tie & ~1u) != 0 || cnt > (u32)CAP) my[0] = 0xFFFEu; /* (bit 0 of m1 ^ m2: the two strands of a tie may differ) */
+        /* the two end k-mers' records: window_minimizer's rule on the minima of windows 0 and npos */
+        auto resolve = [&](u32 k1, u32 k2, int wbase, int j0, u32 &t, u32 &rev) {
+            const int ffirst = wbase + (int)((k1 >> 1) & 0x7Fu) - j0, flast = wbase + 127 - (int)((k2 >> 1) & 0x7Fu) - j0;
+            int fsel = ffirst;
+            if (ffirst == flast)
+                rev = k1 & 1u;
+            else {
+                rev = kmer_is_rev(p, v.S, j0, k);
+                fsel = rev ? flast : ffirst;
+            }
+            t = rev ? (u32)(NF - 1 - fsel) : (u32)fsel;
+            return mmer_key(p, v.S, j0 + fsel, m);
+        };
+        u32 tp, rp, ts, rs;
+        const u64 kp = resolve(P1, P2, 0, 0, tp, rp);
+        const u64 ks = resolve(X1, X2, (int)Xbase, npos, ts, rs);
+        const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
+        const u32 sp = COUNT ? atomicAdd(&bkt[bp], 1u) : 0u;
+        const u32 ss = COUNT ? atomicAdd(&bkt[bs], 1u) : 0u;
+        rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
+        rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
+    }
+    __syncthreads();
+    const u64 r0 = (u64)blockIdx.x * 256u;
+    const u64 nr = (hi - lo) - r0 < 256u ? (hi - lo) - r0 : 256u;
+    u32 *__restrict__ dst = runs + r0 * (CAP / 2);
+    for (u32 x = tid; x < (u32)nr * (CAP / 2); x += 256u) dst[x] = ((const u32 *)s_runs)[x];
+}
+
 /* bkt = exclusive scan of the counts: record goes to bkt[bucket] + slot */
 __global__ void index_fill_kernel(u64 n2, const ulonglong2 *__restrict__ rec, const u32 *__restrict__ bkt, u64 *__restrict__ ent)
 {
@@ -377,8 +523,10 @@ struct ProbeRare {
     u32 *big_cnt;
     u32 *n_big;
     u32 big_cap;
-    u32 reserved;
+    u32 slow_cap;
     u64 *ctr;
+    u64 *slow_list; /* probe_runs_kernel: reads without a usable run list (ties, too many runs), left to probe_kernel's list pass */
+    u32 *n_slow;
 };
 struct ProbeArgs {
     DiscoView v;
@@ -404,9 +552,13 @@ struct ProbeArgs {
  * is built for one wave per SIMD fewer. Round 2: 8 / 7 waves per SIMD instead of 7 / 6 — the kernel as it stands now fits 73
  * registers without spilling (round 1's did not: 14 spilled registers, 48 instead of 40 ms) and the seventh wave hides more of the
  * bucket and record fetches: 38.9 -> 36.5 ms, A/B in one box (tools/ab_build.py); at 9 / 8 it spills 12 registers (40.4 ms) */
-template <bool BIG, bool LDSROW, bool ROW17>
+/* PMODE 0: the query range in processing order; 1 (BIG): the reads of big_list, whose rows did not fit their chunk, with rows of
+ * exactly the size the first pass counted; 2 (LIST): the reads of slow_list (probe_runs_kernel could not use their run lists), rows in
+ * chunks as in mode 0 */
+template <int PMODE, bool LDSROW, bool ROW17>
 __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
 {
+    constexpr bool BIG = PMODE == 1, LISTED = PMODE != 0;
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
      * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
     __shared__ u32 s_k1[PROBE_SEGP + 32]; /* range-minimum tables over the order hashes of the segment's m-mers (+ slack  */
@@ -427,7 +579,7 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
     u64 chunk_base = 0;
     u32 chunk_used = PROBE_CHUNK;
     u32 my_maxrow = 0;
-    const u64 n_items = BIG ? (u64)min(*a.rare->n_big, a.rare->big_cap) : (a.v.q_hi - a.v.q_lo);
+    const u64 n_items = BIG ? (u64)min(*a.rare->n_big, a.rare->big_cap) : (PMODE == 2 ? (u64)min(*a.rare->n_slow, a.rare->slow_cap) : (a.v.q_hi - a.v.q_lo));
 
     /* the next read's row and length are fetched while the current read is processed (LDSROW implies S <= 64 words) */
     u64 pre_w = 0;
@@ -436,25 +588,25 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
     u64 ord_chunk = 0; /* lane i: the read the chunk's item i stands for (WQ_CHUNK == 64) */
     auto rid = [&](u64 it) { return readlane_u64(ord_chunk, (u32)(it - cbeg)); }; /* packed: ORDER_ID / ORDER_LEN */
     while (wq_grab(a.v.wq, n_items, cbeg, cend)) {
-    if (!BIG) {
+    if (!LISTED) {
         const u64 i = min(cbeg + lane, cend - 1);
         ord_chunk = a.order ? a.order[i] : ORDER_MAKE(a.v.q_lo + i, a.v.len[a.v.q_lo + i]);
     }
-    if (!BIG && LDSROW) {
+    if (!LISTED && LDSROW) {
         const u64 o0 = rid(cbeg);
         const u64 A0 = ORDER_ID(o0);
         pre_len = ORDER_LEN(o0);
         if ((int)lane < S) pre_w = a.v.reads[A0 * S + lane];
     }
     for (u64 it = cbeg; it < cend; it++) {
-        const u64 bl = BIG ? a.rare->big_list[it] : 0ull; /* read id | position in the order << 32 */
-        const u64 oe = BIG ? 0ull : rid(it);
-        const u64 A = BIG ? (bl & 0xFFFFFFFFull) : ORDER_ID(oe);
-        const u64 opos = BIG ? (bl >> 32) : it;
+        const u64 bl = BIG ? a.rare->big_list[it] : (PMODE == 2 ? a.rare->slow_list[it] : 0ull); /* read id | position in the order << 32 */
+        const u64 oe = LISTED ? 0ull : rid(it);
+        const u64 A = LISTED ? (bl & 0xFFFFFFFFull) : ORDER_ID(oe);
+        const u64 opos = LISTED ? (bl >> 32) : it;
         const u64 *ga = a.v.reads + A * S;
         int LA;
         __syncthreads();
-        if (!BIG && LDSROW) {
+        if (!LISTED && LDSROW) {
             LA = pre_len;
             if ((int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? pre_w : 0ull;
             const u64 itn = it + 1;
@@ -465,7 +617,7 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                 if ((int)lane < S) pre_w = a.v.reads[An * S + lane];
             }
         } else {
-            LA = BIG ? (int)a.v.len[A] : ORDER_LEN(oe);
+            LA = LISTED ? (int)a.v.len[A] : ORDER_LEN(oe);
             if (LDSROW && (int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? ga[lane] : 0ull;
         }
         const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
@@ -742,6 +894,234 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
 }
 
 /* ================================================================================================================
+ * probe_runs_kernel — candidate generation (the same getListOfReads hit set as probe_kernel) from the minimizer runs that
+ * index_runs_kernel left for every read: the kernel starts at the bucket lookups. A run = (first window, end window, occurrence,
+ * strand): one bucket lookup per run, and a record of the bucket matches AT MOST ONE window — t before the occurrence when the
+ * run's windows are canonical-forward, k - m - t before it when they are reversed — which must lie inside the run.
+ * Several reads per wavefront: a read has about 13 runs, so one read per wave would use a fifth of the lanes. A GROUP of
+ * G = 64 / LPR reads is processed together (LPR lanes load one read's 2 LPR run entries): the runs of the group are compacted into
+ * one occurrence list, looked up 64 at a time, and the records of all their buckets are walked as ONE concatenated list, lane =
+ * record (about 400 records per group of 4: 6-7 full passes instead of 4 x 2 half-empty ones). Which occurrence owns record i:
+ * a byte mark at the first record of every non-empty bucket, ballot + population count per pass. Occurrences are in (read, run)
+ * order and records in occurrence order, so the candidates of one read leave the walk contiguously: every read of the group gets
+ * its own row in the wave's private chunk of the hit buffer, in the order verify_kernel reads them.
+ * Reads whose run list is marked unusable go to slow_list (probe_kernel<2>), rows that do not fit the chunk to big_list
+ * (probe_kernel<1>), as before.
+ * ============================================================================================================== */
+#define PR_MARKCAP 1024 /* records of one batch of 64 lookups that can be owner-marked in LDS (more: binary search)        */
+#define PR_CHUNK 8192   /* hit slots a wave reserves at a time                                                           */
+#define PR_RESERVE 1024 /* room a wave makes sure of before it starts a group                                            */
+
+__device__ __forceinline__ u64 shfl_u64(u64 x, u32 l)
+{
+    return ((u64)(u32)__shfl((int)(u32)(x >> 32), (int)l) << 32) | (u32)__shfl((int)(u32)x, (int)l);
+}
+
+#ifndef PR_WAVES_PER_SIMD
+#define PR_WAVES_PER_SIMD 6 /* no register cap the kernel would feel: it needs 72 vector and ~100 scalar registers, which is 7 waves per SIMD; capped at 7 or 8 hipcc spills scalars into vector lanes and then vector registers */
+#endif
+template <int LPR>
+__global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(ProbeArgs a, const u32 *__restrict__ runs, u64 runs_lo)
+{
+    constexpr int G = 64 / LPR;      /* reads per group                                            */
+    constexpr int RS = VERIFY_SW + 1; /* words of a staged row (+ one readable word for the branch-free extract) */
+    __shared__ u64 s_rows[G * RS];
+    __shared__ u32 s_id[G];
+    __shared__ u32 s_occ[128]; /* the group's runs, compacted: slot << 29 | strand << 22 | (occurrence - first) << 17 | end << 8 | first window */
+    __shared__ u32 s_o_fp[64], s_o_start[64], s_o_excl[64], s_o_desc[64]; /* current batch of lookups with records */
+    __shared__ u8 s_mark[PR_MARKCAP];
+    const u32 lane = threadIdx.x;
+    const int k = a.v.k, m = a.v.m, nf = k - m + 1;
+    const u32 slot = lane / LPR, e = lane % LPR;
+    const u64 lt = lane_mask_lt(), le = lt | (1ull << lane);
+    const u64 nq = a.v.q_hi - a.v.q_lo;
+    u64 chunk_base = 0;
+    u32 chunk_used = PR_CHUNK;
+    u32 my_maxrow = 0;
+    for (u32 x = lane; x < PR_MARKCAP / 8; x += 64) ((u64 *)s_mark)[x] = 0ull;
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, nq, cbeg, cend)) {
+        const u64 ci = min(cbeg + lane, cend - 1);
+        const u64 ord_chunk = a.order ? a.order[ci] : ORDER_MAKE(a.v.q_lo + ci, a.v.len[a.v.q_lo + ci]);
+        /* run words and rows of the group that starts at g0 (addresses clamped, loads unconditional: they are issued one group ahead) */
+        auto fetch = [&](u64 g0, u32 &rw, u64 &roww) {
+            const u64 it = min(g0 + slot, cend - 1);
+            rw = runs[(ORDER_ID(shfl_u64(ord_chunk, (u32)(it - cbeg))) - runs_lo) * LPR + e];
+            const u32 rl = lane & (G * 8 - 1);
+            const u64 itr = min(g0 + (rl >> 3), cend - 1);
+            roww = a.v.reads[ORDER_ID(shfl_u64(ord_chunk, (u32)(itr - cbeg))) * VERIFY_SW + (rl & 7)];
+        };
+        u32 pre_rw;
+        u64 pre_row;
+        fetch(cbeg, pre_rw, pre_row);
+        for (u64 g0 = cbeg; g0 < cend; g0 += G) {
+            const u32 ng = (u32)min((u64)G, cend - g0);
+            const bool sv = slot < ng; /* my slot holds a read */
+            const u64 opos = g0 + (sv ? slot : 0u);
+            const u64 oe = shfl_u64(ord_chunk, (u32)(opos - cbeg));
+            const u32 A = (u32)ORDER_ID(oe);
+            const int LA = ORDER_LEN(oe);
+            const u32 npos = (u32)(LA - k);
+            const u32 rw = pre_rw;
+            __syncthreads();
+            if (lane < (u32)(G * 8)) s_rows[(lane >> 3) * RS + (lane & 7)] = pre_row;
+            if (e == 0) s_id[slot] = sv ? A : 0xFFFFFFFFu;
+            fetch(g0 + G, pre_rw, pre_row);
+            if (PR_CHUNK - chunk_used < PR_RESERVE) {
+                u64 base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(a.rare->bump, (u64)PR_CHUNK);
+                    atomicMax(&a.rare->ctr[CTR_HITS_NEEDED], base + PR_CHUNK);
+                    if (base + PR_CHUNK > a.rare->hits_cap) {
+                        atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
+                        base = ~0ull; /* no room: this wave writes nothing any more */
+                    }
+                }
+                chunk_base = shfl_u64(base, 0);
+                chunk_used = 0;
+            }
+            u64 *grow = nullptr;
+            u32 want = 0;
+            if (chunk_base != ~0ull) {
+                grow = a.hits + chunk_base + chunk_used;
+                want = PR_CHUNK - chunk_used;
+            }
+            /* 1. the group's runs -> one compacted occurrence list in (read, run) order */
+            const u32 e0 = rw & 0xFFFFu, e1 = rw >> 16;
+            const u64 slowm = __ballot(sv && e == 0 && e0 == 0xFFFEu);
+            const bool myslow = (slowm >> (slot * LPR)) & 1ull;
+            const bool v0 = sv && !myslow && e0 < 0xFFFEu, v1 = sv && !myslow && e1 < 0xFFFEu;
+            const u32 nx = (u32)__shfl_down((int)e0, 1); /* the entry after e1 */
+            const u32 wend0 = v1 ? (e1 >> 6) : npos;
+            const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? (nx >> 6) : npos;
+            const u64 m0 = __ballot(v0), m1 = __ballot(v1);
+            const u32 below = (u32)__popcll(m0 & lt) + (u32)__popcll(m1 & lt);
+            if (v0) s_occ[below] = (slot << 29) | ((e0 & 1u) << 22) | (((e0 >> 1) & 31u) << 17) | (wend0 << 8) | (e0 >> 6);
+            if (v1) s_occ[below + 1] = (slot << 29) | ((e1 & 1u) << 22) | (((e1 >> 1) & 31u) << 17) | (wend1 << 8) | (e1 >> 6);
+            const u32 n_occ = (u32)__popcll(m0) + (u32)__popcll(m1);
+            if (sv && e == 0 && myslow) { /* ties / too many runs: probe_kernel<2> does this read */
+                const u32 idx = atomicAdd(a.rare->n_slow, 1u);
+                if (idx < a.rare->slow_cap) a.rare->slow_list[idx] = (u64)A | (opos << 32);
+                else atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
+                a.row_cnt[A] = 0;
+                a.row_start[A] = 0;
+                a.meta_ord[opos] = make_ulonglong2(0ull, (u64)LA << 32);
+            }
+            u32 nrow = 0;
+            u32 c_slot[G];
+#pragma unroll
+            for (int s = 0; s < G; s++) c_slot[s] = 0;
+            __syncthreads();
+            for (u32 ob = 0; ob < n_occ; ob += 64) {
+                /* 2. one bucket lookup per occurrence */
+                const u32 oi = ob + lane;
+                u32 d = 0, st = 0, cnt = 0, fp = 0;
+                if (oi < n_occ) {
+                    d = s_occ[oi];
+                    const int prel = (int)(d & 0xFFu) + (int)((d >> 17) & 31u);
+                    const u64 key = mmer_key<true>(s_rows + (d >> 29) * RS, RS, prel, m);
+                    const u64 b = key >> a.v.bshift;
+                    uint2 se;
+                    __builtin_memcpy(&se, a.v.bkt + b, sizeof se); /* bkt[b], bkt[b + 1] */
+                    st = se.x;
+                    cnt = se.y - se.x;
+                    fp = KEY_FP(key);
+                }
+                const u32 incl = wave_inclusive_add(cnt);
+                const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                const u64 nz = __ballot(cnt > 0);
+                const u32 nne = (u32)__popcll(nz);
+                const u32 excl = incl - cnt;
+                __syncthreads();
+                if (cnt > 0) { /* only the buckets that hold records keep a slot: their starts in the concatenated list increase strictly */
+                    const u32 r = (u32)__popcll(nz & lt);
+                    s_o_fp[r] = fp;
+                    s_o_start[r] = st;
+                    s_o_excl[r] = excl;
+                    s_o_desc[r] = d;
+                    if (excl < PR_MARKCAP) s_mark[excl] = 1;
+                }
+                __syncthreads();
+                /* 3. all records of the batch's buckets, lane = record */
+                const bool marks = total <= PR_MARKCAP;
+                u32 nbefore = 0;
+                for (u32 base = 0; base < total; base += 64) {
+                    const u32 idx = base + lane;
+                    const bool in = idx < total;
+                    u32 lo;
+                    if (marks) {
+                        const u64 sm = __ballot(in && s_mark[in ? idx : 0u] != 0);
+                        lo = nbefore + (u32)__popcll(sm & le) - 1u;
+                        nbefore += (u32)__popcll(sm);
+                    } else {
+                        lo = 0;
+                        u32 hi = nne; /* largest o with excl[o] <= idx */
+                        while (hi - lo > 1) {
+                            const u32 mid = (lo + hi) >> 1;
+                            if (s_o_excl[mid] <= idx) lo = mid;
+                            else hi = mid;
+                        }
+                    }
+                    if (!in) lo = 0;
+                    const u32 dd = s_o_desc[lo];
+                    u64 pay = 0;
+                    if (in) pay = a.v.ent[s_o_start[lo] + (idx - s_o_excl[lo])];
+                    const u32 dslot = dd >> 29, rv = (dd >> 22) & 1u;
+                    const int wst = (int)(dd & 0xFFu), wen = (int)((dd >> 8) & 0x1FFu), prel = wst + (int)((dd >> 17) & 31u);
+                    const int t = (int)PAY_T(pay);
+                    /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k - m - t before */
+                    const int w = rv ? prel - (nf - 1 - t) : prel - t;
+                    const bool take = in && PAY_FP(pay) == s_o_fp[lo] && (u32)PAY_ID(pay) != s_id[dslot] /* self: BG/OverlapGraph.cpp:421,655 */
+                                      && w >= wst && w < wen;
+                    const u64 mm = __ballot(take);
+                    if (take) {
+                        const u32 pos = nrow + (u32)__popcll(mm & lt);
+                        if (pos < want) grow[pos] = HIT_MAKE(w, PAY_ID(pay), PAY_SUFFIX(pay), PAY_REV(pay) ^ rv, PAY_LEN(pay));
+                    }
+                    nrow += (u32)__popcll(mm);
+#pragma unroll
+                    for (int s = 0; s < G; s++) c_slot[s] += (u32)__popcll(mm & __ballot(dslot == (u32)s));
+                }
+                if (cnt > 0 && excl < PR_MARKCAP) s_mark[excl] = 0;
+            }
+            /* rows: the candidates of slot s follow those of the slots before it */
+            u32 mystart = 0, mycnt = 0, run = 0;
+#pragma unroll
+            for (int s = 0; s < G; s++) {
+                if (slot == (u32)s) {
+                    mystart = run;
+                    mycnt = c_slot[s];
+                }
+                run += c_slot[s];
+                my_maxrow = max(my_maxrow, c_slot[s]);
+            }
+            if (sv && e == 0 && !myslow) {
+                if (grow && mystart + mycnt <= want) {
+                    const u64 rs = chunk_base + chunk_used + mystart;
+                    a.row_start[A] = rs;
+                    a.row_cnt[A] = mycnt;
+                    a.meta_ord[opos] = make_ulonglong2(rs, (u64)mycnt | ((u64)LA << 32));
+                } else {
+                    if (grow) { /* does not fit what is left of the chunk: the BIG pass gives it a row of its own */
+                        const u32 idx = atomicAdd(a.rare->n_big, 1u);
+                        if (idx < a.rare->big_cap) {
+                            a.rare->big_list[idx] = (u64)A | (opos << 32);
+                            a.rare->big_cnt[idx] = mycnt;
+                        } else
+                            atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
+                    }
+                    a.row_cnt[A] = 0;
+                    a.row_start[A] = 0;
+                    a.meta_ord[opos] = make_ulonglong2(0ull, (u64)LA << 32);
+                }
+            }
+            if (grow) chunk_used = nrow <= want ? chunk_used + nrow : PR_CHUNK;
+        }
+    }
+    if (lane == 0) atomicMax(&a.rare->ctr[CTR_MAX_ROW], (u64)my_maxrow);
+}
+
+/* ================================================================================================================
  * verify — checkOverlapForContainedRead (BG/OverlapGraph.cpp:517-554) and checkOverlap (:567-595) on every candidate,
  * both as ONE shifted packed compare over the whole aligned region, preceded by the exact k-mer compare (the index
  * matches on minimizers only, so this is what makes a candidate a hit of getListOfReads).
@@ -764,7 +1144,6 @@ struct VerifyArgs {
     u32 max_subs;         /* INEXACT: substitutions an aligned region may carry (disco_params.max_substitutions)          */
 };
 
-#define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
 
 /* 32 bases starting at base position pos >= -32 of a row staged in LDS with a zero word in front and zero words behind */
 __device__ __forceinline__ u64 extract32_padded(const u64 *row, int pos)
