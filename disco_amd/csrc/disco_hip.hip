@@ -131,6 +131,11 @@ struct disco_ctx {
     u32 *d_ocnt = nullptr, *d_okey = nullptr, *d_oslot = nullptr;
     u64 *d_order_own = nullptr;
     u64 okey_cap = 0, oslot_cap = 0, order_cap = 0, ocnt_cap = 0;
+    /* the grouping's counting pass ran inside the index pass, for the reads [lo, hi) with 2^bits buckets (d_ocnt holds the counts,
+     * d_oslot the slots): the next disco_probe over exactly that range skips its own */
+    bool order_counted = false;
+    u64 order_counted_lo = 0, order_counted_hi = 0;
+    int order_counted_bits = 0;
     ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
     u64 meta_cap = 0;
     u64 *d_nref = nullptr; /* multi-GPU flow: reference words nref[2u + cls] of the neighbour-row store */
@@ -502,10 +507,39 @@ static void free_reads(disco_ctx *c)
  * allows them — a window of 17 m-mers (min-overlap 40, the default), 64-byte rows (reads up to 256 bases, so a read has at most 256
  * windows), and memory for 64 / 128 bytes per read (DISCO_RUNS_MAX_GB, default 16: beyond that — config 5's 2 x 10^8 reads on ONE
  * GPU — the buffer would crowd the hit buffer out of the 288 GB) — otherwise index_count_kernel and the wave-per-read probe_kernel. */
+/* does disco_probe group a query range of nq reads itself, and into how many buckets (about one per read: a group has ~13 reads at
+ * 30x, few groups share a bucket) */
+static bool own_order_wanted(const disco_ctx *c, u64 nq, int *bits)
+{
+    const u64 order_min = getenv("DISCO_ORDER_MIN_READS") ? (u64)atoll(getenv("DISCO_ORDER_MIN_READS")) : 4096; /* tests: 1 */
+    int b = 16;
+    while (b < 27 && (1ull << b) < nq) ++b;
+    *bits = b;
+    return !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= order_min && nq > 0;
+}
+
 template <bool COUNT>
 static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec, u64 lo, u64 hi)
 {
     const u64 nloc = hi - lo;
+    /* the counting pass of the grouping rides along when the indexed range is the query range (always, unless a caller narrows it) */
+    u32 *ocnt = nullptr, *oslot = nullptr;
+    u32 oshift = 0;
+    c->order_counted = false;
+    int obits = 0;
+    if (lo == c->q_lo && hi == c->q_hi && own_order_wanted(c, nloc, &obits) && !getenv("DISCO_NO_ORDER_FUSE")) {
+        const u64 order_buckets = 1ull << obits;
+        CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
+        CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nloc));
+        HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
+        ocnt = c->d_ocnt;
+        oslot = c->d_oslot;
+        oshift = 32u - (u32)obits;
+        c->order_counted = true;
+        c->order_counted_lo = lo;
+        c->order_counted_hi = hi;
+        c->order_counted_bits = obits;
+    }
     c->runs_lpr = 0;
     c->runs_n = 0;
     int lpr = 0;
@@ -519,13 +553,13 @@ static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec,
     const dim3 grid((unsigned)((nloc + 255) / 256));
     if (lpr) {
         CHK(ensure_cap(c, &c->d_runs, &c->runs_cap, nloc * (u64)lpr));
-        if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs);
-        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs);
+        if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs, ocnt, oslot, oshift);
+        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs, ocnt, oslot, oshift);
         c->runs_lpr = lpr;
         c->runs_lo = lo;
         c->runs_n = nloc;
     } else
-        hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi);
+        hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, ocnt, oslot, oshift);
     HIPCHK(c, hipGetLastError());
     return DISCO_OK;
 }
@@ -968,12 +1002,13 @@ int disco_probe(disco_ctx *c)
         CHK(ensure_cap(c, &c->d_meta_ord, &c->meta_cap, std::max<u64>(nq, 1)));
         a.meta_ord = c->d_meta_ord;
         /* grouping of the query range by read-level minimizer for the probe and verify passes (DISCO_NO_ORDER=1: file order) */
-        const u64 order_min = getenv("DISCO_ORDER_MIN_READS") ? (u64)atoll(getenv("DISCO_ORDER_MIN_READS")) : 4096; /* tests: 1 */
-        const bool own_order = !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= order_min && nq > 0;
+        int order_bits = 16;
+        const bool own_order = own_order_wanted(c, nq, &order_bits);
         a.order = nullptr;
-        int order_bits = 16; /* buckets of the grouping: about one per read (a group has ~13 reads at 30x: few groups share a bucket) */
-        while (order_bits < 27 && (1ull << order_bits) < nq) ++order_bits;
         const u64 order_buckets = 1ull << order_bits;
+        /* the index pass counted already (once: a retry of this loop finds the counters scanned and counts again) */
+        const bool counted = c->order_counted && c->order_counted_lo == c->q_lo && c->order_counted_hi == c->q_hi && c->order_counted_bits == order_bits;
+        c->order_counted = false;
         if (own_order) {
             CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
             CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nq));
@@ -981,8 +1016,10 @@ int disco_probe(disco_ctx *c)
             /* keys -> counts (+ slots) -> starts -> order */
             const u32 oshift = 32u - (u32)order_bits;
             ph_begin(c, DISCO_PH_ORDER);
-            HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
-            hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, nq, oshift, c->d_ocnt, c->d_oslot);
+            if (!counted) {
+                HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
+                hipLaunchKernelGGL(order_count_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, nq, oshift, c->d_ocnt, c->d_oslot);
+            }
             CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
             hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_okey + c->q_lo, c->d_oslot, c->d_ocnt, oshift, c->q_lo, nq, c->d_len, c->d_order_own);
             ph_end(c, DISCO_PH_ORDER);

@@ -26,6 +26,7 @@
 #define ES_CAP 256        /* edge_select: hits of one read sorted in LDS (longer rows: global-scratch variant)  */
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
+#define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift)) /* bucket of a read-level minimizer in the grouping ("processing order") */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
@@ -189,7 +190,8 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * (multi-GPU): no counting atomics — the records are routed to the rank that owns their bucket range first and counted there
  * (shard_count_kernel), which is what replaces the range-partitioned hashData of RMA/HashTable.cpp:95-116. */
 template <bool COUNT>
-__global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi)
+__global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
+                                                          u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
 {
     /* rec[2i], rec[2i+1] = {bucket << 32 | slot inside the bucket, record} of the prefix / suffix k-mer of read i: the slot is
      * what the counting atomic returns, so the fill pass needs no second round of atomics */
@@ -238,6 +240,7 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
         k2s = min(k2s, o + ((u32)(63 - (q - sfx0)) << 1));
     }
     if (okey) okey[i] = best;
+    if (ocnt) oslot[i - lo] = atomicAdd(&ocnt[ORDER_BUCKET(best, oshift)], 1u); /* the grouping's counting pass (order_count_kernel), fused */
     auto resolve = [&](u32 k1, u32 k2, int j0, u32 &t, u32 &rev) {
         const int ffirst = (int)((k1 >> 1) & 63u), flast = 63 - (int)((k2 >> 1) & 63u);
         int fsel = ffirst;
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
  * The entries are staged in LDS (each thread its own CAP slots) and leave as one coalesced copy per block. */
 template <bool COUNT, int NF, int NL>
 __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
-                                                         u32 *__restrict__ runs)
+                                                         u32 *__restrict__ runs, u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
 {
     constexpr int CAP = 32 * NL;
     __shared__ u16 s_runs[256 * CAP];
@@ -375,6 +378,7 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
             }
         }
         if (okey) okey[i] = best;
+        if (ocnt) oslot[i - lo] = atomicAdd(&ocnt[ORDER_BUCKET(best, oshift)], 1u); /* the grouping's counting pass (order_count_kernel), fused */
         if ((tie & ~1u) != 0 || cnt > (u32)CAP) my[0] = 0xFFFEu; /* (bit 0 of m1 ^ m2: the two strands of a tie may differ) */
         /* the two end k-mers' records: window_minimizer's rule on the minima of windows 0 and npos */
         auto resolve = [&](u32 k1, u32 k2, int wbase, int j0, u32 &t, u32 &rev) {
@@ -876,14 +880,17 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                     a.rare->big_cnt[idx] = nrow;
                 } else
                     atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
-                a.row_cnt[A] = 0;
-                a.row_start[A] = 0;
                 a.meta_ord[opos] = make_ulonglong2(0ull, (u64)LA << 32); /* the BIG pass fills it in */
             }
         } else {
             if (lane == 0) {
-                a.row_start[A] = grow ? chunk_base + chunk_used : 0;
-                a.row_cnt[A] = grow ? nrow : 0;
+                /* the per-read arrays (a random 64-byte line each) only serve rows beyond the register paths of verify / edge
+                 * selection (more than 64 entries); every other consumer reads the header by position in the order. row_cnt is
+                 * zeroed by the host before the pass. */
+                if (grow && nrow > 64) {
+                    a.row_start[A] = chunk_base + chunk_used;
+                    a.row_cnt[A] = nrow;
+                }
                 a.meta_ord[opos] = make_ulonglong2(grow ? chunk_base + chunk_used : 0ull, (u64)(grow ? nrow : 0u) | ((u64)LA << 32));
             }
             if (grow) chunk_used += nrow;
@@ -1003,8 +1010,6 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                 const u32 idx = atomicAdd(a.rare->n_slow, 1u);
                 if (idx < a.rare->slow_cap) a.rare->slow_list[idx] = (u64)A | (opos << 32);
                 else atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
-                a.row_cnt[A] = 0;
-                a.row_start[A] = 0;
                 a.meta_ord[opos] = make_ulonglong2(0ull, (u64)LA << 32);
             }
             u32 nrow = 0;
@@ -1098,8 +1103,10 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
             if (sv && e == 0 && !myslow) {
                 if (grow && mystart + mycnt <= want) {
                     const u64 rs = chunk_base + chunk_used + mystart;
-                    a.row_start[A] = rs;
-                    a.row_cnt[A] = mycnt;
+                    if (mycnt > 64) { /* rows beyond the register paths of verify / edge selection are found by read id (probe_kernel) */
+                        a.row_start[A] = rs;
+                        a.row_cnt[A] = mycnt;
+                    }
                     a.meta_ord[opos] = make_ulonglong2(rs, (u64)mycnt | ((u64)LA << 32));
                 } else {
                     if (grow) { /* does not fit what is left of the chunk: the BIG pass gives it a row of its own */
@@ -1110,8 +1117,6 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                         } else
                             atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
                     }
-                    a.row_cnt[A] = 0;
-                    a.row_start[A] = 0;
                     a.meta_ord[opos] = make_ulonglong2(0ull, (u64)LA << 32);
                 }
             }
@@ -1444,7 +1449,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             }
             if (MODE != 1) {
                 if (lane == 0) {
-                    a.row_cnt[A] = nkeep;
+                    if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
                     my_raw += nkeep;
                 }
                 if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
@@ -2892,7 +2897,6 @@ __global__ void uf_edge_file_kernel(const u64 *__restrict__ out_src, const u8 *_
  * The keys come out of index_count_kernel's rolling pass over every read (okey[read]).
  * The order changes no result: every consumer is order independent per read (rows are keyed by read id).
  * ============================================================================================================== */
-#define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift))
 __global__ void order_count_kernel(const u32 *__restrict__ okey, u64 nq, u32 shift, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
