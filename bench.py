@@ -386,9 +386,13 @@ def main():
         try:
             h2h = g.host_to_host_pass()
             h2h["overlaps_per_s"] = e_pre / (h2h["total_ms"] * 1e-3)
-            h2h["what"] = ("pinned packed reads in host memory -> disco_upload_reads -> whole pass (the context keeps its buffers for a read set of the same shape) -> "
-                           "disco_fetch_contained + disco_fetch_edges into host structs")
+            h2h["what"] = ("pinned packed reads in host memory (rows at the words they use) -> disco_upload_reads (chunked copy, rows spread and the index's count "
+                           "pass behind it) -> whole pass (contained rows leave on a side stream during it) -> disco_fetch_contained + disco_fetch_edges into "
+                           "host structs (12 bytes per row / edge over the link); second of two such passes: the context keeps its buffers and the caller "
+                           "its result arrays")
             out["graph_host_to_host"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in h2h.items()}
+            # SURVEY.md 8(d)'s t_graph (host buffers in, host structs out) next to the HBM-resident `value`
+            out["value_host_to_host"] = h2h["overlaps_per_s"]
         except Exception as e:
             out["graph_host_to_host"] = {"failed": str(e)}
     if sharded:  # rank 0's view of the exchanges of the last pass

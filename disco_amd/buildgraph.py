@@ -459,43 +459,60 @@ class BuildGraph:
         out["ms"] = {x: float(d.ms[i]) for i, x in enumerate(XCHG)}
         return out
 
-    def host_to_host_pass(self) -> dict:
+    def host_to_host_pass(self, passes: int = 2) -> dict:
         """SURVEY.md §8(d) 'graph' wall: packed reads in (pinned) HOST memory -> upload -> whole graph pass -> contained rows and
         edges in HOST structs. Uses the reads the context currently holds: they are downloaded first (untimed) into pinned
-        memory and uploaded again (a read set of the same shape: the context keeps its buffers, as a service that processes one
-        sample after the other would). Returns milliseconds per part."""
+        memory — at the words the rows use, as the input stage hands them over (disco_amd/host/fastx.cpp: 5 words at 150 bp) — and
+        uploaded again (a read set of the same shape: the context keeps its buffers, and the caller its result arrays, as a service
+        that processes one sample after the other would). Returns milliseconds per part of the LAST of `passes` passes."""
         import time
 
         n, s = self.num_reads, self.stride_words
-        nbytes = max(n * s * 8, 8)
-        p = self.L.disco_host_alloc(nbytes)
+        p = self.L.disco_host_alloc(max(n * s * 8, 8))
         if not p:
             raise DiscoError("disco_host_alloc failed")
+        q = None
         try:
             lens = np.zeros(n, dtype=np.uint16)
             self._chk(self.L.disco_download_reads(self._h, p, lens.ctypes.data))
-            t0 = time.perf_counter()
-            self._chk(self.L.disco_upload_reads(self._h, p, s, lens.ctypes.data, n))
-            self.synchronize()
-            t1 = time.perf_counter()
-            self.run_graph()
-            self.synchronize()
-            t2 = time.perf_counter()
-            nc = self._chk(self.L.disco_fetch_contained(self._h, None, 0))
-            ne = self._chk(self.L.disco_fetch_edges(self._h, None, 0))
-            rows = np.empty(max(nc, 1), dtype=CONTAINED_DTYPE)
-            edges = np.empty(max(ne, 1), dtype=EDGE_DTYPE)
-            t3 = time.perf_counter()
-            if nc:
-                self._chk(self.L.disco_fetch_contained(self._h, rows.ctypes.data, nc))
-            if ne:
-                self._chk(self.L.disco_fetch_edges(self._h, edges.ctypes.data, ne))
-            t4 = time.perf_counter()
-            return {"upload_ms": (t1 - t0) * 1e3, "graph_ms": (t2 - t1) * 1e3, "fetch_ms": (t4 - t3) * 1e3,
-                    "total_ms": (t2 - t0 + t4 - t3) * 1e3, "upload_bytes": int(n * s * 8), "fetch_bytes": int(nc * 40 + ne * 32),
-                    "n_contained": int(nc), "e_out": int(ne)}
+            w = max(1, (int(lens.max()) + 31) // 32) if n else 1
+            src, sw = p, s
+            if w < s:
+                q = self.L.disco_host_alloc(max(n * w * 8, 8))
+                if not q:
+                    raise DiscoError("disco_host_alloc failed")
+                full = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, s))
+                np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_uint64)), shape=(n, w))[:] = full[:, :w]
+                src, sw = q, w
+            rows = edges = None
+            out = {}
+            for _ in range(max(1, passes)):
+                t0 = time.perf_counter()
+                self._chk(self.L.disco_upload_reads(self._h, src, sw, lens.ctypes.data, n))
+                t1 = time.perf_counter()
+                self.run_graph()
+                self.synchronize()
+                t2 = time.perf_counter()
+                nc = self._chk(self.L.disco_fetch_contained(self._h, None, 0))
+                ne = self._chk(self.L.disco_fetch_edges(self._h, None, 0))
+                if rows is None or len(rows) < nc or len(edges) < ne:
+                    rows = np.zeros(max(nc, 1), dtype=CONTAINED_DTYPE)
+                    edges = np.zeros(max(ne, 1), dtype=EDGE_DTYPE)
+                t3 = time.perf_counter()
+                if nc:
+                    self._chk(self.L.disco_fetch_contained(self._h, rows.ctypes.data, nc))
+                t4 = time.perf_counter()
+                if ne:
+                    self._chk(self.L.disco_fetch_edges(self._h, edges.ctypes.data, ne))
+                t5 = time.perf_counter()
+                out = {"upload_ms": (t1 - t0) * 1e3, "graph_ms": (t2 - t1) * 1e3, "fetch_contained_ms": (t4 - t3) * 1e3, "fetch_edges_ms": (t5 - t4) * 1e3,
+                       "fetch_ms": (t5 - t3) * 1e3, "total_ms": (t2 - t0 + t5 - t3) * 1e3, "upload_bytes": int(n * sw * 8), "fetch_bytes": int(nc * 12 + ne * 12),
+                       "result_bytes": int(nc * 40 + ne * 32), "n_contained": int(nc), "e_out": int(ne)}
+            return out
         finally:
             self.L.disco_host_free(p)
+            if q:
+                self.L.disco_host_free(q)
 
     def counters(self) -> dict:
         c = Counters()

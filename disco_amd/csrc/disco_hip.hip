@@ -84,6 +84,7 @@ struct disco_ctx {
     u16 *d_len = nullptr;
     bool reads_owned = false;
     std::vector<uint16_t> h_len; /* lazily mirrored for result decoding */
+    bool h_len_ok = false;       /* h_len holds the lengths of the current reads */
     u64 q_lo = 0, q_hi = 0;
 
     /* index */
@@ -134,6 +135,24 @@ struct disco_ctx {
     /* the grouping's counting pass ran inside the index pass, for the reads [lo, hi) with 2^bits buckets (d_ocnt holds the counts,
      * d_oslot the slots): the next disco_probe over exactly that range skips its own */
     bool order_counted = false;
+    /* contained rows on their way to the host while the pass goes on (disco_mark_contained -> disco_fetch_contained) */
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_crows = nullptr;
+    u32 *d_cpos = nullptr, *d_crow_id = nullptr;
+    u64 *d_crow_key = nullptr;
+    u64 cpos_cap = 0, crow_cap = 0;
+    u64 *d_tile2 = nullptr, *d_total2 = nullptr; /* scan temporaries of the side stream */
+    size_t tile2_cap = 0;
+    void *h_crows = nullptr; /* pinned: keys u64[crows_hcap] then ids u32[crows_hcap] */
+    u64 crows_hcap = 0, crows_n = 0;
+    bool crows_pending = false; /* the rows of the CURRENT flags are on their way / in h_crows */
+    /* disco_fetch_edges: the compacted edges before they travel (kept across passes) */
+    u32 *d_fetch_src = nullptr;
+    u64 *d_fetch_ent = nullptr;
+    u64 fetch_cap = 0;
+    hipStream_t copy_stream = nullptr; /* disco_upload_reads: the chunks of the host buffer travel here */
+    hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr}, ev_unpacked[3] = {nullptr, nullptr, nullptr};
+    bool index_counted = false; /* disco_upload_reads ran the index's count pass behind its copies: disco_build_index starts at the scan */
     u64 order_counted_lo = 0, order_counted_hi = 0;
     int order_counted_bits = 0;
     ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
@@ -387,25 +406,31 @@ static int zero_counter(disco_ctx *c, int idx)
 /* exclusive scan of in[0..n) into out[0..n) (+ out[n] = total when write_total); returns total through *total_host
  * when non-null (this synchronises the stream) */
 template <typename InT, typename OutT>
-static int scan_exclusive(disco_ctx *c, const InT *in, u64 n, OutT *out, bool write_total, u64 *total_host)
+static int scan_exclusive_on(disco_ctx *c, hipStream_t st, u64 **tile, size_t *tile_cap, u64 *total, const InT *in, u64 n, OutT *out, bool write_total, u64 *total_host)
 {
     u64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nt == 0) nt = 1;
-    if (nt > c->tile_cap) {
-        dev_free(c, &c->d_tile, c->tile_cap);
-        CHK(dev_alloc(c, &c->d_tile, nt));
-        c->tile_cap = nt;
+    if (nt > *tile_cap) {
+        dev_free(c, tile, *tile_cap);
+        CHK(dev_alloc(c, tile, nt));
+        *tile_cap = nt;
     }
-    hipLaunchKernelGGL((scan_tile_sums_kernel<InT>), dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, c->stream, in, n, c->d_tile);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile, nt, c->d_total);
-    hipLaunchKernelGGL((scan_apply_kernel<InT, OutT>), dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, c->stream, in, n, c->d_tile, out);
-    if (write_total) hipLaunchKernelGGL((scan_write_total_kernel<OutT>), dim3(1), dim3(1), 0, c->stream, c->d_total, out + n);
+    hipLaunchKernelGGL((scan_tile_sums_kernel<InT>), dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, st, in, n, *tile);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, *tile, nt, total);
+    hipLaunchKernelGGL((scan_apply_kernel<InT, OutT>), dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, st, in, n, *tile, out);
+    if (write_total) hipLaunchKernelGGL((scan_write_total_kernel<OutT>), dim3(1), dim3(1), 0, st, total, out + n);
     HIPCHK(c, hipGetLastError());
     if (total_host) {
-        HIPCHK(c, hipMemcpyAsync(total_host, c->d_total, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(total_host, total, sizeof(u64), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
     }
     return DISCO_OK;
+}
+
+template <typename InT, typename OutT>
+static int scan_exclusive(disco_ctx *c, const InT *in, u64 n, OutT *out, bool write_total, u64 *total_host)
+{
+    return scan_exclusive_on<InT, OutT>(c, c->stream, &c->d_tile, &c->tile_cap, c->d_total, in, n, out, write_total, total_host);
 }
 
 static void free_graph_state(disco_ctx *c)
@@ -518,13 +543,23 @@ static bool own_order_wanted(const disco_ctx *c, u64 nq, int *bits)
     return !c->order_external && !getenv("DISCO_NO_ORDER") && nq >= order_min && nq > 0;
 }
 
-template <bool COUNT>
-static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec, u64 lo, u64 hi)
-{
-    const u64 nloc = hi - lo;
-    /* the counting pass of the grouping rides along when the indexed range is the query range (always, unless a caller narrows it) */
+/* the count pass in two steps so that it can run chunk by chunk behind an upload (disco_upload_reads): index_count_plan fixes, for the
+ * whole range [lo, hi), whether the minimizer runs and the grouping's counting pass ride along and sizes their buffers;
+ * index_count_chunk launches the kernel over a sub-range. */
+struct IndexCountPlan {
+    u64 lo = 0, hi = 0;
+    int lpr = 0;
     u32 *ocnt = nullptr, *oslot = nullptr;
     u32 oshift = 0;
+};
+
+static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, IndexCountPlan *pl)
+{
+    const u64 nloc = hi - lo;
+    *pl = IndexCountPlan();
+    pl->lo = lo;
+    pl->hi = hi;
+    /* the counting pass of the grouping rides along when the indexed range is the query range (always, unless a caller narrows it) */
     c->order_counted = false;
     int obits = 0;
     if (lo == c->q_lo && hi == c->q_hi && own_order_wanted(c, nloc, &obits) && !getenv("DISCO_NO_ORDER_FUSE")) {
@@ -532,9 +567,9 @@ static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec,
         CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
         CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nloc));
         HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
-        ocnt = c->d_ocnt;
-        oslot = c->d_oslot;
-        oshift = 32u - (u32)obits;
+        pl->ocnt = c->d_ocnt;
+        pl->oslot = c->d_oslot;
+        pl->oshift = 32u - (u32)obits;
         c->order_counted = true;
         c->order_counted_lo = lo;
         c->order_counted_hi = hi;
@@ -549,21 +584,127 @@ static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec,
         const double max_gb = getenv("DISCO_RUNS_MAX_GB") ? atof(getenv("DISCO_RUNS_MAX_GB")) : 16.0;
         if ((double)nloc * lpr * 4.0 > max_gb * 1e9) lpr = 0;
     }
-    if (!nloc) return DISCO_OK;
-    const dim3 grid((unsigned)((nloc + 255) / 256));
-    if (lpr) {
+    if (lpr && nloc) {
         CHK(ensure_cap(c, &c->d_runs, &c->runs_cap, nloc * (u64)lpr));
-        if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs, ocnt, oslot, oshift);
-        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, c->d_runs, ocnt, oslot, oshift);
         c->runs_lpr = lpr;
         c->runs_lo = lo;
         c->runs_n = nloc;
+        pl->lpr = lpr;
+    }
+    return DISCO_OK;
+}
+
+/* reads [a, b) of the planned range; rec_base = the records of read pl.lo */
+template <bool COUNT>
+static int index_count_chunk(disco_ctx *c, const DiscoView &v, const IndexCountPlan &pl, ulonglong2 *rec_base, u64 a, u64 b)
+{
+    if (b <= a) return DISCO_OK;
+    const dim3 grid((unsigned)((b - a + 255) / 256));
+    ulonglong2 *rec = rec_base + 2 * (a - pl.lo);
+    u32 *oslot = pl.oslot ? pl.oslot + (a - pl.lo) : nullptr;
+    if (pl.lpr) {
+        u32 *runs = c->d_runs + (a - pl.lo) * (u64)pl.lpr;
+        if (pl.lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);
+        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);
     } else
-        hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, lo, hi, ocnt, oslot, oshift);
+        hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
     HIPCHK(c, hipGetLastError());
     return DISCO_OK;
 }
 
+template <bool COUNT>
+static int launch_index_count(disco_ctx *c, const DiscoView &v, ulonglong2 *rec, u64 lo, u64 hi)
+{
+    IndexCountPlan pl;
+    CHK(index_count_plan(c, v, lo, hi, &pl));
+    return index_count_chunk<COUNT>(c, v, pl, rec, lo, hi);
+}
+
+/* sizes of the index for the context's reads and the cleared bucket table (the start of disco_build_index, or of an upload that
+ * counts while it copies) */
+static int index_begin(disco_ctx *c)
+{
+    u64 T = 1024;
+    int logT = 10;
+    /* records are keyed by minimizer: about one distinct key per 3-4 records at 30x. T >= 2n buckets (measured at 50 M reads:
+     * n / 2n / 4n / 8n buckets -> index 15.2 / 16.4 / 18.6 / 21.0 ms, probe 47.0 / 45.6 / 45.4 / 45.4 ms) */
+    double tscale = 2.0;
+    if (const char *e = getenv("DISCO_BUCKET_SCALE")) tscale = atof(e);
+    while ((double)T < tscale * (double)c->n && logT < 32) {
+        T <<= 1;
+        logT++;
+    }
+    c->T = T;
+    c->bshift = 64 - logT;
+    CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
+    CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
+    /* {key, record} of both end k-mers of every read, computed once by the count pass and re-read by the fill pass */
+    CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
+    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n)); /* grouping keys of all reads (disco_probe orders its query range by them) */
+    c->adj_imported = false;
+    HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (T + 1) * sizeof(u32), c->stream));
+    return DISCO_OK;
+}
+
+/* The contained rows start for the host as soon as the flags are fixed, on a side stream, while edge selection and the reduction run:
+ * (id, key) of the contained reads in ascending id (scan of the flags, gather: 12 bytes per row) into pinned staging memory kept by the
+ * context; disco_fetch_contained then only waits for the event and decodes. (Taken after the pass, the same work — three allocations of up
+ * to n + 1 words, the scan, two pageable copies — was 32 ms of the host-to-host wall at 50 M reads.) Single-GPU passes with up to
+ * DISCO_EAGER_ROWS_MAX (16 M) contained rows; otherwise disco_fetch_contained gathers on demand as before. */
+static int start_contained_rows(disco_ctx *c)
+{
+    c->crows_pending = false;
+    const u64 nc = c->n_contained;
+    const u64 max_rows = getenv("DISCO_EAGER_ROWS_MAX") ? (u64)atoll(getenv("DISCO_EAGER_ROWS_MAX")) : (16ull << 20);
+    if (c->comm || nc == 0 || nc > max_rows || c->n >= (1ull << 31)) return DISCO_OK;
+    if (!c->aux_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_crows, hipEventDisableTiming));
+        HIPCHK(c, hipMalloc((void **)&c->d_total2, sizeof(u64)));
+    }
+    CHK(ensure_cap(c, &c->d_cpos, &c->cpos_cap, c->n + 1));
+    if (nc > c->crow_cap) {
+        dev_free(c, &c->d_crow_id, c->crow_cap);
+        dev_free(c, &c->d_crow_key, c->crow_cap);
+        c->crow_cap = 0;
+        const u64 want = nc + nc / 4 + 1024;
+        CHK(dev_alloc(c, &c->d_crow_id, want));
+        CHK(dev_alloc(c, &c->d_crow_key, want));
+        c->crow_cap = want;
+    }
+    if (nc > c->crows_hcap) {
+        if (c->h_crows) (void)hipHostFree(c->h_crows);
+        c->h_crows = nullptr;
+        c->crows_hcap = 0;
+        const u64 want = nc + nc / 4 + 1024;
+        if (hipHostMalloc(&c->h_crows, want * 12) != hipSuccess) { /* no pinned memory to be had: the on-demand path */
+            c->h_crows = nullptr;
+            (void)hipGetLastError();
+            return DISCO_OK;
+        }
+        c->crows_hcap = want;
+    }
+    /* (the flags are complete: disco_mark_contained has just synchronised the context's stream) */
+    CHK((scan_exclusive_on<u8, u32>(c, c->aux_stream, &c->d_tile2, &c->tile2_cap, c->d_total2, c->d_contained, c->n, c->d_cpos, false, nullptr)));
+    hipLaunchKernelGGL(contain_rows32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->aux_stream, c->d_best, c->d_contained, c->d_cpos, c->n, c->d_crow_id, c->d_crow_key);
+    HIPCHK(c, hipGetLastError());
+    u64 *hkey = (u64 *)c->h_crows;
+    u32 *hid = (u32 *)(hkey + c->crows_hcap);
+    HIPCHK(c, hipMemcpyAsync(hkey, c->d_crow_key, nc * 8, hipMemcpyDeviceToHost, c->aux_stream));
+    HIPCHK(c, hipMemcpyAsync(hid, c->d_crow_id, nc * 4, hipMemcpyDeviceToHost, c->aux_stream));
+    HIPCHK(c, hipEventRecord(c->ev_crows, c->aux_stream));
+    c->crows_n = nc;
+    c->crows_pending = true;
+    return DISCO_OK;
+}
+
+/* the side stream reads best[] and the flags: nothing may rewrite them before it is done */
+static int settle_contained_rows(disco_ctx *c)
+{
+    if (c->crows_pending) HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+    c->crows_pending = false;
+    return DISCO_OK;
+}
 
 static int dist_mark_contained(disco_ctx *c); /* multi-GPU flow, below */
 
@@ -645,6 +786,24 @@ void disco_destroy(disco_ctx *c)
     delete c->comm;
     c->comm = c->comm_bulk = nullptr;
     if (c->bulk_stream) (void)hipStreamDestroy(c->bulk_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        (void)hipStreamDestroy(c->aux_stream);
+        (void)hipEventDestroy(c->ev_crows);
+        (void)hipFree(c->d_total2);
+    }
+    dev_free(c, &c->d_tile2, c->tile2_cap);
+    dev_free(c, &c->d_cpos, c->cpos_cap);
+    dev_free(c, &c->d_crow_id, c->crow_cap);
+    dev_free(c, &c->d_crow_key, c->crow_cap);
+    dev_free(c, &c->d_fetch_src, c->fetch_cap);
+    dev_free(c, &c->d_fetch_ent, c->fetch_cap);
+    if (c->h_crows) (void)hipHostFree(c->h_crows);
+    for (int i = 0; i < 3; i++) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_unpacked[i]) (void)hipEventDestroy(c->ev_unpacked[i]);
+    }
     if (c->ev_bulk) (void)hipEventDestroy(c->ev_bulk);
     for (int i = 0; i < DISCO_PH_COUNT; i++) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
@@ -711,11 +870,14 @@ static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride, bool *keep = n
 {
     if (n >= (1ull << 31)) return fail(c, DISCO_E_UNSUPPORTED, "more than 2^31 reads per context are not supported");
     if (stride == 0 || stride > 1024) return fail(c, DISCO_E_ARG, "stride_words %u out of range", stride);
+    c->index_counted = false;
+    if (c->crows_pending && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    c->crows_pending = false;
     if (keep) {
         *keep = c->reads_owned && !c->dist_reads && !c->comm && c->d_reads && c->d_len && n > 0 && c->n == n && c->n_alloc == n && c->S == (int)stride &&
                 !getenv("DISCO_NO_BUFFER_REUSE");
         if (*keep) {
-            c->h_len.clear();
+            c->h_len_ok = false; /* (not cleared: the next upload overwrites it in place) */
             c->n_out = c->out_used = 0;
             c->adj_total = 0;
             c->flags_pending = false;
@@ -765,6 +927,28 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
     HIPCHK(c, hipSetDevice(c->device));
     /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
     const uint32_t dstride = (stride_words + 7u) & ~7u;
+    /* the lengths are checked where they are (the host has them): min_overlap < len <= min(32767, 32 * stride) (BG/Dataset.cpp:305,
+     * BG/HashTable.cpp:531); longest / shortest decide the kernel variants of the pass */
+    std::atomic<u64> a_bad{0};
+    std::atomic<u32> a_max{0}, a_min{0xFFFFu};
+    {
+        const u32 mo = c->prm.min_overlap, cap = std::min<u32>(32767u, stride_words * 32u);
+        parallel_for(n, [&](u64 b0, u64 e0) {
+            u64 bad = 0;
+            u32 mx = 0, mn = 0xFFFFu;
+            for (u64 i = b0; i < e0; i++) {
+                const u32 L = len[i];
+                bad += (L <= mo || L > cap);
+                mx = std::max(mx, L);
+                mn = std::min(mn, L);
+            }
+            a_bad += bad;
+            u32 cur = a_max.load();
+            while (mx > cur && !a_max.compare_exchange_weak(cur, mx)) {}
+            cur = a_min.load();
+            while (mn < cur && !a_min.compare_exchange_weak(cur, mn)) {}
+        });
+    }
     bool kept = false;
     CHK(set_reads_common(c, n, dstride, &kept));
     if (!kept) {
@@ -772,29 +956,67 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
         CHK(dev_alloc(c, &c->d_len, n));
     }
     c->reads_owned = true;
+    if (a_bad.load())
+        return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)a_bad.load(), c->prm.min_overlap);
+    c->max_len = n ? a_max.load() : 0;
+    c->min_len = n ? a_min.load() : 0;
     if (n) {
-        if (dstride != stride_words) {
-            /* narrower host rows (150 bp: 5 of the 8 words): ONE dense copy at the link's rate and a kernel that spreads the rows over the
-             * table — a 2-D copy of 40-byte rows ran at 8.7 GB/s (buildG, config 3: 0.23 s for 2 GB) */
-            u64 *dense = nullptr;
-            HIPCHK(c, hipMemsetAsync(c->d_reads, 0, n * (u64)dstride * 8, c->stream));
-            if (dev_alloc(c, &dense, n * (u64)stride_words) == DISCO_OK) {
-                hipError_t e1 = hipMemcpyAsync(dense, packed, n * (u64)stride_words * 8, hipMemcpyHostToDevice, c->stream);
-                hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, n * (u64)stride_words)), dim3(256), 0, c->stream, dense, (int)dstride, (int)stride_words, (u64)n, (u64)0,
-                                   (u64)0, c->d_reads);
-                hipError_t e2 = hipStreamSynchronize(c->stream);
-                dev_free(c, &dense, n * (u64)stride_words);
-                if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, DISCO_E_HIP, "disco_upload_reads: copy failed");
-            } else { /* no room for the staging copy next to the table: row by row */
-                c->err.clear();
-                HIPCHK(c, hipMemcpy2DAsync(c->d_reads, (size_t)dstride * 8, packed, (size_t)stride_words * 8, (size_t)stride_words * 8, n, hipMemcpyHostToDevice, c->stream));
+        /* The copy runs in chunks on a stream of its own; behind it, chunk by chunk on the context's stream: rows spread to the 64-byte
+         * stride of the table (host rows at the words they use: 5 of 8 at 150 bp — 2.0 instead of 3.2 GB over the link; a 2-D copy of 40-byte
+         * rows ran at 8.7 GB/s) and the COUNT PASS OF THE INDEX over the chunk's reads (index_runs_kernel: 9 ms at 50 M reads, hidden behind
+         * the 38 ms of the copy) — disco_build_index then starts at its scan. The call returns when the host buffer is free again. */
+        if (!c->copy_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 3; i++) {
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_unpacked[i], hipEventDisableTiming));
             }
-        } else /* (a 2-D copy whose width equals both pitches still ran at a third of this one's rate: 181 against 61 ms for 3.2 GB) */
-            HIPCHK(c, hipMemcpyAsync(c->d_reads, packed, n * (u64)dstride * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
+        CH = std::max<u64>((CH + 255) & ~255ull, 256);
+        const bool narrow = dstride != stride_words;
+        const bool eager = !c->comm && !getenv("DISCO_NO_EAGER_INDEX");
         HIPCHK(c, hipMemcpyAsync(c->d_len, len, n * 2, hipMemcpyHostToDevice, c->stream));
-    }
-    c->h_len.assign(len, len + n);
-    return validate_reads(c);
+        if (narrow) CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, 3 * std::min<u64>(CH, n) * (u64)stride_words));
+        IndexCountPlan pl;
+        DiscoView v;
+        if (eager) {
+            CHK(index_begin(c));
+            v = view(c);
+            CHK(index_count_plan(c, v, 0, n, &pl));
+        }
+        u64 k = 0;
+        for (u64 lo = 0; lo < n; lo += CH, k++) {
+            const u64 hi = std::min<u64>(n, lo + CH);
+            const int b = (int)(k % 3);
+            if (narrow) {
+                u64 *ring = c->d_dense + (u64)b * std::min<u64>(CH, n) * stride_words;
+                if (k >= 3) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_unpacked[b], 0));
+                HIPCHK(c, hipMemcpyAsync(ring, packed + lo * stride_words, (hi - lo) * (u64)stride_words * 8, hipMemcpyHostToDevice, c->copy_stream));
+                HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+                hipLaunchKernelGGL(unpack_pad_kernel, dim3(flat_grid(c, (hi - lo) * (u64)dstride)), dim3(256), 0, c->stream, ring, (int)dstride, (int)stride_words, hi - lo,
+                                   c->d_reads + lo * dstride);
+                HIPCHK(c, hipEventRecord(c->ev_unpacked[b], c->stream));
+            } else { /* (one 1-D copy per chunk: a 2-D copy whose width equals both pitches ran at a third of the rate) */
+                HIPCHK(c, hipMemcpyAsync(c->d_reads + lo * dstride, packed + lo * dstride, (hi - lo) * (u64)dstride * 8, hipMemcpyHostToDevice, c->copy_stream));
+                HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+            }
+            if (eager) CHK((index_count_chunk<true>(c, v, pl, c->d_rec, lo, hi)));
+        }
+        HIPCHK(c, hipGetLastError());
+        /* the host's copy of the lengths (result decoding) while the chunks travel */
+        if (c->h_len.size() != n) c->h_len.resize(n);
+        uint16_t *hl = c->h_len.data();
+        parallel_for(n, [&, hl](u64 b0, u64 e0) { memcpy(hl + b0, len + b0, (e0 - b0) * 2); });
+        c->h_len_ok = true;
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        c->index_counted = eager;
+    } else
+        c->h_len.clear();
+    c->phase = 1;
+    return DISCO_OK;
 }
 
 int disco_adopt_reads(disco_ctx *c, const void *d_packed, uint32_t stride_words, const void *d_len, uint64_t n)
@@ -839,6 +1061,7 @@ int disco_substitute_bases(disco_ctx *c, uint64_t seed, uint32_t rate_ppm)
     const u64 lo = c->comm ? c->q_lo : 0, hi = c->comm ? c->q_hi : c->n; /* multi-GPU flow: the other ranks' rows arrive by all-gather */
     if (hi > lo && rate_ppm)
         hipLaunchKernelGGL(substitute_bases_kernel, dim3(flat_grid(c, (hi - lo) * (u64)c->S)), dim3(256), 0, c->stream, (u64)seed, rate_ppm, c->d_reads, c->d_len, c->S, lo, hi);
+    c->index_counted = c->order_counted = false; /* what an upload counted ahead was counted on the reads as they were */
     HIPCHK(c, hipGetLastError());
     return DISCO_OK;
 }
@@ -873,31 +1096,15 @@ int disco_build_index(disco_ctx *c)
     if (!c) return DISCO_E_ARG;
     if (c->phase < 1) return fail(c, DISCO_E_STATE, "disco_build_index: no reads");
     HIPCHK(c, hipSetDevice(c->device));
-    u64 T = 1024;
-    int logT = 10;
-    /* records are keyed by minimizer: about one distinct key per 3-4 records at 30x. T >= 2n buckets (measured at 50 M reads:
-     * n / 2n / 4n / 8n buckets -> index 15.2 / 16.4 / 18.6 / 21.0 ms, probe 47.0 / 45.6 / 45.4 / 45.4 ms) */
-    double tscale = 2.0;
-    if (const char *e = getenv("DISCO_BUCKET_SCALE")) tscale = atof(e);
-    while ((double)T < tscale * (double)c->n && logT < 32) {
-        T <<= 1;
-        logT++;
-    }
-    c->T = T;
-    c->bshift = 64 - logT;
-    CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
-    CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
-    c->adj_imported = false;
     ph_begin(c, DISCO_PH_INDEX);
-    HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (T + 1) * sizeof(u32), c->stream));
-    DiscoView v = view(c);
-    /* {key, record} of both end k-mers of every read, computed once by the count pass and re-read by the fill pass */
-    CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, 2 * c->n));
-    ulonglong2 *rec = c->d_rec;
-    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n)); /* grouping keys of all reads (disco_probe orders its query range by them) */
-    CHK(launch_index_count<true>(c, v, rec, 0, c->n));
-    CHK((scan_exclusive<u32, u32>(c, c->d_bkt, T + 1, c->d_bkt, false, nullptr)));
-    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, rec, c->d_bkt, c->d_ent);
+    if (c->index_counted) { /* disco_upload_reads counted while it copied: the bucket counts, records, runs and keys are in place */
+        c->index_counted = false;
+    } else {
+        CHK(index_begin(c));
+        CHK(launch_index_count<true>(c, view(c), c->d_rec, 0, c->n));
+    }
+    CHK((scan_exclusive<u32, u32>(c, c->d_bkt, c->T + 1, c->d_bkt, false, nullptr)));
+    if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, c->d_rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
     ph_end(c, DISCO_PH_INDEX);
     c->phase = 2;
@@ -911,6 +1118,7 @@ int disco_probe(disco_ctx *c)
     if (!c) return DISCO_E_ARG;
     if (c->phase < 2) return fail(c, DISCO_E_STATE, "disco_probe: build the index first");
     HIPCHK(c, hipSetDevice(c->device));
+    CHK(settle_contained_rows(c)); /* rows of the previous pass still travelling read best[] */
     const u64 nq = c->q_hi - c->q_lo;
     if (!c->d_best) {
         CHK(dev_alloc(c, &c->d_best, c->n_alloc));
@@ -1162,6 +1370,7 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
     c->n_contained = c->h_ctr[CTR_N_CONTAINED];
     if (n_contained) *n_contained = c->n_contained;
     c->phase = 4;
+    CHK(start_contained_rows(c));
     return DISCO_OK;
 }
 
@@ -1758,9 +1967,10 @@ int disco_run_graph(disco_ctx *c)
 /* ---------------------------------------------------------------------------------------------------------------- */
 static int ensure_host_len(disco_ctx *c)
 {
-    if (c->h_len.size() == c->n) return DISCO_OK;
+    if (c->h_len_ok && c->h_len.size() == c->n) return DISCO_OK;
     c->h_len.resize(c->n);
     if (c->n) HIPCHK(c, hipMemcpy(c->h_len.data(), c->d_len, c->n * 2, hipMemcpyDeviceToHost));
+    c->h_len_ok = true;
     return DISCO_OK;
 }
 
@@ -1775,6 +1985,33 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     if (cap < nc) return fail(c, DISCO_E_ARG, "disco_fetch_contained: need room for %llu rows", (unsigned long long)nc);
     if (nc == 0) return 0;
     CHK(ensure_host_len(c));
+    auto decode = [&](auto id_of, const u64 *keys_h) {
+        const u16 *hlen = c->h_len.data();
+        const u32 kk = (u32)c->k;
+        parallel_for(nc, [&, hlen, kk](u64 b, u64 e_) {
+            for (u64 i = b; i < e_; i++) {
+                const u64 key = keys_h[i];
+                disco_contained_row &r = out[i];
+                r.contained = id_of(i);
+                r.super = CKEY_SUPER(key);
+                r.j = CKEY_J(key);
+                r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
+                r.len2 = hlen[r.contained];
+                r.len1 = hlen[r.super];
+                u32 orient, off;
+                disco_map_type(r.type, r.len1, kk, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
+                r.orient = orient;
+                r.start = off;
+            }
+        });
+    };
+    if (c->crows_pending && c->crows_n == nc) { /* they left during the pass (start_contained_rows) */
+        HIPCHK(c, hipEventSynchronize(c->ev_crows));
+        const u64 *hkey = (const u64 *)c->h_crows;
+        const u32 *hid = (const u32 *)(hkey + c->crows_hcap);
+        decode([hid](u64 i) { return (u64)hid[i]; }, hkey);
+        return (int64_t)nc;
+    }
     u64 *pos = nullptr, *ids = nullptr, *keys = nullptr;
     std::vector<u64> hid(nc), hkey(nc);
     auto gather = [&]() -> int {
@@ -1793,24 +2030,7 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     dev_free(c, &ids, nc);
     dev_free(c, &keys, nc);
     CHK(grc);
-    const u16 *hlen = c->h_len.data();
-    const u32 kk = (u32)c->k;
-    parallel_for(nc, [&, hlen, kk](u64 b, u64 e_) {
-        for (u64 i = b; i < e_; i++) {
-            const u64 key = hkey[i];
-            disco_contained_row &r = out[i];
-            r.contained = hid[i];
-            r.super = CKEY_SUPER(key);
-            r.j = CKEY_J(key);
-            r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
-            r.len2 = hlen[r.contained];
-            r.len1 = hlen[r.super];
-            u32 orient, off;
-            disco_map_type(r.type, r.len1, kk, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
-            r.orient = orient;
-            r.start = off;
-        }
-    });
+    decode([&hid](u64 i) { return hid[i]; }, hkey.data());
     return (int64_t)nc;
 }
 
@@ -1825,13 +2045,22 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     if (cap < ne) return fail(c, DISCO_E_ARG, "disco_fetch_edges: need room for %llu edges", (unsigned long long)ne);
     if (ne == 0) return 0;
     CHK(ensure_host_len(c));
-    /* drop the unused chunk tails of the emission, then copy out: chunk k travels into pinned staging memory (kept by the context) while
-     * the host threads turn chunk k - 1 into disco_edge records — a copy into pageable memory ran at a third of the link's rate */
-    u64 *csrc = nullptr, *cent = nullptr;
-    CHK(dev_alloc(c, &csrc, ne));
-    CHK(dev_alloc(c, &cent, ne));
-    hipLaunchKernelGGL(emit_compact_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos, c->out_used, csrc, cent);
-    const u64 CHUNK = 1ull << 22; /* 4 M edges: 2 x 32 MB per buffer */
+    /* drop the unused chunk tails of the emission (into buffers the context keeps: two allocations of 0.4 GB per call cost more than the
+     * copy), then copy out 12 bytes per edge — source as 32 bits, packed entry — chunk k into pinned staging memory (kept by the context)
+     * while the host threads turn chunk k - 1 into disco_edge records; a copy into pageable memory ran at a third of the link's rate */
+    if (ne > c->fetch_cap) {
+        dev_free(c, &c->d_fetch_src, c->fetch_cap);
+        dev_free(c, &c->d_fetch_ent, c->fetch_cap);
+        c->fetch_cap = 0;
+        const u64 want = ne + ne / 8 + 1024;
+        CHK(dev_alloc(c, &c->d_fetch_src, want));
+        CHK(dev_alloc(c, &c->d_fetch_ent, want));
+        c->fetch_cap = want;
+    }
+    u32 *csrc = c->d_fetch_src;
+    u64 *cent = c->d_fetch_ent;
+    hipLaunchKernelGGL(emit_compact32_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->d_out_ent, c->d_out_valid, c->d_out_pos, c->out_used, csrc, cent);
+    const u64 CHUNK = 1ull << 22; /* 4 M edges: 48 MB per half */
     if (!c->h_stage) {
         if (hipHostMalloc((void **)&c->h_stage, 4 * CHUNK * sizeof(u64)) != hipSuccess) c->h_stage = nullptr;
         for (int i = 0; i < 2 && c->h_stage; i++)
@@ -1841,7 +2070,7 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
             }
     }
     const u16 *hlen = c->h_len.data();
-    auto convert = [&](const u64 *hsp, const u64 *hep, u64 base, u64 cnt) {
+    auto convert = [&](const u32 *hsp, const u64 *hep, u64 base, u64 cnt) {
         parallel_for(cnt, [&, hlen, hsp, hep, base](u64 b, u64 e_) {
             for (u64 i = b; i < e_; i++) {
                 disco_edge &e = out[base + i];
@@ -1857,28 +2086,28 @@ int64_t disco_fetch_edges(disco_ctx *c, disco_edge *out, uint64_t cap)
     bool ok = true;
     if (c->h_stage) {
         const u64 nch = (ne + CHUNK - 1) / CHUNK;
+        auto half_ent = [&](u64 k) { return c->h_stage + (k & 1) * 2 * CHUNK; };          /* entries: CHUNK words   */
+        auto half_src = [&](u64 k) { return (u32 *)(c->h_stage + (k & 1) * 2 * CHUNK + CHUNK); }; /* sources: CHUNK / 2 words */
         auto issue = [&](u64 k) {
-            u64 *hs = c->h_stage + (k & 1) * 2 * CHUNK, *he = hs + CHUNK;
             const u64 cnt = std::min(CHUNK, ne - k * CHUNK);
-            ok = ok && hipMemcpyAsync(hs, csrc + k * CHUNK, cnt * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                 hipMemcpyAsync(he, cent + k * CHUNK, cnt * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+            ok = ok && hipMemcpyAsync(half_src(k), csrc + k * CHUNK, cnt * 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                 hipMemcpyAsync(half_ent(k), cent + k * CHUNK, cnt * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                  hipEventRecord(c->ev_stage[k & 1], c->stream) == hipSuccess;
         };
         issue(0);
         for (u64 k = 0; k < nch && ok; k++) {
             ok = hipEventSynchronize(c->ev_stage[k & 1]) == hipSuccess;
             if (k + 1 < nch) issue(k + 1); /* into the other half, converted one iteration ago */
-            if (ok) convert(c->h_stage + (k & 1) * 2 * CHUNK, c->h_stage + (k & 1) * 2 * CHUNK + CHUNK, k * CHUNK, std::min(CHUNK, ne - k * CHUNK));
+            if (ok) convert(half_src(k), half_ent(k), k * CHUNK, std::min(CHUNK, ne - k * CHUNK));
         }
         ok = (hipStreamSynchronize(c->stream) == hipSuccess) && ok;
     } else { /* no pinned memory to be had: one pageable copy */
-        std::unique_ptr<u64[]> hs(new u64[ne]), he(new u64[ne]); /* not zero-filled: 0.7 GB at 45 M edges */
-        ok = hipMemcpyAsync(hs.get(), csrc, ne * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+        std::unique_ptr<u32[]> hs(new u32[ne]);
+        std::unique_ptr<u64[]> he(new u64[ne]); /* not zero-filled: 0.5 GB at 45 M edges */
+        ok = hipMemcpyAsync(hs.get(), csrc, ne * 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
              hipMemcpyAsync(he.get(), cent, ne * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
         if (ok) convert(hs.get(), he.get(), 0, ne);
     }
-    dev_free(c, &csrc, ne);
-    dev_free(c, &cent, ne);
     if (!ok) return fail(c, DISCO_E_HIP, "disco_fetch_edges: copy failed");
     return (int64_t)ne;
 }

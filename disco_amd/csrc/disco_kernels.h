@@ -1281,7 +1281,13 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             r.aw = own[lane < (u32)NW ? lane : 0u];
             if (PREF) {
                 u64 w[staged ? NW : 1];
+#if defined(VERIFY_EXP_NOROWS) /* timing experiment (tools/ab_build.py; results are wrong): every lane fetches the read's own row */
+                load_row(w, own);
+#elif defined(VERIFY_EXP_NEARROWS) /* ... : rows next to the read's own (one per lane, distinct lines that consecutive reads share) */
+                load_row(w, a.v.reads + ((A & ~63ull) + lane < a.v.n ? (A & ~63ull) + lane : A) * S);
+#else
                 load_row(w, (lane < mt.c && in_pass(h, mt.L)) ? a.v.reads + HIT_ID(h) * S : own);
+#endif
 #pragma unroll
                 for (int t = 0; t < RW; t++) r.w[t] = w[t % (staged ? NW : 1)];
             }
@@ -1500,6 +1506,18 @@ __global__ void contain_rows_kernel(const u64 *__restrict__ best, const u8 *__re
     for (; i < n; i += (u64)gridDim.x * blockDim.x)
         if (contained[i]) {
             out_id[pos[i]] = i;
+            out_key[pos[i]] = best[i];
+        }
+}
+
+/* the same with 32-bit positions and ids (fewer than 2^31 reads per context): what travels to the host is 12 bytes per row */
+__global__ void contain_rows32_kernel(const u64 *__restrict__ best, const u8 *__restrict__ contained, const u32 *__restrict__ pos,
+                                      u64 n, u32 *__restrict__ out_id, u64 *__restrict__ out_key)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (contained[i]) {
+            out_id[pos[i]] = (u32)i;
             out_key[pos[i]] = best[i];
         }
 }
@@ -2756,6 +2774,18 @@ __global__ void emit_valid_kernel(const u64 *__restrict__ out_src, u64 n, u8 *__
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (u64)gridDim.x * blockDim.x) valid[i] = out_src[i] != ~0ull;
+}
+
+/* the copy-out form: 12 bytes per edge (the source as 32 bits) */
+__global__ void emit_compact32_kernel(const u64 *__restrict__ out_src, const u64 *__restrict__ out_ent, const u8 *__restrict__ valid,
+                                      const u64 *__restrict__ pos, u64 n, u32 *__restrict__ dst_src, u64 *__restrict__ dst_ent)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (valid[i]) {
+            dst_src[pos[i]] = (u32)out_src[i];
+            dst_ent[pos[i]] = out_ent[i];
+        }
 }
 
 __global__ void emit_compact_kernel(const u64 *__restrict__ out_src, const u64 *__restrict__ out_ent, const u8 *__restrict__ valid,

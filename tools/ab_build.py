@@ -10,9 +10,10 @@ sys.path.insert(0, ROOT)
 from disco_amd import build  # noqa: E402
 
 name, flags = sys.argv[1], sys.argv[2:]
+os.makedirs(os.path.join(ROOT, "gpurun_tmp"), exist_ok=True)
 out = os.path.join(ROOT, "gpurun_tmp", f"lib_{name}.so")
 cmd = [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Rpass-analysis=kernel-resource-usage", "-o", out] + flags + \
-      build.HIP_SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+      build.HIP_SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"]
 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 if r.returncode:
     sys.exit(r.stderr[-3000:])
