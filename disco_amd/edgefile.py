@@ -55,3 +55,48 @@ def text_files(prefix, tags=None):
             tag = tags[t] if tags else str(t)
             out[f"{prefix}_{tag}_{suffix}.txt"] = "".join(lines(rec[rec["file"] == t]))
     return out
+
+
+def _header(magic, dtype, n, n_files):
+    h = np.zeros(1, dtype=HEADER)
+    h["magic"], h["version"], h["record_bytes"], h["n_records"], h["n_files"] = magic, 1, dtype.itemsize, n, n_files
+    return h.tobytes()
+
+
+def from_text(prefix, n_files, out_prefix=None, empty_text=False):
+    """the binary pair <out_prefix>_edges.bin / _contained.bin from the text files <prefix>_<t>_parGraph.txt / _containedReads.txt,
+    t = 0 .. n_files - 1 (what `buildG --binary-out` writes beside them; here for files that exist as text only: fixtures, the
+    reference's own output). empty_text: truncate the text files afterwards — the state `buildG --no-text` leaves, which is what
+    makes a loader with the binary patch (oracle/patches) take its binary path."""
+    out_prefix = out_prefix or prefix
+    e_rows, c_rows = [], []
+    for t in range(n_files):
+        with open(f"{prefix}_{t}_parGraph.txt") as f:
+            for line in f:
+                if not line.strip():
+                    continue
+                a, b, info = line.rstrip("\n").split("\t")[:3]
+                p = info.split(",")
+                # orient, ovl, subst, edits, len1, start1, stop1, len2, start2, stop2, NA, flag
+                e_rows.append((int(a), int(b), int(p[0]), int(p[5]), int(p[4]), int(p[7]), t, int(p[11]) if len(p) > 11 else 2, int(p[2])))
+        with open(f"{prefix}_{t}_containedReads.txt") as f:
+            for line in f:
+                if not line.strip():
+                    continue
+                a, b, info = line.rstrip("\n").split("\t")[:3]
+                p = info.split(",")
+                # orient, len2, 0, 0, len2, 0, len2, len1, start, start + len2
+                c_rows.append((int(a), int(b), int(p[0]), int(p[1]), int(p[7]), int(p[8]), t, 0, 0))
+    e = np.array(e_rows, dtype=EDGE) if e_rows else np.zeros(0, dtype=EDGE)
+    c = np.array(c_rows, dtype=CONTAINED) if c_rows else np.zeros(0, dtype=CONTAINED)
+    with open(out_prefix + "_edges.bin", "wb") as f:
+        f.write(_header(b"DISCOEDG", EDGE, len(e), n_files))
+        f.write(e.tobytes())
+    with open(out_prefix + "_contained.bin", "wb") as f:
+        f.write(_header(b"DISCOCON", CONTAINED, len(c), n_files))
+        f.write(c.tobytes())
+    if empty_text:
+        for t in range(n_files):
+            open(f"{out_prefix}_{t}_parGraph.txt", "w").close()
+            open(f"{out_prefix}_{t}_containedReads.txt", "w").close()
+    return len(e), len(c)

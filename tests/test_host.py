@@ -502,3 +502,74 @@ def test_edge_lines_formatted_on_the_gpu_are_the_host_writers_bytes(tmp_path, ca
                      [open(f"{prefix}_{t}_startRead.txt", "rb").read() for t in range(threads)]
     assert files["gpu"] == files["host"]
     assert sum(len(x) for x in files["gpu"][:threads]) > 200  # lines
+
+
+REF_PS_BIN = REF_PS + "_bin"  # the reference parsimplify with the binary loader spliced in (oracle/Makefile: ref_binary_loaders)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_PS_INITLEN) and os.path.exists(REF_PS_BIN)),
+                    reason="prebuilt reference parsimplify with / without the binary loader (make -C oracle ref_parsimplify ref_binary_loaders) not present")
+@pytest.mark.parametrize("name", ["u150_5k", "mixed_4k", "k30_6k", "multifile"])
+def test_reference_loader_patch_reads_the_binary_edge_file(tmp_path, name):
+    """SURVEY.md 8 f-3, the consumer's half: the REAL parsimplify with oracle/patches spliced into its loader, given an EMPTY
+    <prefix>_<t>_parGraph.txt next to <prefix>_edges.bin (the state buildG --no-text leaves), writes the lines it writes for the text
+    file — two files, flags 0 / 1 on the edges that cross them, so that the file filter and the marks of the binary path are exercised."""
+    from disco_amd import edgefile
+
+    lines = [l.rstrip("\n") for l in open(os.path.join(gu.GOLD, name + ".edges.txt")) if l.strip()]
+    ids = sorted({int(x) for l in lines for x in l.split("\t")[:2]})
+    cut = ids[len(ids) // 2]
+    text = str(tmp_path / "t")
+    files = [open(f"{text}_{t}_parGraph.txt", "w") for t in range(2)]
+    for l in lines:
+        a, b = (int(x) for x in l.split("\t")[:2])
+        lo, hi = a < cut, b < cut
+        if lo or hi:
+            files[0].write(l + (",2\n" if lo and hi else (",0\n" if lo else ",1\n")))
+        if not lo or not hi:
+            files[1].write(l + (",2\n" if not lo and not hi else (",0\n" if not lo else ",1\n")))
+    for f in files:
+        f.close()
+    for t in range(2):
+        open(f"{text}_{t}_containedReads.txt", "w").close()
+    binp = str(tmp_path / "b")
+    ne, _ = edgefile.from_text(text, 2, out_prefix=binp, empty_text=True)
+    assert ne >= len(lines) and os.path.getsize(f"{binp}_0_parGraph.txt") == 0
+    for t in range(2):
+        want, got = str(tmp_path / f"want_{t}.txt"), str(tmp_path / f"got_{t}.txt")
+        _run_ps(REF_PS_INITLEN, f"{text}_{t}_parGraph.txt", want, 30, 2)
+        p = subprocess.run([REF_PS_BIN, f"{binp}_{t}_parGraph.txt", got, "30", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0 and "edges loaded to memory from" in p.stdout, p.stdout[-2000:]
+        a, b = _par_lines(want), _par_lines(got)
+        assert len(a) > 0 and a == b, (t, len(a), len(b))
+        # the patched binary on the TEXT file takes the reference's own path
+        again = str(tmp_path / f"again_{t}.txt")
+        _run_ps(REF_PS_BIN, f"{text}_{t}_parGraph.txt", again, 30, 2)
+        assert _par_lines(again) == a
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(REF_PS_INITLEN) and os.path.exists(REF_PS_BIN)), reason="prebuilt reference parsimplify binaries not present")
+def test_buildg_no_text_feeds_the_patched_reference_loader(tmp_path):
+    """buildG --no-text (binary side output only, text files left empty) -> the REAL parsimplify with the loader patch, file by file:
+    the lines it writes for the text files of an ordinary buildG run on the same reads"""
+    from disco_amd import readgen
+
+    build.build_host()
+    spec = readgen.GenSpec.coverage(seed=9, n_reads=40000, read_len=110, cov=25.0, n_contigs=5, len_max=200)
+    fa = str(tmp_path / "r.fasta")
+    readgen.write_fasta(fa, readgen.generate_reads(spec))
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\n")
+    out = {}
+    for how, extra in (("text", []), ("bin", ["--no-text"])):
+        prefix = str(tmp_path / how)
+        p = subprocess.run([os.path.join(BIN, "buildG"), "-se", fa, "-f", prefix, "-p", str(cfg), "-t", "3"] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout
+        out[how] = []
+        for t in range(3):
+            res = str(tmp_path / f"{how}_{t}.out")
+            _run_ps(REF_PS_INITLEN if how == "text" else REF_PS_BIN, f"{prefix}_{t}_parGraph.txt", res, 40, 2)
+            out[how].append(_par_lines(res))
+    assert os.path.getsize(str(tmp_path / "bin_0_parGraph.txt")) == 0 and os.path.getsize(str(tmp_path / "bin_edges.bin")) > 1000
+    assert out["text"] == out["bin"] and sum(len(x) for x in out["text"]) > 0

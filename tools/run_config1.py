@@ -12,7 +12,10 @@ reads from one 0.6 Mbp uniform-random genome (25x; at the 3x of a 4.6 Mbp genome
                                   runDisco.sh -osg: the reference's fullsimplify / parsimplify consume the drop-in's files
   ours-simple DIR GRAPHDIR      : as `ours`, with the drop-in's <out>/assembly/disco_<i>_ParSimpleEdges.txt in place too (buildG under
                                   DISCO_PAR_SIMPLE=1): fullsimplify loads them and never starts parsimplify
-  fixture REFDIR OURSDIR [OURSSIMPLEDIR] : canonical digests of both graphs + scaffold statistics of both runs -> tests/golden/config1.json
+  ours-binary DIR GRAPHDIR      : as `ours`, with the graph as the BINARY side output only (<prefix>_edges.bin / _contained.bin,
+                                  the text files emptied — the state `buildG --no-text` leaves) and the reference's fullsimplify /
+                                  parsimplify with the loader patch of oracle/patches spliced in (oracle/Makefile: ref_binary_loaders)
+  fixture REFDIR OURSDIR [OURSSIMPLEDIR [OURSBINARYDIR]] : canonical digests of both graphs + scaffold statistics of both runs -> tests/golden/config1.json
 """
 import glob
 import hashlib
@@ -71,7 +74,7 @@ def graph_digests(prefix):
             "contained_sha256": pyoracle.digest(pyoracle.contained_text(c))}
 
 
-def stage_dir(d, build_g):
+def stage_dir(d, build_g, suffix=""):
     """runDisco.sh looks for buildG / fullsimplify / parsimplify and disco*.cfg beside itself (runDisco.sh:3-7,16-18,142-150)"""
     b = os.path.join(d, "bin")
     os.makedirs(b, exist_ok=True)
@@ -80,8 +83,8 @@ def stage_dir(d, build_g):
     os.chmod(os.path.join(b, "runDisco.sh"), 0o755)
     ref = os.path.join(ROOT, "oracle", "_ref")
     shutil.copy(build_g, os.path.join(b, "buildG"))
-    shutil.copy(os.path.join(ref, "fullsimplify_ref"), os.path.join(b, "fullsimplify"))
-    shutil.copy(os.path.join(ref, "parsimplify_ref"), os.path.join(b, "parsimplify"))
+    shutil.copy(os.path.join(ref, "fullsimplify_ref" + suffix), os.path.join(b, "fullsimplify"))
+    shutil.copy(os.path.join(ref, "parsimplify_ref" + suffix), os.path.join(b, "parsimplify"))
     return b
 
 
@@ -109,7 +112,7 @@ def main():
         rc = subprocess.call([os.path.join(b, "runDisco.sh"), "-inP", os.path.join(d, "reads.fasta"), "-d", os.path.join(d, "out"), "-n", str(THREADS), "-m", "8"], cwd=d)
         print("runDisco.sh rc", rc, seq_stats(os.path.join(d, "out", "disco_scaffoldsFinalCombined.fasta")))
         sys.exit(rc)
-    if cmd in ("ours", "ours-simple"):
+    if cmd in ("ours", "ours-simple", "ours-binary"):
         d, graph = os.path.abspath(sys.argv[2]), os.path.abspath(sys.argv[3])
         os.makedirs(os.path.join(d, "out", "graph"), exist_ok=True)
         write_reads(os.path.join(d, "reads.fasta"))
@@ -122,11 +125,17 @@ def main():
                 shutil.copy(f, os.path.join(d, "out", "assembly"))
                 n += 1
             assert n == THREADS, n
-        b = stage_dir(d, os.path.join(ROOT, "disco_amd", "bin", "buildG"))  # present beside the script, not run: -osg
+        if cmd == "ours-binary":  # binary records instead of text: the loaders must take their binary path for every file
+            from disco_amd import edgefile
+
+            ne, nc = edgefile.from_text(os.path.join(d, "out", "graph", "disco"), THREADS, empty_text=True)
+            print("binary side output:", ne, "edge records,", nc, "contained rows; text files emptied")
+        b = stage_dir(d, os.path.join(ROOT, "disco_amd", "bin", "buildG"), "_bin" if cmd == "ours-binary" else "")  # buildG: present beside the script, not run (-osg)
         rc = subprocess.call([os.path.join(b, "runDisco.sh"), "-inP", os.path.join(d, "reads.fasta"), "-d", os.path.join(d, "out"), "-n", str(THREADS), "-m", "8", "-osg"], cwd=d)
         log = open(os.path.join(d, "out", "disco.log")).read()
         print("runDisco.sh -osg rc", rc, seq_stats(os.path.join(d, "out", "disco_scaffoldsFinalCombined.fasta")),
-              "| parsimplify step skipped:", "Partial graphs already exist" in log)
+              "| parsimplify step skipped:", "Partial graphs already exist" in log,
+              "| binary loader used:", log.count("edges loaded to memory from"), "edge files,", log.count("_contained.bin"), "contained files")
         sys.exit(rc)
     if cmd == "fixture":
         refd, oursd = os.path.abspath(sys.argv[2]), os.path.abspath(sys.argv[3])
@@ -150,6 +159,10 @@ def main():
               **({"scaffolds_drop_in_with_its_own_partial_simplification": seq_stats(os.path.join(os.path.abspath(sys.argv[4]), "out", "disco_scaffoldsFinalCombined.fasta")),
                   "scaffold_sequences_identical": open(os.path.join(os.path.abspath(sys.argv[4]), "out", "disco_scaffoldsFinalCombined.fasta")).read().split("\n", 1)[1:] ==
                   open(os.path.join(refd, "out", "disco_scaffoldsFinalCombined.fasta")).read().split("\n", 1)[1:]} if len(sys.argv) > 4 else {}),
+              **({"scaffolds_from_binary_side_output_through_patched_reference_loaders": seq_stats(os.path.join(os.path.abspath(sys.argv[5]), "out", "disco_scaffoldsFinalCombined.fasta")),
+                  "scaffold_sequences_identical_from_binary_side_output":
+                  open(os.path.join(os.path.abspath(sys.argv[5]), "out", "disco_scaffoldsFinalCombined.fasta")).read().split("\n", 1)[1:] ==
+                  open(os.path.join(refd, "out", "disco_scaffoldsFinalCombined.fasta")).read().split("\n", 1)[1:]} if len(sys.argv) > 5 else {}),
               "how": "tools/run_config1.py: ref = runDisco.sh with the real buildG / fullsimplify / parsimplify; drop-in = disco_amd/bin/buildG on the MI355X "
                      "(the command runDisco.sh:200 issues) + runDisco.sh -osg with the real fullsimplify / parsimplify on its files"}
         json.dump(fx, open(os.path.join(ROOT, "tests", "golden", "config1.json"), "w"), indent=1, sort_keys=True)
