@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--no-stage", action="store_true", help="skip the stage wall (FASTA -> files through disco_amd/bin/buildG) at the benched config")
     ap.add_argument("--errors-ppm", type=int, default=0, help="per-base substitution rate in 10^-6 (SURVEY.md 8d: the optional Illumina-like variant, 1000; "
                     "not a BASELINE config: implies --no-cpu-baseline --no-stage --no-host-to-host)")
+    ap.add_argument("--partitioned-index", action="store_true", help="multi-GPU passes keep the index hash-partitioned: lookups travel to the buckets' owners, "
+                    "matching records back (slower than replicating the built slices wherever the index fits every GPU; DESIGN.md section 5)")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path (RCCL communicator, every exchange) even with one rank")
     return ap.parse_args()
 
@@ -276,7 +278,7 @@ def main():
         if not sharded:
             g.run_graph()
         else:
-            g.dist_run_graph(gather_reads=True)  # every pass starts from the range-partitioned reads: the all-gather is timed
+            g.dist_run_graph(gather_reads=True, partitioned_index=args.partitioned_index)  # every pass starts from the range-partitioned reads: the all-gather is timed
 
     def fence():
         g.synchronize()

@@ -105,9 +105,10 @@ ABI = [
 ]
 
 FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
-XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins")
+XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins", "queries", "hits")
 UNIQUE_ID_BYTES = 128
 DIST_GATHER_READS = 1
+DIST_KEEP_INDEX_PARTITIONED = 2
 
 
 CHAIN_EDGE_DTYPE = np.dtype([("a", "<u8"), ("b", "<u8"), ("offset", "<u8"), ("orient", "<u4"), ("n_links", "<u4"), ("first_link", "<u8")])
@@ -448,8 +449,10 @@ class BuildGraph:
         s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
         self._chk(self.L.disco_dist_generate_reads(self._h, C.byref(s)))
 
-    def dist_run_graph(self, gather_reads: bool = True):
-        self._chk(self.L.disco_dist_run_graph(self._h, DIST_GATHER_READS if gather_reads else 0))
+    def dist_run_graph(self, gather_reads: bool = True, partitioned_index: bool = False):
+        """one collective pass; partitioned_index: the index stays hash-partitioned, lookups travel to the buckets' owners and the
+        matching records back (every rank must pass the same flags)"""
+        self._chk(self.L.disco_dist_run_graph(self._h, (DIST_GATHER_READS if gather_reads else 0) | (DIST_KEEP_INDEX_PARTITIONED if partitioned_index else 0)))
 
     def dist_info(self) -> dict:
         d = DistInfo()

@@ -49,6 +49,10 @@ struct DiscoComm {
     /* control plane: n host values per rank -> all[world * n], rank-major (synchronises the stream) */
     virtual int host_all_gather(const unsigned long long *mine, int n, unsigned long long *all, hipStream_t s) = 0;
     virtual int barrier(hipStream_t s) = 0;
+    /* a rank that leaves a pass on an error of its own must not let the others wait for it inside a collective: in-process ranks are
+     * released with an error; an RCCL communicator is aborted (its peers see the failure through their own communicator's async
+     * error / launcher, buildG _exit()s — the process-level convention of the reference's MPI binaries) */
+    virtual void abort() = 0;
 };
 
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -158,6 +162,11 @@ struct RcclComm final : DiscoComm {
         unsigned long long x = 0;
         std::vector<unsigned long long> all((size_t)world);
         return host_all_gather(&x, 1, all.data(), s);
+    }
+    void abort() override
+    {
+        if (comm) (void)ncclCommAbort(comm);
+        comm = nullptr;
     }
 };
 
@@ -311,6 +320,7 @@ struct LoopComm final : DiscoComm {
         LOOP_WAIT();
         return DISCO_OK;
     }
+    void abort() override { g->abort(); }
 #undef LOOP_WAIT
 };
 

@@ -107,6 +107,12 @@ __global__ void unpack_pad_kernel(const u64 *__restrict__ dense, int S, int W, u
     }
 }
 
+__global__ void add_u64_kernel(u64 *__restrict__ p, u64 n, u64 val)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] += val;
+}
+
 /* ---- hash-partitioned index build (the owner's side) ------------------------------------------------------------------ */
 /* records received from all ranks: count per bucket of this rank's range; the atomic hands every record its slot */
 __global__ void shard_count_kernel(ulonglong2 *__restrict__ rec, u64 n, u32 *__restrict__ bkt)
@@ -479,6 +485,203 @@ __global__ void __launch_bounds__(64) emit_push_recv_kernel(EmitRecvArgs a)
             }
         }
     close_chunk();
+}
+
+/* ==== the index that STAYS partitioned (disco_dist_run_graph with DISCO_DIST_KEEP_INDEX_PARTITIONED) ========================
+ * replaces RMA/HashTable.cpp:644-705 (one MPI_Get per bucket out of the window over the range-split hashData) and :1066-1087
+ * (needsProcessing by bucket owner) with the north star's all-to-all pair: every LOOKUP of a rank's reads travels to the rank that
+ * owns the bucket (queries out), the owner walks its slice of the record array and the matching records travel back (hits back);
+ * no rank ever holds more than its slice of the bucket table and of the records. A query is one minimizer RUN of a read
+ * (index_runs_kernel): bucket, key fingerprint, the run's windows, occurrence and strand — the owner applies exactly
+ * probe_runs_kernel's test (fingerprint, not the read itself, the one window the record's minimizer offset names lies inside the
+ * run), so the set of (window, record) candidates is the replicated flow's.
+ *   query : x = bucket << 32 | read index inside the requester's range ; y = PQ_Y(requester rank, fingerprint, strand, occ - first, end, first)
+ *   hit   : x = requester rank << 32 | read index inside its range      ; y = HIT_MAKE(window, id, suffix, strand relation, length)
+ * ======================================================================================================================= */
+#define PQ_Y(rank, fp, rev, delta, wend, wstart) \
+    (((u64)(rank) << 40) | ((u64)(fp) << 24) | ((u64)(rev) << 23) | ((u64)(delta) << 18) | ((u64)(wend) << 9) | (u64)(wstart))
+#define PQ_WSTART(y) ((int)((y)&0x1FFu))
+#define PQ_WEND(y) ((int)(((y) >> 9) & 0x1FFu))
+#define PQ_DELTA(y) ((int)(((y) >> 18) & 31u))
+#define PQ_REV(y) ((u32)(((y) >> 23) & 1u))
+#define PQ_FP(y) ((u32)(((y) >> 24) & 0x3FFu))
+#define PQ_RANK(y) ((u32)(((y) >> 40) & 0x3Fu))
+
+struct RouteByHitRank { /* {rank << 32 | read index, hit} */
+    __device__ __forceinline__ u32 operator()(const ulonglong2 &h) const { return (u32)(h.x >> 32); }
+};
+
+/* runs of the reads [lo, hi) -> queries; reads whose run list is unusable (ties, too many runs) -> slow list (pq_slow_kernel).
+ * LPR u32 words of run entries per read (index_runs_kernel); one thread per word = two entries. out == nullptr: count only. */
+template <int LPR>
+__global__ void __launch_bounds__(256) pq_make_kernel(DiscoView v, const u32 *__restrict__ runs, u64 lo, u64 hi, u32 my_rank, ulonglong2 *__restrict__ out,
+                                                      u64 *__restrict__ n_out, u32 *__restrict__ slow, u32 slow_cap, u32 *__restrict__ n_slow)
+{
+    const u64 nloc = hi - lo, total = nloc * (u64)LPR;
+    const u64 t0 = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 base = t0 - lane; base < total; base += (u64)gridDim.x * 256u) { /* whole wavefronts walk together (ballots) */
+        const u64 t = base + lane;
+        const bool in = t < total;
+        const u64 ri = in ? t / LPR : 0;
+        const u32 e = (u32)(t % LPR);
+        const u32 rw = in ? runs[t] : 0xFFFFFFFFu;
+        const u32 e0 = rw & 0xFFFFu, e1 = rw >> 16;
+        const u32 first = (u32)__shfl((int)e0, (int)(lane - e)); /* entry 0 of this read's list (LPR lanes of one read are neighbours) */
+        const bool slowread = first == 0xFFFEu;
+        const u32 nx = (u32)__shfl_down((int)e0, 1);
+        const u64 A = lo + ri;
+        const int L = in ? (int)v.len[A] : 0;
+        const u32 npos = (u32)(L - v.k);
+        const bool v0 = in && !slowread && e0 < 0xFFFEu, v1 = in && !slowread && e1 < 0xFFFEu;
+        if (in && slowread && e == 0 && slow) { /* (first pass only) */
+            const u32 si = atomicAdd(n_slow, 1u);
+            if (si < slow_cap) slow[si] = (u32)ri;
+        }
+        const u32 wend0 = v1 ? (e1 >> 6) : npos;
+        const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? (nx >> 6) : npos;
+        const u64 m0 = __ballot(v0), m1 = __ballot(v1);
+        const u32 cnt = (u32)__popcll(m0) + (u32)__popcll(m1);
+        if (cnt == 0) continue;
+        u64 wbase = 0;
+        if (lane == 0) wbase = atomicAdd(n_out, (u64)cnt);
+        wbase = ((u64)(u32)__shfl((int)(u32)(wbase >> 32), 0) << 32) | (u32)__shfl((int)(u32)wbase, 0);
+        if (!out) continue;
+        const u64 lt = lane_mask_lt();
+        const u64 pos = wbase + (u32)__popcll(m0 & lt) + (u32)__popcll(m1 & lt);
+        const u64 *row = v.reads + A * v.S;
+        auto emit = [&](u64 where, u32 en, u32 wend) {
+            const u32 wstart = en >> 6, delta = (en >> 1) & 31u, rev = en & 1u;
+            const u64 key = mmer_key(row, v.S, (int)(wstart + delta), v.m);
+            out[where] = make_ulonglong2(((key >> v.bshift) << 32) | (u64)(u32)ri, PQ_Y(my_rank, KEY_FP(key), rev, delta, wend, wstart));
+        };
+        if (v0) emit(pos, e0, wend0);
+        if (v1) emit(pos + 1, e1, wend1);
+    }
+}
+
+/* reads without a usable run list, the long way: window_minimizer's rule (disco_device.h) for every window from the order words of
+ * its NF m-mers, one query per maximal range of consecutive windows with the same (occurrence, strand) — with ties an occurrence can
+ * own several such ranges; their windows are disjoint, so the owner's test still yields every (window, record) pair once.
+ * One thread per read (about 2 reads in 10 000 on random sequence). cap_per_read queries of room per read at out + i * cap_per_read. */
+__global__ void pq_slow_kernel(DiscoView v, const u32 *__restrict__ slow, u32 n_slow, u64 lo, u32 my_rank, u32 cap_per_read, ulonglong2 *__restrict__ out,
+                               u32 *__restrict__ out_cnt)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slow) return;
+    const u64 ri = slow[i], A = lo + ri;
+    const u64 *row = v.reads + A * v.S;
+    const int L = v.len[A], k = v.k, m = v.m, nf = k - m + 1, npos = L - k;
+    ulonglong2 *o = out + (u64)i * cap_per_read;
+    u32 n = 0;
+    int run_w = 0, run_p = -1;
+    u32 run_rev = 0;
+    auto flush = [&](int wend) {
+        if (run_p < 0) return;
+        const u64 key = mmer_key(row, v.S, run_p, m);
+        if (n < cap_per_read) o[n] = make_ulonglong2(((key >> v.bshift) << 32) | (u64)(u32)ri, PQ_Y(my_rank, KEY_FP(key), run_rev, run_p - run_w, wend, run_w));
+        n++;
+    };
+    for (int w = 0; w < npos; w++) {
+        u32 k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, st1 = 0;
+        for (int f = 0; f < nf; f++) {
+            const u32 ow = mmer_order(row, v.S, w + f, m);
+            const u32 a1 = (ow & ~0x1FFu) | (u32)f, a2 = (ow & ~0x1FFu) | (u32)(511 - f);
+            if (a1 < k1) {
+                k1 = a1;
+                st1 = ow & 1u;
+            }
+            k2 = a2 < k2 ? a2 : k2;
+        }
+        const int f1 = (int)(k1 & 511u), f2 = 511 - (int)(k2 & 511u);
+        u32 rev;
+        int p;
+        if (f1 == f2) {
+            rev = st1;
+            p = w + f1;
+        } else {
+            rev = kmer_is_rev(row, v.S, w, k);
+            p = w + (rev ? f2 : f1);
+        }
+        if (p != run_p || rev != run_rev) {
+            flush(w);
+            run_w = w;
+            run_p = p;
+            run_rev = rev;
+        }
+    }
+    flush(npos);
+    out_cnt[i] = n;
+}
+
+/* queries of the slow reads (cap_per_read slots each, cnt used) appended to the flat list */
+__global__ void pq_slow_append_kernel(const ulonglong2 *__restrict__ in, const u32 *__restrict__ cnt, const u64 *__restrict__ start, u32 n_slow, u32 cap_per_read,
+                                      ulonglong2 *__restrict__ out)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = t / cap_per_read, q = t % cap_per_read;
+    if (i < n_slow && q < cnt[i]) out[start[i] + q] = in[i * cap_per_read + q];
+}
+
+/* the owner's side: one thread per query walks its bucket (bkt / ent: this rank's slices, bucket indices relative to blo, record
+ * positions relative to the slice). FILL = false: hits per query -> cnt; FILL = true: the hits at out + start[query]. */
+template <bool FILL>
+__global__ void __launch_bounds__(256) pq_answer_kernel(const ulonglong2 *__restrict__ q, u64 nq, const u32 *__restrict__ bkt, const u64 *__restrict__ ent, u64 blo,
+                                                        u64 per, int nf, u32 *__restrict__ cnt, const u64 *__restrict__ start, ulonglong2 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nq; i += (u64)gridDim.x * blockDim.x) {
+        const ulonglong2 qq = q[i];
+        const u64 b = (qq.x >> 32) - blo;
+        const u32 idx = (u32)qq.x, rank = PQ_RANK(qq.y), fp = PQ_FP(qq.y), rev = PQ_REV(qq.y);
+        const int wstart = PQ_WSTART(qq.y), wend = PQ_WEND(qq.y), prel = wstart + PQ_DELTA(qq.y);
+        const u64 self = (u64)rank * per + idx; /* BG/OverlapGraph.cpp:421,655: a read is no candidate of its own */
+        const u32 s = bkt[b], e = bkt[b + 1];
+        u32 n = 0;
+        u64 at = FILL ? start[i] : 0;
+        for (u32 r = s; r < e; r++) {
+            const u64 pay = ent[r];
+            const int t = (int)PAY_T(pay);
+            const int w = rev ? prel - (nf - 1 - t) : prel - t;
+            if (PAY_FP(pay) == fp && PAY_ID(pay) != self && w >= wstart && w < wend) {
+                if (FILL) out[at + n] = make_ulonglong2(((u64)rank << 32) | idx, HIT_MAKE(w, PAY_ID(pay), PAY_SUFFIX(pay), PAY_REV(pay) ^ rev, PAY_LEN(pay)));
+                n++;
+            }
+        }
+        if (!FILL) cnt[i] = n;
+    }
+}
+
+/* the requester's side: hits -> rows of the hit buffer. count: row_cnt[lo + idx]++ ; place: hits[row_start[idx] + slot] */
+__global__ void pq_rows_count_kernel(const ulonglong2 *__restrict__ h, u64 n, u32 *__restrict__ cnt_own)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&cnt_own[(u32)h[i].x], 1u);
+}
+__global__ void pq_rows_place_kernel(const ulonglong2 *__restrict__ h, u64 n, const u64 *__restrict__ start_own, u32 *__restrict__ cursor_own, u64 *__restrict__ hits)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 idx = (u32)h[i].x;
+        hits[start_own[idx] + atomicAdd(&cursor_own[idx], 1u)] = h[i].y;
+    }
+}
+/* per-read headers: by read id for rows beyond the register paths, by position in the processing order for everybody (what
+ * probe_kernel / probe_runs_kernel leave) */
+__global__ void pq_rows_meta_kernel(const u64 *__restrict__ order, u64 lo, u64 nq, const u16 *__restrict__ len, const u64 *__restrict__ start_own,
+                                    const u32 *__restrict__ cnt_own, u64 *__restrict__ row_start, u32 *__restrict__ row_cnt, ulonglong2 *__restrict__ meta_ord)
+{
+    u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; pos < nq; pos += (u64)gridDim.x * blockDim.x) {
+        const u64 A = order ? ORDER_ID(order[pos]) : lo + pos;
+        const u32 c = cnt_own[A - lo];
+        const u64 rs = start_own[A - lo];
+        if (c > 64) {
+            row_start[A] = rs;
+            row_cnt[A] = c;
+        }
+        meta_ord[pos] = make_ulonglong2(rs, (u64)c | ((u64)len[A] << 32));
+    }
 }
 
 /* u8 flags of the own range only: everything outside [lo, hi) is not this rank's business (fetch_contained scans all n) */

@@ -232,6 +232,10 @@ struct disco_ctx {
     bool wait_bulk_before_verify = false;
     u64 per = 0;        /* nodes per rank: ceil(n / world) rounded up to a multiple of 64 */
     u64 n_alloc = 0;    /* rows of the per-read tables (n on one GPU, world * per in the multi-GPU flow) */
+    bool part_index = false;   /* the current multi-GPU pass keeps the index partitioned (DISCO_DIST_KEEP_INDEX_PARTITIONED) */
+    u64 part_blo = 0, part_bhi = 0, part_nrec = 0; /* this rank's bucket range and records */
+    u64 *d_pq_start = nullptr; /* scan scratch of the lookup exchange */
+    u64 pq_start_cap = 0;
     bool dist_reads = false;   /* the read table was set through disco_dist_*: rows [q_lo, q_hi) are this rank's */
     bool dist_active = false;  /* the current pass is a multi-GPU pass in the regular regime (emission judges local pairs only) */
     u64 *d_route = nullptr;    /* [2 * DIST_MAX_WORLD] counters / cursors of the routing kernels */
@@ -509,6 +513,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_deg_tmp, c->deg_tmp_cap);
     dev_free(c, &c->d_dense, c->dense_cap);
     c->dense_cap = 0;
+    dev_free(c, &c->d_pq_start, c->pq_start_cap);
+    c->pq_start_cap = 0;
     c->x16a_cap = c->x16b_cap = c->req_flat_cap = c->req_s_cap = c->req_r_cap = c->rdeg_s_cap = c->rdeg_r_cap = c->rdata_s_cap = 0;
     c->rpos_cap = c->nadj_cap = c->nadj_used = c->deg_tmp_cap = 0;
     c->d_push_r = nullptr;
@@ -707,6 +713,7 @@ static int settle_contained_rows(disco_ctx *c)
 }
 
 static int dist_mark_contained(disco_ctx *c); /* multi-GPU flow, below */
+static int dist_partitioned_probe(disco_ctx *c);
 
 /* ================================================================================================================ */
 extern "C" {
@@ -1243,15 +1250,20 @@ int disco_probe(disco_ctx *c)
         a.order = c->d_order_used;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-        if (nq) {
+        const bool partitioned = c->dist_active && c->part_index; /* the lookups travel to the buckets' owners (collective) */
+        if (partitioned) CHK(dist_partitioned_probe(c));
+        else if (nq) {
             launch_probe(a, 0, grid);
         }
         ph_end(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipGetLastError());
         u32 n_big = 0, n_slow = 0;
-        HIPCHK(c, hipMemcpyAsync(&n_slow, c->d_n_slow, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        if (!partitioned) {
+            HIPCHK(c, hipMemcpyAsync(&n_slow, c->d_n_slow, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        }
         CHK(read_counters(c));
+        if (partitioned) c->h_ctr[CTR_HITS_NEEDED] = c->hits_used;
         if (!c->h_ctr[CTR_OVERFLOW] && n_slow) { /* reads without a usable run list, the long way (they may add big rows) */
             int g2 = wave_grid(c, (n_slow + WQ_CHUNK - 1) / WQ_CHUNK, 24);
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
@@ -1260,7 +1272,7 @@ int disco_probe(disco_ctx *c)
             HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
             CHK(read_counters(c));
         }
-        c->slow_rows = n_slow;
+        if (!partitioned) c->slow_rows = n_slow;
         if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
             int g2 = wave_grid(c, (n_big + WQ_CHUNK - 1) / WQ_CHUNK, 8);
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
@@ -2779,8 +2791,13 @@ static int dist_build_index(disco_ctx *c)
     }
     c->T = T;
     c->bshift = 64 - logT;
-    CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
-    CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
+    auto blo_of = [&](u64 g) { return (g * T + G - 1) / G; };
+    const u64 blo = blo_of(r), bhi = blo_of(r + 1);
+    const bool part = c->part_index;
+    if (!part) { /* (partitioned: the slices are sized below, once the records have arrived) */
+        CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
+        CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
+    }
     CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n));
     CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, std::max<u64>(2 * nloc, 1)));
     c->adj_imported = false;
@@ -2797,8 +2814,6 @@ static int dist_build_index(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nrec, 1)));
     CHK(a2a_items(c, DISCO_X_INDEX_RECORDS, c->d_x16a, scnt, c->d_x16b, rcnt, sizeof(ulonglong2)));
     /* my bucket range and the position of my records in the global record array (shards in rank order) */
-    auto blo_of = [&](u64 g) { return (g * T + G - 1) / G; };
-    const u64 blo = blo_of(r), bhi = blo_of(r + 1);
     std::vector<u64> shard((size_t)G, 0);
     for (u32 p = 0; p < G; p++)
         for (u32 q = 0; q < G; q++) shard[q] += matrix[(size_t)p * G + q];
@@ -2806,6 +2821,24 @@ static int dist_build_index(disco_ctx *c)
     for (u32 q = 0; q < r; q++) base += shard[q];
     if (shard[r] != nrec) return fail(c, DISCO_E_STATE, "index shard: %llu records received, %llu announced", (unsigned long long)nrec, (unsigned long long)shard[r]);
     if (vsum(shard) != 2 * c->n) return fail(c, DISCO_E_STATE, "index: %llu records over all ranks, expected %llu", (unsigned long long)vsum(shard), (unsigned long long)(2 * c->n));
+    if (part) {
+        /* the index STAYS partitioned: this rank's slice of the bucket table (bhi - blo + 1 entries, bucket b at [b - blo]) and its
+         * records (positions inside the slice) are all it ever holds; the lookups come to it (dist_partitioned_probe) */
+        CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, bhi - blo + 1));
+        CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, std::max<u64>(nrec, 1)));
+        u32 *bkt0 = c->d_bkt - blo; /* indexed by global bucket number */
+        HIPCHK(c, hipMemsetAsync(c->d_bkt, 0, (bhi - blo + 1) * sizeof(u32), c->stream));
+        if (nrec) hipLaunchKernelGGL(shard_count_kernel, dim3(flat_grid(c, nrec)), dim3(256), 0, c->stream, c->d_x16b, nrec, bkt0);
+        CHK((scan_exclusive<u32, u32>(c, c->d_bkt, bhi - blo + 1, c->d_bkt, false, nullptr)));
+        if (nrec) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, nrec)), dim3(256), 0, c->stream, nrec, c->d_x16b, bkt0, c->d_ent);
+        HIPCHK(c, hipGetLastError());
+        c->part_blo = blo;
+        c->part_bhi = bhi;
+        c->part_nrec = nrec;
+        ph_end(c, DISCO_PH_INDEX);
+        c->phase = 2;
+        return DISCO_OK;
+    }
     if (bhi > blo) HIPCHK(c, hipMemsetAsync(c->d_bkt + blo, 0, (bhi - blo) * sizeof(u32), c->stream));
     if (nrec) hipLaunchKernelGGL(shard_count_kernel, dim3(flat_grid(c, nrec)), dim3(256), 0, c->stream, c->d_x16b, nrec, c->d_bkt);
     if (bhi > blo) {
@@ -2840,6 +2873,144 @@ static int dist_build_index(disco_ctx *c)
     }
     ph_end(c, DISCO_PH_INDEX);
     c->phase = 2;
+    return DISCO_OK;
+}
+
+/* ---- 2'. the probe against an index that stays partitioned: lookups to the owners, matching records back --------------------- */
+/* (kernels and formats: disco_dist.h "the index that STAYS partitioned"). Fills the hit buffer and the per-read headers exactly as
+ * probe_runs_kernel does for the replicated index: rows by read, headers by position in the processing order. Collective. */
+static int dist_partitioned_probe(disco_ctx *c)
+{
+    DISCO_TRACE("dist_partitioned_probe");
+    const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    const u64 lo = c->q_lo, nloc = c->q_hi - c->q_lo;
+    DiscoView v = view(c);
+    const int nf = v.k - v.m + 1;
+    if (nloc && (c->runs_lpr == 0 || c->runs_lo != lo || c->runs_n != nloc)) /* (every rank decides alike: the shape of the JOB) */
+        return fail(c, DISCO_E_UNSUPPORTED, "a partitioned index needs the minimizer runs of the index pass: min-overlap 40 (windows of 17 m-mers), reads of up to 256 bases");
+    int logT = 0;
+    while ((1ull << logT) < c->T) ++logT;
+    /* 1. queries: count, then fill; reads without a usable run list the long way */
+    if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
+    u32 *d_nslow = c->d_n_slow;
+    auto make = [&](ulonglong2 *out, bool collect_slow) {
+        const int grid = flat_grid(c, nloc * (u64)c->runs_lpr);
+        u32 *slow = collect_slow ? (u32 *)c->d_slow_list : nullptr;
+        const u32 cap = c->slow_cap * 2; /* (the list's u64 slots hold two read indices each) */
+        if (c->runs_lpr == 16) hipLaunchKernelGGL(pq_make_kernel<16>, dim3(grid), dim3(256), 0, c->stream, v, (const u32 *)c->d_runs, lo, c->q_hi, r, out, c->d_list_n, slow, cap, d_nslow);
+        else hipLaunchKernelGGL(pq_make_kernel<32>, dim3(grid), dim3(256), 0, c->stream, v, (const u32 *)c->d_runs, lo, c->q_hi, r, out, c->d_list_n, slow, cap, d_nslow);
+    };
+    u64 nq_fast = 0;
+    u32 n_slow = 0;
+    for (int attempt = 0;; attempt++) { /* the list of reads without a usable run list: sized by a first try */
+        const u32 want = attempt ? n_slow / 2 + 1024 : (u32)std::min<u64>(nloc, nloc / 128 + 1024);
+        if (want > c->slow_cap) {
+            dev_free(c, &c->d_slow_list, c->slow_cap);
+            c->slow_cap = 0;
+            CHK(dev_alloc(c, &c->d_slow_list, want));
+            c->slow_cap = want;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(d_nslow, 0, sizeof(u32), c->stream));
+        if (nloc) make(nullptr, true);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&nq_fast, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&n_slow, d_nslow, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_slow <= c->slow_cap * 2 || attempt) break;
+    }
+    if (n_slow > c->slow_cap * 2) return fail(c, DISCO_E_CAPACITY, "dist_partitioned_probe: slow list could not be sized");
+    const u32 *slow = (const u32 *)c->d_slow_list;
+    /* slow reads: up to one query per window each */
+    const u32 cap_per_read = c->max_len > (u32)c->k ? c->max_len - (u32)c->k : 1u;
+    ulonglong2 *slow_q = nullptr;
+    u32 *slow_cnt = nullptr;
+    u64 *slow_start = nullptr;
+    u64 nq_slow = 0;
+    int rc = DISCO_OK;
+    auto slow_part = [&]() -> int {
+        if (!n_slow) return DISCO_OK;
+        CHK(dev_alloc(c, &slow_q, (u64)n_slow * cap_per_read));
+        CHK(dev_alloc(c, &slow_cnt, n_slow));
+        CHK(dev_alloc(c, &slow_start, (u64)n_slow + 1));
+        hipLaunchKernelGGL(pq_slow_kernel, dim3((n_slow + 63) / 64), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, cap_per_read, slow_q, slow_cnt);
+        CHK((scan_exclusive<u32, u64>(c, slow_cnt, n_slow, slow_start, false, &nq_slow)));
+        return DISCO_OK;
+    };
+    rc = slow_part();
+    const u64 nqs = nq_fast + nq_slow;
+    if (rc == DISCO_OK) rc = ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nqs, 1)); /* flat list | partitioned by owner */
+    if (rc == DISCO_OK) {
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        if (nloc) make(c->d_x16a, false);
+        if (n_slow) {
+            hipLaunchKernelGGL(add_u64_kernel, dim3(flat_grid(c, n_slow)), dim3(256), 0, c->stream, slow_start, (u64)n_slow, nq_fast);
+            hipLaunchKernelGGL(pq_slow_append_kernel, dim3((unsigned)(((u64)n_slow * cap_per_read + 255) / 256)), dim3(256), 0, c->stream, slow_q, slow_cnt, slow_start, n_slow, cap_per_read,
+                               c->d_x16a);
+        }
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DISCO_E_HIP, "dist_partitioned_probe: query kernels failed");
+    }
+    dev_free(c, &slow_q, (u64)n_slow * cap_per_read);
+    dev_free(c, &slow_cnt, n_slow);
+    dev_free(c, &slow_start, (u64)n_slow + 1);
+    CHK(rc);
+    c->slow_rows = n_slow;
+    /* 2. queries -> owners of their buckets */
+    std::vector<u64> scnt, rcnt;
+    RouteByBucket fb{logT, G};
+    ulonglong2 *q_sorted = c->d_x16a + nqs;
+    CHK(route_items(c, c->d_x16a, nqs, fb, q_sorted, scnt));
+    CHK(exchange_counts(c, scnt, rcnt));
+    const u64 nq_in = vsum(rcnt);
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nq_in, 1)));
+    CHK(a2a_items(c, DISCO_X_QUERIES, q_sorted, scnt, c->d_x16b, rcnt, sizeof(ulonglong2)));
+    /* 3. the owner answers: hits per query, scan, fill */
+    CHK(ensure_cap(c, &c->d_deg_tmp, &c->deg_tmp_cap, std::max<u64>(nq_in, 1)));
+    CHK(ensure_cap(c, &c->d_pq_start, &c->pq_start_cap, nq_in + 1));
+    const u32 *bkt = c->d_bkt;
+    u64 n_hits_out = 0;
+    if (nq_in) hipLaunchKernelGGL(pq_answer_kernel<false>, dim3(flat_grid(c, nq_in)), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_x16b, nq_in, bkt, (const u64 *)c->d_ent, c->part_blo, c->per,
+                                  nf, c->d_deg_tmp, (const u64 *)nullptr, (ulonglong2 *)nullptr);
+    CHK((scan_exclusive<u32, u64>(c, c->d_deg_tmp, nq_in, c->d_pq_start, false, &n_hits_out)));
+    /* hits: flat list | partitioned by requester — in the send buffer (the queries it held have been answered into counts) */
+    CHK(ensure_cap_keep(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * n_hits_out, 1), 0));
+    if (nq_in) hipLaunchKernelGGL(pq_answer_kernel<true>, dim3(flat_grid(c, nq_in)), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_x16b, nq_in, bkt, (const u64 *)c->d_ent, c->part_blo, c->per,
+                                  nf, c->d_deg_tmp, (const u64 *)c->d_pq_start, c->d_x16a);
+    HIPCHK(c, hipGetLastError());
+    /* 4. hits -> the reads' owners */
+    ulonglong2 *h_sorted = c->d_x16a + n_hits_out;
+    RouteByHitRank fh;
+    CHK(route_items(c, c->d_x16a, n_hits_out, fh, h_sorted, scnt));
+    CHK(exchange_counts(c, scnt, rcnt));
+    const u64 n_hits = vsum(rcnt);
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(n_hits, 1)));
+    CHK(a2a_items(c, DISCO_X_HITS, h_sorted, scnt, c->d_x16b, rcnt, sizeof(ulonglong2)));
+    /* 5. rows of the hit buffer (exactly sized), headers by read and by position in the processing order */
+    if (n_hits + 65536 > c->hits_cap) {
+        dev_free(c, &c->d_hits, c->hits_cap);
+        c->hits_cap = 0;
+        const u64 want = n_hits + n_hits / 8 + 65536;
+        CHK(dev_alloc(c, &c->d_hits, want));
+        c->hits_cap = want;
+    }
+    CHK(ensure_cap(c, &c->d_deg_tmp, &c->deg_tmp_cap, std::max<u64>(2 * nloc, 1))); /* counts | cursors of the own reads */
+    CHK(ensure_cap(c, &c->d_pq_start, &c->pq_start_cap, nloc + 1));
+    HIPCHK(c, hipMemsetAsync(c->d_deg_tmp, 0, std::max<u64>(2 * nloc, 1) * sizeof(u32), c->stream));
+    if (n_hits) hipLaunchKernelGGL(pq_rows_count_kernel, dim3(flat_grid(c, n_hits)), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_x16b, n_hits, c->d_deg_tmp);
+    u64 placed = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_deg_tmp, nloc, c->d_pq_start, false, &placed)));
+    if (placed != n_hits) return fail(c, DISCO_E_STATE, "dist_partitioned_probe: %llu hits received, %llu placed", (unsigned long long)n_hits, (unsigned long long)placed);
+    if (n_hits) hipLaunchKernelGGL(pq_rows_place_kernel, dim3(flat_grid(c, n_hits)), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_x16b, n_hits, (const u64 *)c->d_pq_start, c->d_deg_tmp + nloc,
+                                   c->d_hits);
+    if (nloc) {
+        hipLaunchKernelGGL(pq_rows_meta_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_order_used, lo, nloc, (const u16 *)c->d_len, (const u64 *)c->d_pq_start,
+                           (const u32 *)c->d_deg_tmp, c->d_row_start, c->d_row_cnt, c->d_meta_ord);
+        CHK(zero_counter(c, CTR_MAX_ROW));
+        hipLaunchKernelGGL(max_u32_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, (const u32 *)c->d_deg_tmp, nloc, c->d_ctr + CTR_MAX_ROW);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->hits_used = n_hits;
+    c->big_rows = 0;
     return DISCO_OK;
 }
 
@@ -3249,15 +3420,16 @@ int disco_comm_init(disco_ctx *c, const void *unique_id, int nranks, int rank)
 {
     if (!c || !unique_id || nranks < 1 || nranks > DIST_MAX_WORLD || rank < 0 || rank >= nranks) return c ? fail(c, DISCO_E_ARG, "disco_comm_init: bad argument") : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    const bool one_comm = getenv("DISCO_DIST_ONE_COMM") != nullptr; /* (every rank alike) */
     RcclComm *cm = new (std::nothrow) RcclComm();
-    RcclComm *bulk = new (std::nothrow) RcclComm();
-    if (!cm || !bulk) {
+    RcclComm *bulk = one_comm ? nullptr : new (std::nothrow) RcclComm();
+    if (!cm || (!bulk && !one_comm)) {
         delete cm;
         delete bulk;
         return fail(c, DISCO_E_NOMEM, "disco_comm_init: out of host memory");
     }
     int rc = cm->init(unique_id, nranks, rank);
-    if (rc == DISCO_OK) { /* the id of the second communicator travels over the first one */
+    if (rc == DISCO_OK && bulk) { /* the id of the second communicator travels over the first one */
         ncclUniqueId id2;
         memset(&id2, 0, sizeof id2);
         void *d_id = nullptr;
@@ -3273,7 +3445,7 @@ int disco_comm_init(disco_ctx *c, const void *unique_id, int nranks, int rank)
         else cm->err = "exchange of the second communicator's id failed";
     }
     if (rc != DISCO_OK) {
-        fail(c, rc, "disco_comm_init: %s %s", cm->err.c_str(), bulk->err.c_str());
+        fail(c, rc, "disco_comm_init: %s %s", cm->err.c_str(), bulk ? bulk->err.c_str() : "");
         delete cm;
         delete bulk;
         return rc;
@@ -3383,7 +3555,20 @@ int disco_dist_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
     return dist_validate(c);
 }
 
+static int dist_run_graph_impl(disco_ctx *c, uint32_t flags);
+
 int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
+{
+    const int rc = dist_run_graph_impl(c, flags);
+    if (rc != DISCO_OK && c && c->comm && rc != DISCO_E_ARG && rc != DISCO_E_STATE) {
+        /* this rank leaves the pass early: whoever waits for it inside a collective must not wait forever */
+        c->comm->abort();
+        if (c->comm_bulk) c->comm_bulk->abort();
+    }
+    return rc;
+}
+
+static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
 {
     DISCO_TRACE("disco_dist_run_graph");
     if (!c) return DISCO_E_ARG;
@@ -3400,10 +3585,20 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
     di.own_lo = c->q_lo;
     di.own_hi = c->q_hi;
     c->dist_active = true;
+    c->part_index = (flags & DISCO_DIST_KEEP_INDEX_PARTITIONED) != 0 || getenv("DISCO_DIST_PARTITIONED_INDEX") != nullptr;
     c->n_push_r = 0;
     c->h_len.clear();
     /* 0. everybody gets every read — on the second communicator and stream: the index build and the probe of the own reads
-     *    need nothing of it, verify waits for it (disco_probe) */
+     *    need nothing of it, verify waits for it (disco_probe).
+     *    Two communicators in flight on one device are safe when every rank issues their operations in the same order (RCCL / NCCL's
+     *    rule for concurrent communicators) and every kernel that shares the device with them terminates: all ranks run this very
+     *    function — the all-gather of the reads is the only kind of operation comm_bulk ever carries and sits at the same place of
+     *    the program order of every rank, in front of the pass's operations on comm — and the compute kernels next to it are finite passes over a work
+     *    queue. DISCO_DIST_ONE_COMM=1 (every rank alike) takes the second communicator out of the picture: the all-gather then runs on
+     *    comm and the context's stream, in front of the index exchanges, at the price of its 5 ms (G = 8, config 4) on the critical path. */
+    const bool one_comm = c->comm_bulk == nullptr || getenv("DISCO_DIST_ONE_COMM") != nullptr;
+    DiscoComm *const bulk = one_comm ? c->comm : c->comm_bulk;
+    const hipStream_t bstream = one_comm ? c->stream : c->bulk_stream;
     if (flags & DISCO_DIST_GATHER_READS) {
         const auto t0 = HClock::now();
         const u64 row_bytes = (u64)c->S * 8;
@@ -3411,7 +3606,7 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
 #define BULK_CHK(expr)                                                                                        \
     do {                                                                                                      \
         int rc_ = (expr);                                                                                     \
-        if (rc_ != DISCO_OK) return fail(c, rc_, "%s: %s", #expr, c->comm_bulk->err.c_str());                 \
+        if (rc_ != DISCO_OK) return fail(c, rc_, "%s: %s", #expr, bulk->err.c_str());                 \
     } while (0)
         const int W = (int)((c->max_len + 31) / 32); /* words the longest read of the job uses (150 bp: 5 of the 8-word stride) */
         u64 sent_row_bytes = row_bytes;
@@ -3421,17 +3616,17 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
             const u64 total_rows = c->per * (u64)G;
             CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, total_rows * (u64)W));
             u64 *mine = c->d_dense + (u64)r * c->per * W;
-            hipLaunchKernelGGL(pack_rows_kernel, dim3(flat_grid(c, c->per * W)), dim3(256), 0, c->bulk_stream, c->d_reads, c->S, W, (u64)r * c->per, c->per, mine);
-            BULK_CHK(c->comm_bulk->all_gather(mine, c->d_dense, c->per * (u64)W * 8, c->bulk_stream));
-            hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, total_rows * W)), dim3(256), 0, c->bulk_stream, c->d_dense, c->S, W, total_rows, (u64)r * c->per,
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(flat_grid(c, c->per * W)), dim3(256), 0, bstream, c->d_reads, c->S, W, (u64)r * c->per, c->per, mine);
+            BULK_CHK(bulk->all_gather(mine, c->d_dense, c->per * (u64)W * 8, bstream));
+            hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, total_rows * W)), dim3(256), 0, bstream, c->d_dense, c->S, W, total_rows, (u64)r * c->per,
                                (u64)(r + 1) * c->per, c->d_reads);
             HIPCHK(c, hipGetLastError());
             sent_row_bytes = (u64)W * 8;
         } else
-            BULK_CHK(c->comm_bulk->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, c->bulk_stream));
-        BULK_CHK(c->comm_bulk->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, c->bulk_stream));
+            BULK_CHK(bulk->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, bstream));
+        BULK_CHK(bulk->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, bstream));
 #undef BULK_CHK
-        HIPCHK(c, hipEventRecord(c->ev_bulk, c->bulk_stream));
+        HIPCHK(c, hipEventRecord(c->ev_bulk, bstream));
         c->wait_bulk_before_verify = true;
         di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (sent_row_bytes + 2);
         di.ms[DISCO_X_READS] += ms_since(t0); /* time to ISSUE it (RCCL: asynchronous; in-process transport: the copies themselves) */

@@ -1746,12 +1746,54 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     return true;
 }
 
+/* ascending sort of the wave's adjacency entries (one per lane, ~0 = none) for reads of up to 256 bases, by COUNTING on the offset —
+ * the entry's leading field, below 256 then: a histogram over 256 LDS bins whose counting atomic hands every entry its rank inside
+ * its bin, an exclusive scan of the bins (four per lane + one wave scan), a scatter. Entries of EQUAL offset (common: a read has
+ * about five such pairs, on its two sides) land in arbitrary order inside their bin; odd-even exchanges of neighbours put them right
+ * (bins are runs of at most a few entries: one or two rounds, the last one finding nothing to do). About 75 vector instructions
+ * where the 21-step bitonic network on 64-bit keys takes 126. bins: 256 u32, srt: 64 u64 (LDS). Returns lane i's entry of the
+ * sorted order (~0 behind the last one). */
+__device__ __forceinline__ u64 wave_sort_by_offset(u64 ent, bool valid, u32 lane, u32 *bins, u64 *srt)
+{
+    ((uint4 *)bins)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    srt[lane] = ~0ull;
+    __syncthreads();
+    const u32 off = valid ? ADJ_OFF(ent) : 0u;
+    u32 rk = 0;
+    if (valid) rk = atomicAdd(&bins[off], 1u);
+    __syncthreads();
+    const uint4 c = ((const uint4 *)bins)[lane]; /* lane owns bins 4 lane .. 4 lane + 3 */
+    const u32 s1 = c.x + c.y, s2 = s1 + c.z, s3 = s2 + c.w;
+    const u32 excl = wave_inclusive_add(s3) - s3;
+    __syncthreads();
+    ((uint4 *)bins)[lane] = make_uint4(excl, excl + c.x, excl + s1, excl + s2);
+    __syncthreads();
+    if (valid) srt[bins[off] + rk] = ent;
+    __syncthreads();
+    u64 x = srt[lane];
+    /* entries of one bin in arbitrary order: neighbour exchanges until nothing is out of order (~0 sorts last) */
+    for (;;) {
+        const u64 nx = ((u64)(u32)__shfl_down((int)(u32)(x >> 32), 1) << 32) | (u32)__shfl_down((int)(u32)x, 1);
+        if (!__any(lane < 63 && x > nx)) break;
+        /* pairs (0,1) (2,3) ... */
+        u64 y = lane_xor64(x, 1);
+        bool lower = (lane & 1u) == 0;
+        x = ((x < y) == lower) ? x : y;
+        /* pairs (1,2) (3,4) ... : lanes 0 and 63 sit out */
+        const u32 partner = (lane & 1u) ? lane + 1 : lane - 1;
+        y = ((u64)(u32)__shfl((int)(u32)(x >> 32), (int)(partner & 63u)) << 32) | (u32)__shfl((int)(u32)x, (int)(partner & 63u));
+        lower = (lane & 1u) == 1;
+        if (lane != 0 && lane != 63) x = ((x < y) == lower) ? x : y;
+    }
+    return x;
+}
+
 /* the common case of the common case: no destination occurs twice and no k-mer has more than max_per_kmer hits, so every
  * verified hit to a non-contained read becomes an edge and the consumption order is irrelevant: one 32-bit sort of the
  * destinations proves the first condition, an LDS histogram of the windows the second, and only the sort by offset remains.
  * Anything else falls through to edge_select_row_fast (exact for every row of at most 64 hits). */
 __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A, u64 rs, u32 LA, u64 hit, u32 lane, u32 *s_jcnt, u8 *s_dup,
-                                                    u64 &n_edges)
+                                                    u64 &n_edges, u32 *s_bins = nullptr, u64 *s_srt = nullptr)
 {
     u64 *row = a.hits + rs;
     const bool valid = hit != ~0ull;
@@ -1785,7 +1827,11 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
         disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
         ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit));
     }
-    ent = wave_bitonic_sort(ent, lane);
+#ifndef ES_NO_COUNT_SORT
+    if (s_bins && LA <= 256u) ent = wave_sort_by_offset(ent, valid, lane, s_bins, s_srt); /* (LA is wave uniform) */
+    else
+#endif
+        ent = wave_bitonic_sort(ent, lane);
     const u32 nacc = __popcll(__ballot(valid));
     if (lane < nacc) row[lane] = ent;
     if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
@@ -1799,8 +1845,8 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
 template <bool BIG>
 __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(EdgeSelArgs a)
 {
-    __shared__ u64 s_h[BIG ? 1 : ES_CAP];
-    __shared__ u64 s_t[BIG ? 1 : ES_CAP];
+    __shared__ __attribute__((aligned(16))) u64 s_h[BIG ? 2 : ES_CAP];
+    __shared__ __attribute__((aligned(16))) u64 s_t[BIG ? 2 : ES_CAP];
     __shared__ u32 s_jcnt[128];
     __shared__ u8 s_dup[BIG ? 1 : ES_DUPTAB];
     const u32 lane = threadIdx.x;
@@ -1886,7 +1932,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
                     else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
                     a.ref[A] = 0;
                 }
-            } else if (c0 <= 64 && edge_select_row_all(a, A, s0, L0, g0, lane, s_jcnt, s_dup, n_edges)) {
+            } else if (c0 <= 64 && edge_select_row_all(a, A, s0, L0, g0, lane, s_jcnt, s_dup, n_edges, (u32 *)s_t, s_h)) { /* (s_t / s_h: free here) */
             } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
             } else {
                 n_slow++;

@@ -49,6 +49,7 @@ static void usage()
               << "  --gpu\tfirst GPU to use (default 0)\n"
               << "  --gpus\tnumber of GPUs = ranks (default 1): reads and graph partitioned over them, RCCL exchanges\n"
               << "  --same-device\tall ranks on the GPU given by --gpu (in-process exchanges; single-GPU boxes)\n"
+              << "  --partitioned-index\twith --gpus: the index stays hash-partitioned (buildG-MPIRMA's split hashData): lookups travel to the owners\n"
               << "  --mpi-names\tfile names <prefix>_<rank>_<thread>_... as written by buildG-MPI / buildG-MPIRMA (runDisco-MPI.sh)\n"
               << "  --par-simple\tprefix: also write <prefix>_<i>_ParSimpleEdges.txt, the output of the reference's parsimplify step on\n"
               << "\t\tevery edge file (fullsimplify then skips that step); DISCO_PAR_SIMPLE=1 in the environment derives the prefix\n"
@@ -150,7 +151,7 @@ int main(int argc, char **argv)
     std::vector<std::string> pe, se;
     std::string prefix, cfg;
     int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
-    bool same_device = false, mpi_names = false, binary_out = false, no_text = false;
+    bool same_device = false, mpi_names = false, binary_out = false, no_text = false, partitioned_index = false;
     std::string par_simple; /* prefix of the <prefix>_<i>_ParSimpleEdges.txt files, or empty */
     long long max_subs_cli = -1; /* --max-substitutions (overrides MaxSubstitutions4BuildGraph of the parameter file) */
     std::cout << "PRINTING ARGUMENTS\n";
@@ -187,6 +188,7 @@ int main(int argc, char **argv)
         else if (a == "--gpu") gpu = (int)num(0, 1023);
         else if (a == "--gpus") gpus = (int)num(1, 64);
         else if (a == "--same-device") same_device = true;
+        else if (a == "--partitioned-index") partitioned_index = true;
         else if (a == "--mpi-names") mpi_names = true;
         else if (a == "--par-simple") par_simple = next();
         else if (a == "--max-substitutions") max_subs_cli = (long long)num(0, 32767);
@@ -392,7 +394,7 @@ int main(int argc, char **argv)
                 uint64_t lo = 0, hi = 0;
                 if (disco_dist_range(c, rs.size(), &lo, &hi) < 0) bail("disco_dist_range");
                 if (disco_dist_upload_reads(c, rs.packed + lo * rs.stride_words, rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
-                if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS) < 0) bail("disco_dist_run_graph");
+                if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS | (partitioned_index ? DISCO_DIST_KEEP_INDEX_PARTITIONED : 0)) < 0) bail("disco_dist_run_graph");
                 if (disco_dist_get_info(c, &R.info) < 0) bail("disco_dist_get_info");
                 if (verbose && r == 0) fprintf(stderr, "[disco host] transport %s, %d ranks\n", disco_comm_kind(c), gpus);
                 R.rows.resize(R.info.n_contained_local);

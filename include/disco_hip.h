@@ -194,9 +194,17 @@ enum { /* exchanges of one pass (disco_dist_info.bytes_sent) */
     DISCO_X_PUSH,          /* all-to-all: surviving half-edges to the owner of the smaller endpoint    */
     DISCO_X_ADJACENCY,     /* regime 1 only: all-gather of the whole adjacency                          */
     DISCO_X_TWINS,         /* regime 2 only: drop bitmap all-gather + all-to-all of {node, twin entry} into reads that dropped a hit */
+    DISCO_X_QUERIES,       /* partitioned index only: all-to-all of the lookups (one per minimizer run) to the bucket's owner */
+    DISCO_X_HITS,          /* partitioned index only: all-to-all of the matching records back to the read's owner             */
     DISCO_X_COUNT
 };
-enum { DISCO_DIST_GATHER_READS = 1 }; /* disco_dist_run_graph flags: the pass starts from range-partitioned reads */
+/* disco_dist_run_graph flags. GATHER_READS: the pass starts from range-partitioned reads. KEEP_INDEX_PARTITIONED: the index is
+ * built hash-partitioned and STAYS so — every rank holds its slice of the bucket table and of the records only, the lookups of a
+ * rank's reads travel to the owners and the matching records back (replaces the RMA window over the split hashData with its
+ * MPI_Get per bucket, RMA/HashTable.cpp:95-116,644-705); default: the built slices are replicated by one all-gather, which is the
+ * faster exchange whenever the index fits every GPU. Every rank must pass the same flags
+ * (DISCO_DIST_PARTITIONED_INDEX=1 in the environment sets the second one). */
+enum { DISCO_DIST_GATHER_READS = 1, DISCO_DIST_KEEP_INDEX_PARTITIONED = 2 };
 typedef struct disco_dist_info {
     uint32_t world, rank;
     uint64_t n_reads, own_lo, own_hi;

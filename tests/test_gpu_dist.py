@@ -199,3 +199,81 @@ def test_config5_shape_through_8_ranks_equals_reference():
     cc = np.stack([r["contained"].astype(np.int64) + one, r["super"].astype(np.int64) + one] + [np.asarray(r[k], dtype=np.int64) for k in ("orient", "len2", "len1", "start")], axis=1)
     cc = cc[np.lexsort(tuple(cc[:, i] for i in range(5, -1, -1)))]
     assert pyoracle.digest_array(cc) == c["contained_sha256"]
+
+
+def test_ranks_one_communicator_equals_reference(monkeypatch):
+    """DISCO_DIST_ONE_COMM=1: the all-gather of the reads on the pass's own communicator and stream, in front of the index exchanges
+    (no second communicator in flight) — same result"""
+    monkeypatch.setenv("DISCO_DIST_ONE_COMM", "1")
+    reads, fidx, mo = gu.case_inputs("mixed_4k")
+    edges, rows, info, _ = run_ranks_reads(reads, mo, 3)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden("mixed_4k", ce, cc)
+    assert info["regime"] == 0 and info["bytes_sent"]["reads"] > 0
+
+
+@pytest.mark.parametrize("name,G", [("u150_5k", 2), ("u150_5k", 3), ("mixed_4k", 4), ("contigs_20k", 8), ("u150_5k", 1)])
+def test_ranks_with_the_index_kept_partitioned_equal_reference(name, G):
+    """DISCO_DIST_KEEP_INDEX_PARTITIONED (the split hashData of buildG-MPIRMA): no rank ever holds more than its
+    slice of the bucket table and of the records; every lookup travels to the bucket's owner, the matching records travel back"""
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G, partitioned_index=True)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden(name, ce, cc)
+    assert info["regime"] == 0 and info["asymmetric_pairs"] == 0
+    if G > 1:
+        assert sum(i["bytes_sent"]["queries"] for i in infos) > 0 and sum(i["bytes_sent"]["hits"] for i in infos) > 0
+        assert sum(i["bytes_sent"]["index_shards"] for i in infos) == 0  # nothing of the built index is ever replicated
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_ranks_partitioned_index_on_repeats_equals_single_gpu(G):
+    """repeats: windows whose smallest m-mer hash ties (reads without a usable run list: their lookups are made the long way, one
+    per range of windows with the same occurrence and strand), the cap binds, pairs are found from one side only"""
+    from oracle import pyoracle
+
+    reads, fidx, mo = gu.case_inputs("repeats_8k")
+    edges, rows, info, _ = run_ranks_reads(reads, mo, G, partitioned_index=True)
+    ce, cc = canon_hip(edges, rows, fidx)
+    oce, occ, ocnt = pyoracle.oracle_canonical(reads, fidx, mo, count_hits=True)
+    assert info["asymmetric_pairs"] == ocnt["asymmetric_pairs"] > 0 and info["e_pre"] == ocnt["e_pre"] and info["kmer_hits"] == ocnt["kmer_hits"]
+    assert np.array_equal(cc, occ) and np.array_equal(ce, oce)
+
+
+def test_ranks_partitioned_index_generated_reads_match_single_gpu():
+    """200 k generated reads, 4 ranks: every counter of the job equals the single-GPU pass, k-mer hits included"""
+    from disco_amd import buildgraph
+
+    spec = readgen.GenSpec.coverage(seed=7, n_reads=200_000, read_len=150, cov=30.0)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        e1, r1, c1 = g.fetch_edges(), g.fetch_contained(), g.counters()
+    edges, rows, info, infos = run_ranks(4, 40, lambda g: g.dist_generate_reads(spec), passes=2, partitioned_index=True)
+    for key in ("e_pre", "e_out", "n_contained", "probes", "kmer_hits", "cap_bind_sites"):
+        assert info[key] == c1[key], (key, info[key], c1[key])
+    ce1, cc1 = canon_hip(e1, r1)
+    ce2, cc2 = canon_hip(edges, rows)
+    assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
+
+
+def test_config2_reads_through_4_ranks_with_partitioned_index_hash_like_the_reference():
+    """BASELINE config 2's reads (1 M x 150 bp) through 4 ranks that keep the index partitioned: the digests of the REAL reference's
+    files (tests/golden/cases_big.json: u150_1m)"""
+    import json
+    import os
+
+    from oracle import pyoracle
+
+    c = json.load(open(os.path.join(gu.GOLD, "cases_big.json")))["u150_1m"]
+    spec = readgen.GenSpec.coverage(c["seed"], c["reads"], c["read_len"], c["coverage"], n_contigs=c.get("n_contigs", 1))
+    e, r, info, infos = run_ranks(4, c["min_overlap"], lambda g: g.dist_generate_reads(spec), partitioned_index=True)
+    assert info["regime"] == 0 and (info["e_out"], info["n_contained"]) == (c["n_edges"], c["n_contained"])
+    one = np.int64(1)
+    ce = pyoracle.canonical_edges_large(e["src"].astype(np.int64) + one, e["dst"].astype(np.int64) + one, e["orient"], e["offset"], e["len_src"], e["len_dst"])
+    assert pyoracle.digest_array(ce) == c["edges_sha256"]
+    cc = np.stack([r["contained"].astype(np.int64) + one, r["super"].astype(np.int64) + one] + [np.asarray(r[k], dtype=np.int64) for k in ("orient", "len2", "len1", "start")], axis=1)
+    cc = cc[np.lexsort(tuple(cc[:, i] for i in range(5, -1, -1)))]
+    assert pyoracle.digest_array(cc) == c["contained_sha256"]
+    sent = {k: sum(i["bytes_sent"][k] for i in infos) for k in infos[0]["bytes_sent"]}
+    assert sent["queries"] > 0 and sent["hits"] > 0 and sent["index_shards"] == 0

@@ -100,8 +100,9 @@ def _file_tags(threads, gpus, mpi_names):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads,gpus,mpi_names", [(1, 1, False), (4, 1, False), (3, 2, False), (3, 2, True), (2, 3, True), (1, 2, True)])
-def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_names):
+@pytest.mark.parametrize("threads,gpus,mpi_names,part", [(1, 1, False, False), (4, 1, False, False), (3, 2, False, False), (3, 2, True, False), (2, 3, True, False),
+                                                         (1, 2, True, False), (3, 3, False, True)])
+def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_names, part):
     """whole drop-in: argv in, files out; canonical content identical to the real reference's files — on one GPU and with
     --gpus N ranks (here all on one device: --same-device), plain and buildG-MPI file names"""
     build.build_host()
@@ -116,6 +117,8 @@ def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_nam
         cmd += ["--gpus", str(gpus), "--same-device"]
     if mpi_names:
         cmd += ["--mpi-names"]
+    if part:  # the index stays hash-partitioned over the ranks (buildG-MPIRMA's split hashData)
+        cmd += ["--partitioned-index"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0, p.stdout
     etags, ctags = _file_tags(threads, gpus, mpi_names)
