@@ -1588,10 +1588,15 @@ __device__ __forceinline__ void lds_bitonic_sort(u64 *h, u32 P, u32 lane)
 /* WCAP > 0: h / t are LDS arrays of WCAP entries (a power of two) and s_jcnt a 128-slot LDS histogram: rows of up to WCAP hits
  * may take the accept-all shortcut */
 template <int WCAP>
-__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 *h, u64 *t, u32 c, u32 lane, u32 *s_jcnt, u32 &cap_sites,
+/* rs: start of the row in the hit buffer (the header by position for rows of the main pass; row_start[A] — kept for rows of more
+ * than 64 entries only — for the listed ones) */
+__device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 rs, u64 *h, u64 *t, u32 c, u32 lane, u32 *s_jcnt, u32 &cap_sites,
                                                 u32 &dropped, u64 &n_edges)
 {
-    u64 *row = a.hits + a.row_start[A];
+#ifdef ES_EXP_STALE_ROWSTART /* tools/ab_build.py: the defect tests/test_gpu_parity.py::test_cap_binds_in_short_rows guards against */
+    rs = a.row_start[A];
+#endif
+    u64 *row = a.hits + rs;
     const u32 LA = a.v.len[A];
     /* 1. drop hits to contained reads */
     u32 m = 0;
@@ -1653,7 +1658,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
             __syncthreads();
             lds_bitonic_sort(h, P, lane);
             for (u32 i = lane; i < m; i += 64) row[i] = h[i];
-            if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], m);
+            if (lane == 0) a.ref[A] = REF_MAKE(rs, m);
             n_edges += m;
             __syncthreads();
             return;
@@ -1696,7 +1701,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     wave_rank_sort(h, t, nacc, lane);
     __syncthreads();
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
-    if (lane == 0) a.ref[A] = REF_MAKE(a.row_start[A], nacc);
+    if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
     n_edges += nacc;
     dropped += m - nacc;
     if (lane == 0 && m != nacc) atomicOr(&a.dropbits[A >> 6], 1ull << (A & 63));
@@ -1898,7 +1903,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
                 const u64 A = a.big_list[it];
                 n_slow++;
                 if (a.row_cnt[A] <= ES_MID) continue; /* done by edge_select_mid_kernel */
-                edge_select_row<0>(a, A, h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges);
+                edge_select_row<0>(a, A, a.row_start[A], h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges);
             }
             continue;
         }
@@ -1936,7 +1941,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
             } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
             } else {
                 n_slow++;
-                edge_select_row<ES_CAP>(a, A, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges);
+                edge_select_row<ES_CAP>(a, A, s0, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges);
             }
             c0 = c1; s0 = s1; L0 = L1; h0 = h1; w0 = w1;
             c1 = c2; s1 = m2.rs; L1 = m2.LA; r1 = r2;
@@ -1966,7 +1971,7 @@ __global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a)
         const u32 c = a.row_cnt[A];
         if (c > ES_MID) continue;
         n_slow++;
-        edge_select_row<ES_MID>(a, A, s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges);
+        edge_select_row<ES_MID>(a, A, a.row_start[A], s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges);
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);

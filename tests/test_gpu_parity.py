@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from disco_amd import buildgraph, readgen
-from tests.util import assert_parity
+from tests.util import assert_parity, canon_hip, run_oracle_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -302,3 +302,41 @@ def test_read_sets_of_the_same_shape_reuse_the_buffers():
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), i
             for k in ("e_pre", "e_out", "n_contained", "kmer_hits", "probes"):
                 assert cnt[k] == wcnt[k], (i, k)
+
+
+def test_cap_binds_in_short_rows():
+    """rows of a handful of hits in which ONE window collects eight acceptable hits: read A ends 42 bases into a 45-base unit U,
+    eight reads B_i start with U and continue into flanks of their own — A's suffix overlaps every B_i's prefix at the same window, the
+    cap of four binds inside a register-sized row, which then takes the sequential accept scan with the row found through the header by
+    position (the per-read arrays only serve rows of more than 64 entries: a kernel that looked there computed garbage or crashed —
+    tools/ab_build.py -DES_EXP_STALE_ROWSTART rebuilds that defect). Twice on one context, behind a read set of another shape."""
+    from disco_amd import buildgraph
+
+    rng = np.random.default_rng(5)
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))  # noqa: E731
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = []
+    for _ in range(12):
+        u = rnd(45)
+        reads.append(rnd(70) + u[:42])
+        reads += [u + rnd(70) for _ in range(8)]
+    genome = rnd(12000)
+    for _ in range(1200):  # an ordinary 10x background around them
+        L = int(rng.integers(90, 111))
+        p = int(rng.integers(0, len(genome) - L))
+        reads.append(genome[p:p + L])
+    reads = [r.translate(comp)[::-1] if rng.random() < 0.5 else r for r in reads]
+    perm = rng.permutation(len(reads))
+    reads = [reads[i] for i in perm]
+    c = assert_parity(reads, 40, "cap in short rows")
+    assert c["cap_bind_sites"] >= 12 and c["asymmetric_pairs"] > 0
+    oe, orows, oc = run_oracle_reads(reads, 40)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.upload_ascii([r[::-1] for r in reads[:700]])  # a different read set first: stale rows of another shape in every per-read array
+        g.run_graph()
+        g.upload_ascii(reads)
+        g.run_graph()
+        he, hr, hc = g.fetch_edges(), g.fetch_contained(), g.counters()
+    ce, cc = canon_hip(he, hr)
+    oce, occ = canon_hip(oe, orows)
+    assert np.array_equal(ce, oce) and np.array_equal(cc, occ) and hc["cap_bind_sites"] == oc["cap_bind_sites"]

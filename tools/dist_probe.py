@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """multi-GPU flow on ONE GPU: G ranks = G host threads over the in-process communicator; prints every rank's exchange
 volumes and timings. usage: dist_probe.py G N_READS [len_min len_max cov passes]
-env ERRORS_PPM=n: substitution errors per 10^6 bases (the reads then drop hits at chance repeats: regime 2)"""
+env ERRORS_PPM=n: substitution errors per 10^6 bases (the reads then drop hits at chance repeats: regime 2); PARTITIONED_INDEX=1: the index stays
+hash-partitioned (lookups to the owners, records back)"""
 import json
 import os
 import sys
@@ -28,7 +29,7 @@ def setup(g):
         g.substitute_bases(7, ppm)
 
 
-edges, rows, info, infos = run_ranks(G, 40, setup, passes=passes)
+edges, rows, info, infos = run_ranks(G, 40, setup, passes=passes, partitioned_index=bool(os.environ.get("PARTITIONED_INDEX")))
 print(f"wall {time.time() - t0:.2f} s; e_pre {info['e_pre']} e_out {info['e_out']} contained {info['n_contained']} regime {info['regime']} "
       f"tr_rounds {info['tr_rounds']} deferred {info['tr_deferred']} asymmetric_pairs {info['asymmetric_pairs']} dropped {info['dropped_hits']}")
 for i in infos:
