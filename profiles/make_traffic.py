@@ -15,6 +15,9 @@ pmc = json.load(open(src))
 kern = {}
 for k, v in pmc.items():
     base = k.split("<")[0].strip()
+    # (the candidate-generation phase is probe_runs_kernel since round 3, with probe_kernel for the reads it hands over; bench.py names
+    # the phase "probe_kernel"; likewise index_runs_kernel / index_count_kernel)
+    base = {"probe_runs_kernel": "probe_kernel", "index_runs_kernel": "index_count_kernel"}.get(base, base)
     if base in ("probe_kernel", "verify_kernel", "edge_select_kernel", "transitive_mark_kernel", "index_count_kernel"):
         kern[base] = kern.get(base, 0.0) + (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
 out = {"reads": reads, "gpus": 1, "kernels": kern, "kernels_sha16": bench.kernels_sha16(),

@@ -40,7 +40,13 @@ for it in range(iters):
     seed = int(rng.integers(1, 1 << 30))
     G = int(rng.integers(2, 6))
     tp = buildgraph.FLAG_TWO_PASS_VERIFY if rng.random() < 0.5 else 0
-    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} G={G} two_pass_in_ranks={tp}"
+    part = False
+    if rng.random() < 0.5:  # half of the cases in the shape that takes the minimizer runs; half of those with the index kept partitioned
+        lmin = int(rng.choice([45, 60, 100, 150, 151, 200, 256]))
+        lmax = lmin if rng.random() < 0.3 else int(min(256, lmin + rng.integers(1, 2 * lmin)))
+        mo = 40 if lmin > 48 else max(31, lmin - 8)
+        part = mo == 40 and rng.random() < 0.5
+    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} G={G} two_pass_in_ranks={tp} partitioned_index={part}"
     try:
         spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
         reads = list(readgen.generate_reads(spec))
@@ -69,7 +75,7 @@ for it in range(iters):
         e2, r2, c2 = run_hip_reads(reads, mo, flags=buildgraph.FLAG_TWO_PASS_VERIFY)  # (b)
         ce2, cc2 = canon_hip(e2, r2)
         assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2), "two-pass verify differs"
-        e3, r3_, info, _ = run_ranks_reads(reads, mo, G, flags=tp)  # (c)
+        e3, r3_, info, _ = run_ranks_reads(reads, mo, G, flags=tp, partitioned_index=part)  # (c)
         ce3, cc3 = canon_hip(e3, r3_)
         assert np.array_equal(cc1, cc3), f"{G} ranks: contained rows differ ({len(cc1)} vs {len(cc3)})"
         assert np.array_equal(ce1, ce3), f"{G} ranks: edges differ ({len(ce1)} vs {len(ce3)})"

@@ -1,7 +1,9 @@
 """differential fuzzing: HIP path (C-ABI) vs the CPU oracle on random generator settings.
-   python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1] [inexact]
+   python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1] [inexact | runs]
    with "inexact": every data set gets sequencing errors and a random substitution threshold (the f-4 extension, checked against
-   the oracle's statement of the same rule, substitutions per edge included)"""
+   the oracle's statement of the same rule, substitutions per edge included); with "runs": min-overlap 40 and reads of up to 256 bases
+   throughout — the shapes that take the minimizer runs of the index pass (index_runs_kernel / probe_runs_kernel), low-complexity and
+   repeat genomes (ties of the window minimum: reads handed to probe_kernel's list pass) more often"""
 import os, sys, time, traceback
 os.environ.setdefault('DISCO_ORDER_MIN_READS', '1')  # the grouped verify order on every data set, however small
 sys.path.insert(0, '.')
@@ -12,12 +14,17 @@ from tests.util import assert_parity
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 inexact = len(sys.argv) > 3 and sys.argv[3] == "inexact"
+runs = len(sys.argv) > 3 and sys.argv[3] == "runs"
 fails = 0
 t0 = time.time()
 for it in range(iters):
     lmin = int(rng.choice([45, 60, 80, 100, 150, 151, 168, 200, 256, 257, 300, 500, 1000, 1025, 2000, 5000]))
     lmax = lmin if rng.random() < 0.4 else int(lmin + rng.integers(1, 2 * lmin))
     mo = int(rng.choice([31, 32, 33, 40, 41, 50, 64, 65]))
+    if runs:
+        lmin = int(rng.choice([45, 60, 80, 100, 128, 150, 151, 167, 168, 200, 250, 256]))
+        lmax = lmin if rng.random() < 0.4 else int(min(256, lmin + rng.integers(1, 2 * lmin)))
+        mo = 40
     if mo >= lmin:
         mo = max(31, lmin - 8)
     cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700, 1500]))
@@ -48,7 +55,12 @@ for it in range(iters):
                 b[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[r2.integers(0, 4, int(hit.sum()))]
                 out.append(b.tobytes().decode())
             reads = out
-        if rng.random() < 0.2:  # a genome with repeat copies: duplicate destinations, the per-k-mer cap, one-sided pairs
+        if runs and rng.random() < 0.15:  # low-complexity stretches: the smallest m-mer hash of a window ties
+            r4 = np.random.default_rng(seed + 2)
+            units = ["AC", "AAT", "ACGT", "A", "AGGC", "ACACG"]
+            reads = [(s[:int(len(s) * 0.3)] + (units[int(r4.integers(0, len(units)))] * 200)[:int(len(s) * 0.4)] + s[int(len(s) * 0.7):]) if r4.random() < 0.3 else s for s in reads]
+            label += " lowcomplexity"
+        if rng.random() < (0.35 if runs else 0.2):  # a genome with repeat copies: duplicate destinations, the per-k-mer cap, one-sided pairs
             r3 = np.random.default_rng(seed + 1)
             rep = "".join(r3.choice(list("ACGT"), int(r3.integers(60, 400))))
             genome = "".join("".join(r3.choice(list("ACGT"), int(r3.integers(30, 300)))) + rep for _ in range(int(r3.integers(3, 40))))
