@@ -102,6 +102,8 @@ ABI = [
     ("disco_dist_generate_reads", C.c_int, [_P, C.POINTER(GenSpecABI)]),
     ("disco_dist_run_graph", C.c_int, [_P, C.c_uint32]),
     ("disco_dist_get_info", C.c_int, [_P, _P]),
+    ("disco_ingest_fasta", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int, C.c_uint32, _P, _P]),
+    ("disco_ingest_fetch", C.c_int, [_P, _P, _P]),
 ]
 
 FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
@@ -113,6 +115,15 @@ DIST_KEEP_INDEX_PARTITIONED = 2
 
 CHAIN_EDGE_DTYPE = np.dtype([("a", "<u8"), ("b", "<u8"), ("offset", "<u8"), ("orient", "<u4"), ("n_links", "<u4"), ("first_link", "<u8")])
 CHAIN_LINK_DTYPE = np.dtype([("to", "<u4"), ("offset", "<u4"), ("orient", "<u4")])
+
+
+class IngestFile(C.Structure):
+    _fields_ = [("first_index", C.c_uint64), ("last_index", C.c_uint64), ("good", C.c_uint64), ("bad", C.c_uint64)]
+
+
+class IngestInfo(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("total_records", C.c_uint64), ("too_long", C.c_uint64), ("stride_words", C.c_uint32), ("shortest", C.c_uint32),
+                ("longest", C.c_uint32), ("read_s", C.c_float), ("device_s", C.c_float)]
 
 
 class DistInfo(C.Structure):
@@ -448,6 +459,24 @@ class BuildGraph:
     def dist_generate_reads(self, spec):
         s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
         self._chk(self.L.disco_dist_generate_reads(self._h, C.byref(s)))
+
+    def ingest_fasta(self, paths, threads: int = 16):
+        """the input stage on the GPU (disco_ingest_fasta): FASTA files -> the context's read table. Returns (info dict, per-file
+        dicts), or None when a file is not of the form the device stage accepts (the caller then takes the host stage)"""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        info, files = IngestInfo(), (IngestFile * len(paths))()
+        rc = self.L.disco_ingest_fasta(self._h, arr, len(paths), threads, C.byref(info), files)
+        if rc == -6:  # DISCO_E_UNSUPPORTED
+            return None
+        self._chk(rc)
+        return ({n: getattr(info, n) for n, _ in IngestInfo._fields_}, [{n: getattr(f, n) for n, _ in IngestFile._fields_} for f in files])
+
+    def ingest_fetch(self):
+        """(lengths, 1-based file indices) of the reads the last ingest_fasta kept"""
+        n = self.num_reads
+        ln, fi = np.zeros(n, dtype=np.uint16), np.zeros(n, dtype=np.uint64)
+        self._chk(self.L.disco_ingest_fetch(self._h, ln.ctypes.data, fi.ctypes.data))
+        return ln, fi
 
     def dist_run_graph(self, gather_reads: bool = True, partitioned_index: bool = False):
         """one collective pass; partitioned_index: the index stays hash-partitioned, lookups travel to the buckets' owners and the

@@ -23,6 +23,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string>
 #include <memory>
 #include <thread>
@@ -33,11 +36,16 @@
 #include "disco_dist.h"
 #include "disco_chains.h"
 #include "disco_text.h"
+#include "disco_ingest.h"
+#include "read_filter_tables.h"
 #include "disco_comm.h"
 
 static_assert(sizeof(disco_genspec) == sizeof(disco_genspec_abi), "genspec ABI mismatch");
 
 static thread_local std::string g_create_error;
+
+using HClock = std::chrono::steady_clock;
+static float ms_since(HClock::time_point t0) { return std::chrono::duration<float, std::milli>(HClock::now() - t0).count(); }
 
 /* tracing hooks (the reference brackets its functions with CLOCKSTART / CLOCKSTOP, BG/Common.h:71-95): every
  * phase of the path is a named roctx range, so `rocprofv3 --marker-trace --kernel-trace` shows the kernels under the C-ABI call
@@ -150,6 +158,14 @@ struct disco_ctx {
     u32 *d_fetch_src = nullptr;
     u64 *d_fetch_ent = nullptr;
     u64 fetch_cap = 0;
+    /* input stage on the GPU (disco_ingest_fasta): what disco_ingest_fetch hands to the host afterwards */
+    u32 *d_rec_of_read = nullptr;
+    u64 rec_of_read_cap = 0;
+    std::vector<u64> ingest_id_base, ingest_rec_base; /* per file: first read id, records before the file */
+    u64 ingest_n = 0;
+    void *h_ring = nullptr; /* pinned: two halves of the text staging ring */
+    size_t ring_half = 0;
+    hipEvent_t ev_ring[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr; /* disco_upload_reads: the chunks of the host buffer travel here */
     hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr}, ev_unpacked[3] = {nullptr, nullptr, nullptr};
     bool index_counted = false; /* disco_upload_reads ran the index's count pass behind its copies: disco_build_index starts at the scan */
@@ -680,6 +696,10 @@ static int start_contained_rows(disco_ctx *c)
     }
     if (nc > c->crows_hcap) {
         if (c->h_crows) (void)hipHostFree(c->h_crows);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    for (int i = 0; i < 2; i++)
+        if (c->ev_ring[i]) (void)hipEventDestroy(c->ev_ring[i]);
+    dev_free(c, &c->d_rec_of_read, c->rec_of_read_cap);
         c->h_crows = nullptr;
         c->crows_hcap = 0;
         const u64 want = nc + nc / 4 + 1024;
@@ -1023,6 +1043,303 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
     } else
         c->h_len.clear();
     c->phase = 1;
+    return DISCO_OK;
+}
+
+/* ================================================================================================================
+ * input stage on the GPU (kernels: disco_ingest.h)
+ * ============================================================================================================== */
+namespace {
+struct IngestFile {
+    std::string path;
+    u64 n = 0;
+    u8 *d_text = nullptr;
+    u64 text_cap = 0;
+    u64 *d_start = nullptr, *d_seq = nullptr;
+    u16 *d_glen = nullptr;
+    u64 n_start = 0, n_rec = 0, good = 0;
+};
+} // namespace
+
+static void ingest_tables(FxTables *tb)
+{
+    memset(tb, 0, sizeof *tb);
+    auto code = [](char ch) { return ch == 'A' ? 0ull : (ch == 'C' ? 1ull : (ch == 'G' ? 2ull : 3ull)); };
+    tb->n_rep = (u32)DISCO_N_END_REPEATS;
+    for (u32 r = 0; r < tb->n_rep; r++) {
+        u64 v = 0;
+        for (int x = 0; x < 29; x++) v = (v << 2) | code(kEndRepeats[r][x]);
+        tb->rep58[r] = v;
+    }
+    tb->n_motif = (u32)DISCO_N_MOTIFS;
+    for (u32 m = 0; m < tb->n_motif; m++) {
+        const size_t l = strlen(kMotifs[m]);
+        tb->motif_len[m] = (u8)l;
+        for (size_t x = 0; x < l; x++) {
+            tb->motif[m][x] = (u8)kMotifs[m][x];
+            tb->need[m][code(kMotifs[m][x])]++;
+        }
+    }
+    static_assert(DISCO_N_END_REPEATS <= FX_MAX_REPEATS && DISCO_N_MOTIFS <= FX_MAX_MOTIFS, "filter tables");
+}
+
+/* the file's bytes into d_text: host threads pread slices of a chunk into one half of a pinned ring while the other half travels */
+static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned threads)
+{
+    const size_t HALF = 128u << 20;
+    if (!c->h_ring) {
+        if (hipHostMalloc(&c->h_ring, 2 * HALF) != hipSuccess) {
+            c->h_ring = nullptr;
+            (void)hipGetLastError();
+            return fail(c, DISCO_E_NOMEM, "disco_ingest_fasta: no pinned staging memory");
+        }
+        c->ring_half = HALF;
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ring[i], hipEventDisableTiming));
+    }
+    if (!c->copy_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 3; i++) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_unpacked[i], hipEventDisableTiming));
+        }
+    }
+    threads = std::max(1u, std::min(threads, 32u));
+    u64 k = 0;
+    for (u64 off = 0; off < n; off += HALF, k++) {
+        const size_t len = (size_t)std::min<u64>(HALF, n - off);
+        char *half = (char *)c->h_ring + (k & 1) * HALF;
+        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_ring[k & 1])); /* the copy out of this half two chunks ago */
+        std::atomic<bool> ok{true};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < threads; t++)
+            th.emplace_back([&, t]() {
+                size_t p0 = len * t / threads, p1 = len * (t + 1) / threads;
+                while (p0 < p1) {
+                    const ssize_t got = pread(fd, half + p0, p1 - p0, (off_t)(off + p0));
+                    if (got <= 0) {
+                        ok.store(false);
+                        return;
+                    }
+                    p0 += (size_t)got;
+                }
+            });
+        for (auto &x : th) x.join();
+        if (!ok.load()) return fail(c, DISCO_E_ARG, "disco_ingest_fasta: read error");
+        HIPCHK(c, hipMemcpyAsync(d_text + off, half, len, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_ring[k & 1], c->copy_stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    return DISCO_OK;
+}
+
+extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_files, uint32_t host_threads, disco_ingest_info *info, disco_ingest_file *files)
+{
+    DISCO_TRACE("disco_ingest_fasta");
+    if (!c || !paths || n_files < 1 || !info || !files) return c ? fail(c, DISCO_E_ARG, "disco_ingest_fasta: null argument") : DISCO_E_ARG;
+    if (c->comm) return fail(c, DISCO_E_UNSUPPORTED, "disco_ingest_fasta: single-GPU contexts only");
+    HIPCHK(c, hipSetDevice(c->device));
+    const auto t_begin = HClock::now();
+    std::vector<IngestFile> F((size_t)n_files);
+    u64 *d_ctr = nullptr, *d_tile_base = nullptr, *d_pos = nullptr;
+    u32 *d_tile_cnt = nullptr;
+    u8 *d_flag = nullptr;
+    u64 tiles_cap = 0, pos_cap = 0;
+    int rc = DISCO_OK;
+    float read_s = 0;
+    auto cleanup = [&]() {
+        for (auto &f : F) {
+            dev_free(c, &f.d_text, f.text_cap);
+            dev_free(c, &f.d_start, f.n_start);
+            dev_free(c, &f.d_seq, f.n_rec);
+            dev_free(c, &f.d_glen, f.n_rec);
+        }
+        dev_free(c, &d_ctr, (size_t)FX_CTR_COUNT);
+        dev_free(c, &d_tile_base, tiles_cap + 1);
+        dev_free(c, &d_tile_cnt, tiles_cap);
+        dev_free(c, &d_pos, pos_cap + 1);
+        dev_free(c, &d_flag, pos_cap);
+    };
+    auto unsupported = [&](const char *why, const std::string &path) {
+        cleanup();
+        return fail(c, DISCO_E_UNSUPPORTED, "disco_ingest_fasta: %s (%s): the host input stage takes this job", why, path.c_str());
+    };
+    FxTables tb;
+    ingest_tables(&tb);
+    if ((rc = dev_alloc(c, &d_ctr, (size_t)FX_CTR_COUNT)) != DISCO_OK) return rc;
+    u64 total_records = 0, n_good = 0, too_long = 0;
+    u32 longest = 0, shortest = 0xFFFFu;
+    /* ---- pass A: every file into HBM, record starts, clean + filter ------------------------------------------------------------ */
+    for (int fi = 0; fi < n_files; fi++) {
+        IngestFile &f = F[(size_t)fi];
+        f.path = paths[fi] ? paths[fi] : "";
+        if (f.path.size() >= 3 && f.path.compare(f.path.size() - 3, 3, ".gz") == 0) return unsupported("gzip input", f.path);
+        const int fd = open(f.path.c_str(), O_RDONLY);
+        if (fd < 0) return unsupported("unreadable file", f.path);
+        struct stat st;
+        char first = 0, last = 0;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 1 || pread(fd, &first, 1, 0) != 1 || pread(fd, &last, 1, st.st_size - 1) != 1) {
+            close(fd);
+            return unsupported("empty or unreadable file", f.path);
+        }
+        if (first != '>') {
+            close(fd);
+            return unsupported("not FASTA", f.path);
+        }
+        f.n = (u64)st.st_size;
+        f.text_cap = (f.n + FX_TILE + 63) / FX_TILE * FX_TILE + 64; /* whole tiles (16-byte loads) and aligned 8-byte words behind the end */
+        const auto t_read = HClock::now();
+        if ((rc = dev_alloc(c, &f.d_text, f.text_cap)) == DISCO_OK && hipMemsetAsync(f.d_text + f.n, 0, f.text_cap - f.n, c->stream) != hipSuccess) rc = DISCO_E_HIP;
+        if (rc == DISCO_OK) rc = ingest_read_file(c, fd, f.n, f.d_text, host_threads ? host_threads : 16u);
+        close(fd);
+        read_s += ms_since(t_read) * 1e-3f;
+        if (rc != DISCO_OK) {
+            cleanup();
+            return rc;
+        }
+        const u64 tiles = (f.n + FX_TILE - 1) / FX_TILE;
+        if (tiles > tiles_cap) {
+            dev_free(c, &d_tile_base, tiles_cap + 1);
+            dev_free(c, &d_tile_cnt, tiles_cap);
+            tiles_cap = 0;
+            if ((rc = dev_alloc(c, &d_tile_base, tiles + 1)) != DISCO_OK || (rc = dev_alloc(c, &d_tile_cnt, tiles)) != DISCO_OK) {
+                cleanup();
+                return rc;
+            }
+            tiles_cap = tiles;
+        }
+        auto body = [&]() -> int {
+            HIPCHK(c, hipMemsetAsync(d_ctr, 0, FX_CTR_COUNT * sizeof(u64), c->stream));
+            hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, d_tile_cnt, (const u64 *)nullptr, (u64 *)nullptr, d_ctr);
+            CHK((scan_exclusive<u32, u64>(c, d_tile_cnt, tiles, d_tile_base, false, &f.n_start)));
+            if (f.n_start == 0 || f.n_start >= (1ull << 32)) return DISCO_E_UNSUPPORTED;
+            /* a '>' that is the very last byte starts nothing (the reference's next getline fails) unless it is the only one; it still ends
+             * the sequence of the record before it (disco_amd/host/fastx.cpp) */
+            f.n_rec = (f.n_start > 1 && last == '>') ? f.n_start - 1 : f.n_start;
+            CHK(dev_alloc(c, &f.d_start, f.n_start));
+            CHK(dev_alloc(c, &f.d_seq, f.n_rec));
+            CHK(dev_alloc(c, &f.d_glen, f.n_rec));
+            hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start, d_ctr);
+            FxFilterArgs fa;
+            fa.text = f.d_text;
+            fa.n = f.n;
+            fa.start = f.d_start;
+            fa.n_start = f.n_start;
+            fa.n_rec = f.n_rec;
+            fa.min_overlap = c->prm.min_overlap;
+            fa.glen = f.d_glen;
+            fa.seq_begin = f.d_seq;
+            fa.ctr = d_ctr;
+            hipLaunchKernelGGL(fx_filter_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, fa, tb);
+            HIPCHK(c, hipGetLastError());
+            u64 h[FX_CTR_COUNT];
+            HIPCHK(c, hipMemcpyAsync(h, d_ctr, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (h[FX_CTR_BAD_GT] || h[FX_CTR_MULTILINE]) return DISCO_E_UNSUPPORTED;
+            f.good = h[FX_CTR_GOOD];
+            too_long += h[FX_CTR_TOO_LONG];
+            if (f.good) {
+                longest = std::max(longest, (u32)h[FX_CTR_MAX_LEN]);
+                shortest = std::min(shortest, 0xFFFFu - (u32)h[FX_CTR_MIN_LEN_INV]);
+            }
+            return DISCO_OK;
+        };
+        rc = body();
+        if (rc == DISCO_E_UNSUPPORTED) return unsupported("a '>' inside a line, a sequence over several lines, or no record", f.path);
+        if (rc != DISCO_OK) {
+            cleanup();
+            return rc;
+        }
+        files[fi].first_index = total_records + 1;
+        files[fi].last_index = total_records + f.n_rec;
+        files[fi].good = f.good;
+        files[fi].bad = f.n_rec - f.good;
+        total_records += f.n_rec;
+        n_good += f.good;
+    }
+    if (n_good == 0 || n_good >= (1ull << 31)) return unsupported("no good read (or more than 2^31)", F[0].path);
+    /* ---- pass B: ids in file order, rows of the read table -------------------------------------------------------------------- */
+    const uint32_t stride_words = std::max<u32>(1, (longest + 31) / 32), dstride = (stride_words + 7u) & ~7u;
+    auto pass_b = [&]() -> int {
+        bool kept = false;
+        CHK(set_reads_common(c, n_good, dstride, &kept));
+        if (!kept) {
+            CHK(dev_alloc(c, &c->d_reads, n_good * (u64)dstride));
+            CHK(dev_alloc(c, &c->d_len, n_good));
+        }
+        c->reads_owned = true;
+        CHK(ensure_cap(c, &c->d_rec_of_read, &c->rec_of_read_cap, n_good));
+        c->ingest_id_base.assign((size_t)n_files + 1, 0);
+        c->ingest_rec_base.assign((size_t)n_files + 1, 0);
+        u64 id_base = 0, rec_base = 0;
+        for (int fi = 0; fi < n_files; fi++) {
+            IngestFile &f = F[(size_t)fi];
+            c->ingest_id_base[(size_t)fi] = id_base;
+            c->ingest_rec_base[(size_t)fi] = rec_base;
+            if (f.n_rec > pos_cap) {
+                dev_free(c, &d_pos, pos_cap + 1);
+                dev_free(c, &d_flag, pos_cap);
+                pos_cap = 0;
+                CHK(dev_alloc(c, &d_pos, f.n_rec + 1));
+                CHK(dev_alloc(c, &d_flag, f.n_rec));
+                pos_cap = f.n_rec;
+            }
+            hipLaunchKernelGGL(fx_flags_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, (const u16 *)f.d_glen, f.n_rec, d_flag);
+            u64 good = 0;
+            CHK((scan_exclusive<u8, u64>(c, d_flag, f.n_rec, d_pos, false, &good)));
+            if (good != f.good) return fail(c, DISCO_E_STATE, "disco_ingest_fasta: %llu good reads counted, %llu placed", (unsigned long long)f.good, (unsigned long long)good);
+            hipLaunchKernelGGL(fx_ids_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, (const u16 *)f.d_glen, (const u64 *)d_pos, f.n_rec, id_base, c->d_rec_of_read, c->d_len);
+            if (f.good)
+                hipLaunchKernelGGL(fx_pack_kernel, dim3(flat_grid(c, f.good * (u64)dstride)), dim3(256), 0, c->stream, (const u8 *)f.d_text, (const u64 *)f.d_seq, (const u32 *)c->d_rec_of_read,
+                                   (const u16 *)c->d_len, id_base, f.good, (int)dstride, c->d_reads);
+            HIPCHK(c, hipGetLastError());
+            id_base += f.good;
+            rec_base += f.n_rec;
+        }
+        c->ingest_id_base[(size_t)n_files] = id_base;
+        c->ingest_rec_base[(size_t)n_files] = rec_base;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return DISCO_OK;
+    };
+    rc = pass_b();
+    cleanup();
+    CHK(rc);
+    c->ingest_n = n_good;
+    c->max_len = longest;
+    c->min_len = shortest;
+    c->h_len_ok = false;
+    c->phase = 1;
+    info->n_reads = n_good;
+    info->total_records = total_records;
+    info->too_long = too_long;
+    info->stride_words = stride_words;
+    info->shortest = shortest;
+    info->longest = longest;
+    info->read_s = read_s;
+    info->device_s = ms_since(t_begin) * 1e-3f - read_s;
+    return DISCO_OK;
+}
+
+extern "C" int disco_ingest_fetch(disco_ctx *c, uint16_t *len, uint64_t *file_index)
+{
+    if (!c || !len || !file_index) return c ? fail(c, DISCO_E_ARG, "disco_ingest_fetch: null argument") : DISCO_E_ARG;
+    if (c->phase < 1 || c->ingest_n == 0 || c->ingest_n != c->n) return fail(c, DISCO_E_STATE, "disco_ingest_fetch: the reads of the context did not come from disco_ingest_fasta");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 n = c->n;
+    std::unique_ptr<u32[]> rec(new u32[n]);
+    HIPCHK(c, hipMemcpyAsync(len, c->d_len, n * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rec.get(), c->d_rec_of_read, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u32 *r = rec.get();
+    for (size_t fi = 0; fi + 1 < c->ingest_id_base.size(); fi++) {
+        const u64 lo = c->ingest_id_base[fi], hi = c->ingest_id_base[fi + 1], rb = c->ingest_rec_base[fi];
+        parallel_for(hi - lo, [&, lo, rb](u64 b, u64 e_) {
+            for (u64 i = lo + b; i < lo + e_; i++) file_index[i] = rb + (u64)r[i] + 1; /* BG/Dataset.cpp:294: every record counts */
+        });
+    }
+    if (c->h_len.size() != n) c->h_len.resize(n);
+    uint16_t *hl = c->h_len.data();
+    parallel_for(n, [&, hl](u64 b, u64 e_) { memcpy(hl + b, len + b, (e_ - b) * 2); });
+    c->h_len_ok = true;
     return DISCO_OK;
 }
 
@@ -2659,8 +2976,6 @@ int disco_get_counters(disco_ctx *c, disco_counters *o)
  *   order-dependent regime (some rank dropped a hit: per-k-mer cap, second hit to a destination): the whole adjacency is
  *   gathered and every rank completes, marks and judges all lists itself (exact, not scalable; never on BASELINE data)
  * ============================================================================================================== */
-using HClock = std::chrono::steady_clock;
-static float ms_since(HClock::time_point t0) { return std::chrono::duration<float, std::milli>(HClock::now() - t0).count(); }
 
 #define COMM_CHK(c, expr)                                                                        \
     do {                                                                                         \

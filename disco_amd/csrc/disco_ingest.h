@@ -1,0 +1,264 @@
+/*
+ * disco_ingest.h — the input stage on the GPU (SURVEY.md section 8 a-1 … a-3, f-2): FASTA text in HBM -> record starts -> clean +
+ * Dataset::testRead per record -> ids of the good reads in file order -> 2-bit rows of the read table. Replaces, for the files it
+ * accepts, the host pass of disco_amd/host/fastx.cpp (which stays for .gz, FASTQ and any FASTA it declines), i.e.
+ * Dataset::readDataset / testRead (BG/Dataset.cpp:161-380,403-452) and the packing of HashTable::insertIntoTable
+ * (BG/HashTable.cpp:456-477). Host side: disco_hip.hip "input stage on the GPU".
+ *
+ * Accepted form (decided on the device, per file; anything else makes the caller fall back to the host stage, which follows the
+ * reference's getline calls literally): the file starts with '>', every '>' is the first byte of a line, and every record's sequence
+ * is ONE line (header line, sequence line, optional final newline). Lower case, N, CR and any other byte are handled as the reference
+ * handles them (upper-cased; anything but ACGT rejects the read, BG/Dataset.cpp:411).
+ *
+ * All kernels are byte / integer work on text that is read once or twice: HBM-bound streaming (8.1 GB of text at 50 M reads).
+ */
+#ifndef DISCO_INGEST_H_
+#define DISCO_INGEST_H_
+
+#include "disco_device.h"
+
+#define FX_TILE 4096 /* bytes of text per block of fx_starts_kernel */
+#define FX_MAX_MOTIFS 16
+#define FX_MAX_REPEATS 40
+
+/* counters of one ingest (u64 each) */
+enum { FX_CTR_BAD_GT = 0, FX_CTR_MULTILINE, FX_CTR_TOO_LONG, FX_CTR_MAX_LEN, FX_CTR_MIN_LEN_INV, FX_CTR_GOOD, FX_CTR_COUNT };
+
+struct FxTables { /* Dataset::testRead's patterns (read_filter_tables.h), prepared by the host */
+    u64 rep58[FX_MAX_REPEATS]; /* the 29-mers that may be neither prefix nor suffix of a read, 2 bits per base */
+    u32 n_rep;
+    u32 n_motif;
+    u8 motif[FX_MAX_MOTIFS][8]; /* upper-case characters */
+    u8 motif_len[FX_MAX_MOTIFS];
+    u8 need[FX_MAX_MOTIFS][4];  /* bases of each kind in the motif */
+};
+
+/* byte p of the text through ALIGNED 8-byte loads (the buffer is padded to a multiple of 8 bytes, little endian) */
+struct FxBytes {
+    const u64 *w;
+    u64 cur_idx;
+    u64 cur;
+    __device__ __forceinline__ explicit FxBytes(const u8 *text) : w((const u64 *)text), cur_idx(~0ull), cur(0) {}
+    __device__ __forceinline__ u32 at(u64 p)
+    {
+        const u64 i = p >> 3;
+        if (i != cur_idx) {
+            cur = w[i];
+            cur_idx = i;
+        }
+        return (u32)(cur >> (8 * (p & 7))) & 0xFFu;
+    }
+};
+
+__device__ __forceinline__ u32 fx_upper(u32 c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
+/* A0 C1 G2 T3 (BG/HashTable.h:16-24), anything else 4 */
+__device__ __forceinline__ u32 fx_code(u32 c) { return c == 'A' ? 0u : (c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 4u))); }
+
+/* record starts: '>' at the first byte of a line. count != nullptr: starts per tile; pos != nullptr: their positions at
+ * base[tile] + rank inside the tile. A '>' anywhere else raises FX_CTR_BAD_GT (the file is not of the accepted form). */
+__global__ void __launch_bounds__(256) fx_starts_kernel(const u8 *__restrict__ text, u64 n, u32 *__restrict__ count, const u64 *__restrict__ base,
+                                                        u64 *__restrict__ pos, u64 *__restrict__ ctr)
+{
+    __shared__ u32 s_w[4];
+    const u64 tile = blockIdx.x;
+    const u64 p0 = tile * FX_TILE + (u64)threadIdx.x * 16u;
+    u32 mask = 0, bad = 0; /* bit i: byte p0 + i starts a record */
+    if (p0 < n) {
+        const uint4 q = *(const uint4 *)(text + p0); /* (padded buffer) */
+        const u32 wds[4] = {q.x, q.y, q.z, q.w};
+        u32 prev = p0 ? text[p0 - 1] : (u32)'\n';
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32 c = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            if (p0 + i < n && c == '>') {
+                if (prev == '\n') mask |= 1u << i;
+                else bad = 1;
+            }
+            prev = c;
+        }
+    }
+    if (bad) atomicAdd(&ctr[FX_CTR_BAD_GT], 1ull);
+    const u32 mine = (u32)__popc(mask);
+    /* exclusive prefix of `mine` over the block */
+    u32 incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = (u32)__shfl_up((int)incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 off = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_w[w];
+    if (count) {
+        if (threadIdx.x == 255) count[tile] = off + mine;
+    } else {
+        u64 at = base[tile] + off;
+        u32 m = mask;
+        while (m) {
+            const int i = __ffs((int)m) - 1;
+            m &= m - 1;
+            pos[at++] = p0 + (u64)i;
+        }
+    }
+}
+
+struct FxFilterArgs {
+    const u8 *text;
+    u64 n;           /* bytes of the file */
+    const u64 *start; /* [n_start] record starts */
+    u64 n_start;
+    u64 n_rec;       /* records (n_start, or one less when the last '>' is the last byte of the file) */
+    u32 min_overlap;
+    u16 *glen;       /* out [n_rec]: 0 = rejected, else the read length */
+    u64 *seq_begin;  /* out [n_rec]: first byte of the sequence */
+    u64 *ctr;
+};
+
+/* one thread per record: clean (upper case) + count in one pass over the sequence line, then Dataset::testRead
+ * (BG/Dataset.cpp:403-452) exactly as disco_amd/host/fastx.cpp:test_read_counted evaluates it */
+__global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables tb)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 my_max = 0, my_min = 0xFFFFu, my_good = 0;
+    for (; i < a.n_rec; i += (u64)gridDim.x * blockDim.x) {
+        const u64 s = a.start[i], e = (i + 1 < a.n_start) ? a.start[i + 1] : a.n;
+        FxBytes tx(a.text);
+        u64 p = s;
+        while (p < e && tx.at(p) != '\n') p++; /* header line */
+        const u64 sb = p < e ? p + 1 : e;
+        u64 se = e;
+        if (se > sb && tx.at(se - 1) == '\n') se--;
+        a.seq_begin[i] = sb;
+        const u64 L = se - sb;
+        /* counters packed into words (a dynamically indexed local array would live in scratch memory): A | C << 32, G | T << 32, the six
+         * dimers of two different letters — their occurrences cannot overlap, so plain counts — AC | AG << 21 | AT << 42, CG | CT << 21 | GT << 42 */
+        u64 acgt01 = 0, acgt23 = 0, dimA = 0, dimB = 0, other = 0;
+        u64 head = 0, tail = 0;
+        u32 prev = 4;
+        bool multiline = false;
+        for (u64 q = 0; q < L; q++) {
+            const u32 raw = tx.at(sb + q);
+            if (raw == '\n') multiline = true;
+            const u32 c = fx_code(fx_upper(raw));
+            if (c < 2) acgt01 += 1ull << (32 * c);
+            else if (c < 4) acgt23 += 1ull << (32 * (c - 2));
+            else other++;
+            if (c < 4 && c > prev) { /* (prev, c) in (0,1)(0,2)(0,3) | (1,2)(1,3)(2,3) */
+                if (prev == 0) dimA += 1ull << (21 * (c - 1));
+                else dimB += 1ull << (21 * (prev + c - 3));
+            }
+            tail = ((tail << 2) | (c & 3u)) & ((1ull << 58) - 1ull);
+            if (q == 28) head = tail;
+            prev = c;
+        }
+        const u32 cnt[5] = {(u32)acgt01, (u32)(acgt01 >> 32), (u32)acgt23, (u32)(acgt23 >> 32), (u32)other};
+        const u32 dim[6] = {(u32)(dimA & 0x1FFFFFu), (u32)((dimA >> 21) & 0x1FFFFFu), (u32)((dimA >> 42) & 0x1FFFFFu),
+                            (u32)(dimB & 0x1FFFFFu), (u32)((dimB >> 21) & 0x1FFFFFu), (u32)((dimB >> 42) & 0x1FFFFFu)};
+        if (multiline) { /* not the accepted form: the whole file goes to the host stage */
+            atomicAdd(&a.ctr[FX_CTR_MULTILINE], 1ull);
+            a.glen[i] = 0;
+            continue;
+        }
+        bool good = L > (u64)a.min_overlap && L >= 30 && cnt[4] == 0; /* BG/Dataset.cpp:305, MIN_READ_SIZE, :411 */
+        if (good) {
+            const u64 thr = (u64)((double)L * .7);
+            for (int b = 0; b < 4; b++)
+                if ((u64)cnt[b] >= thr) good = false;
+        }
+        if (good) {
+            for (u32 r = 0; r < tb.n_rep; r++)
+                if (head == tb.rep58[r] || tail == tb.rep58[r]) good = false;
+        }
+        if (good) {
+            const u64 thr = (u64)((double)L * .5);
+            for (u32 mi = 0; mi < tb.n_motif && good; mi++) {
+                const u32 ml = tb.motif_len[mi];
+                const u64 qq = (thr + ml - 1) / ml;
+                bool skip = false; /* the motif cannot occur often enough for the base counts (exact upper bound: fastx.cpp) */
+                for (int b = 0; b < 4; b++)
+                    if (tb.need[mi][b] && (u64)cnt[b] < (u64)tb.need[mi][b] * qq) skip = true;
+                if (skip) continue;
+                u64 covered;
+                const u32 x = fx_code(tb.motif[mi][0]), y = fx_code(tb.motif[mi][1]);
+                if (ml == 2 && x < y && y < 4) {
+                    covered = 2ull * dim[x == 0 ? y - 1 : (x == 1 ? y + 1 : 5)];
+                } else { /* left to right, non-overlapping: BG/Common.h:173-183 */
+                    u64 hits = 0;
+                    for (u64 q = 0; q + ml <= L;) {
+                        bool eq = true;
+                        for (u32 t = 0; t < ml && eq; t++) eq = fx_upper(tx.at(sb + q + t)) == tb.motif[mi][t];
+                        if (eq) {
+                            hits++;
+                            q += ml;
+                        } else
+                            q++;
+                    }
+                    covered = hits * ml;
+                }
+                if (covered >= thr) good = false;
+            }
+        }
+        if (good && L > 32767) { /* the packed layout has the reference's 15-bit length field (BG/HashTable.cpp:531) */
+            atomicAdd(&a.ctr[FX_CTR_TOO_LONG], 1ull);
+            good = false;
+        }
+        a.glen[i] = good ? (u16)L : (u16)0;
+        if (good) {
+            my_good++;
+            my_max = max(my_max, (u32)L);
+            my_min = min(my_min, (u32)L);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        my_max = max(my_max, (u32)__shfl_down((int)my_max, o));
+        my_min = min(my_min, (u32)__shfl_down((int)my_min, o));
+        my_good += (u32)__shfl_down((int)my_good, o);
+    }
+    if ((threadIdx.x & 63) == 0 && my_good) {
+        atomicMax(&a.ctr[FX_CTR_MAX_LEN], (u64)my_max);
+        atomicMax(&a.ctr[FX_CTR_MIN_LEN_INV], (u64)(0xFFFFu - my_min));
+        atomicAdd(&a.ctr[FX_CTR_GOOD], (u64)my_good);
+    }
+}
+
+__global__ void fx_flags_kernel(const u16 *__restrict__ glen, u64 n, u8 *__restrict__ flag)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) flag[i] = glen[i] != 0;
+}
+
+/* good record i -> read id_base + pos[i]: its record number (for the file index), its length */
+__global__ void fx_ids_kernel(const u16 *__restrict__ glen, const u64 *__restrict__ pos, u64 n_rec, u64 id_base, u32 *__restrict__ rec_of_read, u16 *__restrict__ len)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_rec; i += (u64)gridDim.x * blockDim.x)
+        if (glen[i]) {
+            rec_of_read[id_base + pos[i]] = (u32)i;
+            len[id_base + pos[i]] = glen[i];
+        }
+}
+
+/* word w of the row of read id: bases [32 w, 32 w + 32) of its sequence line, 2 bits per base, MSB first (BG/HashTable.cpp:456-477);
+ * words behind the read are zero. One thread per word of the table rows [id_base, id_base + n_good). */
+__global__ void __launch_bounds__(256) fx_pack_kernel(const u8 *__restrict__ text, const u64 *__restrict__ seq_begin, const u32 *__restrict__ rec_of_read,
+                                                      const u16 *__restrict__ len, u64 id_base, u64 n_good, int S, u64 *__restrict__ reads)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = n_good * (u64)S;
+    for (; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 id = id_base + t / (u64)S;
+        const u32 w = (u32)(t % (u64)S);
+        const u32 L = len[id];
+        u64 acc = 0;
+        if (32u * w < L) {
+            const u64 sb = seq_begin[rec_of_read[id]] + 32u * w;
+            const u32 nb = min(32u, L - 32u * w);
+            FxBytes tx(text);
+            for (u32 x = 0; x < nb; x++) acc = (acc << 2) | (fx_code(fx_upper(tx.at(sb + x))) & 3u);
+            acc <<= 2 * (32 - nb);
+        }
+        reads[id * (u64)S + w] = acc;
+    }
+}
+
+#endif

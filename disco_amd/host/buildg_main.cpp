@@ -240,7 +240,50 @@ int main(int argc, char **argv)
         pinned.alloc = disco_host_alloc;
         pinned.free = disco_host_free;
     }
-    if (!disco::load_reads(pe, se, min_overlap, threads, rs, err, pinned)) return die(err);
+    /* The input stage on the GPU (disco_ingest_fasta: the files travel to HBM as text; records, read filter, ids and the 2-bit rows are
+     * kernels) for one GPU and plain FASTA files of the common form; DISCO_E_UNSUPPORTED (FASTQ, .gz, a '>' inside a line, sequences over
+     * several lines, unreadable or empty files) leaves everything to the host stage below, which follows the reference's getline calls
+     * literally and prints its messages. DISCO_HOST_INPUT=1: the host stage always. */
+    disco_ctx *ctx1 = nullptr; /* the single-GPU context, created here when the device stage is tried */
+    bool ingested = false;
+    if (gpus == 1 && !getenv("DISCO_HOST_INPUT")) {
+        const disco_params prm0{min_overlap, 4, getenv("DISCO_EXACT_COUNTERS") ? 0u : DISCO_FLAG_TWO_PASS_VERIFY, max_subs};
+        if (disco_create(gpu, &prm0, &ctx1) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
+        std::vector<const char *> paths;
+        for (auto &f : pe) paths.push_back(f.c_str());
+        for (auto &f : se) paths.push_back(f.c_str());
+        std::vector<disco_ingest_file> ifiles(paths.size());
+        disco_ingest_info ii;
+        const int irc = disco_ingest_fasta(ctx1, paths.data(), (int)paths.size(), (uint32_t)threads, &ii, ifiles.data());
+        if (irc == DISCO_OK) {
+            rs.n_reads = ii.n_reads;
+            rs.stride_words = ii.stride_words;
+            rs.total_records = ii.total_records;
+            rs.too_long = ii.too_long;
+            rs.shortest = ii.shortest;
+            rs.longest = ii.longest;
+            rs.len.resize(ii.n_reads);
+            rs.file_index.resize(ii.n_reads);
+            if (disco_ingest_fetch(ctx1, rs.len.data(), rs.file_index.data()) < 0) return die(disco_last_error(ctx1));
+            for (size_t i = 0; i < paths.size(); i++) {
+                disco::FileRange fr;
+                fr.name = paths[i];
+                fr.paired = i < pe.size();
+                fr.first_index = ifiles[i].first_index;
+                fr.last_index = ifiles[i].last_index;
+                fr.good = ifiles[i].good;
+                fr.bad = ifiles[i].bad;
+                rs.files.push_back(fr);
+            }
+            ingested = true;
+            if (getenv("DISCO_VERBOSE"))
+                fprintf(stderr, "[disco host] input stage on the GPU: files into HBM %.3f s, records + filter + ids + rows %.3f s\n", ii.read_s, ii.device_s);
+        } else if (irc != DISCO_E_UNSUPPORTED)
+            return die(std::string("disco_ingest_fasta: ") + disco_last_error(ctx1));
+        else if (getenv("DISCO_VERBOSE"))
+            fprintf(stderr, "[disco host] %s\n", disco_last_error(ctx1));
+    }
+    if (!ingested && !disco::load_reads(pe, se, min_overlap, threads, rs, err, pinned)) return die(err);
     for (auto &fr : rs.files) {
         std::cout << "File name: " << fr.name << "\n"
                   << "  " << fr.good << " good reads in current dataset.\n  " << fr.bad << " bad reads in current dataset.\n  "
@@ -299,9 +342,9 @@ int main(int argc, char **argv)
         t1 = Clock::now();
     };
     if (gpus == 1) {
-        disco_ctx *ctx = nullptr;
-        if (disco_create(gpu, &prm, &ctx) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
-        DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed, rs.stride_words, rs.len.data(), rs.size()));
+        disco_ctx *ctx = ctx1;
+        if (!ctx && disco_create(gpu, &prm, &ctx) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
+        if (!ingested) DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed, rs.stride_words, rs.len.data(), rs.size()));
         t_h2d = secs(t0);
         t0 = Clock::now();
         DISCO_CALL(ctx, disco_build_index(ctx));

@@ -29,19 +29,8 @@ namespace disco {
 
 namespace {
 
-/* BG/Dataset.cpp:48-85 — 29-mers that disqualify a read when they are its prefix or suffix */
-const char *const kEndRepeats[] = {
-    "ACACACACACACACACACACACACACACA", "AGAGAGAGAGAGAGAGAGAGAGAGAGAGA", "ATATATATATATATATATATATATATATA", "CGCGCGCGCGCGCGCGCGCGCGCGCGCGC",
-    "CTCTCTCTCTCTCTCTCTCTCTCTCTCTC", "AAGAAGAAGAAGAAGAAGAAGAAGAAGAA", "ATAATAATAATAATAATAATAATAATAAT", "TAATAATAATAATAATAATAATAATAATA",
-    "AACAACAACAACAACAACAACAACAACAA", "ACAACAACAACAACAACAACAACAACAAC", "CAACAACAACAACAACAACAACAACAACA", "AGAAGAAGAAGAAGAAGAAGAAGAAGAAG",
-    "GAAGAAGAAGAAGAAGAAGAAGAAGAAGA", "TTCTTCTTCTTCTTCTTCTTCTTCTTCTT", "AAATAAATAAATAAATAAATAAATAAATA", "TAAATAAATAAATAAATAAATAAATAAAT",
-    "ATAAATAAATAAATAAATAAATAAATAAA", "AATAAATAAATAAATAAATAAATAAATAA", "AATTAATTAATTAATTAATTAATTAATTA", "ATTAATTAATTAATTAATTAATTAATTAA",
-    "TTAATTAATTAATTAATTAATTAATTAAT", "TAATTAATTAATTAATTAATTAATTAATT", "AAAGAAAGAAAGAAAGAAAGAAAGAAAGA", "AGAAAGAAAGAAAGAAAGAAAGAAAGAAA",
-    "GAAAGAAAGAAAGAAAGAAAGAAAGAAAG", "TACATACATACATACATACATACATACAT", "ACATACATACATACATACATACATACATA", "CATACATACATACATACATACATACATAC",
-    "ATACATACATACATACATACATACATACA", "GTTTGTTTGTTTGTTTGTTTGTTTGTTTG", "TGTTTGTTTGTTTGTTTGTTTGTTTGTTT", "TTTGTTTGTTTGTTTGTTTGTTTGTTTGT",
-    "AGGGAGGGAGGGAGGGAGGGAGGGAGGGA", "GAGGGAGGGAGGGAGGGAGGGAGGGAGGG", "GGAGGGAGGGAGGGAGGGAGGGAGGGAGG", "GGGAGGGAGGGAGGGAGGGAGGGAGGGAG"};
-/* BG/Dataset.cpp:87 — motifs whose non-overlapping occurrences may not cover half of the read */
-const char *const kMotifs[] = {"AC", "AG", "AT", "CG", "CT", "GT", "AAT", "ATA", "TAA", "AAC", "ACA", "CAA", "AAG", "AGA", "GAA", "GGGGCC"};
+/* kEndRepeats / kMotifs: the read filter's pattern tables (BG/Dataset.cpp:48-87), shared with the GPU input stage */
+#include "../csrc/read_filter_tables.h"
 
 size_t covered_by(const char *s, size_t n, const char *motif, size_t m)
 {

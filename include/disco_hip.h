@@ -244,6 +244,29 @@ int disco_dist_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
 int disco_dist_run_graph(disco_ctx *ctx, uint32_t flags);
 int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
 
+/* ---- input stage on the GPU (SURVEY.md section 8 a-1 … a-3, f-2) ------------------------------------------------------------- */
+/* Reads FASTA files itself (parallel pread through pinned staging), finds the records, cleans and filters every read
+ * (Dataset::readDataset / testRead, BG/Dataset.cpp:161-380,403-452) and packs the good ones into the context's read table, all on the
+ * device: replaces parse + filter + pack on the host cores AND the upload. Read ids = rank among the good reads in file order over the
+ * files in the order given (pass the -pe files, then the -se files). Returns DISCO_E_UNSUPPORTED — nothing changed — when a file is not
+ * of the form the device stage accepts (it must start with '>', every '>' must begin a line, every record's sequence must be one
+ * line; .gz, FASTQ, empty or unreadable files): the caller then runs its host stage (disco_amd/host/fastx.cpp follows the reference's
+ * getline calls literally and produces its error messages) and disco_upload_reads. */
+typedef struct disco_ingest_file {
+    uint64_t first_index, last_index; /* 1-based file indices of the file's first / last record (every record counts, BG/Dataset.cpp:294) */
+    uint64_t good, bad;
+} disco_ingest_file;
+typedef struct disco_ingest_info {
+    uint64_t n_reads, total_records, too_long; /* too_long: otherwise good reads beyond 32767 bases (dropped; BG/HashTable.cpp:531) */
+    uint32_t stride_words;                     /* words per read the longest good read needs                                         */
+    uint32_t shortest, longest;
+    float read_s, device_s;                    /* host wall: files into HBM / everything after                                        */
+} disco_ingest_info;
+int disco_ingest_fasta(disco_ctx *ctx, const char *const *paths, int n_files, uint32_t host_threads, disco_ingest_info *info, disco_ingest_file *files);
+/* lengths and 1-based file indices (for <prefix>_ReadIDMap.txt and the id columns of every output line) of the reads the last
+ * disco_ingest_fasta kept: len[n_reads], file_index[n_reads] */
+int disco_ingest_fetch(disco_ctx *ctx, uint16_t *len, uint64_t *file_index);
+
 /* ---- results --------------------------------------------------------------------------------------------------- */
 /* rows in ascending contained-read id; returns the number of rows written, or a negative error */
 int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);

@@ -1,0 +1,188 @@
+"""-m gpu : the input stage on the GPU (disco_ingest_fasta: records, Dataset::testRead, ids and 2-bit rows as kernels) against the
+CPU restatement of the reference's parser and filter (oracle/pyoracle.load_good_reads, pinned in tests/test_oracle_golden.py /
+tests/test_host.py) and against the host stage of the drop-in: the same reads kept, the same file indices, the same packed rows —
+and the files it must DECLINE (so that the host stage, which follows the reference's getline calls literally, takes them)."""
+import glob
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from disco_amd import build, buildgraph
+from oracle import pyoracle
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "disco_amd", "bin")
+MOTIFS = ["AC", "AG", "AT", "CG", "CT", "GT", "AAT", "ATA", "TAA", "AAC", "ACA", "CAA", "AAG", "AGA", "GAA", "GGGGCC"]
+
+
+def _decode(packed, lens):
+    out = []
+    for row, L in zip(packed, lens):
+        s = []
+        for t in range(int(L)):
+            s.append("ACGT"[(int(row[t >> 5]) >> (62 - 2 * (t & 31))) & 3])
+        out.append("".join(s))
+    return out
+
+
+def _adversarial(rng, n):
+    """reads around every threshold of Dataset::testRead (BG/Dataset.cpp:403-452), lower case, N, CR, short and very long ones"""
+    reads = []
+    for i in range(n):
+        L = int(rng.integers(25, 260))
+        kind = i % 8
+        if kind == 0:
+            s = "".join(rng.choice(list("ACGT"), L))
+        elif kind == 1:  # one base near the 70 % threshold
+            b = "ACGT"[i % 4]
+            frac = rng.uniform(0.62, 0.78)
+            s = "".join(b if rng.random() < frac else rng.choice(list("ACGT")) for _ in range(L))
+        elif kind == 2:  # a motif covering about half of the read, scattered
+            m = MOTIFS[int(rng.integers(0, len(MOTIFS)))]
+            reps = int(L * rng.uniform(0.40, 0.60) / len(m))
+            parts = [m] * reps + list(rng.choice(list("ACGT"), max(L - reps * len(m), 0)))
+            rng.shuffle(parts)
+            s = "".join(parts)[:L]
+        elif kind == 3:  # motif run + random tail
+            m = MOTIFS[int(rng.integers(0, len(MOTIFS)))]
+            run = int(L * rng.uniform(0.45, 0.55))
+            s = (m * (run // len(m) + 1))[:run] + "".join(rng.choice(list("ACGT"), L - run))
+        elif kind == 4:  # micro-repeat prefix / suffix
+            unit = ["AC", "AAG", "AAAT", "AATT", "TACA", "GTTT", "AGGG"][i % 7]
+            rep = (unit * 10)[:29]
+            body = "".join(rng.choice(list("ACGT"), L))
+            s = rep + body if i % 2 else body + rep
+        elif kind == 5:  # lower case, N, mixed case
+            s = "".join(rng.choice(list("ACGT"), L))
+            s = s.lower() if i % 3 == 0 else (s[:10] + "N" + s[11:] if i % 3 == 1 else s[:L // 2].lower() + s[L // 2:])
+        elif kind == 6:  # lengths around the minimum overlap and MIN_READ_SIZE
+            s = "".join(rng.choice(list("ACGT"), int(rng.integers(20, 45))))
+        else:            # a few very long reads (beyond the 15-bit length field: dropped and counted)
+            s = "".join(rng.choice(list("ACGT"), 33000 if i % 64 == 7 else L))
+        reads.append(s)
+    return reads
+
+
+def _ingest(paths, min_overlap):
+    with buildgraph.BuildGraph(min_overlap=min_overlap) as g:
+        res = g.ingest_fasta(paths, threads=8)
+        if res is None:
+            return None
+        info, files = res
+        ln, fi = g.ingest_fetch()
+        packed, lens = g.download_reads()
+        assert np.array_equal(ln, lens) and info["n_reads"] == len(ln) == g.num_reads
+        return info, files, _decode(packed, lens), fi
+
+
+@pytest.mark.parametrize("min_overlap,eol,final_newline", [(30, "\n", True), (40, "\n", False), (31, "\r\n", True)])
+def test_ingest_keeps_what_the_reference_parser_keeps(tmp_path, min_overlap, eol, final_newline):
+    rng = np.random.default_rng(7 + min_overlap)
+    reads = _adversarial(rng, 5000)
+    text = "".join(f">r{i} some description{eol}{s}{eol}" for i, s in enumerate(reads))
+    if not final_newline:
+        text = text[:-len(eol)]
+    fa = tmp_path / "adv.fasta"
+    fa.write_bytes(text.encode())
+    want, wfidx, wtotal = pyoracle.load_good_reads([str(fa)], min_overlap)
+    # reads beyond the 15-bit length field of the index records (BG/HashTable.cpp:531) are dropped and counted, by the host stage too
+    keep = [i for i, s in enumerate(want) if len(s) <= 32767]
+    n_long = len(want) - len(keep)
+    want, wfidx = [want[i] for i in keep], np.asarray(wfidx)[keep]
+    if eol == "\r\n":  # a CR is a character that is not ACGT (the reference strips the newline only): every read is rejected, and a job
+        assert want == [] and _ingest([str(fa)], min_overlap) is None  # without a good read goes to the host stage for its error message
+        return
+    info, files, got, fidx = _ingest([str(fa)], min_overlap)
+    assert info["total_records"] == wtotal == len(reads) and info["too_long"] == n_long
+    assert got == want and np.array_equal(fidx.astype(np.int64), np.asarray(wfidx, dtype=np.int64))
+    assert files[0]["good"] == len(want) and files[0]["good"] + files[0]["bad"] == len(reads)
+    assert 800 < len(got) < 4500 and n_long > 0  # both outcomes well represented; the long reads were counted
+
+
+def test_ingest_of_several_files_numbers_the_records_through(tmp_path):
+    rng = np.random.default_rng(3)
+    paths, all_reads = [], []
+    for f in range(3):
+        reads = _adversarial(rng, 700 + 100 * f)
+        p = tmp_path / f"f{f}.fa"
+        p.write_text("".join(f">x{i}\n{s}\n" for i, s in enumerate(reads)))
+        paths.append(str(p))
+        all_reads += reads
+    want, wfidx, wtotal = pyoracle.load_good_reads(paths, 35)
+    keep = [i for i, s in enumerate(want) if len(s) <= 32767]
+    want, wfidx = [want[i] for i in keep], np.asarray(wfidx)[keep]
+    info, files, got, fidx = _ingest(paths, 35)
+    assert info["total_records"] == wtotal == len(all_reads) and got == want
+    assert np.array_equal(fidx.astype(np.int64), np.asarray(wfidx, dtype=np.int64))
+    assert [f["first_index"] for f in files] == [1, 701, 1501] and files[2]["last_index"] == len(all_reads)
+
+
+def test_ingest_declines_what_only_the_literal_parser_handles(tmp_path):
+    good = ">a\nACGTTGCAAGCTAGCTAGGATCGATCGTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n"
+    cases = {
+        "multiline.fa": ">a\nACGTTGCAAGCTAGCTAGGATCGATCG\nTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n",
+        "gt_inside.fa": ">a>b\nACGT\n" + good.replace(">a", ">c d>e"),
+        "reads.fq": "@a\nACGT\n+\nIIII\n",
+        "blank_line.fa": good + "\n" + good,
+        "empty.fa": "",
+        "no_header.fa": "ACGT\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_text(text)
+        assert _ingest([str(p)], 30) is None, name
+    gz = tmp_path / "r.fa.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(good)
+    assert _ingest([str(gz)], 30) is None
+    assert _ingest([str(tmp_path / "does_not_exist.fa")], 30) is None
+    ok = tmp_path / "ok.fa"
+    ok.write_text(good * 3 + ">")  # a '>' that is the very last byte starts no record (disco_amd/host/fastx.cpp)
+    info, files, got, fidx = _ingest([str(ok)], 30)
+    assert info["total_records"] == 3 and len(got) == 3 and list(fidx) == [1, 2, 3]
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_buildg_with_the_device_input_stage_writes_the_host_stages_files(tmp_path, threads):
+    """the whole drop-in on a FASTA the device stage accepts, against DISCO_HOST_INPUT=1: every output file line for line; and on the
+    `multifile` fixture (FASTQ, multi-line FASTA: declined) the run still equals the reference's files"""
+    from disco_amd import readgen
+
+    build.build_host()
+    rng = np.random.default_rng(11)
+    spec = readgen.GenSpec.coverage(seed=21, n_reads=20000, read_len=100, cov=20.0, n_contigs=3, len_max=180)
+    reads = list(readgen.generate_reads(spec)) + _adversarial(rng, 2000)
+    order = rng.permutation(len(reads))
+    fa = tmp_path / "r.fasta"
+    fa.write_text("".join(f">q{i}\n{reads[j]}\n" for i, j in enumerate(order)))
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text("MinOverlap4BuildGraph = 40\n")
+    out = {}
+    for how in ("device", "host"):
+        prefix = str(tmp_path / how)
+        env = dict(os.environ, DISCO_VERBOSE="1", **({"DISCO_HOST_INPUT": "1"} if how == "host" else {}))
+        p = subprocess.run([os.path.join(BIN, "buildG"), "-se", str(fa), "-f", prefix, "-p", str(cfg), "-t", str(threads)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+        assert p.returncode == 0, p.stdout
+        assert ("input stage on the GPU" in p.stdout) == (how == "device"), p.stdout[-1500:]
+        out[how] = {os.path.basename(f)[len(how):]: sorted(open(f, "rb").read().splitlines()) for f in sorted(glob.glob(prefix + "_*"))}
+        out[how + "_log"] = [l for l in p.stdout.splitlines() if "reads in current dataset" in l or "read length in all datasets" in l]
+    assert out["device"].keys() == out["host"].keys() and len(out["device"]) >= 3 * threads + 2
+    for k in out["device"]:  # (the order of the edge lines inside a file follows the emission's atomics: compared as sets of lines)
+        assert out["device"][k] == out["host"][k], k
+    assert out["device_log"] == out["host_log"] and len(out["device"]["_ReadIDMap.txt"]) > 0
+    # declined files: the host stage takes over inside the same run
+    c = gu.CASES["multifile"]
+    prefix = str(tmp_path / "m")
+    cmd = [os.path.join(BIN, "buildG"), "-pe", ",".join(os.path.join(gu.GOLD, f) for f in c["pe"]), "-se", ",".join(os.path.join(gu.GOLD, f) for f in c["se"]), "-f", prefix,
+           "-p", str(cfg), "-t", "2"]
+    cfg.write_text(f"MinOverlap4BuildGraph = {c['min_overlap']}\n")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"))
+    assert p.returncode == 0 and "the host input stage takes this job" in p.stdout, p.stdout[-1500:]
+    from oracle import refrun
+
+    gu.check_against_golden("multifile", refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt"))), refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt"))))
