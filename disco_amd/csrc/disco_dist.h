@@ -499,13 +499,13 @@ __global__ void __launch_bounds__(64) emit_push_recv_kernel(EmitRecvArgs a)
  *   hit   : x = requester rank << 32 | read index inside its range      ; y = HIT_MAKE(window, id, suffix, strand relation, length)
  * ======================================================================================================================= */
 #define PQ_Y(rank, fp, rev, delta, wend, wstart) \
-    (((u64)(rank) << 40) | ((u64)(fp) << 24) | ((u64)(rev) << 23) | ((u64)(delta) << 18) | ((u64)(wend) << 9) | (u64)(wstart))
-#define PQ_WSTART(y) ((int)((y)&0x1FFu))
-#define PQ_WEND(y) ((int)(((y) >> 9) & 0x1FFu))
-#define PQ_DELTA(y) ((int)(((y) >> 18) & 31u))
-#define PQ_REV(y) ((u32)(((y) >> 23) & 1u))
-#define PQ_FP(y) ((u32)(((y) >> 24) & 0x3FFu))
-#define PQ_RANK(y) ((u32)(((y) >> 40) & 0x3Fu))
+    (((u64)(rank) << 47) | ((u64)(fp) << 37) | ((u64)(rev) << 36) | ((u64)(delta) << 30) | ((u64)(wend) << 15) | (u64)(wstart))
+#define PQ_WSTART(y) ((int)((y)&0x7FFFu))
+#define PQ_WEND(y) ((int)(((y) >> 15) & 0x7FFFu))
+#define PQ_DELTA(y) ((int)(((y) >> 30) & 63u))
+#define PQ_REV(y) ((u32)(((y) >> 36) & 1u))
+#define PQ_FP(y) ((u32)(((y) >> 37) & 0x3FFu))
+#define PQ_RANK(y) ((u32)(((y) >> 47) & 0x3Fu))
 
 struct RouteByHitRank { /* {rank << 32 | read index, hit} */
     __device__ __forceinline__ u32 operator()(const ulonglong2 &h) const { return (u32)(h.x >> 32); }
@@ -560,67 +560,63 @@ __global__ void __launch_bounds__(256) pq_make_kernel(DiscoView v, const u32 *__
     }
 }
 
-/* reads without a usable run list, the long way: window_minimizer's rule (disco_device.h) for every window from the order words of
- * its NF m-mers, one query per maximal range of consecutive windows with the same (occurrence, strand) — with ties an occurrence can
- * own several such ranges; their windows are disjoint, so the owner's test still yields every (window, record) pair once.
- * One thread per read (about 2 reads in 10 000 on random sequence). cap_per_read queries of room per read at out + i * cap_per_read. */
-__global__ void pq_slow_kernel(DiscoView v, const u32 *__restrict__ slow, u32 n_slow, u64 lo, u32 my_rank, u32 cap_per_read, ulonglong2 *__restrict__ out,
-                               u32 *__restrict__ out_cnt)
+/* reads without a usable run list (ties, too many runs) — or, for shapes the index pass leaves no runs for (windows other than 17
+ * m-mers, reads beyond 256 bases), ALL reads — the long way: window_minimizer's rule (disco_device.h) for every window from the order
+ * words of its NF m-mers, one query per maximal range of consecutive windows with the same (occurrence, strand) — with ties an
+ * occurrence can own several such ranges; their windows are disjoint, so the owner's test still yields every (window, record) pair
+ * once. One thread per read. out == nullptr: queries per read -> cnt; else the queries at out + start[i]. list == nullptr: read i of
+ * the range itself. */
+__global__ void pq_slow_kernel(DiscoView v, const u32 *__restrict__ list, u64 n_list, u64 lo, u32 my_rank, u32 *__restrict__ cnt, const u64 *__restrict__ start,
+                               ulonglong2 *__restrict__ out)
 {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slow) return;
-    const u64 ri = slow[i], A = lo + ri;
-    const u64 *row = v.reads + A * v.S;
-    const int L = v.len[A], k = v.k, m = v.m, nf = k - m + 1, npos = L - k;
-    ulonglong2 *o = out + (u64)i * cap_per_read;
-    u32 n = 0;
-    int run_w = 0, run_p = -1;
-    u32 run_rev = 0;
-    auto flush = [&](int wend) {
-        if (run_p < 0) return;
-        const u64 key = mmer_key(row, v.S, run_p, m);
-        if (n < cap_per_read) o[n] = make_ulonglong2(((key >> v.bshift) << 32) | (u64)(u32)ri, PQ_Y(my_rank, KEY_FP(key), run_rev, run_p - run_w, wend, run_w));
-        n++;
-    };
-    for (int w = 0; w < npos; w++) {
-        u32 k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, st1 = 0;
-        for (int f = 0; f < nf; f++) {
-            const u32 ow = mmer_order(row, v.S, w + f, m);
-            const u32 a1 = (ow & ~0x1FFu) | (u32)f, a2 = (ow & ~0x1FFu) | (u32)(511 - f);
-            if (a1 < k1) {
-                k1 = a1;
-                st1 = ow & 1u;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_list; i += (u64)gridDim.x * blockDim.x) {
+        const u64 ri = list ? (u64)list[i] : i, A = lo + ri;
+        const u64 *row = v.reads + A * v.S;
+        const int L = v.len[A], k = v.k, m = v.m, nf = k - m + 1, npos = L - k;
+        ulonglong2 *o = out ? out + start[i] : nullptr;
+        u32 n = 0;
+        int run_w = 0, run_p = -1;
+        u32 run_rev = 0;
+        auto flush = [&](int wend) {
+            if (run_p < 0) return;
+            if (o) {
+                const u64 key = mmer_key(row, v.S, run_p, m);
+                o[n] = make_ulonglong2(((key >> v.bshift) << 32) | (u64)(u32)ri, PQ_Y(my_rank, KEY_FP(key), run_rev, run_p - run_w, wend, run_w));
             }
-            k2 = a2 < k2 ? a2 : k2;
+            n++;
+        };
+        for (int w = 0; w < npos; w++) {
+            u32 k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, st1 = 0;
+            for (int f = 0; f < nf; f++) {
+                const u32 ow = mmer_order(row, v.S, w + f, m);
+                const u32 a1 = (ow & ~0x1FFu) | (u32)f, a2 = (ow & ~0x1FFu) | (u32)(511 - f);
+                if (a1 < k1) {
+                    k1 = a1;
+                    st1 = ow & 1u;
+                }
+                k2 = a2 < k2 ? a2 : k2;
+            }
+            const int f1 = (int)(k1 & 511u), f2 = 511 - (int)(k2 & 511u);
+            u32 rev;
+            int p;
+            if (f1 == f2) {
+                rev = st1;
+                p = w + f1;
+            } else {
+                rev = kmer_is_rev(row, v.S, w, k);
+                p = w + (rev ? f2 : f1);
+            }
+            if (p != run_p || rev != run_rev) {
+                flush(w);
+                run_w = w;
+                run_p = p;
+                run_rev = rev;
+            }
         }
-        const int f1 = (int)(k1 & 511u), f2 = 511 - (int)(k2 & 511u);
-        u32 rev;
-        int p;
-        if (f1 == f2) {
-            rev = st1;
-            p = w + f1;
-        } else {
-            rev = kmer_is_rev(row, v.S, w, k);
-            p = w + (rev ? f2 : f1);
-        }
-        if (p != run_p || rev != run_rev) {
-            flush(w);
-            run_w = w;
-            run_p = p;
-            run_rev = rev;
-        }
+        flush(npos);
+        if (!out) cnt[i] = n;
     }
-    flush(npos);
-    out_cnt[i] = n;
-}
-
-/* queries of the slow reads (cap_per_read slots each, cnt used) appended to the flat list */
-__global__ void pq_slow_append_kernel(const ulonglong2 *__restrict__ in, const u32 *__restrict__ cnt, const u64 *__restrict__ start, u32 n_slow, u32 cap_per_read,
-                                      ulonglong2 *__restrict__ out)
-{
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 i = t / cap_per_read, q = t % cap_per_read;
-    if (i < n_slow && q < cnt[i]) out[start[i] + q] = in[i * cap_per_read + q];
 }
 
 /* the owner's side: one thread per query walks its bucket (bkt / ent: this rank's slices, bucket indices relative to blo, record

@@ -1052,12 +1052,29 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
 namespace {
 struct IngestFile {
     std::string path;
+    int fd = -1;
+    char last = 0;
     u64 n = 0;
     u8 *d_text = nullptr;
     u64 text_cap = 0;
     u64 *d_start = nullptr, *d_seq = nullptr;
     u16 *d_glen = nullptr;
     u64 n_start = 0, n_rec = 0, good = 0;
+};
+/* the transient buffers of the input stage are carved out of ONE arena — the context's hit buffer, sized here as the probe will want it
+ * (64 candidate slots per read: about three times the text): freeing 10 GB right before the pass made its first allocations take
+ * 0.6 s on these boxes, and the text simply lives where the candidates will */
+struct IngestArena {
+    u8 *base = nullptr;
+    u64 cap = 0, used = 0;
+    void *take(u64 nbytes)
+    {
+        const u64 bytes = (nbytes + 255) & ~255ull;
+        if (!base || used + bytes > cap) return nullptr;
+        void *p = base + used;
+        used += bytes;
+        return p;
+    }
 };
 } // namespace
 
@@ -1140,84 +1157,108 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
     HIPCHK(c, hipSetDevice(c->device));
     const auto t_begin = HClock::now();
     std::vector<IngestFile> F((size_t)n_files);
-    u64 *d_ctr = nullptr, *d_tile_base = nullptr, *d_pos = nullptr;
-    u32 *d_tile_cnt = nullptr;
-    u8 *d_flag = nullptr;
-    u64 tiles_cap = 0, pos_cap = 0;
-    int rc = DISCO_OK;
-    float read_s = 0;
+    struct Owned { /* pieces that did not fit the arena */
+        void *p;
+        size_t bytes;
+    };
+    std::vector<Owned> owned;
+    IngestArena arena;
     auto cleanup = [&]() {
-        for (auto &f : F) {
-            dev_free(c, &f.d_text, f.text_cap);
-            dev_free(c, &f.d_start, f.n_start);
-            dev_free(c, &f.d_seq, f.n_rec);
-            dev_free(c, &f.d_glen, f.n_rec);
+        for (auto &f : F)
+            if (f.fd >= 0) close(f.fd);
+        for (auto &o : owned) {
+            (void)hipFree(o.p);
+            c->hbm_bytes = c->hbm_bytes >= o.bytes ? c->hbm_bytes - o.bytes : 0;
         }
-        dev_free(c, &d_ctr, (size_t)FX_CTR_COUNT);
-        dev_free(c, &d_tile_base, tiles_cap + 1);
-        dev_free(c, &d_tile_cnt, tiles_cap);
-        dev_free(c, &d_pos, pos_cap + 1);
-        dev_free(c, &d_flag, pos_cap);
+        owned.clear();
     };
     auto unsupported = [&](const char *why, const std::string &path) {
         cleanup();
         return fail(c, DISCO_E_UNSUPPORTED, "disco_ingest_fasta: %s (%s): the host input stage takes this job", why, path.c_str());
     };
-    FxTables tb;
-    ingest_tables(&tb);
-    if ((rc = dev_alloc(c, &d_ctr, (size_t)FX_CTR_COUNT)) != DISCO_OK) return rc;
-    u64 total_records = 0, n_good = 0, too_long = 0;
-    u32 longest = 0, shortest = 0xFFFFu;
-    /* ---- pass A: every file into HBM, record starts, clean + filter ------------------------------------------------------------ */
+    /* ---- the files: regular, not gzip, first byte '>' --------------------------------------------------------------------------- */
+    u64 total_bytes = 0;
     for (int fi = 0; fi < n_files; fi++) {
         IngestFile &f = F[(size_t)fi];
         f.path = paths[fi] ? paths[fi] : "";
         if (f.path.size() >= 3 && f.path.compare(f.path.size() - 3, 3, ".gz") == 0) return unsupported("gzip input", f.path);
-        const int fd = open(f.path.c_str(), O_RDONLY);
-        if (fd < 0) return unsupported("unreadable file", f.path);
+        f.fd = open(f.path.c_str(), O_RDONLY);
+        if (f.fd < 0) return unsupported("unreadable file", f.path);
         struct stat st;
-        char first = 0, last = 0;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 1 || pread(fd, &first, 1, 0) != 1 || pread(fd, &last, 1, st.st_size - 1) != 1) {
-            close(fd);
+        char first = 0;
+        if (fstat(f.fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 1 || pread(f.fd, &first, 1, 0) != 1 || pread(f.fd, &f.last, 1, st.st_size - 1) != 1)
             return unsupported("empty or unreadable file", f.path);
-        }
-        if (first != '>') {
-            close(fd);
-            return unsupported("not FASTA", f.path);
-        }
+        if (first != '>') return unsupported("not FASTA", f.path);
         f.n = (u64)st.st_size;
         f.text_cap = (f.n + FX_TILE + 63) / FX_TILE * FX_TILE + 64; /* whole tiles (16-byte loads) and aligned 8-byte words behind the end */
-        const auto t_read = HClock::now();
-        if ((rc = dev_alloc(c, &f.d_text, f.text_cap)) == DISCO_OK && hipMemsetAsync(f.d_text + f.n, 0, f.text_cap - f.n, c->stream) != hipSuccess) rc = DISCO_E_HIP;
-        if (rc == DISCO_OK) rc = ingest_read_file(c, fd, f.n, f.d_text, host_threads ? host_threads : 16u);
-        close(fd);
-        read_s += ms_since(t_read) * 1e-3f;
-        if (rc != DISCO_OK) {
-            cleanup();
-            return rc;
-        }
-        const u64 tiles = (f.n + FX_TILE - 1) / FX_TILE;
-        if (tiles > tiles_cap) {
-            dev_free(c, &d_tile_base, tiles_cap + 1);
-            dev_free(c, &d_tile_cnt, tiles_cap);
-            tiles_cap = 0;
-            if ((rc = dev_alloc(c, &d_tile_base, tiles + 1)) != DISCO_OK || (rc = dev_alloc(c, &d_tile_cnt, tiles)) != DISCO_OK) {
-                cleanup();
-                return rc;
+        total_bytes += f.text_cap;
+    }
+    /* ---- the arena = the hit buffer as the probe will want it (a previous pass's results in it are gone) ------------------------- */
+    if (c->phase > 1) c->phase = 1;
+    c->d_adj = nullptr;
+    c->adj_total = 0;
+    {
+        const u64 want = (total_bytes / 100) * 64 + (u64)c->n_cu * 32 * PR_CHUNK + (1u << 16); /* entries: 64 per read, a chunk per resident wave */
+        if (want > c->hits_cap) {
+            size_t fr = 0, tot = 0;
+            HIPCHK(c, hipMemGetInfo(&fr, &tot));
+            if ((u64)fr + c->hits_cap * 8 > want * 8 + (total_bytes / 100) * 200 + (4ull << 30)) { /* room for it next to the table and the index */
+                dev_free(c, &c->d_hits, c->hits_cap);
+                c->hits_cap = 0;
+                if (dev_alloc(c, &c->d_hits, want) == DISCO_OK) c->hits_cap = want;
+                else c->err.clear();
             }
-            tiles_cap = tiles;
         }
+        arena.base = (u8 *)c->d_hits;
+        arena.cap = c->hits_cap * 8;
+    }
+    int rc = DISCO_OK;
+    auto get = [&](auto **pp, u64 count) -> int { /* from the arena, or an allocation of its own */
+        using T = typename std::remove_pointer<typename std::remove_pointer<decltype(pp)>::type>::type;
+        const size_t bytes = std::max<u64>(count, 1) * sizeof(T);
+        *pp = (T *)arena.take(bytes);
+        if (*pp) return DISCO_OK;
+        if (hipMalloc((void **)pp, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, DISCO_E_NOMEM, "disco_ingest_fasta: out of device memory");
+        }
+        c->hbm_bytes += bytes;
+        owned.push_back({(void *)*pp, bytes});
+        return DISCO_OK;
+    };
+    FxTables tb;
+    ingest_tables(&tb);
+    u64 *d_ctr = nullptr;
+    if ((rc = get(&d_ctr, (u64)FX_CTR_COUNT)) != DISCO_OK) {
+        cleanup();
+        return rc;
+    }
+    u64 total_records = 0, n_good = 0, too_long = 0;
+    u32 longest = 0, shortest = 0xFFFFu;
+    float read_s = 0;
+    /* ---- pass A: every file into HBM, record starts, clean + filter ------------------------------------------------------------ */
+    for (int fi = 0; fi < n_files; fi++) {
+        IngestFile &f = F[(size_t)fi];
+        const auto t_read = HClock::now();
+        if ((rc = get(&f.d_text, f.text_cap)) == DISCO_OK && hipMemsetAsync(f.d_text + f.n, 0, f.text_cap - f.n, c->stream) != hipSuccess) rc = DISCO_E_HIP;
+        if (rc == DISCO_OK) rc = ingest_read_file(c, f.fd, f.n, f.d_text, host_threads ? host_threads : 16u);
+        read_s += ms_since(t_read) * 1e-3f;
+        const u64 tiles = (f.n + FX_TILE - 1) / FX_TILE;
+        u64 *d_tile_base = nullptr;
+        u32 *d_tile_cnt = nullptr;
         auto body = [&]() -> int {
+            CHK(get(&d_tile_base, tiles + 1));
+            CHK(get(&d_tile_cnt, tiles));
             HIPCHK(c, hipMemsetAsync(d_ctr, 0, FX_CTR_COUNT * sizeof(u64), c->stream));
             hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, d_tile_cnt, (const u64 *)nullptr, (u64 *)nullptr, d_ctr);
             CHK((scan_exclusive<u32, u64>(c, d_tile_cnt, tiles, d_tile_base, false, &f.n_start)));
             if (f.n_start == 0 || f.n_start >= (1ull << 32)) return DISCO_E_UNSUPPORTED;
             /* a '>' that is the very last byte starts nothing (the reference's next getline fails) unless it is the only one; it still ends
              * the sequence of the record before it (disco_amd/host/fastx.cpp) */
-            f.n_rec = (f.n_start > 1 && last == '>') ? f.n_start - 1 : f.n_start;
-            CHK(dev_alloc(c, &f.d_start, f.n_start));
-            CHK(dev_alloc(c, &f.d_seq, f.n_rec));
-            CHK(dev_alloc(c, &f.d_glen, f.n_rec));
+            f.n_rec = (f.n_start > 1 && f.last == '>') ? f.n_start - 1 : f.n_start;
+            CHK(get(&f.d_start, f.n_start));
+            CHK(get(&f.d_seq, f.n_rec));
+            CHK(get(&f.d_glen, f.n_rec));
             hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start, d_ctr);
             FxFilterArgs fa;
             fa.text = f.d_text;
@@ -1243,7 +1284,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             }
             return DISCO_OK;
         };
-        rc = body();
+        if (rc == DISCO_OK) rc = body();
         if (rc == DISCO_E_UNSUPPORTED) return unsupported("a '>' inside a line, a sequence over several lines, or no record", f.path);
         if (rc != DISCO_OK) {
             cleanup();
@@ -1260,8 +1301,15 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
     /* ---- pass B: ids in file order, rows of the read table -------------------------------------------------------------------- */
     const uint32_t stride_words = std::max<u32>(1, (longest + 31) / 32), dstride = (stride_words + 7u) & ~7u;
     auto pass_b = [&]() -> int {
+        u64 *keep_hits = c->d_hits; /* set_reads_common may drop the graph state of a read set of another shape: the arena must survive it */
+        const u64 keep_cap = c->hits_cap;
+        c->d_hits = nullptr;
+        c->hits_cap = 0;
         bool kept = false;
-        CHK(set_reads_common(c, n_good, dstride, &kept));
+        const int src = set_reads_common(c, n_good, dstride, &kept);
+        c->d_hits = keep_hits;
+        c->hits_cap = keep_cap;
+        CHK(src);
         if (!kept) {
             CHK(dev_alloc(c, &c->d_reads, n_good * (u64)dstride));
             CHK(dev_alloc(c, &c->d_len, n_good));
@@ -1270,19 +1318,17 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         CHK(ensure_cap(c, &c->d_rec_of_read, &c->rec_of_read_cap, n_good));
         c->ingest_id_base.assign((size_t)n_files + 1, 0);
         c->ingest_rec_base.assign((size_t)n_files + 1, 0);
+        u64 max_rec = 0;
+        for (auto &f : F) max_rec = std::max(max_rec, f.n_rec);
+        u64 *d_pos = nullptr;
+        u8 *d_flag = nullptr;
+        CHK(get(&d_pos, max_rec + 1));
+        CHK(get(&d_flag, max_rec));
         u64 id_base = 0, rec_base = 0;
         for (int fi = 0; fi < n_files; fi++) {
             IngestFile &f = F[(size_t)fi];
             c->ingest_id_base[(size_t)fi] = id_base;
             c->ingest_rec_base[(size_t)fi] = rec_base;
-            if (f.n_rec > pos_cap) {
-                dev_free(c, &d_pos, pos_cap + 1);
-                dev_free(c, &d_flag, pos_cap);
-                pos_cap = 0;
-                CHK(dev_alloc(c, &d_pos, f.n_rec + 1));
-                CHK(dev_alloc(c, &d_flag, f.n_rec));
-                pos_cap = f.n_rec;
-            }
             hipLaunchKernelGGL(fx_flags_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, (const u16 *)f.d_glen, f.n_rec, d_flag);
             u64 good = 0;
             CHK((scan_exclusive<u8, u64>(c, d_flag, f.n_rec, d_pos, false, &good)));
@@ -3201,11 +3247,11 @@ static int dist_partitioned_probe(disco_ctx *c)
     const u64 lo = c->q_lo, nloc = c->q_hi - c->q_lo;
     DiscoView v = view(c);
     const int nf = v.k - v.m + 1;
-    if (nloc && (c->runs_lpr == 0 || c->runs_lo != lo || c->runs_n != nloc)) /* (every rank decides alike: the shape of the JOB) */
-        return fail(c, DISCO_E_UNSUPPORTED, "a partitioned index needs the minimizer runs of the index pass: min-overlap 40 (windows of 17 m-mers), reads of up to 256 bases");
+    const bool have_runs = c->runs_lpr != 0 && c->runs_lo == lo && c->runs_n == nloc; /* (every rank decides alike: the shape of the JOB) */
     int logT = 0;
     while ((1ull << logT) < c->T) ++logT;
-    /* 1. queries: count, then fill; reads without a usable run list the long way */
+    /* 1. queries. With the minimizer runs of the index pass: one per run (count, then fill), reads with an unusable run list the long
+     *    way; without them (windows other than 17 m-mers, reads beyond 256 bases) every read the long way */
     if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
     u32 *d_nslow = c->d_n_slow;
     auto make = [&](ulonglong2 *out, bool collect_slow) {
@@ -3215,61 +3261,59 @@ static int dist_partitioned_probe(disco_ctx *c)
         if (c->runs_lpr == 16) hipLaunchKernelGGL(pq_make_kernel<16>, dim3(grid), dim3(256), 0, c->stream, v, (const u32 *)c->d_runs, lo, c->q_hi, r, out, c->d_list_n, slow, cap, d_nslow);
         else hipLaunchKernelGGL(pq_make_kernel<32>, dim3(grid), dim3(256), 0, c->stream, v, (const u32 *)c->d_runs, lo, c->q_hi, r, out, c->d_list_n, slow, cap, d_nslow);
     };
-    u64 nq_fast = 0;
-    u32 n_slow = 0;
-    for (int attempt = 0;; attempt++) { /* the list of reads without a usable run list: sized by a first try */
-        const u32 want = attempt ? n_slow / 2 + 1024 : (u32)std::min<u64>(nloc, nloc / 128 + 1024);
-        if (want > c->slow_cap) {
-            dev_free(c, &c->d_slow_list, c->slow_cap);
-            c->slow_cap = 0;
-            CHK(dev_alloc(c, &c->d_slow_list, want));
-            c->slow_cap = want;
+    u64 nq_fast = 0, n_slow = 0;
+    const u32 *slow = nullptr; /* null: every read of the range */
+    if (have_runs) {
+        u32 ns = 0;
+        for (int attempt = 0;; attempt++) { /* the list of reads without a usable run list: sized by a first try */
+            const u32 want = attempt ? ns / 2 + 1024 : (u32)std::min<u64>(nloc, nloc / 128 + 1024);
+            if (want > c->slow_cap) {
+                dev_free(c, &c->d_slow_list, c->slow_cap);
+                c->slow_cap = 0;
+                CHK(dev_alloc(c, &c->d_slow_list, want));
+                c->slow_cap = want;
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(d_nslow, 0, sizeof(u32), c->stream));
+            if (nloc) make(nullptr, true);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(&nq_fast, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&ns, d_nslow, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (ns <= c->slow_cap * 2 || attempt) break;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(d_nslow, 0, sizeof(u32), c->stream));
-        if (nloc) make(nullptr, true);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&nq_fast, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&n_slow, d_nslow, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (n_slow <= c->slow_cap * 2 || attempt) break;
-    }
-    if (n_slow > c->slow_cap * 2) return fail(c, DISCO_E_CAPACITY, "dist_partitioned_probe: slow list could not be sized");
-    const u32 *slow = (const u32 *)c->d_slow_list;
-    /* slow reads: up to one query per window each */
-    const u32 cap_per_read = c->max_len > (u32)c->k ? c->max_len - (u32)c->k : 1u;
-    ulonglong2 *slow_q = nullptr;
+        if (ns > c->slow_cap * 2) return fail(c, DISCO_E_CAPACITY, "dist_partitioned_probe: slow list could not be sized");
+        n_slow = ns;
+        slow = (const u32 *)c->d_slow_list;
+    } else
+        n_slow = nloc;
+    /* the long way: queries per read, scan, fill behind the fast ones */
     u32 *slow_cnt = nullptr;
     u64 *slow_start = nullptr;
     u64 nq_slow = 0;
     int rc = DISCO_OK;
-    auto slow_part = [&]() -> int {
+    auto slow_count = [&]() -> int {
         if (!n_slow) return DISCO_OK;
-        CHK(dev_alloc(c, &slow_q, (u64)n_slow * cap_per_read));
         CHK(dev_alloc(c, &slow_cnt, n_slow));
-        CHK(dev_alloc(c, &slow_start, (u64)n_slow + 1));
-        hipLaunchKernelGGL(pq_slow_kernel, dim3((n_slow + 63) / 64), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, cap_per_read, slow_q, slow_cnt);
+        CHK(dev_alloc(c, &slow_start, n_slow + 1));
+        hipLaunchKernelGGL(pq_slow_kernel, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)nullptr, (ulonglong2 *)nullptr);
         CHK((scan_exclusive<u32, u64>(c, slow_cnt, n_slow, slow_start, false, &nq_slow)));
         return DISCO_OK;
     };
-    rc = slow_part();
+    rc = slow_count();
     const u64 nqs = nq_fast + nq_slow;
     if (rc == DISCO_OK) rc = ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nqs, 1)); /* flat list | partitioned by owner */
     if (rc == DISCO_OK) {
         HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-        if (nloc) make(c->d_x16a, false);
-        if (n_slow) {
-            hipLaunchKernelGGL(add_u64_kernel, dim3(flat_grid(c, n_slow)), dim3(256), 0, c->stream, slow_start, (u64)n_slow, nq_fast);
-            hipLaunchKernelGGL(pq_slow_append_kernel, dim3((unsigned)(((u64)n_slow * cap_per_read + 255) / 256)), dim3(256), 0, c->stream, slow_q, slow_cnt, slow_start, n_slow, cap_per_read,
-                               c->d_x16a);
-        }
+        if (have_runs && nloc) make(c->d_x16a, false);
+        if (n_slow)
+            hipLaunchKernelGGL(pq_slow_kernel, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)slow_start, c->d_x16a + nq_fast);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DISCO_E_HIP, "dist_partitioned_probe: query kernels failed");
     }
-    dev_free(c, &slow_q, (u64)n_slow * cap_per_read);
     dev_free(c, &slow_cnt, n_slow);
-    dev_free(c, &slow_start, (u64)n_slow + 1);
+    dev_free(c, &slow_start, n_slow + 1);
     CHK(rc);
-    c->slow_rows = n_slow;
+    c->slow_rows = have_runs ? n_slow : 0;
     /* 2. queries -> owners of their buckets */
     std::vector<u64> scnt, rcnt;
     RouteByBucket fb{logT, G};

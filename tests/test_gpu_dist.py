@@ -277,3 +277,14 @@ def test_config2_reads_through_4_ranks_with_partitioned_index_hash_like_the_refe
     assert pyoracle.digest_array(cc) == c["contained_sha256"]
     sent = {k: sum(i["bytes_sent"][k] for i in infos) for k in infos[0]["bytes_sent"]}
     assert sent["queries"] > 0 and sent["hits"] > 0 and sent["index_shards"] == 0
+
+
+@pytest.mark.parametrize("name,G", [("k30_6k", 3), ("long_2k", 2), ("k64_3k", 4)])
+def test_ranks_partitioned_index_on_shapes_without_runs(name, G):
+    """windows other than 17 m-mers / reads beyond 256 bases: the index pass leaves no minimizer runs, every read's lookups are made
+    the long way (pq_slow_kernel) — same result"""
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G, partitioned_index=True)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden(name, ce, cc)
+    assert sum(i["bytes_sent"]["queries"] for i in infos) > 0 and sum(i["bytes_sent"]["index_shards"] for i in infos) == 0
