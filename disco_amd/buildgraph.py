@@ -75,6 +75,7 @@ ABI = [
     ("disco_export_adjacency", C.c_int, [_P, _P, _P]),
     ("disco_import_adjacency", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("disco_fetch_contained", C.c_int64, [_P, _P, C.c_uint64]),
+    ("disco_fetch_contained_grouped", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_fetch_edges", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_fetch_edge_substitutions", C.c_int64, [_P, _P, C.c_uint64]),
     ("disco_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
@@ -309,6 +310,18 @@ class BuildGraph:
         out = np.zeros(n, dtype=CONTAINED_DTYPE)
         if n:
             self._chk(self.L.disco_fetch_contained(self._h, out.ctypes.data, n))
+        return out
+
+    def fetch_contained_grouped(self):
+        """the contained rows in the order of the contained-read files (containing read, j, contained read), sorted on the device
+        during the pass; None when that did not happen (DISCO_E_UNSUPPORTED: sort fetch_contained()'s rows instead)"""
+        n = self._chk(self.L.disco_fetch_contained_grouped(self._h, None, 0))
+        out = np.zeros(n, dtype=CONTAINED_DTYPE)
+        if n:
+            rc = self.L.disco_fetch_contained_grouped(self._h, out.ctypes.data, n)
+            if rc == -6:
+                return None
+            self._chk(rc)
         return out
 
     def fetch_edges(self) -> np.ndarray:

@@ -154,6 +154,11 @@ struct disco_ctx {
     void *h_crows = nullptr; /* pinned: keys u64[crows_hcap] then ids u32[crows_hcap] */
     u64 crows_hcap = 0, crows_n = 0;
     bool crows_pending = false; /* the rows of the CURRENT flags are on their way / in h_crows */
+    u32 *d_cgrp_cur = nullptr, *d_cgrp_id = nullptr; /* the same rows grouped by containing read (disco_fetch_contained_grouped) */
+    u64 *d_cgrp_key = nullptr, *d_cgrp_big = nullptr;
+    u64 cgrp_cur_cap = 0, cgrp_cap = 0;
+    u64 h_cgrp_big = 0;
+    bool cgrp_pending = false;
     /* disco_fetch_edges: the compacted edges before they travel (kept across passes) */
     u32 *d_fetch_src = nullptr;
     u64 *d_fetch_ent = nullptr;
@@ -676,6 +681,7 @@ static int index_begin(disco_ctx *c)
 static int start_contained_rows(disco_ctx *c)
 {
     c->crows_pending = false;
+    c->cgrp_pending = false;
     const u64 nc = c->n_contained;
     const u64 max_rows = getenv("DISCO_EAGER_ROWS_MAX") ? (u64)atoll(getenv("DISCO_EAGER_ROWS_MAX")) : (16ull << 20);
     if (c->comm || nc == 0 || nc > max_rows || c->n >= (1ull << 31)) return DISCO_OK;
@@ -703,7 +709,7 @@ static int start_contained_rows(disco_ctx *c)
         c->h_crows = nullptr;
         c->crows_hcap = 0;
         const u64 want = nc + nc / 4 + 1024;
-        if (hipHostMalloc(&c->h_crows, want * 12) != hipSuccess) { /* no pinned memory to be had: the on-demand path */
+        if (hipHostMalloc(&c->h_crows, want * 24) != hipSuccess) { /* (both orders) no pinned memory to be had: the on-demand path */
             c->h_crows = nullptr;
             (void)hipGetLastError();
             return DISCO_OK;
@@ -721,6 +727,35 @@ static int start_contained_rows(disco_ctx *c)
     HIPCHK(c, hipEventRecord(c->ev_crows, c->aux_stream));
     c->crows_n = nc;
     c->crows_pending = true;
+    /* ... and once more in the order of the contained-read files (crow_* kernels), behind the first copy on the same stream */
+    c->cgrp_pending = false;
+    if (!getenv("DISCO_NO_GROUPED_ROWS")) {
+        CHK(ensure_cap(c, &c->d_cgrp_cur, &c->cgrp_cur_cap, c->n + 1));
+        if (nc > c->cgrp_cap) {
+            dev_free(c, &c->d_cgrp_id, c->cgrp_cap);
+            dev_free(c, &c->d_cgrp_key, c->cgrp_cap);
+            c->cgrp_cap = 0;
+            const u64 want = nc + nc / 4 + 1024;
+            CHK(dev_alloc(c, &c->d_cgrp_id, want));
+            CHK(dev_alloc(c, &c->d_cgrp_key, want));
+            c->cgrp_cap = want;
+        }
+        if (!c->d_cgrp_big) CHK(dev_alloc(c, &c->d_cgrp_big, 1));
+        HIPCHK(c, hipMemsetAsync(c->d_cpos, 0, (c->n + 1) * sizeof(u32), c->aux_stream)); /* (the flag scan has served the gather) */
+        HIPCHK(c, hipMemsetAsync(c->d_cgrp_big, 0, sizeof(u64), c->aux_stream));
+        hipLaunchKernelGGL(crow_count_kernel, dim3(flat_grid(c, nc)), dim3(256), 0, c->aux_stream, (const u64 *)c->d_crow_key, nc, c->d_cpos);
+        CHK((scan_exclusive_on<u32, u32>(c, c->aux_stream, &c->d_tile2, &c->tile2_cap, c->d_total2, c->d_cpos, c->n + 1, c->d_cgrp_cur, false, nullptr)));
+        hipLaunchKernelGGL(crow_place_kernel, dim3(flat_grid(c, nc)), dim3(256), 0, c->aux_stream, (const u32 *)c->d_crow_id, (const u64 *)c->d_crow_key, nc, c->d_cgrp_cur, c->d_cgrp_id,
+                           c->d_cgrp_key);
+        hipLaunchKernelGGL(crow_sort_groups_kernel, dim3(flat_grid(c, nc)), dim3(256), 0, c->aux_stream, c->d_cgrp_id, c->d_cgrp_key, nc, c->d_cgrp_big);
+        HIPCHK(c, hipGetLastError());
+        u64 *gkey = (u64 *)((char *)c->h_crows + c->crows_hcap * 12);
+        u32 *gid = (u32 *)(gkey + c->crows_hcap);
+        HIPCHK(c, hipMemcpyAsync(gkey, c->d_cgrp_key, nc * 8, hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipMemcpyAsync(gid, c->d_cgrp_id, nc * 4, hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipMemcpyAsync(&c->h_cgrp_big, c->d_cgrp_big, sizeof(u64), hipMemcpyDeviceToHost, c->aux_stream));
+        c->cgrp_pending = true;
+    }
     return DISCO_OK;
 }
 
@@ -729,6 +764,7 @@ static int settle_contained_rows(disco_ctx *c)
 {
     if (c->crows_pending) HIPCHK(c, hipStreamSynchronize(c->aux_stream));
     c->crows_pending = false;
+    c->cgrp_pending = false;
     return DISCO_OK;
 }
 
@@ -824,6 +860,10 @@ void disco_destroy(disco_ctx *c)
     dev_free(c, &c->d_cpos, c->cpos_cap);
     dev_free(c, &c->d_crow_id, c->crow_cap);
     dev_free(c, &c->d_crow_key, c->crow_cap);
+    dev_free(c, &c->d_cgrp_cur, c->cgrp_cur_cap);
+    dev_free(c, &c->d_cgrp_id, c->cgrp_cap);
+    dev_free(c, &c->d_cgrp_key, c->cgrp_cap);
+    dev_free(c, &c->d_cgrp_big, 1);
     dev_free(c, &c->d_fetch_src, c->fetch_cap);
     dev_free(c, &c->d_fetch_ent, c->fetch_cap);
     if (c->h_crows) (void)hipHostFree(c->h_crows);
@@ -900,6 +940,7 @@ static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride, bool *keep = n
     c->index_counted = false;
     if (c->crows_pending && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     c->crows_pending = false;
+    c->cgrp_pending = false;
     if (keep) {
         *keep = c->reads_owned && !c->dist_reads && !c->comm && c->d_reads && c->d_len && n > 0 && c->n == n && c->n_alloc == n && c->S == (int)stride &&
                 !getenv("DISCO_NO_BUFFER_REUSE");
@@ -1372,9 +1413,12 @@ extern "C" int disco_ingest_fetch(disco_ctx *c, uint16_t *len, uint64_t *file_in
     HIPCHK(c, hipSetDevice(c->device));
     const u64 n = c->n;
     std::unique_ptr<u32[]> rec(new u32[n]);
-    HIPCHK(c, hipMemcpyAsync(len, c->d_len, n * 2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(rec.get(), c->d_rec_of_read, n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* on the copy stream: the call may run on a host thread of its own while the context's stream is busy with the pass (buildG does
+     * that: the per-read arrays are only needed by the writers) */
+    hipStream_t st = c->copy_stream ? c->copy_stream : c->stream;
+    HIPCHK(c, hipMemcpyAsync(len, c->d_len, n * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(rec.get(), c->d_rec_of_read, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     const u32 *r = rec.get();
     for (size_t fi = 0; fi + 1 < c->ingest_id_base.size(); fi++) {
         const u64 lo = c->ingest_id_base[fi], hi = c->ingest_id_base[fi + 1], rb = c->ingest_rec_base[fi];
@@ -2406,6 +2450,44 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     dev_free(c, &keys, nc);
     CHK(grc);
     decode([&hid](u64 i) { return hid[i]; }, hkey.data());
+    return (int64_t)nc;
+}
+
+int64_t disco_fetch_contained_grouped(disco_ctx *c, disco_contained_row *out, uint64_t cap)
+{
+    DISCO_TRACE("disco_fetch_contained_grouped");
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 4) return fail(c, DISCO_E_STATE, "disco_fetch_contained_grouped: run disco_mark_contained first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 nc = c->n_contained;
+    if (!out) return (int64_t)nc;
+    if (cap < nc) return fail(c, DISCO_E_ARG, "disco_fetch_contained_grouped: need room for %llu rows", (unsigned long long)nc);
+    if (nc == 0) return 0;
+    if (!(c->cgrp_pending && c->crows_pending && c->crows_n == nc))
+        return fail(c, DISCO_E_UNSUPPORTED, "disco_fetch_contained_grouped: the rows were not grouped on the device (sort what disco_fetch_contained returns)");
+    HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+    if (c->h_cgrp_big) return fail(c, DISCO_E_UNSUPPORTED, "disco_fetch_contained_grouped: a containing read has more than %d rows (sort what disco_fetch_contained returns)", CROW_GROUP_MAX);
+    CHK(ensure_host_len(c));
+    const u64 *hkey = (const u64 *)((const char *)c->h_crows + c->crows_hcap * 12);
+    const u32 *hid = (const u32 *)(hkey + c->crows_hcap);
+    const u16 *hlen = c->h_len.data();
+    const u32 kk = (u32)c->k;
+    parallel_for(nc, [&, hlen, kk, hkey, hid](u64 b, u64 e_) {
+        for (u64 i = b; i < e_; i++) {
+            const u64 key = hkey[i];
+            disco_contained_row &r = out[i];
+            r.contained = hid[i];
+            r.super = CKEY_SUPER(key);
+            r.j = CKEY_J(key);
+            r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
+            r.len2 = hlen[r.contained];
+            r.len1 = hlen[r.super];
+            u32 orient, off;
+            disco_map_type(r.type, r.len1, kk, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
+            r.orient = orient;
+            r.start = off;
+        }
+    });
     return (int64_t)nc;
 }
 

@@ -1522,6 +1522,55 @@ __global__ void contain_rows32_kernel(const u64 *__restrict__ best, const u8 *__
         }
 }
 
+/* ---- the contained rows in the order the contained-read files are written in: grouped by containing read (rows of one containing
+ * read adjacent: SG/DataSet.cpp:316-335), inside a group ascending (j, contained id) — a counting sort on the containing read
+ * (count, scan, place) and an insertion sort inside the groups, which are a handful of rows (groups beyond CROW_GROUP_MAX are left
+ * unsorted and counted: the caller then sorts on the host) ---------------------------------------------------------------------- */
+#define CROW_GROUP_MAX 256
+__global__ void crow_count_kernel(const u64 *__restrict__ key, u64 nc, u32 *__restrict__ cnt)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nc; i += (u64)gridDim.x * blockDim.x) atomicAdd(&cnt[CKEY_SUPER(key[i])], 1u);
+}
+/* cursor = the exclusive scan of cnt (consumed: afterwards cursor[s] = end of group s) */
+__global__ void crow_place_kernel(const u32 *__restrict__ id, const u64 *__restrict__ key, u64 nc, u32 *__restrict__ cursor, u32 *__restrict__ out_id, u64 *__restrict__ out_key)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nc; i += (u64)gridDim.x * blockDim.x) {
+        const u32 at = atomicAdd(&cursor[CKEY_SUPER(key[i])], 1u);
+        out_id[at] = id[i];
+        out_key[at] = key[i];
+    }
+}
+/* one thread per row that starts a group */
+__global__ void crow_sort_groups_kernel(u32 *__restrict__ id, u64 *__restrict__ key, u64 nc, u64 *__restrict__ n_big_groups)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < nc; i += (u64)gridDim.x * blockDim.x) {
+        const u64 s = CKEY_SUPER(key[i]);
+        if (i > 0 && CKEY_SUPER(key[i - 1]) == s) continue;
+        u64 e = i + 1;
+        while (e < nc && CKEY_SUPER(key[e]) == s) e++;
+        if (e - i < 2) continue;
+        if (e - i > CROW_GROUP_MAX) {
+            atomicAdd(n_big_groups, 1ull);
+            continue;
+        }
+        for (u64 a = i + 1; a < e; a++) { /* (j, contained): the key's (super, j) bits, then the id */
+            const u64 k = key[a], kj = k >> 2;
+            const u32 d = id[a];
+            u64 b = a;
+            while (b > i && ((key[b - 1] >> 2) > kj || ((key[b - 1] >> 2) == kj && id[b - 1] > d))) {
+                key[b] = key[b - 1];
+                id[b] = id[b - 1];
+                b--;
+            }
+            key[b] = k;
+            id[b] = d;
+        }
+    }
+}
+
 /* ================================================================================================================
  * edge selection — insertAllEdgesOfRead (BG/OverlapGraph.cpp:631-678) for every non-contained query read, from the
  * verified hits of the probe: drop hits to contained reads (:657; getListOfReads skips them :533), order the rest as

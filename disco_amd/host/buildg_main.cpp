@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -246,6 +247,19 @@ int main(int argc, char **argv)
      * literally and prints its messages. DISCO_HOST_INPUT=1: the host stage always. */
     disco_ctx *ctx1 = nullptr; /* the single-GPU context, created here when the device stage is tried */
     bool ingested = false;
+    struct Joiner { /* (an early return must not leave a joinable thread behind) */
+        std::thread t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } ingest_fetch_holder;
+    std::thread &ingest_fetch = ingest_fetch_holder.t;
+    std::atomic<int> ingest_fetch_rc{0};
+    auto join_ingest_fetch = [&]() -> bool {
+        if (ingest_fetch.joinable()) ingest_fetch.join();
+        return ingest_fetch_rc.load() >= 0;
+    };
     if (gpus == 1 && !getenv("DISCO_HOST_INPUT")) {
         const disco_params prm0{min_overlap, 4, getenv("DISCO_EXACT_COUNTERS") ? 0u : DISCO_FLAG_TWO_PASS_VERIFY, max_subs};
         if (disco_create(gpu, &prm0, &ctx1) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
@@ -262,9 +276,13 @@ int main(int argc, char **argv)
             rs.too_long = ii.too_long;
             rs.shortest = ii.shortest;
             rs.longest = ii.longest;
-            rs.len.resize(ii.n_reads);
-            rs.file_index.resize(ii.n_reads);
-            if (disco_ingest_fetch(ctx1, rs.len.data(), rs.file_index.data()) < 0) return die(disco_last_error(ctx1));
+            /* lengths and file indices of the reads come to the host on a thread of their own while the graph is built: only the
+             * writers need them */
+            ingest_fetch = std::thread([&rs, &ingest_fetch_rc, ctx1, n = ii.n_reads]() {
+                rs.len.resize(n);
+                rs.file_index.resize(n);
+                ingest_fetch_rc = disco_ingest_fetch(ctx1, rs.len.data(), rs.file_index.data());
+            });
             for (size_t i = 0; i < paths.size(); i++) {
                 disco::FileRange fr;
                 fr.name = paths[i];
@@ -331,6 +349,7 @@ int main(int argc, char **argv)
     std::unique_ptr<uint16_t[]> edge_subs; /* substitutions per edge (third number of an edge line); stays null with exact overlaps */
     uint64_t n_cont = 0, e_pre = 0, e_out = 0;
     std::vector<disco_contained_row> rows;
+    bool rows_grouped = false; /* rows already are in the contained-read files' order (disco_fetch_contained_grouped) */
     std::unique_ptr<disco_edge[]> edges;
     std::unique_ptr<uint16_t[]> edge_file;
     const int n_edge_files = mpi_names ? gpus * std::max(threads - 1, 1) : threads;
@@ -369,8 +388,14 @@ int main(int argc, char **argv)
                       << std::endl;
         t0 = Clock::now();
         t1 = Clock::now();
+        if (!join_ingest_fetch()) return die(disco_last_error(ctx));
         rows.resize(n_cont);
-        if (n_cont && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
+        if (n_cont) { /* in the files' order where the device grouped them during the pass; by id (sorted by the writer) otherwise */
+            const int64_t grc = getenv("DISCO_HOST_ROW_SORT") ? (int64_t)DISCO_E_UNSUPPORTED : disco_fetch_contained_grouped(ctx, rows.data(), n_cont);
+            rows_grouped = grc >= 0;
+            if (grc < 0 && grc != DISCO_E_UNSUPPORTED) return die(disco_last_error(ctx));
+            if (!rows_grouped && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
+        }
         lap("fetch contained rows");
         /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
          * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
@@ -541,7 +566,7 @@ int main(int argc, char **argv)
         rows.clear();
         e_out = 0;
     }
-    if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags)) return die(err);
+    if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags, rows_grouped)) return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
     if (edge_text && !no_text) {

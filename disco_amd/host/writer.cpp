@@ -174,7 +174,7 @@ static void sort_contained(std::vector<disco_contained_row> &rows, uint64_t n)
 }
 
 bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err,
-                     const FileTags *tags)
+                     const FileTags *tags, bool grouped)
 {
     const bool verbose = getenv("DISCO_VERBOSE") != nullptr;
     double t_last = omp_get_wtime();
@@ -184,7 +184,7 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
     };
     /* rows of one containing read must be contiguous (SG/DataSet.cpp:316-335); the reference emits them per super read in
      * (j, bucket order) = ascending (j, contained id, record kind) */
-    sort_contained(rows, rs.size());
+    if (!grouped) sort_contained(rows, rs.size());
     lap("sort");
     const uint64_t n = rs.size();
     /* rows are sorted by containing read, so every file owns one contiguous run of them: format fixed-size chunks in

@@ -32,8 +32,9 @@ struct FileTags {
 void set_writer_threads(int n);
 bool write_read_id_map(const std::string &prefix, const ReadSet &rs, std::string &err);
 /* every file gets written, empty ones included (the consumer aborts on a missing file) */
+/* grouped: the rows already are in the files' order (containing read, j, contained read): disco_fetch_contained_grouped */
 bool write_contained(const std::string &prefix, int n_files, std::vector<disco_contained_row> &rows, const ReadSet &rs, std::string &err,
-                     const FileTags *tags = nullptr);
+                     const FileTags *tags = nullptr, bool grouped = false);
 /* edge_file: file of every edge when both of its ends have ALL their edges there (disco_fetch_edge_files: connected components
  * dealt out to the files) — every line then carries flag 2; nullptr: files own contiguous id ranges, an edge between two
  * files is written to both with flags 0 / 1 */

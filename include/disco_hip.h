@@ -270,6 +270,12 @@ int disco_ingest_fetch(disco_ctx *ctx, uint16_t *len, uint64_t *file_index);
 /* ---- results --------------------------------------------------------------------------------------------------- */
 /* rows in ascending contained-read id; returns the number of rows written, or a negative error */
 int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
+/* the same rows in the order the contained-read files are written in — grouped by containing read (SG/DataSet.cpp:316-335 needs the
+ * rows of one containing read adjacent), ascending (containing read, j, contained read) = the reference's emission order per
+ * containing read (BG/OverlapGraph.cpp:438-447). Sorted on the device while the pass goes on; returns DISCO_E_UNSUPPORTED when that
+ * did not happen (multi-GPU contexts, more rows than DISCO_EAGER_ROWS_MAX, a containing read with more than 256 rows): the caller
+ * then sorts what disco_fetch_contained returns. */
+int64_t disco_fetch_contained_grouped(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
 /* edges of the local query range (src < dst), in no particular order; returns count or negative error */
 int64_t disco_fetch_edges(disco_ctx *ctx, disco_edge *out, uint64_t cap);
 /* substitutions of every edge's overlap, in the order of disco_fetch_edges — the third number of an edge line, "no substitutions"

@@ -340,3 +340,28 @@ def test_cap_binds_in_short_rows():
     ce, cc = canon_hip(he, hr)
     oce, occ = canon_hip(oe, orows)
     assert np.array_equal(ce, oce) and np.array_equal(cc, occ) and hc["cap_bind_sites"] == oc["cap_bind_sites"]
+
+
+def test_contained_rows_grouped_on_the_device_are_the_sorted_rows():
+    """disco_fetch_contained_grouped: the rows in the order of the contained-read files — (containing read, j, contained read) — sorted on the
+    device during the pass; equal to the host sort of disco_fetch_contained's rows. A containing read with more than 256 rows makes it
+    decline (the caller sorts)."""
+    spec = readgen.GenSpec.coverage(seed=3, n_reads=60000, read_len=60, cov=40.0, len_max=250)  # mixed lengths: most reads contained
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        rows = g.fetch_contained()
+        grouped = g.fetch_contained_grouped()
+    assert grouped is not None and len(grouped) == len(rows) > 20000
+    order = np.lexsort((rows["contained"], rows["j"], rows["super"]))
+    assert np.array_equal(grouped, rows[order])
+    assert len(np.unique(rows["super"])) < len(rows)  # groups of several rows exist
+    # one long read that contains hundreds of short ones
+    rng = np.random.default_rng(1)
+    long_read = "".join(rng.choice(list("ACGT"), 3000))
+    reads = [long_read] + [long_read[p:p + 80] for p in rng.integers(0, 2900, 400)]
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.upload_ascii(reads)
+        g.run_graph()
+        rows = g.fetch_contained()
+        assert g.fetch_contained_grouped() is None and len(rows) >= 300
