@@ -673,16 +673,19 @@ static int index_begin(disco_ctx *c)
     return DISCO_OK;
 }
 
-/* The contained rows start for the host as soon as the flags are fixed, on a side stream, while edge selection and the reduction run:
- * (id, key) of the contained reads in ascending id (scan of the flags, gather: 12 bytes per row) into pinned staging memory kept by the
- * context; disco_fetch_contained then only waits for the event and decodes. (Taken after the pass, the same work — three allocations of up
- * to n + 1 words, the scan, two pageable copies — was 32 ms of the host-to-host wall at 50 M reads.) Single-GPU passes with up to
- * DISCO_EAGER_ROWS_MAX (16 M) contained rows; otherwise disco_fetch_contained gathers on demand as before. */
-static int start_contained_rows(disco_ctx *c)
+/* The contained rows for the host: (id, key) of the contained reads in ascending id (scan of the flags, gather: 12 bytes per row) into
+ * buffers and pinned staging memory KEPT by the context — with three allocations of up to n + 1 words, the scan and two pageable
+ * copies per call this was 32 ms of the host-to-host wall at 50 M reads; now 2 ms of device work and copy + the decode. On request the
+ * same rows once more in the order of the contained-read files (a counting sort by containing read on the device: the host sort took
+ * 0.23 s). Started by the fetch calls, on a side stream (measured: started from disco_mark_contained, to overlap the rest of the pass, the
+ * extra kernels cost the pass 0.8 ms, and 3.5 ms with the grouping — more than they hid). Single-GPU passes with up to
+ * DISCO_EAGER_ROWS_MAX (16 M) contained rows; otherwise disco_fetch_contained gathers on demand the old way. */
+static int start_contained_rows(disco_ctx *c, bool grouped)
 {
-    c->crows_pending = false;
-    c->cgrp_pending = false;
     const u64 nc = c->n_contained;
+    if (c->crows_pending && c->crows_n == nc && (!grouped || c->cgrp_pending)) return DISCO_OK; /* already on their way */
+    const bool have_rows = c->crows_pending && c->crows_n == nc;
+    if (!have_rows) c->crows_pending = c->cgrp_pending = false;
     const u64 max_rows = getenv("DISCO_EAGER_ROWS_MAX") ? (u64)atoll(getenv("DISCO_EAGER_ROWS_MAX")) : (16ull << 20);
     if (c->comm || nc == 0 || nc > max_rows || c->n >= (1ull << 31)) return DISCO_OK;
     if (!c->aux_stream) {
@@ -702,10 +705,6 @@ static int start_contained_rows(disco_ctx *c)
     }
     if (nc > c->crows_hcap) {
         if (c->h_crows) (void)hipHostFree(c->h_crows);
-    if (c->h_ring) (void)hipHostFree(c->h_ring);
-    for (int i = 0; i < 2; i++)
-        if (c->ev_ring[i]) (void)hipEventDestroy(c->ev_ring[i]);
-    dev_free(c, &c->d_rec_of_read, c->rec_of_read_cap);
         c->h_crows = nullptr;
         c->crows_hcap = 0;
         const u64 want = nc + nc / 4 + 1024;
@@ -716,7 +715,8 @@ static int start_contained_rows(disco_ctx *c)
         }
         c->crows_hcap = want;
     }
-    /* (the flags are complete: disco_mark_contained has just synchronised the context's stream) */
+    if (!have_rows) {
+    /* (the flags are complete: disco_mark_contained synchronised the context's stream) */
     CHK((scan_exclusive_on<u8, u32>(c, c->aux_stream, &c->d_tile2, &c->tile2_cap, c->d_total2, c->d_contained, c->n, c->d_cpos, false, nullptr)));
     hipLaunchKernelGGL(contain_rows32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->aux_stream, c->d_best, c->d_contained, c->d_cpos, c->n, c->d_crow_id, c->d_crow_key);
     HIPCHK(c, hipGetLastError());
@@ -727,9 +727,9 @@ static int start_contained_rows(disco_ctx *c)
     HIPCHK(c, hipEventRecord(c->ev_crows, c->aux_stream));
     c->crows_n = nc;
     c->crows_pending = true;
-    /* ... and once more in the order of the contained-read files (crow_* kernels), behind the first copy on the same stream */
-    c->cgrp_pending = false;
-    if (!getenv("DISCO_NO_GROUPED_ROWS")) {
+    }
+    /* ... and, on request, once more in the order of the contained-read files (crow_* kernels), behind the first copy on the same stream */
+    if (grouped && !c->cgrp_pending) {
         CHK(ensure_cap(c, &c->d_cgrp_cur, &c->cgrp_cur_cap, c->n + 1));
         if (nc > c->cgrp_cap) {
             dev_free(c, &c->d_cgrp_id, c->cgrp_cap);
@@ -867,6 +867,10 @@ void disco_destroy(disco_ctx *c)
     dev_free(c, &c->d_fetch_src, c->fetch_cap);
     dev_free(c, &c->d_fetch_ent, c->fetch_cap);
     if (c->h_crows) (void)hipHostFree(c->h_crows);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    for (int i = 0; i < 2; i++)
+        if (c->ev_ring[i]) (void)hipEventDestroy(c->ev_ring[i]);
+    dev_free(c, &c->d_rec_of_read, c->rec_of_read_cap);
     for (int i = 0; i < 3; i++) {
         if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
         if (c->ev_unpacked[i]) (void)hipEventDestroy(c->ev_unpacked[i]);
@@ -1239,11 +1243,13 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
     c->d_adj = nullptr;
     c->adj_total = 0;
     {
-        const u64 want = (total_bytes / 100) * 64 + (u64)c->n_cu * 32 * PR_CHUNK + (1u << 16); /* entries: 64 per read, a chunk per resident wave */
+        /* entries: 64 per read as the probe will ask, a chunk per resident wave; reads estimated at one per 150 bytes of text (shorter
+         * records: the probe grows the buffer itself). Not more than needed: on a cold device a hipMalloc costs about 30 ms per GB */
+        const u64 want = (total_bytes / 150) * 64 + (u64)c->n_cu * 32 * PR_CHUNK + (1u << 16);
         if (want > c->hits_cap) {
             size_t fr = 0, tot = 0;
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
-            if ((u64)fr + c->hits_cap * 8 > want * 8 + (total_bytes / 100) * 200 + (4ull << 30)) { /* room for it next to the table and the index */
+            if ((u64)fr + c->hits_cap * 8 > want * 8 + (total_bytes / 150) * 200 + (4ull << 30)) { /* room for it next to the table and the index */
                 dev_free(c, &c->d_hits, c->hits_cap);
                 c->hits_cap = 0;
                 if (dev_alloc(c, &c->d_hits, want) == DISCO_OK) c->hits_cap = want;
@@ -1789,7 +1795,7 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
     c->n_contained = c->h_ctr[CTR_N_CONTAINED];
     if (n_contained) *n_contained = c->n_contained;
     c->phase = 4;
-    CHK(start_contained_rows(c));
+    c->crows_pending = c->cgrp_pending = false; /* rows of other flags */
     return DISCO_OK;
 }
 
@@ -2424,7 +2430,8 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
             }
         });
     };
-    if (c->crows_pending && c->crows_n == nc) { /* they left during the pass (start_contained_rows) */
+    CHK(start_contained_rows(c, false));
+    if (c->crows_pending && c->crows_n == nc) {
         HIPCHK(c, hipEventSynchronize(c->ev_crows));
         const u64 *hkey = (const u64 *)c->h_crows;
         const u32 *hid = (const u32 *)(hkey + c->crows_hcap);
@@ -2463,6 +2470,8 @@ int64_t disco_fetch_contained_grouped(disco_ctx *c, disco_contained_row *out, ui
     if (!out) return (int64_t)nc;
     if (cap < nc) return fail(c, DISCO_E_ARG, "disco_fetch_contained_grouped: need room for %llu rows", (unsigned long long)nc);
     if (nc == 0) return 0;
+    if (getenv("DISCO_NO_GROUPED_ROWS")) return fail(c, DISCO_E_UNSUPPORTED, "disco_fetch_contained_grouped: switched off (DISCO_NO_GROUPED_ROWS)");
+    CHK(start_contained_rows(c, true));
     if (!(c->cgrp_pending && c->crows_pending && c->crows_n == nc))
         return fail(c, DISCO_E_UNSUPPORTED, "disco_fetch_contained_grouped: the rows were not grouped on the device (sort what disco_fetch_contained returns)");
     HIPCHK(c, hipStreamSynchronize(c->aux_stream));
