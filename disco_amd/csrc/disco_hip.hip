@@ -1099,6 +1099,7 @@ struct IngestFile {
     std::string path;
     int fd = -1;
     char last = 0;
+    bool fastq = false;
     u64 n = 0;
     u8 *d_text = nullptr;
     u64 text_cap = 0;
@@ -1233,7 +1234,8 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         char first = 0;
         if (fstat(f.fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 1 || pread(f.fd, &first, 1, 0) != 1 || pread(f.fd, &f.last, 1, st.st_size - 1) != 1)
             return unsupported("empty or unreadable file", f.path);
-        if (first != '>') return unsupported("not FASTA", f.path);
+        if (first != '>' && first != '@') return unsupported("neither FASTA nor FASTQ", f.path);
+        f.fastq = first == '@';
         f.n = (u64)st.st_size;
         f.text_cap = (f.n + FX_TILE + 63) / FX_TILE * FX_TILE + 64; /* whole tiles (16-byte loads) and aligned 8-byte words behind the end */
         total_bytes += f.text_cap;
@@ -1297,16 +1299,26 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             CHK(get(&d_tile_base, tiles + 1));
             CHK(get(&d_tile_cnt, tiles));
             HIPCHK(c, hipMemsetAsync(d_ctr, 0, FX_CTR_COUNT * sizeof(u64), c->stream));
-            hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, d_tile_cnt, (const u64 *)nullptr, (u64 *)nullptr, d_ctr);
-            CHK((scan_exclusive<u32, u64>(c, d_tile_cnt, tiles, d_tile_base, false, &f.n_start)));
+            if (f.fastq) {
+                u64 n_newlines = 0;
+                hipLaunchKernelGGL(fx_lines_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, d_tile_cnt, (const u64 *)nullptr, (u64 *)nullptr);
+                CHK((scan_exclusive<u32, u64>(c, d_tile_cnt, tiles, d_tile_base, false, &n_newlines)));
+                const u64 n_lines = n_newlines + (f.last == '\n' ? 0 : 1); /* a last line without a newline is a line */
+                f.n_start = (n_lines + 3) / 4; /* the reference starts a record whenever bytes are left (BG/Dataset.cpp:255-293) */
+                f.n_rec = f.n_start;
+            } else {
+                hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, d_tile_cnt, (const u64 *)nullptr, (u64 *)nullptr, d_ctr);
+                CHK((scan_exclusive<u32, u64>(c, d_tile_cnt, tiles, d_tile_base, false, &f.n_start)));
+                /* a '>' that is the very last byte starts nothing (the reference's next getline fails) unless it is the only one; it still
+                 * ends the sequence of the record before it (disco_amd/host/fastx.cpp) */
+                f.n_rec = (f.n_start > 1 && f.last == '>') ? f.n_start - 1 : f.n_start;
+            }
             if (f.n_start == 0 || f.n_start >= (1ull << 32)) return DISCO_E_UNSUPPORTED;
-            /* a '>' that is the very last byte starts nothing (the reference's next getline fails) unless it is the only one; it still ends
-             * the sequence of the record before it (disco_amd/host/fastx.cpp) */
-            f.n_rec = (f.n_start > 1 && f.last == '>') ? f.n_start - 1 : f.n_start;
             CHK(get(&f.d_start, f.n_start));
             CHK(get(&f.d_seq, f.n_rec));
             CHK(get(&f.d_glen, f.n_rec));
-            hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start, d_ctr);
+            if (f.fastq) hipLaunchKernelGGL(fx_lines_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start);
+            else hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start, d_ctr);
             FxFilterArgs fa;
             fa.text = f.d_text;
             fa.n = f.n;
@@ -1314,6 +1326,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             fa.n_start = f.n_start;
             fa.n_rec = f.n_rec;
             fa.min_overlap = c->prm.min_overlap;
+            fa.fastq = f.fastq ? 1u : 0u;
             fa.glen = f.d_glen;
             fa.seq_begin = f.d_seq;
             fa.ctr = d_ctr;

@@ -5,10 +5,11 @@
  * Dataset::readDataset / testRead (BG/Dataset.cpp:161-380,403-452) and the packing of HashTable::insertIntoTable
  * (BG/HashTable.cpp:456-477). Host side: disco_hip.hip "input stage on the GPU".
  *
- * Accepted form (decided on the device, per file; anything else makes the caller fall back to the host stage, which follows the
- * reference's getline calls literally): the file starts with '>', every '>' is the first byte of a line, and every record's sequence
- * is ONE line (header line, sequence line, optional final newline). Lower case, N, CR and any other byte are handled as the reference
- * handles them (upper-cased; anything but ACGT rejects the read, BG/Dataset.cpp:411).
+ * Accepted forms (decided on the device, per file; anything else makes the caller fall back to the host stage, which follows the
+ * reference's getline calls literally): FASTA — the file starts with '>', every '>' is the first byte of a line, and every record's
+ * sequence is ONE line (header line, sequence line, optional final newline); FASTQ — the file starts with '@': records of four lines
+ * (found by counting lines, as the reference's four getline calls do). Lower case, N, CR and any other byte are handled as the
+ * reference handles them (upper-cased; anything but ACGT rejects the read, BG/Dataset.cpp:411).
  *
  * All kernels are byte / integer work on text that is read once or twice: HBM-bound streaming (8.1 GB of text at 50 M reads).
  */
@@ -102,6 +103,52 @@ __global__ void __launch_bounds__(256) fx_starts_kernel(const u8 *__restrict__ t
     }
 }
 
+/* FASTQ: a record is four lines (header, sequence, '+', qualities: the reference reads them with four getline calls,
+ * BG/Dataset.cpp:255-293 — a quality line may well begin with '@', so only the line COUNT says where a record starts). Pass 1
+ * (count != nullptr): newlines per tile. Pass 2: base[tile] = newlines before the tile; every byte that begins a line (byte 0, or the
+ * byte behind a '\n') whose line index is a multiple of 4 is a record start: its position goes to pos[line / 4]. */
+__global__ void __launch_bounds__(256) fx_lines_kernel(const u8 *__restrict__ text, u64 n, u32 *__restrict__ count, const u64 *__restrict__ base,
+                                                       u64 *__restrict__ pos)
+{
+    __shared__ u32 s_w[4];
+    const u64 tile = blockIdx.x;
+    const u64 p0 = tile * FX_TILE + (u64)threadIdx.x * 16u;
+    u32 nlmask = 0; /* bit i: byte p0 + i is a newline */
+    if (p0 < n) {
+        const uint4 q = *(const uint4 *)(text + p0);
+        const u32 wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (p0 + i < n && ((wds[i >> 2] >> (8 * (i & 3))) & 0xFFu) == '\n') nlmask |= 1u << i;
+    }
+    const u32 mine = (u32)__popc(nlmask);
+    u32 incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = (u32)__shfl_up((int)incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 off = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_w[w];
+    if (count) {
+        if (threadIdx.x == 255) count[tile] = off + mine;
+        return;
+    }
+    if (p0 >= n) return;
+    /* line index of the line that BEGINS at byte p0 + i = newlines before that byte */
+    u64 before = base[tile] + off;
+    const bool starts_line = p0 == 0 || text[p0 - 1] == '\n';
+    if (starts_line && (before & 3ull) == 0) pos[before >> 2] = p0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (nlmask & (1u << i)) {
+            before++;
+            if (p0 + i + 1 < n && (before & 3ull) == 0) pos[before >> 2] = p0 + (u64)i + 1; /* the byte behind this newline begins a line */
+        }
+    }
+}
+
 struct FxFilterArgs {
     const u8 *text;
     u64 n;           /* bytes of the file */
@@ -109,6 +156,7 @@ struct FxFilterArgs {
     u64 n_start;
     u64 n_rec;       /* records (n_start, or one less when the last '>' is the last byte of the file) */
     u32 min_overlap;
+    u32 fastq;       /* the record's sequence is its SECOND line only (four-line records) */
     u16 *glen;       /* out [n_rec]: 0 = rejected, else the read length */
     u64 *seq_begin;  /* out [n_rec]: first byte of the sequence */
     u64 *ctr;
@@ -127,7 +175,11 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
         while (p < e && tx.at(p) != '\n') p++; /* header line */
         const u64 sb = p < e ? p + 1 : e;
         u64 se = e;
-        if (se > sb && tx.at(se - 1) == '\n') se--;
+        if (a.fastq) { /* the sequence line ends at its newline (or with the file) */
+            se = sb;
+            while (se < e && tx.at(se) != '\n') se++;
+        } else if (se > sb && tx.at(se - 1) == '\n')
+            se--;
         a.seq_begin[i] = sb;
         const u64 L = se - sb;
         /* counters packed into words (a dynamically indexed local array would live in scratch memory): A | C << 32, G | T << 32, the six

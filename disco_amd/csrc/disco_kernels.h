@@ -23,8 +23,12 @@
 #define ES_MID 1024       /* edge_select: rows of ES_CAP+1..ES_MID hits get LDS arrays of their own (edge_select_mid_kernel) */
 #define ES_DUPBITS 11     /* edge_select: byte table of the duplicate-destination pre-check                         */
 #define ES_DUPTAB (1 << ES_DUPBITS)
+#ifndef ES_CAP
 #define ES_CAP 256        /* edge_select: hits of one read sorted in LDS (longer rows: global-scratch variant)  */
+#endif
+#ifndef TR_CAP
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
+#endif
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
 #define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift)) /* bucket of a read-level minimizer in the grouping ("processing order") */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */

@@ -245,12 +245,12 @@ int disco_dist_run_graph(disco_ctx *ctx, uint32_t flags);
 int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
 
 /* ---- input stage on the GPU (SURVEY.md section 8 a-1 … a-3, f-2) ------------------------------------------------------------- */
-/* Reads FASTA files itself (parallel pread through pinned staging), finds the records, cleans and filters every read
+/* Reads FASTA / FASTQ files itself (parallel pread through pinned staging), finds the records, cleans and filters every read
  * (Dataset::readDataset / testRead, BG/Dataset.cpp:161-380,403-452) and packs the good ones into the context's read table, all on the
  * device: replaces parse + filter + pack on the host cores AND the upload. Read ids = rank among the good reads in file order over the
  * files in the order given (pass the -pe files, then the -se files). Returns DISCO_E_UNSUPPORTED — nothing changed — when a file is not
- * of the form the device stage accepts (it must start with '>', every '>' must begin a line, every record's sequence must be one
- * line; .gz, FASTQ, empty or unreadable files): the caller then runs its host stage (disco_amd/host/fastx.cpp follows the reference's
+ * of a form the device stage accepts (FASTA: it must start with '>', every '>' must begin a line, every record's sequence must be one
+ * line; FASTQ: it starts with '@', records of four lines; not accepted: .gz, empty or unreadable files): the caller then runs its host stage (disco_amd/host/fastx.cpp follows the reference's
  * getline calls literally and produces its error messages) and disco_upload_reads. */
 typedef struct disco_ingest_file {
     uint64_t first_index, last_index; /* 1-based file indices of the file's first / last record (every record counts, BG/Dataset.cpp:294) */

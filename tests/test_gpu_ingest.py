@@ -122,12 +122,47 @@ def test_ingest_of_several_files_numbers_the_records_through(tmp_path):
     assert [f["first_index"] for f in files] == [1, 701, 1501] and files[2]["last_index"] == len(all_reads)
 
 
+@pytest.mark.parametrize("tail", ["full", "no_final_newline", "header_only", "three_lines"])
+def test_ingest_reads_fastq_by_counting_lines(tmp_path, tail):
+    """FASTQ: records of four lines, found by the line count (the reference's four getline calls, BG/Dataset.cpp:255-293) — quality lines
+    that begin with '@' or '>' must not start a record; a truncated last record still counts as a record"""
+    rng = np.random.default_rng(17)
+    reads = _adversarial(rng, 3000)
+    reads = [r for r in reads if len(r) <= 32767]
+    recs = []
+    for i, s in enumerate(reads):
+        q = "".join(rng.choice(list("@>IF#+"), len(s)))
+        if i % 5 == 0:
+            q = "@" + q[1:]
+        if i % 7 == 0:
+            q = ">" + q[1:]
+        recs.append(f"@r{i} x\n{s}\n+\n{q}\n")
+    text = "".join(recs)
+    if tail == "no_final_newline":
+        text = text[:-1]
+    elif tail == "header_only":
+        text += "@last"
+    elif tail == "three_lines":
+        text += "@last\n" + "ACGT" * 20 + "\n+"
+    fq = tmp_path / "r.fastq"
+    fq.write_text(text)
+    want, wfidx, wtotal = pyoracle.load_good_reads([str(fq)], 33)
+    info, files, got, fidx = _ingest([str(fq)], 33)
+    assert info["total_records"] == wtotal == len(reads) + (tail in ("header_only", "three_lines"))
+    assert got == want and np.array_equal(fidx.astype(np.int64), np.asarray(wfidx, dtype=np.int64)) and len(got) > 500
+    # FASTA and FASTQ files in one job
+    fa = tmp_path / "r.fasta"
+    fa.write_text("".join(f">x{i}\n{s}\n" for i, s in enumerate(reads[:500])))
+    want2, wfidx2, wtotal2 = pyoracle.load_good_reads([str(fa), str(fq)], 33)
+    info2, files2, got2, fidx2 = _ingest([str(fa), str(fq)], 33)
+    assert got2 == want2 and np.array_equal(fidx2.astype(np.int64), np.asarray(wfidx2, dtype=np.int64)) and info2["total_records"] == wtotal2
+
+
 def test_ingest_declines_what_only_the_literal_parser_handles(tmp_path):
     good = ">a\nACGTTGCAAGCTAGCTAGGATCGATCGTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n"
     cases = {
         "multiline.fa": ">a\nACGTTGCAAGCTAGCTAGGATCGATCG\nTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n",
         "gt_inside.fa": ">a>b\nACGT\n" + good.replace(">a", ">c d>e"),
-        "reads.fq": "@a\nACGT\n+\nIIII\n",
         "blank_line.fa": good + "\n" + good,
         "empty.fa": "",
         "no_header.fa": "ACGT\n",

@@ -1,6 +1,7 @@
 """differential fuzzing of the input stage (disco_amd/bin/fastx_dump = the parser / filter / id assignment of the drop-in buildG)
 against the oracle's restatement of Dataset::readDataset + testRead, on randomly malformed FASTA / FASTQ text.
-   python tools/fuzz_fastx.py [ITERATIONS=200] [SEED=1]      (CPU only)"""
+   python tools/fuzz_fastx.py [ITERATIONS=200] [SEED=1] [gpu]      (CPU only; with "gpu": the input stage on the GPU, disco_ingest_fasta, on
+   the same files as well — whatever it ACCEPTS must come out exactly as the oracle's parser has it; declining is always allowed)"""
 import gzip, os, subprocess, sys, tempfile
 sys.path.insert(0, '.')
 import numpy as np
@@ -11,6 +12,25 @@ build.build_host()
 BIN = os.path.join("disco_amd", "bin", "fastx_dump")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+GPU = len(sys.argv) > 3 and sys.argv[3] == "gpu"
+gpu_accepted = 0
+
+
+def ingest(mo, paths):
+    """(reads, file indices, total records) through disco_ingest_fasta, or None when it declines"""
+    from disco_amd import buildgraph
+
+    with buildgraph.BuildGraph(min_overlap=mo) as g:
+        res = g.ingest_fasta(paths, threads=4)
+        if res is None:
+            return None
+        info, _ = res
+        ln, fi = g.ingest_fetch()
+        packed, lens = g.download_reads()
+    reads = []
+    for row, L in zip(packed, lens):
+        reads.append("".join("ACGT"[(int(row[t >> 5]) >> (62 - 2 * (t & 31))) & 3] for t in range(int(L))))
+    return reads, [int(x) for x in fi], int(info["total_records"])
 
 
 def dump(mo, paths):
@@ -92,6 +112,14 @@ with tempfile.TemporaryDirectory() as d:
             oreads, ofidx, ototal = want[0], [int(x) for x in want[1]], want[2]
         got = dump(mo, paths)
         ok = (got is None and oreads is None) or (got is not None and oreads is not None and got[0] == oreads and got[1] == ofidx and got[2] == ototal)
+        if GPU:
+            gi = ingest(mo, paths)
+            if gi is not None:
+                gpu_accepted += 1
+                keep_idx = None if oreads is None else [i for i, r in enumerate(oreads) if len(r) <= 32767]
+                if oreads is None or gi[0] != [oreads[i] for i in keep_idx] or gi[1] != [ofidx[i] for i in keep_idx] or gi[2] != ototal:
+                    ok = False
+                    print("     (device input stage differs: %s)" % (None if gi is None else (len(gi[0]), gi[2]),), flush=True)
         if not ok:
             fails += 1
             keep = os.path.join(tempfile.gettempdir(), "fuzz_fastx_fail_%d" % it)
@@ -102,5 +130,5 @@ with tempfile.TemporaryDirectory() as d:
                   None if got is None else (len(got[0]), got[2]), None if oreads is None else (len(oreads), ototal)), flush=True)
         for p in set(paths + plain):
             os.remove(p)
-print("%d/%d ok" % (iters - fails, iters))
+print("%d/%d ok" % (iters - fails, iters) + (" (device input stage accepted %d of the jobs)" % gpu_accepted if GPU else ""))
 sys.exit(1 if fails else 0)
