@@ -575,7 +575,7 @@ static bool own_order_wanted(const disco_ctx *c, u64 nq, int *bits)
  * index_count_chunk launches the kernel over a sub-range. */
 struct IndexCountPlan {
     u64 lo = 0, hi = 0;
-    int lpr = 0;
+    int lpr = 0, nf = 0;
     u32 *ocnt = nullptr, *oslot = nullptr;
     u32 oshift = 0;
 };
@@ -605,9 +605,15 @@ static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, In
     c->runs_lpr = 0;
     c->runs_n = 0;
     int lpr = 0;
-    if (v.k - v.m + 1 == 17 && c->S == VERIFY_SW && c->max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
+    const int nf = v.k - v.m + 1;
+    /* (index_runs_kernel keeps a block of NF order words in registers: one instantiation per window length — the reference's default
+     * min-overlap 30 (NF 7), 35, BASELINE's 40 (NF 17), 45, 50) */
+    const bool nf_built = nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27;
+    if (nf_built && c->S == VERIFY_SW && c->max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
         const u32 maxwin = c->max_len - (u32)c->k;
-        lpr = maxwin <= 128 ? 16 : (maxwin <= 256 ? 32 : 0);
+        /* a read of W windows has about 2 W / (NF + 1) runs: 32 entries where that stays below 20 (room for the spread), else 64 */
+        const u32 expect = 2u * maxwin / (u32)(nf + 1);
+        lpr = maxwin <= 256 ? (maxwin <= 128 && expect <= 20 ? 16 : (expect <= 44 ? 32 : 0)) : 0;
         const double max_gb = getenv("DISCO_RUNS_MAX_GB") ? atof(getenv("DISCO_RUNS_MAX_GB")) : 16.0;
         if ((double)nloc * lpr * 4.0 > max_gb * 1e9) lpr = 0;
     }
@@ -617,6 +623,7 @@ static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, In
         c->runs_lo = lo;
         c->runs_n = nloc;
         pl->lpr = lpr;
+        pl->nf = nf;
     }
     return DISCO_OK;
 }
@@ -631,8 +638,19 @@ static int index_count_chunk(disco_ctx *c, const DiscoView &v, const IndexCountP
     u32 *oslot = pl.oslot ? pl.oslot + (a - pl.lo) : nullptr;
     if (pl.lpr) {
         u32 *runs = c->d_runs + (a - pl.lo) * (u64)pl.lpr;
-        if (pl.lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);
-        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 17, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);
+#define DISCO_RUNS_LAUNCH(NF_)                                                                                                                              \
+    do {                                                                                                                                                  \
+        if (pl.lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, NF_, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift); \
+        else hipLaunchKernelGGL((index_runs_kernel<COUNT, NF_, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);             \
+    } while (0)
+        switch (pl.nf) {
+        case 7: DISCO_RUNS_LAUNCH(7); break;
+        case 12: DISCO_RUNS_LAUNCH(12); break;
+        case 17: DISCO_RUNS_LAUNCH(17); break;
+        case 22: DISCO_RUNS_LAUNCH(22); break;
+        default: DISCO_RUNS_LAUNCH(27); break;
+        }
+#undef DISCO_RUNS_LAUNCH
     } else
         hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
     HIPCHK(c, hipGetLastError());
@@ -1581,7 +1599,10 @@ int disco_probe(disco_ctx *c)
             else hipLaunchKernelGGL(probe_runs_kernel<32>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
         } else if (mode == 0) DISCO_PROBE_MODE(0);
         else if (mode == 1) DISCO_PROBE_MODE(1);
-        else DISCO_PROBE_LAUNCH(2, true, true); /* slow_list only exists next to probe_runs_kernel: 64-byte rows, windows of 17 */
+        else { /* slow_list only exists next to probe_runs_kernel: 64-byte rows */
+            if (row17) DISCO_PROBE_LAUNCH(2, true, true);
+            else DISCO_PROBE_LAUNCH(2, true, false);
+        }
 #undef DISCO_PROBE_MODE
 #undef DISCO_PROBE_LAUNCH
     };

@@ -14,6 +14,10 @@ def _gen(seed, n, lmin, cov, lmax=None, contigs=1):
 
 @pytest.mark.parametrize("seed,n,lmin,lmax,cov,minovl", [
     (42, 5000, 150, 150, 30.0, 40),     # BASELINE shape (uniform 150 bp, k = 39)
+    (61, 5000, 100, 200, 30.0, 30),     # the reference's default min-overlap (disco.cfg): windows of 7 m-mers, 64 run entries per read
+    (62, 4000, 150, 150, 30.0, 35),     # windows of 12
+    (63, 4000, 120, 250, 40.0, 45),     # windows of 22, two reads per group
+    (64, 4000, 150, 150, 30.0, 50),     # windows of 27
     (7, 4000, 100, 250, 30.0, 40),      # mixed lengths: heavy containment
     (11, 6000, 60, 90, 20.0, 31),       # k = 30 (even: palindromic k-mers possible), k <= 32 single word
     (13, 3000, 80, 120, 25.0, 66),      # k = 65 is rejected; see test_k_limits — here k = 64 via min_overlap 65

@@ -1,7 +1,7 @@
 """differential fuzzing: HIP path (C-ABI) vs the CPU oracle on random generator settings.
    python tools/fuzz_parity.py [ITERATIONS=50] [SEED=1] [inexact | runs]
    with "inexact": every data set gets sequencing errors and a random substitution threshold (the f-4 extension, checked against
-   the oracle's statement of the same rule, substitutions per edge included); with "runs": min-overlap 40 and reads of up to 256 bases
+   the oracle's statement of the same rule, substitutions per edge included); with "runs": min-overlap 30 / 35 / 40 / 45 / 50 and reads of up to 256 bases
    throughout — the shapes that take the minimizer runs of the index pass (index_runs_kernel / probe_runs_kernel), low-complexity and
    repeat genomes (ties of the window minimum: reads handed to probe_kernel's list pass) more often"""
 import os, sys, time, traceback
@@ -24,7 +24,7 @@ for it in range(iters):
     if runs:
         lmin = int(rng.choice([45, 60, 80, 100, 128, 150, 151, 167, 168, 200, 250, 256]))
         lmax = lmin if rng.random() < 0.4 else int(min(256, lmin + rng.integers(1, 2 * lmin)))
-        mo = 40
+        mo = int(rng.choice([40, 40, 30, 35, 45, 50]))  # the window lengths index_runs_kernel is built for
     if mo >= lmin:
         mo = max(31, lmin - 8)
     cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700, 1500]))
