@@ -43,6 +43,13 @@ typedef unsigned char u8;
 #define HIT_SUFFIX(h) ((u32)(((h) >> 16) & 1u))
 #define HIT_REV(h) ((u32)(((h) >> 15) & 1u))
 #define HIT_LEN(h) ((u32)((h)&0x7FFFu))
+/* bit 63 of a VERIFIED hit, inexact overlaps only: the other read cannot find this pair from its side (a substitution inside this
+ * read's end k-mer there). Edge selection carries it into the entry's ADJ_FLAG bit, the twin search reads and clears it. Hits are
+ * consumed in ascending order of the other 63 bits: HIT_SORT_KEY moves the flag below them, HIT_FROM_SORT_KEY undoes it. */
+#define HIT_HIDDEN_BIT (1ull << 63)
+#define HIT_HIDDEN(h) ((u32)((h) >> 63))
+#define HIT_SORT_KEY(h) (((h) << 1) | ((h) >> 63))
+#define HIT_FROM_SORT_KEY(x) (((x) >> 1) | ((x) << 63))
 
 /* ---- adjacency entry: sorts numerically by (offset, dst, orient) = list order of BG/OverlapGraph.cpp:675-676 ---- */
 /* offset(15) | dst(31) | orient(2) | len(dst)(15): the destination's length rides along so that the twin's offset     */

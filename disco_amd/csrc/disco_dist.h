@@ -343,9 +343,8 @@ __global__ void twin_recv_kernel(const ulonglong2 *__restrict__ items, u64 n_ite
         atomicAdd(&ctr[CTR_ASYM], 1ull);
         const u32 idx = atomicAdd(n_extra, 1u);
         if (idx < extra_cap) {
-            extra_node[idx] = w;
+            extra_node[idx] = EXTRA_NODE_MAKE(w, atomicAdd(&extra_cnt[w], 1u));
             extra_key[idx] = twin;
-            atomicAdd(&extra_cnt[w], 1u);
         } else
             atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
     }

@@ -1875,6 +1875,7 @@ static int select_edges(disco_ctx *c)
     c->drop_lo = c->q_lo;
     c->drop_hi = c->q_hi;
     a.dropbits = c->d_dropbits;
+    a.hidden_flags = c->prm.max_substitutions != 0;
     a.contained = c->d_cbits;
     a.hits = c->d_hits;
     a.row_start = c->d_row_start;
@@ -1933,8 +1934,25 @@ static int select_edges(disco_ctx *c)
     return DISCO_OK;
 }
 
+/* the few-extras merge moves only the rows that grow; otherwise every row is rebuilt (merge_extras) */
+static bool merge_is_sparse(const disco_ctx *c) { return c->d_adj == c->d_hits && c->n_extra <= 16384 && !getenv("DISCO_MERGE_REBUILD"); }
+
+static int twin_check_search(disco_ctx *c, u64 lo, u64 hi);
+
 /* twin check over targets [lo,hi); collects extras, does not merge */
 static int twin_check(disco_ctx *c, u64 lo, u64 hi)
+{
+    CHK(twin_check_search(c, lo, hi));
+    /* inexact overlaps: edge selection left "hidden from the other read" flags in the entries (ADJ_HIDDEN_OF); rows that the merge
+     * does not rebuild are cleaned here */
+    if (c->prm.max_substitutions != 0 && c->n && (c->n_extra == 0 || merge_is_sparse(c))) {
+        hipLaunchKernelGGL(clear_adj_flags_kernel, dim3(flat_grid(c, c->n * 16)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->n);
+        HIPCHK(c, hipGetLastError());
+    }
+    return DISCO_OK;
+}
+
+static int twin_check_search(disco_ctx *c, u64 lo, u64 hi)
 {
     DISCO_TRACE("twin_check");
     if (!c->d_extra_cnt) CHK(dev_alloc(c, &c->d_extra_cnt, c->n));
@@ -1961,8 +1979,11 @@ static int twin_check(disco_ctx *c, u64 lo, u64 hi)
     /* Something was dropped — but only the lists of the reads that dropped something can lack a twin (same argument, per read):
      * with their bitmap at hand the search is limited to finds INTO those reads, a few thousand instead of every entry of
      * every list (real data always drop something at their repeats: 95 -> 5 ms at 50 M reads with 0.3 % errors) */
-    const bool by_bitmap = c->prm.max_substitutions == 0 && c->d_dropbits && lo >= c->drop_lo && hi <= c->drop_hi && !getenv("DISCO_FORCE_TWIN_CHECK");
+    const bool by_bitmap = c->d_dropbits && lo >= c->drop_lo && hi <= c->drop_hi && !getenv("DISCO_FORCE_TWIN_CHECK");
     a.dropbits = by_bitmap ? c->d_dropbits : nullptr;
+    /* inexact overlaps: the same, plus every find verify_kernel flagged as hidden from the other read (a substitution inside this
+     * read's end k-mer there) — 0.13 -> 0.04 s of search at 50 M reads with 0.3 % errors */
+    a.hidden_flags = by_bitmap && c->prm.max_substitutions != 0;
     /* (inexact overlaps: one-sided pairs are the rule — a substitution inside an end k-mer hides the pair from the other read —
      * so the proof of symmetry is not attempted) */
     if (!by_bitmap && c->prm.max_substitutions == 0) {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
@@ -2036,7 +2057,7 @@ static int merge_extras(disco_ctx *c)
     if (c->n_extra == 0) return DISCO_OK;
     /* a handful of extras and the rows still where edge selection left them (one GPU): move only the rows that grow into the free
      * tail of the hit buffer — 84 ms of the 272 ms pass at 50 M reads with 0.3 % errors went into rebuilding all of it for 953 extras */
-    if (c->d_adj == c->d_hits && c->n_extra <= 16384 && !getenv("DISCO_MERGE_REBUILD")) {
+    if (merge_is_sparse(c)) {
         HIPCHK(c, hipMemsetAsync(c->d_bump, 0, sizeof(u64), c->stream));
         hipLaunchKernelGGL(merge_need_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, c->d_bump);
         u64 need = 0;
@@ -2054,19 +2075,16 @@ static int merge_extras(disco_ctx *c)
             return DISCO_OK;
         }
     }
-    u32 *new_deg = nullptr, *fill = nullptr;
+    u32 *new_deg = nullptr;
     u64 *new_start = nullptr, *new_adj = nullptr, *scratch = nullptr;
     u64 total = 0, scratch_n = 0;
     auto body = [&]() -> int {
         CHK(dev_alloc(c, &new_deg, c->n));
-        CHK(dev_alloc(c, &fill, c->n));
         CHK(dev_alloc(c, &new_start, c->n + 1));
         hipLaunchKernelGGL(merge_deg_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, new_deg);
         CHK((scan_exclusive<u32, u64>(c, new_deg, c->n, new_start, true, &total)));
         CHK(dev_alloc(c, &new_adj, total));
-        HIPCHK(c, hipMemsetAsync(fill, 0, c->n * sizeof(u32), c->stream));
-        hipLaunchKernelGGL(merge_copy_kernel, dim3(wave_grid(c, c->n, 16)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, new_start, new_adj, c->n);
-        hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_ref, new_start, fill, new_adj);
+        hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_ref, new_start, new_adj);
         /* row scratch: the longest merged row (reduced on the device) */
         CHK(zero_counter(c, CTR_MAX_DEG));
         hipLaunchKernelGGL(max_u32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, new_deg, c->n, c->d_ctr + CTR_MAX_DEG);
@@ -2076,7 +2094,7 @@ static int merge_extras(disco_ctx *c)
         const int g = (int)std::min<u64>(c->n, (u64)c->n_cu * 32); /* one wavefront per row at a time */
         scratch_n = (u64)g * (maxdeg + 1);
         CHK(dev_alloc(c, &scratch, scratch_n));
-        hipLaunchKernelGGL(merge_sort_kernel, dim3(g), dim3(64), 0, c->stream, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);
+        hipLaunchKernelGGL(merge_rows_kernel, dim3(g), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_extra_cnt, new_start, new_adj, c->n, scratch, maxdeg + 1);
         hipLaunchKernelGGL(ref_from_start_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, new_start, new_deg, c->n, c->d_adj_ref);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2085,7 +2103,6 @@ static int merge_extras(disco_ctx *c)
     const int rc = body();
     dev_free(c, &scratch, scratch_n);
     dev_free(c, &new_deg, c->n);
-    dev_free(c, &fill, c->n);
     dev_free(c, &new_start, c->n + 1);
     if (rc != DISCO_OK) {
         dev_free(c, &new_adj, total);
@@ -2162,7 +2179,8 @@ int disco_export_adjacency(disco_ctx *c, void *d_deg_u32, void *d_entries_u64)
         u64 total = 0;
         int rc = scan_exclusive<u32, u64>(c, (const u32 *)d_deg_u32, nq, start, true, &total);
         if (rc == DISCO_OK && total != c->adj_total) rc = fail(c, DISCO_E_STATE, "disco_export_adjacency: degree sum %llu != %llu", (unsigned long long)total, (unsigned long long)c->adj_total);
-        if (rc == DISCO_OK) hipLaunchKernelGGL(rows_gather_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, c->q_lo, c->q_hi, start, (u64 *)d_entries_u64);
+        if (rc == DISCO_OK) hipLaunchKernelGGL(rows_gather_kernel, dim3(wave_grid(c, nq, 16)), dim3(64), 0, c->stream, c->d_adj, c->d_adj_ref, c->q_lo, c->q_hi, start, (u64 *)d_entries_u64,
+                                              (c->phase == 5 && c->prm.max_substitutions != 0) ? 0ull : (u64)ADJ_FLAG); /* (hidden flags travel to the twin search) */
         hipError_t e = hipStreamSynchronize(c->stream);
         CHK(rc);
         if (e != hipSuccess) return fail(c, DISCO_E_HIP, "disco_export_adjacency: %s", hipGetErrorString(e));

@@ -40,6 +40,12 @@
 #define REF_POS(r) ((r)&0xFFFFFFFFFFull)
 #define REF_DEG(r) ((u32)((r) >> 40))
 #define ADJ_FLAG (1ull << 15)
+/* an entry of the extras list: the node (31 bits, like ADJ_DST) and the extra's place among that node's extras */
+/* between edge selection and the twin search the flag bit says "the twin of this entry is hidden from the other read" */
+#define ADJ_HIDDEN_OF(hit) ((u64)HIT_HIDDEN(hit) << 15)
+#define EXTRA_NODE_MAKE(w, slot) ((u64)(w) | ((u64)(slot) << 32))
+#define EXTRA_NODE(e) ((e)&0xFFFFFFFFull)
+#define EXTRA_SLOT(e) ((u32)((e) >> 32))
 
 /* global counters (u64 each) */
 enum {
@@ -1347,7 +1353,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 /* s2 = B or revcomp(B); s2[p] lies under A[p + d]; aligned region in A coordinates [x0, x1) */
                 const int d = prefix_align ? j : j + k - LB;
                 const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
-                bool contain, overlap;
+                bool contain, overlap, hidden = false;
+                const int hk = prefix_align ? x1 - k : x0; /* A's end k-mer inside a proper overlap: the seed of the twin find */
                 if (prefix_align) {
                     contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
                     overlap = !contain && j >= 1; /* :579 */
@@ -1416,6 +1423,22 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                         if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                         ov = overlap;
                     }
+                    if (INEXACT && __any(ov)) {
+                        /* does B see this pair from its side? Its window there is A's end k-mer inside the overlap — [hk, hk + k)
+                         * in A coordinates — and the seed must be exact: one substitution in it hides the pair (HIT_HIDDEN) */
+                        const int H0 = rev ? LA - hk - k : hk, H1 = H0 + k;
+                        const int hw0 = (H0 >> 5) - w0, hw1 = ((H1 - 1) >> 5) - w0;
+                        const u64 hfirst = ~0ull >> (2 * (H0 & 31)), hlast = ~0ull << (62 - 2 * ((H1 - 1) & 31));
+                        u64 hd = 0;
+                        if (ov)
+                            for (int t = hw0; t <= hw1; t++) {
+                                u64 xt = xor_word(t, bp[t], bp[t + 1]);
+                                if (t == hw0) xt &= hfirst;
+                                if (t == hw1) xt &= hlast;
+                                hd |= xt;
+                            }
+                        hidden = ov && hd != 0;
+                    }
                 } else if (act) {
                     const u64 *gb = a.v.reads + B * S;
                     if (seg_equal<false>(ga, gb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
@@ -1424,13 +1447,14 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                                     : seg_equal<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev)) {
                             if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                             ov = overlap;
+                            if (INEXACT && ov) hidden = !seg_equal<false>(ga, gb, S, LB, hk, hk - d, k, rev);
                         }
                     }
                 }
                 /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
                 if (MODE != 1) { /* the containment pass leaves the candidate list as it is */
                     const u64 mk = __ballot(ov);
-                    if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+                    if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = INEXACT && hidden ? h | HIT_HIDDEN_BIT : h;
                     nkeep += __popcll(mk);
                 }
                 __syncthreads();
@@ -1607,6 +1631,8 @@ struct EdgeSelArgs {
     const u64 *order;
     const ulonglong2 *meta_ord;
     u64 *dropbits; /* out: one bit per read whose selection dropped a verified hit (only those lists can lack a twin: twin_check) */
+    u32 hidden_flags; /* inexact overlaps: verified hits carry HIT_HIDDEN_BIT; it is kept out of the consumption order and handed on in
+                         the entry's ADJ_FLAG bit (ADJ_HIDDEN_OF) */
 };
 
 /* stable-free rank sort of m distinct keys from src into dst (wave cooperative) */
@@ -1704,7 +1730,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
                     const u64 hit = h[i];
                     u32 orient, off;
                     disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, HIT_J(hit), &orient, &off);
-                    ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit));
+                    ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit)) | ADJ_HIDDEN_OF(hit);
                 }
                 h[i] = ent;
             }
@@ -1718,14 +1744,18 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         }
         __syncthreads();
     }
-    /* 2. consumption order */
+    /* 2. consumption order (the hidden flag of a hit — inexact overlaps — kept out of it) */
+    if (a.hidden_flags) {
+        for (u32 i = lane; i < m; i += 64) h[i] = HIT_SORT_KEY(h[i]);
+        __syncthreads();
+    }
     wave_rank_sort(h, t, m, lane);
     __syncthreads();
     /* 3. sequential accept scan (wave-uniform control flow; lanes share the membership test) */
     u32 nacc = 0, ctr = 0, curj = 0xFFFFFFFFu;
     bool capflag = false;
     for (u32 i = 0; i < m; i++) {
-        const u64 hit = t[i];
+        const u64 hit = a.hidden_flags ? HIT_FROM_SORT_KEY(t[i]) : t[i];
         const u32 j = HIT_J(hit);
         const u64 B = HIT_ID(hit);
         if (j != curj) {
@@ -1740,7 +1770,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         if (ctr < a.max_per_kmer) {
             u32 orient, off;
             disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
-            if (lane == 0) h[nacc] = ADJ_MAKE(off, B, orient, HIT_LEN(hit));
+            if (lane == 0) h[nacc] = ADJ_MAKE(off, B, orient, HIT_LEN(hit)) | ADJ_HIDDEN_OF(hit);
             nacc++;
             ctr++;
             __syncthreads();
@@ -1767,7 +1797,8 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
 __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A, u64 rs, u32 LA, u64 hit, u32 lane, u32 &dropped, u64 &n_edges)
 {
     u64 *row = a.hits + rs;
-    hit = wave_bitonic_sort(hit, lane);
+    if (a.hidden_flags) hit = HIT_FROM_SORT_KEY(wave_bitonic_sort(HIT_SORT_KEY(hit), lane)); /* (~0 stays ~0) */
+    else hit = wave_bitonic_sort(hit, lane);
     const bool valid = hit != ~0ull;
     const u32 m = __popcll(__ballot(valid));
     const u32 B = (u32)HIT_ID(hit);
@@ -1792,7 +1823,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     if (nondup) {
         u32 orient, off;
         disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
-        ent = ADJ_MAKE(off, B, orient, HIT_LEN(hit));
+        ent = ADJ_MAKE(off, B, orient, HIT_LEN(hit)) | ADJ_HIDDEN_OF(hit);
     }
     ent = wave_bitonic_sort(ent, lane);
     const u32 nacc = __popcll(nd);
@@ -1883,7 +1914,7 @@ __device__ __forceinline__ bool edge_select_row_all(const EdgeSelArgs &a, u64 A,
     if (valid) {
         u32 orient, off;
         disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
-        ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit));
+        ent = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit)) | ADJ_HIDDEN_OF(hit);
     }
 #ifndef ES_NO_COUNT_SORT
     if (s_bins && LA <= 256u) ent = wave_sort_by_offset(ent, valid, lane, s_bins, s_srt); /* (LA is wave uniform) */
@@ -2055,15 +2086,16 @@ __global__ void ref_from_start_kernel(const u64 *__restrict__ start, const u32 *
 }
 
 /* rows of the nodes [lo,hi) copied into node order: dst[dst_start[v-lo] + i] (export for the all-gather; flags stripped) */
+/* (strip: all flag bits of the copy cleared; 0 keeps the hidden flags of a selection with inexact overlaps for the twin search) */
 __global__ void __launch_bounds__(64) rows_gather_kernel(const u64 *__restrict__ adj, const u64 *__restrict__ ref, u64 lo, u64 hi,
-                                                         const u64 *__restrict__ dst_start, u64 *__restrict__ dst)
+                                                         const u64 *__restrict__ dst_start, u64 *__restrict__ dst, u64 strip)
 {
     for (u64 v = lo + blockIdx.x; v < hi; v += gridDim.x) {
         const u64 r = ref[v];
         const u32 d = REF_DEG(r);
         const u64 *src = adj + REF_POS(r);
         u64 *o = dst + dst_start[v - lo];
-        for (u32 i = threadIdx.x; i < d; i += 64) o[i] = src[i] & ~ADJ_FLAG;
+        for (u32 i = threadIdx.x; i < d; i += 64) o[i] = src[i] & ~strip;
     }
 }
 
@@ -2116,14 +2148,47 @@ struct TwinArgs {
                             other find needs no search */
     int up_only;    /* 1: search only finds with src < dst and count both kinds; equality of the two counts plus no
                        missing twin proves symmetry (the up-finds inject into the down-finds); no extras recorded */
+    int hidden_flags; /* inexact overlaps, dropbits given: verify_kernel told which finds the other read cannot see (ADJ_FLAG of the
+                         entry, ADJ_HIDDEN_OF). A find it CAN see is in its list unless that read's selection dropped something —
+                         the argument of the exact case plus an exact seed — so only hidden finds and finds into reads of the bitmap
+                         are searched: a quarter of the entries. clear_adj_flags_kernel / the rebuilding merge remove the flags afterwards. */
 };
 
+#ifndef TW_PEND
+#define TW_PEND 256 /* missing twins a wavefront collects in LDS before it appends them to the extras with ONE atomic */
+#endif
 __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
 {
+    /* With inexact overlaps a third of all finds lack their twin (a substitution inside the other read's end k-mer hides the pair
+     * from that side): one append per trip was 50 M atomics on a single address — 0.42 s of a 0.52 s launch at 50 M reads. The
+     * misses of several trips are parked in LDS and appended TW_PEND at a time: the list stays dense, the counter sees 1/50th. */
+    __shared__ u64 s_node[4][TW_PEND];
+    __shared__ u64 s_key[4][TW_PEND];
     const u32 lane = threadIdx.x & 63;
+    const u32 wv = threadIdx.x >> 6;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     u32 asym = 0, n_up = 0, n_down = 0;
+    u32 pend = 0; /* wave-uniform */
+    auto flush = [&]() {
+        if (!pend) return;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(a.n_extra, pend);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        for (u32 i0 = 0; i0 < pend; i0 += 64) {
+            const u32 i = i0 + lane;
+            const bool have = i < pend;
+            const bool put = have && base + i < a.extra_cap;
+            if (put) {
+                const u64 w = s_node[wv][i];
+                a.extra_node[base + i] = EXTRA_NODE_MAKE(w, atomicAdd(&a.extra_cnt[w], 1u)); /* its place among w's extras rides along */
+                a.extra_key[base + i] = s_key[wv][i];
+            }
+            const u64 over = __ballot(have && !put); /* the sizing pass overflows by design */
+            if (over && lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], (u64)__popcll(over));
+        }
+        pend = 0;
+    };
     for (u64 u = wave; u < a.v.n; u += nwaves) {
         const u64 ru = a.ref[u];
         const u32 du = REF_DEG(ru);
@@ -2131,10 +2196,12 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
         const u64 s = REF_POS(ru);
         const u32 Lu = a.v.len[u];
         const bool u_in = (u >= a.lo && u < a.hi);
-        for (u32 p0 = 0; p0 < du; p0 += 64) { /* wave-uniform trips: the missing twins of a trip are appended with ONE atomic */
+        for (u32 p0 = 0; p0 < du; p0 += 64) { /* wave-uniform trips */
             const u32 p = p0 + lane;
             bool search = p < du;
-            const u64 ent = search ? a.adj[s + p] & ~ADJ_FLAG : 0ull;
+            const u64 raw = search ? a.adj[s + p] : 0ull;
+            const u64 ent = raw & ~ADJ_FLAG;
+            const bool hid = (raw & ADJ_FLAG) != 0; /* (left in place: the launch is repeated when the extras overflow) */
             const u64 w = ADJ_DST(ent);
             if (search && a.up_only) {
                 if (w < u) { /* a down-find, counted at its source */
@@ -2146,7 +2213,7 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
                     n_up++;
             } else if (search && (w < a.lo || w >= a.hi))
                 search = false;
-            if (search && a.dropbits && !((a.dropbits[w >> 6] >> (w & 63)) & 1ull)) search = false;
+            if (search && a.dropbits && !(a.hidden_flags && hid) && !((a.dropbits[w >> 6] >> (w & 63)) & 1ull)) search = false;
             bool miss = false;
             u64 twin = 0;
             if (search) {
@@ -2156,24 +2223,21 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
                 miss = adj_find(a.adj + REF_POS(rw), REF_DEG(rw), twin) < 0;
             }
             asym += miss ? 1u : 0u;
-            const u64 mk = __ballot(miss && !a.up_only);
+            const bool put = miss && !a.up_only;
+            const u64 mk = __ballot(put);
             if (mk) {
-                const u32 leader = (u32)__ffsll((long long)mk) - 1u;
-                u32 base = 0;
-                if (lane == leader) base = atomicAdd(a.n_extra, (u32)__popcll(mk));
-                base = (u32)__builtin_amdgcn_readlane((int)base, (int)leader);
-                const u32 idx = base + (u32)__popcll(mk & lane_mask_lt());
-                const bool put = miss && !a.up_only;
-                if (put && idx < a.extra_cap) {
-                    a.extra_node[idx] = w;
-                    a.extra_key[idx] = twin;
-                    atomicAdd(&a.extra_cnt[w], 1u);
+                const u32 cnt = (u32)__popcll(mk);
+                if (pend + cnt > TW_PEND) flush();
+                if (put) {
+                    const u32 pos = pend + (u32)__popcll(mk & lane_mask_lt());
+                    s_node[wv][pos] = w;
+                    s_key[wv][pos] = twin;
                 }
-                const u64 over = __ballot(put && idx >= a.extra_cap); /* the sizing pass overflows by design: one atomic per trip */
-                if (over && lane == leader) atomicAdd(&a.v.ctr[CTR_OVERFLOW], (u64)__popcll(over));
+                pend += cnt;
             }
         }
     }
+    flush();
     for (int o = 32; o > 0; o >>= 1) {
         asym += __shfl_down(asym, o);
         n_up += __shfl_down(n_up, o);
@@ -2186,6 +2250,23 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
     }
 }
 
+/* inexact overlaps: the hidden flags of edge selection out of the rows again (ADJ_FLAG belongs to the transitive marking from here
+ * on); 16 lanes per row. Not needed when the merge rebuilds every row. */
+__global__ void __launch_bounds__(256) clear_adj_flags_kernel(const u64 *__restrict__ ref, u64 *__restrict__ adj, u64 n)
+{
+    const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((u64)gridDim.x * blockDim.x) >> 4;
+    const u32 sub = threadIdx.x & 15u;
+    for (u64 v = g; v < n; v += ng) {
+        const u64 r = ref[v];
+        const u64 s = REF_POS(r);
+        const u32 d = REF_DEG(r);
+        for (u32 i = sub; i < d; i += 16) {
+            const u64 x = adj[s + i];
+            if (x & ADJ_FLAG) adj[s + i] = x & ~ADJ_FLAG;
+        }
+    }
+}
+
 /* extras merge (only when asymmetric pairs exist): new_deg = deg + extra_cnt -> scan -> copy rows -> scatter extras
  * -> re-sort the rows that received extras -> node-ordered CSR */
 __global__ void merge_deg_kernel(const u64 *__restrict__ ref, const u32 *__restrict__ extra_cnt, u64 n, u32 *__restrict__ out)
@@ -2194,28 +2275,14 @@ __global__ void merge_deg_kernel(const u64 *__restrict__ ref, const u32 *__restr
     for (; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = REF_DEG(ref[i]) + extra_cnt[i];
 }
 
-__global__ void __launch_bounds__(64) merge_copy_kernel(const u64 *__restrict__ old_ref, const u64 *__restrict__ old_adj,
-                                                        const u64 *__restrict__ new_start, u64 *__restrict__ new_adj, u64 n)
-{
-    for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
-        const u64 r = old_ref[v];
-        const u64 s = REF_POS(r);
-        const u32 d = REF_DEG(r);
-        const u64 o = new_start[v];
-        for (u32 i = threadIdx.x; i < d; i += 64) new_adj[o + i] = old_adj[s + i] & ~ADJ_FLAG;
-    }
-}
-
 __global__ void merge_scatter_kernel(const u64 *__restrict__ extra_node, const u64 *__restrict__ extra_key, u32 n_extra,
-                                     const u64 *__restrict__ old_ref, const u64 *__restrict__ new_start,
-                                     u32 *__restrict__ fill, u64 *__restrict__ new_adj)
+                                     const u64 *__restrict__ old_ref, const u64 *__restrict__ new_start, u64 *__restrict__ new_adj)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n_extra; i += gridDim.x * blockDim.x) {
-        u64 w = extra_node[i];
-        u32 d = REF_DEG(old_ref[w]);
-        u32 slot = atomicAdd(&fill[w], 1u);
-        new_adj[new_start[w] + d + slot] = extra_key[i];
+        const u64 en = extra_node[i];
+        const u64 w = EXTRA_NODE(en);
+        new_adj[new_start[w] + REF_DEG(old_ref[w]) + EXTRA_SLOT(en)] = extra_key[i]; /* the slot was drawn when the extra was recorded */
     }
 }
 
@@ -2235,10 +2302,10 @@ __global__ void __launch_bounds__(64) merge_sparse_kernel(const u64 *__restrict_
 {
     const u32 lane = threadIdx.x;
     for (u32 i = blockIdx.x; i < n_extra; i += gridDim.x) {
-        const u64 v = extra_node[i];
+        const u64 v = EXTRA_NODE(extra_node[i]);
         /* the node is handled by the wave that holds its FIRST extra */
         bool earlier = false;
-        for (u32 t = lane; t < i; t += 64) earlier |= extra_node[t] == v;
+        for (u32 t = lane; t < i; t += 64) earlier |= EXTRA_NODE(extra_node[t]) == v;
         if (__any(earlier)) continue;
         const u64 r = ref[v];
         const u32 d = REF_DEG(r), nd = d + extra_cnt[v];
@@ -2250,7 +2317,7 @@ __global__ void __launch_bounds__(64) merge_sparse_kernel(const u64 *__restrict_
         u32 at = d;
         for (u32 t0 = i; t0 < n_extra; t0 += 64) {
             const u32 t = t0 + lane;
-            const bool mine = t < n_extra && extra_node[t] == v;
+            const bool mine = t < n_extra && EXTRA_NODE(extra_node[t]) == v;
             const u64 mk = __ballot(mine);
             if (mine) up[at + __popcll(mk & lane_mask_lt())] = extra_key[t];
             at += __popcll(mk);
@@ -2262,25 +2329,46 @@ __global__ void __launch_bounds__(64) merge_sparse_kernel(const u64 *__restrict_
     }
 }
 
-/* sort (ascending) the rows that received extras: up to 64 entries in registers (one bitonic network), longer rows through a global
- * scratch row */
-__global__ void __launch_bounds__(64) merge_sort_kernel(const u32 *__restrict__ extra_cnt, const u64 *__restrict__ new_start,
-                                                        u64 *__restrict__ new_adj, u64 n, u64 *__restrict__ scratch, u64 scratch_cap)
+/* the merged row of every node, after the extras were scattered behind the place of the old row: old entries (sorted) + extras (not)
+ * -> sorted new row. Up to 64 entries stay in registers: every extra is broadcast once, its rank is one ballot, every old entry
+ * moves down by the extras before it (keys are unique) — 6 instructions per extra where a sorting network takes 250 per row; rows
+ * with many extras take the network, longer rows a global scratch row. Rows without extras are copied. */
+#define MERGE_RANK_MAX 24
+__global__ void __launch_bounds__(64) merge_rows_kernel(const u64 *__restrict__ old_ref, const u64 *__restrict__ old_adj, const u32 *__restrict__ extra_cnt,
+                                                        const u64 *__restrict__ new_start, u64 *__restrict__ new_adj, u64 n, u64 *__restrict__ scratch,
+                                                        u64 scratch_cap)
 {
     u64 *tmp = scratch + (u64)blockIdx.x * scratch_cap;
     const u32 lane = threadIdx.x;
     for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
-        if (!extra_cnt[v]) continue;
-        u64 s = new_start[v];
-        u32 d = (u32)(new_start[v + 1] - s);
+        const u64 r = old_ref[v];
+        const u64 so = REF_POS(r);
+        const u32 d0 = REF_DEG(r);
+        const u32 x = extra_cnt[v];
+        const u64 o = new_start[v];
+        const u32 d = d0 + x;
         if (d <= 64) {
-            const u64 x = wave_bitonic_sort(lane < d ? new_adj[s + lane] : ~0ull, lane); /* entries are < ~0: the padding sorts behind them */
-            if (lane < d) new_adj[s + lane] = x;
+            u64 e = ~0ull; /* entries are < ~0: the padding sorts behind them */
+            if (lane < d0) e = old_adj[so + lane] & ~ADJ_FLAG;
+            else if (lane < d) e = new_adj[o + lane];
+            u32 pos = lane;
+            if (x > MERGE_RANK_MAX) e = wave_bitonic_sort(e, lane);
+            else
+                for (u32 j = 0; j < x; j++) { /* wave-uniform trips */
+                    const u64 bj = readlane_u64(e, d0 + j);
+                    const u32 rank = (u32)__popcll(__ballot(e < bj));
+                    if (lane == d0 + j) pos = rank;
+                    else if (lane < d0 && bj < e) pos++;
+                }
+            if (lane < d) new_adj[o + pos] = e;
             continue;
         }
-        wave_rank_sort(new_adj + s, tmp, d, lane);
+        for (u32 i = lane; i < d0; i += 64) new_adj[o + i] = old_adj[so + i] & ~ADJ_FLAG;
+        if (!x) continue;
         __syncthreads();
-        for (u32 i = lane; i < d; i += 64) new_adj[s + i] = tmp[i];
+        wave_rank_sort(new_adj + o, tmp, d, lane);
+        __syncthreads();
+        for (u32 i = lane; i < d; i += 64) new_adj[o + i] = tmp[i];
         __syncthreads();
     }
 }

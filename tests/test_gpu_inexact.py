@@ -73,6 +73,24 @@ def _assert_inexact_parity(codes, off, min_overlap, t, label):
 ])
 def test_inexact_against_the_oracle(seed, n, lmin, lmax, cov, minovl, rate, t):
     codes, off = _mutated(seed, n, lmin, lmax, cov, rate)
+    _check_inexact(codes, off, seed, minovl, t)
+
+
+@pytest.mark.parametrize("seed,n,lmin,lmax,cov,minovl,rate,t", [
+    (111, 4000, 150, 150, 30.0, 40, 0.004, 3),    # a few extras per row: ranked into the old row
+    (112, 3000, 100, 250, 30.0, 40, 0.006, 2),
+    (113, 5000, 150, 150, 100.0, 40, 0.006, 4),   # rows beyond 64 entries (scratch row) and rows with dozens of extras (sorting network)
+    (114, 1500, 150, 150, 60.0, 40, 0.012, 8),    # most end k-mers carry an error: more extras than old entries
+])
+def test_inexact_with_every_row_rebuilt(seed, n, lmin, lmax, cov, minovl, rate, t, monkeypatch):
+    """data sets of test size have few enough one-sided pairs for the sparse merge; at scale a third of all pairs are one-sided and
+    every row is rebuilt (merge_rows_kernel) — force that path"""
+    monkeypatch.setenv("DISCO_MERGE_REBUILD", "1")
+    codes, off = _mutated(seed, n, lmin, lmax, cov, rate)
+    _check_inexact(codes, off, seed, minovl, t)
+
+
+def _check_inexact(codes, off, seed, minovl, t):
     hc, hs = _assert_inexact_parity(codes, off, minovl, t, f"seed{seed}")
     assert hc["e_out"] > 0 and hs.max() > 0          # the threshold was used
     assert hc["asymmetric_pairs"] > 0                # pairs hidden from one side by an error inside an end k-mer exist
