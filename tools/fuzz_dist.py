@@ -4,7 +4,9 @@ repeat genomes that bind the cap), every case through
    (a) the single-GPU pass,  (b) the single-GPU pass with DISCO_FLAG_TWO_PASS_VERIFY,  (c) G = 2..5 ranks on one GPU (in-process
    transport), two-pass flag at random
 and (a) is checked against the CPU oracle (tests.util.assert_parity); (b) and (c) must equal (a) bit for bit.
-   python tools/fuzz_dist.py [ITERATIONS=50] [SEED=1]"""
+   python tools/fuzz_dist.py [ITERATIONS=50] [SEED=1] [inexact]
+with "inexact": every case gets substitution errors and a random threshold (the f-4 extension): (a) against the oracle's statement
+of the rule, (c) against (a); (b) does not apply (the two-pass verify is an exact-mode form)."""
 import os
 import sys
 import time
@@ -20,6 +22,7 @@ from tests.util import assert_parity, canon_hip, run_hip_reads  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+inexact = len(sys.argv) > 3 and sys.argv[3] == "inexact"
 fails = 0
 t0 = time.time()
 for it in range(iters):
@@ -69,6 +72,28 @@ for it in range(iters):
         if rng.random() < 0.2:
             comp = str.maketrans("ACGT", "TGCA")
             reads += [reads[i] if rng.random() < 0.5 else reads[i].translate(comp)[::-1] for i in rng.integers(0, len(reads), max(len(reads) // 10, 1))]
+        if inexact:
+            err = float(rng.choice([0.001, 0.003, 0.006, 0.012]))
+            tsub = int(rng.choice([1, 2, 3, 5, 9]))
+            label += f" err={err} tsub={tsub}"
+            r2 = np.random.default_rng(seed + 5)
+            out = []
+            for s_ in reads:
+                b = np.frombuffer(s_.encode(), dtype=np.uint8).copy()
+                hit = r2.random(len(b)) < err
+                b[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[r2.integers(0, 4, int(hit.sum()))]
+                out.append(b.tobytes().decode())
+            reads = out
+            c = assert_parity(reads, mo, label, max_substitutions=tsub)  # (a) vs the oracle
+            e1, r1, _ = run_hip_reads(reads, mo, max_substitutions=tsub)
+            ce1, cc1 = canon_hip(e1, r1)
+            e3, r3_, info, _ = run_ranks_reads(reads, mo, G, max_substitutions=tsub)  # (c)
+            ce3, cc3 = canon_hip(e3, r3_)
+            assert np.array_equal(cc1, cc3), f"{G} ranks: contained rows differ ({len(cc1)} vs {len(cc3)})"
+            assert np.array_equal(ce1, ce3), f"{G} ranks: edges differ ({len(ce1)} vs {len(ce3)})"
+            assert info["e_pre"] == c["e_pre"] and info["asymmetric_pairs"] == c["asymmetric_pairs"] and info["cap_bind_sites"] == c["cap_bind_sites"], (info, c)
+            print("ok  ", label, "e_pre", c["e_pre"], "e_out", c["e_out"], "contained", c["n_contained"], "asym", c["asymmetric_pairs"], "regime", info["regime"], flush=True)
+            continue
         c = assert_parity(reads, mo, label)  # (a) vs the oracle
         e1, r1, _ = run_hip_reads(reads, mo)
         ce1, cc1 = canon_hip(e1, r1)
