@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver supports dmabuf IPC only: without this RCCL's buffer sharing between the rank processes fails with
+# "hipIpcGetMemHandle: invalid argument". Exported on the boxes already; set before the HIP runtime loads in case a launcher drops it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is attainable
 

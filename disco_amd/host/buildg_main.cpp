@@ -149,6 +149,7 @@ int main(int argc, char **argv)
 {
     std::cout << "Software: Disco Assembler BuildGraph, MI355X-native drop-in (disco_amd)\n";
     auto t_main = Clock::now();
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); /* hosts with dmabuf IPC only: RCCL's buffer sharing needs it; before any HIP call */
     std::vector<std::string> pe, se;
     std::string prefix, cfg;
     int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
