@@ -30,6 +30,16 @@
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
 #endif
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
+/* verify_kernel is bound by the rate of 64-byte row fetches that miss the L2 (78 GB at the 2.55 TB/s a pure row gather reaches); the
+ * rows of a locus are re-used by the dozen reads of its group, as long as the L2 still holds them. What streams through once —
+ * candidate lists in, verified hits out — is loaded / stored non-temporally so that it does not push rows out. */
+#ifndef VERIFY_NO_STREAM_HINTS
+#define STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#define STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define STREAM_LOAD(p) (*(p))
+#define STREAM_STORE(v, p) (*(p) = (v))
+#endif
 #define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift)) /* bucket of a read-level minimizer in the grouping ("processing order") */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
 #define SCAN_BLOCK 256
@@ -1262,7 +1272,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
      * the line's L2 channel becomes a hot spot) */
     auto load_cands = [&](const Meta &mt, u64 A) {
         const bool ok = lane < mt.c;
-        const u64 h = a.hits[ok ? mt.rs + lane : (mt.c ? mt.rs : (A & 0xFFFFull))]; /* the hit buffer has more than 65536 slots */
+        const u64 h = STREAM_LOAD(&a.hits[ok ? mt.rs + lane : (mt.c ? mt.rs : (A & 0xFFFFull))]); /* the hit buffer has more than 65536 slots */
         return ok ? h : 0ull;
     };
     auto load_row = [&](u64 (&w)[staged ? NW : 1], const u64 *g) {
@@ -1386,59 +1396,59 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                         if (t == nl) xt &= lastmask;
                         return xt;
                     };
-                    u64 diff = 0, blo = 0;
+                    u64 blo = 0;
                     u32 nsub = 0;
+                    /* The seed k-mer [K0, K1) sits at one END of the aligned region (T coordinates): at its start for types 0 / 3
+                     * (prefix_align != rev), at its end for 1 / 2. "The k-mer alone matches" — what makes a candidate a hit of
+                     * getListOfReads, counted in kmer_hits — is therefore "the mismatch nearest that end is at least k bases in",
+                     * and the first / last non-zero XOR word of the one pass below decides it. (Until round 3 the failing lanes
+                     * re-walked their k-mer's words in a loop of their own: 130 of verify_kernel's 233 vector instructions per
+                     * read, for a counter.) The other end of a proper overlap is this read's end k-mer inside it, the seed of the
+                     * TWIN find: inexact overlaps read both ends (HIT_HIDDEN_BIT). */
+                    const bool at_start = prefix_align != (rev != 0);
+                    u64 fx = 0, lx = 0; /* first / last non-zero XOR word of the region ... */
+                    int ft = 0, lt = 0; /* ... and which word it is */
                     if (act) blo = bp[0];
 #pragma unroll
                     for (int t = 0; t < NW; t++) {
                         if (!__any(t <= nl)) continue;
                         if (t <= nl) {
                             const u64 bhi = bp[t + 1];
-                            if (INEXACT) nsub += base_mismatches(xor_word(t, blo, bhi));
-                            else diff |= xor_word(t, blo, bhi);
+                            const u64 xt = xor_word(t, blo, bhi);
+                            if (INEXACT) nsub += base_mismatches(xt);
+                            const bool nz = xt != 0;
+                            if (INEXACT) {
+                                if (nz && fx == 0) {
+                                    fx = xt;
+                                    ft = t;
+                                }
+                                if (nz) {
+                                    lx = xt;
+                                    lt = t;
+                                }
+                            } else if (nz && (!at_start || fx == 0)) { /* exact: one end per lane is enough */
+                                fx = xt;
+                                ft = t;
+                            }
                             blo = bhi;
                         }
                     }
-                    const bool region_ok = act && (INEXACT ? nsub <= a.max_subs : diff == 0);
-                    bool kmer_ok = region_ok; /* exact compare: the k-mer lies inside the aligned region */
-                    if (__any(act && (INEXACT || !region_ok))) {
-                        /* the exact k-mer compare on its own (what makes a candidate a hit of getListOfReads), over the same
-                         * XOR words: k-mer region [K0, K1) in T coordinates */
-                        const int K0 = rev ? LA - j - k : j, K1 = K0 + k;
-                        const int kw0 = (K0 >> 5) - w0, kw1 = ((K1 - 1) >> 5) - w0;
-                        const u64 kfirst = ~0ull >> (2 * (K0 & 31)), klast = ~0ull << (62 - 2 * ((K1 - 1) & 31));
-                        u64 kd = 0;
-                        if (act && (INEXACT || !region_ok))
-                            for (int t = kw0; t <= kw1; t++) {
-                                u64 xt = xor_word(t, bp[t], bp[t + 1]);
-                                if (t == kw0) xt &= kfirst;
-                                if (t == kw1) xt &= klast;
-                                kd |= xt;
-                            }
-                        kmer_ok = act && kd == 0;
-                    }
+                    const bool region_ok = act && (INEXACT ? nsub <= a.max_subs : fx == 0);
+                    /* position (T coordinates) of the first / last differing base; a clean region has none */
+                    const u64 ex = INEXACT ? lx : fx; /* the word the END side looks at */
+                    const int et = INEXACT ? lt : ft;
+                    const bool first_clean = fx == 0 || 32 * (w0 + ft) + (__clzll((long long)fx) >> 1) >= X0 + k;
+                    const bool last_clean = ex == 0 || 32 * (w0 + et) + ((64 - __ffsll((long long)ex)) >> 1) < X1 - k;
+                    const bool kmer_ok = act && (at_start ? first_clean : last_clean);
                     const bool full_ok = region_ok && kmer_ok;
                     if (kmer_ok) my_khits++;
                     if (full_ok) {
                         if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                         ov = overlap;
                     }
-                    if (INEXACT && __any(ov)) {
-                        /* does B see this pair from its side? Its window there is A's end k-mer inside the overlap — [hk, hk + k)
-                         * in A coordinates — and the seed must be exact: one substitution in it hides the pair (HIT_HIDDEN) */
-                        const int H0 = rev ? LA - hk - k : hk, H1 = H0 + k;
-                        const int hw0 = (H0 >> 5) - w0, hw1 = ((H1 - 1) >> 5) - w0;
-                        const u64 hfirst = ~0ull >> (2 * (H0 & 31)), hlast = ~0ull << (62 - 2 * ((H1 - 1) & 31));
-                        u64 hd = 0;
-                        if (ov)
-                            for (int t = hw0; t <= hw1; t++) {
-                                u64 xt = xor_word(t, bp[t], bp[t + 1]);
-                                if (t == hw0) xt &= hfirst;
-                                if (t == hw1) xt &= hlast;
-                                hd |= xt;
-                            }
-                        hidden = ov && hd != 0;
-                    }
+                    /* does B see this pair from its side? Its window there is A's end k-mer inside the overlap — the region's other
+                     * end — and the seed must be exact: one substitution in it hides the pair */
+                    if (INEXACT) hidden = ov && !(at_start ? last_clean : first_clean);
                 } else if (act) {
                     const u64 *gb = a.v.reads + B * S;
                     if (seg_equal<false>(ga, gb, S, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
@@ -1454,7 +1464,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
                 if (MODE != 1) { /* the containment pass leaves the candidate list as it is */
                     const u64 mk = __ballot(ov);
-                    if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = INEXACT && hidden ? h | HIT_HIDDEN_BIT : h;
+                    if (ov) STREAM_STORE(INEXACT && hidden ? h | HIT_HIDDEN_BIT : h, &row[nkeep + __popcll(mk & lane_mask_lt())]);
                     nkeep += __popcll(mk);
                 }
                 __syncthreads();
