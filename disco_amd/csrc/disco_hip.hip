@@ -198,6 +198,8 @@ struct disco_ctx {
     u64 *d_adj_ref = nullptr; /* [n] position | degree << 40 */
     u64 *d_adj = nullptr;     /* entries: the hit buffer itself (single GPU) or d_adj_own (imported / merged, node-ordered) */
     u64 *d_adj_own = nullptr; /* kept across passes: re-allocating GBs every pass costs more than the kernels */
+    u64 *d_adj_spare = nullptr; /* the rebuilding merge writes here and swaps: its 9 GB at 50 M reads are not allocated and freed per pass */
+    u64 adj_spare_cap = 0;
     u64 *d_start_tmp = nullptr; /* [n+1] scan scratch of export / import */
     u64 adj_total = 0; /* directed edges the context currently addresses */
     u64 adj_cap = 0, flag_cap = 0, out_cap = 0, valid_cap = 0, bkt_cap = 0, ent_cap = 0; /* buffers are kept across passes */
@@ -482,6 +484,7 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_dropbits, c->n_alloc / 64 + 1);
     dev_free(c, &c->d_adj_ref, c->n);
     dev_free(c, &c->d_adj_own, c->adj_cap);
+    dev_free(c, &c->d_adj_spare, c->adj_spare_cap);
     dev_free(c, &c->d_start_tmp, c->start_cap);
     c->start_cap = 0;
     dev_free(c, &c->d_nref, c->nref_cap);
@@ -505,7 +508,7 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_wide, c->wide_cap);
     dev_free(c, &c->d_n_wide, 1);
     c->wide_cap = 0;
-    c->adj_total = c->adj_cap = c->flag_cap = 0;
+    c->adj_total = c->adj_cap = c->adj_spare_cap = c->flag_cap = 0;
     dev_free(c, &c->d_out_valid, c->valid_cap);
     dev_free(c, &c->d_ch_comp, c->ch_comp_cap);
     dev_free(c, &c->d_ch_links, c->ch_links_cap);
@@ -2077,13 +2080,21 @@ static int merge_extras(disco_ctx *c)
     }
     u32 *new_deg = nullptr;
     u64 *new_start = nullptr, *new_adj = nullptr, *scratch = nullptr;
-    u64 total = 0, scratch_n = 0;
+    u64 total = 0, scratch_n = 0, new_cap = 0;
     auto body = [&]() -> int {
         CHK(dev_alloc(c, &new_deg, c->n));
         CHK(dev_alloc(c, &new_start, c->n + 1));
         hipLaunchKernelGGL(merge_deg_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_extra_cnt, c->n, new_deg);
         CHK((scan_exclusive<u32, u64>(c, new_deg, c->n, new_start, true, &total)));
-        CHK(dev_alloc(c, &new_adj, total));
+        if (c->adj_spare_cap >= total && c->d_adj_spare) { /* the buffer the previous pass's merge left behind */
+            new_adj = c->d_adj_spare;
+            new_cap = c->adj_spare_cap;
+            c->d_adj_spare = nullptr;
+            c->adj_spare_cap = 0;
+        } else {
+            CHK(dev_alloc(c, &new_adj, total + total / 16));
+            new_cap = total + total / 16;
+        }
         hipLaunchKernelGGL(merge_scatter_kernel, dim3(flat_grid(c, c->n_extra)), dim3(256), 0, c->stream, c->d_extra_node, c->d_extra_key, c->n_extra, c->d_adj_ref, new_start, new_adj);
         /* row scratch: the longest merged row (reduced on the device) */
         CHK(zero_counter(c, CTR_MAX_DEG));
@@ -2105,13 +2116,16 @@ static int merge_extras(disco_ctx *c)
     dev_free(c, &new_deg, c->n);
     dev_free(c, &new_start, c->n + 1);
     if (rc != DISCO_OK) {
-        dev_free(c, &new_adj, total);
+        dev_free(c, &new_adj, new_cap);
         return rc;
     }
-    dev_free(c, &c->d_adj_own, c->adj_cap);
+    /* the rows move to new_adj; what held the imported / merged rows so far waits for the next pass's merge */
+    dev_free(c, &c->d_adj_spare, c->adj_spare_cap);
+    c->d_adj_spare = c->d_adj_own;
+    c->adj_spare_cap = c->d_adj_own ? c->adj_cap : 0;
     c->d_adj_own = new_adj;
     c->d_adj = new_adj;
-    c->adj_cap = std::max<u64>(total, 1);
+    c->adj_cap = new_cap;
     c->adj_total = total;
     c->adj_span = total; /* compact, node ordered */
     c->n_extra = 0;

@@ -30,16 +30,6 @@
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
 #endif
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
-/* verify_kernel is bound by the rate of 64-byte row fetches that miss the L2 (78 GB at the 2.55 TB/s a pure row gather reaches); the
- * rows of a locus are re-used by the dozen reads of its group, as long as the L2 still holds them. What streams through once —
- * candidate lists in, verified hits out — is loaded / stored non-temporally so that it does not push rows out. */
-#ifndef VERIFY_NO_STREAM_HINTS
-#define STREAM_LOAD(p) __builtin_nontemporal_load(p)
-#define STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#else
-#define STREAM_LOAD(p) (*(p))
-#define STREAM_STORE(v, p) (*(p) = (v))
-#endif
 #define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift)) /* bucket of a read-level minimizer in the grouping ("processing order") */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
 #define SCAN_BLOCK 256
@@ -1209,7 +1199,13 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
      * statically known address space; the zero words make the shifted extracts branch free */
     constexpr bool staged = NW != 0;
     constexpr bool PREF = NW != 0 && NW <= VERIFY_SW; /* candidate rows prefetched into registers one read ahead */
-    constexpr int RW = PREF ? NW : 1;                  /* row words carried in the pipeline registers */
+    /* PREF: the candidate rows are fetched COOPERATIVELY — four lanes per row, 16 bytes each, 16 rows per load instruction, four
+     * instructions for the 64 candidates of a batch: an instruction touches 16 cache lines instead of 64. With one lane per row
+     * (16 + 16 + 8 bytes in three instructions) every instruction walked 64 different lines through the vector L1, and that walk, not
+     * HBM bytes, instructions or occupancy, was what verify_kernel's time followed (round 3: 27 fewer / 130 fewer vector
+     * instructions per read, 78 or 101 GB of traffic, 14 to 24 waves per CU — always 31 ms; every lane on ONE line: 19 ms). The
+     * quarters go straight to their place in the LDS staging area, where lane = candidate again. */
+    constexpr int NQ = PREF ? 4 : 1;                   /* row quarters carried in the pipeline registers */
     constexpr int SA = (NW > VERIFY_SW ? NW : VERIFY_SW) + 4;
     constexpr int BST = (NW + 3) | 1;
     __shared__ u64 s_b[staged ? 1 + 64 * BST : 1];
@@ -1236,8 +1232,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
         u64 rs;
     };
     struct Rows {
-        u64 w[RW];
-        u64 aw; /* lane < NW: word `lane` of the read's own row */
+        ulonglong2 q[NQ]; /* q[p]: quarter (lane & 3) of the row of candidate 16 p + (lane >> 2) */
+        u64 aw;           /* lane < NW: word `lane` of the read's own row */
     };
     u64 cbeg = 0, cend = 0;
     /* every pipelined load is UNCONDITIONAL (clamped address + select): a load under an exec-mask branch makes the number
@@ -1272,7 +1268,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
      * the line's L2 channel becomes a hot spot) */
     auto load_cands = [&](const Meta &mt, u64 A) {
         const bool ok = lane < mt.c;
-        const u64 h = STREAM_LOAD(&a.hits[ok ? mt.rs + lane : (mt.c ? mt.rs : (A & 0xFFFFull))]); /* the hit buffer has more than 65536 slots */
+        const u64 h = a.hits[ok ? mt.rs + lane : (mt.c ? mt.rs : (A & 0xFFFFull))]; /* the hit buffer has more than 65536 slots */
         return ok ? h : 0ull;
     };
     auto load_row = [&](u64 (&w)[staged ? NW : 1], const u64 *g) {
@@ -1294,25 +1290,38 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
     };
     auto load_rows = [&](const Meta &mt, u64 h, u64 A) {
         Rows r;
-        r.w[0] = 0;
+        r.q[0] = make_ulonglong2(0, 0);
         r.aw = 0;
         if (staged) {
             const u64 *own = a.v.reads + A * S;
             r.aw = own[lane < (u32)NW ? lane : 0u];
             if (PREF) {
-                u64 w[staged ? NW : 1];
+                /* the row behind this lane's candidate (lanes without one: the read's own row, a line the wave holds anyway) */
 #if defined(VERIFY_EXP_NOROWS) /* timing experiment (tools/ab_build.py; results are wrong): every lane fetches the read's own row */
-                load_row(w, own);
-#elif defined(VERIFY_EXP_NEARROWS) /* ... : rows next to the read's own (one per lane, distinct lines that consecutive reads share) */
-                load_row(w, a.v.reads + ((A & ~63ull) + lane < a.v.n ? (A & ~63ull) + lane : A) * S);
+                const u32 vid = (u32)A;
 #else
-                load_row(w, (lane < mt.c && in_pass(h, mt.L)) ? a.v.reads + HIT_ID(h) * S : own);
+                const u32 vid = (lane < mt.c && in_pass(h, mt.L)) ? (u32)HIT_ID(h) : (u32)A;
 #endif
 #pragma unroll
-                for (int t = 0; t < RW; t++) r.w[t] = w[t % (staged ? NW : 1)];
+                for (int p = 0; p < NQ; p++) {
+                    const u32 id = (u32)__shfl((int)vid, (int)(16 * p + (lane >> 2)));
+                    r.q[p] = ((const ulonglong2 *)(a.v.reads + (u64)id * S))[lane & 3u]; /* (S = 8 words: the four quarters of a row) */
+                }
             }
         }
         return r;
+    };
+    /* the quarters of a prefetched batch to their rows in the staging area (row r at s_b + 1 + r BST, NW words, zeros behind) */
+    auto stage_rows = [&](const Rows &r) {
+        const u32 qq = lane & 3u;
+        if (2 * qq < (u32)NW) {
+#pragma unroll
+            for (int p = 0; p < NQ; p++) {
+                u64 *dst = s_b + 1 + (16 * p + (lane >> 2)) * BST + 2 * qq;
+                dst[0] = r.q[p].x;
+                dst[1] = 2 * qq + 1 < (u32)NW ? r.q[p].y : 0ull; /* (NW odd: the word behind the row stays zero) */
+            }
+        }
     };
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
     {
@@ -1352,7 +1361,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             }
             u32 nkeep = 0;
             /* one batch of 64 candidates: lane = candidate h with its row words w (staged variants) */
-            auto batch = [&](const bool act0, const u64 h, const u64 (&w)[staged ? NW : 1]) {
+            auto batch = [&](const bool act0, const u64 h, const u64 (&w)[staged ? NW : 1], const bool rows_staged) {
                 const bool act = act0 && in_pass(h, LA);
                 bool ov = false;
                 const int j = (int)HIT_J(h);
@@ -1373,7 +1382,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                     overlap = d <= 0 && j >= 1; /* :591 */
                 }
                 if (staged) {
-                    if (act) {
+                    if (act && !rows_staged) {
                         u64 *sb = s_b + 1 + lane * BST;
 #pragma unroll
                         for (int t = 0; t < NW; t++) sb[t] = w[t % (staged ? NW : 1)];
@@ -1402,39 +1411,57 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                      * (prefix_align != rev), at its end for 1 / 2. "The k-mer alone matches" — what makes a candidate a hit of
                      * getListOfReads, counted in kmer_hits — is therefore "the mismatch nearest that end is at least k bases in",
                      * and the first / last non-zero XOR word of the one pass below decides it. (Until round 3 the failing lanes
-                     * re-walked their k-mer's words in a loop of their own: 130 of verify_kernel's 233 vector instructions per
-                     * read, for a counter.) The other end of a proper overlap is this read's end k-mer inside it, the seed of the
-                     * TWIN find: inexact overlaps read both ends (HIT_HIDDEN_BIT). */
+                     * re-walked their k-mer's words in a loop of their own: 130 vector instructions more whenever a lane of the
+                     * batch failed — rare on clean reads, the rule on real ones — for a counter.) The other end of a proper overlap
+                     * is this read's end k-mer inside it, the seed of the TWIN find: inexact overlaps read both ends
+                     * (HIT_HIDDEN_BIT). The XOR words stay in registers; the scan for the first / last one runs when it is needed. */
                     const bool at_start = prefix_align != (rev != 0);
-                    u64 fx = 0, lx = 0; /* first / last non-zero XOR word of the region ... */
+                    u64 xw[NW > 0 ? NW : 1]; /* exact: the region's XOR words (zero behind the region) */
+                    u64 diff = 0;
+                    u64 fx = 0, lx = 0; /* first / last non-zero XOR word ... */
                     int ft = 0, lt = 0; /* ... and which word it is */
+                    auto track = [&](int t, u64 xt) {
+                        const bool nz = xt != 0;
+                        if (INEXACT) { /* both ends */
+                            if (nz && fx == 0) {
+                                fx = xt;
+                                ft = t;
+                            }
+                            if (nz) {
+                                lx = xt;
+                                lt = t;
+                            }
+                        } else if (nz && (!at_start || fx == 0)) { /* exact: the seed's end */
+                            fx = xt;
+                            ft = t;
+                        }
+                    };
                     if (act) blo = bp[0];
 #pragma unroll
                     for (int t = 0; t < NW; t++) {
+                        xw[t] = 0;
                         if (!__any(t <= nl)) continue;
                         if (t <= nl) {
                             const u64 bhi = bp[t + 1];
                             const u64 xt = xor_word(t, blo, bhi);
-                            if (INEXACT) nsub += base_mismatches(xt);
-                            const bool nz = xt != 0;
                             if (INEXACT) {
-                                if (nz && fx == 0) {
-                                    fx = xt;
-                                    ft = t;
-                                }
-                                if (nz) {
-                                    lx = xt;
-                                    lt = t;
-                                }
-                            } else if (nz && (!at_start || fx == 0)) { /* exact: one end per lane is enough */
-                                fx = xt;
-                                ft = t;
+                                nsub += base_mismatches(xt);
+                                track(t, xt);
+                            } else {
+                                diff |= xt;
+                                xw[t] = xt;
                             }
                             blo = bhi;
                         }
                     }
-                    const bool region_ok = act && (INEXACT ? nsub <= a.max_subs : fx == 0);
-                    /* position (T coordinates) of the first / last differing base; a clean region has none */
+                    const bool region_ok = act && (INEXACT ? nsub <= a.max_subs : diff == 0);
+                    /* exact overlaps: a failing lane is rare on clean reads (the words are scanned when there is one) and the rule on
+                     * real ones; inexact overlaps tracked along the way */
+                    if (!INEXACT && __any(act && !region_ok)) {
+#pragma unroll
+                        for (int t = 0; t < NW; t++) track(t, xw[t]);
+                    }
+                    /* no differing base within k bases of the region's start / end (T coordinates)? */
                     const u64 ex = INEXACT ? lx : fx; /* the word the END side looks at */
                     const int et = INEXACT ? lt : ft;
                     const bool first_clean = fx == 0 || 32 * (w0 + ft) + (__clzll((long long)fx) >> 1) >= X0 + k;
@@ -1464,7 +1491,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
                 if (MODE != 1) { /* the containment pass leaves the candidate list as it is */
                     const u64 mk = __ballot(ov);
-                    if (ov) STREAM_STORE(INEXACT && hidden ? h | HIT_HIDDEN_BIT : h, &row[nkeep + __popcll(mk & lane_mask_lt())]);
+                    if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = INEXACT && hidden ? h | HIT_HIDDEN_BIT : h;
                     nkeep += __popcll(mk);
                 }
                 __syncthreads();
@@ -1473,15 +1500,15 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
              * first batch's code path: a load there would make the compiler drain the whole pipeline) */
             if (PREF) {
                 u64 w[staged ? NW : 1];
-#pragma unroll
-                for (int t = 0; t < (staged ? NW : 1); t++) w[t] = R0.w[t % RW];
-                batch(lane < c, h0, w);
+                w[0] = 0;
+                stage_rows(R0);
+                batch(lane < c, h0, w, true);
             } else { /* wide rows (and the generic variant): fetched now */
                 const bool act = lane < c;
                 u64 w[staged ? NW : 1];
                 w[0] = 0;
                 if (staged) load_row(w, (act && in_pass(h0, LA)) ? a.v.reads + HIT_ID(h0) * S : ga);
-                batch(act, h0, w);
+                batch(act, h0, w, false);
             }
             for (u32 i0 = 64; i0 < c; i0 += 64) {
                 const bool act = i0 + lane < c;
@@ -1489,7 +1516,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 u64 w[staged ? NW : 1];
                 w[0] = 0;
                 if (staged) load_row(w, (act && in_pass(h, LA)) ? a.v.reads + HIT_ID(h) * S : ga);
-                batch(act, act ? h : 0ull, w);
+                batch(act, act ? h : 0ull, w, false);
             }
             if (MODE != 1) {
                 if (lane == 0) {
