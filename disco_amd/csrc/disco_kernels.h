@@ -1319,9 +1319,10 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             for (int p = 0; p < NQ; p++) {
                 u64 *dst = s_b + 1 + (16 * p + (lane >> 2)) * BST + 2 * qq;
                 dst[0] = r.q[p].x;
-                dst[1] = 2 * qq + 1 < (u32)NW ? r.q[p].y : 0ull; /* (NW odd: the word behind the row stays zero) */
+                dst[1] = r.q[p].y;
             }
         }
+        if (NW & 1) s_b[1 + lane * BST + NW] = 0; /* NW odd: the last quarter brought one word too many; the word behind a row stays zero */
     };
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
     {
@@ -1416,7 +1417,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                      * is this read's end k-mer inside it, the seed of the TWIN find: inexact overlaps read both ends
                      * (HIT_HIDDEN_BIT). The XOR words stay in registers; the scan for the first / last one runs when it is needed. */
                     const bool at_start = prefix_align != (rev != 0);
-                    u64 xw[NW > 0 ? NW : 1]; /* exact: the region's XOR words (zero behind the region) */
+                    u64 xw[NW > 0 ? NW : 1]; /* exact: the region's XOR words t <= nl (the others are never read: no cost to keep them) */
                     u64 diff = 0;
                     u64 fx = 0, lx = 0; /* first / last non-zero XOR word ... */
                     int ft = 0, lt = 0; /* ... and which word it is */
@@ -1439,7 +1440,6 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                     if (act) blo = bp[0];
 #pragma unroll
                     for (int t = 0; t < NW; t++) {
-                        xw[t] = 0;
                         if (!__any(t <= nl)) continue;
                         if (t <= nl) {
                             const u64 bhi = bp[t + 1];
@@ -1459,7 +1459,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                      * real ones; inexact overlaps tracked along the way */
                     if (!INEXACT && __any(act && !region_ok)) {
 #pragma unroll
-                        for (int t = 0; t < NW; t++) track(t, xw[t]);
+                        for (int t = 0; t < NW; t++)
+                            if (t <= nl) track(t, xw[t]);
                     }
                     /* no differing base within k bases of the region's start / end (T coordinates)? */
                     const u64 ex = INEXACT ? lx : fx; /* the word the END side looks at */
