@@ -1516,8 +1516,17 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 const u64 h = row[act ? i0 + lane : 0];
                 u64 w[staged ? NW : 1];
                 w[0] = 0;
-                if (staged) load_row(w, (act && in_pass(h, LA)) ? a.v.reads + HIT_ID(h) * S : ga);
-                batch(act, act ? h : 0ull, w, false);
+                if (PREF) { /* the same cooperative fetch, on the spot (100x coverage: two of a read's three batches) */
+                    Meta mb;
+                    mb.c = c - i0;
+                    mb.L = LA;
+                    mb.rs = 0;
+                    stage_rows(load_rows(mb, h, A));
+                    batch(act, act ? h : 0ull, w, true);
+                } else {
+                    if (staged) load_row(w, (act && in_pass(h, LA)) ? a.v.reads + HIT_ID(h) * S : ga);
+                    batch(act, act ? h : 0ull, w, false);
+                }
             }
             if (MODE != 1) {
                 if (lane == 0) {
