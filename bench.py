@@ -251,6 +251,23 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if world > 1:
+        # a multi-rank run that stops making progress (a rank lost, a collective that never completes) must end by itself with a
+        # message, not sit in a collective until somebody else's limit kills the box: stacks to stderr, then exit
+        import faulthandler
+        import threading
+
+        limit = float(os.environ.get("DISCO_BENCH_WATCHDOG_S", "900"))
+
+        def _expired():
+            sys.stderr.write(f"bench.py: rank {rank} of {world} still running after {limit:.0f} s — giving up (DISCO_BENCH_WATCHDOG_S)\n")
+            faulthandler.dump_traceback(file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(124)
+
+        wd = threading.Timer(limit, _expired)
+        wd.daemon = True
+        wd.start()
     import torch
 
     from disco_amd import buildgraph, launch, readgen
