@@ -1324,6 +1324,32 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
         }
         if (NW & 1) s_b[1 + lane * BST + NW] = 0; /* NW odd: the last quarter brought one word too many; the word behind a row stays zero */
     };
+    /* wide rows (NW = 16 / 24 / 32 words, fetched when their read's turn comes): the same idea — NW / 2 lanes per row, 16 bytes each,
+     * 8 / 5 / 4 rows per load instruction — straight into the staging area. (One lane per row meant NW / 2 instructions of 64 lines
+     * each.) cnt: candidates of this batch, h: this lane's, A / LA: the read */
+    auto fetch_wide_rows = [&](u32 cnt, u64 h, u64 A, int LA) {
+        constexpr int LR = NW > VERIFY_SW ? NW / 2 : 1; /* lanes per row */
+        constexpr int RPI = 64 / LR;                    /* rows per instruction */
+        constexpr int NI = (64 + RPI - 1) / RPI;        /* instructions per batch */
+        const u32 vid = (lane < cnt && in_pass(h, LA)) ? (u32)HIT_ID(h) : (u32)A;
+        const u32 sub = lane % (u32)LR, rsel = lane / (u32)LR;
+        ulonglong2 q[NI];
+#pragma unroll
+        for (int p = 0; p < NI; p++) {
+            const u32 r = (u32)(p * RPI) + rsel;
+            const u32 id = (u32)__shfl((int)vid, (int)(r < 64u ? r : 0u));
+            q[p] = ((const ulonglong2 *)(a.v.reads + (u64)id * S))[sub];
+        }
+#pragma unroll
+        for (int p = 0; p < NI; p++) {
+            const u32 r = (u32)(p * RPI) + rsel;
+            if (rsel < (u32)RPI && r < 64u) {
+                u64 *dst = s_b + 1 + r * BST + 2 * sub;
+                dst[0] = q[p].x;
+                dst[1] = q[p].y;
+            }
+        }
+    };
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
     {
         const u64 i = cbeg + (lane < cend - cbeg ? lane : 0u); /* WQ_CHUNK <= 64: one lane per read of the chunk */
@@ -1508,8 +1534,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 const bool act = lane < c;
                 u64 w[staged ? NW : 1];
                 w[0] = 0;
-                if (staged) load_row(w, (act && in_pass(h0, LA)) ? a.v.reads + HIT_ID(h0) * S : ga);
-                batch(act, h0, w, false);
+                if (staged) fetch_wide_rows(c, h0, A, LA);
+                batch(act, h0, w, staged);
             }
             for (u32 i0 = 64; i0 < c; i0 += 64) {
                 const bool act = i0 + lane < c;
@@ -1524,8 +1550,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                     stage_rows(load_rows(mb, h, A));
                     batch(act, act ? h : 0ull, w, true);
                 } else {
-                    if (staged) load_row(w, (act && in_pass(h, LA)) ? a.v.reads + HIT_ID(h) * S : ga);
-                    batch(act, act ? h : 0ull, w, false);
+                    if (staged) fetch_wide_rows(c - i0, h, A, LA);
+                    batch(act, act ? h : 0ull, w, staged);
                 }
             }
             if (MODE != 1) {
