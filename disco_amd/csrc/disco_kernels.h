@@ -1194,8 +1194,8 @@ __device__ __forceinline__ u64 uniform_u64(u64 x)
 template <int NW, int MODE = 0, bool INEXACT = false>
 __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(VerifyArgs a)
 {
-    /* staged: the candidate rows (one per lane, NW words + zero words behind; odd stride; the last zero word of a lane is
-     * the zero word in front of the next lane's row), the read's own row and its reverse complement live in LDS with a
+    /* staged: the candidate rows (row i = candidate i = lane i's: NW words + zero words behind; odd stride; the last zero word of a
+     * row is the zero word in front of the next one), the read's own row and its reverse complement live in LDS with a
      * statically known address space; the zero words make the shifted extracts branch free */
     constexpr bool staged = NW != 0;
     constexpr bool PREF = NW != 0 && NW <= VERIFY_SW; /* candidate rows prefetched into registers one read ahead */
@@ -1270,23 +1270,6 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
         const bool ok = lane < mt.c;
         const u64 h = a.hits[ok ? mt.rs + lane : (mt.c ? mt.rs : (A & 0xFFFFull))]; /* the hit buffer has more than 65536 slots */
         return ok ? h : 0ull;
-    };
-    auto load_row = [&](u64 (&w)[staged ? NW : 1], const u64 *g) {
-        if (NW > VERIFY_SW) {
-#pragma unroll
-            for (int t = 0; t < NW; t += 2) {
-                const ulonglong2 q = ((const ulonglong2 *)g)[t / 2];
-                w[t % (staged ? NW : 1)] = q.x;
-                w[(t + 1) % (staged ? NW : 1)] = q.y;
-            }
-        } else if (NW == 5) { /* 16 + 16 + 8 bytes */
-            const ulonglong2 q0 = ((const ulonglong2 *)g)[0], q1 = ((const ulonglong2 *)g)[1];
-            w[0] = q0.x; w[1] = q0.y; w[2 % (staged ? NW : 1)] = q1.x; w[3 % (staged ? NW : 1)] = q1.y; w[4 % (staged ? NW : 1)] = g[4];
-        } else if (NW == 8) {
-            const ulonglong2 q0 = ((const ulonglong2 *)g)[0], q1 = ((const ulonglong2 *)g)[1], q2 = ((const ulonglong2 *)g)[2], q3 = ((const ulonglong2 *)g)[3];
-            w[0] = q0.x; w[1] = q0.y; w[2 % (staged ? NW : 1)] = q1.x; w[3 % (staged ? NW : 1)] = q1.y;
-            w[4 % (staged ? NW : 1)] = q2.x; w[5 % (staged ? NW : 1)] = q2.y; w[6 % (staged ? NW : 1)] = q3.x; w[7 % (staged ? NW : 1)] = q3.y;
-        }
     };
     auto load_rows = [&](const Meta &mt, u64 h, u64 A) {
         Rows r;
@@ -1388,7 +1371,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             }
             u32 nkeep = 0;
             /* one batch of 64 candidates: lane = candidate h with its row words w (staged variants) */
-            auto batch = [&](const bool act0, const u64 h, const u64 (&w)[staged ? NW : 1], const bool rows_staged) {
+            auto batch = [&](const bool act0, const u64 h) { /* (staged variants: the batch's rows are in the staging area) */
                 const bool act = act0 && in_pass(h, LA);
                 bool ov = false;
                 const int j = (int)HIT_J(h);
@@ -1409,11 +1392,6 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                     overlap = d <= 0 && j >= 1; /* :591 */
                 }
                 if (staged) {
-                    if (act && !rows_staged) {
-                        u64 *sb = s_b + 1 + lane * BST;
-#pragma unroll
-                        for (int t = 0; t < NW; t++) sb[t] = w[t % (staged ? NW : 1)];
-                    }
                     __syncthreads();
                     /* ONE pass of XORs over the aligned region. A reversed candidate is compared as revcomp(A) against B itself
                      * (coordinates y = LA-1-x), so no candidate row is ever reverse-complemented:
@@ -1526,33 +1504,24 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             /* the first 64 candidates and their rows were prefetched; longer rows fetch the rest on the spot (kept out of the
              * first batch's code path: a load there would make the compiler drain the whole pipeline) */
             if (PREF) {
-                u64 w[staged ? NW : 1];
-                w[0] = 0;
                 stage_rows(R0);
-                batch(lane < c, h0, w, true);
-            } else { /* wide rows (and the generic variant): fetched now */
-                const bool act = lane < c;
-                u64 w[staged ? NW : 1];
-                w[0] = 0;
+                batch(lane < c, h0);
+            } else { /* wide rows: fetched now (the generic variant compares from global memory) */
                 if (staged) fetch_wide_rows(c, h0, A, LA);
-                batch(act, h0, w, staged);
+                batch(lane < c, h0);
             }
             for (u32 i0 = 64; i0 < c; i0 += 64) {
                 const bool act = i0 + lane < c;
                 const u64 h = row[act ? i0 + lane : 0];
-                u64 w[staged ? NW : 1];
-                w[0] = 0;
                 if (PREF) { /* the same cooperative fetch, on the spot (100x coverage: two of a read's three batches) */
                     Meta mb;
                     mb.c = c - i0;
                     mb.L = LA;
                     mb.rs = 0;
                     stage_rows(load_rows(mb, h, A));
-                    batch(act, act ? h : 0ull, w, true);
-                } else {
-                    if (staged) fetch_wide_rows(c - i0, h, A, LA);
-                    batch(act, act ? h : 0ull, w, staged);
-                }
+                } else if (staged)
+                    fetch_wide_rows(c - i0, h, A, LA);
+                batch(act, act ? h : 0ull);
             }
             if (MODE != 1) {
                 if (lane == 0) {
