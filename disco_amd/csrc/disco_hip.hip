@@ -34,6 +34,8 @@
 #include "../../include/disco_hip.h"
 #include "disco_kernels.h"
 #include "disco_dist.h"
+
+#define DROP_LIST_CAP (1u << 20) /* dropped hits edge selection writes down for the twin search (16 MB); more than that: the bitmap search */
 #include "disco_chains.h"
 #include "disco_text.h"
 #include "disco_ingest.h"
@@ -191,6 +193,8 @@ struct disco_ctx {
     u8 *d_contained = nullptr;
     u64 *d_cbits = nullptr; /* one bit per read */
     u64 *d_dropbits = nullptr; /* one bit per read: its edge selection dropped a verified hit; valid for reads [drop_lo, drop_hi) */
+    u64 *d_drop_node = nullptr, *d_drop_key = nullptr; /* exact overlaps: the dropped hits themselves (EdgeSelArgs.drop_node), DROP_LIST_CAP items */
+    u64 n_drop_items = 0;                              /* how many the last selection recorded (or would have: > DROP_LIST_CAP = list useless) */
     u64 drop_lo = 0, drop_hi = 0;
     u64 n_contained = 0;
 
@@ -482,6 +486,8 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_contained, c->n_alloc);
     dev_free(c, &c->d_cbits, c->n_alloc / 64 + 1);
     dev_free(c, &c->d_dropbits, c->n_alloc / 64 + 1);
+    dev_free(c, &c->d_drop_node, DROP_LIST_CAP);
+    dev_free(c, &c->d_drop_key, DROP_LIST_CAP);
     dev_free(c, &c->d_adj_ref, c->n);
     dev_free(c, &c->d_adj_own, c->adj_cap);
     dev_free(c, &c->d_adj_spare, c->adj_spare_cap);
@@ -1879,6 +1885,16 @@ static int select_edges(disco_ctx *c)
     c->drop_hi = c->q_hi;
     a.dropbits = c->d_dropbits;
     a.hidden_flags = c->prm.max_substitutions != 0;
+    a.drop_node = a.drop_key = nullptr;
+    a.drop_cap = 0;
+    CHK(zero_counter(c, CTR_DROP_ITEMS));
+    if (c->prm.max_substitutions == 0 && !getenv("DISCO_NO_DROP_LIST")) {
+        if (!c->d_drop_node) CHK(dev_alloc(c, &c->d_drop_node, DROP_LIST_CAP));
+        if (!c->d_drop_key) CHK(dev_alloc(c, &c->d_drop_key, DROP_LIST_CAP));
+        a.drop_node = c->d_drop_node;
+        a.drop_key = c->d_drop_key;
+        a.drop_cap = DROP_LIST_CAP;
+    }
     a.contained = c->d_cbits;
     a.hits = c->d_hits;
     a.row_start = c->d_row_start;
@@ -1923,6 +1939,7 @@ static int select_edges(disco_ctx *c)
         CHK(rc);
     }
     c->dropped = c->dropped_local = c->h_ctr[CTR_DROPPED];
+    c->n_drop_items = a.drop_node ? c->h_ctr[CTR_DROP_ITEMS] : ~0ull;
     if (getenv("DISCO_VERBOSE"))
         fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
                 (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
@@ -1982,14 +1999,19 @@ static int twin_check_search(disco_ctx *c, u64 lo, u64 hi)
     /* Something was dropped — but only the lists of the reads that dropped something can lack a twin (same argument, per read):
      * with their bitmap at hand the search is limited to finds INTO those reads, a few thousand instead of every entry of
      * every list (real data always drop something at their repeats: 95 -> 5 ms at 50 M reads with 0.3 % errors) */
-    const bool by_bitmap = c->d_dropbits && lo >= c->drop_lo && hi <= c->drop_hi && !getenv("DISCO_FORCE_TWIN_CHECK");
+    /* One GPU, exact overlaps: the dropped hits themselves are on a list (every one of them, or the list is not used). A twin is missing
+     * from w's list only where w dropped exactly that hit, so each item is looked up once in the OTHER read's list — no pass over the
+     * entries at all (16 -> 0.1 ms at 50 M reads with 0.1 % errors) */
+    const bool by_list = c->prm.max_substitutions == 0 && c->d_drop_node && lo == 0 && hi == c->n && c->q_lo == 0 && c->q_hi == c->n && !c->adj_imported &&
+                         c->n_drop_items == c->dropped && c->n_drop_items <= DROP_LIST_CAP && !getenv("DISCO_FORCE_TWIN_CHECK");
+    const bool by_bitmap = !by_list && c->d_dropbits && lo >= c->drop_lo && hi <= c->drop_hi && !getenv("DISCO_FORCE_TWIN_CHECK");
     a.dropbits = by_bitmap ? c->d_dropbits : nullptr;
     /* inexact overlaps: the same, plus every find verify_kernel flagged as hidden from the other read (a substitution inside this
      * read's end k-mer there) — 0.13 -> 0.04 s of search at 50 M reads with 0.3 % errors */
     a.hidden_flags = by_bitmap && c->prm.max_substitutions != 0;
     /* (inexact overlaps: one-sided pairs are the rule — a substitution inside an end k-mer hides the pair from the other read —
      * so the proof of symmetry is not attempted) */
-    if (!by_bitmap && c->prm.max_substitutions == 0) {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
+    if (!by_bitmap && !by_list && c->prm.max_substitutions == 0) {   /* one-sided pass: half the searches, no extras. Symmetric iff nothing is missing and #up == #down. */
         CHK(zero_counter(c, CTR_ASYM));
         CHK(zero_counter(c, CTR_TW_UP));
         CHK(zero_counter(c, CTR_TW_DOWN));
@@ -2014,6 +2036,7 @@ static int twin_check_search(disco_ctx *c, u64 lo, u64 hi)
         }
     }
     u32 want = std::max<u32>(4096, c->extra_cap); /* the lists kept from the last pass are the best guess */
+    if (by_list) want = std::max<u32>(want, (u32)c->n_drop_items); /* (an item yields at most one extra) */
     for (int attempt = 0; attempt < 6; attempt++) {
         if (want > c->extra_cap) {
             dev_free(c, &c->d_extra_node, c->extra_cap);
@@ -2031,7 +2054,12 @@ static int twin_check_search(disco_ctx *c, u64 lo, u64 hi)
         a.extra_cap = c->extra_cap;
         a.up_only = 0;
         ph_begin(c, DISCO_PH_TWIN);
-        if (c->n) hipLaunchKernelGGL(twin_check_kernel, dim3(flat_grid(c, c->n * 64)), dim3(256), 0, c->stream, a);
+        if (by_list) {
+            if (c->n_drop_items)
+                hipLaunchKernelGGL(twin_from_drops_kernel, dim3(flat_grid(c, c->n_drop_items)), dim3(256), 0, c->stream, a, (const u64 *)c->d_drop_node,
+                                   (const u64 *)c->d_drop_key, (u32)c->n_drop_items);
+        } else if (c->n)
+            hipLaunchKernelGGL(twin_check_kernel, dim3(flat_grid(c, c->n * 64)), dim3(256), 0, c->stream, a);
         ph_end(c, DISCO_PH_TWIN);
         HIPCHK(c, hipGetLastError());
         u32 ne = 0;

@@ -69,6 +69,7 @@ enum {
     CTR_MAX_LEN, /* longest read */
     CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
     CTR_MIN_LEN, /* ~shortest read (stored complemented so that atomicMax finds the minimum from a zeroed counter) */
+    CTR_DROP_ITEMS, /* dropped hits recorded in (or, beyond its capacity, lost to) the drop list of edge selection */
     CTR_COUNT
 };
 
@@ -1673,6 +1674,11 @@ struct EdgeSelArgs {
     const u64 *order;
     const ulonglong2 *meta_ord;
     u64 *dropbits; /* out: one bit per read whose selection dropped a verified hit (only those lists can lack a twin: twin_check) */
+    /* exact overlaps, or null: every dropped hit as {read, the entry it would have become}. A twin can be missing from a list only where
+     * its owner dropped exactly that hit (twin_check in disco_hip.hip), so the twin search needs these few thousand items, not a
+     * pass over every entry of every list (16 ms at 50 M reads with 0.1 % errors — real reads always drop something) */
+    u64 *drop_node, *drop_key;
+    u32 drop_cap;
     u32 hidden_flags; /* inexact overlaps: verified hits carry HIT_HIDDEN_BIT; it is kept out of the consumption order and handed on in
                          the entry's ADJ_FLAG bit (ADJ_HIDDEN_OF) */
 };
@@ -1704,6 +1710,19 @@ __device__ __forceinline__ void lds_bitonic_sort(u64 *h, u32 P, u32 lane)
             }
             __syncthreads();
         }
+}
+
+/* one lane: the dropped verified hit of read A goes to the drop list */
+__device__ __forceinline__ void record_drop(const EdgeSelArgs &a, u64 A, u32 LA, u64 hit)
+{
+    if (!a.drop_node) return;
+    const u64 idx = atomicAdd(&a.v.ctr[CTR_DROP_ITEMS], 1ull);
+    if (idx < a.drop_cap) {
+        u32 orient, off;
+        disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, HIT_J(hit), &orient, &off);
+        a.drop_node[idx] = A;
+        a.drop_key[idx] = ADJ_MAKE(off, HIT_ID(hit), orient, HIT_LEN(hit));
+    }
 }
 
 /* WCAP > 0: h / t are LDS arrays of WCAP entries (a power of two) and s_jcnt a 128-slot LDS histogram: rows of up to WCAP hits
@@ -1805,10 +1824,16 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
             ctr = 0;
             capflag = false;
         }
-        if (ctr >= a.max_per_kmer && capflag) continue;
+        if (ctr >= a.max_per_kmer && capflag) {
+            if (lane == 0) record_drop(a, A, LA, hit);
+            continue;
+        }
         bool seen = false;
         for (u32 x = lane; x < nacc; x += 64) seen |= (ADJ_DST(h[x]) == B);
-        if (__any(seen)) continue;
+        if (__any(seen)) {
+            if (lane == 0) record_drop(a, A, LA, hit);
+            continue;
+        }
         if (ctr < a.max_per_kmer) {
             u32 orient, off;
             disco_map_type(disco_hit_type(HIT_SUFFIX(hit), HIT_REV(hit)), LA, (u32)a.v.k, j, &orient, &off);
@@ -1819,6 +1844,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
         } else {
             cap_sites++; /* the cap cut off a hit that would have been accepted */
             capflag = true;
+            if (lane == 0) record_drop(a, A, LA, hit);
         }
     }
     __syncthreads();
@@ -1861,6 +1887,7 @@ __device__ __forceinline__ bool edge_select_row_fast(const EdgeSelArgs &a, u64 A
     const u64 range = lt & ~((1ull << gs) - 1ull);
     const bool viol = nondup && (u32)__popcll(nd & range) >= a.max_per_kmer;
     if (__any(viol)) return false;
+    if (valid && dup) record_drop(a, A, LA, hit);
     u64 ent = ~0ull;
     if (nondup) {
         u32 orient, off;
@@ -2289,6 +2316,28 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
         if (asym) atomicAdd(&a.v.ctr[CTR_ASYM], (u64)asym);
         if (n_up) atomicAdd(&a.v.ctr[CTR_TW_UP], (u64)n_up);
         if (n_down) atomicAdd(&a.v.ctr[CTR_TW_DOWN], (u64)n_down);
+    }
+}
+
+/* the same from edge selection's drop list (exact overlaps, one GPU): item = {w, the entry w -> u that w did not keep}. Its twin u -> w
+ * in u's list <=> the pair is one-sided and the entry is owed to w. Thread per item. */
+__global__ void __launch_bounds__(256) twin_from_drops_kernel(TwinArgs a, const u64 *__restrict__ drop_node, const u64 *__restrict__ drop_key, u32 n_drop)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_drop; i += gridDim.x * blockDim.x) {
+        const u64 w = drop_node[i], e = drop_key[i];
+        const u64 u = ADJ_DST(e);
+        const u32 Lw = a.v.len[w];
+        const u64 twin = ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lw, w, disco_twin_orient(ADJ_ORI(e)), Lw); /* u -> w */
+        const u64 ru = a.ref[u];
+        if (adj_find(a.adj + REF_POS(ru), REF_DEG(ru), twin) < 0) continue;
+        atomicAdd(&a.v.ctr[CTR_ASYM], 1ull);
+        const u32 idx = atomicAdd(a.n_extra, 1u);
+        if (idx < a.extra_cap) {
+            a.extra_node[idx] = EXTRA_NODE_MAKE(w, atomicAdd(&a.extra_cnt[w], 1u));
+            a.extra_key[idx] = e;
+        } else
+            atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
     }
 }
 

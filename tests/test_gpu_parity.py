@@ -87,6 +87,15 @@ def test_twin_check_shortcut_is_sound(monkeypatch):
         (ce1, cc1), (ce2, cc2) = canon_hip(e1, r1), canon_hip(e2, r2)  # the emission order is not defined
         assert np.array_equal(ce1, ce2) and np.array_equal(cc1, cc2)
         assert c1["asymmetric_pairs"] == c2["asymmetric_pairs"] and c1["e_pre"] == c2["e_pre"]
+        # the third way to the same answer: without the list of dropped hits the search goes by the bitmap of the reads that dropped
+        # something (what the multi-GPU flow and selections with more than 2^20 drops use)
+        monkeypatch.delenv("DISCO_FORCE_TWIN_CHECK")
+        monkeypatch.setenv("DISCO_NO_DROP_LIST", "1")
+        e3, r3, c3 = run_hip_reads(reads, mo)
+        monkeypatch.delenv("DISCO_NO_DROP_LIST")
+        ce3, cc3 = canon_hip(e3, r3)
+        assert np.array_equal(ce1, ce3) and np.array_equal(cc1, cc3)
+        assert c1["asymmetric_pairs"] == c3["asymmetric_pairs"] and c1["e_pre"] == c3["e_pre"]
 
 
 def test_long_reads_generic_stride_paths():

@@ -73,7 +73,7 @@ for n, lmin, lmax, cov, nc, skew, ppm, tsub in SHAPES:
     try:
         a, da = single()
         b, _ = single(flags=buildgraph.FLAG_TWO_PASS_VERIFY) if not tsub else single(env={"DISCO_FORCE_TWIN_CHECK": "1"})  # (inexact: the full twin search instead)
-        c_, _ = single(env={"DISCO_NO_RUNS": "1"})
+        c_, _ = single(env={"DISCO_NO_RUNS": "1", "DISCO_NO_DROP_LIST": "1"})  # round 2's probe; the twin search by bitmap instead of the drop list
         e4, r4, info, _ = run_ranks(4, 40, setup, max_substitutions=tsub)
         d4 = digests(e4, r4)
         _, _, infop, _ = run_ranks(4, 40, setup, partitioned_index=True, max_substitutions=tsub)
