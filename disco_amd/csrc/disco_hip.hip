@@ -1893,7 +1893,7 @@ static int select_edges(disco_ctx *c)
         if (!c->d_drop_key) CHK(dev_alloc(c, &c->d_drop_key, DROP_LIST_CAP));
         a.drop_node = c->d_drop_node;
         a.drop_key = c->d_drop_key;
-        a.drop_cap = DROP_LIST_CAP;
+        a.drop_cap = (u32)std::min<u64>(DROP_LIST_CAP, (u64)env_int("DISCO_DROP_LIST_CAP", (int)DROP_LIST_CAP)); /* (tests: a list that overflows) */
     }
     a.contained = c->d_cbits;
     a.hits = c->d_hits;
@@ -2003,7 +2003,7 @@ static int twin_check_search(disco_ctx *c, u64 lo, u64 hi)
      * from w's list only where w dropped exactly that hit, so each item is looked up once in the OTHER read's list — no pass over the
      * entries at all (16 -> 0.1 ms at 50 M reads with 0.1 % errors) */
     const bool by_list = c->prm.max_substitutions == 0 && c->d_drop_node && lo == 0 && hi == c->n && c->q_lo == 0 && c->q_hi == c->n && !c->adj_imported &&
-                         c->n_drop_items == c->dropped && c->n_drop_items <= DROP_LIST_CAP && !getenv("DISCO_FORCE_TWIN_CHECK");
+                         c->n_drop_items == c->dropped && c->n_drop_items <= (u64)env_int("DISCO_DROP_LIST_CAP", (int)DROP_LIST_CAP) && !getenv("DISCO_FORCE_TWIN_CHECK");
     const bool by_bitmap = !by_list && c->d_dropbits && lo >= c->drop_lo && hi <= c->drop_hi && !getenv("DISCO_FORCE_TWIN_CHECK");
     a.dropbits = by_bitmap ? c->d_dropbits : nullptr;
     /* inexact overlaps: the same, plus every find verify_kernel flagged as hidden from the other read (a substitution inside this

@@ -1716,6 +1716,9 @@ __device__ __forceinline__ void lds_bitonic_sort(u64 *h, u32 P, u32 lane)
 __device__ __forceinline__ void record_drop(const EdgeSelArgs &a, u64 A, u32 LA, u64 hit)
 {
     if (!a.drop_node) return;
+    /* a full list is a useless list (the host falls back to the bitmap search when the count differs from the number of drops): stop
+     * counting then — a repeat-rich read set drops hits by the hundred million, all on this one address */
+    if (__atomic_load_n(&a.v.ctr[CTR_DROP_ITEMS], __ATOMIC_RELAXED) >= a.drop_cap) return;
     const u64 idx = atomicAdd(&a.v.ctr[CTR_DROP_ITEMS], 1ull);
     if (idx < a.drop_cap) {
         u32 orient, off;

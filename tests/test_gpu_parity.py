@@ -96,6 +96,13 @@ def test_twin_check_shortcut_is_sound(monkeypatch):
         ce3, cc3 = canon_hip(e3, r3)
         assert np.array_equal(ce1, ce3) and np.array_equal(cc1, cc3)
         assert c1["asymmetric_pairs"] == c3["asymmetric_pairs"] and c1["e_pre"] == c3["e_pre"]
+        # ... and a list that is too short for what was dropped must be noticed and left unused
+        monkeypatch.setenv("DISCO_DROP_LIST_CAP", "3")
+        e4, r4, c4 = run_hip_reads(reads, mo)
+        monkeypatch.delenv("DISCO_DROP_LIST_CAP")
+        ce4, cc4 = canon_hip(e4, r4)
+        assert np.array_equal(ce1, ce4) and np.array_equal(cc1, cc4)
+        assert c1["asymmetric_pairs"] == c4["asymmetric_pairs"] and c1["e_pre"] == c4["e_pre"]
 
 
 def test_long_reads_generic_stride_paths():
