@@ -1760,13 +1760,18 @@ int disco_probe(disco_ctx *c)
             const bool two_pass = !inexact && (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && c->S == VERIFY_SW && (nq || c->dist_active) &&
                                   (u64)c->min_len * 10 < (u64)c->max_len * 9 && !getenv("DISCO_NO_TWO_PASS");
             c->two_pass_last = two_pass;
+            /* 64-byte rows, exact overlaps: candidates of a 64-read chunk as one flat list, full wavefronts (verify_flat_kernel) */
+            const bool flat = !inexact && c->S == VERIFY_SW && !getenv("DISCO_NO_FLAT_VERIFY");
             ph_begin(c, DISCO_PH_VERIFY);
             if (two_pass) {
                 if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
                 if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
                 va.cbits = c->d_cbits;
                 const bool short_rows = c->max_len <= 160;
-                if (nq) {
+                if (nq && flat) {
+                    if (short_rows) hipLaunchKernelGGL((verify_flat_kernel<5, 1>), dim3(wq_grid(c, verify_flat_kernel<5, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                    else hipLaunchKernelGGL((verify_flat_kernel<8, 1>), dim3(wq_grid(c, verify_flat_kernel<8, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                } else if (nq) {
                     if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 1>), dim3(wq_grid(c, verify_kernel<5, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                     else hipLaunchKernelGGL((verify_kernel<8, 1>), dim3(wq_grid(c, verify_kernel<8, 1>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 }
@@ -1777,7 +1782,10 @@ int disco_probe(disco_ctx *c)
                     CHK(zero_counter(c, CTR_N_CONTAINED));
                     hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
                 }
-                if (nq) {
+                if (nq && flat) {
+                    if (short_rows) hipLaunchKernelGGL((verify_flat_kernel<5, 2>), dim3(wq_grid(c, verify_flat_kernel<5, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                    else hipLaunchKernelGGL((verify_flat_kernel<8, 2>), dim3(wq_grid(c, verify_flat_kernel<8, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                } else if (nq) {
                     if (short_rows) hipLaunchKernelGGL((verify_kernel<5, 2>), dim3(wq_grid(c, verify_kernel<5, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                     else hipLaunchKernelGGL((verify_kernel<8, 2>), dim3(wq_grid(c, verify_kernel<8, 2>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 }
@@ -1793,7 +1801,9 @@ int disco_probe(disco_ctx *c)
 #undef VERIFY_INEXACT
             } else if (nq) {
                 va.cbits = nullptr;
-                if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                if (flat && c->max_len <= 160) hipLaunchKernelGGL(verify_flat_kernel<5>, dim3(wq_grid(c, verify_flat_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (flat) hipLaunchKernelGGL(verify_flat_kernel<8>, dim3(wq_grid(c, verify_flat_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<8>, dim3(wq_grid(c, verify_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == 16) hipLaunchKernelGGL(verify_kernel<16>, dim3(wq_grid(c, verify_kernel<16>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == 24) hipLaunchKernelGGL(verify_kernel<24>, dim3(wq_grid(c, verify_kernel<24>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);

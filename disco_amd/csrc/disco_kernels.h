@@ -1550,6 +1550,291 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
 }
 
 /* ================================================================================================================
+ * verify_flat_kernel (round 4) — the same checkOverlapForContainedRead / checkOverlap compare (BG/OverlapGraph.cpp:517-595) as
+ * verify_kernel, for the 64-byte rows (reads up to 256 bases, exact overlaps), with FULL wavefronts: verify_kernel runs lane =
+ * candidate of ONE read, and a read has 44 candidates (150 bp, 30x): 69 % of the lanes of 276 vector instructions per read. Here the
+ * candidates of the 64 reads of a work-queue chunk are ONE flat list (exclusive scan of the counts in the chunk's headers), cut into
+ * batches of 64 regardless of read boundaries: lane = candidate f of the chunk, its read ("segment") found by a scalar walk over the
+ * few boundaries inside the batch. What used to be scalar per read — own row, reverse complement, length, row start — is per lane:
+ * the 64 reads' rows and reverse complements are staged in LDS once per chunk (lane = read), a lane picks its segment's by address.
+ * Rows of any length are just longer segments (no path of their own). The compare runs on 32-bit words with v_alignbit_b32 (one
+ * full-rate instruction per 16 bases instead of three 64-bit shifts and two ORs per 32): LDS rows hold the dwords in SEQUENCE order
+ * (a packed u64 has its first 16 bases in the HIGH dword). Verified hits are compacted to the front of their own row as before
+ * (segmented rank: ballot prefix minus the prefix at the segment's first lane, plus what the segment kept in earlier batches).
+ * ============================================================================================================== */
+/* bits [bitpos, bitpos + 32) of the MSB-first bit stream d[0], d[1], ... (bitpos >= -31; d[-1] and d[i + 1] readable) */
+__device__ __forceinline__ u32 stream_bits32(const u32 *d, int bitpos)
+{
+    const int i = (bitpos - 1) >> 5;
+    return __builtin_amdgcn_alignbit(d[i], d[i + 1], (u32)(32 * i + 32 - bitpos));
+}
+/* reverse the order of the 16 2-bit groups of x */
+__device__ __forceinline__ u32 rev2_32(u32 x)
+{
+    const u32 y = __brev(x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+/* a copy the compiler cannot see through (register moves at a place of the program's choosing) */
+__device__ __forceinline__ u64 pinned_copy(u64 x)
+{
+    u32 lo, hi;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"((u32)x), "v"((u32)(x >> 32)));
+    return ((u64)hi << 32) | lo;
+}
+#ifndef VERIFY_FLAT_WAVES_PER_SIMD
+#define VERIFY_FLAT_WAVES_PER_SIMD 1
+#endif
+template <int NW, int MODE = 0>
+__global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_kernel(VerifyArgs a)
+{
+    constexpr int ND = 2 * NW;       /* dwords of a row */
+    constexpr int BSTR = ND + 1;     /* candidate row r: dwords [1 + r BSTR, + ND); the dword in front belongs to the row before (never zero, never needed: masked) */
+    constexpr int TSTR = 2 * ND + 1; /* segment s: [1 + s TSTR, + ND) the read, [+ ND, + 2 ND) its reverse complement */
+    constexpr int S = VERIFY_SW;
+    __shared__ u32 s_b[64 * BSTR + ND + 4];
+    __shared__ u32 s_t[64 * TSTR + ND + 4];
+    __shared__ ulonglong2 s_hdr[64]; /* {row start, first flat index | candidates << 32} */
+    __shared__ uint2 s_al[64];       /* {read id, length} */
+    __shared__ u32 s_nk[64];         /* verified hits of the segment */
+    const u32 lane = threadIdx.x;
+    const int k = a.v.k;
+    u64 my_khits = 0, my_raw = 0;
+    u64 cbeg = 0, cend = 0;
+    /* is the candidate of this pass? (verify_kernel's in_pass) */
+    auto in_pass = [&](u64 h, int LA) -> bool {
+        if (MODE == 0) return true;
+        const int j = (int)HIT_J(h), LB = (int)HIT_LEN(h);
+        const bool contain = (HIT_SUFFIX(h) == HIT_REV(h)) ? (LA - j >= LB) : (j + k - LB >= 0);
+        return MODE == 1 ? contain : (!contain && j >= 1);
+    };
+    while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
+        const u32 n = (u32)(cend - cbeg);
+        const u64 ci = cbeg + (lane < n ? lane : 0u);
+        const u64 ordw = a.order ? a.order[ci] : a.v.q_lo + ci;
+        const u32 A = (u32)ORDER_ID(ordw);
+        const ulonglong2 meta = a.meta_ord[ci];
+        /* the read's own row (lane = read) */
+        const ulonglong2 *own = (const ulonglong2 *)(a.v.reads + (u64)A * S);
+        ulonglong2 ow[(NW + 1) / 2];
+#pragma unroll
+        for (int t = 0; t < (NW + 1) / 2; t++) ow[t] = own[t];
+        u32 c = lane < n ? (u32)meta.y : 0u;
+        const int L = (int)(meta.y >> 32);
+        if (MODE == 2) { /* contained reads have nothing left to do */
+            if ((((const u32 *)a.cbits)[A >> 5] >> (A & 31)) & 1u) c = 0u;
+        }
+        const u32 incl = wave_inclusive_add(c);
+        const u32 P = incl - c;
+        const u32 C = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        __syncthreads();
+        s_hdr[lane] = make_ulonglong2(meta.x, (u64)P | ((u64)c << 32));
+        s_al[lane] = make_uint2(A, (u32)L);
+        s_nk[lane] = 0u;
+        u32 *tf = s_t + 1 + lane * TSTR;
+#pragma unroll
+        for (int t = 0; t < NW; t++) {
+            const u64 w = (t & 1) ? ow[t >> 1].y : ow[t >> 1].x;
+            tf[2 * t] = (u32)(w >> 32);
+            tf[2 * t + 1] = (u32)w;
+        }
+        __syncthreads();
+        /* dword g of revcomp(A) = reverse complement of A[L - 16 (g + 1), L - 16 g); what lies beyond the read is masked by every consumer */
+#pragma unroll
+        for (int g = 0; g < ND; g++) {
+            int pos = L - 16 * (g + 1);
+            pos = pos > -15 ? pos : -15;
+            tf[ND + g] = rev2_32(~stream_bits32(tf, 2 * pos));
+        }
+        __syncthreads();
+
+        const u32 nb = (C + 63u) >> 6;
+        u32 sscan = 0; /* wave uniform (kept in a scalar register: readfirstlane): the last segment that starts at or before the first lane of the next batch to be located */
+        /* flat index (clamped to the chunk's last candidate: idle lanes repeat it, a line the wave touches anyway) and segment of this
+         * lane in batch b: a scalar walk over the segment starts inside the batch */
+        auto locate = [&](u32 b, u32 &seg, u32 &f) {
+            const u32 last = C - 1u;
+            f = 64u * b + lane;
+            f = f < last ? f : last;
+            u32 fl = 64u * b + 63u;
+            fl = fl < last ? fl : last;
+            seg = sscan;
+            u32 s = (u32)__builtin_amdgcn_readfirstlane((int)sscan) + 1u;
+            while (s < 64u) {
+                const u32 Ps = (u32)__builtin_amdgcn_readlane((int)P, (int)s);
+                if (Ps > fl) break;
+                seg = f >= Ps ? s : seg;
+                s++;
+            }
+            sscan = s - 1u;
+        };
+        auto load_cand = [&](u32 seg, u32 f) -> u64 {
+            const ulonglong2 hd = s_hdr[seg];
+            return a.hits[hd.x + (u64)(f - (u32)hd.y)];
+        };
+        /* q[p] of a batch: quarter (lane & 3) of the row of candidate 16 p + (lane >> 2) */
+        auto row_ptr = [&](u64 h, u32 seg, int p) -> const ulonglong2 * {
+            u32 vid = (u32)HIT_ID(h);
+            if (MODE != 0) { /* candidates of the other pass: the read's own row instead */
+                const uint2 al = s_al[seg];
+                if (!in_pass(h, (int)al.y)) vid = al.x;
+            }
+            const u32 id = (u32)__shfl((int)vid, (int)(16 * p + (lane >> 2)));
+            return (const ulonglong2 *)(a.v.reads + (u64)id * S) + (lane & 3u);
+        };
+        auto stage_rows = [&](const ulonglong2 q0, const ulonglong2 q1, const ulonglong2 q2, const ulonglong2 q3) {
+            const u32 qq = lane & 3u;
+            u32 *dst = s_b + 1 + (lane >> 2) * BSTR + 4 * qq;
+            if (2 * qq + 1 < (u32)NW) { /* both words of the quarter belong to the row */
+                dst[0] = (u32)(q0.x >> 32), dst[1] = (u32)q0.x, dst[2] = (u32)(q0.y >> 32), dst[3] = (u32)q0.y;
+                dst[16 * BSTR + 0] = (u32)(q1.x >> 32), dst[16 * BSTR + 1] = (u32)q1.x, dst[16 * BSTR + 2] = (u32)(q1.y >> 32), dst[16 * BSTR + 3] = (u32)q1.y;
+                dst[32 * BSTR + 0] = (u32)(q2.x >> 32), dst[32 * BSTR + 1] = (u32)q2.x, dst[32 * BSTR + 2] = (u32)(q2.y >> 32), dst[32 * BSTR + 3] = (u32)q2.y;
+                dst[48 * BSTR + 0] = (u32)(q3.x >> 32), dst[48 * BSTR + 1] = (u32)q3.x, dst[48 * BSTR + 2] = (u32)(q3.y >> 32), dst[48 * BSTR + 3] = (u32)q3.y;
+            } else if (2 * qq < (u32)NW) { /* NW odd: the row's last word */
+                dst[0] = (u32)(q0.x >> 32), dst[1] = (u32)q0.x;
+                dst[16 * BSTR + 0] = (u32)(q1.x >> 32), dst[16 * BSTR + 1] = (u32)q1.x;
+                dst[32 * BSTR + 0] = (u32)(q2.x >> 32), dst[32 * BSTR + 1] = (u32)q2.x;
+                dst[48 * BSTR + 0] = (u32)(q3.x >> 32), dst[48 * BSTR + 1] = (u32)q3.x;
+            }
+        };
+        if (nb) {
+            /* software pipeline: while batch b is compared, the candidate rows of batch b + 1 and the candidates of batch b + 2 are in
+             * flight. Every register that a load targets is free when the load is issued (the rows were staged, the candidates
+             * copied on), so nothing that is still in flight is ever copied (a copy waits for its load) */
+            u32 carry = 0; /* wave uniform: hits the segment that is open at the batch's first lane has kept so far */
+            u32 sg0, sg1, ftmp;
+            locate(0, sg0, ftmp);
+            u64 h0 = load_cand(sg0, ftmp);
+            locate(1, sg1, ftmp);
+            u64 h1 = load_cand(sg1, ftmp);
+            ulonglong2 q0 = *row_ptr(h0, sg0, 0), q1 = *row_ptr(h0, sg0, 1), q2 = *row_ptr(h0, sg0, 2), q3 = *row_ptr(h0, sg0, 3);
+            for (u32 b = 0; b < nb; b++) {
+                __syncthreads();
+                stage_rows(q0, q1, q2, q3);
+                /* (the copies are opaque to the compiler: left alone it keeps h in h0's register, moves h1 -> h0 and the freshly loaded
+                 * value -> h1 at the loop's end, and that last move waits for every load of the iteration) */
+                const u64 h = pinned_copy(h0);
+                const u32 seg = sg0;
+                q0 = *row_ptr(h1, sg1, 0);
+                q1 = *row_ptr(h1, sg1, 1);
+                q2 = *row_ptr(h1, sg1, 2);
+                q3 = *row_ptr(h1, sg1, 3);
+                h0 = pinned_copy(h1);
+                sg0 = sg1;
+                locate(b + 2, sg1, ftmp);
+                h1 = load_cand(sg1, ftmp);
+                __syncthreads();
+                const bool valid = 64u * b + lane < C;
+                const ulonglong2 hd = s_hdr[seg];
+                const uint2 al = s_al[seg];
+                const u32 Pseg = (u32)hd.y, cseg = (u32)(hd.y >> 32);
+                const u32 Aseg = al.x;
+                const int LA = (int)al.y;
+                const bool act = valid && in_pass(h, LA);
+                const int j = (int)HIT_J(h);
+                const u32 B = (u32)HIT_ID(h);
+                const int LB = (int)HIT_LEN(h);
+                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
+                /* s2 = B or revcomp(B); s2[p] lies under A[p + d]; aligned region in A coordinates [x0, x1) */
+                const int d = prefix_align ? j : j + k - LB;
+                const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
+                bool contain, overlap;
+                if (prefix_align) {
+                    contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
+                    overlap = !contain && j >= 1; /* :579 */
+                } else {
+                    contain = d >= 0;           /* :547 */
+                    overlap = d <= 0 && j >= 1; /* :591 */
+                }
+                /* a reversed candidate is compared as revcomp(A) against B itself (coordinates y = LA-1-x):
+                 * T[X] == B[X - dd] for X in [X0, X1), T = A or revcomp(A) */
+                const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
+                const int dd = rev ? LA - LB - d : d;
+                const int W0 = X0 >> 4, nl = ((X1 - 1) >> 4) - W0; /* first dword of the region in T, index of its last one */
+                const int bitpos = 2 * (16 * W0 - dd);             /* >= -30: B's bit under the first bit of T's dword W0 */
+                const int i0 = (bitpos - 1) >> 5;
+                const u32 sh = (u32)(32 * i0 + 32 - bitpos);
+                const u32 *bp = s_b + 1 + lane * BSTR + i0;
+                const u32 *tp = s_t + 1 + seg * TSTR + (rev ? ND : 0) + W0;
+                const u32 fm = ~0u >> (2 * (X0 & 15)), lm = ~0u << (30 - 2 * ((X1 - 1) & 15));
+                u32 bd[ND + 1], td[ND];
+#pragma unroll
+                for (int t = 0; t <= ND; t++) bd[t] = bp[t];
+#pragma unroll
+                for (int t = 0; t < ND; t++) td[t] = tp[t];
+                u32 diff = 0;
+                /* dwords in front of the region's last one: whole (the first one under fm) */
+#pragma unroll
+                for (int t = 0; t < ND - 1; t++) {
+                    u32 x = __builtin_amdgcn_alignbit(bd[t], bd[t + 1], sh) ^ td[t];
+                    if (t == 0) x &= fm;
+                    diff |= t < nl ? x : 0u;
+                }
+                { /* the last one, wherever it is */
+                    const u32 x = __builtin_amdgcn_alignbit(bp[nl], bp[nl + 1], sh) ^ tp[nl];
+                    diff |= x & (nl == 0 ? (lm & fm) : lm);
+                }
+                const bool region_ok = act && diff == 0;
+                /* "the k-mer alone matches" (kmer_hits, what makes a candidate a hit of getListOfReads): the seed k-mer sits at the
+                 * START of the region (T coordinates) for types 0 / 3, at its END for 1 / 2: the differing base nearest that end must
+                 * be at least k bases in. A failing region is rare on clean reads; its lanes walk their dwords again. */
+                bool kmer_ok = region_ok;
+                if (__any(act && diff != 0)) {
+                    if (act && diff != 0) {
+                        const bool at_start = prefix_align != (rev != 0);
+                        int fpos = -1, lpos = -1;
+                        for (int t = 0; t <= nl; t++) {
+                            u32 x = __builtin_amdgcn_alignbit(bp[t], bp[t + 1], sh) ^ tp[t];
+                            if (t == 0) x &= fm;
+                            if (t == nl) x &= lm;
+                            if (x) {
+                                if (fpos < 0) fpos = 16 * (W0 + t) + (__clz((int)x) >> 1);
+                                lpos = 16 * (W0 + t) + ((32 - __ffs((int)x)) >> 1);
+                            }
+                        }
+                        kmer_ok = at_start ? fpos >= X0 + k : lpos < X1 - k;
+                    }
+                }
+                if (kmer_ok) my_khits++;
+                bool ov = false;
+                if (region_ok) {
+                    if (contain && (LA > LB || (LA == LB && Aseg < B))) atomicMin(&a.best[B], CKEY_MAKE(Aseg, j, suf, rev));
+                    ov = overlap;
+                }
+                /* compact the verified overlap hits to the front of their segment's row (writes never pass the candidates still to be read) */
+                if (MODE != 1) {
+                    const u64 mk = __ballot(ov);
+                    const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));
+                    const int lo_lane = (int)Pseg - (int)(64u * b); /* the segment's first lane in this batch; < 0: it began earlier */
+                    const u32 below_seg = (u32)__shfl((int)below, lo_lane > 0 ? lo_lane : 0);
+                    const u32 rank = (lo_lane < 0 ? carry : 0u) + below - below_seg;
+                    if (ov) a.hits[hd.x + rank] = h;
+                    const u32 kept = rank + (ov ? 1u : 0u);
+                    const bool last = valid && (64u * b + lane - Pseg == cseg - 1u); /* the segment ends on this lane */
+                    if (last) {
+                        s_nk[seg] = kept;
+                        my_raw += kept;
+                        if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
+                    }
+                    carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
+                }
+            }
+        }
+        __syncthreads();
+        /* the counts of the whole chunk in one coalesced store: {row start, verified hits | length << 32} by position in the order */
+        if (MODE != 1 && lane < n) a.meta_ord[cbeg + lane].y = (u64)s_nk[lane] | (meta.y & 0xFFFFFFFF00000000ull);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        my_khits += __shfl_down(my_khits, o);
+        my_raw += __shfl_down(my_raw, o);
+    }
+    if (lane == 0) {
+        if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
+        if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
+    }
+}
+
+/* ================================================================================================================
  * containment finalisation — contained flag per read from the reduced keys (BG/OverlapGraph.cpp:495-503 count)
  * ============================================================================================================== */
 __global__ void contain_flags_kernel(const u64 *__restrict__ best, u64 n, u8 *__restrict__ contained, u64 *__restrict__ cbits, u64 *ctr)
