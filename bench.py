@@ -51,19 +51,28 @@ def parse_args():
     return ap.parse_args()
 
 
+# phase of disco_phase_ms -> the kernel(s) behind it
+PHASE_KERNELS = {"index": "index_runs_kernel + scan + index_fill_kernel", "probe_kernel": "probe_runs_kernel", "verify": "verify_flat_kernel",
+                 "contain": "contain_flags_kernel", "select": "edge_select_kernel", "trmark": "transitive_mark_kernel", "emit": "emit_half_kernel"}
+
+
 def algorithmic_bytes(cnt, n_reads, words_mean):
     """SURVEY.md §8(d) contract: B = N*R (pack/read once for indexing) + 2N*16 (index entries) + N*R (read again to generate
     queries) + Q*8 (one 8-byte index word per probe) + H*R (fetch candidate sequence to verify) + E_pre*16 (write overlap
     records) + 2*E_pre*16 (read both directions for reduction) + E_out*16 + C*16 (write results).
-    Returns (whole path, {kernel: its share}) for one pass; the two probe-stage kernels split the probe terms:
-      probe_kernel  = N*R + Q*8          (query reads + the index words of all probes)
-      verify_kernel = H*R + E_pre*16     (candidate rows + overlap records)"""
+    Returns (whole path, {phase: its share}) for one pass; every term of the contract belongs to exactly one phase:
+      index   = N*R + 2N*16        (reads packed once + the two index entries of a read)
+      probe   = N*R + Q*8          (query reads + the index words of all probes)
+      verify  = H*R + E_pre*16     (candidate rows + overlap records)
+      select  = E_pre*16           (the overlap records read once: 2 E_pre directed hits of 8 bytes)
+      trmark  = E_pre*16           (... and the adjacency they became, read for the reduction)
+      emit    = E_out*16 ; contain = C*16   (results)"""
     R = 8.0 * words_mean
     N, Q, H = n_reads, cnt["probes"], cnt["kmer_hits"]
     E_pre, E_out, C = cnt["e_pre"], cnt["e_out"], cnt["n_contained"]
-    total = N * R + 2 * N * 16 + N * R + Q * 8 + H * R + E_pre * 16 + 2 * E_pre * 16 + E_out * 16 + C * 16
-    per_kernel = {"probe_kernel": N * R + Q * 8, "verify_kernel": H * R + E_pre * 16}
-    return total, per_kernel
+    per_phase = {"index": N * R + 2 * N * 16, "probe_kernel": N * R + Q * 8, "verify": H * R + E_pre * 16, "select": E_pre * 16, "trmark": E_pre * 16,
+                 "emit": E_out * 16, "contain": C * 16}
+    return sum(per_phase.values()), per_phase
 
 
 KERNEL_SOURCES = tuple(sorted("disco_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "disco_amd", "csrc")) if f.endswith((".h", ".hip"))))
@@ -265,9 +274,28 @@ def main():
             sys.stderr.flush()
             os._exit(124)
 
-        wd = threading.Timer(limit, _expired)
-        wd.daemon = True
-        wd.start()
+        wd_state = {"t": None}
+
+        def kick():
+            """progress: re-arm the watchdog (every step and every phase of the run calls it)"""
+            if wd_state["t"] is not None:
+                wd_state["t"].cancel()
+            wd_state["t"] = threading.Timer(limit, _expired)
+            wd_state["t"].daemon = True
+            wd_state["t"].start()
+
+        def unwatch():
+            if wd_state["t"] is not None:
+                wd_state["t"].cancel()
+                wd_state["t"] = None
+
+        kick()
+    else:
+        def kick():
+            pass
+
+        def unwatch():
+            pass
     import torch
 
     from disco_amd import buildgraph, launch, readgen
@@ -310,14 +338,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kern_ms = {"probe_kernel": [], "verify_kernel": []}
+        kick()
+    kern_ms = {k: [] for k in PHASE_KERNELS}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         ph = g.phase_ms()  # HIP events around each kernel launch on the stream it was launched on
-        kern_ms["probe_kernel"].append(ph["probe_kernel"])
-        kern_ms["verify_kernel"].append(ph["verify"])
+        for k in kern_ms:
+            kern_ms[k].append(ph.get(k, 0.0))
+        kick()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -362,18 +392,24 @@ def main():
     except Exception:
         gather_measured = None
 
-    def roof(kname):
-        b_launch = kern_b[kname] / world  # one launch processes one shard
-        ms = avg_ms[kname]
+    def roof(ph):
+        b_launch = kern_b[ph] / world  # one launch processes one shard
+        ms = avg_ms[ph]
         ach = b_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        # counter traffic: FETCH_SIZE reads 1.014 x the known bytes on a pure 64-byte row gather and 0.500 x on a wide coalesced stream
+        # (calibration kernels in the same profile; MI355X_MICROARCH.md, HBM section); the hot kernels mix both, so the true figure lies
+        # between traffic_lo (fetch x 1 + write) and traffic_hi (fetch x 2 + write). `traffic` = traffic_lo.
+        t = tj.get("phases", {}).get(ph) or {}
+        return {"bound": "hbm", "kernel": PHASE_KERNELS[ph], "phase": ph, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "peak_measured_copy": hbm_measured, "peak_measured_row_gather": gather_measured,
-                "traffic": tj.get("kernels", {}).get(kname), "traffic_source": traffic_note, "algorithmic_bytes_per_launch": b_launch,
-                "avg_launch_ms": ms}
+                "traffic": t.get("lo"), "traffic_lo": t.get("lo"), "traffic_hi": t.get("hi"), "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": ms}
 
     out = {
         "metric": "overlaps/sec (BuildGraph stage), 150 bp reads",
         "value": e_pre / (ms_per_step * 1e-3),
+        "timer": "hbm_resident",  # reads resident in HBM when the timed region starts, results left in HBM; SURVEY.md 8(d)'s t_graph
+                                  # (host buffers in, host structs out) is value_host_to_host, its stage timer stage_drop_in
         "unit": "overlaps/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -401,7 +437,10 @@ def main():
             "path_gbs": total_b / (ms_per_step * 1e-3) / 1e9,
         },
         "roofline": roof(dominant),
-        "roofline_other": [roof(k) for k in avg_ms if k != dominant],
+        "roofline_other": [roof(k) for k in sorted(avg_ms, key=lambda k: -avg_ms[k]) if k != dominant],
+        # share of ms_per_step that the kernels with a roofline entry account for (the rest: the grouping's scan / scatter, small
+        # bookkeeping kernels, launch gaps)
+        "roofline_coverage_of_step": sum(avg_ms.values()) / ms_per_step if ms_per_step > 0 else None,
     }
     if not sharded and not args.no_host_to_host:
         # SURVEY.md §8(d) 'graph' wall: host buffers in, host structs out (the HBM-resident `value` never includes the copies)
@@ -414,7 +453,9 @@ def main():
                            "its result arrays")
             out["graph_host_to_host"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in h2h.items()}
             # SURVEY.md 8(d)'s t_graph (host buffers in, host structs out) next to the HBM-resident `value`
-            out["value_host_to_host"] = h2h["overlaps_per_s"]
+            out["value_host_to_host"] = h2h["overlaps_per_s"]  # steady state (second pass of a warm context)
+            if h2h.get("first_pass_total_ms"):
+                out["value_host_to_host_first_pass"] = e_pre / (h2h["first_pass_total_ms"] * 1e-3)  # what a cold caller sees
         except Exception as e:
             out["graph_host_to_host"] = {"failed": str(e)}
     if sharded:  # rank 0's view of the exchanges of the last pass
@@ -425,6 +466,7 @@ def main():
     g.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
+            kick()
             out["cpu_baseline"] = cpu_baseline(args, spec)
         except Exception as e:  # the baseline is a reported extra; never lose the bench line over it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e}"}
@@ -439,6 +481,7 @@ def main():
             out["stage_drop_in"] = {"failed": str(e)}
     if sharded:
         cp.close()
+    unwatch()
     if rank == 0:
         try:  # RCCL writes its version banner through C stdio, which is flushed at exit: push it out before the JSON line
             import ctypes

@@ -530,8 +530,8 @@ class BuildGraph:
                 np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_uint64)), shape=(n, w))[:] = full[:, :w]
                 src, sw = q, w
             rows = edges = None
-            out = {}
-            for _ in range(max(1, passes)):
+            out, first = {}, None
+            for ip in range(max(1, passes)):
                 t0 = time.perf_counter()
                 self._chk(self.L.disco_upload_reads(self._h, src, sw, lens.ctypes.data, n))
                 t1 = time.perf_counter()
@@ -553,6 +553,11 @@ class BuildGraph:
                 out = {"upload_ms": (t1 - t0) * 1e3, "graph_ms": (t2 - t1) * 1e3, "fetch_contained_ms": (t4 - t3) * 1e3, "fetch_edges_ms": (t5 - t4) * 1e3,
                        "fetch_ms": (t5 - t3) * 1e3, "total_ms": (t2 - t0 + t5 - t3) * 1e3, "upload_bytes": int(n * sw * 8), "fetch_bytes": int(nc * 12 + ne * 12),
                        "result_bytes": int(nc * 40 + ne * 32), "n_contained": int(nc), "e_out": int(ne)}
+                if ip == 0:
+                    first = out["total_ms"]
+            # the first pass pays the page faults of the caller's never-touched result arrays and the context's first allocations:
+            # what a cold caller sees; total_ms is the steady state of a service that processes one sample after the other
+            out["first_pass_total_ms"] = first
             return out
         finally:
             self.L.disco_host_free(p)

@@ -29,6 +29,7 @@
 #include <string>
 #include <memory>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "../../include/disco_hip.h"
@@ -95,6 +96,8 @@ struct disco_ctx {
     bool reads_owned = false;
     std::vector<uint16_t> h_len; /* lazily mirrored for result decoding */
     bool h_len_ok = false;       /* h_len holds the lengths of the current reads */
+    std::mutex h_len_mu;         /* disco_ingest_fetch may run on a host thread of its own next to a pass (the one call allowed to):
+                                    it and ensure_host_len are the two writers that can meet */
     u64 q_lo = 0, q_hi = 0;
 
     /* index */
@@ -1472,10 +1475,15 @@ extern "C" int disco_ingest_fetch(disco_ctx *c, uint16_t *len, uint64_t *file_in
             for (u64 i = lo + b; i < lo + e_; i++) file_index[i] = rb + (u64)r[i] + 1; /* BG/Dataset.cpp:294: every record counts */
         });
     }
-    if (c->h_len.size() != n) c->h_len.resize(n);
-    uint16_t *hl = c->h_len.data();
-    parallel_for(n, [&, hl](u64 b, u64 e_) { memcpy(hl + b, len + b, (e_ - b) * 2); });
-    c->h_len_ok = true;
+    {
+        std::lock_guard<std::mutex> lk(c->h_len_mu);
+        if (!(c->h_len_ok && c->h_len.size() == n)) { /* (ensure_host_len may have mirrored them meanwhile) */
+            if (c->h_len.size() != n) c->h_len.resize(n);
+            uint16_t *hl = c->h_len.data();
+            parallel_for(n, [&, hl](u64 b, u64 e_) { memcpy(hl + b, len + b, (e_ - b) * 2); });
+            c->h_len_ok = true;
+        }
+    }
     return DISCO_OK;
 }
 
@@ -2496,6 +2504,7 @@ int disco_run_graph(disco_ctx *c)
 /* ---------------------------------------------------------------------------------------------------------------- */
 static int ensure_host_len(disco_ctx *c)
 {
+    std::lock_guard<std::mutex> lk(c->h_len_mu);
     if (c->h_len_ok && c->h_len.size() == c->n) return DISCO_OK;
     c->h_len.resize(c->n);
     if (c->n) HIPCHK(c, hipMemcpy(c->h_len.data(), c->d_len, c->n * 2, hipMemcpyDeviceToHost));

@@ -1674,6 +1674,9 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
         /* q[p] of a batch: quarter (lane & 3) of the row of candidate 16 p + (lane >> 2) */
         auto row_ptr = [&](u64 h, u32 seg, int p) -> const ulonglong2 * {
             u32 vid = (u32)HIT_ID(h);
+#if defined(VERIFY_EXP_NOROWS) /* timing experiment (tools/ab_build.py; results are wrong): every lane fetches its read's own row */
+            vid = s_al[seg].x;
+#endif
             if (MODE != 0) { /* candidates of the other pass: the read's own row instead */
                 const uint2 al = s_al[seg];
                 if (!in_pass(h, (int)al.y)) vid = al.x;
@@ -1774,6 +1777,9 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
                     const u32 x = __builtin_amdgcn_alignbit(bp[nl], bp[nl + 1], sh) ^ tp[nl];
                     diff |= x & (nl == 0 ? (lm & fm) : lm);
                 }
+#if defined(VERIFY_EXP_NOROWS)
+                diff = 0;
+#endif
                 const bool region_ok = act && diff == 0;
                 /* "the k-mer alone matches" (kmer_hits, what makes a candidate a hit of getListOfReads): the seed k-mer sits at the
                  * START of the region (T coordinates) for types 0 / 3, at its END for 1 / 2: the differing base nearest that end must

@@ -264,7 +264,9 @@ typedef struct disco_ingest_info {
 } disco_ingest_info;
 int disco_ingest_fasta(disco_ctx *ctx, const char *const *paths, int n_files, uint32_t host_threads, disco_ingest_info *info, disco_ingest_file *files);
 /* lengths and 1-based file indices (for <prefix>_ReadIDMap.txt and the id columns of every output line) of the reads the last
- * disco_ingest_fasta kept: len[n_reads], file_index[n_reads] */
+ * disco_ingest_fasta kept: len[n_reads], file_index[n_reads]. The ONE call that may run on a host thread of its own while another
+ * thread drives a pass on the same context (it works on the copy stream and shares only the mirrored lengths, under a lock); its
+ * error text, if any, goes to the context's error buffer like everybody's — read it after joining the thread */
 int disco_ingest_fetch(disco_ctx *ctx, uint16_t *len, uint64_t *file_index);
 
 /* ---- results --------------------------------------------------------------------------------------------------- */

@@ -12,18 +12,28 @@ import bench  # noqa: E402
 
 src, reads = sys.argv[1], int(sys.argv[2])
 pmc = json.load(open(src))
-kern = {}
+PHASE_OF = {"index_runs_kernel": "index", "index_count_kernel": "index", "index_fill_kernel": "index", "scan_tile_sums_kernel": "index", "scan_sums_kernel": "index",
+            "scan_apply_kernel": "index", "probe_runs_kernel": "probe_kernel", "probe_kernel": "probe_kernel", "verify_flat_kernel": "verify",
+            "verify_kernel": "verify", "contain_flags_kernel": "contain", "edge_select_kernel": "select", "transitive_mark_kernel": "trmark",
+            "emit_half_kernel": "emit", "emit_kernel": "emit"}
+phases = {}
 for k, v in pmc.items():
-    base = k.split("<")[0].strip()
-    # (the candidate-generation phase is probe_runs_kernel since round 3, with probe_kernel for the reads it hands over; bench.py names
-    # the phase "probe_kernel"; likewise index_runs_kernel / index_count_kernel)
-    base = {"probe_runs_kernel": "probe_kernel", "index_runs_kernel": "index_count_kernel"}.get(base, base)
-    if base in ("probe_kernel", "verify_kernel", "edge_select_kernel", "transitive_mark_kernel", "index_count_kernel"):
-        kern[base] = kern.get(base, 0.0) + (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
-out = {"reads": reads, "gpus": 1, "kernels": kern, "kernels_sha16": bench.kernels_sha16(),
-       "source": f"{os.path.relpath(src, ROOT)}: FETCH_SIZE + WRITE_SIZE (KB) x 1024 from separate --pmc passes (profiles/prof_pmc.sh); row-gather "
-                 "kernels taken undoubled (calibration: gather_rows_kernel reports 1.014 x its known bytes, the streaming copy 0.500 x, "
-                 "profiles/r01m_50M_pmc.json)"}
+    ph = PHASE_OF.get(k.split("<")[0].strip())
+    if ph is None:
+        continue
+    # (the scans also serve the grouping: rocprofv3's per-kernel sums cannot tell them apart — a few hundred MB either way)
+    f, w = v.get("FETCH_SIZE", 0.0) * 1024.0, v.get("WRITE_SIZE", 0.0) * 1024.0
+    p = phases.setdefault(ph, {"fetch": 0.0, "write": 0.0, "kernels": []})
+    p["fetch"] += f
+    p["write"] += w
+    p["kernels"].append(k)
+for p in phases.values():
+    p["lo"] = p["fetch"] + p["write"]        # FETCH_SIZE as counted (a pure 64-byte row gather calibrates at 1.014 x)
+    p["hi"] = 2.0 * p["fetch"] + p["write"]  # ... doubled (a wide coalesced stream calibrates at 0.500 x)
+out = {"reads": reads, "gpus": 1, "phases": phases, "kernels_sha16": bench.kernels_sha16(),
+       "source": f"{os.path.relpath(src, ROOT)}: FETCH_SIZE, WRITE_SIZE (KB) x 1024 from separate --pmc passes (profiles/prof_pmc.sh) per phase; lo = fetch + "
+                 "write, hi = 2 x fetch + write (calibration: gather_rows_kernel reports 1.014 x its known bytes, the streaming copy 0.500 x: the "
+                 "hot kernels mix row gathers and streams, the truth lies between)"}
 old = os.path.join(ROOT, "profiles", "probe_traffic.json")
 if os.path.exists(old):
     try:

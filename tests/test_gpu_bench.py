@@ -39,6 +39,16 @@ def test_bench_line_has_the_contract_fields():
     h = d["graph_host_to_host"]  # host buffers in, host structs out
     assert h["e_out"] == d["config"]["e_out"] and h["total_ms"] > 0 and h["upload_bytes"] > 0
     assert "traffic_source" in r
+    # round 4: the timer is named, every term of the SURVEY.md 8(d) byte contract belongs to a phase with a roofline entry, the
+    # counter traffic comes as a bracket (FETCH_SIZE x 1 .. x 2)
+    assert d["timer"] == "hbm_resident" and d["value_host_to_host"] > 0 and d["value_host_to_host_first_pass"] > 0
+    entries = [r] + d["roofline_other"]
+    assert {e["phase"] for e in entries} == {"index", "probe_kernel", "verify", "contain", "select", "trmark", "emit"}
+    for e in entries:
+        for k in ("kernel", "achieved", "frac", "traffic", "traffic_lo", "traffic_hi", "algorithmic_bytes_per_launch", "avg_launch_ms"):
+            assert k in e, (e["phase"], k)
+    assert abs(sum(e["algorithmic_bytes_per_launch"] for e in entries) - d["config"]["algorithmic_bytes_per_step"]) < 1.0
+    assert 0.2 < d["roofline_coverage_of_step"] <= 1.05
 
 
 def test_bench_stage_wall_through_the_drop_in_executable():
