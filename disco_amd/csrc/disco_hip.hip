@@ -1927,7 +1927,13 @@ static int select_edges(disco_ctx *c)
     a.order = c->d_order_used; /* the headers in meta_ord are by position in THIS order */
     a.meta_ord = c->d_meta_ord;
     ph_begin(c, DISCO_PH_SELECT);
-    if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
+    /* reads of up to 256 bases, exact overlaps: the hits of several reads as one flat list, full wavefronts (edge_select_flat_kernel) */
+    const bool flat_select = c->S == VERIFY_SW && c->max_len <= 256 && !a.hidden_flags && a.max_per_kmer < 255u && !getenv("DISCO_NO_FLAT_SELECT");
+    /* sub-chunks of up to 4 rows / 4 batches: 9.7 KB of LDS, 16 waves per CU. Larger ones fill their last batch better and repeat the
+     * per-sub-chunk work less often (8 rows: 140 instead of 175 vector instructions per read) but hold 11 waves per CU, and the kernel's
+     * time follows the resident waves (LDS round trips between its phases): 8 x 4: 25.4 ms, 4 x 4: 19.2 ms at 50 M reads */
+    if (nq && flat_select) hipLaunchKernelGGL((edge_select_flat_kernel<4, 4>), dim3(wq_grid(c, edge_select_flat_kernel<4, 4>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
+    else if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;

@@ -2401,6 +2401,296 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
     if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
 
+/* ================================================================================================================
+ * edge_select_flat_kernel (round 4) — the same selection (insertAllEdgesOfRead, BG/OverlapGraph.cpp:631-678) with FULL wavefronts for
+ * reads of up to 256 bases, exact overlaps. edge_select_kernel runs lane = hit of ONE read: a row has about 40 hits, 62 % of the lanes of
+ * 172 vector instructions per read. Here ROWS consecutive reads of the work-queue chunk form a sub-chunk whose verified hits are ONE
+ * flat list (exclusive scan of the counts in the chunk's headers), processed 64 at a time regardless of row boundaries, lane = hit:
+ *   1. hit, contained bit of its destination, entry (offset | dst | orient | len); per ROW and exact, by LDS atomics: "no destination
+ *      twice" (a hash set of 128 slots, compare-and-swap) and "no k-mer above the cap" (byte counters by window mod 128) — a row that
+ *      fails either is left untouched and done the old way at the end of the chunk (edge_select_row_fast / edge_select_row); the
+ *      counting atomic of the row's 256 offset bins (byte counters, four per word) hands the entry its arrival rank inside its bin;
+ *   2. per row one wave step: exclusive scan of the 256 bins -> their first positions;
+ *   3. entries to their bin's places in LDS (arrival order inside a bin);
+ *   4. entries of one offset (about five pairs per row) are ordered by the full key: an entry counts the bin-mates below it; the row
+ *      goes to its place in the hit buffer, sorted by (offset, dst, orient) like wave_sort_by_offset's.
+ * Every hit of the sub-chunk is in a register before the first row is written. Same rows, same counters as edge_select_kernel.
+ * ============================================================================================================== */
+#ifndef SELECT_FLAT_WAVES_PER_SIMD
+#define SELECT_FLAT_WAVES_PER_SIMD 1
+#endif
+__device__ __forceinline__ u32 pinned_copy32(u32 x)
+{
+    u32 y;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+template <int ROWS, int NB>
+__global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_flat_kernel(EdgeSelArgs a)
+{
+    /* a sub-chunk: consecutive reads of the chunk, as many as fit ROWS rows and NB batches of 64 hits (greedy) */
+    constexpr u32 SETW = 128;
+    static_assert(NB >= 1 && ROWS >= 1 && ROWS <= 8, "a row has at most 64 hits: one batch always holds a row; the jc array is cleared by one store per lane");
+    __shared__ __attribute__((aligned(16))) u64 s_ent[ROWS * 64 > 2 * ES_CAP ? ROWS * 64 : 2 * ES_CAP]; /* row r: [64 r, 64 r + 64); old paths: their two work arrays */
+    __shared__ __attribute__((aligned(16))) u32 s_bins[ROWS * 64];  /* row r, offset o: byte o & 3 of word 64 r + (o >> 2): entries */
+    __shared__ __attribute__((aligned(16))) u32 s_start[ROWS * 64]; /* ... : first position of the bin */
+    __shared__ __attribute__((aligned(16))) u32 s_jc[ROWS * 32 > 128 ? ROWS * 32 : 128]; /* row r, window j: byte j & 3 of word 32 r + ((j & 127) >> 2) */
+    __shared__ __attribute__((aligned(16))) u32 s_set[ROWS * SETW]; /* row r: destinations seen (0xFFFFFFFF = free) */
+    __shared__ u32 s_flag[ROWS];                                    /* row r must be done the old way */
+    __shared__ ulonglong2 s_hdr[64];                                /* read i of the chunk: {row start, first flat index | length << 32} */
+    const u32 lane = threadIdx.x;
+    const u32 k = (u32)a.v.k;
+    u32 cap_sites = 0, dropped = 0, n_slow = 0;
+    u64 n_edges = 0;
+    u64 cbeg = 0, cend = 0;
+    while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
+        const u32 n = (u32)(cend - cbeg);
+        const u64 ci = cbeg + (lane < n ? lane : 0u);
+        const u64 ordw = a.order ? a.order[ci] : a.v.q_lo + ci;
+        const u32 A = (u32)ORDER_ID(ordw);
+        const ulonglong2 meta = a.meta_ord[ci];
+        const u32 cw = ((const u32 *)a.contained)[A >> 5];
+        const bool mine = lane < n && !((cw >> (A & 31)) & 1u); /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
+        const u32 craw = mine ? (u32)meta.y : 0u;
+        const u32 LAme = (u32)(meta.y >> 32);
+        const bool longrow = craw > 64u;
+        const u32 c = longrow ? 0u : craw;
+        const u32 incl = wave_inclusive_add(c);
+        const u32 P = incl - c;
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        u64 slowmask = __ballot(longrow); /* reads of the chunk for the old paths */
+        u32 nacc_me = 0;                  /* lane = read: its finds */
+        __syncthreads();
+        s_hdr[lane] = make_ulonglong2(meta.x, (u64)P | ((u64)LAme << 32));
+        __syncthreads();
+        /* Three stages, one sub-chunk each: A issues the hit loads, B turns the arrived hits into entries and issues the gathers of their
+         * destinations' contained words, C does the rows. All loads are unconditional (clamped addresses: the number in flight is
+         * known to the compiler) and live in registers nobody copies while they are in flight. */
+        struct Sub {
+            u32 r0, r1, base, end; /* reads [r0, r1) of the chunk, flat indices [base, end) */
+        };
+        auto Pat = [&](u32 r) { return r < 64u ? (u32)__builtin_amdgcn_readlane((int)P, (int)r) : total; };
+        auto sub_from = [&](u32 r0) { /* (wave uniform, scalar loop) */
+            Sub x;
+            x.r0 = r0 < 64u ? r0 : 64u;
+            x.base = Pat(x.r0);
+            x.r1 = x.r0;
+            x.end = x.base;
+            while (x.r1 < 64u && x.r1 - x.r0 < (u32)ROWS) {
+                const u32 e = Pat(x.r1 + 1u);
+                if (e - x.base > 64u * (u32)NB) break;
+                x.r1++;
+                x.end = e;
+            }
+            return x;
+        };
+        u64 H[NB];    /* hits in flight */
+        u32 segH[NB]; /* their read of the chunk | valid << 6 */
+        auto stageA = [&](const Sub &sb) {
+            const u32 base = sb.base, end = sb.end, r0 = sb.r0;
+            u32 sscan = r0;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                u32 f = base + 64u * (u32)i + lane;
+                const bool valid = f < end;
+                u32 seg = 0;
+                u64 addr = (cbeg & 0xFFFFull) + lane; /* nothing to load: some line of the hit buffer (it has more than 65536 slots) */
+                if (base + 64u * (u32)i < end) {      /* (wave uniform) */
+                    f = valid ? f : end - 1u;
+                    u32 fl = base + 64u * (u32)i + 63u;
+                    fl = fl < end ? fl : end - 1u;
+                    seg = sscan;
+                    u32 s2 = (u32)__builtin_amdgcn_readfirstlane((int)sscan) + 1u;
+                    while (s2 < sb.r1) {
+                        const u32 Ps = (u32)__builtin_amdgcn_readlane((int)P, (int)s2);
+                        if (Ps > fl) break;
+                        seg = f >= Ps ? s2 : seg;
+                        s2++;
+                    }
+                    sscan = s2 - 1u;
+                    const ulonglong2 hd = s_hdr[seg];
+                    addr = hd.x + (u64)(f - (u32)hd.y);
+                }
+                H[i] = a.hits[addr];
+                segH[i] = seg | (valid ? 64u : 0u);
+            }
+        };
+        u64 ent1[NB];
+        u32 seg1[NB], CW1[NB];
+        auto stageB = [&]() {
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const u64 h = H[i];
+                const u32 seg = segH[i] & 63u;
+                const bool valid = segH[i] & 64u;
+                const u32 id = valid ? (u32)HIT_ID(h) : 0u;
+                const u32 LA = (u32)(s_hdr[seg].y >> 32);
+                u32 orient, off;
+                disco_map_type(disco_hit_type(HIT_SUFFIX(h), HIT_REV(h)), LA, k, HIT_J(h), &orient, &off);
+                /* (the window's low 7 bits — all the row's cap test needs — ride along in seg1) */
+                ent1[i] = ADJ_MAKE(off, id, orient, HIT_LEN(h));
+                seg1[i] = segH[i] | ((HIT_J(h) & 127u) << 8);
+                CW1[i] = ((const u32 *)a.contained)[id >> 5];
+            }
+        };
+        Sub sC = sub_from(0), sB = sub_from(sC.r1), sA = sub_from(sB.r1);
+        stageA(sC);
+        stageB();
+        stageA(sB);
+        for (; sC.r0 < 64u; sC = sB, sB = sA, sA = sub_from(sA.r1)) {
+            /* this sub-chunk's entries and contained words (arrived: the copy is where the wait belongs) */
+            u64 ent[NB];
+            u32 segm[NB], cwd[NB];
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                ent[i] = ent1[i];
+                segm[i] = seg1[i];
+                cwd[i] = pinned_copy32(CW1[i]);
+            }
+            stageB();   /* the next sub-chunk: its hits have arrived */
+            stageA(sA); /* the one after */
+            const u32 r0 = sC.r0, base = sC.base, end = sC.end;
+            if (end == base) continue;
+            const u32 nbat = (end - base + 63u) >> 6;
+            __syncthreads();
+            {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u), f = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+                for (u32 x = 0; x < (ROWS * 64 / 4 + 63) / 64; x++)
+                    if (x * 64 + lane < ROWS * 64 / 4) ((uint4 *)s_bins)[x * 64 + lane] = z;
+#pragma unroll
+                for (u32 x = 0; x < (ROWS * SETW / 4 + 63) / 64; x++)
+                    if (x * 64 + lane < ROWS * SETW / 4) ((uint4 *)s_set)[x * 64 + lane] = f;
+                if (lane < ROWS * 32 / 4) ((uint4 *)s_jc)[lane] = z;
+                if (lane < ROWS) s_flag[lane] = 0u;
+            }
+            __syncthreads();
+            /* 1. the row's tests, bins. segm: read (6) | ok << 6 | window & 127 << 8 -> read | ok << 6 | arrival rank << 8 */
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                if ((u32)i < nbat) {
+                    const u32 seg = segm[i] & 63u, rl = seg - r0;
+                    const u32 id = (u32)ADJ_DST(ent[i]);
+                    const bool ok = (segm[i] & 64u) && !((cwd[i] >> (id & 31u)) & 1u);
+                    const u32 jw = (segm[i] >> 8) & 127u;
+                    const u32 off = ADJ_OFF(ent[i]);
+                    u32 rank = 0;
+                    if (ok) {
+                        bool bad = false;
+                        u32 idx = (id * 0x9E3779B1u) >> 25; /* SETW = 128 slots */
+                        for (;;) {
+                            const u32 old = atomicCAS(&s_set[rl * SETW + idx], 0xFFFFFFFFu, id);
+                            if (old == 0xFFFFFFFFu) break;
+                            if (old == id) { /* a second hit to this destination (BG/OverlapGraph.cpp:656): the consumption order decides */
+                                bad = true;
+                                break;
+                            }
+                            idx = (idx + 1u) & (SETW - 1u);
+                        }
+                        const u32 jold = atomicAdd(&s_jc[rl * 32u + (jw >> 2)], 1u << (8u * (jw & 3u)));
+                        bad |= ((jold >> (8u * (jw & 3u))) & 0xFFu) >= a.max_per_kmer; /* (windows 128 apart share a counter: conservative) */
+                        if (bad) s_flag[rl] = 1u;
+                        const u32 bold = atomicAdd(&s_bins[rl * 64u + (off >> 2)], 1u << (8u * (off & 3u)));
+                        rank = (bold >> (8u * (off & 3u))) & 0xFFu;
+                    }
+                    segm[i] = seg | (ok ? 64u : 0u) | (rank << 8);
+                }
+            }
+            __syncthreads();
+            /* rows for the old paths */
+            {
+                const u32 fl = lane < ROWS ? s_flag[lane] : 0u;
+                slowmask |= __ballot(fl != 0u) << r0;
+            }
+            /* 2. per row: bins -> first positions; the row's number of finds */
+#pragma unroll
+            for (u32 r = 0; r < (u32)ROWS; r++) {
+                if (r0 + r >= sC.r1) break; /* (wave uniform) */
+                const u32 x = s_bins[r * 64u + lane];
+                const u32 sum = (x * 0x01010101u) >> 24;
+                const u32 inc = wave_inclusive_add(sum);
+                s_start[r * 64u + lane] = x * 0x01010100u + (inc - sum) * 0x01010101u; /* (no byte carries: a row has at most 64 entries) */
+                const u32 tot = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+                if (lane == r0 + r) nacc_me = tot;
+            }
+            __syncthreads();
+            /* 3. entries to their bins' places (arrival order inside a bin); segm: read | go << 6 | arrival rank << 8 | bin size << 16 | first position << 24 */
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                if ((u32)i < nbat) {
+                    const u32 rl = (segm[i] & 63u) - r0, off = ADJ_OFF(ent[i]);
+                    const bool go = (segm[i] & 64u) && !s_flag[rl];
+                    const u32 st = (s_start[rl * 64u + (off >> 2)] >> (8u * (off & 3u))) & 0xFFu;
+                    const u32 cnt = go ? (s_bins[rl * 64u + (off >> 2)] >> (8u * (off & 3u))) & 0xFFu : 0u;
+                    if (go) s_ent[rl * 64u + st + ((segm[i] >> 8) & 0xFFu)] = ent[i];
+                    segm[i] = (segm[i] & 0xFF3Fu) | (go ? 64u : 0u) | (cnt << 16) | (st << 24);
+                }
+            }
+            __syncthreads();
+            /* 4. place among the entries of the same offset by the full key, and out. Bins of two (most ties): the other one decides */
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                if ((u32)i < nbat) {
+                    const u32 seg = segm[i] & 63u, rl = seg - r0;
+                    const u32 st = segm[i] >> 24, cnt = (segm[i] >> 16) & 0xFFu, rk = (segm[i] >> 8) & 0xFFu;
+                    const u64 other = s_ent[rl * 64u + st + (cnt == 2u ? (rk ^ 1u) : rk)];
+                    u32 below = other < ent[i] ? 1u : 0u;
+                    if (__any(cnt > 2u)) {
+                        if (cnt > 2u) {
+                            below = 0;
+                            for (u32 t = 0; t < cnt; t++) below += s_ent[rl * 64u + st + t] < ent[i] ? 1u : 0u;
+                        }
+                    }
+                    if (segm[i] & 64u) a.hits[s_hdr[seg].x + st + below] = ent[i];
+                }
+            }
+        }
+        /* the reads' reference words; reads for the old paths write their own */
+        if (lane < n && !((slowmask >> lane) & 1ull)) a.ref[A] = c ? REF_MAKE(meta.x, nacc_me) : 0ull;
+        {
+            u32 t = ((slowmask >> lane) & 1ull) ? 0u : nacc_me;
+            t = wave_inclusive_add(t);
+            n_edges += (u32)__builtin_amdgcn_readlane((int)t, 63);
+        }
+        /* rows with a destination twice, a k-mer over the cap, or more than 64 hits: as edge_select_kernel does them */
+        while (slowmask) {
+            const u32 i = (u32)__ffsll((long long)slowmask) - 1u;
+            slowmask &= slowmask - 1ull;
+            const u64 Ai = (u32)__builtin_amdgcn_readlane((int)A, (int)i);
+            const u64 rs = readlane_u64(meta.x, i);
+            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)craw, (int)i);
+            const u32 L0 = (u32)__builtin_amdgcn_readlane((int)LAme, (int)i);
+            __syncthreads();
+            if (c0 > ES_CAP) {
+                if (lane == 0) {
+                    const u32 idx = atomicAdd(a.n_big, 1u);
+                    if (idx < a.big_cap) a.big_list[idx] = Ai;
+                    else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
+                    a.ref[Ai] = 0;
+                }
+                continue;
+            }
+            bool done = false;
+            if (c0 <= 64u) {
+                u64 g = ~0ull;
+                if (lane < c0) {
+                    g = a.hits[rs + lane];
+                    if (is_contained(a.contained, HIT_ID(g))) g = ~0ull;
+                }
+                done = edge_select_row_fast(a, Ai, rs, L0, g, lane, dropped, n_edges);
+            }
+            if (!done) {
+                n_slow++;
+                edge_select_row<ES_CAP>(a, Ai, rs, s_ent, s_ent + ES_CAP, c0, lane, s_jc, cap_sites, dropped, n_edges);
+            }
+        }
+    }
+    if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
+    if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
+    if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+    if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
+}
+
 /* rows of ES_CAP+1 .. ES_MID hits (coverage of a few hundred): the big-row list again, with LDS arrays large enough for the
  * accept-all shortcut; longer rows are left to the global-scratch variant */
 __global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a)
