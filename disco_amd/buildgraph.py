@@ -133,7 +133,9 @@ class DistInfo(C.Structure):
                 ("n_contained_local", C.c_uint64), ("cap_bind_sites", C.c_uint64), ("asymmetric_pairs", C.c_uint64),
                 ("dropped_hits", C.c_uint64), ("probes", C.c_uint64), ("kmer_hits", C.c_uint64), ("regime", C.c_uint32),
                 ("tr_rounds", C.c_uint32), ("tr_deferred", C.c_uint64), ("bytes_sent", C.c_uint64 * len(XCHG)),
-                ("ms", C.c_float * len(XCHG)), ("ms_total", C.c_float)]
+                ("ms", C.c_float * len(XCHG)), ("ms_total", C.c_float), ("kernel_ms", C.c_float), ("comm_ops", C.c_uint32),
+                ("host_syncs", C.c_uint32), ("device_allocs", C.c_uint32), ("device_frees", C.c_uint32), ("arena_bytes", C.c_uint64),
+                ("arena_peak", C.c_uint64), ("hbm_peak", C.c_uint64)]
 
 PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit", "order")
 

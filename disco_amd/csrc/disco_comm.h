@@ -33,6 +33,8 @@
 
 struct DiscoComm {
     int rank = 0, world = 1;
+    unsigned n_ops = 0;      /* operations issued on this communicator (counted by the implementations, reported per pass) */
+    unsigned n_host_ops = 0; /* ... of which exchanges of host values: each one waits for the stream */
     std::string err;
     virtual ~DiscoComm() {}
     virtual const char *kind() const = 0;
@@ -53,6 +55,12 @@ struct DiscoComm {
      * released with an error; an RCCL communicator is aborted (its peers see the failure through their own communicator's async
      * error / launcher, buildG _exit()s — the process-level convention of the reference's MPI binaries) */
     virtual void abort() = 0;
+    /* measurement aid of the in-process transport (DISCO_LOOP_SERIALIZE=1): the ranks of one process share a device, and with it the
+     * compute segments of a pass — between two operations on the communicator — run one rank at a time, so that a rank's phase timers
+     * show its own kernels and the sum over the ranks is the work of the whole job (tools/dist_profile.py: work inflation). A pass
+     * holds the token from begin_pass to end_pass and gives it up inside every operation. No-ops on RCCL. */
+    virtual void begin_pass() {}
+    virtual void end_pass() {}
 };
 
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -104,12 +112,14 @@ struct RcclComm final : DiscoComm {
     }
     int all_gather(const void *send, void *recv, size_t bytes, hipStream_t s) override
     {
+        n_ops++;
         if (bytes == 0) return DISCO_OK;
         DISCO_NCCL(ncclAllGather(send, recv, bytes, ncclInt8, comm, s));
         return DISCO_OK;
     }
     int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
     {
+        n_ops++;
         DISCO_NCCL(ncclGroupStart());
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
@@ -124,6 +134,7 @@ struct RcclComm final : DiscoComm {
     int all_to_all_v(const void *send, const size_t *soff, const size_t *scnt, void *recv, const size_t *roff, const size_t *rcnt,
                      hipStream_t s) override
     {
+        n_ops++;
         DISCO_NCCL(ncclGroupStart());
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
@@ -137,12 +148,15 @@ struct RcclComm final : DiscoComm {
     }
     int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) override
     {
+        n_ops++;
         if (per == 0) return DISCO_OK;
         DISCO_NCCL(ncclReduceScatter(buf, (long long *)buf + (size_t)rank * per, per, ncclInt64, ncclMin, comm, s));
         return DISCO_OK;
     }
     int host_all_gather(const unsigned long long *mine, int n, unsigned long long *all, hipStream_t s) override
     {
+        n_ops++;
+        n_host_ops++;
         const size_t need = (size_t)(world + 1) * n;
         if (need > small_cap) {
             if (d_small) (void)hipFree(d_small);
@@ -159,6 +173,8 @@ struct RcclComm final : DiscoComm {
     }
     int barrier(hipStream_t s) override
     {
+        n_ops++;
+        n_host_ops++;
         unsigned long long x = 0;
         std::vector<unsigned long long> all((size_t)world);
         return host_all_gather(&x, 1, all.data(), s);
@@ -183,6 +199,34 @@ __global__ void loop_min_i64_kernel(long long *__restrict__ dst, const long long
         dst[off + i] = m;
     }
 }
+
+/* DISCO_LOOP_SERIALIZE=1: one token per process (the two communicators of a context share it) */
+struct LoopDeviceToken {
+    std::mutex m;
+    const bool on = getenv("DISCO_LOOP_SERIALIZE") != nullptr;
+    static LoopDeviceToken &get()
+    {
+        static LoopDeviceToken t;
+        return t;
+    }
+    static bool &holding() /* this thread (= this rank) is inside a pass and has the token */
+    {
+        static thread_local bool h = false;
+        return h;
+    }
+};
+/* gives the token up for the duration of an operation on a communicator (the rank's stream has been synchronised: its segment is over) */
+struct LoopTokenPause {
+    const bool held;
+    LoopTokenPause() : held(LoopDeviceToken::holding())
+    {
+        if (held) LoopDeviceToken::get().m.unlock();
+    }
+    ~LoopTokenPause()
+    {
+        if (held) LoopDeviceToken::get().m.lock();
+    }
+};
 
 /* state shared by the ranks (threads) of one in-process group */
 struct LoopGroup {
@@ -245,13 +289,15 @@ struct LoopComm final : DiscoComm {
     }
     int all_gather(const void *send, void *recv, size_t bytes, hipStream_t s) override
     {
-        std::vector<size_t> off((size_t)world), cnt((size_t)world, bytes);
+        std::vector<size_t> off((size_t)world), cnt((size_t)world, bytes); /* (counted by all_gather_v) */
         for (int p = 0; p < world; p++) off[(size_t)p] = (size_t)p * bytes;
         return all_gather_v(send, recv, off.data(), cnt.data(), s);
     }
     int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
     {
+        n_ops++;
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP); /* my block is complete */
+        LoopTokenPause pause;
         g->ptr[(size_t)rank] = send;
         LOOP_WAIT();
         for (int p = 0; p < world; p++) {
@@ -266,7 +312,9 @@ struct LoopComm final : DiscoComm {
     int all_to_all_v(const void *send, const size_t *soff, const size_t *scnt, void *recv, const size_t *roff, const size_t *rcnt,
                      hipStream_t s) override
     {
+        n_ops++;
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LoopTokenPause pause;
         g->ptr[(size_t)rank] = send;
         g->off[(size_t)rank].assign(soff, soff + world);
         g->cnt[(size_t)rank].assign(scnt, scnt + world);
@@ -286,7 +334,9 @@ struct LoopComm final : DiscoComm {
     }
     int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) override
     {
+        n_ops++;
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LoopTokenPause pause;
         g->ptr[(size_t)rank] = buf;
         LOOP_WAIT();
         if (per) {
@@ -302,7 +352,10 @@ struct LoopComm final : DiscoComm {
     }
     int host_all_gather(const unsigned long long *mine, int n, unsigned long long *all, hipStream_t s) override
     {
+        n_ops++;
+        n_host_ops++;
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LoopTokenPause pause;
         {
             std::lock_guard<std::mutex> lk(g->m);
             if (g->host.size() < (size_t)world * n) g->host.resize((size_t)world * n);
@@ -316,11 +369,28 @@ struct LoopComm final : DiscoComm {
     }
     int barrier(hipStream_t s) override
     {
+        n_ops++;
+        n_host_ops++;
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        LoopTokenPause pause;
         LOOP_WAIT();
         return DISCO_OK;
     }
     void abort() override { g->abort(); }
+    void begin_pass() override
+    {
+        if (LoopDeviceToken::get().on && !LoopDeviceToken::holding()) {
+            LoopDeviceToken::get().m.lock();
+            LoopDeviceToken::holding() = true;
+        }
+    }
+    void end_pass() override
+    {
+        if (LoopDeviceToken::holding()) {
+            LoopDeviceToken::holding() = false;
+            LoopDeviceToken::get().m.unlock();
+        }
+    }
 #undef LOOP_WAIT
 };
 

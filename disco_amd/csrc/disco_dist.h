@@ -171,38 +171,88 @@ __device__ __forceinline__ u32 request_for(u64 e, u64 lo, u64 hi, u64 *__restric
 }
 
 /* round 1: every register-resident node (degree <= 64) asks for the two rows its marking sweeps for certain — slot 0 and the
- * first slot on the other side of the node (exactly transitive_mark_kernel's speculative pair) */
-__global__ void __launch_bounds__(256) tr_request_first_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, u64 lo, u64 hi,
-                                                               u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+ * first slot on the other side of the node (exactly transitive_mark_kernel's speculative pair). Eight lanes per node read its row 64
+ * bytes at a time (round 4; one lane per node walked its row entry by entry, a sector per step: 2.5 ms per rank at 8 x 6.25 M
+ * nodes) and count, while they are at it, the entries on either side of the node: cls_cnt[i] = entries a sweep of class 0 uses |
+ * entries a sweep of class 1 uses << 16 (BG/OverlapGraph.cpp:705-708: class 1 -> types 0/1, class 0 -> types 2/3), what the owner
+ * answers a request's size from (tr_respond_deg_kernel) instead of reading the row once more. 0xFFFFFFFF: too long to count here. */
+__global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, u64 lo, u64 hi,
+                                                               u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr,
+                                                               u32 *__restrict__ cls_cnt)
 {
     const u64 nloc = hi - lo;
-    const u64 n64 = (nloc + 63) & ~63ull;
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < n64; i += (u64)gridDim.x * blockDim.x) {
-        u32 rq0 = 0xFFFFFFFFu, rq2 = 0xFFFFFFFFu;
-        if (i < nloc) {
-            const u64 rv = ref[lo + i];
+    const u32 lane = threadIdx.x & 63u, sub = lane & 7u, g0 = lane & ~7u;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    __shared__ u32 s_rq[1][128]; /* (one wavefront per workgroup) the requests of a block of 64 nodes (appended with two atomics: the list's counter is ONE address) */
+    u32 *rqs = s_rq[0];
+    for (u64 blk = wave * 64; blk < nloc; blk += nwaves * 64) { /* (wave uniform: 64 nodes per wavefront and trip, eight at a time) */
+        rqs[lane] = 0xFFFFFFFFu;
+        rqs[lane + 64] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (u32 t = 0; t < 8; t++) {
+            const u64 i = blk + 8 * t + (lane >> 3);
+            const bool live = i < nloc;
+            const u64 rv = live ? ref[lo + i] : 0ull;
             const u32 d = REF_DEG(rv);
-            if (d != 0 && d <= 64) {
-                const u64 *row = adj + REF_POS(rv);
-                const u64 e0 = row[0];
-                const u32 side0 = ADJ_ORI(e0) >> 1;
-                u64 e2 = 0;
-                bool has2 = false;
-                for (u32 s = 1; s < d; s++) {
-                    const u64 e = row[s];
-                    if ((ADJ_ORI(e) >> 1) != side0) {
-                        e2 = e;
-                        has2 = true;
-                        break;
-                    }
+            const u64 *row = adj + REF_POS(rv);
+            u32 dmax = d < 65536u ? d : 0u;
+            dmax = max(dmax, (u32)__shfl_xor((int)dmax, 8));
+            dmax = max(dmax, (u32)__shfl_xor((int)dmax, 16));
+            dmax = max(dmax, (u32)__shfl_xor((int)dmax, 32));
+            u32 n_side0 = 0, n_side1 = 0, side0 = 0;
+            u64 e0 = 0, e2 = 0;
+            bool has2 = false;
+            for (u32 s0 = 0; s0 < dmax; s0 += 8) {
+                const u32 s = s0 + sub;
+                const bool in = s < d && d < 65536u;
+                const u64 e = in ? row[s] : 0ull;
+                if (s0 == 0) {
+                    e0 = shfl_u64(e, g0);
+                    side0 = ADJ_ORI(e0) >> 1;
                 }
-                rq0 = request_for(e0, lo, hi, nref);
-                if (has2) rq2 = request_for(e2, lo, hi, nref);
+                const u32 side = ADJ_ORI(e) >> 1;
+                const u32 m1 = (u32)(__ballot(in && side == 1u) >> g0) & 0xFFu, m0 = (u32)(__ballot(in && side == 0u) >> g0) & 0xFFu;
+                n_side1 += (u32)__popc(m1);
+                n_side0 += (u32)__popc(m0);
+                const u32 mo = side0 ? m0 : m1; /* entries on the other side than slot 0 */
+                const u64 cand = shfl_u64(e, g0 + (mo ? (u32)__ffs((int)mo) - 1u : 0u));
+                if (!has2 && mo) {
+                    e2 = cand;
+                    has2 = true;
+                }
+            }
+            if (live && sub == 0) {
+                cls_cnt[i] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
+                if (d != 0 && d <= 64) {
+                    rqs[2 * (8 * t + (lane >> 3))] = request_for(e0, lo, hi, nref);
+                    if (has2) rqs[2 * (8 * t + (lane >> 3)) + 1] = request_for(e2, lo, hi, nref);
+                }
             }
         }
-        request_append(rq0, list, n_list, cap, ctr);
-        request_append(rq2, list, n_list, cap, ctr);
+        __syncthreads();
+        request_append(rqs[lane], list, n_list, cap, ctr);
+        request_append(rqs[lane + 64], list, n_list, cap, ctr);
+        __syncthreads();
+    }
+}
+
+/* the owner's side: how many entries the answer to request i has — from the counts tr_request_first_kernel left for every own
+ * node (rows too long for them: counted here, by the one lane) */
+__global__ void tr_respond_deg_kernel(const u32 *__restrict__ req, u64 n_req, const u32 *__restrict__ cls_cnt, u64 lo, const u64 *__restrict__ ref,
+                                      const u64 *__restrict__ adj, u32 *__restrict__ deg)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_req; i += (u64)gridDim.x * blockDim.x) {
+        const u32 rq = req[i], cls = rq & 1u;
+        const u32 cc = cls_cnt[(u64)(rq >> 1) - lo];
+        u32 n = (cc >> (16u * cls)) & 0xFFFFu;
+        if (cc == 0xFFFFFFFFu) {
+            const u64 rv = ref[rq >> 1];
+            const u64 *row = adj + REF_POS(rv);
+            n = 0;
+            for (u32 s = 0; s < REF_DEG(rv); s++) n += (ADJ_ORI(row[s]) >> 1) != cls ? 1u : 0u;
+        }
+        deg[i] = n;
     }
 }
 
@@ -365,8 +415,12 @@ __global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ 
     const u32 lane = threadIdx.x & 63u;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 mine = 0;
-    /* one candidate per lane and call: the wavefront's items are appended with one atomic */
-    auto push = [&](bool have, u64 e, u64 b, u32 Lb) {
+    /* the items of a wavefront's trip (up to HALF_CAP per node) are appended with ONE atomic (round 4: one per call was 390 000
+     * atomics on one address per rank — 2.1 of this kernel's 2.3 ms) */
+    auto item_of = [&](u64 e, u64 b, u32 Lb) {
+        return make_ulonglong2(ADJ_DST(e), ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lb, b, disco_twin_orient(ADJ_ORI(e)), Lb));
+    };
+    auto push = [&](bool have, u64 e, u64 b, u32 Lb) { /* one candidate per lane and call (the rows of nodes with many survivors) */
         const bool take = have && ADJ_DST(e) < lo; /* else: a > b, or a on this rank (judged locally) */
         const u64 mk = __ballot(take);
         if (!mk) return;
@@ -380,7 +434,7 @@ __global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ 
         base = readlane_u64(base, leader);
         if (take) {
             const u64 p = base + __popcll(mk & lane_mask_lt());
-            if (p < cap) list[p] = make_ulonglong2(ADJ_DST(e), ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lb, b, disco_twin_orient(ADJ_ORI(e)), Lb));
+            if (p < cap) list[p] = item_of(e, b, Lb);
             else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
         }
     };
@@ -389,10 +443,35 @@ __global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ 
         const u64 b = lo + (live ? i : 0);
         const u32 cnt = live ? hcnt[b] : 0u, Lb = live ? (u32)len[b] : 0u;
         const bool narrow = cnt <= HALF_CAP;
+        u64 he[HALF_CAP];
+        u32 takem = 0; /* bit r: survivor r of this lane's node is pushed */
 #pragma unroll
         for (u32 r = 0; r < HALF_CAP; r++) {
             const bool have = narrow && r < cnt;
-            push(have, have ? half[b * HALF_CAP + r] : 0ull, b, Lb);
+            he[r] = have ? half[b * HALF_CAP + r] : 0ull;
+            if (have && ADJ_DST(he[r]) < lo) takem |= 1u << r;
+        }
+        {
+            const u32 mycnt = (u32)__popc(takem);
+            const u32 incl = wave_inclusive_add(mycnt);
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            if (tot) {
+                if (!FILL) {
+                    if (lane == 0) mine += tot;
+                } else {
+                    u64 base = 0;
+                    if (lane == 0) base = atomicAdd(n_list, (u64)tot);
+                    base = readlane_u64(base, 0);
+                    u64 p = base + (incl - mycnt);
+#pragma unroll
+                    for (u32 r = 0; r < HALF_CAP; r++)
+                        if (takem & (1u << r)) {
+                            if (p < cap) list[p] = item_of(he[r], b, Lb);
+                            else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+                            p++;
+                        }
+                }
+            }
         }
         /* many survivors (rare): the row carries the flags; the wavefront walks the rows of its wide lanes one after the other */
         u64 wide = __ballot(!narrow);

@@ -29,6 +29,7 @@
 #include <string>
 #include <memory>
 #include <thread>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -78,15 +79,87 @@ static void parallel_for(u64 n, F f)
 }
 
 
+/* What a pass did besides launching kernels, per host thread (= per rank: one thread drives one rank, in-process or not):
+ * device allocations and frees that reached the HIP runtime, blocking waits on the device, operations on a communicator. A
+ * multi-GPU pass reports them (disco_dist_info): allocations between two collectives of a pass are a hazard when several ranks
+ * share a process, and every blocking wait / collective launch is host time on the critical path of an 8-GPU pass. */
+struct PassCounters {
+    u32 dev_allocs = 0, dev_frees = 0, host_syncs = 0, comm_ops = 0;
+};
+static thread_local PassCounters tl_pass;
+static inline hipError_t counted_stream_sync(hipStream_t s)
+{
+    tl_pass.host_syncs++;
+    return hipStreamSynchronize(s);
+}
+static inline hipError_t counted_event_sync(hipEvent_t e)
+{
+    tl_pass.host_syncs++;
+    return hipEventSynchronize(e);
+}
+#define hipStreamSynchronize(s) counted_stream_sync(s)
+#define hipEventSynchronize(e) counted_event_sync(e)
+
+/* Arena of a multi-GPU context: ONE device allocation made before the first collective of the first pass; every buffer of the pass
+ * is carved out of it (first fit, neighbours coalesced on free: a few hundred calls per pass), so that no hipMalloc / hipFree runs
+ * between the collectives of a pass — with one host thread per rank in one process (buildG --gpus N) a device allocation while
+ * another rank's RCCL kernels are in flight can serialise against them or deadlock. A request the arena cannot serve falls back to
+ * the runtime and is counted (disco_dist_info.device_allocs). */
+struct DevArena {
+    char *base = nullptr;
+    size_t size = 0, used = 0, peak = 0;
+    std::map<size_t, size_t> free_at; /* offset -> bytes of every free block */
+    bool owns(const void *p) const { return base && (const char *)p >= base && (const char *)p < base + size; }
+    void *alloc(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (auto it = free_at.begin(); it != free_at.end(); ++it)
+            if (it->second >= bytes) {
+                const size_t off = it->first, len = it->second;
+                free_at.erase(it);
+                if (len > bytes) free_at[off + bytes] = len - bytes;
+                live[off] = bytes;
+                used += bytes;
+                peak = std::max(peak, used);
+                return base + off;
+            }
+        return nullptr;
+    }
+    void release(void *p)
+    {
+        const size_t off = (size_t)((char *)p - base);
+        auto lv = live.find(off);
+        if (lv == live.end()) return;
+        size_t start = off, end = off + lv->second;
+        used -= lv->second;
+        live.erase(lv);
+        auto nx = free_at.lower_bound(off); /* the first free block behind the freed one */
+        if (nx != free_at.end() && nx->first == end) {
+            end += nx->second;
+            nx = free_at.erase(nx);
+        }
+        if (nx != free_at.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == start) {
+                start = pv->first;
+                free_at.erase(pv);
+            }
+        }
+        free_at[start] = end - start;
+    }
+    std::map<size_t, size_t> live; /* offset -> bytes of every block handed out */
+};
+
 struct disco_ctx {
     int device = 0;
     disco_params prm{};
+    DevArena arena;
     int k = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int n_cu = 256;
     std::string err;
-    size_t hbm_bytes = 0;
+    size_t hbm_bytes = 0, hbm_peak = 0;
 
     /* reads */
     u64 n = 0;
@@ -181,6 +254,8 @@ struct disco_ctx {
     bool index_counted = false; /* disco_upload_reads ran the index's count pass behind its copies: disco_build_index starts at the scan */
     u64 order_counted_lo = 0, order_counted_hi = 0;
     int order_counted_bits = 0;
+    u32 *d_cls_cnt = nullptr; /* multi-GPU flow, own nodes: entries on either side of the node (tr_request_first_kernel) */
+    u64 cls_cnt_cap = 0;
     ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
     u64 meta_cap = 0;
     u64 *d_nref = nullptr; /* multi-GPU flow: reference words nref[2u + cls] of the neighbour-row store */
@@ -338,8 +413,18 @@ template <typename T>
 static int dev_alloc(disco_ctx *c, T **p, size_t count)
 {
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (c->arena.base) {
+        if (void *q = c->arena.alloc(bytes)) {
+            *p = (T *)q;
+            c->hbm_bytes += bytes;
+            c->hbm_peak = std::max(c->hbm_peak, c->hbm_bytes);
+            return DISCO_OK;
+        }
+    }
+    tl_pass.dev_allocs++;
     HIPCHK(c, hipMalloc((void **)p, bytes));
     c->hbm_bytes += bytes;
+    c->hbm_peak = std::max(c->hbm_peak, c->hbm_bytes);
     return DISCO_OK;
 }
 
@@ -347,7 +432,11 @@ template <typename T>
 static void dev_free(disco_ctx *c, T **p, size_t count)
 {
     if (*p) {
-        (void)hipFree(*p);
+        if (c->arena.owns(*p)) c->arena.release(*p);
+        else {
+            tl_pass.dev_frees++;
+            (void)hipFree(*p);
+        }
         size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
         c->hbm_bytes = c->hbm_bytes >= bytes ? c->hbm_bytes - bytes : 0;
         *p = nullptr;
@@ -501,6 +590,7 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_ocnt, c->ocnt_cap);
     dev_free(c, &c->d_okey, c->okey_cap);
     dev_free(c, &c->d_meta_ord, c->meta_cap);
+    dev_free(c, &c->d_cls_cnt, c->cls_cnt_cap);
     c->meta_cap = 0;
     dev_free(c, &c->d_oslot, c->oslot_cap);
     dev_free(c, &c->d_order_own, c->order_cap);
@@ -911,6 +1001,7 @@ void disco_destroy(disco_ctx *c)
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->arena.base) (void)hipFree(c->arena.base); /* (every buffer carved out of it was released above or dies with it) */
     delete c;
 }
 
@@ -3630,7 +3721,7 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     CHK(ensure_cap(c, &c->d_rdeg_s, &c->rdeg_s_cap, std::max<u64>(nrq, 1)));
     CHK(ensure_cap(c, &c->d_rpos, &c->rpos_cap, std::max<u64>(std::max(nrq, n_flat), 1) + 1));
     const int rgrid = (int)std::max<u64>(std::min<u64>(nrq, (u64)c->n_cu * 32), 1);
-    if (nrq) hipLaunchKernelGGL(tr_respond_kernel<false>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, c->d_rdeg_s, (const u64 *)nullptr, (u32 *)nullptr);
+    if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
     HIPCHK(c, hipGetLastError());
     u64 total_s = 0;
     CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_s, nrq, c->d_rpos, true, &total_s)));
@@ -3683,7 +3774,8 @@ static int dist_transitive_mark(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, 2 * nloc + 64));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, lo, hi, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
+    CHK(ensure_cap(c, &c->d_cls_cnt, &c->cls_cnt_cap, std::max<u64>(nloc, 1)));
+    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, lo, hi, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr, c->d_cls_cnt);
     HIPCHK(c, hipGetLastError());
     u64 n_flat = 0;
     HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -4137,6 +4229,33 @@ int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
     return rc;
 }
 
+/* the arena of a multi-GPU context (DevArena): made once, before the first collective of the first pass. Sized for what a pass keeps
+ * per read — measured with 8 ranks at 50 M x 150 bp (8.9 GB per rank): about 760 bytes per own read (hit buffer, adjacency, headers,
+ * exchange buffers) + 46 per read of the job (index, containment keys, bitmaps) — with 60 % on top; DISCO_DIST_ARENA_MB overrides, DISCO_DIST_NO_ARENA=1
+ * switches it off (every request then goes to the runtime, as in rounds 1-3) */
+static int arena_reserve(disco_ctx *c)
+{
+    if (c->arena.base || getenv("DISCO_DIST_NO_ARENA")) return DISCO_OK;
+    const u64 own = c->q_hi - c->q_lo;
+    size_t want = (size_t)((double)(own * 760ull + c->n * 46ull) * 1.6) + (256ull << 20);
+    if (const char *e = getenv("DISCO_DIST_ARENA_MB")) want = (size_t)atoll(e) << 20;
+    size_t fr = 0, tot = 0;
+    HIPCHK(c, hipMemGetInfo(&fr, &tot));
+    want = std::min(want, fr / 10 * 9);
+    void *p = nullptr;
+    while (want >= (64ull << 20)) {
+        if (hipMalloc(&p, want) == hipSuccess) break;
+        (void)hipGetLastError();
+        p = nullptr;
+        want /= 2;
+    }
+    if (!p) return DISCO_OK; /* no arena: the runtime serves the pass (counted) */
+    c->arena.base = (char *)p;
+    c->arena.size = want & ~(size_t)255;
+    c->arena.free_at[0] = c->arena.size;
+    return DISCO_OK;
+}
+
 static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
 {
     DISCO_TRACE("disco_dist_run_graph");
@@ -4145,7 +4264,17 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
     if (!c->dist_reads || c->phase < 1) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: set the reads with disco_dist_upload_reads / disco_dist_generate_reads");
     HIPCHK(c, hipSetDevice(c->device));
     const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    CHK(arena_reserve(c));
+    struct PassToken { /* (in-process transport, DISCO_LOOP_SERIALIZE: one rank's compute segment on the device at a time) */
+        DiscoComm *cm;
+        explicit PassToken(DiscoComm *x) : cm(x) { cm->begin_pass(); }
+        ~PassToken() { cm->end_pass(); }
+    } pass_token(c->comm);
     const auto t_pass = HClock::now();
+    const PassCounters pc0 = tl_pass;
+    const u32 ops0 = c->comm->n_ops + (c->comm_bulk ? c->comm_bulk->n_ops : 0u);
+    const u32 hops0 = c->comm->n_host_ops + (c->comm_bulk ? c->comm_bulk->n_host_ops : 0u);
+    c->hbm_peak = c->hbm_bytes;
     disco_dist_info &di = c->dinfo;
     memset(&di, 0, sizeof di);
     di.world = G;
@@ -4268,6 +4397,18 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
     di.e_out = tot[0];
     di.e_out_local = n_out;
     di.ms_total = ms_since(t_pass);
+    di.device_allocs = tl_pass.dev_allocs - pc0.dev_allocs;
+    di.device_frees = tl_pass.dev_frees - pc0.dev_frees;
+    di.host_syncs = tl_pass.host_syncs - pc0.host_syncs + (c->comm->n_host_ops + (c->comm_bulk ? c->comm_bulk->n_host_ops : 0u) - hops0);
+    di.comm_ops = c->comm->n_ops + (c->comm_bulk ? c->comm_bulk->n_ops : 0u) - ops0;
+    di.arena_bytes = c->arena.size;
+    di.arena_peak = c->arena.peak;
+    di.hbm_peak = c->hbm_peak;
+    {
+        float km = 0;
+        for (int i = 0; i < DISCO_PH_COUNT; i++) km += c->ph_ms[i];
+        di.kernel_ms = km;
+    }
     return DISCO_OK;
 }
 

@@ -221,6 +221,13 @@ typedef struct disco_dist_info {
     uint64_t bytes_sent[DISCO_X_COUNT];       /* this rank's payload bytes to OTHER ranks, last pass          */
     float ms[DISCO_X_COUNT];                  /* host wall time of each exchange on this rank, last pass      */
     float ms_total;
+    /* round 4 (appended): what the last pass did on this rank besides its kernels */
+    float kernel_ms;                          /* sum of the phase timers (HIP events around the kernels of each phase)              */
+    uint32_t comm_ops;                        /* operations issued on the communicator(s): collectives and small host exchanges       */
+    uint32_t host_syncs;                      /* blocking waits of the host on the device (stream / event synchronisations)           */
+    uint32_t device_allocs, device_frees;     /* requests that reached the HIP runtime DURING the pass (0 with the arena in place)    */
+    uint64_t arena_bytes, arena_peak;         /* the context's arena (one allocation before the first collective) and its high water  */
+    uint64_t hbm_peak;                        /* most device memory the context's buffers held during the pass (arena or not)         */
 } disco_dist_info;
 /* fills out[0..DISCO_UNIQUE_ID_BYTES) on ONE rank (ncclGetUniqueId); the caller hands it to the others (MPI_Bcast-like, any
  * side channel) */
