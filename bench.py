@@ -213,7 +213,9 @@ def stage_wall(args, spec, e_pre):
             return {"failed": p.stdout[-500:]}
         parts = {}
         for key, pat in (("parse_filter_pack_s", r"Function readDataset\(\) finished in ([0-9.eE+-]+)"), ("graph_s", r"\[GPU\] finished in ([0-9.eE+-]+)"),
-                         ("upload_s", r"host->device ([0-9.eE+-]+)"), ("fetch_and_write_s", r"Function saveParGraphToFile\(\) finished in ([0-9.eE+-]+)")):
+                         ("upload_s", r"host->device ([0-9.eE+-]+)"), ("fetch_and_write_s", r"Function saveParGraphToFile\(\) finished in ([0-9.eE+-]+)"),
+                         ("process_start_to_context_s", r"process start to context ready\s+([0-9.eE+-]+)"), ("files_into_hbm_s", r"files into HBM ([0-9.eE+-]+) s"),
+                         ("main_s", r"Function main\(\) finished in ([0-9.eE+-]+)")):
             m = re.search(pat, p.stdout)
             if m:
                 parts[key] = float(m.group(1))

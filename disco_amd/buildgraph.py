@@ -85,6 +85,8 @@ ABI = [
     ("disco_partition_edges", C.c_int64, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     ("disco_format_edges", C.c_int64, [_P, C.c_uint32, _P, _P, _P]),
     ("disco_fetch_edge_text", C.c_int, [_P, _P, C.c_uint64]),
+    ("disco_write_edge_text", C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    ("disco_start_contained_rows", C.c_int, [_P, C.c_int]),
     ("disco_contract_chains", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("disco_contract_chains_of", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("disco_fetch_chains", C.c_int, [_P, _P, _P, _P]),

@@ -232,6 +232,7 @@ struct disco_ctx {
     void *h_crows = nullptr; /* pinned: keys u64[crows_hcap] then ids u32[crows_hcap] */
     u64 crows_hcap = 0, crows_n = 0;
     bool crows_pending = false; /* the rows of the CURRENT flags are on their way / in h_crows */
+    bool crows_in_ring = false; /* h_crows is the input stage's pinned ring (h_ring), not an allocation of its own */
     u32 *d_cgrp_cur = nullptr, *d_cgrp_id = nullptr; /* the same rows grouped by containing read (disco_fetch_contained_grouped) */
     u64 *d_cgrp_key = nullptr, *d_cgrp_big = nullptr;
     u64 cgrp_cur_cap = 0, cgrp_cap = 0;
@@ -247,6 +248,12 @@ struct disco_ctx {
     std::vector<u64> ingest_id_base, ingest_rec_base; /* per file: first read id, records before the file */
     u64 ingest_n = 0;
     void *h_ring = nullptr; /* pinned: two halves of the text staging ring */
+    std::vector<u64> text_off; /* disco_format_edges: byte range of every file inside d_text */
+    u8 *d_ingest = nullptr; /* the input stage's own arena (text, record arrays) when the hit buffer is allocated NEXT to it ... */
+    u64 ingest_cap = 0;
+    std::thread hits_prealloc; /* ... by this thread, while the files travel and the filter runs (settle_hits_prealloc) */
+    u64 *prealloc_ptr = nullptr;
+    u64 prealloc_cap = 0;
     size_t ring_half = 0;
     hipEvent_t ev_ring[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr; /* disco_upload_reads: the chunks of the host buffer travel here */
@@ -823,8 +830,17 @@ static int start_contained_rows(disco_ctx *c, bool grouped)
         CHK(dev_alloc(c, &c->d_crow_key, want));
         c->crow_cap = want;
     }
-    if (nc > c->crows_hcap) {
+    if (nc > c->crows_hcap && c->h_ring && !c->crows_in_ring && (u64)c->ring_half * 2 >= (nc + 1024) * 24) {
+        /* the pinned ring of the input stage is idle between the input stage and the text output: the rows stage there (pinning
+         * 140 MB for them took 0.05 s of the host thread that feeds the pass) */
         if (c->h_crows) (void)hipHostFree(c->h_crows);
+        c->h_crows = c->h_ring;
+        c->crows_hcap = (u64)c->ring_half * 2 / 24;
+        c->crows_in_ring = true;
+    }
+    if (nc > c->crows_hcap) {
+        if (c->h_crows && !c->crows_in_ring) (void)hipHostFree(c->h_crows);
+        c->crows_in_ring = false;
         c->h_crows = nullptr;
         c->crows_hcap = 0;
         const u64 want = nc + nc / 4 + 1024;
@@ -886,6 +902,38 @@ static int settle_contained_rows(disco_ctx *c)
     c->crows_pending = false;
     c->cgrp_pending = false;
     return DISCO_OK;
+}
+
+/* the pinned ring is wanted for text again (input stage, edge text): rows that stage in it and have not been fetched are given up
+ * (the fetch gathers them again on demand) */
+static int ring_back_from_rows(disco_ctx *c)
+{
+    if (!c->crows_in_ring) return DISCO_OK;
+    if (c->crows_pending && c->aux_stream) HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+    c->crows_pending = c->cgrp_pending = false;
+    c->h_crows = nullptr;
+    c->crows_hcap = 0;
+    c->crows_in_ring = false;
+    return DISCO_OK;
+}
+
+/* the hit buffer the input stage asked for on a thread of its own: take it over (a device allocation costs 17-33 ms per GB on these
+ * boxes — 0.5 to 0.9 s for the 28 GB of 50 M reads — and nothing needs the buffer before the probe) */
+static void settle_hits_prealloc(disco_ctx *c)
+{
+    if (!c->hits_prealloc.joinable()) return;
+    c->hits_prealloc.join();
+    if (c->prealloc_ptr) {
+        if (c->prealloc_cap > c->hits_cap) {
+            dev_free(c, &c->d_hits, c->hits_cap);
+            c->d_hits = c->prealloc_ptr;
+            c->hits_cap = c->prealloc_cap;
+            c->hbm_bytes += c->prealloc_cap * 8;
+        } else
+            (void)hipFree(c->prealloc_ptr);
+        c->prealloc_ptr = nullptr;
+        c->prealloc_cap = 0;
+    }
 }
 
 static int dist_mark_contained(disco_ctx *c); /* multi-GPU flow, below */
@@ -986,7 +1034,9 @@ void disco_destroy(disco_ctx *c)
     dev_free(c, &c->d_cgrp_big, 1);
     dev_free(c, &c->d_fetch_src, c->fetch_cap);
     dev_free(c, &c->d_fetch_ent, c->fetch_cap);
-    if (c->h_crows) (void)hipHostFree(c->h_crows);
+    if (c->h_crows && !c->crows_in_ring) (void)hipHostFree(c->h_crows);
+    settle_hits_prealloc(c);
+    dev_free(c, &c->d_ingest, c->ingest_cap);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     for (int i = 0; i < 2; i++)
         if (c->ev_ring[i]) (void)hipEventDestroy(c->ev_ring[i]);
@@ -1271,6 +1321,7 @@ static void ingest_tables(FxTables *tb)
 static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned threads)
 {
     const size_t HALF = 128u << 20;
+    CHK(ring_back_from_rows(c));
     if (!c->h_ring) {
         if (hipHostMalloc(&c->h_ring, 2 * HALF) != hipSuccess) {
             c->h_ring = nullptr;
@@ -1361,27 +1412,67 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         f.text_cap = (f.n + FX_TILE + 63) / FX_TILE * FX_TILE + 64; /* whole tiles (16-byte loads) and aligned 8-byte words behind the end */
         total_bytes += f.text_cap;
     }
-    /* ---- the arena = the hit buffer as the probe will want it (a previous pass's results in it are gone) ------------------------- */
+    /* ---- the arena. The transient buffers of this stage (text, record arrays) come out of ONE allocation. Where memory is plentiful it
+     * is the stage's own (kept by the context: freeing 10 GB right before the pass made the pass's first allocations take 0.6 s), and the
+     * hit buffer the probe will want — 64 candidate slots per read, 28 GB at 50 M reads, 0.5-0.9 s of hipMalloc — is allocated by a
+     * thread of its own while the files travel to HBM and the filter runs. Where it is not (2 x 10^8 reads on one GPU), the arena IS
+     * the hit buffer, as in round 3: the text lives where the candidates will. A previous pass's results are gone either way. */
     if (c->phase > 1) c->phase = 1;
     c->d_adj = nullptr;
     c->adj_total = 0;
+    settle_hits_prealloc(c);
     {
-        /* entries: 64 per read as the probe will ask, a chunk per resident wave; reads estimated at one per 150 bytes of text (shorter
-         * records: the probe grows the buffer itself). Not more than needed: on a cold device a hipMalloc costs about 30 ms per GB */
+        /* hit entries: 64 per read as the probe will ask, a chunk per resident wave; reads estimated at one per 150 bytes of text (shorter
+         * records: the probe grows the buffer itself) */
         const u64 want = (total_bytes / 150) * 64 + (u64)c->n_cu * 32 * PR_CHUNK + (1u << 16);
-        if (want > c->hits_cap) {
-            size_t fr = 0, tot = 0;
-            HIPCHK(c, hipMemGetInfo(&fr, &tot));
-            if ((u64)fr + c->hits_cap * 8 > want * 8 + (total_bytes / 150) * 200 + (4ull << 30)) { /* room for it next to the table and the index */
+        const u64 own_bytes = total_bytes + (total_bytes / 100) * 24 + (64ull << 20); /* text + record arrays (a record per 100 bytes at worst here; more: pieces of their own) */
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            cleanup();
+            return fail(c, DISCO_E_HIP, "disco_ingest_fasta: hipMemGetInfo failed");
+        }
+        const u64 rest = (total_bytes / 150) * 200 + (4ull << 30); /* the read table and the index next to it */
+        if (c->arena.base && !c->comm && c->arena.used == 0 && !c->d_ingest) { /* the last call's arena, idle again: this call's text goes there */
+            c->d_ingest = (u8 *)c->arena.base;
+            c->ingest_cap = c->arena.size;
+            c->arena = DevArena();
+        }
+        const bool split = !getenv("DISCO_INGEST_SHARED_ARENA") && !c->arena.base && (u64)fr + c->hits_cap * 8 + c->ingest_cap > std::max(want, c->hits_cap) * 8 + own_bytes + rest + (16ull << 30);
+        if (split) {
+            if (own_bytes > c->ingest_cap) {
+                dev_free(c, &c->d_ingest, c->ingest_cap);
+                c->ingest_cap = 0;
+                if (dev_alloc(c, &c->d_ingest, own_bytes) == DISCO_OK) c->ingest_cap = own_bytes;
+                else c->err.clear();
+            }
+            if (want > c->hits_cap && c->ingest_cap) {
+                const int dev = c->device;
+                disco_ctx *cc = c;
+                c->hits_prealloc = std::thread([cc, dev, want]() {
+                    void *p = nullptr;
+                    if (hipSetDevice(dev) == hipSuccess && hipMalloc(&p, want * 8) == hipSuccess) {
+                        cc->prealloc_ptr = (u64 *)p;
+                        cc->prealloc_cap = want;
+                    } else
+                        (void)hipGetLastError();
+                });
+            }
+        }
+        if (split && c->ingest_cap) {
+            arena.base = c->d_ingest;
+            arena.cap = c->ingest_cap;
+        } else {
+            if (want > c->hits_cap && (u64)fr + c->hits_cap * 8 > want * 8 + rest) { /* room for it next to the table and the index */
                 dev_free(c, &c->d_hits, c->hits_cap);
                 c->hits_cap = 0;
                 if (dev_alloc(c, &c->d_hits, want) == DISCO_OK) c->hits_cap = want;
                 else c->err.clear();
             }
+            arena.base = (u8 *)c->d_hits;
+            arena.cap = c->hits_cap * 8;
         }
-        arena.base = (u8 *)c->d_hits;
-        arena.cap = c->hits_cap * 8;
     }
+    const float t_arena = ms_since(t_begin) * 1e-3f;
     int rc = DISCO_OK;
     auto get = [&](auto **pp, u64 count) -> int { /* from the arena, or an allocation of its own */
         using T = typename std::remove_pointer<typename std::remove_pointer<decltype(pp)>::type>::type;
@@ -1527,9 +1618,23 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return DISCO_OK;
     };
+    const float t_pass_a = ms_since(t_begin) * 1e-3f;
     rc = pass_b();
     cleanup();
     CHK(rc);
+    if (getenv("DISCO_VERBOSE"))
+        fprintf(stderr, "[disco] input stage: arena of %.1f GB %.3f s, files + records + filter %.3f s (files %.3f), table + ids + rows %.3f s\n", arena.cap / 1e9, t_arena,
+                t_pass_a - t_arena, read_s, ms_since(t_begin) * 1e-3f - t_pass_a);
+    /* the stage's own arena is free space from here on: the context's allocator serves the pass from it (its index, headers, adjacency
+     * and result buffers: a dozen device allocations of 5-10 ms each that the first pass of a fresh context otherwise waits for) */
+    if (c->d_ingest && arena.base == c->d_ingest && owned.empty() && !getenv("DISCO_NO_ARENA_HANDOVER")) {
+        c->arena = DevArena();
+        c->arena.base = (char *)c->d_ingest;
+        c->arena.size = c->ingest_cap & ~(u64)255;
+        c->arena.free_at[0] = c->arena.size;
+        c->d_ingest = nullptr;
+        c->ingest_cap = 0;
+    }
     c->ingest_n = n_good;
     c->max_len = longest;
     c->min_len = shortest;
@@ -1678,6 +1783,7 @@ int disco_probe(disco_ctx *c)
     if (c->phase < 2) return fail(c, DISCO_E_STATE, "disco_probe: build the index first");
     HIPCHK(c, hipSetDevice(c->device));
     CHK(settle_contained_rows(c)); /* rows of the previous pass still travelling read best[] */
+    settle_hits_prealloc(c);
     const u64 nq = c->q_hi - c->q_lo;
     if (!c->d_best) {
         CHK(dev_alloc(c, &c->d_best, c->n_alloc));
@@ -2991,6 +3097,7 @@ int64_t disco_format_edges(disco_ctx *c, uint32_t n_files, const uint16_t *edge_
             base += total;
         }
         file_offsets[n_files] = base;
+        c->text_off.assign(file_offsets, file_offsets + n_files + 1);
         CHK(ensure_cap(c, &c->d_text, &c->text_cap, std::max<u64>(base, 1)));
         hipLaunchKernelGGL(text_write_kernel, dim3(flat_grid(c, g.n_slots)), dim3(256), 0, c->stream, g, place, c->d_text);
         HIPCHK(c, hipGetLastError());
@@ -3018,6 +3125,94 @@ int disco_fetch_edge_text(disco_ctx *c, char *out, uint64_t cap)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return DISCO_OK;
+}
+
+/* the formatted edge lines straight into the caller's open files (fds[f] receives the bytes of file f, from its offset 0): the text
+ * leaves the device in 128 MB pieces through the context's pinned ring, and while a piece travels host threads pwrite the one before
+ * it — the mirror image of disco_ingest_fasta's file reader. (disco_fetch_edge_text into 2.5 GB of fresh pageable memory, then the
+ * writer: 0.19 s at config 3; this: the link's 0.05 s.) */
+int disco_write_edge_text(disco_ctx *c, const int *fds, uint32_t n_files, uint32_t host_threads)
+{
+    DISCO_TRACE("disco_write_edge_text");
+    if (!c || !fds) return DISCO_E_ARG;
+    if (c->text_off.size() != (size_t)n_files + 1) return fail(c, DISCO_E_STATE, "disco_write_edge_text: run disco_format_edges for %u files first", n_files);
+    HIPCHK(c, hipSetDevice(c->device));
+    const u64 n = c->text_bytes;
+    if (n == 0) return DISCO_OK;
+    const size_t HALF = 128u << 20;
+    CHK(ring_back_from_rows(c));
+    if (!c->h_ring) {
+        if (hipHostMalloc(&c->h_ring, 2 * HALF) != hipSuccess) {
+            c->h_ring = nullptr;
+            (void)hipGetLastError();
+            return fail(c, DISCO_E_NOMEM, "disco_write_edge_text: no pinned staging memory");
+        }
+        c->ring_half = HALF;
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ring[i], hipEventDisableTiming));
+    }
+    (void)host_threads; /* one writer per file and round: writes to ONE file serialise on its inode lock (16 threads on one file: 12 GB/s;
+                           one thread on each of 16 files: the link's rate) */
+    std::atomic<bool> ok{true};
+    /* a round moves one slice of every file: slice r of file f = bytes [r S, (r + 1) S) of it, S = the ring half divided among the files */
+    const size_t S = (HALF / n_files) & ~(size_t)4095;
+    if (S == 0) return fail(c, DISCO_E_UNSUPPORTED, "disco_write_edge_text: too many files for the staging ring");
+    u64 longest = 0;
+    for (uint32_t f = 0; f < n_files; f++) longest = std::max(longest, c->text_off[f + 1] - c->text_off[f]);
+    const u64 rounds = (longest + S - 1) / S;
+    auto slice = [&](uint32_t f, u64 r, u64 &lo, size_t &len) { /* file-local byte range of the slice */
+        const u64 fl = c->text_off[f + 1] - c->text_off[f];
+        lo = std::min<u64>(r * S, fl);
+        len = (size_t)(std::min<u64>((r + 1) * S, fl) - lo);
+    };
+    auto drain = [&](u64 r, const char *half) {
+        std::vector<std::thread> th;
+        for (uint32_t f = 0; f < n_files; f++) {
+            u64 lo;
+            size_t len;
+            slice(f, r, lo, len);
+            if (!len) continue;
+            th.emplace_back([&, f, lo, len]() {
+                size_t done = 0;
+                while (done < len) {
+                    const ssize_t w = pwrite(fds[f], half + (size_t)f * S + done, len - done, (off_t)(lo + done));
+                    if (w <= 0) {
+                        ok.store(false);
+                        return;
+                    }
+                    done += (size_t)w;
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+    };
+    for (u64 r = 0; r < rounds; r++) {
+        char *half = (char *)c->h_ring + (r & 1) * HALF;
+        for (uint32_t f = 0; f < n_files; f++) {
+            u64 lo;
+            size_t len;
+            slice(f, r, lo, len);
+            if (len) HIPCHK(c, hipMemcpyAsync(half + (size_t)f * S, c->d_text + c->text_off[f] + lo, len, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_ring[r & 1], c->stream));
+        if (r >= 1) drain(r - 1, (const char *)c->h_ring + ((r - 1) & 1) * HALF); /* (its copies were waited for below, one round ago) */
+        HIPCHK(c, hipEventSynchronize(c->ev_ring[r & 1]));
+    }
+    if (rounds) drain(rounds - 1, (const char *)c->h_ring + ((rounds - 1) & 1) * HALF);
+    if (!ok.load()) return fail(c, DISCO_E_ARG, "disco_write_edge_text: write error");
+    return DISCO_OK;
+}
+
+/* the contained rows of the current flags start their way to the host now, on a side stream (grouped: also in the order of the
+ * contained-read files), instead of when they are asked for: for callers that have work between disco_mark_contained and
+ * disco_fetch_contained[_grouped] — buildG: edge selection and the reduction (they lose 1-3 ms to the side stream; the fetch then
+ * only waits for what is left and decodes) */
+int disco_start_contained_rows(disco_ctx *c, int grouped)
+{
+    if (!c) return DISCO_E_ARG;
+    if (c->phase < 4) return fail(c, DISCO_E_STATE, "disco_start_contained_rows: run disco_mark_contained first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_contained == 0) return DISCO_OK;
+    return start_contained_rows(c, grouped != 0);
 }
 
 /* ---- chains of the reduced graph as composite edges (kernels and the argument: disco_chains.h) ------------- */

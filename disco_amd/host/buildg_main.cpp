@@ -264,6 +264,7 @@ int main(int argc, char **argv)
     if (gpus == 1 && !getenv("DISCO_HOST_INPUT")) {
         const disco_params prm0{min_overlap, 4, getenv("DISCO_EXACT_COUNTERS") ? 0u : DISCO_FLAG_TWO_PASS_VERIFY, max_subs};
         if (disco_create(gpu, &prm0, &ctx1) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
+        if (getenv("DISCO_VERBOSE")) fprintf(stderr, "[disco host] process start to context ready   %.3f s\n", secs(t_main));
         std::vector<const char *> paths;
         for (auto &f : pe) paths.push_back(f.c_str());
         for (auto &f : se) paths.push_back(f.c_str());
@@ -280,9 +281,14 @@ int main(int argc, char **argv)
             /* lengths and file indices of the reads come to the host on a thread of their own while the graph is built: only the
              * writers need them */
             ingest_fetch = std::thread([&rs, &ingest_fetch_rc, ctx1, n = ii.n_reads]() {
-                rs.len.resize(n);
+                const auto tf = Clock::now();
+                /* (first touch by two threads: value-initialising 500 MB in one took 0.12 s, which the graph pass does not cover) */
+                std::thread zl([&rs, n]() { rs.len.resize(n); });
                 rs.file_index.resize(n);
+                zl.join();
+                const double tz = secs(tf);
                 ingest_fetch_rc = disco_ingest_fetch(ctx1, rs.len.data(), rs.file_index.data());
+                if (getenv("DISCO_VERBOSE")) fprintf(stderr, "[disco host] lengths + file indices to the host  %.3f s (of which first touch %.3f)\n", secs(tf), tz);
             });
             for (size_t i = 0; i < paths.size(); i++) {
                 disco::FileRange fr;
@@ -357,6 +363,18 @@ int main(int argc, char **argv)
     double t_graph = 0, t_h2d = 0;
     t0 = Clock::now();
     auto t1 = Clock::now();
+    /* (threads declared before anything that may return early: their holders join on the way out) */
+    struct ThreadHolder {
+        std::thread t;
+        ~ThreadHolder()
+        {
+            if (t.joinable()) t.join();
+        }
+    } contained_writer_holder, ctx_releaser_holder;
+    std::thread &contained_writer = contained_writer_holder.t, &ctx_releaser = ctx_releaser_holder.t;
+    bool contained_early = false, contained_ok = true, edge_text_streamed = false;
+    std::string contained_err;
+    const disco::FileTags ctags_early = mpi_names ? disco::FileTags::mpi_contained(gpus, threads) : disco::FileTags::plain(threads);
     auto lap = [&](const char *what) {
         if (verbose) fprintf(stderr, "[disco host] %-28s %.3f s\n", what, secs(t1));
         t1 = Clock::now();
@@ -372,6 +390,8 @@ int main(int argc, char **argv)
         DISCO_CALL(ctx, disco_mark_contained(ctx, &n_cont));
         std::cout << "\n" << (rs.size() - n_cont) << " Non-contained reads. (Keep as is)\n"
                   << n_cont << " contained reads. (Need to change their mate-pair information)" << std::endl;
+        /* the contained rows leave now, grouped for their files, while the edges are selected and reduced */
+        if (n_cont && !getenv("DISCO_HOST_ROW_SORT") && !getenv("DISCO_LATE_ROWS")) (void)disco_start_contained_rows(ctx, 1);
         DISCO_CALL(ctx, disco_build_edges(ctx, &e_pre));
         DISCO_CALL(ctx, disco_transitive_reduce(ctx, &e_out));
         t_graph = secs(t0);
@@ -390,6 +410,7 @@ int main(int argc, char **argv)
         t0 = Clock::now();
         t1 = Clock::now();
         if (!join_ingest_fetch()) return die(disco_last_error(ctx));
+        lap("wait for lengths + file indices");
         rows.resize(n_cont);
         if (n_cont) { /* in the files' order where the device grouped them during the pass; by id (sorted by the writer) otherwise */
             const int64_t grc = getenv("DISCO_HOST_ROW_SORT") ? (int64_t)DISCO_E_UNSUPPORTED : disco_fetch_contained_grouped(ctx, rows.data(), n_cont);
@@ -398,6 +419,16 @@ int main(int argc, char **argv)
             if (!rows_grouped && disco_fetch_contained(ctx, rows.data(), n_cont) < 0) return die(disco_last_error(ctx));
         }
         lap("fetch contained rows");
+        /* the contained-read files are written by a thread of their own while the device partitions and formats the edges (their rows
+         * have been final since the contained flags were fixed); joined before the checkpoint is written */
+        if (!no_text && !binary_out) {
+            contained_early = true;
+            contained_writer = std::thread([&]() {
+                std::string e2;
+                contained_ok = disco::write_contained(prefix, (int)ctags_early.tag.size(), rows, rs, e2, &ctags_early, rows_grouped);
+                if (!contained_ok) contained_err = e2;
+            });
+        }
         /* connected components of the reduced graph dealt out to the files: every node has all its edges in one file, which is
          * what lets parsimplify work on the files independently (the reference gets it from its BFS batches) */
         edge_file.reset(new uint16_t[std::max<uint64_t>(e_out, 1)]);
@@ -409,12 +440,27 @@ int main(int argc, char **argv)
             edge_text_off.assign((size_t)n_edge_files + 1, 0);
             const int64_t nb = disco_format_edges(ctx, (uint32_t)n_edge_files, edge_file.get(), identity ? nullptr : rs.file_index.data(), edge_text_off.data());
             if (nb < 0) return die(disco_last_error(ctx));
-            edge_text.reset(new char[std::max<int64_t>(nb, 1)]);
-            DISCO_CALL(ctx, disco_fetch_edge_text(ctx, edge_text.get(), (uint64_t)nb));
             lap("format edge lines on the GPU");
+            if (!binary_out && par_simple.empty() && !getenv("DISCO_TEXT_VIA_HOST")) {
+                /* straight from the device into the edge files (pieces through a pinned ring, host threads pwrite behind the copies) */
+                const disco::FileTags et = mpi_names ? disco::FileTags::mpi_edges(gpus, threads) : disco::FileTags::plain(threads);
+                std::vector<int> fds((size_t)n_edge_files, -1);
+                std::string ferr;
+                if (!disco::open_edge_files(prefix, (int)n_edge_files, &et, rs.size(), fds.data(), ferr)) return die(ferr);
+                const int wrc = disco_write_edge_text(ctx, fds.data(), (uint32_t)n_edge_files, (uint32_t)threads);
+                for (int fd : fds)
+                    if (fd >= 0) close(fd);
+                if (wrc < 0) return die(disco_last_error(ctx));
+                edge_text_streamed = true;
+                lap("edge lines into the files");
+            } else {
+                edge_text.reset(new char[std::max<int64_t>(nb, 1)]);
+                DISCO_CALL(ctx, disco_fetch_edge_text(ctx, edge_text.get(), (uint64_t)nb));
+                lap("fetch edge lines");
+            }
         }
         /* the edges as host records: only for what still works on them there (binary side output, partial simplification, host-formatted text) */
-        if (binary_out || !par_simple.empty() || (!edge_text && !no_text)) {
+        if (binary_out || !par_simple.empty() || (!edge_text && !edge_text_streamed && !no_text)) {
             edges.reset(new disco_edge[std::max<uint64_t>(e_out, 1)]); /* 1.8 GB at 45 M edges: not zero-filled first */
             if (e_out && disco_fetch_edges(ctx, edges.get(), e_out) < 0) return die(disco_last_error(ctx));
             if (max_subs) {
@@ -432,8 +478,9 @@ int main(int argc, char **argv)
             DISCO_CALL(ctx, disco_fetch_chains(ctx, ch_comp.data(), ch_links.get(), ch_absorbed.get()));
             lap("contract chains on the GPU");
         }
-        disco_destroy(ctx);
-        lap("release GPU context");
+        /* the context is released by a thread of its own while the files are written (0.07 s of hipFree at config 3) */
+        ctx_releaser = std::thread([ctx]() { disco_destroy(ctx); });
+        lap("release GPU context (in the background)");
     } else {
         /* one rank per GPU, one host thread per rank (replaces mpirun -np N of runDisco-MPI.sh:214-258): rank r holds the reads
          * [r*per, (r+1)*per), every exchange is an RCCL collective inside libdisco_hip.so */
@@ -567,15 +614,21 @@ int main(int argc, char **argv)
         rows.clear();
         e_out = 0;
     }
-    if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags, rows_grouped)) return die(err);
+    if (contained_early) {
+        contained_writer.join();
+        if (!contained_ok) return die(contained_err);
+    } else if (!disco::write_contained(prefix, (int)ctags.tag.size(), rows, rs, err, &ctags, rows_grouped))
+        return die(err);
     lap("write contained rows");
     if (!disco::write_checkpoint(prefix, true, false, false, err)) return die(err);
-    if (edge_text && !no_text) {
+    if (edge_text_streamed && !no_text) { /* written while the text left the device */
+    } else if (edge_text && !no_text) {
         if (!disco::write_edge_text(prefix, (int)etags.tag.size(), edge_text.get(), edge_text_off.data(), rs.size(), err, &etags)) return die(err);
     } else if (!disco::write_edges(prefix, (int)etags.tag.size(), edges.get(), e_out, rs, threads, err, e_out ? edge_file.get() : nullptr, &etags, edge_subs.get()))
         return die(err);
     lap("write edges");
     if (!disco::write_checkpoint(prefix, false, true, true, err)) return die(err);
+    if (ctx_releaser.joinable()) ctx_releaser.join();
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;
     std::cout << "Function main() finished in " << secs(t_main) << " Seconds." << std::endl;
     return 0;

@@ -1,5 +1,7 @@
 /* writer.cpp — see writer.h */
 #include "writer.h"
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <omp.h>
 #include <sched.h>
@@ -391,6 +393,25 @@ bool write_edge_text(const std::string &prefix, int n_files, const char *text, c
         flush(prefix + "_" + tag_of(tags, t) + "_startRead.txt", std::to_string(first) + "\n", e2);
     }
     return ok;
+}
+
+/* the edge files of write_edge_text, created empty and handed back open (disco_write_edge_text fills them), with their
+ * <prefix>_<tag>_startRead.txt (layout compatibility: one start id per file, BG/OverlapGraph.cpp:211) */
+bool open_edge_files(const std::string &prefix, int n_files, const FileTags *tags, uint64_t n_reads, int *fds, std::string &err)
+{
+    for (int t = 0; t < n_files; t++) {
+        const std::string path = prefix + "_" + tag_of(tags, t) + "_parGraph.txt";
+        fds[t] = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fds[t] < 0) {
+            err = "Unable to write file: " + path;
+            for (int x = 0; x < t; x++) close(fds[x]);
+            return false;
+        }
+        std::string e2;
+        const uint64_t first = n_files ? (uint64_t)(((__uint128_t)n_reads * (unsigned)t + n_files - 1) / n_files) + 1 : 1;
+        flush(prefix + "_" + tag_of(tags, t) + "_startRead.txt", std::to_string(first) + "\n", e2);
+    }
+    return true;
 }
 
 namespace {

@@ -43,6 +43,7 @@ bool write_contained(const std::string &prefix, int n_files, std::vector<disco_c
 bool write_edges(const std::string &prefix, int n_files, const disco_edge *edges, size_t n_edges, const ReadSet &rs, int threads, std::string &err,
                  const uint16_t *edge_file = nullptr, const FileTags *tags = nullptr, const uint16_t *edge_subs = nullptr);
 /* the same files from text the GPU has formatted (disco_format_edges): file t = text[offsets[t], offsets[t + 1]) */
+bool open_edge_files(const std::string &prefix, int n_files, const FileTags *tags, uint64_t n_reads, int *fds, std::string &err);
 bool write_edge_text(const std::string &prefix, int n_files, const char *text, const uint64_t *offsets, uint64_t n_reads, std::string &err,
                      const FileTags *tags = nullptr);
 /* Binary side output: the same content as the text files without the formatting on this side and the parsing on

@@ -255,7 +255,8 @@ int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
 /* Reads FASTA / FASTQ files itself (parallel pread through pinned staging), finds the records, cleans and filters every read
  * (Dataset::readDataset / testRead, BG/Dataset.cpp:161-380,403-452) and packs the good ones into the context's read table, all on the
  * device: replaces parse + filter + pack on the host cores AND the upload. Read ids = rank among the good reads in file order over the
- * files in the order given (pass the -pe files, then the -se files). Returns DISCO_E_UNSUPPORTED — nothing changed — when a file is not
+ * files in the order given (pass the -pe files, then the -se files). The graph results of a previous pass on the context are discarded
+ * by the call, whatever it returns. Returns DISCO_E_UNSUPPORTED — the context's reads are unchanged — when a file is not
  * of a form the device stage accepts (FASTA: it must start with '>', every '>' must begin a line, every record's sequence must be one
  * line; FASTQ: it starts with '@', records of four lines; not accepted: .gz, empty or unreadable files): the caller then runs its host stage (disco_amd/host/fastx.cpp follows the reference's
  * getline calls literally and produces its error messages) and disco_upload_reads. */
@@ -277,6 +278,9 @@ int disco_ingest_fasta(disco_ctx *ctx, const char *const *paths, int n_files, ui
 int disco_ingest_fetch(disco_ctx *ctx, uint16_t *len, uint64_t *file_index);
 
 /* ---- results --------------------------------------------------------------------------------------------------- */
+/* optional: the rows start their way to the host NOW, on a side stream (grouped != 0: also in the contained-read files' order),
+ * for callers with device work between disco_mark_contained and the fetch (it costs that work 1-3 ms; the fetch then only waits) */
+int disco_start_contained_rows(disco_ctx *ctx, int grouped);
 /* rows in ascending contained-read id; returns the number of rows written, or a negative error */
 int64_t disco_fetch_contained(disco_ctx *ctx, disco_contained_row *out, uint64_t cap);
 /* the same rows in the order the contained-read files are written in — grouped by containing read (SG/DataSet.cpp:316-335 needs the
@@ -333,6 +337,9 @@ int disco_get_query_order(disco_ctx *ctx, const void **d_order_u64);
  * total number of bytes. At most 256 files, exact overlaps only (otherwise DISCO_E_UNSUPPORTED: the host writer formats). */
 int64_t disco_format_edges(disco_ctx *ctx, uint32_t n_files, const uint16_t *edge_file, const uint64_t *file_index, uint64_t *file_offsets);
 int disco_fetch_edge_text(disco_ctx *ctx, char *out, uint64_t cap);
+/* ... or straight into the caller's open files: fds[f] receives the bytes of file f (file_offsets[f] .. file_offsets[f + 1] of the
+ * last disco_format_edges for n_files files) from its offset 0; host_threads pwrite while the next piece leaves the device */
+int disco_write_edge_text(disco_ctx *ctx, const int *fds, uint32_t n_files, uint32_t host_threads);
 
 /* ---- chains of the reduced graph as composite edges ---------------------------------------------------- */
 /* The consumer's first step on the files this stage writes is parsimplify: every maximal chain of nodes with exactly two edges that
