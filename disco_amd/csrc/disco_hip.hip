@@ -1275,6 +1275,7 @@ struct IngestFile {
     u8 *d_text = nullptr;
     u64 text_cap = 0;
     u64 *d_start = nullptr, *d_seq = nullptr;
+    u32 *d_wrap = nullptr;
     u16 *d_glen = nullptr;
     u64 n_start = 0, n_rec = 0, good = 0;
 };
@@ -1425,7 +1426,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         /* hit entries: 64 per read as the probe will ask, a chunk per resident wave; reads estimated at one per 150 bytes of text (shorter
          * records: the probe grows the buffer itself) */
         const u64 want = (total_bytes / 150) * 64 + (u64)c->n_cu * 32 * PR_CHUNK + (1u << 16);
-        const u64 own_bytes = total_bytes + (total_bytes / 100) * 24 + (64ull << 20); /* text + record arrays (a record per 100 bytes at worst here; more: pieces of their own) */
+        const u64 own_bytes = total_bytes + (total_bytes / 100) * 28 + (64ull << 20); /* text + record arrays (a record per 100 bytes at worst here; more: pieces of their own) */
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
             cleanup();
@@ -1529,6 +1530,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             CHK(get(&f.d_start, f.n_start));
             CHK(get(&f.d_seq, f.n_rec));
             CHK(get(&f.d_glen, f.n_rec));
+            CHK(get(&f.d_wrap, f.n_rec));
             if (f.fastq) hipLaunchKernelGGL(fx_lines_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start);
             else hipLaunchKernelGGL(fx_starts_kernel, dim3((unsigned)tiles), dim3(256), 0, c->stream, (const u8 *)f.d_text, f.n, (u32 *)nullptr, (const u64 *)d_tile_base, f.d_start, d_ctr);
             FxFilterArgs fa;
@@ -1541,6 +1543,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             fa.fastq = f.fastq ? 1u : 0u;
             fa.glen = f.d_glen;
             fa.seq_begin = f.d_seq;
+            fa.wrap = f.d_wrap;
             fa.ctr = d_ctr;
             hipLaunchKernelGGL(fx_filter_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, fa, tb);
             HIPCHK(c, hipGetLastError());
@@ -1557,7 +1560,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             return DISCO_OK;
         };
         if (rc == DISCO_OK) rc = body();
-        if (rc == DISCO_E_UNSUPPORTED) return unsupported("a '>' inside a line, a sequence over several lines, or no record", f.path);
+        if (rc == DISCO_E_UNSUPPORTED) return unsupported("a '>' inside a line, an irregularly wrapped long record, or no record", f.path);
         if (rc != DISCO_OK) {
             cleanup();
             return rc;
@@ -1607,7 +1610,7 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             if (good != f.good) return fail(c, DISCO_E_STATE, "disco_ingest_fasta: %llu good reads counted, %llu placed", (unsigned long long)f.good, (unsigned long long)good);
             hipLaunchKernelGGL(fx_ids_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, (const u16 *)f.d_glen, (const u64 *)d_pos, f.n_rec, id_base, c->d_rec_of_read, c->d_len);
             if (f.good)
-                hipLaunchKernelGGL(fx_pack_kernel, dim3(flat_grid(c, f.good * (u64)dstride)), dim3(256), 0, c->stream, (const u8 *)f.d_text, (const u64 *)f.d_seq, (const u32 *)c->d_rec_of_read,
+                hipLaunchKernelGGL(fx_pack_kernel, dim3(flat_grid(c, f.good * (u64)dstride)), dim3(256), 0, c->stream, (const u8 *)f.d_text, (const u64 *)f.d_seq, (const u32 *)f.d_wrap, (const u32 *)c->d_rec_of_read,
                                    (const u16 *)c->d_len, id_base, f.good, (int)dstride, c->d_reads);
             HIPCHK(c, hipGetLastError());
             id_base += f.good;

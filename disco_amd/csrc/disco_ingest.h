@@ -6,8 +6,11 @@
  * (BG/HashTable.cpp:456-477). Host side: disco_hip.hip "input stage on the GPU".
  *
  * Accepted forms (decided on the device, per file; anything else makes the caller fall back to the host stage, which follows the
- * reference's getline calls literally): FASTA — the file starts with '>', every '>' is the first byte of a line, and every record's
- * sequence is ONE line (header line, sequence line, optional final newline); FASTQ — the file starts with '@': records of four lines
+ * reference's getline calls literally): FASTA — the file starts with '>' and every '>' is the first byte of a line; a record is its
+ * header line and everything up to the next '>' with the newlines taken out (BG/Dataset.cpp:270-281), so sequences may be wrapped
+ * (round 4). Records wrapped at ONE width (every line as long as the first, the last one at most that: what every FASTA writer
+ * produces) are addressed by arithmetic; irregular ones by walking, which is why an irregular record of more than FX_WALK_MAX bases, or any
+ * record of 2^21 bytes or more, still sends the file to the host stage. FASTQ — the file starts with '@': records of four lines
  * (found by counting lines, as the reference's four getline calls do). Lower case, N, CR and any other byte are handled as the
  * reference handles them (upper-cased; anything but ACGT rejects the read, BG/Dataset.cpp:411).
  *
@@ -21,6 +24,8 @@
 #define FX_TILE 4096 /* bytes of text per block of fx_starts_kernel */
 #define FX_MAX_MOTIFS 16
 #define FX_MAX_REPEATS 40
+#define FX_WALK_MAX 4096u /* bases of an irregularly wrapped record the device stage still addresses by walking its bytes */
+#define FX_WRAP_IRREGULAR 0xFFFFFFFFu
 
 /* counters of one ingest (u64 each) */
 enum { FX_CTR_BAD_GT = 0, FX_CTR_MULTILINE, FX_CTR_TOO_LONG, FX_CTR_MAX_LEN, FX_CTR_MIN_LEN_INV, FX_CTR_GOOD, FX_CTR_COUNT };
@@ -159,8 +164,22 @@ struct FxFilterArgs {
     u32 fastq;       /* the record's sequence is its SECOND line only (four-line records) */
     u16 *glen;       /* out [n_rec]: 0 = rejected, else the read length */
     u64 *seq_begin;  /* out [n_rec]: first byte of the sequence */
+    u32 *wrap;       /* out [n_rec]: bases per line of the (wrapped) sequence — base b is byte seq_begin + b + b / wrap; FX_WRAP_IRREGULAR: walk */
     u64 *ctr;
 };
+
+/* raw byte of base b of a sequence that begins at byte sb: by arithmetic for a sequence wrapped at `wrap` bases per line (a sequence on
+ * one line: wrap = its length), by walking over the newlines otherwise */
+__device__ __forceinline__ u64 fx_raw_of(FxBytes &tx, u64 sb, u32 wrap, u32 b)
+{
+    if (wrap != FX_WRAP_IRREGULAR) return sb + b + (wrap ? b / wrap : 0u);
+    u64 p = sb;
+    for (u32 seen = 0;; p++) {
+        if (tx.at(p) == '\n') continue;
+        if (seen == b) return p;
+        seen++;
+    }
+}
 
 /* one thread per record: clean (upper case) + count in one pass over the sequence line, then Dataset::testRead
  * (BG/Dataset.cpp:403-452) exactly as disco_amd/host/fastx.cpp:test_read_counted evaluates it */
@@ -178,19 +197,38 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
         if (a.fastq) { /* the sequence line ends at its newline (or with the file) */
             se = sb;
             while (se < e && tx.at(se) != '\n') se++;
-        } else if (se > sb && tx.at(se - 1) == '\n')
-            se--;
+        }
         a.seq_begin[i] = sb;
-        const u64 L = se - sb;
         /* counters packed into words (a dynamically indexed local array would live in scratch memory): A | C << 32, G | T << 32, the six
          * dimers of two different letters — their occurrences cannot overlap, so plain counts — AC | AG << 21 | AT << 42, CG | CT << 21 | GT << 42 */
         u64 acgt01 = 0, acgt23 = 0, dimA = 0, dimB = 0, other = 0;
         u64 head = 0, tail = 0;
         u32 prev = 4;
-        bool multiline = false;
-        for (u64 q = 0; q < L; q++) {
-            const u32 raw = tx.at(sb + q);
-            if (raw == '\n') multiline = true;
+        /* FASTA: the newlines inside [sb, se) are not part of the sequence (BG/Dataset.cpp:270-281). W = bases on the first line; the
+         * record is regular while every later line has W bases too, except that the lines may end with one shorter one */
+        u64 L = 0;
+        u32 W = 0, run = 0, n_nl = 0;
+        bool short_seen = false, irregular = false;
+        if (se - sb >= (1ull << 21)) { /* the 21-bit dimer counters; such a record is no read anyway: the host stage says so in its words */
+            atomicAdd(&a.ctr[FX_CTR_MULTILINE], 1ull);
+            a.glen[i] = 0;
+            a.wrap[i] = 0;
+            continue;
+        }
+        for (u64 q = sb; q < se; q++) {
+            const u32 raw = tx.at(q);
+            if (raw == '\n') { /* (FASTQ: se stops in front of the line's newline) */
+                if (n_nl == 0) W = run;
+                else {
+                    if (run > W) irregular = true;
+                    if (run < W) short_seen = true;
+                }
+                n_nl++;
+                run = 0;
+                continue;
+            }
+            if (short_seen) irregular = true; /* bases behind a line shorter than the first */
+            run++;
             const u32 c = fx_code(fx_upper(raw));
             if (c < 2) acgt01 += 1ull << (32 * c);
             else if (c < 4) acgt23 += 1ull << (32 * (c - 2));
@@ -200,13 +238,19 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
                 else dimB += 1ull << (21 * (prev + c - 3));
             }
             tail = ((tail << 2) | (c & 3u)) & ((1ull << 58) - 1ull);
-            if (q == 28) head = tail;
+            if (L == 28) head = tail;
             prev = c;
+            L++;
         }
+        if (n_nl == 0) W = (u32)L;           /* one line without a newline behind it (the end of the file) */
+        else if (run > W) irregular = true;  /* ... a last line without a newline, longer than the first */
+        if (W == 0 && L != 0) irregular = true; /* an empty first line */
+        const u32 wrap = irregular ? FX_WRAP_IRREGULAR : W;
+        a.wrap[i] = wrap;
         const u32 cnt[5] = {(u32)acgt01, (u32)(acgt01 >> 32), (u32)acgt23, (u32)(acgt23 >> 32), (u32)other};
         const u32 dim[6] = {(u32)(dimA & 0x1FFFFFu), (u32)((dimA >> 21) & 0x1FFFFFu), (u32)((dimA >> 42) & 0x1FFFFFu),
                             (u32)(dimB & 0x1FFFFFu), (u32)((dimB >> 21) & 0x1FFFFFu), (u32)((dimB >> 42) & 0x1FFFFFu)};
-        if (multiline) { /* not the accepted form: the whole file goes to the host stage */
+        if (irregular && L > FX_WALK_MAX) { /* not a form this stage addresses: the whole file goes to the host stage */
             atomicAdd(&a.ctr[FX_CTR_MULTILINE], 1ull);
             a.glen[i] = 0;
             continue;
@@ -238,7 +282,7 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
                     u64 hits = 0;
                     for (u64 q = 0; q + ml <= L;) {
                         bool eq = true;
-                        for (u32 t = 0; t < ml && eq; t++) eq = fx_upper(tx.at(sb + q + t)) == tb.motif[mi][t];
+                        for (u32 t = 0; t < ml && eq; t++) eq = fx_upper(tx.at(fx_raw_of(tx, sb, wrap, (u32)(q + t)))) == tb.motif[mi][t];
                         if (eq) {
                             hits++;
                             q += ml;
@@ -292,8 +336,9 @@ __global__ void fx_ids_kernel(const u16 *__restrict__ glen, const u64 *__restric
 
 /* word w of the row of read id: bases [32 w, 32 w + 32) of its sequence line, 2 bits per base, MSB first (BG/HashTable.cpp:456-477);
  * words behind the read are zero. One thread per word of the table rows [id_base, id_base + n_good). */
-__global__ void __launch_bounds__(256) fx_pack_kernel(const u8 *__restrict__ text, const u64 *__restrict__ seq_begin, const u32 *__restrict__ rec_of_read,
-                                                      const u16 *__restrict__ len, u64 id_base, u64 n_good, int S, u64 *__restrict__ reads)
+__global__ void __launch_bounds__(256) fx_pack_kernel(const u8 *__restrict__ text, const u64 *__restrict__ seq_begin, const u32 *__restrict__ wrap,
+                                                      const u32 *__restrict__ rec_of_read, const u16 *__restrict__ len, u64 id_base, u64 n_good, int S,
+                                                      u64 *__restrict__ reads)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 total = n_good * (u64)S;
@@ -303,10 +348,15 @@ __global__ void __launch_bounds__(256) fx_pack_kernel(const u8 *__restrict__ tex
         const u32 L = len[id];
         u64 acc = 0;
         if (32u * w < L) {
-            const u64 sb = seq_begin[rec_of_read[id]] + 32u * w;
+            const u32 rec = rec_of_read[id];
             const u32 nb = min(32u, L - 32u * w);
             FxBytes tx(text);
-            for (u32 x = 0; x < nb; x++) acc = (acc << 2) | (fx_code(fx_upper(tx.at(sb + x))) & 3u);
+            u64 p = fx_raw_of(tx, seq_begin[rec], wrap[rec], 32u * w); /* (the bytes from there on: newlines skipped as they come) */
+            for (u32 x = 0; x < nb; x++, p++) {
+                u32 ch = tx.at(p);
+                while (ch == '\n') ch = tx.at(++p);
+                acc = (acc << 2) | (fx_code(fx_upper(ch)) & 3u);
+            }
             acc <<= 2 * (32 - nb);
         }
         reads[id * (u64)S + w] = acc;

@@ -244,7 +244,7 @@ int main(int argc, char **argv)
     }
     /* The input stage on the GPU (disco_ingest_fasta: the files travel to HBM as text; records, read filter, ids and the 2-bit rows are
      * kernels) for one GPU and plain FASTA / FASTQ files of the common form; DISCO_E_UNSUPPORTED (.gz, a '>' inside a line of a FASTA
-     * file, sequences over several lines, unreadable or empty files) leaves everything to the host stage below, which follows the reference's getline calls
+     * file, irregularly wrapped long records, unreadable or empty files) leaves everything to the host stage below, which follows the reference's getline calls
      * literally and prints its messages. DISCO_HOST_INPUT=1: the host stage always. */
     disco_ctx *ctx1 = nullptr; /* the single-GPU context, created here when the device stage is tried */
     bool ingested = false;

@@ -257,8 +257,9 @@ int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
  * device: replaces parse + filter + pack on the host cores AND the upload. Read ids = rank among the good reads in file order over the
  * files in the order given (pass the -pe files, then the -se files). The graph results of a previous pass on the context are discarded
  * by the call, whatever it returns. Returns DISCO_E_UNSUPPORTED — the context's reads are unchanged — when a file is not
- * of a form the device stage accepts (FASTA: it must start with '>', every '>' must begin a line, every record's sequence must be one
- * line; FASTQ: it starts with '@', records of four lines; not accepted: .gz, empty or unreadable files): the caller then runs its host stage (disco_amd/host/fastx.cpp follows the reference's
+ * of a form the device stage accepts (FASTA: it must start with '>' and every '>' must begin a line; sequences may be wrapped — at one
+ * width per record, or irregularly up to 4096 bases; FASTQ: it starts with '@', records of four lines; not accepted: .gz, empty or
+ * unreadable files): the caller then runs its host stage (disco_amd/host/fastx.cpp follows the reference's
  * getline calls literally and produces its error messages) and disco_upload_reads. */
 typedef struct disco_ingest_file {
     uint64_t first_index, last_index; /* 1-based file indices of the file's first / last record (every record counts, BG/Dataset.cpp:294) */

@@ -158,12 +158,68 @@ def test_ingest_reads_fastq_by_counting_lines(tmp_path, tail):
     assert got2 == want2 and np.array_equal(fidx2.astype(np.int64), np.asarray(wfidx2, dtype=np.int64)) and info2["total_records"] == wtotal2
 
 
+def _wrapped(rng, s, how):
+    """the sequence s over several lines: 'w60' = wrapped at 60 (the last line shorter or full), 'irregular' = lines of random widths,
+    'blank' = a blank line inside, 'trail' = blank lines behind the last one"""
+    if how.startswith("w"):
+        w = int(how[1:])
+        return "\n".join(s[i:i + w] for i in range(0, len(s), w)) if s else ""
+    if how == "irregular":
+        out, i = [], 0
+        while i < len(s):
+            w = int(rng.integers(1, 90))
+            out.append(s[i:i + w])
+            i += w
+        return "\n".join(out)
+    if how == "blank":
+        h = len(s) // 2
+        return s[:h] + "\n\n" + s[h:]
+    if how == "trail":
+        return s + "\n\n"
+    return s
+
+
+@pytest.mark.parametrize("final_newline", [True, False])
+def test_ingest_reads_wrapped_fasta(tmp_path, final_newline):
+    """round 4: FASTA records over several lines — a record is its header line and everything up to the next '>' with the newlines
+    taken out (BG/Dataset.cpp:270-281): fixed widths (arithmetic addressing), irregular widths, blank lines inside and behind (walking),
+    next to one-line records, against the CPU restatement of the reference's parser"""
+    rng = np.random.default_rng(23)
+    reads = [r for r in _adversarial(rng, 4000) if len(r) <= 32767]
+    hows = ["w60", "w70", "w7", "w1", "irregular", "blank", "trail", "one", "w150", "w29"]
+    text = "".join(f">r{i} d\n{_wrapped(rng, s, hows[i % len(hows)])}\n" for i, s in enumerate(reads))
+    if not final_newline:
+        text = text.rstrip("\n")
+    fa = tmp_path / "wrapped.fasta"
+    fa.write_text(text)
+    want, wfidx, wtotal = pyoracle.load_good_reads([str(fa)], 33)
+    info, files, got, fidx = _ingest([str(fa)], 33)
+    assert info["total_records"] == wtotal == len(reads)
+    assert got == want and np.array_equal(fidx.astype(np.int64), np.asarray(wfidx, dtype=np.int64)) and len(got) > 600
+    # a long record wrapped at one width is addressed by arithmetic (kept, or dropped for its length like a one-line one); an irregular
+    # one beyond the walking limit sends the file to the host stage
+    long_seq = "".join(rng.choice(list("ACGT"), 20000))
+    ok = tmp_path / "long_regular.fasta"
+    ok.write_text(text + "\n>long\n" + _wrapped(rng, long_seq, "w80") + "\n")
+    want2, wfidx2, wtotal2 = pyoracle.load_good_reads([str(ok)], 33)
+    info2, files2, got2, fidx2 = _ingest([str(ok)], 33)
+    assert got2 == want2 and got2[-1] == long_seq and info2["total_records"] == wtotal2
+    bad = tmp_path / "long_irregular.fasta"
+    bad.write_text(text + "\n>long\n" + _wrapped(rng, long_seq, "irregular") + "\n")
+    assert _ingest([str(bad)], 33) is None
+
+
 def test_ingest_declines_what_only_the_literal_parser_handles(tmp_path):
     good = ">a\nACGTTGCAAGCTAGCTAGGATCGATCGTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n"
+    # (round 4: sequences over several lines and blank lines between records are read on the device: test_ingest_reads_wrapped_fasta)
+    for name, text in {"multiline.fa": ">a\nACGTTGCAAGCTAGCTAGGATCGATCG\nTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n", "blank_line.fa": good + "\n" + good}.items():
+        p = tmp_path / name
+        p.write_text(text)
+        want, wfidx, wtotal = pyoracle.load_good_reads([str(p)], 30)
+        info, files, got, fidx = _ingest([str(p)], 30)
+        assert got == want and len(got) == wtotal and list(fidx) == list(wfidx), name
     cases = {
-        "multiline.fa": ">a\nACGTTGCAAGCTAGCTAGGATCGATCG\nTAGCTAGCTAGCATCGATGCTAGCTAGTCGATCGAT\n",
         "gt_inside.fa": ">a>b\nACGT\n" + good.replace(">a", ">c d>e"),
-        "blank_line.fa": good + "\n" + good,
         "empty.fa": "",
         "no_header.fa": "ACGT\n",
     }
@@ -185,7 +241,7 @@ def test_ingest_declines_what_only_the_literal_parser_handles(tmp_path):
 @pytest.mark.parametrize("threads", [1, 5])
 def test_buildg_with_the_device_input_stage_writes_the_host_stages_files(tmp_path, threads):
     """the whole drop-in on a FASTA the device stage accepts, against DISCO_HOST_INPUT=1: every output file line for line; and on the
-    `multifile` fixture (FASTQ, multi-line FASTA: declined) the run still equals the reference's files"""
+    `multifile` fixture (FASTQ, multi-line FASTA, a .gz among the files: declined) the run still equals the reference's files"""
     from disco_amd import readgen
 
     build.build_host()
@@ -210,14 +266,21 @@ def test_buildg_with_the_device_input_stage_writes_the_host_stages_files(tmp_pat
     for k in out["device"]:  # (the order of the edge lines inside a file follows the emission's atomics: compared as sets of lines)
         assert out["device"][k] == out["host"][k], k
     assert out["device_log"] == out["host_log"] and len(out["device"]["_ReadIDMap.txt"]) > 0
-    # declined files: the host stage takes over inside the same run
-    c = gu.CASES["multifile"]
-    prefix = str(tmp_path / "m")
-    cmd = [os.path.join(BIN, "buildG"), "-pe", ",".join(os.path.join(gu.GOLD, f) for f in c["pe"]), "-se", ",".join(os.path.join(gu.GOLD, f) for f in c["se"]), "-f", prefix,
-           "-p", str(cfg), "-t", "2"]
-    cfg.write_text(f"MinOverlap4BuildGraph = {c['min_overlap']}\n")
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"))
-    assert p.returncode == 0 and "the host input stage takes this job" in p.stdout, p.stdout[-1500:]
+    # the `multifile` fixture — wrapped FASTA with filter cases, FASTQ, plain FASTA — through the device stage (round 4), and with one
+    # of its files gzipped: declined, the host stage takes over inside the same run; the reference's files either way
+    import shutil
+
     from oracle import refrun
 
-    gu.check_against_golden("multifile", refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt"))), refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt"))))
+    c = gu.CASES["multifile"]
+    cfg.write_text(f"MinOverlap4BuildGraph = {c['min_overlap']}\n")
+    gz = tmp_path / "plain.fasta.gz"
+    with open(os.path.join(gu.GOLD, c["se"][0]), "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    for how, se in (("dev", ",".join(os.path.join(gu.GOLD, f) for f in c["se"])), ("declined", str(gz))):
+        prefix = str(tmp_path / ("m_" + how))
+        cmd = [os.path.join(BIN, "buildG"), "-pe", ",".join(os.path.join(gu.GOLD, f) for f in c["pe"]), "-se", se, "-f", prefix, "-p", str(cfg), "-t", "2"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"))
+        assert p.returncode == 0, p.stdout[-1500:]
+        assert ("the host input stage takes this job" in p.stdout) == (how == "declined") and ("input stage on the GPU" in p.stdout) == (how == "dev"), p.stdout[-1500:]
+        gu.check_against_golden("multifile", refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt"))), refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt"))))
