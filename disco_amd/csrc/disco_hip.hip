@@ -263,6 +263,7 @@ struct disco_ctx {
     int order_counted_bits = 0;
     u32 *d_cls_cnt = nullptr; /* multi-GPU flow, own nodes: entries on either side of the node (tr_request_first_kernel) */
     u64 cls_cnt_cap = 0;
+    u64 order_q_lo = 0, order_q_hi = 0;
     ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
     u64 meta_cap = 0;
     u64 *d_nref = nullptr; /* multi-GPU flow: reference words nref[2u + cls] of the neighbour-row store */
@@ -1912,6 +1913,8 @@ int disco_probe(disco_ctx *c)
         } else
             c->d_order_used = nullptr;
         a.order = c->d_order_used;
+        c->order_q_lo = c->q_lo; /* (the range the order in d_order_used belongs to: later phases of the pass walk it too) */
+        c->order_q_hi = c->q_hi;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         const bool partitioned = c->dist_active && c->part_index; /* the lookups travel to the buckets' owners (collective) */
@@ -2530,6 +2533,7 @@ int disco_transitive_mark(disco_ctx *c)
     a.wide_cap = c->wide_cap;
     a.nref = nullptr;
     a.nadj32 = nullptr;
+    a.order = (c->d_order_used && c->order_q_lo == c->q_lo && c->order_q_hi == c->q_hi && !c->adj_imported && !getenv("DISCO_TR_NO_ORDER")) ? c->d_order_used : nullptr;
     /* every row needs its flags when the emission cannot rely on the survivor lists alone */
     a.all_flags = (c->adj_imported || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
@@ -3995,6 +3999,7 @@ static int dist_transitive_mark(disco_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     TrArgs a;
     a.v = view(c);
+    a.order = nullptr;
     a.ref = c->d_adj_ref;
     a.adj = c->d_adj;
     a.big_list = c->d_big_list;

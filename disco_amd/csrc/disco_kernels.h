@@ -3081,6 +3081,9 @@ struct TrArgs {
      * IS its survivor list, and rewriting 34 of 36 entries per node was a quarter of this kernel's memory requests (single GPU
      * with survivor lists); 1: every row gets its flags (sharded flows: the flag exchange may need all of them) */
     u32 all_flags;
+    /* the nodes are taken in the processing order of probe / verify / edge selection (reads that share their read-level minimizer back
+     * to back) where the caller has one for the query range, or in id order (null): nodes of one locus sweep the same few rows */
+    const u64 *order;
 };
 
 #define TR_UNAVAIL 0xFFFFFFFFFFFFFFFFull   /* nref word: row not fetched (degree field 0xFFFFFF, never a real degree) */
@@ -3224,10 +3227,12 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     u32 hc = 64;
     while (hc < TR_HASH_LOAD * d) hc <<= 1; /* d <= 64: at most 4 * 64 of the 2 * TR_CAP slots */
     const u32 hmask = hc - 1;
-    for (u32 i = lane; i <= hmask; i += 64) {
-        hkey[i] = TR_EMPTY;
-        hstate[i] = 0;
-    }
+    /* round 4: a slot is ONE 32-bit word — the node id (below 2^31) with the ELIMINATED state in bit 31, 0xFFFFFFFF = free — in the
+     * space of hkey: the table is cleared by one 16-byte store per lane (8-byte keys and a byte array of states took eight stores), a
+     * probe reads and a mark writes one word */
+    u32 *ht = (u32 *)hkey;
+    (void)hstate;
+    for (u32 i = lane; i < hc / 4; i += 64) ((uint4 *)ht)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     /* speculative rows (fetched by the pipeline of the kernel): slot 0 and the first slot on the other side of v */
     const u32 s2 = nd.s2;
     const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
@@ -3238,11 +3243,11 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     __syncthreads();
     u32 sent = 0;
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
-        const u64 id = ADJ_DST(e);
+        const u32 id = (u32)ADJ_DST(e);
         u32 idx = tr_hash(id, hmask);
         for (;;) {
-            u64 old = atomicCAS(&hkey[idx], TR_EMPTY, id);
-            if (old == TR_EMPTY || old == id) break;
+            const u32 old = atomicCAS(&ht[idx], 0xFFFFFFFFu, id);
+            if (old == 0xFFFFFFFFu || old == id) break;
             idx = (idx + 1) & hmask;
         }
         sent = idx;
@@ -3253,7 +3258,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
      * states as they are now" is exactly the sequential loop — found with one ballot instead of one LDS read per slot. */
     int cur = -1;
     for (;;) {
-        const bool inplay = (lane < d) && !hstate[sent];
+        const bool inplay = (lane < d) && !(ht[sent] >> 31);
         u64 mk = __ballot(inplay);
         if (cur >= 0) mk &= ~((2ull << cur) - 1ull); /* slots after cur */
         if (!mk) break;
@@ -3271,9 +3276,9 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
             const u32 w = (u32)ADJ_DST(e2); /* ids are below 2^31: the low word of a slot identifies the node, 0xFFFFFFFF = empty */
             u32 idx = tr_hash(w, hmask);
             do {
-                const u32 kk = ((const u32 *)hkey)[2 * idx];
-                const bool hit = pend && kk == w;
-                hstate[hit ? idx : (2u * TR_CAP - 1u)] = 1; /* ELIMINATED; the last slot is never a table slot (hc <= 256) */
+                const u32 kk = ht[idx];
+                const bool hit = pend && (kk & 0x7FFFFFFFu) == w; /* (a free slot's low bits are no id) */
+                ht[hit ? idx : hc] = kk | 0x80000000u; /* ELIMINATED; slot hc is never a table slot: it takes the stores of the lanes without a hit */
                 pend = pend && !hit && kk != 0xFFFFFFFFu;
                 idx = (idx + 1) & hmask;
             } while (__any(pend));
@@ -3321,7 +3326,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         __syncthreads();
         return;
     }
-    const bool fl = lane < d && hstate[sent];
+    const bool fl = lane < d && (ht[sent] >> 31);
     const bool fr = lane < d && !fl;
     const u64 mk = __ballot(fr);
     if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
@@ -3368,13 +3373,13 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
      * flight unknown to the compiler, which then drains the pipeline at the next use. */
     const u64 n_nodes = a.v.n;
     u64 cbeg = 0, cend = 0;
-    u64 rv_chunk = 0;
+    u64 rv_chunk = 0, v_chunk = 0;
     auto stage_row = [&](u64 it) { /* needs rv_chunk */
         TrNodeRegs r;
         const bool ok = it < cend;
         const u64 itc = ok ? it : cend - 1;
         const u64 rv = readlane_u64(rv_chunk, (u32)(itc - cbeg));
-        r.v = a.v.q_lo + itc;
+        r.v = readlane_u64(v_chunk, (u32)(itc - cbeg));
         r.vs = REF_POS(rv);
         r.dfull = ok ? REF_DEG(rv) : 0u;
         r.d = (r.dfull <= 64) ? r.dfull : 0u;
@@ -3423,8 +3428,9 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         continue;
     }
     {
-        const u64 idx = cbeg + lane;
-        rv_chunk = a.ref[a.v.q_lo + (idx < cend ? idx : cend - 1)];
+        const u64 idx = cbeg + lane, ic = idx < cend ? idx : cend - 1;
+        v_chunk = a.order ? ORDER_ID(a.order[ic]) : a.v.q_lo + ic;
+        rv_chunk = a.ref[v_chunk];
     }
     TrNodeRegs n0 = stage_row(cbeg), n1 = stage_row(cbeg + 1), n2 = stage_row(cbeg + 2);
     stage_refs(n0);
@@ -3434,7 +3440,7 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         stage_rows(n1);
         stage_refs(n2);
         TrNodeRegs n3 = stage_row(it + 3);
-        const u64 v = a.v.q_lo + it;
+        const u64 v = n0.v;
         if (n0.d != 0)
             tr_node_small<N32>(a, n0, s_hkey, s_state, lane);
         else if (n0.dfull != 0) {
