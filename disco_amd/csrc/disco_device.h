@@ -254,13 +254,30 @@ __device__ __forceinline__ void kmer_revcomp(u64 hi, u64 lo, int k, u64 &rhi, u6
 /* canonical orientation of the k-mer at j (the reference canonicalises through min(hash(fwd), hash(rc)),
  * BG/HashTable.cpp:383-391; any strand-symmetric choice gives the same buckets' contents up to order):
  * 1 when the reverse complement is the smaller 2k-bit integer. A palindrome (k even) has 0. */
-template <bool NB = false>
+/* LONGK (round 4: k up to 94; the kernels are instantiated for it separately — inside probe_kernel the registers of the loop are the
+ * ones that spill, so the variants for k <= 64 do not carry it): 32 bases at a time from the left — word i of the reverse complement
+ * is the reverse complement of the k-mer's bases [k - 32 i - n, k - 32 i), n = the bases of that word; the first differing word decides
+ * (= the comparison of the two 2k-bit integers) */
+template <bool NB = false, bool LONGK = false>
 __device__ __forceinline__ u32 kmer_is_rev(const u64 *p, int S, int j, int k)
 {
-    u64 hi, lo, rhi, rlo;
-    kmer_at<NB>(p, S, j, k, hi, lo);
-    kmer_revcomp(hi, lo, k, rhi, rlo);
-    return ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
+    if (!LONGK) {
+        u64 hi, lo, rhi, rlo;
+        kmer_at<NB>(p, S, j, k, hi, lo);
+        kmer_revcomp(hi, lo, k, rhi, rlo);
+        return ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
+    }
+#pragma clang loop unroll(disable)
+    for (int i = 0; 32 * i < k; i++) {
+        const int n = k - 32 * i < 32 ? k - 32 * i : 32;
+        const u64 mask = n == 32 ? ~0ull : (~0ull << (64 - 2 * n));
+        const u64 fw = extract32<NB>(p, S, j + 32 * i) & mask;
+        u64 rc = rev2_64(~extract32<NB>(p, S, j + k - 32 * i - n));
+        if (n < 32) rc <<= 2 * (32 - n);
+        rc &= mask;
+        if (rc != fw) return rc < fw ? 1u : 0u;
+    }
+    return 0u; /* its own reverse complement */
 }
 
 /* canonical m-mer (m <= 32) at base pos: value of min(m-mer, reverse complement); strand = 1 when the reverse complement
@@ -288,7 +305,9 @@ __device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
 
 __device__ __forceinline__ u32 order_hash32(u64 c)
 {
-    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24), 0x85EBCBu) + 0x7F4A7C15u;
+    /* (canonical m-mers of up to 23 bases have 46 bits: the third product is zero for them — the order of rounds 1-3; m up to 31,
+     * which k above 86 needs, brings 62) */
+    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24) & 0xFFFFFFu, 0x85EBCBu) + __umul24((u32)(c >> 48), 0xC2B2AEu) + 0x7F4A7C15u;
     h ^= h >> 15;
     return h * 0x2C1B3C6Du;
 }
@@ -314,8 +333,12 @@ __host__ __device__ __forceinline__ int disco_minimizer_len(int k)
 {
     int m = k < 23 ? k : 23;
     if ((m & 1) == 0) m -= 1;
+    /* a record stores the minimizer's offset inside its k-mer in six bits (PAY_T) and a window's m-mers are one 64-lane pass: k - m <= 63.
+     * k above 86 takes longer minimizers for that: m = k - 63, odd, at most 31 (an m-mer is extracted as one 64-bit word): k <= 94 */
+    if (k - m > 63) m = (k - 63) | 1;
     return m < 1 ? 1 : m;
 }
+#define DISCO_MAX_K 94
 
 /* THE WINDOW-MINIMIZER RULE ("window_minimizer's rule" elsewhere). For the k-mer window at base j with the order words
  * h(0..nf-1) of its m-mers (forward offsets), the window's CANONICAL ORIENTATION and the chosen occurrence are defined

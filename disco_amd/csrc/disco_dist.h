@@ -644,6 +644,7 @@ __global__ void __launch_bounds__(256) pq_make_kernel(DiscoView v, const u32 *__
  * occurrence can own several such ranges; their windows are disjoint, so the owner's test still yields every (window, record) pair
  * once. One thread per read. out == nullptr: queries per read -> cnt; else the queries at out + start[i]. list == nullptr: read i of
  * the range itself. */
+template <bool LONGK>
 __global__ void pq_slow_kernel(DiscoView v, const u32 *__restrict__ list, u64 n_list, u64 lo, u32 my_rank, u32 *__restrict__ cnt, const u64 *__restrict__ start,
                                ulonglong2 *__restrict__ out)
 {
@@ -682,7 +683,7 @@ __global__ void pq_slow_kernel(DiscoView v, const u32 *__restrict__ list, u64 n_
                 rev = st1;
                 p = w + f1;
             } else {
-                rev = kmer_is_rev(row, v.S, w, k);
+                rev = kmer_is_rev<false, LONGK>(row, v.S, w, k);
                 p = w + (rev ? f2 : f1);
             }
             if (p != run_p || rev != run_rev) {

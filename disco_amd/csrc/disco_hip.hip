@@ -762,7 +762,8 @@ static int index_count_chunk(disco_ctx *c, const DiscoView &v, const IndexCountP
         }
 #undef DISCO_RUNS_LAUNCH
     } else
-        hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
+        if (c->k > 64) hipLaunchKernelGGL((index_count_kernel<COUNT, true>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
+        else hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
     HIPCHK(c, hipGetLastError());
     return DISCO_OK;
 }
@@ -948,8 +949,8 @@ int disco_abi_version(void) { return DISCO_ABI_VERSION; }
 int disco_create(int device, const disco_params *p, disco_ctx **out)
 {
     if (!p || !out) return fail(nullptr, DISCO_E_ARG, "disco_create: null argument");
-    if (p->min_overlap < 2 || p->min_overlap - 1 > 64)
-        return fail(nullptr, DISCO_E_UNSUPPORTED, "disco_create: min_overlap %u unsupported (k = min_overlap-1 must be in [1,64])", p->min_overlap);
+    if (p->min_overlap < 2 || p->min_overlap - 1 > DISCO_MAX_K)
+        return fail(nullptr, DISCO_E_UNSUPPORTED, "disco_create: min_overlap %u unsupported (k = min_overlap-1 must be in [1,%d])", p->min_overlap, DISCO_MAX_K);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, DISCO_E_HIP, "disco_create: no HIP device (%s)", hipGetErrorString(e));
@@ -1798,18 +1799,22 @@ int disco_probe(disco_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
     const bool ldsrow = c->S <= PROBE_ACAP;
     const bool row17 = c->k - view(c).m == 16 && !getenv("DISCO_NO_ROW17"); /* window = 17 m-mers: DPP row-scan variant */
+    const bool longk = c->k > 64;                                            /* three-word k-mers: variants of their own (kmer_is_rev) */
     /* the index pass left the minimizer runs of the whole query range: probe_runs_kernel (several reads per wavefront, starts at the
      * bucket lookups); probe_kernel then only does the reads it is handed (unusable run lists, rows that outgrew their chunk) */
     const bool use_runs = c->runs_lpr != 0 && c->d_runs && c->q_lo >= c->runs_lo && c->q_hi <= c->runs_lo + c->runs_n;
     const int grid = use_runs ? (c->runs_lpr == 16 ? wq_grid(c, probe_runs_kernel<16>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_runs_kernel<32>, nq, "DISCO_PROBE_WAVES"))
+                     : longk  ? (ldsrow ? wq_grid(c, probe_kernel<0, true, false, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<0, false, false, true>, nq, "DISCO_PROBE_WAVES"))
                      : row17  ? (ldsrow ? wq_grid(c, probe_kernel<0, true, true>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<0, false, true>, nq, "DISCO_PROBE_WAVES"))
                               : (ldsrow ? wq_grid(c, probe_kernel<0, true, false>, nq, "DISCO_PROBE_WAVES") : wq_grid(c, probe_kernel<0, false, false>, nq, "DISCO_PROBE_WAVES"));
     /* mode 0: the query range, 1: big_list (rows of known size), 2: slow_list */
     auto launch_probe = [&](const ProbeArgs &a, int mode, int g) {
 #define DISCO_PROBE_LAUNCH(B, L, R) hipLaunchKernelGGL((probe_kernel<B, L, R>), dim3(g), dim3(64), 0, c->stream, a)
+#define DISCO_PROBE_LAUNCH_LONG(B, L) hipLaunchKernelGGL((probe_kernel<B, L, false, true>), dim3(g), dim3(64), 0, c->stream, a)
 #define DISCO_PROBE_MODE(B)                                                                      \
     do {                                                                                         \
-        if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(B, true, true); else DISCO_PROBE_LAUNCH(B, true, false); }   \
+        if (longk) { if (ldsrow) DISCO_PROBE_LAUNCH_LONG(B, true); else DISCO_PROBE_LAUNCH_LONG(B, false); }     \
+        else if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(B, true, true); else DISCO_PROBE_LAUNCH(B, true, false); }   \
         else { if (row17) DISCO_PROBE_LAUNCH(B, false, true); else DISCO_PROBE_LAUNCH(B, false, false); }        \
     } while (0)
         if (mode == 0 && use_runs) {
@@ -1818,9 +1823,11 @@ int disco_probe(disco_ctx *c)
         } else if (mode == 0) DISCO_PROBE_MODE(0);
         else if (mode == 1) DISCO_PROBE_MODE(1);
         else { /* slow_list only exists next to probe_runs_kernel: 64-byte rows */
-            if (row17) DISCO_PROBE_LAUNCH(2, true, true);
+            if (longk) DISCO_PROBE_LAUNCH_LONG(2, true);
+            else if (row17) DISCO_PROBE_LAUNCH(2, true, true);
             else DISCO_PROBE_LAUNCH(2, true, false);
         }
+#undef DISCO_PROBE_LAUNCH_LONG
 #undef DISCO_PROBE_MODE
 #undef DISCO_PROBE_LAUNCH
     };
@@ -3799,7 +3806,8 @@ static int dist_partitioned_probe(disco_ctx *c)
         if (!n_slow) return DISCO_OK;
         CHK(dev_alloc(c, &slow_cnt, n_slow));
         CHK(dev_alloc(c, &slow_start, n_slow + 1));
-        hipLaunchKernelGGL(pq_slow_kernel, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)nullptr, (ulonglong2 *)nullptr);
+        if (c->k > 64) hipLaunchKernelGGL(pq_slow_kernel<true>, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)nullptr, (ulonglong2 *)nullptr);
+        else hipLaunchKernelGGL(pq_slow_kernel<false>, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)nullptr, (ulonglong2 *)nullptr);
         CHK((scan_exclusive<u32, u64>(c, slow_cnt, n_slow, slow_start, false, &nq_slow)));
         return DISCO_OK;
     };
@@ -3810,7 +3818,8 @@ static int dist_partitioned_probe(disco_ctx *c)
         HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
         if (have_runs && nloc) make(c->d_x16a, false);
         if (n_slow)
-            hipLaunchKernelGGL(pq_slow_kernel, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)slow_start, c->d_x16a + nq_fast);
+            if (c->k > 64) hipLaunchKernelGGL(pq_slow_kernel<true>, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)slow_start, c->d_x16a + nq_fast);
+            else hipLaunchKernelGGL(pq_slow_kernel<false>, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)slow_start, c->d_x16a + nq_fast);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DISCO_E_HIP, "dist_partitioned_probe: query kernels failed");
     }
     dev_free(c, &slow_cnt, n_slow);

@@ -200,7 +200,7 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
 /* Reads [lo, hi) (the whole table on one GPU, the rank's own range in the multi-GPU flow); rec is indexed from lo. COUNT = false
  * (multi-GPU): no counting atomics — the records are routed to the rank that owns their bucket range first and counted there
  * (shard_count_kernel), which is what replaces the range-partitioned hashData of RMA/HashTable.cpp:95-116. */
-template <bool COUNT>
+template <bool COUNT, bool LONGK = false>
 __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
                                                           u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
 {
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
         if (ffirst == flast)
             rev = k1 & 1u;
         else {
-            rev = kmer_is_rev(p, v.S, j0, k);
+            rev = kmer_is_rev<false, LONGK>(p, v.S, j0, k);
             fsel = rev ? flast : ffirst;
         }
         t = rev ? (u32)(nf - 1 - fsel) : (u32)fsel;
@@ -570,8 +570,8 @@ struct ProbeArgs {
 /* PMODE 0: the query range in processing order; 1 (BIG): the reads of big_list, whose rows did not fit their chunk, with rows of
  * exactly the size the first pass counted; 2 (LIST): the reads of slow_list (probe_runs_kernel could not use their run lists), rows in
  * chunks as in mode 0 */
-template <int PMODE, bool LDSROW, bool ROW17>
-__global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD) probe_kernel(ProbeArgs a)
+template <int PMODE, bool LDSROW, bool ROW17, bool LONGK = false>
+__global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD)) probe_kernel(ProbeArgs a)
 {
     constexpr bool BIG = PMODE == 1, LISTED = PMODE != 0;
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(64, ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_W
                 if (p1 == p2)
                     rev_w = s_strand[p1];
                 else { /* the smallest hash occurs more than once in the window */
-                    rev_w = kmer_is_rev<LDSROW>(pa, S, w0 + w, k);
+                    rev_w = kmer_is_rev<LDSROW, LONGK>(pa, S, w0 + w, k);
                     prel = rev_w ? p2 : p1;
                 }
                 s_wp[w] = (u16)(prel | (rev_w << 15));

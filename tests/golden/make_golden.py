@@ -53,6 +53,9 @@ GEN_CASES = [
     ("long_2k", dict(seed=5, n_reads=2000, read_len=300, cov=20.0, len_max=600), 40, True),
     ("contigs_20k", dict(seed=9, n_reads=20000, read_len=150, cov=30.0, n_contigs=4), 40, False),
     ("u150_100k", dict(seed=43, n_reads=100000, read_len=150, cov=30.0), 40, False),
+    # round 4: k above 64 (the reference's k-mers are strings: no limit there, BG/HashTable.cpp:396-416)
+    ("k79_4k", dict(seed=21, n_reads=4000, read_len=250, cov=30.0, len_max=500), 80, True),
+    ("k94_4k", dict(seed=22, n_reads=4000, read_len=250, cov=30.0, len_max=500), 95, True),
 ]
 
 
@@ -105,7 +108,13 @@ def main():
     cases = {}
     import tempfile
 
+    only = None  # make_golden.py --only a,b : (re)generate these generated cases and merge them into cases.json
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        only = set(sys.argv[2].split(","))
+        cases = json.load(open(os.path.join(HERE, "cases.json")))
     for name, kw, minovl, full in GEN_CASES:
+        if only is not None and name not in only:
+            continue
         spec = readgen.GenSpec.coverage(**kw)
         reads = readgen.generate_reads(spec)
         d = tempfile.mkdtemp(prefix="golden_")
@@ -117,6 +126,9 @@ def main():
         cases[name] = info
         print(name, info["n_edges"], info["n_contained"], f"{r['wall']:.1f}s", flush=True)
 
+    if only is not None:
+        json.dump(cases, open(os.path.join(HERE, "cases.json"), "w"), indent=1, sort_keys=True)
+        return
     # order-dependent regime (cap of 4 edges per k-mer binds / asymmetric pairs): the reference differs from ITSELF between
     # thread counts here (SURVEY.md preamble item 6); recorded to document the parity domain, not asserted bit-exact
     reads = repeat_reads(99, 8000, 30, 500, 300, 100, 200)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name,G", [(n, g) for n in ("u150_5k", "mixed_4k", "k30_6k", "long_2k") for g in (1, 2, 3, 4)] +
-                         [("u150_5k", 8), ("mixed_4k", 8), ("contigs_20k", 8), ("k64_3k", 5)])
+                         [("u150_5k", 8), ("mixed_4k", 8), ("contigs_20k", 8), ("k64_3k", 5), ("k79_4k", 3), ("k94_4k", 4)])
 def test_ranks_equal_reference(name, G):
     """regular regime: neighbour rows fetched on request"""
     reads, fidx, mo = gu.case_inputs(name)
@@ -279,7 +279,7 @@ def test_config2_reads_through_4_ranks_with_partitioned_index_hash_like_the_refe
     assert sent["queries"] > 0 and sent["hits"] > 0 and sent["index_shards"] == 0
 
 
-@pytest.mark.parametrize("name,G", [("k30_6k", 3), ("long_2k", 2), ("k64_3k", 4)])
+@pytest.mark.parametrize("name,G", [("k30_6k", 3), ("long_2k", 2), ("k64_3k", 4), ("k94_4k", 3)])
 def test_ranks_partitioned_index_on_shapes_without_runs(name, G):
     """windows other than 17 m-mers / reads beyond 256 bases: the index pass leaves no minimizer runs, every read's lookups are made
     the long way (pq_slow_kernel) — same result"""

@@ -15,13 +15,14 @@ def _reads(n=300, L=150):
 
 def test_k_limits():
     with pytest.raises(DiscoError, match="unsupported"):
-        BuildGraph(min_overlap=66)  # k = 65 > 64
+        BuildGraph(min_overlap=96)  # k = 95 > 94 (round 4: k up to 94; rounds 1-3: 64)
     with pytest.raises(DiscoError, match="unsupported"):
         BuildGraph(min_overlap=1)
-    with BuildGraph(min_overlap=65) as g:  # k = 64: the widest supported
-        g.upload_ascii(_reads(200, 150))
-        g.run_graph()
-        assert g.counters()["e_pre"] > 0
+    for mo in (65, 95):  # k = 64 (two-word k-mers), k = 94: the widest supported
+        with BuildGraph(min_overlap=mo) as g:
+            g.upload_ascii(_reads(300, 150))
+            g.run_graph()
+            assert g.counters()["e_pre"] > 0
 
 
 def test_calls_out_of_order_are_state_errors():

@@ -24,6 +24,11 @@ def _gen(seed, n, lmin, cov, lmax=None, contigs=1):
     (5, 2000, 300, 600, 20.0, 40),      # long reads, many words per row
     (43, 3000, 257, 512, 25.0, 40),     # 16-word rows: the staged verify variant for reads of 257..512 bases
     (47, 3000, 260, 500, 40.0, 65),     # the same at k = 64
+    (71, 3000, 250, 500, 30.0, 80),     # round 4: k = 79 (three-word k-mers; windows of 57 m-mers of 23)
+    (73, 3000, 150, 150, 60.0, 80),     # ... on 64-byte rows (the flat verify / selection kernels)
+    (79, 3000, 250, 500, 30.0, 88),     # k = 87: minimizers of 25 bases (k - m <= 63)
+    (83, 2500, 250, 500, 30.0, 95),     # k = 94, the widest supported: minimizers of 31
+    (89, 3000, 130, 250, 40.0, 95),     # ... on 64-byte rows
     (53, 1500, 520, 760, 25.0, 40),     # 24-word rows
     (59, 1500, 800, 1024, 25.0, 50),    # 32-word rows (the widest staged variant; longer reads: generic variant)
     (17, 6000, 150, 150, 100.0, 40),    # 100x coverage: rows of 65..256 hits (wide-row paths of edge selection / marking)
