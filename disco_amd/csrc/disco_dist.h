@@ -183,7 +183,28 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
     const u64 nloc = hi - lo;
     const u32 lane = threadIdx.x & 63u, sub = lane & 7u, g0 = lane & ~7u;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    __shared__ u32 s_rq[1][128]; /* (one wavefront per workgroup) the requests of a block of 64 nodes (appended with two atomics: the list's counter is ONE address) */
+    __shared__ u32 s_rq[1][128]; /* (one wavefront per workgroup) the requests of a block of 64 nodes */
+    /* ... collected over many blocks and appended 2048 at a time: the list's counter is ONE address, and an atomic per block of 64 nodes
+     * (195 000 per rank) was 2.3 of this kernel's 2.6 ms */
+    __shared__ u32 s_out[2048 + 128];
+    u32 n_out = 0; /* wave uniform */
+    auto flush = [&]() {
+        if (n_out == 0) return;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(n_list, (u64)n_out);
+        base = readlane_u64(base, 0);
+        for (u32 x = lane; x < n_out; x += 64) {
+            if (base + x < cap) list[base + x] = s_out[x];
+            else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+        }
+        n_out = 0;
+    };
+    auto stash = [&](u32 rq) {
+        const bool has = rq != 0xFFFFFFFFu;
+        const u64 mk = __ballot(has);
+        if (has) s_out[n_out + __popcll(mk & lane_mask_lt())] = rq;
+        n_out += (u32)__popcll(mk);
+    };
     u32 *rqs = s_rq[0];
     for (u64 blk = wave * 64; blk < nloc; blk += nwaves * 64) { /* (wave uniform: 64 nodes per wavefront and trip, eight at a time) */
         rqs[lane] = 0xFFFFFFFFu;
@@ -224,16 +245,26 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
             if (live && sub == 0) {
                 cls_cnt[i] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
                 if (d != 0 && d <= 64) {
-                    rqs[2 * (8 * t + (lane >> 3))] = request_for(e0, lo, hi, nref);
-                    if (has2) rqs[2 * (8 * t + (lane >> 3)) + 1] = request_for(e2, lo, hi, nref);
+                    /* round 1 asks without looking who else did: marking the word (a random 8-byte compare-and-swap per request,
+                     * 12.5 M per rank: 2 of this kernel's 2.6 ms) saved one request in ten — two nodes of a rank that sweep the same row
+                     * of another rank; now that row travels twice (nref_remote_kernel keeps either copy) */
+                    const u64 u0 = ADJ_DST(e0), u2 = ADJ_DST(e2);
+                    if (u0 < lo || u0 >= hi) rqs[2 * (8 * t + (lane >> 3))] = ((u32)u0 << 1) | ((~ADJ_ORI(e0)) & 1u);
+                    if (has2 && (u2 < lo || u2 >= hi)) rqs[2 * (8 * t + (lane >> 3)) + 1] = ((u32)u2 << 1) | ((~ADJ_ORI(e2)) & 1u);
                 }
             }
         }
         __syncthreads();
-        request_append(rqs[lane], list, n_list, cap, ctr);
-        request_append(rqs[lane + 64], list, n_list, cap, ctr);
+        stash(rqs[lane]);
+        stash(rqs[lane + 64]);
         __syncthreads();
+        if (n_out > 2048) {
+            flush();
+            __syncthreads();
+        }
     }
+    __syncthreads();
+    flush();
 }
 
 /* the owner's side: how many entries the answer to request i has — from the counts tr_request_first_kernel left for every own
@@ -406,7 +437,7 @@ __global__ void twin_recv_kernel(const ulonglong2 *__restrict__ items, u64 n_ite
  * (a -> b) as it stands in a's own list, so the receiver only has to look it up among a's survivors. Lane = own node b.
  * FILL = false counts the items. */
 template <bool FILL>
-__global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u64 *__restrict__ half,
+__global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u64 *__restrict__ half,
                                                         const u32 *__restrict__ hcnt, const u16 *__restrict__ len, u64 lo, u64 hi,
                                                         ulonglong2 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
 {
@@ -415,8 +446,21 @@ __global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ 
     const u32 lane = threadIdx.x & 63u;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 mine = 0;
-    /* the items of a wavefront's trip (up to HALF_CAP per node) are appended with ONE atomic (round 4: one per call was 390 000
-     * atomics on one address per rank — 2.1 of this kernel's 2.3 ms) */
+    /* the items of a wavefront's trips (up to HALF_CAP per node) are collected in LDS and appended 512 at a time (round 4: one atomic
+     * per call was 390 000 atomics on ONE address per rank — 2.1 of this kernel's 2.3 ms). One wavefront per workgroup. */
+    __shared__ ulonglong2 s_items[512 + 64 * HALF_CAP];
+    u32 s_n = 0; /* wave uniform */
+    auto flush_items = [&]() {
+        if (!FILL || s_n == 0) return;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(n_list, (u64)s_n);
+        base = readlane_u64(base, 0);
+        for (u32 x = lane; x < s_n; x += 64) {
+            if (base + x < cap) list[base + x] = s_items[x];
+            else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
+        }
+        s_n = 0;
+    };
     auto item_of = [&](u64 e, u64 b, u32 Lb) {
         return make_ulonglong2(ADJ_DST(e), ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lb, b, disco_twin_orient(ADJ_ORI(e)), Lb));
     };
@@ -458,18 +502,17 @@ __global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ 
             if (tot) {
                 if (!FILL) {
                     if (lane == 0) mine += tot;
-                } else {
-                    u64 base = 0;
-                    if (lane == 0) base = atomicAdd(n_list, (u64)tot);
-                    base = readlane_u64(base, 0);
-                    u64 p = base + (incl - mycnt);
+                } else { /* into the wavefront's LDS buffer, flushed 512 items at a time (one atomic on the list's counter per flush) */
+                    u32 p = s_n + (incl - mycnt);
 #pragma unroll
                     for (u32 r = 0; r < HALF_CAP; r++)
-                        if (takem & (1u << r)) {
-                            if (p < cap) list[p] = item_of(he[r], b, Lb);
-                            else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
-                            p++;
-                        }
+                        if (takem & (1u << r)) s_items[p++] = item_of(he[r], b, Lb);
+                    s_n += tot;
+                    __syncthreads();
+                    if (s_n > 512u) {
+                        flush_items();
+                        __syncthreads();
+                    }
                 }
             }
         }
@@ -490,6 +533,8 @@ __global__ void __launch_bounds__(256) emit_push_kernel(const u64 *__restrict__ 
             }
         }
     }
+    __syncthreads();
+    flush_items();
     if (!FILL && lane == 0 && mine) atomicAdd(n_list, mine);
 }
 

@@ -4099,7 +4099,7 @@ static int dist_push_survivors(disco_ctx *c)
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
     u64 n_items = 0;
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(emit_push_kernel<false>, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
+    if (nloc) hipLaunchKernelGGL(emit_push_kernel<false>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -4107,7 +4107,7 @@ static int dist_push_survivors(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(n_items, 1)));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, c->d_x16b, c->d_list_n, n_items, c->d_ctr);
+    if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, c->d_x16b, c->d_list_n, n_items, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     CHK(read_counters(c));
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "survivor push: the fill pass produced more items than the count pass");
