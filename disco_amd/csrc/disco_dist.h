@@ -339,26 +339,34 @@ template <bool FILL>
 __global__ void __launch_bounds__(64) tr_respond_kernel(const u32 *__restrict__ req, u64 n_req, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
                                                         u32 *__restrict__ deg, const u64 *__restrict__ pos, u32 *__restrict__ out)
 {
-    for (u64 i = blockIdx.x; i < n_req; i += gridDim.x) {
-        const u32 rq = req[i];
-        const u64 rv = ref[rq >> 1];
-        const u32 cls = rq & 1u, d = REF_DEG(rv);
+    /* four requests per wavefront, sixteen lanes each (round 4; a request's row has about 36 entries, half of them of its class: one
+     * request per wavefront kept 4 of 5 lanes idle and paid its three dependent loads one request at a time) */
+    const u32 lane = threadIdx.x, sub = lane & 15u, g0 = lane & ~15u;
+    for (u64 i0 = (u64)blockIdx.x * 4; i0 < n_req; i0 += (u64)gridDim.x * 4) {
+        const u64 i = i0 + (lane >> 4);
+        const bool live = i < n_req;
+        const u32 rq = live ? req[i] : 0u;
+        const u64 rv = live ? ref[rq >> 1] : 0ull;
+        const u32 cls = rq & 1u, d = live ? REF_DEG(rv) : 0u;
         const u64 *row = adj + REF_POS(rv);
+        u32 dmax = d;
+        dmax = max(dmax, (u32)__shfl_xor((int)dmax, 16));
+        dmax = max(dmax, (u32)__shfl_xor((int)dmax, 32));
         u32 n = 0;
-        const u64 base = FILL ? pos[i] : 0ull;
-        for (u32 s0 = 0; s0 < d; s0 += 64) {
-            const u32 s = s0 + threadIdx.x;
+        const u64 base = (FILL && live) ? pos[i] : 0ull;
+        for (u32 s0 = 0; s0 < dmax; s0 += 16) {
+            const u32 s = s0 + sub;
             u64 e = 0;
             bool ok = false;
             if (s < d) {
                 e = row[s];
                 ok = (ADJ_ORI(e) >> 1) != cls;
             }
-            const u64 mk = __ballot(ok);
-            if (FILL && ok) out[base + n + __popcll(mk & lane_mask_lt())] = NBR32_MAKE(e);
-            n += __popcll(mk);
+            const u32 mk = (u32)(__ballot(ok) >> g0) & 0xFFFFu;
+            if (FILL && ok) out[base + n + (u32)__popc(mk & ((1u << sub) - 1u))] = NBR32_MAKE(e);
+            n += (u32)__popc(mk);
         }
-        if (!FILL && threadIdx.x == 0) deg[i] = n;
+        if (!FILL && live && sub == 0) deg[i] = n;
     }
 }
 

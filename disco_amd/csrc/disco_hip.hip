@@ -3931,7 +3931,7 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     /* the owner's side: class-filtered degree of every requested row, positions, entries */
     CHK(ensure_cap(c, &c->d_rdeg_s, &c->rdeg_s_cap, std::max<u64>(nrq, 1)));
     CHK(ensure_cap(c, &c->d_rpos, &c->rpos_cap, std::max<u64>(std::max(nrq, n_flat), 1) + 1));
-    const int rgrid = (int)std::max<u64>(std::min<u64>(nrq, (u64)c->n_cu * 32), 1);
+    const int rgrid = (int)std::max<u64>(std::min<u64>((nrq + 3) / 4, (u64)c->n_cu * 32), 1);
     if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
     HIPCHK(c, hipGetLastError());
     u64 total_s = 0;
