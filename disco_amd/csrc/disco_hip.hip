@@ -2019,7 +2019,10 @@ int disco_probe(disco_ctx *c)
 #undef VERIFY_INEXACT
             } else if (nq) {
                 va.cbits = nullptr;
-                if (flat && c->max_len <= 160) hipLaunchKernelGGL(verify_flat_kernel<5>, dim3(wq_grid(c, verify_flat_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                const bool vcache = getenv("DISCO_VERIFY_CACHE") != nullptr;
+                if (flat && vcache && c->max_len <= 160) hipLaunchKernelGGL((verify_flat_kernel<5, 0, true>), dim3(wq_grid(c, verify_flat_kernel<5, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (flat && vcache) hipLaunchKernelGGL((verify_flat_kernel<8, 0, true>), dim3(wq_grid(c, verify_flat_kernel<8, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                else if (flat && c->max_len <= 160) hipLaunchKernelGGL(verify_flat_kernel<5>, dim3(wq_grid(c, verify_flat_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat) hipLaunchKernelGGL(verify_flat_kernel<8>, dim3(wq_grid(c, verify_flat_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == VERIFY_SW && c->max_len <= 160) hipLaunchKernelGGL(verify_kernel<5>, dim3(wq_grid(c, verify_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (c->S == VERIFY_SW) hipLaunchKernelGGL(verify_kernel<8>, dim3(wq_grid(c, verify_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);

@@ -1584,22 +1584,46 @@ __device__ __forceinline__ u64 pinned_copy(u64 x)
 #ifndef VERIFY_FLAT_WAVES_PER_SIMD
 #define VERIFY_FLAT_WAVES_PER_SIMD 1
 #endif
-template <int NW, int MODE = 0>
+/* CACHE (round 4): the staged rows of the LAST batch stay where they are while the next one is compared against its own buffer, and a
+ * candidate whose read was fetched for the batch before — or for another lane of its own batch — takes that row instead of fetching
+ * it again: reads of one locus come back to back in the processing order and share four candidates in five, so a candidate's read
+ * was, more often than not, somebody's candidate 44 lanes earlier. A 256-entry table of slot numbers (by a hash of the read id; the
+ * slot's id decides) finds it; the misses of a batch are compacted into a fetch list, four lanes per row as before. Measured bound:
+ * with two / four lanes sharing every row verify runs 17.1 / 14.3 ms instead of 23.2. */
+template <int NW, int MODE = 0, bool CACHE = false>
 __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_kernel(VerifyArgs a)
 {
     constexpr int ND = 2 * NW;       /* dwords of a row */
     constexpr int BSTR = ND + 1;     /* candidate row r: dwords [1 + r BSTR, + ND); the dword in front belongs to the row before (never zero, never needed: masked) */
     constexpr int TSTR = 2 * ND + 1; /* segment s: [1 + s TSTR, + ND) the read, [+ ND, + 2 ND) its reverse complement */
     constexpr int S = VERIFY_SW;
-    __shared__ u32 s_b[64 * BSTR + ND + 4];
-    __shared__ u32 s_t[64 * TSTR + ND + 4];
-    __shared__ ulonglong2 s_hdr[64]; /* {row start, first flat index | candidates << 32} */
-    __shared__ uint2 s_al[64];       /* {read id, length} */
-    __shared__ u32 s_nk[64];         /* verified hits of the segment */
+#ifndef VF_CHUNK
+#define VF_CHUNK 64u
+#endif
+    constexpr u32 CH = CACHE ? 32u : VF_CHUNK; /* reads of a work-queue chunk (CACHE: half, for the LDS its second staging buffer takes) */
+    constexpr int NBUF = CACHE ? 2 : 1; /* staging buffers of 64 rows: this batch's and (CACHE) the one before */
+    __shared__ u32 s_b[NBUF * 64 * BSTR + ND + 4];
+    __shared__ u32 s_hid[CACHE ? 128 : 1];  /* CACHE: read id whose row slot s holds (0xFFFFFFFF: none) */
+    __shared__ u8 s_hash[CACHE ? 256 : 1];  /* ... hash of a read id -> the slot that took it last */
+    __shared__ u32 s_lid[CACHE ? 64 : 1];   /* ... fetch list of the batch being decided: read ids */
+    __shared__ u8 s_lslot[CACHE ? 64 : 1];  /* ... and the slots they go to */
+    __shared__ u32 s_t[CH * TSTR + ND + 4];
+    __shared__ ulonglong2 s_hdr[CH]; /* {row start, first flat index | candidates << 32} */
+    __shared__ uint2 s_al[CH];       /* {read id, length} */
+    __shared__ u32 s_nk[CH];         /* verified hits of the segment */
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
     u64 cbeg = 0, cend = 0;
+    u32 gb = 0; /* CACHE: batches this wavefront has decided so far (its low bit names the buffer a batch stages into) */
+    if (CACHE) {
+        s_hid[lane] = 0xFFFFFFFFu;
+        s_hid[lane + 64] = 0xFFFFFFFFu;
+        ((u32 *)s_hash)[lane] = 0u;
+        s_lid[lane] = 0u;
+        s_lslot[lane] = 0;
+        __syncthreads();
+    }
     /* is the candidate of this pass? (verify_kernel's in_pass) */
     auto in_pass = [&](u64 h, int LA) -> bool {
         if (MODE == 0) return true;
@@ -1607,7 +1631,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
         const bool contain = (HIT_SUFFIX(h) == HIT_REV(h)) ? (LA - j >= LB) : (j + k - LB >= 0);
         return MODE == 1 ? contain : (!contain && j >= 1);
     };
-    while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
+    while (wq_grab<CH>(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
         const u32 n = (u32)(cend - cbeg);
         const u64 ci = cbeg + (lane < n ? lane : 0u);
         const u64 ordw = a.order ? a.order[ci] : a.v.q_lo + ci;
@@ -1627,23 +1651,27 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
         const u32 P = incl - c;
         const u32 C = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         __syncthreads();
-        s_hdr[lane] = make_ulonglong2(meta.x, (u64)P | ((u64)c << 32));
-        s_al[lane] = make_uint2(A, (u32)L);
-        s_nk[lane] = 0u;
-        u32 *tf = s_t + 1 + lane * TSTR;
+        u32 *tf = s_t + 1 + (lane < CH ? lane : 0u) * TSTR;
+        if (lane < CH) {
+            s_hdr[lane] = make_ulonglong2(meta.x, (u64)P | ((u64)c << 32));
+            s_al[lane] = make_uint2(A, (u32)L);
+            s_nk[lane] = 0u;
 #pragma unroll
-        for (int t = 0; t < NW; t++) {
-            const u64 w = (t & 1) ? ow[t >> 1].y : ow[t >> 1].x;
-            tf[2 * t] = (u32)(w >> 32);
-            tf[2 * t + 1] = (u32)w;
+            for (int t = 0; t < NW; t++) {
+                const u64 w = (t & 1) ? ow[t >> 1].y : ow[t >> 1].x;
+                tf[2 * t] = (u32)(w >> 32);
+                tf[2 * t + 1] = (u32)w;
+            }
         }
         __syncthreads();
         /* dword g of revcomp(A) = reverse complement of A[L - 16 (g + 1), L - 16 g); what lies beyond the read is masked by every consumer */
+        if (lane < CH) {
 #pragma unroll
-        for (int g = 0; g < ND; g++) {
-            int pos = L - 16 * (g + 1);
-            pos = pos > -15 ? pos : -15;
-            tf[ND + g] = rev2_32(~stream_bits32(tf, 2 * pos));
+            for (int g = 0; g < ND; g++) {
+                int pos = L - 16 * (g + 1);
+                pos = pos > -15 ? pos : -15;
+                tf[ND + g] = rev2_32(~stream_bits32(tf, 2 * pos));
+            }
         }
         __syncthreads();
 
@@ -1659,7 +1687,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             fl = fl < last ? fl : last;
             seg = sscan;
             u32 s = (u32)__builtin_amdgcn_readfirstlane((int)sscan) + 1u;
-            while (s < 64u) {
+            while (s < CH) {
                 const u32 Ps = (u32)__builtin_amdgcn_readlane((int)P, (int)s);
                 if (Ps > fl) break;
                 seg = f >= Ps ? s : seg;
@@ -1671,11 +1699,15 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             const ulonglong2 hd = s_hdr[seg];
             return a.hits[hd.x + (u64)(f - (u32)hd.y)];
         };
-        /* q[p] of a batch: quarter (lane & 3) of the row of candidate 16 p + (lane >> 2) */
+        /* q[p] of a batch: quarter (lane & 3) of the row of candidate 16 p + (lane >> 2) (CACHE: of entry 16 p + (lane >> 2) of the fetch list) */
         auto row_ptr = [&](u64 h, u32 seg, int p) -> const ulonglong2 * {
             u32 vid = (u32)HIT_ID(h);
 #if defined(VERIFY_EXP_NOROWS) /* timing experiment (tools/ab_build.py; results are wrong): every lane fetches its read's own row */
             vid = s_al[seg].x;
+#endif
+#if defined(VERIFY_EXP_SHAREROWS) /* timing experiment (results are wrong): groups of VERIFY_EXP_SHAREROWS lanes fetch ONE row — what a row
+                                     cache with that reuse would leave of the row traffic */
+            vid = (u32)__shfl((int)vid, (int)(lane & ~(u32)(VERIFY_EXP_SHAREROWS - 1)));
 #endif
             if (MODE != 0) { /* candidates of the other pass: the read's own row instead */
                 const uint2 al = s_al[seg];
@@ -1684,26 +1716,187 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             const u32 id = (u32)__shfl((int)vid, (int)(16 * p + (lane >> 2)));
             return (const ulonglong2 *)(a.v.reads + (u64)id * S) + (lane & 3u);
         };
-        auto stage_rows = [&](const ulonglong2 q0, const ulonglong2 q1, const ulonglong2 q2, const ulonglong2 q3) {
+        /* one row's quarter into its place: row r of the staging area at 1 + r BSTR */
+        auto put_quarter = [&](u32 r, const ulonglong2 q) {
             const u32 qq = lane & 3u;
-            u32 *dst = s_b + 1 + (lane >> 2) * BSTR + 4 * qq;
+            u32 *dst = s_b + 1 + r * BSTR + 4 * qq;
             if (2 * qq + 1 < (u32)NW) { /* both words of the quarter belong to the row */
-                dst[0] = (u32)(q0.x >> 32), dst[1] = (u32)q0.x, dst[2] = (u32)(q0.y >> 32), dst[3] = (u32)q0.y;
-                dst[16 * BSTR + 0] = (u32)(q1.x >> 32), dst[16 * BSTR + 1] = (u32)q1.x, dst[16 * BSTR + 2] = (u32)(q1.y >> 32), dst[16 * BSTR + 3] = (u32)q1.y;
-                dst[32 * BSTR + 0] = (u32)(q2.x >> 32), dst[32 * BSTR + 1] = (u32)q2.x, dst[32 * BSTR + 2] = (u32)(q2.y >> 32), dst[32 * BSTR + 3] = (u32)q2.y;
-                dst[48 * BSTR + 0] = (u32)(q3.x >> 32), dst[48 * BSTR + 1] = (u32)q3.x, dst[48 * BSTR + 2] = (u32)(q3.y >> 32), dst[48 * BSTR + 3] = (u32)q3.y;
+                dst[0] = (u32)(q.x >> 32), dst[1] = (u32)q.x, dst[2] = (u32)(q.y >> 32), dst[3] = (u32)q.y;
             } else if (2 * qq < (u32)NW) { /* NW odd: the row's last word */
-                dst[0] = (u32)(q0.x >> 32), dst[1] = (u32)q0.x;
-                dst[16 * BSTR + 0] = (u32)(q1.x >> 32), dst[16 * BSTR + 1] = (u32)q1.x;
-                dst[32 * BSTR + 0] = (u32)(q2.x >> 32), dst[32 * BSTR + 1] = (u32)q2.x;
-                dst[48 * BSTR + 0] = (u32)(q3.x >> 32), dst[48 * BSTR + 1] = (u32)q3.x;
+                dst[0] = (u32)(q.x >> 32), dst[1] = (u32)q.x;
             }
         };
-        if (nb) {
+        auto stage_rows = [&](const ulonglong2 q0, const ulonglong2 q1, const ulonglong2 q2, const ulonglong2 q3) {
+            put_quarter(lane >> 2, q0);
+            put_quarter(16 + (lane >> 2), q1);
+            put_quarter(32 + (lane >> 2), q2);
+            put_quarter(48 + (lane >> 2), q3);
+        };
+        /* CACHE: which staged row does this lane's candidate use — one that is there (the last batch's), another lane's of this batch,
+         * or a fetch of its own (into slot 64 buf + lane)? The batch's fetches are listed (s_lid / s_lslot); returns the lane's slot */
+        auto decide = [&](u64 h, u32 seg, bool valid, u32 buf, u32 &nmiss) -> u32 {
+            bool need = valid;
+            if (MODE != 0) need = need && in_pass(h, (int)s_al[seg].y);
+            const u32 B = (u32)HIT_ID(h);
+            const u32 hs = (B * 0x9E3779B1u) >> 24;
+            u32 slot = s_hash[hs];
+            const bool hit = need && s_hid[slot] == B && (slot >> 6) != buf; /* (this batch's buffer is about to be overwritten) */
+            const u32 myslot = buf * 64u + lane;
+            bool miss = need && !hit;
+            __syncthreads();
+            if (miss) {
+                s_hid[myslot] = B;
+                s_hash[hs] = (u8)myslot;
+            }
+#ifndef VC_NO_INBATCH
+            __syncthreads();
+#endif
+            if (miss) { /* the same read twice in the batch: the lane that registered last fetches, the others take its row */
+#ifdef VC_NO_INBATCH
+                slot = myslot;
+            }
+            if (false) {
+#endif
+                const u32 w = s_hash[hs];
+                if (w != myslot && s_hid[w] == B && (w >> 6) == buf) {
+                    miss = false;
+                    slot = w;
+                    s_hid[myslot] = 0xFFFFFFFFu; /* (nothing will be staged here) */
+                } else
+                    slot = myslot;
+            }
+            const u64 mk = __ballot(miss);
+            if (miss) {
+                const u32 r = (u32)__popcll(mk & lane_mask_lt());
+                s_lid[r] = B;
+                s_lslot[r] = (u8)myslot;
+            }
+            nmiss = (u32)__popcll(mk);
+            __syncthreads();
+            return need ? slot : 0u;
+        };
+        /* CACHE: entry 16 p + (lane >> 2) of the fetch list (clamped: lanes beyond it repeat its last row, a line on its way anyway) */
+        auto list_ptr = [&](u32 nmiss, int p, u32 &lsl) -> const ulonglong2 * {
+            u32 r = 16u * (u32)p + (lane >> 2);
+            const u32 last = nmiss ? nmiss - 1u : 0u;
+            r = r < last ? r : last;
+            lsl |= (u32)s_lslot[r] << (8 * p);
+            return (const ulonglong2 *)(a.v.reads + (u64)s_lid[r] * S) + (lane & 3u);
+        };
+        /* the rows of the fetch list: sixteen per load instruction, and only as many instructions as the list needs (wave uniform) */
+        auto load_list = [&](u32 nmiss, u32 &lsl, ulonglong2 &q0, ulonglong2 &q1, ulonglong2 &q2, ulonglong2 &q3) {
+            lsl = 0;
+            q0 = *list_ptr(nmiss, 0, lsl);
+            if (nmiss > 16u) q1 = *list_ptr(nmiss, 1, lsl);
+            if (nmiss > 32u) q2 = *list_ptr(nmiss, 2, lsl);
+            if (nmiss > 48u) q3 = *list_ptr(nmiss, 3, lsl);
+        };
+        u32 carry = 0; /* wave uniform: hits the segment that is open at the batch's first lane has kept so far */
+        /* batch b: lane's candidate h of segment seg against the row staged in slot myrow */
+        auto compute = [&](const u32 b, const u64 h, const u32 seg, const u32 myrow) {
+            const bool valid = 64u * b + lane < C;
+            const ulonglong2 hd = s_hdr[seg];
+            const uint2 al = s_al[seg];
+            const u32 Pseg = (u32)hd.y, cseg = (u32)(hd.y >> 32);
+            const u32 Aseg = al.x;
+            const int LA = (int)al.y;
+            const bool act = valid && in_pass(h, LA);
+            const int j = (int)HIT_J(h);
+            const u32 B = (u32)HIT_ID(h);
+            const int LB = (int)HIT_LEN(h);
+            const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+            const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
+            /* s2 = B or revcomp(B); s2[p] lies under A[p + d]; aligned region in A coordinates [x0, x1) */
+            const int d = prefix_align ? j : j + k - LB;
+            const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
+            bool contain, overlap;
+            if (prefix_align) {
+                contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
+                overlap = !contain && j >= 1; /* :579 */
+            } else {
+                contain = d >= 0;           /* :547 */
+                overlap = d <= 0 && j >= 1; /* :591 */
+            }
+            /* a reversed candidate is compared as revcomp(A) against B itself (coordinates y = LA-1-x):
+             * T[X] == B[X - dd] for X in [X0, X1), T = A or revcomp(A) */
+            const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
+            const int dd = rev ? LA - LB - d : d;
+            const int W0 = X0 >> 4, nl = ((X1 - 1) >> 4) - W0; /* first dword of the region in T, index of its last one */
+            const int bitpos = 2 * (16 * W0 - dd);             /* >= -30: B's bit under the first bit of T's dword W0 */
+            const int i0 = (bitpos - 1) >> 5;
+            const u32 sh = (u32)(32 * i0 + 32 - bitpos);
+            const u32 *bp = s_b + 1 + myrow * BSTR + i0;
+            const u32 *tp = s_t + 1 + seg * TSTR + (rev ? ND : 0) + W0;
+            const u32 fm = ~0u >> (2 * (X0 & 15)), lm = ~0u << (30 - 2 * ((X1 - 1) & 15));
+            u32 bd[ND + 1], td[ND];
+#pragma unroll
+            for (int t = 0; t <= ND; t++) bd[t] = bp[t];
+#pragma unroll
+            for (int t = 0; t < ND; t++) td[t] = tp[t];
+            u32 diff = 0;
+            /* dwords in front of the region's last one: whole (the first one under fm) */
+#pragma unroll
+            for (int t = 0; t < ND - 1; t++) {
+                u32 x = __builtin_amdgcn_alignbit(bd[t], bd[t + 1], sh) ^ td[t];
+                if (t == 0) x &= fm;
+                diff |= t < nl ? x : 0u;
+            }
+            { /* the last one, wherever it is */
+                const u32 x = __builtin_amdgcn_alignbit(bp[nl], bp[nl + 1], sh) ^ tp[nl];
+                diff |= x & (nl == 0 ? (lm & fm) : lm);
+            }
+#if defined(VERIFY_EXP_NOROWS) || defined(VERIFY_EXP_SHAREROWS)
+            diff = 0;
+#endif
+            const bool region_ok = act && diff == 0;
+            /* "the k-mer alone matches" (kmer_hits, what makes a candidate a hit of getListOfReads): the seed k-mer sits at the
+             * START of the region (T coordinates) for types 0 / 3, at its END for 1 / 2: the differing base nearest that end must
+             * be at least k bases in. A failing region is rare on clean reads; its lanes walk their dwords again. */
+            bool kmer_ok = region_ok;
+            if (__any(act && diff != 0)) {
+                if (act && diff != 0) {
+                    const bool at_start = prefix_align != (rev != 0);
+                    int fpos = -1, lpos = -1;
+                    for (int t = 0; t <= nl; t++) {
+                        u32 x = __builtin_amdgcn_alignbit(bp[t], bp[t + 1], sh) ^ tp[t];
+                        if (t == 0) x &= fm;
+                        if (t == nl) x &= lm;
+                        if (x) {
+                            if (fpos < 0) fpos = 16 * (W0 + t) + (__clz((int)x) >> 1);
+                            lpos = 16 * (W0 + t) + ((32 - __ffs((int)x)) >> 1);
+                        }
+                    }
+                    kmer_ok = at_start ? fpos >= X0 + k : lpos < X1 - k;
+                }
+            }
+            if (kmer_ok) my_khits++;
+            bool ov = false;
+            if (region_ok) {
+                if (contain && (LA > LB || (LA == LB && Aseg < B))) atomicMin(&a.best[B], CKEY_MAKE(Aseg, j, suf, rev));
+                ov = overlap;
+            }
+            /* compact the verified overlap hits to the front of their segment's row (writes never pass the candidates still to be read) */
+            if (MODE != 1) {
+                const u64 mk = __ballot(ov);
+                const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));
+                const int lo_lane = (int)Pseg - (int)(64u * b); /* the segment's first lane in this batch; < 0: it began earlier */
+                const u32 below_seg = (u32)__shfl((int)below, lo_lane > 0 ? lo_lane : 0);
+                const u32 rank = (lo_lane < 0 ? carry : 0u) + below - below_seg;
+                if (ov) a.hits[hd.x + rank] = h;
+                const u32 kept = rank + (ov ? 1u : 0u);
+                const bool last = valid && (64u * b + lane - Pseg == cseg - 1u); /* the segment ends on this lane */
+                if (last) {
+                    s_nk[seg] = kept;
+                    my_raw += kept;
+                    if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
+                }
+                carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
+            }
+        };
+        if (nb && !CACHE) {
             /* software pipeline: while batch b is compared, the candidate rows of batch b + 1 and the candidates of batch b + 2 are in
              * flight. Every register that a load targets is free when the load is issued (the rows were staged, the candidates
              * copied on), so nothing that is still in flight is ever copied (a copy waits for its load) */
-            u32 carry = 0; /* wave uniform: hits the segment that is open at the batch's first lane has kept so far */
             u32 sg0, sg1, ftmp;
             locate(0, sg0, ftmp);
             u64 h0 = load_cand(sg0, ftmp);
@@ -1726,104 +1919,57 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
                 locate(b + 2, sg1, ftmp);
                 h1 = load_cand(sg1, ftmp);
                 __syncthreads();
-                const bool valid = 64u * b + lane < C;
-                const ulonglong2 hd = s_hdr[seg];
-                const uint2 al = s_al[seg];
-                const u32 Pseg = (u32)hd.y, cseg = (u32)(hd.y >> 32);
-                const u32 Aseg = al.x;
-                const int LA = (int)al.y;
-                const bool act = valid && in_pass(h, LA);
-                const int j = (int)HIT_J(h);
-                const u32 B = (u32)HIT_ID(h);
-                const int LB = (int)HIT_LEN(h);
-                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
-                const bool prefix_align = (suf == rev); /* types 0,2: prefix of s2 sits at j ; types 1,3: suffix of s2 ends at j+k */
-                /* s2 = B or revcomp(B); s2[p] lies under A[p + d]; aligned region in A coordinates [x0, x1) */
-                const int d = prefix_align ? j : j + k - LB;
-                const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
-                bool contain, overlap;
-                if (prefix_align) {
-                    contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
-                    overlap = !contain && j >= 1; /* :579 */
-                } else {
-                    contain = d >= 0;           /* :547 */
-                    overlap = d <= 0 && j >= 1; /* :591 */
+                compute(b, h, seg, lane);
+            }
+        }
+        if (nb && CACHE) {
+            /* the same pipeline one stage deeper for the rows: the fetch list of batch b + 2 is decided and its loads are issued while
+             * batch b is compared (the decision is a chain of LDS round trips: issued a batch ahead only, the loads had one compare
+             * to come back in and verify ran no faster than without the cache). Two sets of row registers, E for even batches and O
+             * for odd ones: a set is free as soon as its batch is staged, and the loop is unrolled by two so that no set is ever copied */
+            u32 sg0, sg1, sg2, ftmp;
+            locate(0, sg0, ftmp);
+            u64 h0 = load_cand(sg0, ftmp);
+            locate(1, sg1, ftmp);
+            u64 h1 = load_cand(sg1, ftmp);
+            locate(2, sg2, ftmp);
+            u64 h2 = load_cand(sg2, ftmp);
+            ulonglong2 e0 = make_ulonglong2(0, 0), e1 = e0, e2 = e0, e3 = e0, o0 = e0, o1 = e0, o2 = e0, o3 = e0;
+            u32 nmE = 0, nmO = 0, lslE = 0, lslO = 0;
+            u32 slot0 = decide(h0, sg0, lane < C, gb & 1u, nmE);
+            gb++;
+            load_list(nmE, lslE, e0, e1, e2, e3);
+            u32 slot1 = decide(h1, sg1, 64u + lane < C, gb & 1u, nmO);
+            gb++;
+            load_list(nmO, lslO, o0, o1, o2, o3);
+            auto step = [&](const u32 b, u32 &nmQ, u32 &lslQ, ulonglong2 &q0, ulonglong2 &q1, ulonglong2 &q2, ulonglong2 &q3) {
+                __syncthreads();
+                { /* the fetched rows of batch b to their slots */
+                    const u32 r = lane >> 2;
+                    if (r < nmQ) put_quarter(lslQ & 0xFFu, q0);
+                    if (16u + r < nmQ) put_quarter((lslQ >> 8) & 0xFFu, q1);
+                    if (32u + r < nmQ) put_quarter((lslQ >> 16) & 0xFFu, q2);
+                    if (48u + r < nmQ) put_quarter(lslQ >> 24, q3);
                 }
-                /* a reversed candidate is compared as revcomp(A) against B itself (coordinates y = LA-1-x):
-                 * T[X] == B[X - dd] for X in [X0, X1), T = A or revcomp(A) */
-                const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
-                const int dd = rev ? LA - LB - d : d;
-                const int W0 = X0 >> 4, nl = ((X1 - 1) >> 4) - W0; /* first dword of the region in T, index of its last one */
-                const int bitpos = 2 * (16 * W0 - dd);             /* >= -30: B's bit under the first bit of T's dword W0 */
-                const int i0 = (bitpos - 1) >> 5;
-                const u32 sh = (u32)(32 * i0 + 32 - bitpos);
-                const u32 *bp = s_b + 1 + lane * BSTR + i0;
-                const u32 *tp = s_t + 1 + seg * TSTR + (rev ? ND : 0) + W0;
-                const u32 fm = ~0u >> (2 * (X0 & 15)), lm = ~0u << (30 - 2 * ((X1 - 1) & 15));
-                u32 bd[ND + 1], td[ND];
-#pragma unroll
-                for (int t = 0; t <= ND; t++) bd[t] = bp[t];
-#pragma unroll
-                for (int t = 0; t < ND; t++) td[t] = tp[t];
-                u32 diff = 0;
-                /* dwords in front of the region's last one: whole (the first one under fm) */
-#pragma unroll
-                for (int t = 0; t < ND - 1; t++) {
-                    u32 x = __builtin_amdgcn_alignbit(bd[t], bd[t + 1], sh) ^ td[t];
-                    if (t == 0) x &= fm;
-                    diff |= t < nl ? x : 0u;
-                }
-                { /* the last one, wherever it is */
-                    const u32 x = __builtin_amdgcn_alignbit(bp[nl], bp[nl + 1], sh) ^ tp[nl];
-                    diff |= x & (nl == 0 ? (lm & fm) : lm);
-                }
-#if defined(VERIFY_EXP_NOROWS)
-                diff = 0;
-#endif
-                const bool region_ok = act && diff == 0;
-                /* "the k-mer alone matches" (kmer_hits, what makes a candidate a hit of getListOfReads): the seed k-mer sits at the
-                 * START of the region (T coordinates) for types 0 / 3, at its END for 1 / 2: the differing base nearest that end must
-                 * be at least k bases in. A failing region is rare on clean reads; its lanes walk their dwords again. */
-                bool kmer_ok = region_ok;
-                if (__any(act && diff != 0)) {
-                    if (act && diff != 0) {
-                        const bool at_start = prefix_align != (rev != 0);
-                        int fpos = -1, lpos = -1;
-                        for (int t = 0; t <= nl; t++) {
-                            u32 x = __builtin_amdgcn_alignbit(bp[t], bp[t + 1], sh) ^ tp[t];
-                            if (t == 0) x &= fm;
-                            if (t == nl) x &= lm;
-                            if (x) {
-                                if (fpos < 0) fpos = 16 * (W0 + t) + (__clz((int)x) >> 1);
-                                lpos = 16 * (W0 + t) + ((32 - __ffs((int)x)) >> 1);
-                            }
-                        }
-                        kmer_ok = at_start ? fpos >= X0 + k : lpos < X1 - k;
-                    }
-                }
-                if (kmer_ok) my_khits++;
-                bool ov = false;
-                if (region_ok) {
-                    if (contain && (LA > LB || (LA == LB && Aseg < B))) atomicMin(&a.best[B], CKEY_MAKE(Aseg, j, suf, rev));
-                    ov = overlap;
-                }
-                /* compact the verified overlap hits to the front of their segment's row (writes never pass the candidates still to be read) */
-                if (MODE != 1) {
-                    const u64 mk = __ballot(ov);
-                    const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));
-                    const int lo_lane = (int)Pseg - (int)(64u * b); /* the segment's first lane in this batch; < 0: it began earlier */
-                    const u32 below_seg = (u32)__shfl((int)below, lo_lane > 0 ? lo_lane : 0);
-                    const u32 rank = (lo_lane < 0 ? carry : 0u) + below - below_seg;
-                    if (ov) a.hits[hd.x + rank] = h;
-                    const u32 kept = rank + (ov ? 1u : 0u);
-                    const bool last = valid && (64u * b + lane - Pseg == cseg - 1u); /* the segment ends on this lane */
-                    if (last) {
-                        s_nk[seg] = kept;
-                        my_raw += kept;
-                        if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
-                    }
-                    carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
-                }
+                const u64 h = pinned_copy(h0);
+                const u32 seg = sg0, myrow = slot0;
+                h0 = pinned_copy(h1);
+                sg0 = sg1;
+                slot0 = slot1;
+                h1 = pinned_copy(h2);
+                sg1 = sg2;
+                slot1 = decide(h1, sg1, 64u * (b + 2u) + lane < C, gb & 1u, nmQ); /* batch b + 2: its rows into the set just staged */
+                gb++;
+                load_list(nmQ, lslQ, q0, q1, q2, q3);
+                locate(b + 3, sg2, ftmp);
+                h2 = load_cand(sg2, ftmp);
+                __syncthreads();
+                compute(b, h, seg, myrow);
+            };
+            for (u32 b = 0; b < nb; b += 2) {
+                step(b, nmE, lslE, e0, e1, e2, e3);
+                if (b + 1 >= nb) break;
+                step(b + 1, nmO, lslO, o0, o1, o2, o3);
             }
         }
         __syncthreads();
