@@ -229,7 +229,8 @@ struct disco_ctx {
     u64 cpos_cap = 0, crow_cap = 0;
     u64 *d_tile2 = nullptr, *d_total2 = nullptr; /* scan temporaries of the side stream */
     size_t tile2_cap = 0;
-    void *h_crows = nullptr; /* pinned: keys u64[crows_hcap] then ids u32[crows_hcap] */
+    void *h_crows = nullptr; /* pinned, per order (by id, then grouped): keys u64[crows_hcap], ids u32[crows_hcap], lengths u32[crows_hcap] */
+    u32 *d_crow_len = nullptr; /* [crow_cap] len2 | len1 << 16 of the rows about to leave */
     u64 crows_hcap = 0, crows_n = 0;
     bool crows_pending = false; /* the rows of the CURRENT flags are on their way / in h_crows */
     bool crows_in_ring = false; /* h_crows is the input stage's pinned ring (h_ring), not an allocation of its own */
@@ -826,18 +827,20 @@ static int start_contained_rows(disco_ctx *c, bool grouped)
     if (nc > c->crow_cap) {
         dev_free(c, &c->d_crow_id, c->crow_cap);
         dev_free(c, &c->d_crow_key, c->crow_cap);
+        dev_free(c, &c->d_crow_len, c->crow_cap);
         c->crow_cap = 0;
         const u64 want = nc + nc / 4 + 1024;
         CHK(dev_alloc(c, &c->d_crow_id, want));
         CHK(dev_alloc(c, &c->d_crow_key, want));
+        CHK(dev_alloc(c, &c->d_crow_len, want));
         c->crow_cap = want;
     }
-    if (nc > c->crows_hcap && c->h_ring && !c->crows_in_ring && (u64)c->ring_half * 2 >= (nc + 1024) * 24) {
+    if (nc > c->crows_hcap && c->h_ring && !c->crows_in_ring && (u64)c->ring_half * 2 >= (nc + 1024) * 32) {
         /* the pinned ring of the input stage is idle between the input stage and the text output: the rows stage there (pinning
          * 140 MB for them took 0.05 s of the host thread that feeds the pass) */
         if (c->h_crows) (void)hipHostFree(c->h_crows);
         c->h_crows = c->h_ring;
-        c->crows_hcap = (u64)c->ring_half * 2 / 24;
+        c->crows_hcap = (u64)c->ring_half * 2 / 32;
         c->crows_in_ring = true;
     }
     if (nc > c->crows_hcap) {
@@ -846,7 +849,7 @@ static int start_contained_rows(disco_ctx *c, bool grouped)
         c->h_crows = nullptr;
         c->crows_hcap = 0;
         const u64 want = nc + nc / 4 + 1024;
-        if (hipHostMalloc(&c->h_crows, want * 24) != hipSuccess) { /* (both orders) no pinned memory to be had: the on-demand path */
+        if (hipHostMalloc(&c->h_crows, want * 32) != hipSuccess) { /* (both orders) no pinned memory to be had: the on-demand path */
             c->h_crows = nullptr;
             (void)hipGetLastError();
             return DISCO_OK;
@@ -859,9 +862,12 @@ static int start_contained_rows(disco_ctx *c, bool grouped)
     hipLaunchKernelGGL(contain_rows32_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->aux_stream, c->d_best, c->d_contained, c->d_cpos, c->n, c->d_crow_id, c->d_crow_key);
     HIPCHK(c, hipGetLastError());
     u64 *hkey = (u64 *)c->h_crows;
-    u32 *hid = (u32 *)(hkey + c->crows_hcap);
+    u32 *hid = (u32 *)(hkey + c->crows_hcap), *hln = hid + c->crows_hcap;
+    hipLaunchKernelGGL(crow_lens_kernel, dim3(flat_grid(c, nc)), dim3(256), 0, c->aux_stream, (const u32 *)c->d_crow_id, (const u64 *)c->d_crow_key, nc, (const u16 *)c->d_len, c->d_crow_len);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hkey, c->d_crow_key, nc * 8, hipMemcpyDeviceToHost, c->aux_stream));
     HIPCHK(c, hipMemcpyAsync(hid, c->d_crow_id, nc * 4, hipMemcpyDeviceToHost, c->aux_stream));
+    HIPCHK(c, hipMemcpyAsync(hln, c->d_crow_len, nc * 4, hipMemcpyDeviceToHost, c->aux_stream));
     HIPCHK(c, hipEventRecord(c->ev_crows, c->aux_stream));
     c->crows_n = nc;
     c->crows_pending = true;
@@ -887,10 +893,13 @@ static int start_contained_rows(disco_ctx *c, bool grouped)
                            c->d_cgrp_key);
         hipLaunchKernelGGL(crow_sort_groups_kernel, dim3(flat_grid(c, nc)), dim3(256), 0, c->aux_stream, c->d_cgrp_id, c->d_cgrp_key, nc, c->d_cgrp_big);
         HIPCHK(c, hipGetLastError());
-        u64 *gkey = (u64 *)((char *)c->h_crows + c->crows_hcap * 12);
-        u32 *gid = (u32 *)(gkey + c->crows_hcap);
+        u64 *gkey = (u64 *)((char *)c->h_crows + c->crows_hcap * 16);
+        u32 *gid = (u32 *)(gkey + c->crows_hcap), *gln = gid + c->crows_hcap;
+        /* (the lengths of the rows by id have left: their device array serves the grouped order) */
+        hipLaunchKernelGGL(crow_lens_kernel, dim3(flat_grid(c, nc)), dim3(256), 0, c->aux_stream, (const u32 *)c->d_cgrp_id, (const u64 *)c->d_cgrp_key, nc, (const u16 *)c->d_len, c->d_crow_len);
         HIPCHK(c, hipMemcpyAsync(gkey, c->d_cgrp_key, nc * 8, hipMemcpyDeviceToHost, c->aux_stream));
         HIPCHK(c, hipMemcpyAsync(gid, c->d_cgrp_id, nc * 4, hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipMemcpyAsync(gln, c->d_crow_len, nc * 4, hipMemcpyDeviceToHost, c->aux_stream));
         HIPCHK(c, hipMemcpyAsync(&c->h_cgrp_big, c->d_cgrp_big, sizeof(u64), hipMemcpyDeviceToHost, c->aux_stream));
         c->cgrp_pending = true;
     }
@@ -1030,6 +1039,7 @@ void disco_destroy(disco_ctx *c)
     dev_free(c, &c->d_cpos, c->cpos_cap);
     dev_free(c, &c->d_crow_id, c->crow_cap);
     dev_free(c, &c->d_crow_key, c->crow_cap);
+    dev_free(c, &c->d_crow_len, c->crow_cap);
     dev_free(c, &c->d_cgrp_cur, c->cgrp_cur_cap);
     dev_free(c, &c->d_cgrp_id, c->cgrp_cap);
     dev_free(c, &c->d_cgrp_key, c->cgrp_cap);
@@ -2742,11 +2752,11 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     if (!out) return (int64_t)nc;
     if (cap < nc) return fail(c, DISCO_E_ARG, "disco_fetch_contained: need room for %llu rows", (unsigned long long)nc);
     if (nc == 0) return 0;
-    CHK(ensure_host_len(c));
-    auto decode = [&](auto id_of, const u64 *keys_h) {
-        const u16 *hlen = c->h_len.data();
+    /* lens_h: len2 | len1 << 16 per row where the device sent them along; null: gathered from the host's copy of the length table */
+    auto decode = [&](auto id_of, const u64 *keys_h, const u32 *lens_h) {
+        const u16 *hlen = lens_h ? nullptr : c->h_len.data();
         const u32 kk = (u32)c->k;
-        parallel_for(nc, [&, hlen, kk](u64 b, u64 e_) {
+        parallel_for(nc, [&, hlen, kk, lens_h](u64 b, u64 e_) {
             for (u64 i = b; i < e_; i++) {
                 const u64 key = keys_h[i];
                 disco_contained_row &r = out[i];
@@ -2754,8 +2764,8 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
                 r.super = CKEY_SUPER(key);
                 r.j = CKEY_J(key);
                 r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
-                r.len2 = hlen[r.contained];
-                r.len1 = hlen[r.super];
+                r.len2 = lens_h ? (lens_h[i] & 0xFFFFu) : hlen[r.contained];
+                r.len1 = lens_h ? (lens_h[i] >> 16) : hlen[r.super];
                 u32 orient, off;
                 disco_map_type(r.type, r.len1, kk, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
                 r.orient = orient;
@@ -2768,9 +2778,10 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
         HIPCHK(c, hipEventSynchronize(c->ev_crows));
         const u64 *hkey = (const u64 *)c->h_crows;
         const u32 *hid = (const u32 *)(hkey + c->crows_hcap);
-        decode([hid](u64 i) { return (u64)hid[i]; }, hkey);
+        decode([hid](u64 i) { return (u64)hid[i]; }, hkey, hid + c->crows_hcap);
         return (int64_t)nc;
     }
+    CHK(ensure_host_len(c));
     u64 *pos = nullptr, *ids = nullptr, *keys = nullptr;
     std::vector<u64> hid(nc), hkey(nc);
     auto gather = [&]() -> int {
@@ -2789,7 +2800,7 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     dev_free(c, &ids, nc);
     dev_free(c, &keys, nc);
     CHK(grc);
-    decode([&hid](u64 i) { return hid[i]; }, hkey.data());
+    decode([&hid](u64 i) { return hid[i]; }, hkey.data(), nullptr);
     return (int64_t)nc;
 }
 
@@ -2809,12 +2820,10 @@ int64_t disco_fetch_contained_grouped(disco_ctx *c, disco_contained_row *out, ui
         return fail(c, DISCO_E_UNSUPPORTED, "disco_fetch_contained_grouped: the rows were not grouped on the device (sort what disco_fetch_contained returns)");
     HIPCHK(c, hipStreamSynchronize(c->aux_stream));
     if (c->h_cgrp_big) return fail(c, DISCO_E_UNSUPPORTED, "disco_fetch_contained_grouped: a containing read has more than %d rows (sort what disco_fetch_contained returns)", CROW_GROUP_MAX);
-    CHK(ensure_host_len(c));
-    const u64 *hkey = (const u64 *)((const char *)c->h_crows + c->crows_hcap * 12);
-    const u32 *hid = (const u32 *)(hkey + c->crows_hcap);
-    const u16 *hlen = c->h_len.data();
+    const u64 *hkey = (const u64 *)((const char *)c->h_crows + c->crows_hcap * 16);
+    const u32 *hid = (const u32 *)(hkey + c->crows_hcap), *hln = hid + c->crows_hcap;
     const u32 kk = (u32)c->k;
-    parallel_for(nc, [&, hlen, kk, hkey, hid](u64 b, u64 e_) {
+    parallel_for(nc, [&, kk, hkey, hid, hln](u64 b, u64 e_) {
         for (u64 i = b; i < e_; i++) {
             const u64 key = hkey[i];
             disco_contained_row &r = out[i];
@@ -2822,8 +2831,8 @@ int64_t disco_fetch_contained_grouped(disco_ctx *c, disco_contained_row *out, ui
             r.super = CKEY_SUPER(key);
             r.j = CKEY_J(key);
             r.type = disco_hit_type(CKEY_SUFFIX(key), CKEY_REV(key));
-            r.len2 = hlen[r.contained];
-            r.len1 = hlen[r.super];
+            r.len2 = hln[i] & 0xFFFFu;
+            r.len1 = hln[i] >> 16;
             u32 orient, off;
             disco_map_type(r.type, r.len1, kk, r.j, &orient, &off); /* BG/OverlapGraph.cpp:428-434 */
             r.orient = orient;
