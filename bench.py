@@ -53,7 +53,7 @@ def parse_args():
 
 # phase of disco_phase_ms -> the kernel(s) behind it
 PHASE_KERNELS = {"index": "index_runs_kernel + scan + index_fill_kernel", "probe_kernel": "probe_runs_kernel", "verify": "verify_flat_kernel",
-                 "contain": "contain_flags_kernel", "select": "edge_select_kernel", "trmark": "transitive_mark_kernel", "emit": "emit_half_kernel"}
+                 "contain": "contain_flags_kernel", "select": "edge_select_flat_kernel", "trmark": "transitive_mark_kernel", "emit": "emit_half_kernel"}
 
 
 def algorithmic_bytes(cnt, n_reads, words_mean):

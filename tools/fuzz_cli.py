@@ -17,7 +17,7 @@ fails = skipped = 0
 t0 = time.time()
 for it in range(iters):
     with tempfile.TemporaryDirectory() as d:
-        mo = int(rng.choice([31, 40, 50]))
+        mo = int(rng.choice([31, 40, 50, 80]))
         lmin = int(rng.choice([70, 100, 150, 250]))
         lmax = lmin if rng.random() < 0.5 else lmin + int(rng.integers(1, lmin))
         n = int(rng.integers(200, 3000))

@@ -28,7 +28,7 @@ t0 = time.time()
 for it in range(iters):
     lmin = int(rng.choice([45, 60, 80, 100, 150, 151, 168, 200, 256, 257, 300, 500, 1000, 1025, 2000]))
     lmax = lmin if rng.random() < 0.3 else int(lmin + rng.integers(1, 2 * lmin))
-    mo = int(rng.choice([31, 32, 33, 40, 41, 50, 64, 65]))
+    mo = int(rng.choice([31, 32, 33, 40, 41, 50, 64, 65, 66, 80, 88, 95]))  # (round 4: k up to 94)
     if mo >= lmin:
         mo = max(31, lmin - 8)
     cov = float(rng.choice([3, 8, 20, 30, 60, 120, 300, 700]))

@@ -63,8 +63,12 @@ def fasta(nrec):
         L = int(rng.integers(0, 260))
         s = rand_seq(L)
         hdr = ">r%d" % i + (" x>y" if rng.random() < 0.05 else "")
-        w = int(rng.choice([0, 0, 60, 70, 7]))
-        body = s if not w or not s else eol.join(s[j:j + w] for j in range(0, L, w))
+        w = int(rng.choice([0, 0, 60, 70, 7, -1]))
+        if w < 0 and s:  # lines of random widths (round 4: the device stage walks irregularly wrapped records)
+            cuts = sorted(set(int(x) for x in rng.integers(1, max(L, 2), size=int(rng.integers(1, 6)))))
+            body = eol.join(s[a:b] for a, b in zip([0] + cuts, cuts + [L]))
+        else:
+            body = s if not w or not s else eol.join(s[j:j + w] for j in range(0, L, w))
         if rng.random() < 0.03 and L > 10:
             body = body[:5] + ">" + body[5:]
         t += hdr + eol + body + eol
