@@ -345,6 +345,15 @@ class BuildGraph:
         self._chk(self.L.disco_fetch_edge_text(self._h, buf.ctypes.data, nb))
         return buf[:nb].tobytes(), off
 
+    def write_edge_text(self, fds, threads: int = 8):
+        """the text of the last format_edges straight from the device into open files: fds[f] receives file f (disco_write_edge_text)"""
+        arr = (C.c_int * len(fds))(*fds)
+        self._chk(self.L.disco_write_edge_text(self._h, arr, len(fds), threads))
+
+    def start_contained_rows(self, grouped: bool = False):
+        """the contained rows start their way to the host now (between mark_contained and the fetch)"""
+        self._chk(self.L.disco_start_contained_rows(self._h, 1 if grouped else 0))
+
     def contract_chains(self, min_overlap_simplify: int = 0, edges=None):
         """chains of the reduced graph as composite edges (disco_contract_chains; with `edges`: disco_contract_chains_of on that array).
         Returns (composite edges [CHAIN_EDGE_DTYPE], links [CHAIN_LINK_DTYPE], absorbed flag per edge)"""

@@ -288,3 +288,16 @@ def test_ranks_partitioned_index_on_shapes_without_runs(name, G):
     ce, cc = canon_hip(edges, rows, fidx)
     gu.check_against_golden(name, ce, cc)
     assert sum(i["bytes_sent"]["queries"] for i in infos) > 0 and sum(i["bytes_sent"]["index_shards"] for i in infos) == 0
+
+
+def test_a_pass_allocates_nothing_and_reports_what_it_did():
+    """round 4: the arena of a multi-GPU context (one device allocation before the first collective) serves every buffer of a pass; the
+    pass reports its operations on the communicator, its blocking host waits, the allocations that reached the runtime and its
+    kernel time (disco_dist_info)"""
+    spec = readgen.GenSpec.coverage(seed=5, n_reads=60_000, read_len=150, cov=30.0, n_contigs=3)
+    edges, rows, info, infos = run_ranks(3, 40, lambda g: g.dist_generate_reads(spec), passes=3)
+    for i in infos:   # the last of three passes on warm contexts
+        assert i["device_allocs"] == 0 and i["device_frees"] == 0, i
+        assert i["arena_bytes"] > 0 and 0 < i["arena_peak"] <= i["arena_bytes"] and i["hbm_peak"] >= i["arena_peak"]
+        assert 10 <= i["comm_ops"] <= 40 and 10 <= i["host_syncs"] <= 90 and i["kernel_ms"] > 0
+    assert info["e_out"] == len(edges) > 0

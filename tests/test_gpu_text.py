@@ -52,3 +52,41 @@ def test_gpu_text_limits():
         g.run_graph()
         with pytest.raises(buildgraph.DiscoError):
             g.format_edges(1)                       # the substitutions column is the host writer's
+
+
+def test_edge_text_streamed_into_files_equals_the_fetched_text(tmp_path):
+    """round 4: disco_write_edge_text — the formatted lines from the device into the caller's open files (pieces through the pinned
+    ring, one writer per file and round) — against the text disco_fetch_edge_text returns; and the contained rows sent ahead
+    (disco_start_contained_rows) against the rows fetched on demand"""
+    import os
+
+    spec = readgen.GenSpec.coverage(seed=43, n_reads=200_000, read_len=100, cov=25.0, n_contigs=7, len_max=250)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.build_index()
+        g.probe()
+        n_cont = g.mark_contained()
+        g.start_contained_rows(grouped=True)   # the rows travel while the edges are selected and reduced
+        g.build_edges()
+        g.transitive_reduce()
+        grouped = g.fetch_contained_grouped()
+        rows = g.fetch_contained()
+        for n_files in (1, 7):
+            files = g.fetch_edge_files(n_files)
+            text, off = g.format_edges(n_files, files if n_files > 1 else None, None)
+            paths = [str(tmp_path / f"e{n_files}_{t}.txt") for t in range(n_files)]
+            fds = [os.open(p, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) for p in paths]
+            g.write_edge_text(fds, threads=5)
+            for fd in fds:
+                os.close(fd)
+            for t, p in enumerate(paths):
+                assert open(p, "rb").read() == text[int(off[t]):int(off[t + 1])], (n_files, t)
+            assert len(text) > 1_000_000 and sum(os.path.getsize(p) for p in paths) == len(text)
+    with buildgraph.BuildGraph(min_overlap=40) as g:   # the same rows without the head start
+        g.generate_reads(spec)
+        g.run_graph()
+        rows2 = g.fetch_contained()
+    assert n_cont == len(rows) == len(rows2) > 1000 and np.array_equal(rows, rows2)
+    assert grouped is not None and len(grouped) == len(rows)
+    key = lambda r: np.lexsort((r["contained"], r["j"], r["super"]))
+    assert np.array_equal(grouped, rows[key(rows)])
