@@ -1584,12 +1584,12 @@ __device__ __forceinline__ u64 pinned_copy(u64 x)
 #ifndef VERIFY_FLAT_WAVES_PER_SIMD
 #define VERIFY_FLAT_WAVES_PER_SIMD 1
 #endif
-/* CACHE (round 4): the staged rows of the LAST batch stay where they are while the next one is compared against its own buffer, and a
- * candidate whose read was fetched for the batch before — or for another lane of its own batch — takes that row instead of fetching
- * it again: reads of one locus come back to back in the processing order and share four candidates in five, so a candidate's read
- * was, more often than not, somebody's candidate 44 lanes earlier. A 256-entry table of slot numbers (by a hash of the read id; the
- * slot's id decides) finds it; the misses of a batch are compacted into a fetch list, four lanes per row as before. Measured bound:
- * with two / four lanes sharing every row verify runs 17.1 / 14.3 ms instead of 23.2. */
+/* CACHE (round 4): two batches are decided TOGETHER — a candidate whose read is some other lane's candidate among the 128 takes that
+ * lane's row instead of fetching it again (reads of one locus come back to back in the processing order and share four candidates in
+ * five: 128 consecutive candidates are three reads' worth and name about 60 different reads). Every lane writes its slot number under
+ * a hash of its read id and reads the winner back (the slot's id decides); leaders and displaced lanes are compacted into one fetch
+ * list, four lanes per row as before, only as many load instructions as the list needs; the loads of pair p + 1 are issued while pair
+ * p is compared. Measured bound: with two / four lanes sharing every row verify runs 17.1 / 14.3 ms instead of 23.2. */
 template <int NW, int MODE = 0, bool CACHE = false>
 __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_kernel(VerifyArgs a)
 {
@@ -1601,27 +1601,23 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
 #define VF_CHUNK 64u
 #endif
     constexpr u32 CH = CACHE ? 32u : VF_CHUNK; /* reads of a work-queue chunk (CACHE: half, for the LDS its second staging buffer takes) */
-    constexpr int NBUF = CACHE ? 2 : 1; /* staging buffers of 64 rows: this batch's and (CACHE) the one before */
+    constexpr int NBUF = CACHE ? 2 : 1; /* staged rows: 64 per batch; CACHE: the 128 slots of a pair of batches */
     __shared__ u32 s_b[NBUF * 64 * BSTR + ND + 4];
-    __shared__ u32 s_hid[CACHE ? 128 : 1];  /* CACHE: read id whose row slot s holds (0xFFFFFFFF: none) */
-    __shared__ u8 s_hash[CACHE ? 256 : 1];  /* ... hash of a read id -> the slot that took it last */
-    __shared__ u32 s_lid[CACHE ? 64 : 1];   /* ... fetch list of the batch being decided: read ids */
-    __shared__ u8 s_lslot[CACHE ? 64 : 1];  /* ... and the slots they go to */
     __shared__ u32 s_t[CH * TSTR + ND + 4];
     __shared__ ulonglong2 s_hdr[CH]; /* {row start, first flat index | candidates << 32} */
     __shared__ uint2 s_al[CH];       /* {read id, length} */
     __shared__ u32 s_nk[CH];         /* verified hits of the segment */
+    __shared__ u32 s_hid[CACHE ? 128 : 1];  /* CACHE: read id whose row slot s holds */
+    __shared__ u32 s_hash[CACHE ? 256 : 1]; /* ... hash of a read id -> the slot that registered it last (0xFFFFFFFF: nobody yet) */
+    __shared__ u32 s_lid[CACHE ? 128 : 1];  /* ... fetch list of the pair being decided: read ids */
+    __shared__ u8 s_lslot[CACHE ? 128 : 1]; /* ... and the slots they go to */
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
     u64 cbeg = 0, cend = 0;
-    u32 gb = 0; /* CACHE: batches this wavefront has decided so far (its low bit names the buffer a batch stages into) */
     if (CACHE) {
-        s_hid[lane] = 0xFFFFFFFFu;
-        s_hid[lane + 64] = 0xFFFFFFFFu;
-        ((u32 *)s_hash)[lane] = 0u;
         s_lid[lane] = 0u;
-        s_lslot[lane] = 0;
+        s_lid[lane + 64] = 0u;
         __syncthreads();
     }
     /* is the candidate of this pass? (verify_kernel's in_pass) */
@@ -1732,64 +1728,63 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             put_quarter(32 + (lane >> 2), q2);
             put_quarter(48 + (lane >> 2), q3);
         };
-        /* CACHE: which staged row does this lane's candidate use — one that is there (the last batch's), another lane's of this batch,
-         * or a fetch of its own (into slot 64 buf + lane)? The batch's fetches are listed (s_lid / s_lslot); returns the lane's slot */
-        auto decide = [&](u64 h, u32 seg, bool valid, u32 buf, u32 &nmiss) -> u32 {
-            bool need = valid;
-            if (MODE != 0) need = need && in_pass(h, (int)s_al[seg].y);
-            const u32 B = (u32)HIT_ID(h);
-            const u32 hs = (B * 0x9E3779B1u) >> 24;
-            u32 slot = s_hash[hs];
-            const bool hit = need && s_hid[slot] == B && (slot >> 6) != buf; /* (this batch's buffer is about to be overwritten) */
-            const u32 myslot = buf * 64u + lane;
-            bool miss = need && !hit;
+        /* CACHE: the rows of a PAIR of batches (candidate hA of segment sgA in batch 2p, hB / sgB in batch 2p + 1): which staged row does a
+         * lane's candidate use — its own fetch (slot = lane, 64 + lane) or the fetch of another lane of the pair with the same read?
+         * Every lane registers its slot under a hash of its read id; the last one to register a read fetches it, the others take its
+         * row; a lane displaced by another read (same hash) fetches for itself. The fetches are listed in s_lid / s_lslot. */
+        auto decide_pair = [&](u64 hA, u32 sgA, bool needA, u64 hB, u32 sgB, bool needB, u32 &slotA, u32 &slotB, u32 &nmiss) {
+            if (MODE != 0) {
+                needA = needA && in_pass(hA, (int)s_al[sgA].y);
+                needB = needB && in_pass(hB, (int)s_al[sgB].y);
+            }
+            const u32 idA = (u32)HIT_ID(hA), idB = (u32)HIT_ID(hB);
+            const u32 hsA = (idA * 0x9E3779B1u) >> 24, hsB = (idB * 0x9E3779B1u) >> 24;
+            s_hash[lane] = 0xFFFFFFFFu; /* (every entry a lane will read is written below, by itself if by nobody else; cleared for clarity) */
             __syncthreads();
-            if (miss) {
-                s_hid[myslot] = B;
-                s_hash[hs] = (u8)myslot;
+            if (needA) {
+                s_hid[lane] = idA;
+                s_hash[hsA] = lane;
             }
-#ifndef VC_NO_INBATCH
+            if (needB) {
+                s_hid[64u + lane] = idB;
+                s_hash[hsB] = 64u + lane;
+            }
             __syncthreads();
-#endif
-            if (miss) { /* the same read twice in the batch: the lane that registered last fetches, the others take its row */
-#ifdef VC_NO_INBATCH
-                slot = myslot;
+            slotA = lane;
+            slotB = 64u + lane;
+            if (needA) {
+                const u32 w = s_hash[hsA];
+                if (s_hid[w & 127u] == idA) slotA = w & 127u;
             }
-            if (false) {
-#endif
-                const u32 w = s_hash[hs];
-                if (w != myslot && s_hid[w] == B && (w >> 6) == buf) {
-                    miss = false;
-                    slot = w;
-                    s_hid[myslot] = 0xFFFFFFFFu; /* (nothing will be staged here) */
-                } else
-                    slot = myslot;
+            if (needB) {
+                const u32 w = s_hash[hsB];
+                if (s_hid[w & 127u] == idB) slotB = w & 127u;
             }
-            const u64 mk = __ballot(miss);
-            if (miss) {
-                const u32 r = (u32)__popcll(mk & lane_mask_lt());
-                s_lid[r] = B;
-                s_lslot[r] = (u8)myslot;
+            const bool fA = needA && slotA == lane, fB = needB && slotB == 64u + lane; /* this lane fetches */
+            const u64 mA = __ballot(fA), mB = __ballot(fB);
+            const u32 nA = (u32)__popcll(mA);
+            if (fA) {
+                const u32 r = (u32)__popcll(mA & lane_mask_lt());
+                s_lid[r] = idA;
+                s_lslot[r] = (u8)lane;
             }
-            nmiss = (u32)__popcll(mk);
+            if (fB) {
+                const u32 r = nA + (u32)__popcll(mB & lane_mask_lt());
+                s_lid[r] = idB;
+                s_lslot[r] = (u8)(64u + lane);
+            }
+            nmiss = nA + (u32)__popcll(mB);
+            if (!needA) slotA = 0u;
+            if (!needB) slotB = 0u;
             __syncthreads();
-            return need ? slot : 0u;
         };
         /* CACHE: entry 16 p + (lane >> 2) of the fetch list (clamped: lanes beyond it repeat its last row, a line on its way anyway) */
-        auto list_ptr = [&](u32 nmiss, int p, u32 &lsl) -> const ulonglong2 * {
+        auto list_ptr = [&](u32 nmiss, int p, u64 &lsl) -> const ulonglong2 * {
             u32 r = 16u * (u32)p + (lane >> 2);
             const u32 last = nmiss ? nmiss - 1u : 0u;
             r = r < last ? r : last;
-            lsl |= (u32)s_lslot[r] << (8 * p);
+            lsl |= (u64)s_lslot[r] << (8 * p);
             return (const ulonglong2 *)(a.v.reads + (u64)s_lid[r] * S) + (lane & 3u);
-        };
-        /* the rows of the fetch list: sixteen per load instruction, and only as many instructions as the list needs (wave uniform) */
-        auto load_list = [&](u32 nmiss, u32 &lsl, ulonglong2 &q0, ulonglong2 &q1, ulonglong2 &q2, ulonglong2 &q3) {
-            lsl = 0;
-            q0 = *list_ptr(nmiss, 0, lsl);
-            if (nmiss > 16u) q1 = *list_ptr(nmiss, 1, lsl);
-            if (nmiss > 32u) q2 = *list_ptr(nmiss, 2, lsl);
-            if (nmiss > 48u) q3 = *list_ptr(nmiss, 3, lsl);
         };
         u32 carry = 0; /* wave uniform: hits the segment that is open at the batch's first lane has kept so far */
         /* batch b: lane's candidate h of segment seg against the row staged in slot myrow */
@@ -1923,53 +1918,57 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             }
         }
         if (nb && CACHE) {
-            /* the same pipeline one stage deeper for the rows: the fetch list of batch b + 2 is decided and its loads are issued while
-             * batch b is compared (the decision is a chain of LDS round trips: issued a batch ahead only, the loads had one compare
-             * to come back in and verify ran no faster than without the cache). Two sets of row registers, E for even batches and O
-             * for odd ones: a set is free as soon as its batch is staged, and the loop is unrolled by two so that no set is ever copied */
-            u32 sg0, sg1, sg2, ftmp;
-            locate(0, sg0, ftmp);
-            u64 h0 = load_cand(sg0, ftmp);
-            locate(1, sg1, ftmp);
-            u64 h1 = load_cand(sg1, ftmp);
-            locate(2, sg2, ftmp);
-            u64 h2 = load_cand(sg2, ftmp);
-            ulonglong2 e0 = make_ulonglong2(0, 0), e1 = e0, e2 = e0, e3 = e0, o0 = e0, o1 = e0, o2 = e0, o3 = e0;
-            u32 nmE = 0, nmO = 0, lslE = 0, lslO = 0;
-            u32 slot0 = decide(h0, sg0, lane < C, gb & 1u, nmE);
-            gb++;
-            load_list(nmE, lslE, e0, e1, e2, e3);
-            u32 slot1 = decide(h1, sg1, 64u + lane < C, gb & 1u, nmO);
-            gb++;
-            load_list(nmO, lslO, o0, o1, o2, o3);
-            auto step = [&](const u32 b, u32 &nmQ, u32 &lslQ, ulonglong2 &q0, ulonglong2 &q1, ulonglong2 &q2, ulonglong2 &q3) {
-                __syncthreads();
-                { /* the fetched rows of batch b to their slots */
-                    const u32 r = lane >> 2;
-                    if (r < nmQ) put_quarter(lslQ & 0xFFu, q0);
-                    if (16u + r < nmQ) put_quarter((lslQ >> 8) & 0xFFu, q1);
-                    if (32u + r < nmQ) put_quarter((lslQ >> 16) & 0xFFu, q2);
-                    if (48u + r < nmQ) put_quarter(lslQ >> 24, q3);
-                }
-                const u64 h = pinned_copy(h0);
-                const u32 seg = sg0, myrow = slot0;
-                h0 = pinned_copy(h1);
-                sg0 = sg1;
-                slot0 = slot1;
-                h1 = pinned_copy(h2);
-                sg1 = sg2;
-                slot1 = decide(h1, sg1, 64u * (b + 2u) + lane < C, gb & 1u, nmQ); /* batch b + 2: its rows into the set just staged */
-                gb++;
-                load_list(nmQ, lslQ, q0, q1, q2, q3);
-                locate(b + 3, sg2, ftmp);
-                h2 = load_cand(sg2, ftmp);
-                __syncthreads();
-                compute(b, h, seg, myrow);
+            /* pairs of batches: while pair p is compared, the rows of pair p + 1 (decided at the top of the iteration, right after pair
+             * p's rows were staged and its registers became free) and the candidates of pair p + 2 are in flight */
+            const u32 npairs = (nb + 1u) >> 1;
+            u32 sg0A, sg0B, sg1A, sg1B, ftmp;
+            locate(0, sg0A, ftmp);
+            u64 h0A = load_cand(sg0A, ftmp);
+            locate(1, sg0B, ftmp);
+            u64 h0B = load_cand(sg0B, ftmp);
+            locate(2, sg1A, ftmp);
+            u64 h1A = load_cand(sg1A, ftmp);
+            locate(3, sg1B, ftmp);
+            u64 h1B = load_cand(sg1B, ftmp);
+            ulonglong2 q[8];
+#pragma unroll
+            for (int p = 0; p < 8; p++) q[p] = make_ulonglong2(0, 0);
+            u32 s0A = 0, s0B = 0, nm0 = 0;
+            u64 lsl0 = 0;
+            auto load_list = [&](u32 nmiss, u64 &lsl) { /* sixteen rows per load instruction, as many instructions as the list needs (wave uniform) */
+                lsl = 0;
+                q[0] = *list_ptr(nmiss, 0, lsl);
+#pragma unroll
+                for (int p = 1; p < 8; p++)
+                    if (nmiss > 16u * (u32)p) q[p] = *list_ptr(nmiss, p, lsl);
             };
-            for (u32 b = 0; b < nb; b += 2) {
-                step(b, nmE, lslE, e0, e1, e2, e3);
-                if (b + 1 >= nb) break;
-                step(b + 1, nmO, lslO, o0, o1, o2, o3);
+            decide_pair(h0A, sg0A, lane < C, h0B, sg0B, 64u + lane < C, s0A, s0B, nm0);
+            load_list(nm0, lsl0);
+            for (u32 pp = 0; pp < npairs; pp++) {
+                const u32 b = 2u * pp;
+                __syncthreads();
+                { /* the fetched rows of this pair to their slots */
+                    const u32 r = lane >> 2;
+#pragma unroll
+                    for (int p = 0; p < 8; p++)
+                        if (16u * (u32)p + r < nm0) put_quarter((u32)(lsl0 >> (8 * p)) & 0xFFu, q[p]);
+                }
+                const u64 hA = pinned_copy(h0A), hB = pinned_copy(h0B);
+                const u32 segA = sg0A, segB = sg0B, rowA = s0A, rowB = s0B;
+                h0A = pinned_copy(h1A);
+                h0B = pinned_copy(h1B);
+                sg0A = sg1A;
+                sg0B = sg1B;
+                __syncthreads(); /* (the staging stores are done before the next pair's slots are handed out: s_lslot / s_lid are rewritten) */
+                decide_pair(h0A, sg0A, 64u * (b + 2u) + lane < C, h0B, sg0B, 64u * (b + 3u) + lane < C, s0A, s0B, nm0);
+                load_list(nm0, lsl0);
+                locate(b + 4, sg1A, ftmp);
+                h1A = load_cand(sg1A, ftmp);
+                locate(b + 5, sg1B, ftmp);
+                h1B = load_cand(sg1B, ftmp);
+                __syncthreads();
+                compute(b, hA, segA, rowA);
+                if (b + 1u < nb) compute(b + 1u, hB, segB, rowB);
             }
         }
         __syncthreads();
