@@ -82,6 +82,8 @@ for info, ph, walls in res:
                   "device_frees_in_pass": info["device_frees"], "arena_bytes": info["arena_bytes"], "arena_peak": info["arena_peak"],
                   "hbm_peak": info["hbm_peak"], "pass_wall_ms_serialised": [round(w, 2) for w in walls]})
 i0 = res[0][0]
+kernel_table_path = os.path.join(os.path.dirname(out_path) or ".", os.path.basename(out_path).replace(".json", "_kernels.json"))
+kernel_table = json.load(open(kernel_table_path)) if os.path.exists(kernel_table_path) else {}
 assert single_cnt is None or (i0["e_pre"] == single_cnt["e_pre"] and i0["e_out"] == single_cnt["e_out"]), "the multi-rank pass must reproduce the single-GPU counters"
 sum_kernel = sum(r["kernel_ms"] for r in ranks)
 phases = sorted(single_ph) if single_ph else sorted(ranks[0]["phase_ms"])
@@ -92,14 +94,19 @@ out = {"what": f"{G} ranks on ONE MI355X over the in-process transport, compute 
                f"(BASELINE config 4's data); last of {passes} passes; index {'kept partitioned' if part else 'replicated after the partitioned build'}",
        "ranks": G, "reads": n, "regime": i0["regime"], "e_pre": i0["e_pre"], "e_out": i0["e_out"], "n_contained": i0["n_contained"],
        "single_gpu": {"pass_wall_ms": round(single_wall, 2), "kernel_ms": round(single_kernel, 3), "phase_ms": {k: round(v, 3) for k, v in single_ph.items()}},
-       "sum_kernel_ms_over_ranks": round(sum_kernel, 3), "work_inflation": round(sum_kernel / single_kernel, 3), "per_phase": per_phase,
+       # a phase timer brackets the phase on the rank's stream: the phases with an exchange inside (index: the routed records and the
+       # replicated table; contain: the keys; csr: the degrees) also hold the wait for the other ranks' serialised turns. The job's work
+       # inflation is therefore taken from the kernel table of the same pass (profiles/prof_dist.sh -> tools/dist_kernel_table.py).
+       "phases_with_exchange_waits": ["index", "contain", "csr"], "sum_phase_timers_ms_over_ranks": round(sum_kernel, 3),
+       "work_inflation": kernel_table.get("work_inflation"), "work_inflation_source": kernel_table_path if kernel_table else None,
+       "per_phase": per_phase,
        "per_rank": ranks,
        "bytes_sent_per_rank_mean": {k: int(sum(r["bytes_sent"][k] for r in ranks) / G) for k in ranks[0]["bytes_sent"]},
        "comm_ops_per_pass": max(r["comm_ops"] for r in ranks), "host_syncs_per_pass": max(r["host_syncs"] for r in ranks),
        "device_allocs_in_pass": max(r["device_allocs_in_pass"] for r in ranks), "device_frees_in_pass": max(r["device_frees_in_pass"] for r in ranks)}
 os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
 json.dump(out, open(out_path, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("work_inflation", "sum_kernel_ms_over_ranks", "comm_ops_per_pass", "host_syncs_per_pass", "device_allocs_in_pass",
+print(json.dumps({k: out[k] for k in ("work_inflation", "sum_phase_timers_ms_over_ranks", "comm_ops_per_pass", "host_syncs_per_pass", "device_allocs_in_pass",
                                        "device_frees_in_pass", "bytes_sent_per_rank_mean")}, indent=1))
 print(json.dumps(per_phase, indent=1))
 print("single", single_wall, "arena", ranks[0]["arena_bytes"], ranks[0]["arena_peak"], "hbm_peak", ranks[0]["hbm_peak"])
