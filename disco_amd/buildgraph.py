@@ -59,6 +59,7 @@ ABI = [
     ("disco_download_reads", C.c_int, [_P, _P, _P]),
     ("disco_stride_words", C.c_uint32, [_P]),
     ("disco_num_reads", C.c_uint64, [_P]),
+    ("disco_long_rows", C.c_uint64, [_P]),
     ("disco_set_query_range", C.c_int, [_P, C.c_uint64, C.c_uint64]),
     ("disco_build_index", C.c_int, [_P]),
     ("disco_probe", C.c_int, [_P]),
@@ -248,6 +249,11 @@ class BuildGraph:
     @property
     def stride_words(self) -> int:
         return int(self.L.disco_stride_words(self._h))
+
+    @property
+    def long_rows(self) -> int:
+        """reads of more than 256 bases that got rows of their own (two classes of rows, include/disco_hip.h); 0: one stride"""
+        return int(self.L.disco_long_rows(self._h))
 
     def set_query_range(self, lo: int, hi: int):
         self._chk(self.L.disco_set_query_range(self._h, lo, hi))

@@ -379,6 +379,27 @@ __device__ __forceinline__ bool seg_equal(const u64 *pa, const u64 *pb, int S, i
     return true;
 }
 
+/* seg_equal for rows of different strides (two row classes: a long read against a short one) */
+__device__ __forceinline__ bool seg_equal2(const u64 *pa, int SA, const u64 *pb, int SB, int LB, int a0, int b0, int m, u32 rev)
+{
+    for (int i = 0; i < m; i += 32) {
+        int n = m - i;
+        if (n > 32) n = 32;
+        const u64 wa = extract32<false>(pa, SA, a0 + i);
+        u64 wb;
+        if (!rev) {
+            wb = extract32<false>(pb, SB, b0 + i);
+        } else {
+            const int q = LB - b0 - i - n; /* s2[b0 + i + t] = comp(B[LB - 1 - b0 - i - t]) */
+            wb = rev2_64(~extract32<false>(pb, SB, q));
+            if (n < 32) wb <<= 2 * (32 - n);
+        }
+        const u64 mask = (n == 32) ? ~0ull : (~0ull << (64 - 2 * n));
+        if ((wa ^ wb) & mask) return false;
+    }
+    return true;
+}
+
 /* bases that differ between two packed words (2 bits per base) */
 __device__ __forceinline__ u32 base_mismatches(u64 x) { return (u32)__popcll((x | (x >> 1)) & 0x5555555555555555ull); }
 

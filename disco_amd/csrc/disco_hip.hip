@@ -172,6 +172,18 @@ struct disco_ctx {
     std::mutex h_len_mu;         /* disco_ingest_fetch may run on a host thread of its own next to a pass (the one call allowed to):
                                     it and ensure_host_len are the two writers that can meet */
     u64 q_lo = 0, q_hi = 0;
+    /* two classes of rows (disco_kernels.h, "two classes of rows"): made by two_class_convert at the first index build over a table whose
+     * stride a few long reads forced; c->S is 8 from then on and S_ext what the caller gave (disco_stride_words, disco_download_reads) */
+    bool two_class = false;
+    int S_ext = 0;
+    u64 n_long = 0;
+    u64 reads_rows = 0; /* rows d_reads was allocated with (two classes: n + n_long) */
+    u64 *d_full = nullptr;
+    u32 *d_ovf = nullptr, *d_long_ids = nullptr;
+    u32 max_len_all = 0; /* longest read of the set (max_len: of the short class) */
+    int tailb = 0;
+    u32 *d_lpos = nullptr, *d_n_list = nullptr; /* the long reads' candidate rows of the pass (class_take_rows_kernel) */
+    ulonglong2 *d_lmeta = nullptr;
 
     /* index */
     u64 T = 0;
@@ -484,6 +496,12 @@ static DiscoView view(const disco_ctx *c)
     v.q_hi = c->q_hi;
     v.ctr = c->d_ctr;
     v.wq = c->d_wq;
+    v.full = c->two_class ? c->d_full : nullptr;
+    v.ovf = c->two_class ? c->d_ovf : nullptr;
+    v.long_ids = c->two_class ? c->d_long_ids : nullptr;
+    v.n_long = c->two_class ? (u32)c->n_long : 0u;
+    v.SL = c->two_class ? c->S_ext : 0;
+    v.tailb = c->two_class ? c->tailb : 0;
     return v;
 }
 
@@ -656,9 +674,21 @@ static void free_graph_state(disco_ctx *c)
 static void free_reads(disco_ctx *c)
 {
     if (c->reads_owned) {
-        dev_free(c, &c->d_reads, c->n_alloc * (u64)c->S);
+        dev_free(c, &c->d_reads, (c->reads_rows ? c->reads_rows : c->n_alloc) * (u64)c->S);
         dev_free(c, &c->d_len, c->n_alloc);
     }
+    if (c->two_class) {
+        dev_free(c, &c->d_full, c->n_long * (u64)c->S_ext);
+        dev_free(c, &c->d_ovf, c->n_alloc);
+        dev_free(c, &c->d_long_ids, c->n_long);
+        dev_free(c, &c->d_lpos, c->n_long);
+        dev_free(c, &c->d_lmeta, c->n_long);
+        dev_free(c, &c->d_n_list, 1);
+    }
+    c->two_class = false;
+    c->n_long = c->reads_rows = 0;
+    c->S_ext = 0;
+    c->tailb = 0;
     c->d_reads = nullptr;
     c->d_len = nullptr;
     c->reads_owned = false;
@@ -691,6 +721,33 @@ struct IndexCountPlan {
     u32 oshift = 0;
 };
 
+/* 32-bit words of minimizer runs per read for a table of 64-byte rows whose longest read has max_len bases, or 0: no runs */
+static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
+{
+    int lpr = 0;
+    /* (index_runs_kernel keeps a block of NF order words in registers: one instantiation per window length — the reference's default
+     * min-overlap 30 (NF 7), 35, BASELINE's 40 (NF 17), 45, 50) */
+    const bool nf_built = nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27;
+    if (nf_built && max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
+        const u32 maxwin = max_len - (u32)c->k;
+        /* a read of W windows has about 2 W / (NF + 1) runs: 32 entries where that stays below 20 (room for the spread), else 64 */
+        const u32 expect = 2u * maxwin / (u32)(nf + 1);
+        lpr = maxwin <= 256 ? (maxwin <= 128 && expect <= 20 ? 16 : (expect <= 44 ? 32 : 0)) : 0;
+        const double max_gb = getenv("DISCO_RUNS_MAX_GB") ? atof(getenv("DISCO_RUNS_MAX_GB")) : 16.0;
+        if ((double)nloc * lpr * 4.0 > max_gb * 1e9) lpr = 0;
+    }
+    return lpr;
+}
+
+/* may a table of stride S (words) with n_long reads of more than 256 bases — the others at most short_max — go to two classes of rows? */
+static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short_max)
+{
+    if (c->comm || c->dist_reads || !c->reads_owned || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
+    if (S <= VERIFY_SW || S > PROBE_ACAP || n_long == 0 || n_long * 16 > n || n + n_long >= (1ull << 31)) return false;
+    /* the short class takes the paths of a pure short set (minimizer runs, flat verify); the long one the lists those paths keep */
+    return runs_lpr_for(c, c->k - view(c).m + 1, short_max, n) != 0;
+}
+
 static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, IndexCountPlan *pl)
 {
     const u64 nloc = hi - lo;
@@ -715,19 +772,8 @@ static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, In
     }
     c->runs_lpr = 0;
     c->runs_n = 0;
-    int lpr = 0;
     const int nf = v.k - v.m + 1;
-    /* (index_runs_kernel keeps a block of NF order words in registers: one instantiation per window length — the reference's default
-     * min-overlap 30 (NF 7), 35, BASELINE's 40 (NF 17), 45, 50) */
-    const bool nf_built = nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27;
-    if (nf_built && c->S == VERIFY_SW && c->max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
-        const u32 maxwin = c->max_len - (u32)c->k;
-        /* a read of W windows has about 2 W / (NF + 1) runs: 32 entries where that stays below 20 (room for the spread), else 64 */
-        const u32 expect = 2u * maxwin / (u32)(nf + 1);
-        lpr = maxwin <= 256 ? (maxwin <= 128 && expect <= 20 ? 16 : (expect <= 44 ? 32 : 0)) : 0;
-        const double max_gb = getenv("DISCO_RUNS_MAX_GB") ? atof(getenv("DISCO_RUNS_MAX_GB")) : 16.0;
-        if ((double)nloc * lpr * 4.0 > max_gb * 1e9) lpr = 0;
-    }
+    const int lpr = c->S == VERIFY_SW ? runs_lpr_for(c, nf, c->max_len, nloc) : 0;
     if (lpr && nloc) {
         CHK(ensure_cap(c, &c->d_runs, &c->runs_cap, nloc * (u64)lpr));
         c->runs_lpr = lpr;
@@ -1129,7 +1175,7 @@ static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride, bool *keep = n
     c->crows_pending = false;
     c->cgrp_pending = false;
     if (keep) {
-        *keep = c->reads_owned && !c->dist_reads && !c->comm && c->d_reads && c->d_len && n > 0 && c->n == n && c->n_alloc == n && c->S == (int)stride &&
+        *keep = c->reads_owned && !c->two_class && !c->dist_reads && !c->comm && c->d_reads && c->d_len && n > 0 && c->n == n && c->n_alloc == n && c->S == (int)stride &&
                 !getenv("DISCO_NO_BUFFER_REUSE");
         if (*keep) {
             c->h_len_ok = false; /* (not cleared: the next upload overwrites it in place) */
@@ -1184,24 +1230,29 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
     const uint32_t dstride = (stride_words + 7u) & ~7u;
     /* the lengths are checked where they are (the host has them): min_overlap < len <= min(32767, 32 * stride) (BG/Dataset.cpp:305,
      * BG/HashTable.cpp:531); longest / shortest decide the kernel variants of the pass */
-    std::atomic<u64> a_bad{0};
-    std::atomic<u32> a_max{0}, a_min{0xFFFFu};
+    std::atomic<u64> a_bad{0}, a_long{0};
+    std::atomic<u32> a_max{0}, a_min{0xFFFFu}, a_smax{0};
     {
         const u32 mo = c->prm.min_overlap, cap = std::min<u32>(32767u, stride_words * 32u);
         parallel_for(n, [&](u64 b0, u64 e0) {
-            u64 bad = 0;
-            u32 mx = 0, mn = 0xFFFFu;
+            u64 bad = 0, nlong = 0;
+            u32 mx = 0, mn = 0xFFFFu, smx = 0;
             for (u64 i = b0; i < e0; i++) {
                 const u32 L = len[i];
                 bad += (L <= mo || L > cap);
                 mx = std::max(mx, L);
                 mn = std::min(mn, L);
+                nlong += L > (u32)DISCO_SHORT_MAX;
+                if (L <= (u32)DISCO_SHORT_MAX) smx = std::max(smx, L);
             }
             a_bad += bad;
+            a_long += nlong;
             u32 cur = a_max.load();
             while (mx > cur && !a_max.compare_exchange_weak(cur, mx)) {}
             cur = a_min.load();
             while (mn < cur && !a_min.compare_exchange_weak(cur, mn)) {}
+            cur = a_smax.load();
+            while (smx > cur && !a_smax.compare_exchange_weak(cur, smx)) {}
         });
     }
     bool kept = false;
@@ -1230,7 +1281,8 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
         u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
         CH = std::max<u64>((CH + 255) & ~255ull, 256);
         const bool narrow = dstride != stride_words;
-        const bool eager = !c->comm && !getenv("DISCO_NO_EAGER_INDEX");
+        /* (a table that the index build will take to two classes of rows is counted there, on the rows as they will be) */
+        const bool eager = !c->comm && !getenv("DISCO_NO_EAGER_INDEX") && !two_class_ok(c, (int)dstride, n, a_long.load(), a_smax.load());
         HIPCHK(c, hipMemcpyAsync(c->d_len, len, n * 2, hipMemcpyHostToDevice, c->stream));
         if (narrow) CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, 3 * std::min<u64>(CH, n) * (u64)stride_words));
         IndexCountPlan pl;
@@ -1749,14 +1801,24 @@ int disco_download_reads(disco_ctx *c, uint64_t *packed, uint16_t *len)
 {
     if (!c || c->phase < 1) return c ? fail(c, DISCO_E_STATE, "no reads") : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (packed && c->n) HIPCHK(c, hipMemcpyAsync(packed, c->d_reads, c->n * (u64)c->S * 8, hipMemcpyDeviceToHost, c->stream));
-    if (len && c->n) HIPCHK(c, hipMemcpyAsync(len, c->d_len, c->n * 2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 *joined = nullptr;
+    if (packed && c->n && c->two_class) { /* the table as the caller knows it: one stride */
+        CHK(dev_alloc(c, &joined, c->n * (u64)c->S_ext));
+        hipLaunchKernelGGL(class_join_kernel, dim3(flat_grid(c, c->n * (u64)c->S_ext)), dim3(256), 0, c->stream, (const u64 *)c->d_reads, (const u64 *)c->d_full, c->S_ext,
+                           (const u16 *)c->d_len, (const u32 *)c->d_ovf, c->n, joined);
+        (void)hipMemcpyAsync(packed, joined, c->n * (u64)c->S_ext * 8, hipMemcpyDeviceToHost, c->stream);
+    } else if (packed && c->n)
+        HIPCHK(c, hipMemcpyAsync(packed, c->d_reads, c->n * (u64)c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    if (len && c->n) (void)hipMemcpyAsync(len, c->d_len, c->n * 2, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (joined) dev_free(c, &joined, c->n * (u64)c->S_ext);
+    if (e != hipSuccess) return fail(c, DISCO_E_HIP, "disco_download_reads: %s", hipGetErrorString(e));
     return DISCO_OK;
 }
 
-uint32_t disco_stride_words(const disco_ctx *c) { return c ? (uint32_t)c->S : 0; }
+uint32_t disco_stride_words(const disco_ctx *c) { return c ? (uint32_t)(c->two_class ? c->S_ext : c->S) : 0; }
 uint64_t disco_num_reads(const disco_ctx *c) { return c ? c->n : 0; }
+uint64_t disco_long_rows(const disco_ctx *c) { return c && c->two_class ? c->n_long : 0; }
 
 int disco_set_query_range(disco_ctx *c, uint64_t lo, uint64_t hi)
 {
@@ -1769,6 +1831,57 @@ int disco_set_query_range(disco_ctx *c, uint64_t lo, uint64_t hi)
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */
+/* one stride -> two classes of rows (disco_kernels.h), at the first index build over the table: everything that edits a table (the
+ * generator's substitutions) has been and gone by then. The decision is the device's own count of the long reads; the table that is
+ * given up goes back to the allocator. */
+static int two_class_convert(disco_ctx *c)
+{
+    if (c->two_class || !c->n || c->max_len <= (u32)DISCO_SHORT_MAX || !two_class_ok(c, c->S, c->n, 1, (u32)c->k + 1)) return DISCO_OK; /* (cheap part first) */
+    const int Sx = c->S;
+    u32 *ovf = nullptr;
+    CHK(dev_alloc(c, &ovf, c->n_alloc));
+    CHK(zero_counter(c, CTR_SHORT_MAX));
+    hipLaunchKernelGGL(class_flag_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_len, c->n, ovf, c->d_ctr);
+    u64 n_long = 0;
+    CHK((scan_exclusive<u32, u32>(c, ovf, c->n, ovf, false, &n_long)));
+    CHK(read_counters(c));
+    const u32 short_max = (u32)c->h_ctr[CTR_SHORT_MAX];
+    if (!two_class_ok(c, Sx, c->n, n_long, short_max)) {
+        dev_free(c, &ovf, c->n_alloc);
+        return DISCO_OK;
+    }
+    const int tailb = short_max <= 160 ? 160 : 256; /* what the staged compare of the short class moves per row (verify_flat_kernel<5 / 8>) */
+    u64 *rows8 = nullptr, *full = nullptr;
+    u32 *ids = nullptr;
+    CHK(dev_alloc(c, &rows8, (c->n + n_long) * 8));
+    CHK(dev_alloc(c, &full, n_long * (u64)Sx));
+    CHK(dev_alloc(c, &ids, n_long));
+    CHK(dev_alloc(c, &c->d_lpos, n_long));
+    CHK(dev_alloc(c, &c->d_lmeta, n_long));
+    CHK(dev_alloc(c, &c->d_n_list, 1));
+    hipLaunchKernelGGL(class_split_kernel, dim3(flat_grid(c, c->n * 8)), dim3(256), 0, c->stream, (const u64 *)c->d_reads, Sx, (const u16 *)c->d_len, (const u32 *)ovf, c->n, tailb, rows8,
+                       full, ids);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* (the old table goes back: nothing of it may still be in flight) */
+    dev_free(c, &c->d_reads, c->n_alloc * (u64)Sx);
+    c->d_reads = rows8;
+    c->reads_rows = c->n + n_long;
+    c->d_full = full;
+    c->d_ovf = ovf;
+    c->d_long_ids = ids;
+    c->n_long = n_long;
+    c->S_ext = Sx;
+    c->S = VERIFY_SW;
+    c->tailb = tailb;
+    c->max_len_all = c->max_len;
+    c->max_len = short_max;
+    c->two_class = true;
+    if (getenv("DISCO_VERBOSE"))
+        fprintf(stderr, "[disco] two classes of rows: %llu of %llu reads are longer than 256 bases (up to %u), the others up to %u: 64-byte rows + %d-word rows for those\n",
+                (unsigned long long)n_long, (unsigned long long)c->n, c->max_len_all, short_max, Sx);
+    return DISCO_OK;
+}
+
 int disco_build_index(disco_ctx *c)
 {
     DISCO_TRACE("disco_build_index");
@@ -1779,8 +1892,18 @@ int disco_build_index(disco_ctx *c)
     if (c->index_counted) { /* disco_upload_reads counted while it copied: the bucket counts, records, runs and keys are in place */
         c->index_counted = false;
     } else {
+        CHK(two_class_convert(c));
         CHK(index_begin(c));
-        CHK(launch_index_count<true>(c, view(c), c->d_rec, 0, c->n));
+        const DiscoView v = view(c);
+        IndexCountPlan pl;
+        CHK(index_count_plan(c, v, 0, c->n, &pl));
+        CHK(index_count_chunk<true>(c, v, pl, c->d_rec, 0, c->n));
+        if (c->two_class) { /* the long reads' records, keys and slots, from their full rows */
+            const dim3 g((unsigned)((c->n_long + 255) / 256));
+            if (c->k > 64) hipLaunchKernelGGL((index_count_kernel<true, true, true>), g, dim3(256), 0, c->stream, v, c->d_bkt, c->d_rec, c->d_okey, (u64)0, c->n_long, pl.ocnt, pl.oslot, pl.oshift);
+            else hipLaunchKernelGGL((index_count_kernel<true, false, true>), g, dim3(256), 0, c->stream, v, c->d_bkt, c->d_rec, c->d_okey, (u64)0, c->n_long, pl.ocnt, pl.oslot, pl.oshift);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt, c->T + 1, c->d_bkt, false, nullptr)));
     if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, c->d_rec, c->d_bkt, c->d_ent);
@@ -1807,7 +1930,7 @@ int disco_probe(disco_ctx *c)
     }
     if (c->n_alloc) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n_alloc)), dim3(256), 0, c->stream, c->d_best, c->n_alloc, DISCO_NOKEY);
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
-    const bool ldsrow = c->S <= PROBE_ACAP;
+    const bool ldsrow = c->S <= PROBE_ACAP; /* (two classes of rows: the long class is at most PROBE_ACAP words too, two_class_ok) */
     const bool row17 = c->k - view(c).m == 16 && !getenv("DISCO_NO_ROW17"); /* window = 17 m-mers: DPP row-scan variant */
     const bool longk = c->k > 64;                                            /* three-word k-mers: variants of their own (kmer_is_rev) */
     /* the index pass left the minimizer runs of the whole query range: probe_runs_kernel (several reads per wavefront, starts at the
@@ -1843,7 +1966,7 @@ int disco_probe(disco_ctx *c)
     };
     const u64 chunk_slots = use_runs ? PR_CHUNK : PROBE_CHUNK;
     u64 want_hits = nq * 64 + (u64)grid * chunk_slots + (1u << 16);
-    u32 want_slow = use_runs ? (u32)std::min<u64>(nq, nq / 64 + 1024) : 1u;
+    u32 want_slow = use_runs ? (u32)std::min<u64>(nq, nq / 64 + 1024 + (c->two_class ? c->n_long : 0)) : 1u;
     u32 want_big = (u32)std::min<u64>(nq, nq / 64 + 1024);
     for (int attempt = 0; attempt < 8; attempt++) {
         if (want_hits > c->hits_cap) {
@@ -1985,12 +2108,16 @@ int disco_probe(disco_ctx *c)
             /* (multi-GPU pass: every rank takes the same branch — min / max length are the job's, nq plays no part) */
             const bool inexact = c->prm.max_substitutions != 0; /* single pass: the extension is not tuned for metagenomes */
             va.max_subs = c->prm.max_substitutions;
-            const bool two_pass = !inexact && (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && c->S == VERIFY_SW && (nq || c->dist_active) &&
+            const bool two_pass = !inexact && !c->two_class && (c->prm.flags & DISCO_FLAG_TWO_PASS_VERIFY) && c->S == VERIFY_SW && (nq || c->dist_active) &&
                                   (u64)c->min_len * 10 < (u64)c->max_len * 9 && !getenv("DISCO_NO_TWO_PASS");
             c->two_pass_last = two_pass;
             /* 64-byte rows, exact overlaps: candidates of a 64-read chunk as one flat list, full wavefronts (verify_flat_kernel) */
-            const bool flat = !inexact && c->S == VERIFY_SW && !getenv("DISCO_NO_FLAT_VERIFY");
+            const bool flat = !inexact && c->S == VERIFY_SW && (c->two_class || !getenv("DISCO_NO_FLAT_VERIFY"));
             ph_begin(c, DISCO_PH_VERIFY);
+            if (c->two_class && nq) { /* the long reads' candidate rows: out of the flat pass, to verify_long_kernel behind it */
+                HIPCHK(c, hipMemsetAsync(c->d_n_list, 0, sizeof(u32), c->stream));
+                hipLaunchKernelGGL(class_take_rows_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_meta_ord, nq, c->d_lpos, c->d_lmeta, c->d_n_list, (u32)c->n_long);
+            }
             if (two_pass) {
                 if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
                 if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
@@ -2044,6 +2171,9 @@ int disco_probe(disco_ctx *c)
                 else if (c->S == 32) hipLaunchKernelGGL(verify_kernel<32>, dim3(wq_grid(c, verify_kernel<32>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else hipLaunchKernelGGL(verify_kernel<0>, dim3(wq_grid(c, verify_kernel<0>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
             }
+            if (c->two_class && nq)
+                hipLaunchKernelGGL(verify_long_kernel, dim3(wave_grid(c, c->n_long, 16)), dim3(64), 0, c->stream, va, (const u32 *)c->d_lpos, (const ulonglong2 *)c->d_lmeta,
+                                   (const u32 *)c->d_n_list);
             ph_end(c, DISCO_PH_VERIFY);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));

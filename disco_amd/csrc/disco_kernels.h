@@ -70,6 +70,7 @@ enum {
     CTR_DROPPED, /* verified hits to non-contained reads that edge selection did not turn into an edge */
     CTR_MIN_LEN, /* ~shortest read (stored complemented so that atomicMax finds the minimum from a zeroed counter) */
     CTR_DROP_ITEMS, /* dropped hits recorded in (or, beyond its capacity, lost to) the drop list of edge selection */
+    CTR_SHORT_MAX,  /* two row classes: longest read of at most 256 bases */
     CTR_COUNT
 };
 
@@ -108,7 +109,19 @@ struct DiscoView {
     u64 q_lo, q_hi;
     u64 *ctr;
     u64 *wq; /* work-queue counter of the launch (zeroed by the host) */
+    /* two row classes ("two classes of rows"; null / 0 otherwise): the table keeps its 64-byte rows although a few
+     * reads are longer than 256 bases. Row i < n of a LONG read holds its first 256 bases (all an overlap with a short read at its
+     * prefix end can touch); rows [n, n + n_long) hold the LAST tailb bases of the long reads (the suffix end: the suffix record of long
+     * read long_ids[j] carries the id n + j, so that nothing between the index and the compare has to know); the whole read lives in
+     * full[j][SL]. ovf[i] = number of long reads in front of read i (its j, if it is one). */
+    const u64 *full;
+    const u32 *ovf;
+    const u32 *long_ids;
+    u32 n_long;
+    int SL;
+    int tailb; /* 160 or 256: the bases the staged compare of the short class moves per row */
 };
+#define DISCO_SHORT_MAX 256 /* bases a 64-byte row holds */
 
 /* ================================================================================================================
  * synthetic reads straight into HBM (bench / tests) — twin of readgen.h / readgen.py
@@ -200,15 +213,21 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
 /* Reads [lo, hi) (the whole table on one GPU, the rank's own range in the multi-GPU flow); rec is indexed from lo. COUNT = false
  * (multi-GPU): no counting atomics — the records are routed to the rank that owns their bucket range first and counted there
  * (shard_count_kernel), which is what replaces the range-partitioned hashData of RMA/HashTable.cpp:95-116. */
-template <bool COUNT, bool LONGK = false>
+/* LONGCLASS (two row classes, single GPU): [lo, hi) counts the long reads; read x is long_ids[x], its row full[x][SL]; its records, key
+ * and slot go where the read's would (rec is indexed by read id); the suffix record carries the id of the read's tail row, n + x */
+template <bool COUNT, bool LONGK = false, bool LONGCLASS = false>
 __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
                                                           u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
 {
     /* rec[2i], rec[2i+1] = {bucket << 32 | slot inside the bucket, record} of the prefix / suffix k-mer of read i: the slot is
      * what the counting atomic returns, so the fill pass needs no second round of atomics */
-    const u64 i = lo + (u64)blockIdx.x * 256u + threadIdx.x;
-    if (i >= hi) return;
-    const u64 *__restrict__ p = v.reads + i * v.S;
+    const u64 x = lo + (u64)blockIdx.x * 256u + threadIdx.x;
+    if (x >= hi) return;
+    const u64 i = LONGCLASS ? (u64)v.long_ids[x] : x;
+    if (LONGCLASS) lo = 0;
+    const int S = LONGCLASS ? v.SL : v.S;
+    const u64 *__restrict__ p = LONGCLASS ? v.full + x * (u64)S : v.reads + i * (u64)S;
+    if (!LONGCLASS && v.full && v.len[i] > DISCO_SHORT_MAX) return; /* (a long read's turn comes with the LONGCLASS launch) */
     const int L = v.len[i], k = v.k, m = v.m, nf = k - m + 1;
     const int nmm = L - m + 1; /* m-mer positions (L >= k: validate_len_kernel) */
     const int sfx0 = nmm - nf; /* = L - k: first m-mer of the suffix k-mer */
@@ -258,11 +277,11 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
         if (ffirst == flast)
             rev = k1 & 1u;
         else {
-            rev = kmer_is_rev<false, LONGK>(p, v.S, j0, k);
+            rev = kmer_is_rev<false, LONGK>(p, S, j0, k);
             fsel = rev ? flast : ffirst;
         }
         t = rev ? (u32)(nf - 1 - fsel) : (u32)fsel;
-        return mmer_key(p, v.S, j0 + fsel, m);
+        return mmer_key(p, S, j0 + fsel, m);
     };
     u32 tp, rp, ts, rs;
     const u64 kp = resolve(k1p, k2p, 0, tp, rp);
@@ -271,7 +290,7 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
     const u32 sp = COUNT ? atomicAdd(&bkt[bp], 1u) : 0u;
     const u32 ss = COUNT ? atomicAdd(&bkt[bs], 1u) : 0u;
     rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
-    rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
+    rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, LONGCLASS ? v.n + x : i, ts, rs, 1, L));
 }
 
 /* ----------------------------------------------------------------------------------------------------------------
@@ -309,7 +328,10 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
     for (u32 x = tid; x < 256u * CAP / 2u; x += 256u) ((u32 *)s_runs)[x] = 0xFFFFFFFFu;
     __syncthreads();
     const u64 i = lo + (u64)blockIdx.x * 256u + tid;
-    if (i < hi) {
+    /* two row classes: a long read is index_count_kernel's (from its full row); here it only tells the probe to take it the long way */
+    const bool other_class = i < hi && v.full && v.len[i] > DISCO_SHORT_MAX;
+    if (other_class) s_runs[tid * CAP] = 0xFFFEu;
+    if (i < hi && !other_class) {
         const u64 *__restrict__ p = v.reads + i * v.S;
         const int L = v.len[i], k = v.k, m = v.m;
         const int nmm = L - m + 1; /* m-mer positions */
@@ -620,6 +642,15 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
         const u64 opos = LISTED ? (bl >> 32) : it;
         const u64 *ga = a.v.reads + A * S;
         int LA;
+        /* two row classes: a long read (only ever met here: the lists) is walked in its full row; its suffix record carries the id of its tail row */
+        int Sx = S;
+        u64 A2 = A;
+        if (LISTED && LDSROW && a.v.full && (int)a.v.len[A] > DISCO_SHORT_MAX) { /* (LDSROW: the long class has at most PROBE_ACAP words, two_class_ok) */
+            const u32 x = a.v.ovf[A];
+            Sx = a.v.SL;
+            ga = a.v.full + (u64)x * Sx;
+            A2 = a.v.n + x;
+        }
         __syncthreads();
         if (!LISTED && LDSROW) {
             LA = pre_len;
@@ -633,7 +664,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
             }
         } else {
             LA = LISTED ? (int)a.v.len[A] : ORDER_LEN(oe);
-            if (LDSROW && (int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < S) ? ga[lane] : 0ull;
+            if (LDSROW && (int)lane < PROBE_ACAP + 2) s_a[lane] = ((int)lane < Sx) ? ga[lane] : 0ull;
         }
         const int npos = LA - k; /* windows j in [0, npos) : BG/OverlapGraph.cpp:401 (containment), :638 (edges, j >= 1) */
         const u64 *pa = LDSROW ? (const u64 *)s_a : ga;
@@ -697,7 +728,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
                 if (p1 == p2)
                     rev_w = s_strand[p1];
                 else { /* the smallest hash occurs more than once in the window */
-                    rev_w = kmer_is_rev<LDSROW, LONGK>(pa, S, w0 + w, k);
+                    rev_w = kmer_is_rev<LDSROW, LONGK>(pa, Sx, w0 + w, k);
                     prel = rev_w ? p2 : p1;
                 }
                 s_wp[w] = (u16)(prel | (rev_w << 15));
@@ -715,7 +746,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
                     const int q = (int)lane + 64 * r;
                     h[r] = 0xFFFFFFFFu;
                     if (q < np) { /* np <= 144; the third pass is empty for reads up to 150 bp */
-                        const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
+                        const u32 o = mmer_order<LDSROW>(pa, Sx, w0 + q, m);
                         s_first[q] = 0xFFFFFFFFu;
                         s_strand[q] = (u8)(o & 1u);
                         h[r] = o & ~0x1FFu;
@@ -754,7 +785,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
                 /* 1. order hashes of the segment's m-mers; seeds of the two range-minimum tables: key1 = hash | position
                  *    (smallest hash, then LEFTMOST position), key2 = hash | 511 - position (then RIGHTMOST position) */
                 for (int q = (int)lane; q < np; q += 64) {
-                    const u32 o = mmer_order<LDSROW>(pa, S, w0 + q, m);
+                    const u32 o = mmer_order<LDSROW>(pa, Sx, w0 + q, m);
                     s_first[q] = 0xFFFFFFFFu;
                     s_strand[q] = (u8)(o & 1u);
                     s_k1[q] = (o & ~0x1FFu) | (u32)q;
@@ -807,7 +838,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
                 u32 s = 0, cnt = 0;
                 if (li < nlead) {
                     const u32 prel = s_wp[s_lead[li]] & 0x7FFFu;
-                    const u64 key = mmer_key<LDSROW>(pa, S, w0 + (int)prel, m);
+                    const u64 key = mmer_key<LDSROW>(pa, Sx, w0 + (int)prel, m);
                     const u64 b = key >> a.v.bshift;
                     s = a.v.bkt[b];
                     cnt = a.v.bkt[b + 1] - s;
@@ -861,7 +892,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
                         }
                         pay = a.v.ent[s_occ_start[lo] + (idx - s_occ_excl[lo])];
                         oprel = (int)s_occ_prel[lo];
-                        match = (PAY_FP(pay) == s_occ_fp[lo]) && (PAY_ID(pay) != A); /* self excluded: BG/OverlapGraph.cpp:421,655 */
+                        match = (PAY_FP(pay) == s_occ_fp[lo]) && (PAY_ID(pay) != A) && (PAY_ID(pay) != A2); /* self excluded: BG/OverlapGraph.cpp:421,655 */
                     }
                     /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k-m-t before */
                     const int t = (int)PAY_T(pay);
@@ -1815,7 +1846,9 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             /* a reversed candidate is compared as revcomp(A) against B itself (coordinates y = LA-1-x):
              * T[X] == B[X - dd] for X in [X0, X1), T = A or revcomp(A) */
             const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
-            const int dd = rev ? LA - LB - d : d;
+            int dd = rev ? LA - LB - d : d;
+            /* two row classes: the suffix record of a long read names its tail row, B[LB - tailb, LB) (a.v.tailb = 0 otherwise) */
+            if (a.v.tailb && LB > DISCO_SHORT_MAX && suf) dd += LB - a.v.tailb;
             const int W0 = X0 >> 4, nl = ((X1 - 1) >> 4) - W0; /* first dword of the region in T, index of its last one */
             const int bitpos = 2 * (16 * W0 - dd);             /* >= -30: B's bit under the first bit of T's dword W0 */
             const int i0 = (bitpos - 1) >> 5;
@@ -1877,7 +1910,11 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
                 const int lo_lane = (int)Pseg - (int)(64u * b); /* the segment's first lane in this batch; < 0: it began earlier */
                 const u32 below_seg = (u32)__shfl((int)below, lo_lane > 0 ? lo_lane : 0);
                 const u32 rank = (lo_lane < 0 ? carry : 0u) + below - below_seg;
-                if (ov) a.hits[hd.x + rank] = h;
+                if (ov) {
+                    u64 hw = h;
+                    if (a.v.tailb && B >= (u32)a.v.n) hw = (h & ~(0x7FFFFFFFull << 17)) | ((u64)a.v.long_ids[B - (u32)a.v.n] << 17); /* (a tail row: back to the read's id) */
+                    a.hits[hd.x + rank] = hw;
+                }
                 const u32 kept = rank + (ov ? 1u : 0u);
                 const bool last = valid && (64u * b + lane - Pseg == cseg - 1u); /* the segment ends on this lane */
                 if (last) {
@@ -1979,6 +2016,151 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
         my_khits += __shfl_down(my_khits, o);
         my_raw += __shfl_down(my_raw, o);
     }
+    if (lane == 0) {
+        if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
+        if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
+    }
+}
+
+/* ================================================================================================================
+ * two classes of rows (DiscoView: full / ovf / long_ids / tailb). The reference has no stride: a read is as long as it is
+ * (BG/HashTable.cpp:456-477 packs every read at its own length). A table with one stride pays for its longest read in every row —
+ * 0.1 % reads of 600 bases made every row 192 bytes and took the staged kernels away from the other 99.9 %. So: reads of more than
+ * 256 bases ("long", at most one in sixteen and at most 1024 bases; otherwise the table keeps one stride) leave the 64-byte table
+ * except for their two ENDS, which is all that a short read can overlap them with: the head stays in the read's own row, the tail
+ * becomes row n + j, and the suffix record of the index names that row. The short class then runs the kernels of a pure short set
+ * unchanged (a tail row is a row like any other until a verified hit is written down: its id becomes the read's again). The long
+ * reads themselves — as query reads — take the wave-per-read paths that exist for rare rows anyway (the index's generic count pass, the
+ * probe's list pass, verify_long_kernel below, edge selection's sequential rows), over their full rows.
+ * ============================================================================================================== */
+/* ovf[i] = 1 for a long read (the host scans it in place); the longest read of the short class */
+__global__ void class_flag_kernel(const u16 *__restrict__ len, u64 n, u32 *__restrict__ ovf, u64 *ctr)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 mx = 0;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 L = len[i];
+        ovf[i] = L > (u32)DISCO_SHORT_MAX ? 1u : 0u;
+        if (L <= (u32)DISCO_SHORT_MAX) mx = max(mx, L);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (u32)__shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctr[CTR_SHORT_MAX], (u64)mx);
+}
+
+/* one stride -> two classes: rows8 [n + n_long][8], full [n_long][S] (S = the stride of the table that is given up) */
+__global__ void class_split_kernel(const u64 *__restrict__ old, int S, const u16 *__restrict__ len, const u32 *__restrict__ ovf, u64 n, int tailb,
+                                   u64 *__restrict__ rows8, u64 *__restrict__ full, u32 *__restrict__ long_ids)
+{
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; gid < n * 8; gid += (u64)gridDim.x * blockDim.x) {
+        const u64 i = gid >> 3;
+        const int w = (int)(gid & 7);
+        const u64 *row = old + i * (u64)S;
+        rows8[gid] = row[w];
+        const int L = len[i];
+        if (L > DISCO_SHORT_MAX) {
+            const u64 j = ovf[i];
+            rows8[(n + j) * 8 + w] = 32 * w < tailb ? extract32<false>(row, S, L - tailb + 32 * w) : 0ull;
+            for (int x = w; x < S; x += 8) full[j * (u64)S + x] = row[x];
+            if (w == 0) long_ids[j] = (u32)i;
+        }
+    }
+}
+
+/* and back (disco_download_reads): out [n][S] */
+__global__ void class_join_kernel(const u64 *__restrict__ rows8, const u64 *__restrict__ full, int S, const u16 *__restrict__ len, const u32 *__restrict__ ovf, u64 n,
+                                  u64 *__restrict__ out)
+{
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; gid < n * (u64)S; gid += (u64)gridDim.x * blockDim.x) {
+        const u64 i = gid / (u64)S;
+        const int x = (int)(gid % (u64)S);
+        out[gid] = len[i] > DISCO_SHORT_MAX ? full[(u64)ovf[i] * S + x] : (x < 8 ? rows8[i * 8 + x] : 0ull);
+    }
+}
+
+/* the candidate rows of the long reads leave the flat pass: their headers {row start, candidates | length << 32} move to a list (with
+ * their position in the order) and the pass finds rows of no candidates there */
+__global__ void class_take_rows_kernel(ulonglong2 *__restrict__ meta_ord, u64 nq, u32 *__restrict__ lpos, ulonglong2 *__restrict__ lmeta, u32 *n_list, u32 cap)
+{
+    u64 ci = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; ci < nq; ci += (u64)gridDim.x * blockDim.x) {
+        const ulonglong2 m = meta_ord[ci];
+        if ((u32)(m.y >> 32) > (u32)DISCO_SHORT_MAX && (u32)m.y != 0u) {
+            const u32 at = atomicAdd(n_list, 1u);
+            if (at < cap) { /* (cap = the number of long reads: never short) */
+                lpos[at] = (u32)ci;
+                lmeta[at] = m;
+            }
+            meta_ord[ci].y = m.y & 0xFFFFFFFF00000000ull;
+        }
+    }
+}
+
+/* verify for the rows class_take_rows_kernel set aside: one wavefront per long read, lane = candidate, both reads compared where
+ * they lie (the long one in full[], a short candidate in its 64-byte row) — verify_kernel<0>'s compare with a stride per side.
+ * Candidate ids of tail rows become read ids first; the row is compacted in place as everywhere. */
+__global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32 *__restrict__ lpos, const ulonglong2 *__restrict__ lmeta, const u32 *__restrict__ n_list)
+{
+    const u32 lane = threadIdx.x;
+    const int k = a.v.k;
+    u64 my_khits = 0, my_raw = 0;
+    const u32 nl = *n_list;
+    for (u32 it = blockIdx.x; it < nl; it += gridDim.x) {
+        const u32 ci = lpos[it];
+        const ulonglong2 meta = lmeta[it];
+        const u64 A = ORDER_ID(a.order ? a.order[ci] : a.v.q_lo + ci);
+        const int LA = (int)(meta.y >> 32);
+        const u32 c = (u32)meta.y;
+        const int SA = a.v.SL;
+        const u64 *ga = a.v.full + (u64)a.v.ovf[A] * SA;
+        u64 *row = a.hits + meta.x;
+        u32 nkeep = 0;
+        for (u32 i0 = 0; i0 < c; i0 += 64) {
+            const bool act = i0 + lane < c;
+            u64 h = act ? row[i0 + lane] : 0ull;
+            bool ov = false;
+            if (act) {
+                const int j = (int)HIT_J(h), LB = (int)HIT_LEN(h);
+                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+                u64 B = HIT_ID(h);
+                if (B >= a.v.n) {
+                    B = a.v.long_ids[B - a.v.n];
+                    h = (h & ~(0x7FFFFFFFull << 17)) | (B << 17);
+                }
+                const bool blong = LB > DISCO_SHORT_MAX;
+                const int SB = blong ? a.v.SL : a.v.S;
+                const u64 *gb = blong ? a.v.full + (u64)a.v.ovf[B] * SB : a.v.reads + B * SB;
+                const bool prefix_align = (suf == rev);
+                const int d = prefix_align ? j : j + k - LB;
+                const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
+                bool contain, overlap;
+                if (prefix_align) {
+                    contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
+                    overlap = !contain && j >= 1; /* :579 */
+                } else {
+                    contain = d >= 0;           /* :547 */
+                    overlap = d <= 0 && j >= 1; /* :591 */
+                }
+                if (seg_equal2(ga, SA, gb, SB, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
+                    my_khits++;
+                    if (seg_equal2(ga, SA, gb, SB, LB, x0, x0 - d, x1 - x0, rev)) {
+                        if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                        ov = overlap;
+                    }
+                }
+            }
+            const u64 mk = __ballot(ov);
+            if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+            nkeep += __popcll(mk);
+        }
+        if (lane == 0) {
+            if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
+            my_raw += nkeep;
+            a.meta_ord[ci].y = (u64)nkeep | ((u64)LA << 32);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {
         if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
         if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
@@ -2607,7 +2789,7 @@ __global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_fl
         const bool mine = lane < n && !((cw >> (A & 31)) & 1u); /* BG/OverlapGraph.cpp:657 : both reads must be non-contained */
         const u32 craw = mine ? (u32)meta.y : 0u;
         const u32 LAme = (u32)(meta.y >> 32);
-        const bool longrow = craw > 64u;
+        const bool longrow = craw > 64u || (craw != 0u && LAme > (u32)DISCO_SHORT_MAX); /* (a read of the long class: offsets beyond the bins) */
         const u32 c = longrow ? 0u : craw;
         const u32 incl = wave_inclusive_add(c);
         const u32 P = incl - c;

@@ -1,0 +1,97 @@
+"""-m gpu : two classes of rows (include/disco_hip.h, disco_long_rows) — read sets with a few reads of more than 256 bases keep 64-byte
+rows for the others; results are the oracle's, bit for bit, and those of the one-stride table."""
+import numpy as np
+import pytest
+
+from disco_amd import buildgraph
+from tests.util import assert_parity, canon_hip, run_hip_reads
+
+pytestmark = pytest.mark.gpu
+_COMP = str.maketrans("ACGT", "TGCA")
+
+
+def mixed_reads(seed, n, smin, smax, cov, long_share, lmin, lmax, genome_len=None):
+    """n reads drawn from one random genome, both strands: lengths uniform in [smin, smax] except a share of long ones in [lmin, lmax]"""
+    rng = np.random.default_rng(seed)
+    mean = (1 - long_share) * (smin + smax) / 2 + long_share * (lmin + lmax) / 2
+    G = genome_len or max(int(n * mean / cov), lmax + 1)
+    genome = "".join(rng.choice(list("ACGT"), G))
+    reads = []
+    for _ in range(n):
+        L = int(rng.integers(lmin, lmax + 1)) if rng.random() < long_share else int(rng.integers(smin, smax + 1))
+        p = int(rng.integers(0, G - L + 1))
+        s = genome[p:p + L]
+        reads.append(s.translate(_COMP)[::-1] if rng.random() < 0.5 else s)
+    return reads
+
+
+def _run(reads, minovl):
+    with buildgraph.BuildGraph(min_overlap=minovl) as g:
+        g.upload_ascii(reads)
+        g.run_graph()
+        return g.fetch_edges(), g.fetch_contained(), g.counters(), g.long_rows
+
+
+@pytest.mark.parametrize("seed,n,smin,smax,cov,share,lmin,lmax,minovl", [
+    (1, 6000, 150, 150, 30.0, 0.03, 300, 600, 40),    # the shape the layout is for: 150 bp with a tail of long reads
+    (2, 6000, 100, 250, 30.0, 0.05, 257, 1000, 40),   # mixed short class (256-base compare), long reads up to the widest class
+    (3, 5000, 150, 150, 100.0, 0.02, 400, 800, 40),   # 100x: wide rows on both sides
+    (4, 5000, 120, 160, 30.0, 0.06, 257, 300, 30),    # the reference's default min-overlap; long reads barely long
+    (5, 4000, 150, 250, 40.0, 0.04, 500, 1024, 50),   # windows of 27
+    (6, 4000, 150, 150, 30.0, 0.001, 600, 600, 40),   # a handful of long reads
+])
+def test_mixed_sets_equal_the_oracle(seed, n, smin, smax, cov, share, lmin, lmax, minovl):
+    reads = mixed_reads(seed, n, smin, smax, cov, share, lmin, lmax)
+    n_long = sum(len(r) > 256 for r in reads)
+    assert n_long > 0
+    c = assert_parity(reads, minovl, f"two-class seed{seed}")
+    assert c["e_out"] > 0
+    he, hr, hc, lr = _run(reads, minovl)
+    assert lr == n_long, "the set was expected to take two classes of rows"
+
+
+def test_long_reads_that_contain_and_duplicate_each_other():
+    reads = mixed_reads(11, 3000, 150, 150, 30.0, 0.05, 300, 700)
+    longs = [r for r in reads if len(r) > 256]
+    extra = longs[:20] + [r.translate(_COMP)[::-1] for r in longs[20:40]] + [r[5:-7] for r in longs[40:60]] + [r[:200] for r in longs[60:80]] + [r[-230:] for r in longs[80:100]]
+    assert_parity(reads + extra, 40, "two-class dups")
+
+
+def test_one_stride_and_two_classes_agree(monkeypatch):
+    reads = mixed_reads(12, 5000, 150, 150, 30.0, 0.03, 300, 600)
+    e2, r2, c2, lr2 = _run(reads, 40)
+    monkeypatch.setenv("DISCO_NO_TWO_CLASS", "1")
+    e1, r1, c1, lr1 = _run(reads, 40)
+    assert lr2 > 0 and lr1 == 0
+    a, b = canon_hip(e1, r1), canon_hip(e2, r2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for key in ("probes", "kmer_hits", "n_contained", "e_pre", "e_out"):
+        assert c1[key] == c2[key], key
+
+
+def test_the_table_comes_back_as_it_was_handed_over():
+    reads = mixed_reads(13, 3000, 150, 150, 30.0, 0.03, 300, 600)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.upload_ascii(reads)
+        p0, l0 = g.download_reads()
+        s0 = g.stride_words
+        g.run_graph()
+        assert g.long_rows > 0 and g.stride_words == s0
+        p1, l1 = g.download_reads()
+        assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
+        # a second pass over the re-laid table, and a new set of another shape afterwards
+        e1 = g.fetch_edges()
+        g.run_graph()
+        assert np.array_equal(e1, g.fetch_edges())
+        g.upload_ascii(reads[:1000])
+        g.run_graph()
+
+
+def test_sets_that_keep_one_stride():
+    # too many long reads, and a window length without minimizer runs: the one-stride paths, same results
+    for reads, mo in ((mixed_reads(14, 3000, 150, 150, 30.0, 0.2, 300, 600), 40), (mixed_reads(15, 3000, 150, 150, 30.0, 0.03, 300, 600), 80)):
+        with buildgraph.BuildGraph(min_overlap=mo) as g:
+            g.upload_ascii(reads)
+            g.run_graph()
+            assert g.long_rows == 0
+        assert_parity(reads, mo, "one stride kept")
