@@ -228,7 +228,7 @@ class BuildGraph:
         self._chk(self.L.disco_adopt_reads(self._h, _P(d_packed_ptr), stride_words, _P(d_len_ptr), n))
 
     def generate_reads(self, spec):
-        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
+        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(spec.skew_word if hasattr(spec, "skew_word") else getattr(spec, "skew", 0)))
         self._chk(self.L.disco_generate_reads(self._h, C.byref(s)))
 
     def substitute_bases(self, seed: int, rate_ppm: int):
@@ -489,7 +489,7 @@ class BuildGraph:
         self.dist_upload_reads(packed, lens, n, stride)
 
     def dist_generate_reads(self, spec):
-        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(getattr(spec, "skew", 0)))
+        s = GenSpecABI(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, int(spec.skew_word if hasattr(spec, "skew_word") else getattr(spec, "skew", 0)))
         self._chk(self.L.disco_dist_generate_reads(self._h, C.byref(s)))
 
     def ingest_fasta(self, paths, threads: int = 16):

@@ -1765,10 +1765,13 @@ int disco_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
 {
     DISCO_TRACE("disco_generate_reads");
     if (!c || !s) return c ? fail(c, DISCO_E_ARG, "disco_generate_reads: null argument") : DISCO_E_ARG;
-    if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
+    disco_genspec gs;
+    memcpy(&gs, s, sizeof gs);
+    const uint32_t longest = std::max<uint32_t>(s->len_max, DISCO_GEN_LONG_SHARE(&gs) ? DISCO_GEN_LONG_LEN(&gs) : 0u);
+    if (s->len_min == 0 || s->len_max < s->len_min || longest > 32767 || s->n_contigs == 0 || s->contig_len < longest)
         return fail(c, DISCO_E_ARG, "disco_generate_reads: bad spec");
     HIPCHK(c, hipSetDevice(c->device));
-    uint32_t stride = (((s->len_max + 31) / 32) + 7u) & ~7u; /* 64-B aligned rows */
+    uint32_t stride = (((longest + 31) / 32) + 7u) & ~7u; /* 64-B aligned rows */
     bool kept = false;
     CHK(set_reads_common(c, s->n_reads, stride, &kept));
     if (!kept) {
@@ -4560,13 +4563,14 @@ int disco_dist_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
 {
     DISCO_TRACE("disco_dist_generate_reads");
     if (!c || !s) return c ? fail(c, DISCO_E_ARG, "disco_dist_generate_reads: null argument") : DISCO_E_ARG;
-    if (s->len_min == 0 || s->len_max < s->len_min || s->len_max > 32767 || s->n_contigs == 0 || s->contig_len < s->len_max)
-        return fail(c, DISCO_E_ARG, "disco_dist_generate_reads: bad spec");
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t stride = (((s->len_max + 31) / 32) + 7u) & ~7u;
-    CHK(dist_set_reads(c, s->n_reads, stride));
     disco_genspec g;
     memcpy(&g, s, sizeof g);
+    const uint32_t longest = std::max<uint32_t>(s->len_max, DISCO_GEN_LONG_SHARE(&g) ? DISCO_GEN_LONG_LEN(&g) : 0u);
+    if (s->len_min == 0 || s->len_max < s->len_min || longest > 32767 || s->n_contigs == 0 || s->contig_len < longest)
+        return fail(c, DISCO_E_ARG, "disco_dist_generate_reads: bad spec");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t stride = (((longest + 31) / 32) + 7u) & ~7u;
+    CHK(dist_set_reads(c, s->n_reads, stride));
     const u64 nloc = c->q_hi - c->q_lo;
     if (nloc) hipLaunchKernelGGL(generate_reads_kernel, dim3(flat_grid(c, nloc * stride)), dim3(256), 0, c->stream, g, c->d_reads, c->d_len, (int)stride, c->q_lo, c->q_hi);
     HIPCHK(c, hipGetLastError());

@@ -37,8 +37,14 @@ typedef struct disco_genspec {
     uint32_t n_contigs;   /* number of contigs                                   */
     uint32_t len_min;     /* shortest read                                       */
     uint32_t len_max;     /* longest read (== len_min for fixed length)          */
-    uint32_t skew;        /* 0: contigs equally abundant; 1: "metagenome-like" abundances (see disco_read_location)  */
+    uint32_t skew;        /* bit 0: "metagenome-like" contig abundances (see disco_read_location); 0: contigs equally abundant.
+                             bits 1-15 / 16-31: a tail of LONG reads — their length, and their share of the reads in 1 / 65536
+                             (DISCO_GEN_LONG_*): which reads are long is a pure function of (seed, read) like everything else */
 } disco_genspec;
+#define DISCO_GEN_SKEWED(s) ((s)->skew & 1u)
+#define DISCO_GEN_LONG_LEN(s) (((s)->skew >> 1) & 0x7FFFu)
+#define DISCO_GEN_LONG_SHARE(s) ((s)->skew >> 16)
+#define DISCO_GEN_SKEW_WORD(skewed, long_len, long_share) (((skewed) ? 1u : 0u) | ((uint32_t)(long_len) << 1) | ((uint32_t)(long_share) << 16))
 
 DISCO_HD uint64_t disco_mix64(uint64_t x)
 {
@@ -73,8 +79,9 @@ DISCO_HD disco_readloc disco_read_location(const disco_genspec *s, uint64_t r)
     uint64_t h2 = disco_mix64(sr + 4 * r + 2);
     disco_readloc loc;
     loc.len = s->len_min + (uint32_t)(h2 % (uint64_t)(s->len_max - s->len_min + 1));
+    if (DISCO_GEN_LONG_SHARE(s) && (uint32_t)(disco_mix64(h2 ^ 0x6C6F6E6772656164ull) & 0xFFFFu) < DISCO_GEN_LONG_SHARE(s)) loc.len = DISCO_GEN_LONG_LEN(s);
     uint64_t contig = (h0 & 0x7FFFFFFFFFFFFFFFull) % s->n_contigs;
-    if (s->skew) contig = (contig * (disco_mix64(sr + 4 * r + 3) % s->n_contigs)) / s->n_contigs;
+    if (DISCO_GEN_SKEWED(s)) contig = (contig * (disco_mix64(sr + 4 * r + 3) % s->n_contigs)) / s->n_contigs;
     uint64_t pos = h1 % (s->contig_len - loc.len + 1);
     loc.gpos = contig * s->contig_len + pos;
     loc.strand = (uint32_t)(h0 >> 63);

@@ -48,15 +48,28 @@ class GenSpec:
     len_min: int = 150
     len_max: int = 150
     skew: int = 0  # 1: metagenome-like contig abundances (product of two uniform draws, see csrc/readgen.h)
+    long_len: int = 0  # a tail of long reads: their length ...
+    long_share: int = 0  # ... and their share of the reads in 1 / 65536 (which reads: a pure function of seed and read)
+
+    @property
+    def skew_word(self) -> int:
+        """the ABI's `skew` field (csrc/readgen.h: DISCO_GEN_SKEW_WORD)"""
+        return (1 if self.skew else 0) | (int(self.long_len) << 1) | (int(self.long_share) << 16)
+
+    @property
+    def longest(self) -> int:
+        return max(self.len_max, self.long_len if self.long_share else 0)
 
     @staticmethod
     def coverage(seed: int, n_reads: int, read_len: int = 150, cov: float = 30.0, n_contigs: int = 1,
-                 len_max: int | None = None, skew: int = 0) -> "GenSpec":
+                 len_max: int | None = None, skew: int = 0, long_len: int = 0, long_share: int = 0) -> "GenSpec":
         """uniform-random genome sized for the given (mean) coverage (skew=1: config 5)."""
         len_max = read_len if len_max is None else len_max
-        mean = (read_len + len_max) / 2.0
-        total = max(int(n_reads * mean / cov), n_contigs * (len_max + 1))
-        return GenSpec(seed, n_reads, max(total // n_contigs, len_max + 1), n_contigs, read_len, len_max, skew)
+        f = long_share / 65536.0
+        mean = (1 - f) * (read_len + len_max) / 2.0 + f * long_len
+        longest = max(len_max, long_len if long_share else 0)
+        total = max(int(n_reads * mean / cov), n_contigs * (longest + 1))
+        return GenSpec(seed, n_reads, max(total // n_contigs, longest + 1), n_contigs, read_len, len_max, skew, long_len if long_share else 0, long_share)
 
 
 def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None, ids=None):
@@ -69,6 +82,9 @@ def read_locations(spec: GenSpec, r0: int = 0, r1: int | None = None, ids=None):
         h1 = mix64(sr + np.uint64(4) * r + np.uint64(1))
         h2 = mix64(sr + np.uint64(4) * r + np.uint64(2))
         length = (np.uint64(spec.len_min) + h2 % np.uint64(spec.len_max - spec.len_min + 1)).astype(np.uint64)
+        if getattr(spec, "long_share", 0):
+            is_long = (mix64(h2 ^ np.uint64(0x6C6F6E6772656164)) & np.uint64(0xFFFF)) < np.uint64(spec.long_share)
+            length = np.where(is_long, np.uint64(spec.long_len), length).astype(np.uint64)
         contig = (h0 & np.uint64(0x7FFFFFFFFFFFFFFF)) % np.uint64(spec.n_contigs)
         if spec.skew:
             h3 = mix64(sr + np.uint64(4) * r + np.uint64(3))

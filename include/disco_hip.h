@@ -63,7 +63,8 @@ typedef struct disco_params {
 /* synthetic reads, see disco_amd/csrc/readgen.h (replaces bbmap/randomreads.sh for the BASELINE configs) */
 typedef struct disco_genspec_abi {
     uint64_t seed, n_reads, contig_len;
-    uint32_t n_contigs, len_min, len_max, skew; /* skew 1: metagenome-like contig abundances */
+    uint32_t n_contigs, len_min, len_max, skew; /* skew bit 0: metagenome-like contig abundances; bits 1-15 / 16-31: length of a tail of
+                                                   long reads and their share of the reads in 1 / 65536 (csrc/readgen.h) */
 } disco_genspec_abi;
 
 /* one row of <prefix>_<t>_containedReads.txt (BG/OverlapGraph.cpp:438-447) in read ids */

@@ -56,6 +56,8 @@ GEN_CASES = [
     # round 4: k above 64 (the reference's k-mers are strings: no limit there, BG/HashTable.cpp:396-416)
     ("k79_4k", dict(seed=21, n_reads=4000, read_len=250, cov=30.0, len_max=500), 80, True),
     ("k94_4k", dict(seed=22, n_reads=4000, read_len=250, cov=30.0, len_max=500), 95, True),
+    # round 4: 150 bp reads with a tail of 600 bp reads (1 %): the set the two classes of rows are for (include/disco_hip.h, disco_long_rows)
+    ("tail_20k", dict(seed=23, n_reads=20000, read_len=150, cov=30.0, long_len=600, long_share=650), 40, False),
 ]
 
 

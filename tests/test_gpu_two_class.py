@@ -95,3 +95,37 @@ def test_sets_that_keep_one_stride():
             g.run_graph()
             assert g.long_rows == 0
         assert_parity(reads, mo, "one stride kept")
+
+
+def test_generated_long_tail_on_the_device():
+    """the generator's tail of long reads (csrc/readgen.h, DISCO_GEN_LONG_*): device rows = numpy twin, two classes taken, oracle parity"""
+    from disco_amd import readgen
+    from tests.util import run_oracle_reads
+
+    spec = readgen.GenSpec.coverage(seed=77, n_reads=8000, read_len=150, cov=30.0, long_len=600, long_share=1300)
+    reads = readgen.generate_reads(spec)
+    n_long = sum(len(r) == 600 for r in reads)
+    assert 80 < n_long < 320
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.generate_reads(spec)
+        g.run_graph()
+        assert g.long_rows == n_long
+        he, hr, hc = g.fetch_edges(), g.fetch_contained(), g.counters()
+    oe, orows, oc = run_oracle_reads(reads, 40)
+    a, b = canon_hip(he, hr), canon_hip(oe, orows)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for key in ("probes", "kmer_hits", "n_contained", "e_pre", "e_out"):
+        assert hc[key] == oc[key], key
+
+
+def test_the_real_reference_s_fixture_with_a_tail_of_long_reads():
+    """tests/golden/cases.json: tail_20k — 20 000 reads, 1 % of them 600 bp, outputs of the REAL reference (make_golden.py)"""
+    from tests import golden_util as gu
+
+    reads, fidx, mo = gu.case_inputs("tail_20k")
+    with buildgraph.BuildGraph(min_overlap=mo) as g:
+        g.upload_ascii(reads)
+        g.run_graph()
+        assert g.long_rows == sum(len(r) > 256 for r in reads) > 100
+        ce, cc = canon_hip(g.fetch_edges(), g.fetch_contained(), fidx)
+    gu.check_against_golden("tail_20k", ce, cc)

@@ -32,7 +32,8 @@ class Spec(ctypes.Structure):
 
 @pytest.mark.parametrize("kw", [dict(seed=42, n_reads=700, read_len=150, cov=30.0),
                                 dict(seed=3, n_reads=500, read_len=100, cov=10.0, len_max=250, n_contigs=3),
-                                dict(seed=9, n_reads=900, read_len=100, cov=10.0, len_max=250, n_contigs=7, skew=1)])
+                                dict(seed=9, n_reads=900, read_len=100, cov=10.0, len_max=250, n_contigs=7, skew=1),
+                                dict(seed=10, n_reads=2000, read_len=150, cov=20.0, n_contigs=2, long_len=600, long_share=2000)])
 def test_numpy_twin_equals_c_twin(tmp_path, kw):
     src = tmp_path / "g.c"
     src.write_text(C_SRC)
@@ -41,12 +42,15 @@ def test_numpy_twin_equals_c_twin(tmp_path, kw):
     L = ctypes.CDLL(so)
     spec = readgen.GenSpec.coverage(**kw)
     codes, off = readgen.generate_codes(spec)
-    s = Spec(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, spec.skew)
+    s = Spec(spec.seed, spec.n_reads, spec.contig_len, spec.n_contigs, spec.len_min, spec.len_max, spec.skew_word)
     c2 = np.zeros(len(codes), dtype=np.uint8)
     o2 = np.zeros(len(off), dtype=np.uint64)
     L.gen_codes(ctypes.byref(s), ctypes.c_ulonglong(0), ctypes.c_ulonglong(spec.n_reads), c2.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p))
     assert np.array_equal(off, o2) and np.array_equal(codes, c2)
-    assert codes.max() <= 3 and len(set(np.diff(off).tolist())) >= (1 if spec.len_min == spec.len_max else 2)
+    assert codes.max() <= 3 and len(set(np.diff(off).tolist())) >= (1 if spec.len_min == spec.len_max and not spec.long_share else 2)
+    if spec.long_share:
+        n_long = int((np.diff(off) == spec.long_len).sum())
+        assert 0.5 * spec.n_reads * spec.long_share / 65536 < n_long < 2 * spec.n_reads * spec.long_share / 65536
 
 
 @pytest.mark.gpu
