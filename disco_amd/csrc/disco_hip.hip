@@ -1206,6 +1206,15 @@ static int set_reads_common(disco_ctx *c, u64 n, uint32_t stride, bool *keep = n
     return DISCO_OK;
 }
 
+/* the copy stream starts behind whatever the context's stream still holds (a pass the caller did not wait for may be reading the
+ * table, or the memory the copies are about to fill) */
+static int copy_stream_after_stream(disco_ctx *c)
+{
+    HIPCHK(c, hipEventRecord(c->ev_unpacked[0], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_unpacked[0], 0));
+    return DISCO_OK;
+}
+
 static int validate_reads(disco_ctx *c)
 {
     CHK(zero_counter(c, CTR_BAD_LEN));
@@ -1278,6 +1287,7 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
                 HIPCHK(c, hipEventCreateWithFlags(&c->ev_unpacked[i], hipEventDisableTiming));
             }
         }
+        CHK(copy_stream_after_stream(c));
         u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
         CH = std::max<u64>((CH + 255) & ~255ull, 256);
         const bool narrow = dstride != stride_words;
@@ -1404,6 +1414,7 @@ static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned th
         }
     }
     threads = std::max(1u, std::min(threads, 32u));
+    CHK(copy_stream_after_stream(c));
     u64 k = 0;
     for (u64 off = 0; off < n; off += HALF, k++) {
         const size_t len = (size_t)std::min<u64>(HALF, n - off);

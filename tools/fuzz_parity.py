@@ -14,7 +14,8 @@ from tests.util import assert_parity
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 inexact = len(sys.argv) > 3 and sys.argv[3] == "inexact"
-runs = len(sys.argv) > 3 and sys.argv[3] == "runs"
+tail = len(sys.argv) > 3 and sys.argv[3] == "tail"  # "runs" shapes with a tail of long reads (257..1024 bases, 0.1-6 %): the two classes of rows
+runs = len(sys.argv) > 3 and sys.argv[3] == "runs" or tail
 fails = 0
 t0 = time.time()
 for it in range(iters):
@@ -44,8 +45,12 @@ for it in range(iters):
     seed = int(rng.integers(1, 1 << 30))
     label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} err={err} tsub={tsub}"
     try:
-        spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
+        long_len = int(rng.choice([257, 300, 400, 600, 1000, 1024])) if tail else 0
+        long_share = int(rng.choice([66, 300, 1300, 3900])) if tail else 0
+        spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew, long_len=long_len, long_share=long_share)
         reads = list(readgen.generate_reads(spec))
+        if tail:
+            label += f" long={long_len} share={long_share}/65536"
         if err:
             r2 = np.random.default_rng(seed)
             out = []
@@ -68,6 +73,8 @@ for it in range(iters):
             reads = []
             for _ in range(n):
                 L = int(r3.integers(lmin, lmax + 1))
+                if tail and r3.random() < long_share / 65536:
+                    L = long_len
                 if L >= len(genome):
                     continue
                 p0 = int(r3.integers(0, len(genome) - L))
