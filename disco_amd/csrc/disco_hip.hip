@@ -743,7 +743,7 @@ static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
 static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short_max)
 {
     if (c->comm || c->dist_reads || !c->reads_owned || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
-    if (S <= VERIFY_SW || S > PROBE_ACAP || n_long == 0 || n_long * 16 > n || n + n_long >= (1ull << 31)) return false;
+    if (S <= VERIFY_SW || n_long == 0 || n_long * 16 > n || n + n_long >= (1ull << 31)) return false;
     /* the short class takes the paths of a pure short set (minimizer runs, flat verify); the long one the lists those paths keep */
     return runs_lpr_for(c, c->k - view(c).m + 1, short_max, n) != 0;
 }
@@ -1944,7 +1944,7 @@ int disco_probe(disco_ctx *c)
     }
     if (c->n_alloc) hipLaunchKernelGGL(fill_u64_kernel, dim3(flat_grid(c, c->n_alloc)), dim3(256), 0, c->stream, c->d_best, c->n_alloc, DISCO_NOKEY);
     HIPCHK(c, hipMemsetAsync(c->d_row_cnt, 0, std::max<u64>(c->n, 1) * sizeof(u32), c->stream));
-    const bool ldsrow = c->S <= PROBE_ACAP; /* (two classes of rows: the long class is at most PROBE_ACAP words too, two_class_ok) */
+    const bool ldsrow = c->S <= PROBE_ACAP; /* (two classes of rows: c->S = 8; the lists' kernels take the long class's stride into account: launch_probe) */
     const bool row17 = c->k - view(c).m == 16 && !getenv("DISCO_NO_ROW17"); /* window = 17 m-mers: DPP row-scan variant */
     const bool longk = c->k > 64;                                            /* three-word k-mers: variants of their own (kmer_is_rev) */
     /* the index pass left the minimizer runs of the whole query range: probe_runs_kernel (several reads per wavefront, starts at the
@@ -1964,7 +1964,17 @@ int disco_probe(disco_ctx *c)
         else if (ldsrow) { if (row17) DISCO_PROBE_LAUNCH(B, true, true); else DISCO_PROBE_LAUNCH(B, true, false); }   \
         else { if (row17) DISCO_PROBE_LAUNCH(B, false, true); else DISCO_PROBE_LAUNCH(B, false, false); }        \
     } while (0)
-        if (mode == 0 && use_runs) {
+        if (mode != 0 && c->two_class && c->S_ext > PROBE_ACAP) { /* the long class does not fit the LDS row: the lists' reads from global memory */
+#define DISCO_PROBE_LAUNCH_CLASS(B)                                                                                                            \
+    do {                                                                                                                                        \
+        if (longk) hipLaunchKernelGGL((probe_kernel<B, false, false, true, true>), dim3(g), dim3(64), 0, c->stream, a);                        \
+        else if (row17) hipLaunchKernelGGL((probe_kernel<B, false, true, false, true>), dim3(g), dim3(64), 0, c->stream, a);                   \
+        else hipLaunchKernelGGL((probe_kernel<B, false, false, false, true>), dim3(g), dim3(64), 0, c->stream, a);                             \
+    } while (0)
+            if (mode == 1) DISCO_PROBE_LAUNCH_CLASS(1);
+            else DISCO_PROBE_LAUNCH_CLASS(2);
+#undef DISCO_PROBE_LAUNCH_CLASS
+        } else if (mode == 0 && use_runs) {
             if (c->runs_lpr == 16) hipLaunchKernelGGL(probe_runs_kernel<16>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
             else hipLaunchKernelGGL(probe_runs_kernel<32>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
         } else if (mode == 0) DISCO_PROBE_MODE(0);

@@ -592,9 +592,12 @@ struct ProbeArgs {
 /* PMODE 0: the query range in processing order; 1 (BIG): the reads of big_list, whose rows did not fit their chunk, with rows of
  * exactly the size the first pass counted; 2 (LIST): the reads of slow_list (probe_runs_kernel could not use their run lists), rows in
  * chunks as in mode 0 */
-template <int PMODE, bool LDSROW, bool ROW17, bool LONGK = false>
-__global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD)) probe_kernel(ProbeArgs a)
+/* LONGCLASS (lists only, two classes of rows): long reads of more than PROBE_ACAP words — walked in global memory (LDSROW = false), and so
+ * are the short reads that share the list with them */
+template <int PMODE, bool LDSROW, bool ROW17, bool LONGK = false, bool LONGCLASS = false>
+__global__ void __launch_bounds__(64, (LONGK || LONGCLASS) ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 ? PROBE_WAVES_PER_SIMD - 1 : PROBE_WAVES_PER_SIMD)) probe_kernel(ProbeArgs a)
 {
+    static_assert(!LONGCLASS || (PMODE != 0 && !LDSROW), "the long class is only ever met in the lists");
     constexpr bool BIG = PMODE == 1, LISTED = PMODE != 0;
     /* LDSROW: the query read's own row is staged in LDS (S <= PROBE_ACAP, decided by the host), so that every base
      * extract is a broadcast LDS read with a statically known address space instead of a global/flat load */
@@ -645,7 +648,7 @@ __global__ void __launch_bounds__(64, LONGK ? PROBE_WAVES_PER_SIMD - 2 : (ROW17 
         /* two row classes: a long read (only ever met here: the lists) is walked in its full row; its suffix record carries the id of its tail row */
         int Sx = S;
         u64 A2 = A;
-        if (LISTED && LDSROW && a.v.full && (int)a.v.len[A] > DISCO_SHORT_MAX) { /* (LDSROW: the long class has at most PROBE_ACAP words, two_class_ok) */
+        if (LISTED && (LDSROW || LONGCLASS) && a.v.full && (int)a.v.len[A] > DISCO_SHORT_MAX) { /* (the host picks LDSROW when the long class has at most PROBE_ACAP words) */
             const u32 x = a.v.ovf[A];
             Sx = a.v.SL;
             ga = a.v.full + (u64)x * Sx;
@@ -2026,7 +2029,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
  * two classes of rows (DiscoView: full / ovf / long_ids / tailb). The reference has no stride: a read is as long as it is
  * (BG/HashTable.cpp:456-477 packs every read at its own length). A table with one stride pays for its longest read in every row —
  * 0.1 % reads of 600 bases made every row 192 bytes and took the staged kernels away from the other 99.9 %. So: reads of more than
- * 256 bases ("long", at most one in sixteen and at most 1024 bases; otherwise the table keeps one stride) leave the 64-byte table
+ * 256 bases ("long", at most one in sixteen; otherwise the table keeps one stride) leave the 64-byte table
  * except for their two ENDS, which is all that a short read can overlap them with: the head stays in the read's own row, the tail
  * becomes row n + j, and the suffix record of the index names that row. The short class then runs the kernels of a pure short set
  * unchanged (a tail row is a row like any other until a verified hit is written down: its id becomes the read's again). The long

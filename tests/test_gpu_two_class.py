@@ -39,6 +39,8 @@ def _run(reads, minovl):
     (4, 5000, 120, 160, 30.0, 0.06, 257, 300, 30),    # the reference's default min-overlap; long reads barely long
     (5, 4000, 150, 250, 40.0, 0.04, 500, 1024, 50),   # windows of 27
     (6, 4000, 150, 150, 30.0, 0.001, 600, 600, 40),   # a handful of long reads
+    (7, 4000, 150, 150, 30.0, 0.01, 1500, 5000, 40),  # long reads beyond the probe's LDS row (> 1024 bases): the lists walk global memory
+    (8, 3000, 100, 250, 30.0, 0.003, 20000, 30000, 45),  # a few reads near the format's limit of 32767 bases
 ])
 def test_mixed_sets_equal_the_oracle(seed, n, smin, smax, cov, share, lmin, lmax, minovl):
     reads = mixed_reads(seed, n, smin, smax, cov, share, lmin, lmax)
