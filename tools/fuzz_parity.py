@@ -45,7 +45,7 @@ for it in range(iters):
     seed = int(rng.integers(1, 1 << 30))
     label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} err={err} tsub={tsub}"
     try:
-        long_len = int(rng.choice([257, 300, 400, 600, 1000, 1024])) if tail else 0
+        long_len = int(rng.choice([257, 300, 400, 600, 1000, 1024, 1025, 2000, 8000])) if tail else 0
         long_share = int(rng.choice([66, 300, 1300, 3900])) if tail else 0
         spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew, long_len=long_len, long_share=long_share)
         reads = list(readgen.generate_reads(spec))
