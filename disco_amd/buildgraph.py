@@ -60,6 +60,7 @@ ABI = [
     ("disco_stride_words", C.c_uint32, [_P]),
     ("disco_num_reads", C.c_uint64, [_P]),
     ("disco_long_rows", C.c_uint64, [_P]),
+    ("disco_upload_reads_ragged", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("disco_set_query_range", C.c_int, [_P, C.c_uint64, C.c_uint64]),
     ("disco_build_index", C.c_int, [_P]),
     ("disco_probe", C.c_int, [_P]),
@@ -212,10 +213,26 @@ class BuildGraph:
         self._keep = (packed, lens)
         self._chk(self.L.disco_upload_reads(self._h, packed.ctypes.data, packed.shape[1], lens.ctypes.data, packed.shape[0]))
 
-    def upload_ascii(self, reads):
-        """pack upper-case ACGT strings on the host (disco_pack_ascii) and upload them"""
+    def upload_reads_ragged(self, words: np.ndarray, lens: np.ndarray):
+        """reads back to back: read i = the ceil(lens[i] / 32) words behind those of read i - 1 (disco_upload_reads_ragged)"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        assert words.ndim == 1 and len(words) == int(((lens.astype(np.int64) + 31) // 32).sum())
+        self._chk(self.L.disco_upload_reads_ragged(self._h, words.ctypes.data, lens.ctypes.data, len(lens)))
+
+    def upload_ascii(self, reads, ragged: bool = False):
+        """pack upper-case ACGT strings on the host (disco_pack_ascii) and upload them (ragged: back to back, no stride)"""
         n = len(reads)
         lens = np.fromiter((len(r) for r in reads), dtype=np.uint16, count=n)
+        if ragged:
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum((lens.astype(np.int64) + 31) // 32, out=off[1:])
+            words = np.zeros(max(int(off[-1]), 1), dtype=np.uint64)
+            for i, r in enumerate(reads):
+                b = r.encode()
+                if self.L.disco_pack_ascii(b, len(b), words[off[i]:].ctypes.data) != 0:
+                    raise DiscoError(f"read {i} contains a non-ACGT base")
+            return self.upload_reads_ragged(words[:int(off[-1])], lens)
         stride = int((int(lens.max()) + 31) // 32) if n else 1
         packed = np.zeros((n, stride), dtype=np.uint64)
         for i, r in enumerate(reads):

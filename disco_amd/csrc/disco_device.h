@@ -303,11 +303,12 @@ __device__ __forceinline__ u64 readlane_u64(u64 x, u32 l)
     return ((u64)hi << 32) | lo;
 }
 
+template <bool WIDE = true>
 __device__ __forceinline__ u32 order_hash32(u64 c)
 {
     /* (canonical m-mers of up to 23 bases have 46 bits: the third product is zero for them — the order of rounds 1-3; m up to 31,
-     * which k above 86 needs, brings 62) */
-    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24) & 0xFFFFFFu, 0x85EBCBu) + __umul24((u32)(c >> 48), 0xC2B2AEu) + 0x7F4A7C15u;
+     * which k above 86 needs, brings 62. WIDE = false: the caller knows that m <= 23 and saves the product) */
+    u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24) & 0xFFFFFFu, 0x85EBCBu) + (WIDE ? __umul24((u32)(c >> 48), 0xC2B2AEu) : 0u) + 0x7F4A7C15u;
     h ^= h >> 15;
     return h * 0x2C1B3C6Du;
 }
@@ -339,6 +340,7 @@ __host__ __device__ __forceinline__ int disco_minimizer_len(int k)
     return m < 1 ? 1 : m;
 }
 #define DISCO_MAX_K 94
+#define DISCO_SHORT_MAX 256 /* bases a 64-byte row holds (two classes of rows: longer reads are the long class) */
 
 /* THE WINDOW-MINIMIZER RULE ("window_minimizer's rule" elsewhere). For the k-mer window at base j with the order words
  * h(0..nf-1) of its m-mers (forward offsets), the window's CANONICAL ORIENTATION and the chosen occurrence are defined

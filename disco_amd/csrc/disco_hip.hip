@@ -748,6 +748,8 @@ static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short
     return runs_lpr_for(c, c->k - view(c).m + 1, short_max, n) != 0;
 }
 
+static int two_class_alloc(disco_ctx *c, u64 n_long, int Sx, u32 short_max);
+
 static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, IndexCountPlan *pl)
 {
     const u64 nloc = hi - lo;
@@ -1230,29 +1232,39 @@ static int validate_reads(disco_ctx *c)
     return DISCO_OK;
 }
 
-int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n)
+/* disco_upload_reads (stride_words > 0: one stride on the host) and disco_upload_reads_ragged (stride_words = 0: the reads back to back,
+ * ceil(len / 32) words each — the form the reference itself keeps them in, BG/HashTable.cpp:456-477) */
+static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n)
 {
-    DISCO_TRACE("disco_upload_reads");
-    if (!c || (n && (!packed || !len))) return c ? fail(c, DISCO_E_ARG, "disco_upload_reads: null argument") : DISCO_E_ARG;
+    if (!c || (n && (!packed || !len))) return c ? fail(c, DISCO_E_ARG, "%s: null argument", who) : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
-    const uint32_t dstride = (stride_words + 7u) & ~7u;
+    const bool ragged = stride_words == 0;
+    u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
+    CH = std::max<u64>((CH + 255) & ~255ull, 256);
+    const u64 n_chunks = (n + CH - 1) / CH;
     /* the lengths are checked where they are (the host has them): min_overlap < len <= min(32767, 32 * stride) (BG/Dataset.cpp:305,
-     * BG/HashTable.cpp:531); longest / shortest decide the kernel variants of the pass */
+     * BG/HashTable.cpp:531); longest / shortest decide the kernel variants of the pass, the long reads the layout; ragged: the words of
+     * every chunk of CH reads */
     std::atomic<u64> a_bad{0}, a_long{0};
     std::atomic<u32> a_max{0}, a_min{0xFFFFu}, a_smax{0};
+    std::vector<u64> chunk_words(n_chunks + 1, 0);
     {
-        const u32 mo = c->prm.min_overlap, cap = std::min<u32>(32767u, stride_words * 32u);
-        parallel_for(n, [&](u64 b0, u64 e0) {
+        const u32 mo = c->prm.min_overlap, cap = ragged ? 32767u : std::min<u32>(32767u, stride_words * 32u);
+        parallel_for(n_chunks, [&](u64 k0, u64 k1) {
             u64 bad = 0, nlong = 0;
             u32 mx = 0, mn = 0xFFFFu, smx = 0;
-            for (u64 i = b0; i < e0; i++) {
-                const u32 L = len[i];
-                bad += (L <= mo || L > cap);
-                mx = std::max(mx, L);
-                mn = std::min(mn, L);
-                nlong += L > (u32)DISCO_SHORT_MAX;
-                if (L <= (u32)DISCO_SHORT_MAX) smx = std::max(smx, L);
+            for (u64 k = k0; k < k1; k++) {
+                u64 words = 0;
+                for (u64 i = k * CH; i < std::min<u64>(n, (k + 1) * CH); i++) {
+                    const u32 L = len[i];
+                    bad += (L <= mo || L > cap);
+                    mx = std::max(mx, L);
+                    mn = std::min(mn, L);
+                    nlong += L > (u32)DISCO_SHORT_MAX;
+                    if (L <= (u32)DISCO_SHORT_MAX) smx = std::max(smx, L);
+                    words += (L + 31u) >> 5;
+                }
+                chunk_words[k + 1] = words;
             }
             a_bad += bad;
             a_long += nlong;
@@ -1263,17 +1275,34 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
             cur = a_smax.load();
             while (smx > cur && !a_smax.compare_exchange_weak(cur, smx)) {}
         });
+        for (u64 k = 0; k < n_chunks; k++) chunk_words[k + 1] += chunk_words[k];
     }
+    if (ragged) stride_words = std::max<u32>(1, (a_max.load() + 31) / 32);
+    /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
+    const uint32_t dstride = (stride_words + 7u) & ~7u;
+    if (a_bad.load()) {
+        bool kept0 = false; /* (the context is left with no reads, as before) */
+        (void)set_reads_common(c, 0, dstride, &kept0);
+        return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)a_bad.load(), c->prm.min_overlap);
+    }
+    /* a few long reads among short ones: the chunks are unpacked per class (two classes of rows, disco_kernels.h) — the table of one
+     * stride is never made on the device */
+    c->reads_owned = true;
+    const u64 n_long = a_long.load();
+    const bool classes = n && two_class_ok(c, (int)dstride, n, n_long, a_smax.load());
     bool kept = false;
-    CHK(set_reads_common(c, n, dstride, &kept));
-    if (!kept) {
+    CHK(set_reads_common(c, n, classes ? (uint32_t)VERIFY_SW : dstride, classes ? nullptr : &kept));
+    if (classes) {
+        CHK(dev_alloc(c, &c->d_reads, (n + n_long) * 8));
+        CHK(dev_alloc(c, &c->d_len, n));
+        CHK(two_class_alloc(c, n_long, (int)dstride, a_smax.load()));
+    } else if (!kept) {
         CHK(dev_alloc(c, &c->d_reads, n * (u64)dstride));
         CHK(dev_alloc(c, &c->d_len, n));
     }
     c->reads_owned = true;
-    if (a_bad.load())
-        return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)a_bad.load(), c->prm.min_overlap);
-    c->max_len = n ? a_max.load() : 0;
+    c->max_len = n ? (classes ? a_smax.load() : a_max.load()) : 0;
+    c->max_len_all = n ? a_max.load() : 0;
     c->min_len = n ? a_min.load() : 0;
     if (n) {
         /* The copy runs in chunks on a stream of its own; behind it, chunk by chunk on the context's stream: rows spread to the 64-byte
@@ -1288,13 +1317,27 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
             }
         }
         CHK(copy_stream_after_stream(c));
-        u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
-        CH = std::max<u64>((CH + 255) & ~255ull, 256);
-        const bool narrow = dstride != stride_words;
-        /* (a table that the index build will take to two classes of rows is counted there, on the rows as they will be) */
-        const bool eager = !c->comm && !getenv("DISCO_NO_EAGER_INDEX") && !two_class_ok(c, (int)dstride, n, a_long.load(), a_smax.load());
+        const bool direct = !ragged && !classes && dstride == stride_words; /* the host rows ARE the table's rows: copied where they belong */
+        /* (two classes: the index is counted by disco_build_index, over the classes) */
+        const bool eager = !c->comm && !classes && !getenv("DISCO_NO_EAGER_INDEX");
         HIPCHK(c, hipMemcpyAsync(c->d_len, len, n * 2, hipMemcpyHostToDevice, c->stream));
-        if (narrow) CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, 3 * std::min<u64>(CH, n) * (u64)stride_words));
+        u64 ring_words = 0; /* words of the largest chunk as it lies on the host */
+        for (u64 k = 0; k < n_chunks; k++)
+            ring_words = std::max<u64>(ring_words, ragged ? chunk_words[k + 1] - chunk_words[k] : (std::min<u64>(n, (k + 1) * CH) - k * CH) * (u64)stride_words);
+        if (!direct) CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, 3 * ring_words));
+        u64 *woff = nullptr;
+        u32 *nw = nullptr;
+        if (ragged) { /* word offset of every read: scan of ceil(len / 32) */
+            CHK(dev_alloc(c, &woff, n));
+            CHK(dev_alloc(c, &nw, n));
+            hipLaunchKernelGGL(words_per_read_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, (const u16 *)c->d_len, n, nw);
+            CHK((scan_exclusive<u32, u64>(c, nw, n, woff, false, nullptr)));
+        }
+        if (classes) { /* the long reads' numbers */
+            hipLaunchKernelGGL(class_flag_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, (const u16 *)c->d_len, n, c->d_ovf, c->d_ctr);
+            CHK((scan_exclusive<u32, u32>(c, c->d_ovf, n, c->d_ovf, false, nullptr)));
+            hipLaunchKernelGGL(class_ids_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, (const u16 *)c->d_len, (const u32 *)c->d_ovf, n, c->d_long_ids);
+        }
         IndexCountPlan pl;
         DiscoView v;
         if (eager) {
@@ -1302,18 +1345,21 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
             v = view(c);
             CHK(index_count_plan(c, v, 0, n, &pl));
         }
-        u64 k = 0;
-        for (u64 lo = 0; lo < n; lo += CH, k++) {
-            const u64 hi = std::min<u64>(n, lo + CH);
+        for (u64 k = 0; k < n_chunks; k++) {
+            const u64 lo = k * CH, hi = std::min<u64>(n, lo + CH);
             const int b = (int)(k % 3);
-            if (narrow) {
-                u64 *ring = c->d_dense + (u64)b * std::min<u64>(CH, n) * stride_words;
+            if (!direct) {
+                u64 *ring = c->d_dense + (u64)b * ring_words;
+                const u64 w0 = ragged ? chunk_words[k] : lo * (u64)stride_words, w1 = ragged ? chunk_words[k + 1] : hi * (u64)stride_words;
                 if (k >= 3) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_unpacked[b], 0));
-                HIPCHK(c, hipMemcpyAsync(ring, packed + lo * stride_words, (hi - lo) * (u64)stride_words * 8, hipMemcpyHostToDevice, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(ring, packed + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, c->copy_stream));
                 HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
-                hipLaunchKernelGGL(unpack_pad_kernel, dim3(flat_grid(c, (hi - lo) * (u64)dstride)), dim3(256), 0, c->stream, ring, (int)dstride, (int)stride_words, hi - lo,
-                                   c->d_reads + lo * dstride);
+                hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, (hi - lo) * (u64)c->S)), dim3(256), 0, c->stream, (const u64 *)ring, ragged ? 0 : (int)stride_words, (const u64 *)woff, w0,
+                                   (const u16 *)c->d_len, lo, hi, c->S, classes ? (u32)DISCO_SHORT_MAX : 0xFFFFu, c->d_reads);
+                if (classes)
+                    hipLaunchKernelGGL(unpack_long_rows_kernel, dim3(flat_grid(c, n_long * ((u64)dstride + 8))), dim3(256), 0, c->stream, (const u64 *)ring, ragged ? 0 : (int)stride_words,
+                                       (const u64 *)woff, w0, (const u16 *)c->d_len, lo, hi, (const u32 *)c->d_long_ids, n_long, n, (int)dstride, c->tailb, c->d_full, c->d_reads);
                 HIPCHK(c, hipEventRecord(c->ev_unpacked[b], c->stream));
             } else { /* (one 1-D copy per chunk: a 2-D copy whose width equals both pitches ran at a third of the rate) */
                 HIPCHK(c, hipMemcpyAsync(c->d_reads + lo * dstride, packed + lo * dstride, (hi - lo) * (u64)dstride * 8, hipMemcpyHostToDevice, c->copy_stream));
@@ -1329,11 +1375,29 @@ int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_wor
         parallel_for(n, [&, hl](u64 b0, u64 e0) { memcpy(hl + b0, len + b0, (e0 - b0) * 2); });
         c->h_len_ok = true;
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        if (woff) { /* (read by the unpack kernels on the context's stream) */
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dev_free(c, &woff, n);
+            dev_free(c, &nw, n);
+        }
         c->index_counted = eager;
     } else
         c->h_len.clear();
     c->phase = 1;
     return DISCO_OK;
+}
+
+int disco_upload_reads(disco_ctx *c, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n)
+{
+    DISCO_TRACE("disco_upload_reads");
+    if (c && stride_words == 0) return fail(c, DISCO_E_ARG, "stride_words 0 out of range");
+    return upload_reads_impl(c, "disco_upload_reads", packed, stride_words, len, n);
+}
+
+int disco_upload_reads_ragged(disco_ctx *c, const uint64_t *words, const uint16_t *len, uint64_t n)
+{
+    DISCO_TRACE("disco_upload_reads_ragged");
+    return upload_reads_impl(c, "disco_upload_reads_ragged", words, 0, len, n);
 }
 
 /* ================================================================================================================
@@ -1571,7 +1635,8 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         return rc;
     }
     u64 total_records = 0, n_good = 0, too_long = 0;
-    u32 longest = 0, shortest = 0xFFFFu;
+    u32 longest = 0, shortest = 0xFFFFu, short_max = 0;
+    u64 n_long_reads = 0;
     float read_s = 0;
     /* ---- pass A: every file into HBM, record starts, clean + filter ------------------------------------------------------------ */
     for (int fi = 0; fi < n_files; fi++) {
@@ -1631,6 +1696,8 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             if (f.good) {
                 longest = std::max(longest, (u32)h[FX_CTR_MAX_LEN]);
                 shortest = std::min(shortest, 0xFFFFu - (u32)h[FX_CTR_MIN_LEN_INV]);
+                n_long_reads += h[FX_CTR_N_LONG];
+                short_max = std::max(short_max, (u32)h[FX_CTR_SHORT_MAX]);
             }
             return DISCO_OK;
         };
@@ -1656,11 +1723,19 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         c->d_hits = nullptr;
         c->hits_cap = 0;
         bool kept = false;
-        const int src = set_reads_common(c, n_good, dstride, &kept);
+        /* a few long reads among short ones: the rows are packed per class straight from the text (two classes of rows, disco_kernels.h) —
+         * the table of one stride, n rows as wide as the longest read, is never made */
+        c->reads_owned = true;
+        const bool classes = two_class_ok(c, (int)dstride, n_good, n_long_reads, short_max);
+        const int src = set_reads_common(c, n_good, classes ? (uint32_t)VERIFY_SW : dstride, classes ? nullptr : &kept);
         c->d_hits = keep_hits;
         c->hits_cap = keep_cap;
         CHK(src);
-        if (!kept) {
+        if (classes) {
+            CHK(dev_alloc(c, &c->d_reads, (n_good + n_long_reads) * 8));
+            CHK(dev_alloc(c, &c->d_len, n_good));
+            CHK(two_class_alloc(c, n_long_reads, (int)dstride, short_max));
+        } else if (!kept) {
             CHK(dev_alloc(c, &c->d_reads, n_good * (u64)dstride));
             CHK(dev_alloc(c, &c->d_len, n_good));
         }
@@ -1685,14 +1760,29 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             if (good != f.good) return fail(c, DISCO_E_STATE, "disco_ingest_fasta: %llu good reads counted, %llu placed", (unsigned long long)f.good, (unsigned long long)good);
             hipLaunchKernelGGL(fx_ids_kernel, dim3(flat_grid(c, f.n_rec)), dim3(256), 0, c->stream, (const u16 *)f.d_glen, (const u64 *)d_pos, f.n_rec, id_base, c->d_rec_of_read, c->d_len);
             if (f.good)
-                hipLaunchKernelGGL(fx_pack_kernel, dim3(flat_grid(c, f.good * (u64)dstride)), dim3(256), 0, c->stream, (const u8 *)f.d_text, (const u64 *)f.d_seq, (const u32 *)f.d_wrap, (const u32 *)c->d_rec_of_read,
-                                   (const u16 *)c->d_len, id_base, f.good, (int)dstride, c->d_reads);
+                hipLaunchKernelGGL(fx_pack_kernel, dim3(flat_grid(c, f.good * (u64)c->S)), dim3(256), 0, c->stream, (const u8 *)f.d_text, (const u64 *)f.d_seq, (const u32 *)f.d_wrap, (const u32 *)c->d_rec_of_read,
+                                   (const u16 *)c->d_len, id_base, f.good, c->S, classes ? (u32)DISCO_SHORT_MAX : 0xFFFFu, c->d_reads);
             HIPCHK(c, hipGetLastError());
             id_base += f.good;
             rec_base += f.n_rec;
         }
         c->ingest_id_base[(size_t)n_files] = id_base;
         c->ingest_rec_base[(size_t)n_files] = rec_base;
+        if (classes) { /* every read has its id and length: number the long ones, then their full and tail rows, file by file */
+            hipLaunchKernelGGL(class_flag_kernel, dim3(flat_grid(c, n_good)), dim3(256), 0, c->stream, (const u16 *)c->d_len, n_good, c->d_ovf, c->d_ctr);
+            u64 counted = 0;
+            CHK((scan_exclusive<u32, u32>(c, c->d_ovf, n_good, c->d_ovf, false, &counted)));
+            if (counted != n_long_reads) return fail(c, DISCO_E_STATE, "disco_ingest_fasta: %llu long reads counted, %llu placed", (unsigned long long)n_long_reads, (unsigned long long)counted);
+            hipLaunchKernelGGL(class_ids_kernel, dim3(flat_grid(c, n_good)), dim3(256), 0, c->stream, (const u16 *)c->d_len, (const u32 *)c->d_ovf, n_good, c->d_long_ids);
+            for (int fi = 0; fi < n_files; fi++) {
+                IngestFile &f = F[(size_t)fi];
+                if (!f.good) continue;
+                hipLaunchKernelGGL(fx_pack_long_kernel, dim3(flat_grid(c, n_long_reads * ((u64)dstride + 8))), dim3(256), 0, c->stream, (const u8 *)f.d_text, (const u64 *)f.d_seq, (const u32 *)f.d_wrap,
+                                   (const u32 *)c->d_rec_of_read, (const u16 *)c->d_len, c->ingest_id_base[(size_t)fi], f.good, (const u32 *)c->d_long_ids, n_long_reads, n_good, (int)dstride, c->tailb,
+                                   c->d_full, c->d_reads);
+            }
+            HIPCHK(c, hipGetLastError());
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return DISCO_OK;
     };
@@ -1714,7 +1804,11 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         c->ingest_cap = 0;
     }
     c->ingest_n = n_good;
-    c->max_len = longest;
+    if (c->two_class) {
+        c->max_len_all = longest;
+        c->max_len = short_max;
+    } else
+        c->max_len = longest;
     c->min_len = shortest;
     c->h_len_ok = false;
     c->phase = 1;
@@ -1848,6 +1942,25 @@ int disco_set_query_range(disco_ctx *c, uint64_t lo, uint64_t hi)
 /* one stride -> two classes of rows (disco_kernels.h), at the first index build over the table: everything that edits a table (the
  * generator's substitutions) has been and gone by then. The decision is the device's own count of the long reads; the table that is
  * given up goes back to the allocator. */
+/* the long class's buffers for a table of n_long long reads of stride Sx whose short class has reads of up to short_max bases; the rows
+ * themselves (d_reads: [n + n_long][8]) are the caller's */
+static int two_class_alloc(disco_ctx *c, u64 n_long, int Sx, u32 short_max)
+{
+    if (!c->d_ovf) CHK(dev_alloc(c, &c->d_ovf, c->n_alloc));
+    CHK(dev_alloc(c, &c->d_full, n_long * (u64)Sx));
+    CHK(dev_alloc(c, &c->d_long_ids, n_long));
+    CHK(dev_alloc(c, &c->d_lpos, n_long));
+    CHK(dev_alloc(c, &c->d_lmeta, n_long));
+    CHK(dev_alloc(c, &c->d_n_list, 1));
+    c->reads_rows = c->n + n_long;
+    c->n_long = n_long;
+    c->S_ext = Sx;
+    c->S = VERIFY_SW;
+    c->tailb = short_max <= 160 ? 160 : 256; /* what the staged compare of the short class moves per row (verify_flat_kernel<5 / 8>) */
+    c->two_class = true;
+    return DISCO_OK;
+}
+
 static int two_class_convert(disco_ctx *c)
 {
     if (c->two_class || !c->n || c->max_len <= (u32)DISCO_SHORT_MAX || !two_class_ok(c, c->S, c->n, 1, (u32)c->k + 1)) return DISCO_OK; /* (cheap part first) */
@@ -1864,32 +1977,18 @@ static int two_class_convert(disco_ctx *c)
         dev_free(c, &ovf, c->n_alloc);
         return DISCO_OK;
     }
-    const int tailb = short_max <= 160 ? 160 : 256; /* what the staged compare of the short class moves per row (verify_flat_kernel<5 / 8>) */
-    u64 *rows8 = nullptr, *full = nullptr;
-    u32 *ids = nullptr;
+    u64 *rows8 = nullptr, *old = c->d_reads;
     CHK(dev_alloc(c, &rows8, (c->n + n_long) * 8));
-    CHK(dev_alloc(c, &full, n_long * (u64)Sx));
-    CHK(dev_alloc(c, &ids, n_long));
-    CHK(dev_alloc(c, &c->d_lpos, n_long));
-    CHK(dev_alloc(c, &c->d_lmeta, n_long));
-    CHK(dev_alloc(c, &c->d_n_list, 1));
-    hipLaunchKernelGGL(class_split_kernel, dim3(flat_grid(c, c->n * 8)), dim3(256), 0, c->stream, (const u64 *)c->d_reads, Sx, (const u16 *)c->d_len, (const u32 *)ovf, c->n, tailb, rows8,
-                       full, ids);
+    c->d_ovf = ovf;
+    CHK(two_class_alloc(c, n_long, Sx, short_max));
+    hipLaunchKernelGGL(class_split_kernel, dim3(flat_grid(c, c->n * 8)), dim3(256), 0, c->stream, (const u64 *)old, Sx, (const u16 *)c->d_len, (const u32 *)ovf, c->n, c->tailb, rows8,
+                       c->d_full, c->d_long_ids);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* (the old table goes back: nothing of it may still be in flight) */
-    dev_free(c, &c->d_reads, c->n_alloc * (u64)Sx);
+    dev_free(c, &old, c->n_alloc * (u64)Sx);
     c->d_reads = rows8;
-    c->reads_rows = c->n + n_long;
-    c->d_full = full;
-    c->d_ovf = ovf;
-    c->d_long_ids = ids;
-    c->n_long = n_long;
-    c->S_ext = Sx;
-    c->S = VERIFY_SW;
-    c->tailb = tailb;
     c->max_len_all = c->max_len;
     c->max_len = short_max;
-    c->two_class = true;
     if (getenv("DISCO_VERBOSE"))
         fprintf(stderr, "[disco] two classes of rows: %llu of %llu reads are longer than 256 bases (up to %u), the others up to %u: 64-byte rows + %d-word rows for those\n",
                 (unsigned long long)n_long, (unsigned long long)c->n, c->max_len_all, short_max, Sx);

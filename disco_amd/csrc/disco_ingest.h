@@ -28,7 +28,8 @@
 #define FX_WRAP_IRREGULAR 0xFFFFFFFFu
 
 /* counters of one ingest (u64 each) */
-enum { FX_CTR_BAD_GT = 0, FX_CTR_MULTILINE, FX_CTR_TOO_LONG, FX_CTR_MAX_LEN, FX_CTR_MIN_LEN_INV, FX_CTR_GOOD, FX_CTR_COUNT };
+enum { FX_CTR_BAD_GT = 0, FX_CTR_MULTILINE, FX_CTR_TOO_LONG, FX_CTR_MAX_LEN, FX_CTR_MIN_LEN_INV, FX_CTR_GOOD, FX_CTR_N_LONG, FX_CTR_SHORT_MAX, FX_CTR_COUNT };
+/* (N_LONG / SHORT_MAX: good reads of more than DISCO_SHORT_MAX bases, and the longest of the others — the table may get two classes of rows) */
 
 struct FxTables { /* Dataset::testRead's patterns (read_filter_tables.h), prepared by the host */
     u64 rep58[FX_MAX_REPEATS]; /* the 29-mers that may be neither prefix nor suffix of a read, 2 bits per base */
@@ -186,7 +187,7 @@ __device__ __forceinline__ u64 fx_raw_of(FxBytes &tx, u64 sb, u32 wrap, u32 b)
 __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables tb)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 my_max = 0, my_min = 0xFFFFu, my_good = 0;
+    u32 my_max = 0, my_min = 0xFFFFu, my_good = 0, my_long = 0, my_smax = 0;
     for (; i < a.n_rec; i += (u64)gridDim.x * blockDim.x) {
         const u64 s = a.start[i], e = (i + 1 < a.n_start) ? a.start[i + 1] : a.n;
         FxBytes tx(a.text);
@@ -303,17 +304,23 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
             my_good++;
             my_max = max(my_max, (u32)L);
             my_min = min(my_min, (u32)L);
+            if (L > (u64)DISCO_SHORT_MAX) my_long++;
+            else my_smax = max(my_smax, (u32)L);
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
         my_max = max(my_max, (u32)__shfl_down((int)my_max, o));
         my_min = min(my_min, (u32)__shfl_down((int)my_min, o));
         my_good += (u32)__shfl_down((int)my_good, o);
+        my_long += (u32)__shfl_down((int)my_long, o);
+        my_smax = max(my_smax, (u32)__shfl_down((int)my_smax, o));
     }
     if ((threadIdx.x & 63) == 0 && my_good) {
         atomicMax(&a.ctr[FX_CTR_MAX_LEN], (u64)my_max);
         atomicMax(&a.ctr[FX_CTR_MIN_LEN_INV], (u64)(0xFFFFu - my_min));
         atomicAdd(&a.ctr[FX_CTR_GOOD], (u64)my_good);
+        if (my_long) atomicAdd(&a.ctr[FX_CTR_N_LONG], (u64)my_long);
+        atomicMax(&a.ctr[FX_CTR_SHORT_MAX], (u64)my_smax);
     }
 }
 
@@ -334,10 +341,25 @@ __global__ void fx_ids_kernel(const u16 *__restrict__ glen, const u64 *__restric
         }
 }
 
-/* word w of the row of read id: bases [32 w, 32 w + 32) of its sequence line, 2 bits per base, MSB first (BG/HashTable.cpp:456-477);
- * words behind the read are zero. One thread per word of the table rows [id_base, id_base + n_good). */
+/* 32 bases (fewer at the read's end: zero behind) from base b0 of a sequence, 2 bits per base, MSB first (BG/HashTable.cpp:456-477) */
+__device__ __forceinline__ u64 fx_pack_word(FxBytes &tx, u64 seq_begin, u32 wrap, u32 L, u32 b0)
+{
+    if (b0 >= L) return 0ull;
+    const u32 nb = min(32u, L - b0);
+    u64 acc = 0;
+    u64 p = fx_raw_of(tx, seq_begin, wrap, b0); /* (the bytes from there on: newlines skipped as they come) */
+    for (u32 x = 0; x < nb; x++, p++) {
+        u32 ch = tx.at(p);
+        while (ch == '\n') ch = tx.at(++p);
+        acc = (acc << 2) | (fx_code(fx_upper(ch)) & 3u);
+    }
+    return acc << (2 * (32 - nb));
+}
+
+/* word w of the row of read id: bases [32 w, 32 w + 32) of its sequence line; words behind the read are zero. One thread per word of
+ * the table rows [id_base, id_base + n_good). cap: bases of a read that a row takes (two classes of rows: the first 256 of a long read) */
 __global__ void __launch_bounds__(256) fx_pack_kernel(const u8 *__restrict__ text, const u64 *__restrict__ seq_begin, const u32 *__restrict__ wrap,
-                                                      const u32 *__restrict__ rec_of_read, const u16 *__restrict__ len, u64 id_base, u64 n_good, int S,
+                                                      const u32 *__restrict__ rec_of_read, const u16 *__restrict__ len, u64 id_base, u64 n_good, int S, u32 cap,
                                                       u64 *__restrict__ reads)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,21 +367,38 @@ __global__ void __launch_bounds__(256) fx_pack_kernel(const u8 *__restrict__ tex
     for (; t < total; t += (u64)gridDim.x * blockDim.x) {
         const u64 id = id_base + t / (u64)S;
         const u32 w = (u32)(t % (u64)S);
-        const u32 L = len[id];
+        const u32 L = min((u32)len[id], cap);
         u64 acc = 0;
         if (32u * w < L) {
             const u32 rec = rec_of_read[id];
-            const u32 nb = min(32u, L - 32u * w);
             FxBytes tx(text);
-            u64 p = fx_raw_of(tx, seq_begin[rec], wrap[rec], 32u * w); /* (the bytes from there on: newlines skipped as they come) */
-            for (u32 x = 0; x < nb; x++, p++) {
-                u32 ch = tx.at(p);
-                while (ch == '\n') ch = tx.at(++p);
-                acc = (acc << 2) | (fx_code(fx_upper(ch)) & 3u);
-            }
-            acc <<= 2 * (32 - nb);
+            acc = fx_pack_word(tx, seq_begin[rec], wrap[rec], L, 32u * w);
         }
         reads[id * (u64)S + w] = acc;
+    }
+}
+
+/* two classes of rows (disco_kernels.h): the long reads of the file whose reads are [id_base, id_base + n_good) — their full rows
+ * full[j][SL] and their tail rows rows8[n + j] (the last tailb bases). One thread per word; long read j is long_ids[j]. */
+__global__ void __launch_bounds__(256) fx_pack_long_kernel(const u8 *__restrict__ text, const u64 *__restrict__ seq_begin, const u32 *__restrict__ wrap,
+                                                           const u32 *__restrict__ rec_of_read, const u16 *__restrict__ len, u64 id_base, u64 n_good,
+                                                           const u32 *__restrict__ long_ids, u64 n_long, u64 n, int SL, int tailb, u64 *__restrict__ full,
+                                                           u64 *__restrict__ rows8)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 per = (u64)SL + 8u, total = n_long * per;
+    for (; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 j = t / per;
+        const u32 w = (u32)(t % per);
+        const u64 id = long_ids[j];
+        if (id < id_base || id >= id_base + n_good) continue;
+        const u32 rec = rec_of_read[id], L = len[id];
+        FxBytes tx(text);
+        if (w < (u32)SL) full[j * (u64)SL + w] = fx_pack_word(tx, seq_begin[rec], wrap[rec], L, 32u * w);
+        else {
+            const u32 tw = w - (u32)SL;
+            rows8[(n + j) * 8 + tw] = 32u * tw < (u32)tailb ? fx_pack_word(tx, seq_begin[rec], wrap[rec], L, L - (u32)tailb + 32u * tw) : 0ull;
+        }
     }
 }
 

@@ -121,7 +121,6 @@ struct DiscoView {
     int SL;
     int tailb; /* 160 or 256: the bases the staged compare of the short class moves per row */
 };
-#define DISCO_SHORT_MAX 256 /* bases a 64-byte row holds */
 
 /* ================================================================================================================
  * synthetic reads straight into HBM (bench / tests) — twin of readgen.h / readgen.py
@@ -352,7 +351,7 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
         auto order_word = [&]() {
             next();
             const bool st = r < f;
-            const u32 h = order_hash32(st ? r : f);
+            const u32 h = order_hash32<false>(st ? r : f); /* (a window length the runs are built for means k <= 49: m <= 23) */
             best = min(best, h);
             return (h & ~0x1FFu) | (u32)st;
         };
@@ -2048,6 +2047,66 @@ __global__ void class_flag_kernel(const u16 *__restrict__ len, u64 n, u32 *__res
     }
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (u32)__shfl_down(mx, o));
     if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctr[CTR_SHORT_MAX], (u64)mx);
+}
+
+/* ---- host reads into the table (disco_upload_reads / disco_upload_reads_ragged): a chunk of reads [lo, hi) lies in `src` either at one
+ * stride (src_stride words per read) or back to back (read i at word woff[i] - wbase, ceil(len / 32) words: the reference's own form,
+ * BG/HashTable.cpp:456-477) and goes to rows of S words; cap = bases a row takes (two classes of rows: 256, the head of a long read) */
+__global__ void words_per_read_kernel(const u16 *__restrict__ len, u64 n, u32 *__restrict__ nw)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) nw[i] = ((u32)len[i] + 31u) >> 5;
+}
+
+__global__ void unpack_rows_kernel(const u64 *__restrict__ src, int src_stride, const u64 *__restrict__ woff, u64 wbase, const u16 *__restrict__ len, u64 lo, u64 hi,
+                                   int S, u32 cap, u64 *__restrict__ rows)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = (hi - lo) * (u64)S;
+    for (; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 i = lo + t / (u64)S;
+        const u32 w = (u32)(t % (u64)S);
+        const u32 L = min((u32)len[i], cap);
+        const u64 *p = src + (src_stride ? (i - lo) * (u64)src_stride : woff[i] - wbase);
+        u64 x = 0;
+        if (32u * w < L) {
+            x = p[w];
+            if (L - 32u * w < 32u) x &= ~0ull << (2 * (32 - (L - 32u * w))); /* (bases behind the read, or behind the head of a long one) */
+        }
+        rows[i * (u64)S + w] = x;
+    }
+}
+
+/* two classes of rows: the long reads among [lo, hi) — full rows full[j][SL] and tail rows rows8[n + j]; one thread per word */
+__global__ void unpack_long_rows_kernel(const u64 *__restrict__ src, int src_stride, const u64 *__restrict__ woff, u64 wbase, const u16 *__restrict__ len, u64 lo, u64 hi,
+                                        const u32 *__restrict__ long_ids, u64 n_long, u64 n, int SL, int tailb, u64 *__restrict__ full, u64 *__restrict__ rows8)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 per = (u64)SL + 8u, total = n_long * per;
+    for (; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 j = t / per;
+        const u32 w = (u32)(t % per);
+        const u64 i = long_ids[j];
+        if (i < lo || i >= hi) continue;
+        const int L = len[i], nw = (L + 31) >> 5;
+        const u64 *p = src + (src_stride ? (i - lo) * (u64)src_stride : woff[i] - wbase);
+        if (w < (u32)SL) {
+            u64 x = (int)w < nw ? p[w] : 0ull;
+            if ((int)w == nw - 1 && (L & 31)) x &= ~0ull << (2 * (32 - (L & 31)));
+            full[j * (u64)SL + w] = x;
+        } else {
+            const int tw = (int)w - SL;
+            rows8[(n + j) * 8 + tw] = 32 * tw < tailb ? extract32<false>(p, nw, L - tailb + 32 * tw) : 0ull;
+        }
+    }
+}
+
+/* long_ids[j] = the j-th long read (the input stage: the rows are packed per class from the text) */
+__global__ void class_ids_kernel(const u16 *__restrict__ len, const u32 *__restrict__ ovf, u64 n, u32 *__restrict__ long_ids)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (len[i] > DISCO_SHORT_MAX) long_ids[ovf[i]] = (u32)i;
 }
 
 /* one stride -> two classes: rows8 [n + n_long][8], full [n_long][S] (S = the stride of the table that is given up) */

@@ -382,7 +382,7 @@ int main(int argc, char **argv)
     if (gpus == 1) {
         disco_ctx *ctx = ctx1;
         if (!ctx && disco_create(gpu, &prm, &ctx) < 0) return die(std::string("disco_create: ") + disco_last_error(nullptr));
-        if (!ingested) DISCO_CALL(ctx, disco_upload_reads(ctx, rs.packed, rs.stride_words, rs.len.data(), rs.size()));
+        if (!ingested) DISCO_CALL(ctx, disco_upload_reads_ragged(ctx, rs.packed, rs.len.data(), rs.size()));
         t_h2d = secs(t0);
         t0 = Clock::now();
         DISCO_CALL(ctx, disco_build_index(ctx));
@@ -496,6 +496,7 @@ int main(int argc, char **argv)
             return die(std::string("disco_comm_unique_id: ") + disco_last_error(nullptr));
         std::vector<RankResult> res((size_t)gpus);
         std::vector<std::thread> th;
+        const std::vector<uint64_t> woff = rs.word_offsets();
         for (int r = 0; r < gpus; r++)
             th.emplace_back([&, r]() {
                 RankResult &R = res[(size_t)r];
@@ -509,7 +510,10 @@ int main(int argc, char **argv)
                 if (!same_device && disco_comm_init(c, uid, gpus, r) < 0) bail("disco_comm_init");
                 uint64_t lo = 0, hi = 0;
                 if (disco_dist_range(c, rs.size(), &lo, &hi) < 0) bail("disco_dist_range");
-                if (disco_dist_upload_reads(c, rs.packed + lo * rs.stride_words, rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
+                {
+                    const std::vector<uint64_t> own = rs.rows(lo, hi, woff); /* (the multi-GPU table has one stride: the rank's rows at it) */
+                    if (disco_dist_upload_reads(c, own.data(), rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
+                }
                 if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS | (partitioned_index ? DISCO_DIST_KEEP_INDEX_PARTITIONED : 0)) < 0) bail("disco_dist_run_graph");
                 if (disco_dist_get_info(c, &R.info) < 0) bail("disco_dist_get_info");
                 if (verbose && r == 0) fprintf(stderr, "[disco host] transport %s, %d ranks\n", disco_comm_kind(c), gpus);

@@ -584,10 +584,13 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
     out.shortest = n ? lo : 0;
     out.longest = hi;
     out.stride_words = std::max<uint32_t>(1, (hi + 31) / 32);
-    const uint32_t S = out.stride_words;
     out.n_reads = n;
     out.alloc = alloc;
-    const size_t words = (size_t)n * S;
+    /* the good reads were packed at ceil(L / 32) words each into the arenas, in id order (file, thread): back to back is just that */
+    size_t words = 0;
+    for (auto &fa : arenas)
+        for (auto &ar : fa) words += ar.size();
+    out.n_words = words;
     out.packed = nullptr;
     if (alloc.alloc) out.packed = (uint64_t *)alloc.alloc(std::max<size_t>(words, 1) * 8);
     if (!out.packed) {
@@ -599,13 +602,14 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
     out.file_index.resize(n);
     lap("allocate packed reads");
 
-    /* ---- pass B: pack the good reads at their final place -------------------------------------------------------- */
+    /* ---- pass B: the arenas one behind the other; lengths and file indices by id ------------------------------------ */
     uint64_t id_base = 0, rec_base = 0;
+    size_t word_base = 0;
     for (size_t fi = 0; fi < inputs.size(); fi++) {
         const RecVec &R = recs[fi];
         const std::vector<uint16_t> &G = glen[fi];
         const int nt = threads;
-        std::vector<uint64_t> tbase(nt + 1, 0);
+        std::vector<uint64_t> tbase(nt + 1, 0), wbase(nt + 1, 0);
         const size_t nr = R.size();
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
         for (int t = 0; t < nt; t++) {
@@ -613,19 +617,17 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
             for (size_t i = nr * (size_t)t / nt; i < nr * (size_t)(t + 1) / nt; i++) c += G[i] != 0;
             tbase[t + 1] = c;
         }
-        for (int t = 0; t < nt; t++) tbase[t + 1] += tbase[t];
+        for (int t = 0; t < nt; t++) {
+            tbase[t + 1] += tbase[t];
+            wbase[t + 1] = wbase[t] + arenas[fi][t].size();
+        }
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
         for (int t = 0; t < nt; t++) {
             uint64_t id = id_base + tbase[t];
-            const uint64_t *src = arenas[fi][t].data();
+            if (!arenas[fi][t].empty()) memcpy(out.packed + word_base + wbase[t], arenas[fi][t].data(), arenas[fi][t].size() * 8);
             for (size_t i = nr * (size_t)t / nt; i < nr * (size_t)(t + 1) / nt; i++) {
                 if (!G[i]) continue;
-                const uint32_t L = G[i], W = (L + 31) / 32;
-                uint64_t *w = out.packed + (size_t)id * S;
-                memcpy(w, src, W * 8);
-                for (uint32_t x = W; x < S; x++) w[x] = 0;
-                src += W;
-                out.len[id] = (uint16_t)L;
+                out.len[id] = G[i];
                 out.file_index[id] = rec_base + i + 1; /* BG/Dataset.cpp:294: every record counts */
                 id++;
             }
@@ -633,9 +635,24 @@ bool load_reads(const std::vector<std::string> &pe, const std::vector<std::strin
         }
         id_base += tbase[nt];
         rec_base += nr;
+        word_base += wbase[nt];
     }
     lap("pack");
     return true;
+}
+
+std::vector<uint64_t> ReadSet::word_offsets() const
+{
+    std::vector<uint64_t> o(n_reads + 1, 0);
+    for (uint64_t i = 0; i < n_reads; i++) o[i + 1] = o[i] + ((uint64_t)len[i] + 31) / 32;
+    return o;
+}
+
+std::vector<uint64_t> ReadSet::rows(uint64_t lo, uint64_t hi, const std::vector<uint64_t> &woff) const
+{
+    std::vector<uint64_t> r((hi - lo) * (uint64_t)stride_words, 0);
+    for (uint64_t i = lo; i < hi; i++) memcpy(r.data() + (i - lo) * stride_words, packed + woff[i], (woff[i + 1] - woff[i]) * 8);
+    return r;
 }
 
 ReadSet::~ReadSet()

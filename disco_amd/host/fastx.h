@@ -1,6 +1,7 @@
 /*
  * fastx.h — host-side read input of the buildG drop-in: FASTA/FASTQ(/gz) record splitting, the read-quality filter and
- * 2-bit packing into the fixed-stride layout libdisco_hip.so consumes.
+ * 2-bit packing, every read at its own length and the reads back to back (what disco_upload_reads_ragged takes: a long outlier read
+ * costs its own words, not a wider row for everybody).
  *
  * Behaviour follows the reference's Dataset (cited as BG/ = /root/reference/src/BuildGraph/src/):
  *   record splitting   BG/Dataset.cpp:255-294   (file type from the first byte; FASTA record = header line + everything up
@@ -35,10 +36,15 @@ struct HostAlloc {
 };
 
 struct ReadSet {
-    uint32_t stride_words = 0;
+    uint32_t stride_words = 0;        /* ceil(longest / 32): the stride a table of these reads would have */
     uint64_t n_reads = 0;
-    uint64_t *packed = nullptr;       /* [n][stride_words], from `alloc` or packed_fallback */
-    std::unique_ptr<uint64_t[]> packed_fallback; /* NOT zero-filled: the packer writes every word of every row */
+    uint64_t n_words = 0;             /* sum of ceil(len / 32) */
+    uint64_t *packed = nullptr;       /* [n_words]: read i = the ceil(len[i] / 32) words behind those of read i - 1; from `alloc` or packed_fallback */
+    std::unique_ptr<uint64_t[]> packed_fallback; /* NOT zero-filled: the packer writes every word */
+    /* word offset of every read, [n + 1] (for the consumers that address single reads: the multi-GPU upload, fastx_dump) */
+    std::vector<uint64_t> word_offsets() const;
+    /* reads [lo, hi) as rows of stride_words words (zero behind the read): what disco_dist_upload_reads takes */
+    std::vector<uint64_t> rows(uint64_t lo, uint64_t hi, const std::vector<uint64_t> &woff) const;
     HostAlloc alloc;
     std::vector<uint16_t> len;        /* [n]                                  */
     std::vector<uint64_t> file_index; /* [n] 1-based index over all records   */

@@ -25,9 +25,10 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s\n", err.c_str());
         return 2;
     }
+    const std::vector<uint64_t> woff = rs.word_offsets();
     for (uint64_t i = 0; i < rs.size(); i++) {
         std::string s(rs.len[i], 'A');
-        for (uint32_t t = 0; t < rs.len[i]; t++) s[t] = "ACGT"[(rs.packed[i * rs.stride_words + (t >> 5)] >> (62 - 2 * (t & 31))) & 3];
+        for (uint32_t t = 0; t < rs.len[i]; t++) s[t] = "ACGT"[(rs.packed[woff[i] + (t >> 5)] >> (62 - 2 * (t & 31))) & 3];
         printf("%llu\t%s\n", (unsigned long long)rs.file_index[i], s.c_str());
     }
     printf("#records %llu stride %u\n", (unsigned long long)rs.total_records, rs.stride_words);

@@ -124,6 +124,12 @@ void disco_host_free(void *p);
 /* copy host reads into HBM. packed = [n][stride_words], len[i] in (min_overlap, 32767] (BG/Dataset.cpp:305,
  * 15-bit length field BG/HashTable.cpp:531) */
 int disco_upload_reads(disco_ctx *ctx, const uint64_t *packed, uint32_t stride_words, const uint16_t *len, uint64_t n);
+/* the same with the reads BACK TO BACK, as the reference itself keeps them (every read packed at its own length,
+ * BG/HashTable.cpp:456-477): read i occupies the ceil(len[i] / 32) words that follow those of read i - 1 (disco_pack_ascii's output,
+ * one read after the other). A set with a few long reads then costs neither n rows as wide as the longest one on the host nor that
+ * many bytes over the link; on the device such a set gets two classes of rows (disco_long_rows) straight from the chunks.
+ * disco_stride_words afterwards: ceil(longest / 32) rounded up to a multiple of 8 — the stride disco_download_reads writes. */
+int disco_upload_reads_ragged(disco_ctx *ctx, const uint64_t *words, const uint16_t *len, uint64_t n);
 /* use reads that are already resident in HBM (caller-owned device pointers, must outlive the context's use) */
 int disco_adopt_reads(disco_ctx *ctx, const void *d_packed, uint32_t stride_words, const void *d_len, uint64_t n);
 /* generate synthetic reads directly in HBM (bench / tests) */

@@ -284,3 +284,40 @@ def test_buildg_with_the_device_input_stage_writes_the_host_stages_files(tmp_pat
         assert p.returncode == 0, p.stdout[-1500:]
         assert ("the host input stage takes this job" in p.stdout) == (how == "declined") and ("input stage on the GPU" in p.stdout) == (how == "dev"), p.stdout[-1500:]
         gu.check_against_golden("multifile", refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt"))), refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt"))))
+
+
+@pytest.mark.parametrize("wrapped", [False, True])
+def test_ingest_packs_a_tail_of_long_reads_per_class(tmp_path, wrapped):
+    """a few long reads among short ones (up to the format's 32767 bases): the device stage packs 64-byte rows for everybody and
+    full / tail rows for the long ones straight from the text (two classes of rows: the one-stride table — n rows as wide as the
+    longest read — is never made); what comes back is the table as the parser defines it, and the graph is the oracle's"""
+    from tests.test_gpu_two_class import mixed_reads
+    from tests.util import canon_hip, run_oracle_reads
+
+    rng = np.random.default_rng(5 + wrapped)
+    reads = mixed_reads(31 + wrapped, 6000, 100, 250, 30.0, 0.01, 257, 3000) + _adversarial(rng, 600)
+    reads += ["".join(rng.choice(list("ACGT"), 32000))]  # one outlier: one stride would cost 8 KB for each of the 6601 rows
+    order = rng.permutation(len(reads))
+    paths = []
+    for f, part in enumerate((order[:4000], order[4000:])):
+        p = tmp_path / f"t{f}.fa"
+        with open(p, "w") as fh:
+            for i, j in enumerate(part):
+                s = reads[j]
+                fh.write(f">t{i}\n" + ("\n".join(s[q:q + 70] for q in range(0, len(s), 70)) if wrapped and s else s) + "\n")
+        paths.append(str(p))
+    want, wfidx, wtotal = pyoracle.load_good_reads(paths, 40)
+    keep = [i for i, s in enumerate(want) if len(s) <= 32767]
+    want, wfidx = [want[i] for i in keep], np.asarray(wfidx)[keep]
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        info, files = g.ingest_fasta(paths, threads=4)
+        n_long = sum(len(s) > 256 for s in want)
+        assert g.long_rows == n_long > 30 and g.stride_words == 1000
+        ln, fi = g.ingest_fetch()
+        packed, lens = g.download_reads()
+        assert _decode(packed, lens) == want and np.array_equal(fi.astype(np.int64), np.asarray(wfidx, dtype=np.int64))
+        g.run_graph()
+        he, hr, hc = g.fetch_edges(), g.fetch_contained(), g.counters()
+    oe, orows, oc = run_oracle_reads(want, 40)
+    a, b = canon_hip(he, hr), canon_hip(oe, orows)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and hc["kmer_hits"] == oc["kmer_hits"]

@@ -131,3 +131,54 @@ def test_the_real_reference_s_fixture_with_a_tail_of_long_reads():
         assert g.long_rows == sum(len(r) > 256 for r in reads) > 100
         ce, cc = canon_hip(g.fetch_edges(), g.fetch_contained(), fidx)
     gu.check_against_golden("tail_20k", ce, cc)
+
+
+@pytest.mark.parametrize("kind", ["pure", "tail", "outlier", "all_long"])
+def test_reads_handed_over_back_to_back(kind):
+    """disco_upload_reads_ragged: the reads as the reference keeps them (every read at its own length) — same table, same graph as the
+    upload with one stride; a set with a tail of long reads gets its two classes straight from the chunks"""
+    if kind == "pure":
+        reads = mixed_reads(21, 5000, 150, 150, 30.0, 0.0, 300, 300)
+    elif kind == "tail":
+        reads = mixed_reads(22, 5000, 100, 250, 30.0, 0.03, 257, 2000)
+    elif kind == "outlier":
+        rng = np.random.default_rng(23)
+        reads = mixed_reads(23, 5000, 150, 150, 30.0, 0.0, 300, 300) + ["".join(rng.choice(list("ACGT"), 32767))]
+    else:
+        reads = mixed_reads(24, 1500, 300, 700, 25.0, 0.0, 300, 300)
+    res = {}
+    for ragged in (False, True):
+        with buildgraph.BuildGraph(min_overlap=40) as g:
+            g.upload_ascii(reads, ragged=ragged)
+            lr0, s0 = g.long_rows, g.stride_words
+            packed, lens = g.download_reads()
+            g.run_graph()
+            res[ragged] = (packed, lens, lr0, s0, canon_hip(g.fetch_edges(), g.fetch_contained()), g.counters(), g.long_rows)
+    a, b = res[False], res[True]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[6] == b[6]
+    assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1])
+    for key in ("probes", "kmer_hits", "n_contained", "e_pre", "e_out"):
+        assert a[5][key] == b[5][key], key
+    n_long = sum(len(r) > 256 for r in reads)
+    assert b[2] == (n_long if kind in ("tail", "outlier") else 0)  # (decided at the upload: the chunks are unpacked per class)
+    if kind != "all_long":
+        assert_parity(reads, 40, f"ragged {kind}")
+
+
+def test_back_to_back_upload_checks_lengths_and_chunks(monkeypatch):
+    reads = mixed_reads(25, 3000, 100, 250, 30.0, 0.02, 300, 900)
+    monkeypatch.setenv("DISCO_UPLOAD_CHUNK", "256")  # twelve chunks, the ring of three staging buffers goes round
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.upload_ascii(reads, ragged=True)
+        packed, lens = g.download_reads()
+        g.run_graph()
+        e1 = canon_hip(g.fetch_edges(), g.fetch_contained())
+    monkeypatch.delenv("DISCO_UPLOAD_CHUNK")
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.upload_ascii(reads)
+        p2, l2 = g.download_reads()
+        g.run_graph()
+        e2 = canon_hip(g.fetch_edges(), g.fetch_contained())
+        assert np.array_equal(packed, p2) and np.array_equal(lens, l2) and np.array_equal(e1[0], e2[0]) and np.array_equal(e1[1], e2[1])
+        with pytest.raises(buildgraph.DiscoError, match="length outside"):
+            g.upload_ascii(reads[:10] + ["ACGT" * 5], ragged=True)  # 20 bases <= min-overlap
