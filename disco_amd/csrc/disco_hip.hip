@@ -1239,6 +1239,9 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
     if (!c || (n && (!packed || !len))) return c ? fail(c, DISCO_E_ARG, "%s: null argument", who) : DISCO_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const bool ragged = stride_words == 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lapms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_scan = 0, t_alloc = 0, t_issued = 0, t_mirror = 0;
     u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
     CH = std::max<u64>((CH + 255) & ~255ull, 256);
     const u64 n_chunks = (n + CH - 1) / CH;
@@ -1250,12 +1253,13 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
     std::vector<u64> chunk_words(n_chunks + 1, 0);
     {
         const u32 mo = c->prm.min_overlap, cap = ragged ? 32767u : std::min<u32>(32767u, stride_words * 32u);
-        parallel_for(n_chunks, [&](u64 k0, u64 k1) {
+        std::mutex mu;
+        parallel_for(n, [&](u64 b0, u64 e0) {
             u64 bad = 0, nlong = 0;
             u32 mx = 0, mn = 0xFFFFu, smx = 0;
-            for (u64 k = k0; k < k1; k++) {
+            for (u64 k = b0 / CH; k * CH < e0; k++) { /* the piece of chunk k inside [b0, e0) */
                 u64 words = 0;
-                for (u64 i = k * CH; i < std::min<u64>(n, (k + 1) * CH); i++) {
+                for (u64 i = std::max<u64>(b0, k * CH); i < std::min<u64>(e0, (k + 1) * CH); i++) {
                     const u32 L = len[i];
                     bad += (L <= mo || L > cap);
                     mx = std::max(mx, L);
@@ -1264,7 +1268,8 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
                     if (L <= (u32)DISCO_SHORT_MAX) smx = std::max(smx, L);
                     words += (L + 31u) >> 5;
                 }
-                chunk_words[k + 1] = words;
+                std::lock_guard<std::mutex> lk(mu);
+                chunk_words[k + 1] += words;
             }
             a_bad += bad;
             a_long += nlong;
@@ -1278,6 +1283,7 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
         for (u64 k = 0; k < n_chunks; k++) chunk_words[k + 1] += chunk_words[k];
     }
     if (ragged) stride_words = std::max<u32>(1, (a_max.load() + 31) / 32);
+    t_scan = lapms();
     /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
     const uint32_t dstride = (stride_words + 7u) & ~7u;
     if (a_bad.load()) {
@@ -1338,6 +1344,7 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
             CHK((scan_exclusive<u32, u32>(c, c->d_ovf, n, c->d_ovf, false, nullptr)));
             hipLaunchKernelGGL(class_ids_kernel, dim3(flat_grid(c, n)), dim3(256), 0, c->stream, (const u16 *)c->d_len, (const u32 *)c->d_ovf, n, c->d_long_ids);
         }
+        t_alloc = lapms();
         IndexCountPlan pl;
         DiscoView v;
         if (eager) {
@@ -1369,12 +1376,17 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
             if (eager) CHK((index_count_chunk<true>(c, v, pl, c->d_rec, lo, hi)));
         }
         HIPCHK(c, hipGetLastError());
+        t_issued = lapms();
         /* the host's copy of the lengths (result decoding) while the chunks travel */
         if (c->h_len.size() != n) c->h_len.resize(n);
         uint16_t *hl = c->h_len.data();
         parallel_for(n, [&, hl](u64 b0, u64 e0) { memcpy(hl + b0, len + b0, (e0 - b0) * 2); });
         c->h_len_ok = true;
+        t_mirror = lapms();
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        if (getenv("DISCO_VERBOSE"))
+            fprintf(stderr, "[disco] %s: lengths checked %.1f ms, buffers %.1f, chunks issued %.1f, lengths mirrored %.1f, copies done %.1f (%s%s)\n", who, t_scan, t_alloc, t_issued,
+                    t_mirror, lapms(), classes ? "two classes of rows" : "one stride", eager ? ", index counted behind the copies" : "");
         if (woff) { /* (read by the unpack kernels on the context's stream) */
             HIPCHK(c, hipStreamSynchronize(c->stream));
             dev_free(c, &woff, n);
