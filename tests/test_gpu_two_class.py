@@ -182,3 +182,38 @@ def test_back_to_back_upload_checks_lengths_and_chunks(monkeypatch):
         assert np.array_equal(packed, p2) and np.array_equal(lens, l2) and np.array_equal(e1[0], e2[0]) and np.array_equal(e1[1], e2[1])
         with pytest.raises(buildgraph.DiscoError, match="length outside"):
             g.upload_ascii(reads[:10] + ["ACGT" * 5], ragged=True)  # 20 bases <= min-overlap
+
+
+def test_one_context_through_read_sets_of_every_layout(tmp_path):
+    """the same context takes, one after the other: a pure set, a set with a tail (one stride from the host, then back to back), a
+    generated set with a tail (re-laid at the index build), a FASTA with a tail (packed per class by the input stage), the pure set
+    again — every pass equals a fresh context's"""
+    from disco_amd import readgen
+
+    pure = mixed_reads(41, 4000, 150, 150, 30.0, 0.0, 300, 300)
+    tail = mixed_reads(42, 4000, 150, 150, 30.0, 0.03, 300, 900)
+    spec = readgen.GenSpec.coverage(seed=43, n_reads=4000, read_len=150, cov=30.0, long_len=500, long_share=2000)
+    fa = tmp_path / "t.fa"
+    fa.write_text("".join(f">r{i}\n{s}\n" for i, s in enumerate(tail)))
+
+    def fresh(load):
+        with buildgraph.BuildGraph(min_overlap=40) as g:
+            load(g)
+            g.run_graph()
+            return canon_hip(g.fetch_edges(), g.fetch_contained()), g.long_rows
+
+    steps = [("pure", lambda g: g.upload_ascii(pure)), ("tail, one stride", lambda g: g.upload_ascii(tail)), ("tail, back to back", lambda g: g.upload_ascii(tail, ragged=True)),
+             ("generated tail", lambda g: g.generate_reads(spec)), ("fasta tail", lambda g: g.ingest_fasta([str(fa)], threads=2)), ("pure again", lambda g: g.upload_ascii(pure)),
+             ("tail again", lambda g: g.upload_ascii(tail)), ("tail, a narrower query range", lambda g: (g.upload_ascii(tail), g.set_query_range(0, len(tail)))[0])]
+    want = {name: fresh(load) for name, load in steps}
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        for name, load in steps:
+            load(g)
+            g.run_graph()
+            got = canon_hip(g.fetch_edges(), g.fetch_contained())
+            assert np.array_equal(got[0], want[name][0][0]) and np.array_equal(got[1], want[name][0][1]), name
+            assert g.long_rows == want[name][1], name
+            assert (g.long_rows > 0) == ("tail" in name), name
+            g.run_graph()  # a second pass over the same table
+            again = canon_hip(g.fetch_edges(), g.fetch_contained())
+            assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1]), name + " (second pass)"

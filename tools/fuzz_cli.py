@@ -34,7 +34,7 @@ for it in range(iters):
         nfiles = int(rng.integers(1, 4))
         cuts = sorted(rng.integers(1, n, nfiles - 1).tolist()) if nfiles > 1 else []
         parts = [reads[a:b] for a, b in zip([0] + cuts, cuts + [n])]
-        files, kinds = [], []
+        files, kinds, gz = [], [], set()
         for fi, part in enumerate(parts):
             if not part:
                 part = [reads[0]]
@@ -47,6 +47,11 @@ for it in range(iters):
                     else:
                         w = int(rng.choice([0, 0, 60]))
                         f.write(">r%d\n%s\n" % (i, s if not w else "\n".join(s[j:j + w] for j in range(0, len(s), w))))
+            if rng.random() < 0.25:  # gzipped for the drop-in: its device input stage declines, the host stage (reads back to back) takes the
+                import gzip, shutil  # whole job; the reference build here has no zlib (READGZ): it gets the file as it was
+                with open(p, "rb") as fi, gzip.open(p + ".gz", "wb") as fo:
+                    shutil.copyfileobj(fi, fo)
+                gz.add(p)
             files.append(p)
             kinds.append("-pe" if rng.random() < 0.4 else "-se")
         pe = [f for f, k in zip(files, kinds) if k == "-pe"]
@@ -61,7 +66,8 @@ for it in range(iters):
             extra = ["--gpus", str(int(rng.integers(2, 5))), "--same-device"] + (["--mpi-names"] if rng.random() < 0.3 else [])
 
         def run(exe, prefix, t):
-            cmd = [exe] + (["-pe", ",".join(pe)] if pe else []) + (["-se", ",".join(se)] if se else []) + ["-f", prefix, "-p", cfg, "-t", str(t), "-m", "8"]
+            nm = (lambda f: f + ".gz" if f in gz else f) if exe == MINE else (lambda f: f)
+            cmd = [exe] + (["-pe", ",".join(map(nm, pe))] if pe else []) + (["-se", ",".join(map(nm, se))] if se else []) + ["-f", prefix, "-p", cfg, "-t", str(t), "-m", "8"]
             if exe == MINE:
                 cmd += extra
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -70,7 +76,7 @@ for it in range(iters):
         os.makedirs(os.path.join(d, "ref")); os.makedirs(os.path.join(d, "mine"))
         rc1, log1 = run(refrun.REF_BIN, os.path.join(d, "ref", "g"), 1)
         rc2, log2 = run(MINE, os.path.join(d, "mine", "g"), threads)
-        label = "it%d n=%d len=%d-%d%s mo=%d cov=%g files=%s t=%d %s" % (it, n, lmin, lmax, " +tail" if tailed else "", mo, cov, [k + ":" + os.path.basename(f) for f, k in zip(files, kinds)],
+        label = "it%d n=%d len=%d-%d%s mo=%d cov=%g files=%s t=%d %s" % (it, n, lmin, lmax, " +tail" if tailed else "", mo, cov, [k + ":" + os.path.basename(f) + (".gz" if f in gz else "") for f, k in zip(files, kinds)],
                                                                           threads, " ".join(extra))
         try:
             assert rc2 == 0, log2[-500:]
@@ -79,7 +85,7 @@ for it in range(iters):
             e2 = refrun.parse_pargraph(sorted(glob.glob(os.path.join(d, "mine", "g_*_parGraph.txt"))))
             c2 = refrun.parse_contained(sorted(glob.glob(os.path.join(d, "mine", "g_*_containedReads.txt"))))
             m1 = open(os.path.join(d, "ref", "g_ReadIDMap.txt")).read().replace(d, "")
-            m2 = open(os.path.join(d, "mine", "g_ReadIDMap.txt")).read().replace(d, "")
+            m2 = open(os.path.join(d, "mine", "g_ReadIDMap.txt")).read().replace(d, "").replace(".gz", "")
             assert m1 == m2, "ReadIDMap differs"
             assert np.array_equal(c1, c2), "contained rows differ (%d vs %d)" % (len(c1), len(c2))
             flat = log2.replace(" ", "")
