@@ -95,18 +95,6 @@ __global__ void unpack_rows_kernel(const u64 *__restrict__ dense, int S, int W, 
     }
 }
 
-/* nrows dense rows of W words -> rows of the S-stride table starting at `rows`, the words beyond W cleared (no memset of the table) */
-__global__ void unpack_pad_kernel(const u64 *__restrict__ dense, int S, int W, u64 nrows, u64 *__restrict__ rows)
-{
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 total = nrows * (u64)S;
-    for (; i < total; i += (u64)gridDim.x * blockDim.x) {
-        const u64 r = i / (u64)S;
-        const int w = (int)(i - r * (u64)S);
-        rows[i] = w < W ? dense[r * (u64)W + w] : 0ull;
-    }
-}
-
 __global__ void add_u64_kernel(u64 *__restrict__ p, u64 n, u64 val)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1362,10 +1362,10 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
                 HIPCHK(c, hipMemcpyAsync(ring, packed + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, c->copy_stream));
                 HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
-                hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, (hi - lo) * (u64)c->S)), dim3(256), 0, c->stream, (const u64 *)ring, ragged ? 0 : (int)stride_words, (const u64 *)woff, w0,
+                hipLaunchKernelGGL(unpack_reads_kernel, dim3(flat_grid(c, (hi - lo) * (u64)c->S)), dim3(256), 0, c->stream, (const u64 *)ring, ragged ? 0 : (int)stride_words, (const u64 *)woff, w0,
                                    (const u16 *)c->d_len, lo, hi, c->S, classes ? (u32)DISCO_SHORT_MAX : 0xFFFFu, c->d_reads);
                 if (classes)
-                    hipLaunchKernelGGL(unpack_long_rows_kernel, dim3(flat_grid(c, n_long * ((u64)dstride + 8))), dim3(256), 0, c->stream, (const u64 *)ring, ragged ? 0 : (int)stride_words,
+                    hipLaunchKernelGGL(unpack_long_reads_kernel, dim3(flat_grid(c, n_long * ((u64)dstride + 8))), dim3(256), 0, c->stream, (const u64 *)ring, ragged ? 0 : (int)stride_words,
                                        (const u64 *)woff, w0, (const u16 *)c->d_len, lo, hi, (const u32 *)c->d_long_ids, n_long, n, (int)dstride, c->tailb, c->d_full, c->d_reads);
                 HIPCHK(c, hipEventRecord(c->ev_unpacked[b], c->stream));
             } else { /* (one 1-D copy per chunk: a 2-D copy whose width equals both pitches ran at a third of the rate) */

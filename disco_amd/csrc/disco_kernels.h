@@ -2058,7 +2058,7 @@ __global__ void words_per_read_kernel(const u16 *__restrict__ len, u64 n, u32 *_
     for (; i < n; i += (u64)gridDim.x * blockDim.x) nw[i] = ((u32)len[i] + 31u) >> 5;
 }
 
-__global__ void unpack_rows_kernel(const u64 *__restrict__ src, int src_stride, const u64 *__restrict__ woff, u64 wbase, const u16 *__restrict__ len, u64 lo, u64 hi,
+__global__ void unpack_reads_kernel(const u64 *__restrict__ src, int src_stride, const u64 *__restrict__ woff, u64 wbase, const u16 *__restrict__ len, u64 lo, u64 hi,
                                    int S, u32 cap, u64 *__restrict__ rows)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2078,7 +2078,7 @@ __global__ void unpack_rows_kernel(const u64 *__restrict__ src, int src_stride, 
 }
 
 /* two classes of rows: the long reads among [lo, hi) — full rows full[j][SL] and tail rows rows8[n + j]; one thread per word */
-__global__ void unpack_long_rows_kernel(const u64 *__restrict__ src, int src_stride, const u64 *__restrict__ woff, u64 wbase, const u16 *__restrict__ len, u64 lo, u64 hi,
+__global__ void unpack_long_reads_kernel(const u64 *__restrict__ src, int src_stride, const u64 *__restrict__ woff, u64 wbase, const u16 *__restrict__ len, u64 lo, u64 hi,
                                         const u32 *__restrict__ long_ids, u64 n_long, u64 n, int SL, int tailb, u64 *__restrict__ full, u64 *__restrict__ rows8)
 {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
