@@ -9,4 +9,5 @@ run tools/fuzz_fastx.py 300 405 gpu
 run tools/fuzz_cli.py 100 404
 run tools/fuzz_parity.py 40 406 inexact
 run tools/fuzz_chains.py 40 407
+run tools/fuzz_reuse.py 60 409
 cat $O

@@ -18,13 +18,15 @@ for it in range(iters):
     cov = float(rng.choice([10, 30, 200]))
     if cov == 200:
         n = min(n, 20000)
-    spec = readgen.GenSpec.coverage(int(rng.integers(1, 1 << 30)), n, lmin, cov, n_contigs=int(rng.integers(1, 4)), len_max=lmax)
-    mode = int(rng.integers(0, 3))
+    tailed = lmax <= 256 and rng.random() < 0.5  # a tail of long reads: two classes of rows come and go on the same context
+    spec = readgen.GenSpec.coverage(int(rng.integers(1, 1 << 30)), n, lmin, cov, n_contigs=int(rng.integers(1, 4)), len_max=lmax,
+                                    long_len=int(rng.choice([300, 700, 2500])) if tailed else 0, long_share=int(rng.choice([100, 1300, 3500])) if tailed else 0)
+    mode = int(rng.integers(0, 4))  # 0: generated on the device; 1, 2: uploaded at one stride; 3: uploaded back to back
     try:
-        if mode == 0:
+        if mode == 0 or n > 20000:
             g.generate_reads(spec)
         else:
-            g.upload_ascii(list(readgen.generate_reads(spec)) if n <= 20000 else None) if n <= 20000 else g.generate_reads(spec)
+            g.upload_ascii(list(readgen.generate_reads(spec)), ragged=mode == 3)
         passes = int(rng.integers(1, 3))
         for _ in range(passes):
             g.run_graph()
@@ -38,7 +40,7 @@ for it in range(iters):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "results differ"
         for k in ("e_pre", "e_out", "n_contained", "kmer_hits"):
             assert ca[k] == cb[k], (k, ca[k], cb[k])
-        print("ok  it%d n=%d len=%d-%d cov=%g mode=%d passes=%d e_out=%d" % (it, n, lmin, lmax, cov, mode, passes, ca["e_out"]), flush=True)
+        print("ok  it%d n=%d len=%d-%d%s cov=%g mode=%d passes=%d e_out=%d long_rows=%d" % (it, n, lmin, lmax, " +tail" if tailed else "", cov, mode, passes, ca["e_out"], g.long_rows), flush=True)
     except Exception as e:
         fails += 1
         print("FAIL it%d n=%d len=%d-%d cov=%g mode=%d: %r" % (it, n, lmin, lmax, cov, mode, e), flush=True)
