@@ -183,6 +183,7 @@ struct disco_ctx {
     u32 max_len_all = 0; /* longest read of the set (max_len: of the short class) */
     int tailb = 0;
     u32 *d_lpos = nullptr, *d_n_list = nullptr; /* the long reads' candidate rows of the pass (class_take_rows_kernel) */
+    uint2 *d_linfo = nullptr;
     ulonglong2 *d_lmeta = nullptr;
 
     /* index */
@@ -683,6 +684,7 @@ static void free_reads(disco_ctx *c)
         dev_free(c, &c->d_long_ids, c->n_long);
         dev_free(c, &c->d_lpos, c->n_long);
         dev_free(c, &c->d_lmeta, c->n_long);
+        dev_free(c, &c->d_linfo, c->n_long);
         dev_free(c, &c->d_n_list, 1);
     }
     c->two_class = false;
@@ -1963,6 +1965,7 @@ static int two_class_alloc(disco_ctx *c, u64 n_long, int Sx, u32 short_max)
     CHK(dev_alloc(c, &c->d_long_ids, n_long));
     CHK(dev_alloc(c, &c->d_lpos, n_long));
     CHK(dev_alloc(c, &c->d_lmeta, n_long));
+    CHK(dev_alloc(c, &c->d_linfo, n_long));
     CHK(dev_alloc(c, &c->d_n_list, 1));
     c->reads_rows = c->n + n_long;
     c->n_long = n_long;
@@ -2251,7 +2254,8 @@ int disco_probe(disco_ctx *c)
             ph_begin(c, DISCO_PH_VERIFY);
             if (c->two_class && nq) { /* the long reads' candidate rows: out of the flat pass, to verify_long_kernel behind it */
                 HIPCHK(c, hipMemsetAsync(c->d_n_list, 0, sizeof(u32), c->stream));
-                hipLaunchKernelGGL(class_take_rows_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, c->d_meta_ord, nq, c->d_lpos, c->d_lmeta, c->d_n_list, (u32)c->n_long);
+                hipLaunchKernelGGL(class_take_rows_kernel, dim3((unsigned)std::min<u64>((nq + TAKE_SPAN - 1) / TAKE_SPAN, (u64)c->n_cu * 8)), dim3(256), 0, c->stream, c->d_meta_ord,
+                                   (const u64 *)c->d_order_used, c->q_lo, nq, (const u32 *)c->d_ovf, c->d_lpos, c->d_lmeta, c->d_linfo, c->d_n_list, (u32)c->n_long);
             }
             if (two_pass) {
                 if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
@@ -2307,8 +2311,8 @@ int disco_probe(disco_ctx *c)
                 else hipLaunchKernelGGL(verify_kernel<0>, dim3(wq_grid(c, verify_kernel<0>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
             }
             if (c->two_class && nq)
-                hipLaunchKernelGGL(verify_long_kernel, dim3(wave_grid(c, c->n_long, 16)), dim3(64), 0, c->stream, va, (const u32 *)c->d_lpos, (const ulonglong2 *)c->d_lmeta,
-                                   (const u32 *)c->d_n_list);
+                hipLaunchKernelGGL(verify_long_kernel, dim3(wq_grid(c, verify_long_kernel, c->n_long * 16, "DISCO_VL_WAVES")), dim3(64), 0, c->stream, va, (const u32 *)c->d_lpos, (const ulonglong2 *)c->d_lmeta,
+                                   (const uint2 *)c->d_linfo, (const u32 *)c->d_n_list);
             ph_end(c, DISCO_PH_VERIFY);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));

@@ -994,6 +994,22 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
     while (wq_grab(a.v.wq, nq, cbeg, cend)) {
         const u64 ci = min(cbeg + lane, cend - 1);
         const u64 ord_chunk = a.order ? a.order[ci] : ORDER_MAKE(a.v.q_lo + ci, a.v.len[a.v.q_lo + ci]);
+        if (a.v.full) { /* two classes of rows: the chunk's long reads go to the list pass — ONE counting atomic per chunk (one per read, on the one
+                           counter, made this kernel twice as slow with 6 % long reads) */
+            const bool lng = cbeg + lane < cend && ORDER_LEN(ord_chunk) > DISCO_SHORT_MAX;
+            const u64 lm = __ballot(lng);
+            if (lm) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(a.rare->n_slow, (u32)__popcll(lm));
+                base = (u32)__shfl((int)base, 0);
+                if (lng) {
+                    const u32 idx = base + (u32)__popcll(lm & lt);
+                    if (idx < a.rare->slow_cap) a.rare->slow_list[idx] = ORDER_ID(ord_chunk) | ((cbeg + lane) << 32);
+                    else atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
+                    a.meta_ord[cbeg + lane] = make_ulonglong2(0ull, (u64)ORDER_LEN(ord_chunk) << 32);
+                }
+            }
+        }
         /* run words and rows of the group that starts at g0 (addresses clamped, loads unconditional: they are issued one group ahead) */
         auto fetch = [&](u64 g0, u32 &rw, u64 &roww) {
             const u64 it = min(g0 + slot, cend - 1);
@@ -1050,7 +1066,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
             if (v0) s_occ[below] = (slot << 29) | ((e0 & 1u) << 22) | (((e0 >> 1) & 31u) << 17) | (wend0 << 8) | (e0 >> 6);
             if (v1) s_occ[below + 1] = (slot << 29) | ((e1 & 1u) << 22) | (((e1 >> 1) & 31u) << 17) | (wend1 << 8) | (e1 >> 6);
             const u32 n_occ = (u32)__popcll(m0) + (u32)__popcll(m1);
-            if (sv && e == 0 && myslow) { /* ties / too many runs: probe_kernel<2> does this read */
+            if (sv && e == 0 && myslow && !(a.v.full && LA > DISCO_SHORT_MAX)) { /* ties / too many runs: probe_kernel<2> does this read (long reads: listed with their chunk, above) */
                 const u32 idx = atomicAdd(a.rare->n_slow, 1u);
                 if (idx < a.rare->slow_cap) a.rare->slow_list[idx] = (u64)A | (opos << 32);
                 else atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
@@ -2141,58 +2157,150 @@ __global__ void class_join_kernel(const u64 *__restrict__ rows8, const u64 *__re
     }
 }
 
-/* the candidate rows of the long reads leave the flat pass: their headers {row start, candidates | length << 32} move to a list (with
- * their position in the order) and the pass finds rows of no candidates there */
-__global__ void class_take_rows_kernel(ulonglong2 *__restrict__ meta_ord, u64 nq, u32 *__restrict__ lpos, ulonglong2 *__restrict__ lmeta, u32 *n_list, u32 cap)
+/* the candidate rows of the long reads leave the flat pass: their headers {row start, candidates | length << 32} move to a list — with
+ * their position in the order, their id and their number among the long reads, so that verify_long_kernel has nothing to chase — and
+ * the flat pass finds rows of no candidates there. A block takes TAKE_SPAN consecutive positions and appends its finds with ONE
+ * counting atomic: the list keeps the processing order in long stretches (long reads of one locus are neighbours there; in id order
+ * verify_long_kernel ran 81 instead of 63 ms at 6 % long reads), and the counter is no hot spot (one atomic per wavefront trip: 6.5 ms). */
+#define TAKE_SPAN 4096
+__global__ void __launch_bounds__(256) class_take_rows_kernel(ulonglong2 *__restrict__ meta_ord, const u64 *__restrict__ order, u64 q_lo, u64 nq, const u32 *__restrict__ ovf,
+                                                              u32 *__restrict__ lpos, ulonglong2 *__restrict__ lmeta, uint2 *__restrict__ linfo, u32 *n_list, u32 cap)
 {
-    u64 ci = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; ci < nq; ci += (u64)gridDim.x * blockDim.x) {
-        const ulonglong2 m = meta_ord[ci];
-        if ((u32)(m.y >> 32) > (u32)DISCO_SHORT_MAX && (u32)m.y != 0u) {
-            const u32 at = atomicAdd(n_list, 1u);
-            if (at < cap) { /* (cap = the number of long reads: never short) */
-                lpos[at] = (u32)ci;
-                lmeta[at] = m;
+    __shared__ u32 s_w[4];
+    __shared__ u32 s_base;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (u64 span = (u64)blockIdx.x * TAKE_SPAN; span < nq; span += (u64)gridDim.x * TAKE_SPAN) {
+        const u64 end = span + TAKE_SPAN < nq ? span + TAKE_SPAN : nq;
+        auto mine = [&](u64 ci, ulonglong2 &m) {
+            m = ci < end ? meta_ord[ci] : make_ulonglong2(0, 0);
+            return ci < end && (u32)(m.y >> 32) > (u32)DISCO_SHORT_MAX && (u32)m.y != 0u;
+        };
+        u32 cnt = 0; /* pass 1: the span's finds */
+        for (u64 ci = span + tid; ci - tid < end; ci += 256) {
+            ulonglong2 m;
+            cnt += mine(ci, m) ? 1u : 0u;
+        }
+        cnt = wave_inclusive_add(cnt);
+        __syncthreads();
+        if (lane == 63) s_w[wv] = cnt;
+        __syncthreads();
+        const u32 total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (total == 0) continue; /* (block uniform) */
+        if (tid == 0) s_base = atomicAdd(n_list, total);
+        __syncthreads();
+        u32 at = s_base; /* pass 2: in position order */
+        for (u64 ci = span + tid; ci - tid < end; ci += 256) {
+            ulonglong2 m;
+            const bool take = mine(ci, m);
+            const u64 tm = __ballot(take);
+            __syncthreads();
+            if (lane == 0) s_w[wv] = (u32)__popcll(tm);
+            __syncthreads();
+            u32 off = (u32)__popcll(tm & lane_mask_lt());
+            for (u32 w = 0; w < wv; w++) off += s_w[w];
+            if (take) {
+                const u32 x = at + off;
+                const u64 A = ORDER_ID(order ? order[ci] : q_lo + ci);
+                if (x < cap) { /* (cap = the number of long reads: never short) */
+                    lpos[x] = (u32)ci;
+                    lmeta[x] = m;
+                    linfo[x] = make_uint2((u32)A, ovf[A]);
+                }
+                meta_ord[ci].y = m.y & 0xFFFFFFFF00000000ull;
             }
-            meta_ord[ci].y = m.y & 0xFFFFFFFF00000000ull;
+            at += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         }
     }
 }
 
-/* verify for the rows class_take_rows_kernel set aside: one wavefront per long read, lane = candidate, both reads compared where
- * they lie (the long one in full[], a short candidate in its 64-byte row) — verify_kernel<0>'s compare with a stride per side.
+/* verify for the rows class_take_rows_kernel set aside: one wavefront per long read, lane = candidate. The long read (up to VL_ACAP
+ * words: 4096 bases) and its reverse complement are staged in LDS once per read; a candidate of the short class brings its 64-byte row
+ * (four independent 16-byte loads per lane, into the lane's own staging row) and the aligned region — at most 256 bases, nine words —
+ * is ONE pass of XORs over LDS words, verify_kernel's staged compare with the two reads at their own strides. A first version compared
+ * every pair where it lay (seg_equal2 on global memory: a chain of up to fourteen dependent loads per candidate, 25 us per batch; with
+ * 1 % long reads that was +14 ms of verify, with 6 % +75): kept for long candidates of long reads and for reads beyond VL_ACAP.
  * Candidate ids of tail rows become read ids first; the row is compacted in place as everywhere. */
-__global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32 *__restrict__ lpos, const ulonglong2 *__restrict__ lmeta, const u32 *__restrict__ n_list)
+#define VL_ACAP 128
+__global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32 *__restrict__ lpos, const ulonglong2 *__restrict__ lmeta, const uint2 *__restrict__ linfo,
+                                                          const u32 *__restrict__ n_list)
 {
+    constexpr int BST = (VERIFY_SW + 3) | 1; /* a staged candidate row: 8 words + zero words behind (the last one is the zero word in front of the next row) */
+    __shared__ u64 s_a[VL_ACAP + 12];   /* [0] = 0, [1 ..] = the long read, zeros behind */
+    __shared__ u64 s_arc[VL_ACAP + 12]; /* same layout: its reverse complement, left aligned */
+    __shared__ u64 s_b[1 + 64 * BST];
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
     const u32 nl = *n_list;
-    for (u32 it = blockIdx.x; it < nl; it += gridDim.x) {
-        const u32 ci = lpos[it];
+    for (u32 i = lane; i < 1 + 64 * BST; i += 64) s_b[i] = 0;
+    /* the entries are taken from the work queue four at a time: rows differ in length, and a static deal left the last wavefronts
+     * running alone (62 ms with 16 waves per CU, 51 with 256 per CU queued up behind each other: the same thing said with launches) */
+    u64 qb = 0, qe = 0;
+    while (wq_grab<4>(a.v.wq, (u64)nl, qb, qe))
+    for (u32 it = (u32)qb; it < (u32)qe; it++) { /* entry `it` of the list: header, position, id and number of the long read — nothing to chase */
         const ulonglong2 meta = lmeta[it];
-        const u64 A = ORDER_ID(a.order ? a.order[ci] : a.v.q_lo + ci);
-        const int LA = (int)(meta.y >> 32);
         const u32 c = (u32)meta.y;
+        const u32 ci = lpos[it];
+        const uint2 inf = linfo[it];
+        const u64 A = inf.x;
+        const int LA = (int)(meta.y >> 32);
         const int SA = a.v.SL;
-        const u64 *ga = a.v.full + (u64)a.v.ovf[A] * SA;
+        const u64 *ga = a.v.full + (u64)inf.y * SA;
+        const int AW = (LA + 31) >> 5;
+        const bool a_lds = AW <= VL_ACAP;
+        __syncthreads();
+        if (a_lds) {
+            for (int w = (int)lane; w < VL_ACAP + 12; w += 64) s_a[w] = (w >= 1 && w <= AW) ? ga[w - 1] : 0ull;
+            __syncthreads();
+            /* word i of revcomp(A) = reverse complement of A[LA - 32(i+1), LA - 32i); what lies beyond the read is masked by every consumer */
+            for (int w = (int)lane; w < VL_ACAP + 12; w += 64) {
+                const int pos = LA - 32 * w; /* word w - 1 */
+                s_arc[w] = (w >= 1 && w <= AW && pos > -32) ? rev2_64(~extract32_padded(s_a + 1, pos)) : 0ull;
+            }
+            __syncthreads();
+        }
         u64 *row = a.hits + meta.x;
         u32 nkeep = 0;
+        /* three stages, all loads unconditional (clamped): while batch b is compared, the rows of batch b + 1 and the candidates of batch
+         * b + 2 are in flight (the compaction writes never reach a slot that has not been read: they stay below the batch's own slots) */
+        auto load_cand = [&](u32 i0) -> u64 {
+            const u32 i = i0 + lane;
+            const u64 x = row[i < c ? i : c - 1u];
+            return i < c ? x : 0ull;
+        };
+        struct Rows {
+            ulonglong2 q0, q1, q2, q3;
+        };
+        auto load_rows = [&](u64 hx) { /* a short candidate's 64-byte row (others: the row of read 0, a line like any other) */
+            const bool use = hx != 0ull && a_lds && HIT_LEN(hx) <= (u32)DISCO_SHORT_MAX;
+            const ulonglong2 *q = (const ulonglong2 *)(a.v.reads + (use ? HIT_ID(hx) : 0ull) * VERIFY_SW);
+            Rows r;
+            r.q0 = q[0], r.q1 = q[1], r.q2 = q[2], r.q3 = q[3];
+            return r;
+        };
+        u64 h0 = load_cand(0), h1 = load_cand(64);
+        Rows R0 = load_rows(h0);
         for (u32 i0 = 0; i0 < c; i0 += 64) {
+            const u64 h2 = load_cand(i0 + 128);
+            const Rows R1 = load_rows(h1);
             const bool act = i0 + lane < c;
-            u64 h = act ? row[i0 + lane] : 0ull;
+            u64 h = h0;
             bool ov = false;
+            u64 B = HIT_ID(h);
+            const int LB = act ? (int)HIT_LEN(h) : k;
+            const bool blong = LB > DISCO_SHORT_MAX;
+            const bool fast = act && a_lds && !blong;
+            { /* the rows into the lanes' staging rows */
+                u64 *d = s_b + 1 + lane * BST;
+                d[0] = R0.q0.x, d[1] = R0.q0.y, d[2] = R0.q1.x, d[3] = R0.q1.y, d[4] = R0.q2.x, d[5] = R0.q2.y, d[6] = R0.q3.x, d[7] = R0.q3.y;
+            }
+            if (act && B >= a.v.n) { /* (a tail row's id: a long candidate, compared where it lies below) */
+                B = a.v.long_ids[B - a.v.n];
+                h = (h & ~(0x7FFFFFFFull << 17)) | (B << 17);
+            }
             if (act) {
-                const int j = (int)HIT_J(h), LB = (int)HIT_LEN(h);
+                const int j = (int)HIT_J(h);
                 const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
-                u64 B = HIT_ID(h);
-                if (B >= a.v.n) {
-                    B = a.v.long_ids[B - a.v.n];
-                    h = (h & ~(0x7FFFFFFFull << 17)) | (B << 17);
-                }
-                const bool blong = LB > DISCO_SHORT_MAX;
-                const int SB = blong ? a.v.SL : a.v.S;
-                const u64 *gb = blong ? a.v.full + (u64)a.v.ovf[B] * SB : a.v.reads + B * SB;
                 const bool prefix_align = (suf == rev);
                 const int d = prefix_align ? j : j + k - LB;
                 const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
@@ -2204,17 +2312,57 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                     contain = d >= 0;           /* :547 */
                     overlap = d <= 0 && j >= 1; /* :591 */
                 }
-                if (seg_equal2(ga, SA, gb, SB, LB, j, prefix_align ? 0 : LB - k, k, rev)) {
-                    my_khits++;
-                    if (seg_equal2(ga, SA, gb, SB, LB, x0, x0 - d, x1 - x0, rev)) {
-                        if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
-                        ov = overlap;
+                bool kmer_ok, region_ok;
+                if (fast) {
+                    /* T[X] == B[X - dd] for X in [X0, X1), T = A or revcomp(A) (verify_kernel's staged compare) */
+                    const u64 *T = rev ? s_arc + 1 : s_a + 1;
+                    const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
+                    const int dd = rev ? LA - LB - d : d;
+                    const int w0 = X0 >> 5, nlw = ((X1 - 1) >> 5) - w0; /* <= 8: the region is at most LB <= 256 bases */
+                    const int p = 32 * w0 - dd; /* >= -31: at most one word in front of the row is touched */
+                    const u64 *bp = s_b + 1 + lane * BST + (p >> 5);
+                    const int sh = (p & 31) * 2;
+                    const u64 firstmask = ~0ull >> (2 * (X0 & 31)), lastmask = ~0ull << (62 - 2 * ((X1 - 1) & 31));
+                    u64 diff = 0, fx = 0, lx = 0, blo = bp[0];
+                    int ft = 0, lt = 0;
+#pragma unroll
+                    for (int t = 0; t <= VERIFY_SW; t++) {
+                        if (t <= nlw) {
+                            const u64 bhi = bp[t + 1];
+                            u64 xt = T[w0 + t] ^ ((blo << sh) | ((bhi >> 1) >> (63 - sh)));
+                            if (t == 0) xt &= firstmask;
+                            if (t == nlw) xt &= lastmask;
+                            diff |= xt;
+                            if (xt && fx == 0) fx = xt, ft = t;
+                            if (xt) lx = xt, lt = t;
+                            blo = bhi;
+                        }
                     }
+                    /* the seed k-mer sits at the start of the region (T coordinates) for types 0 / 3, at its end for 1 / 2: it matches iff the
+                     * differing base nearest that end is at least k bases in (verify_kernel) */
+                    const bool at_start = prefix_align != (rev != 0);
+                    const bool first_clean = fx == 0 || 32 * (w0 + ft) + (__clzll((long long)fx) >> 1) >= X0 + k;
+                    const bool last_clean = lx == 0 || 32 * (w0 + lt) + ((64 - __ffsll((long long)lx)) >> 1) < X1 - k;
+                    kmer_ok = at_start ? first_clean : last_clean;
+                    region_ok = diff == 0;
+                } else {
+                    const int SB = blong ? a.v.SL : a.v.S;
+                    const u64 *gb = blong ? a.v.full + (u64)a.v.ovf[B] * SB : a.v.reads + B * SB;
+                    kmer_ok = seg_equal2(ga, SA, gb, SB, LB, j, prefix_align ? 0 : LB - k, k, rev);
+                    region_ok = kmer_ok && seg_equal2(ga, SA, gb, SB, LB, x0, x0 - d, x1 - x0, rev);
+                }
+                if (kmer_ok) my_khits++;
+                if (region_ok) {
+                    if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                    ov = overlap;
                 }
             }
             const u64 mk = __ballot(ov);
             if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
             nkeep += __popcll(mk);
+            h0 = h1;
+            h1 = h2;
+            R0 = R1;
         }
         if (lane == 0) {
             if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
