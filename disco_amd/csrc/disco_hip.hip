@@ -1245,6 +1245,7 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
     auto lapms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     double t_scan = 0, t_alloc = 0, t_issued = 0, t_mirror = 0;
     u64 CH = getenv("DISCO_UPLOAD_CHUNK") ? (u64)atoll(getenv("DISCO_UPLOAD_CHUNK")) : (4ull << 20);
+    if (!ragged) CH = std::min<u64>(CH, (512ull << 20) / ((u64)stride_words * 8)); /* (a chunk of wide rows: at most 512 MB per staging buffer) */
     CH = std::max<u64>((CH + 255) & ~255ull, 256);
     const u64 n_chunks = (n + CH - 1) / CH;
     /* the lengths are checked where they are (the host has them): min_overlap < len <= min(32767, 32 * stride) (BG/Dataset.cpp:305,
