@@ -2296,10 +2296,11 @@ int disco_probe(disco_ctx *c)
 #undef VERIFY_INEXACT
             } else if (nq) {
                 va.cbits = nullptr;
-                /* reads of up to 160 bases: pairs of batches share their row fetches (verify_flat_kernel<5, 0, true>: 21.5 against 22.6 ms and
-                 * 18 GB less traffic at config 3); longer rows would take too much LDS for it (DISCO_VERIFY_CACHE=1 forces it, =0 forbids it) */
+                /* pairs of batches share their row fetches (verify_flat_kernel<·, 0, true>): 21.5 against 22.6 ms and 18 GB less traffic at config 3
+                 * (reads of up to 160 bases); 32.3 against 33.0–35.1 ms on 50 M reads of 100–250 bases, 72.9 against 76.3 with config 5's
+                 * abundances (256-base rows, 15 KB of LDS per wavefront). DISCO_VERIFY_CACHE=0 forbids it */
                 const char *vce = getenv("DISCO_VERIFY_CACHE");
-                const bool vcache = vce ? atoi(vce) != 0 : c->max_len <= 160;
+                const bool vcache = vce ? atoi(vce) != 0 : true;
                 if (flat && vcache && c->max_len <= 160) hipLaunchKernelGGL((verify_flat_kernel<5, 0, true>), dim3(wq_grid(c, verify_flat_kernel<5, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat && vcache) hipLaunchKernelGGL((verify_flat_kernel<8, 0, true>), dim3(wq_grid(c, verify_flat_kernel<8, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat && c->max_len <= 160) hipLaunchKernelGGL(verify_flat_kernel<5>, dim3(wq_grid(c, verify_flat_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
