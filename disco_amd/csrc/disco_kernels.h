@@ -2228,6 +2228,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
     __shared__ u64 s_a[VL_ACAP + 12];   /* [0] = 0, [1 ..] = the long read, zeros behind */
     __shared__ u64 s_arc[VL_ACAP + 12]; /* same layout: its reverse complement, left aligned */
     __shared__ u64 s_b[1 + 64 * BST];
+    __shared__ u64 s_def[64]; /* LONG candidates of the read, set aside: compared lane-dense, a batch of them at a time (below) */
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
@@ -2235,22 +2236,55 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
     for (u32 i = lane; i < 1 + 64 * BST; i += 64) s_b[i] = 0;
     /* the entries are taken from the work queue four at a time: rows differ in length, and a static deal left the last wavefronts
      * running alone (62 ms with 16 waves per CU, 51 with 256 per CU queued up behind each other: the same thing said with launches) */
+    /* The headers of a grab's four entries arrive together (lane = entry), and while an entry is compared the NEXT one's read (two words
+     * per lane) and first two batches of candidates are already on their way: an entry otherwise starts with three round trips in a row —
+     * header, read, candidates — each a translation miss in a buffer of tens of GB (the kernel's time is those round trips: see DESIGN.md). */
+    constexpr int VW = (VL_ACAP + 12 + 63) / 64; /* words of the staging area per lane */
+    const int SA = a.v.SL;
     u64 qb = 0, qe = 0;
-    while (wq_grab<4>(a.v.wq, (u64)nl, qb, qe))
-    for (u32 it = (u32)qb; it < (u32)qe; it++) { /* entry `it` of the list: header, position, id and number of the long read — nothing to chase */
-        const ulonglong2 meta = lmeta[it];
+    while (wq_grab<4>(a.v.wq, (u64)nl, qb, qe)) {
+    const u32 ne = (u32)(qe - qb);
+    const u32 el = lane < ne ? lane : ne - 1u;
+    const ulonglong2 meta_l = lmeta[qb + el];
+    const u32 lpos_l = lpos[qb + el];
+    const uint2 linfo_l = linfo[qb + el];
+    u64 pre_aw[VW], pre_h0 = 0, pre_h1 = 0;
+    auto prefetch = [&](u32 e) { /* (every address comes from the headers: nothing to chase; clamped, unconditional) */
+        const u64 rs = readlane_u64(meta_l.x, e), my = readlane_u64(meta_l.y, e);
+        const u32 cc = (u32)my;
+        const int aw = ((int)(my >> 32) + 31) >> 5;
+        const u64 *g = a.v.full + (u64)(u32)__builtin_amdgcn_readlane((int)linfo_l.y, (int)e) * SA;
+#pragma unroll
+        for (int t = 0; t < VW; t++) {
+            const int w = (int)lane + 64 * t; /* staging word w holds word w - 1 of the read */
+            pre_aw[t] = g[(w >= 1 && w <= aw) ? w - 1 : 0];
+        }
+        const u64 *r = a.hits + rs;
+        pre_h0 = r[lane < cc ? lane : cc - 1u];
+        pre_h1 = r[64u + lane < cc ? 64u + lane : cc - 1u];
+    };
+    prefetch(0);
+    for (u32 e = 0; e < ne; e++) { /* entry qb + e of the list: header, position, id and number of the long read */
+        const ulonglong2 meta = make_ulonglong2(readlane_u64(meta_l.x, e), readlane_u64(meta_l.y, e));
         const u32 c = (u32)meta.y;
-        const u32 ci = lpos[it];
-        const uint2 inf = linfo[it];
-        const u64 A = inf.x;
+        const u32 ci = (u32)__builtin_amdgcn_readlane((int)lpos_l, (int)e);
+        const u64 A = (u32)__builtin_amdgcn_readlane((int)linfo_l.x, (int)e);
         const int LA = (int)(meta.y >> 32);
-        const int SA = a.v.SL;
-        const u64 *ga = a.v.full + (u64)inf.y * SA;
+        const u64 *ga = a.v.full + (u64)(u32)__builtin_amdgcn_readlane((int)linfo_l.y, (int)e) * SA;
         const int AW = (LA + 31) >> 5;
         const bool a_lds = AW <= VL_ACAP;
+        u64 aw_now[VW];
+#pragma unroll
+        for (int t = 0; t < VW; t++) aw_now[t] = pre_aw[t];
+        u64 h0 = lane < c ? pre_h0 : 0ull, h1 = 64u + lane < c ? pre_h1 : 0ull;
+        if (e + 1u < ne) prefetch(e + 1u);
         __syncthreads();
         if (a_lds) {
-            for (int w = (int)lane; w < VL_ACAP + 12; w += 64) s_a[w] = (w >= 1 && w <= AW) ? ga[w - 1] : 0ull;
+#pragma unroll
+            for (int t = 0; t < VW; t++) {
+                const int w = (int)lane + 64 * t;
+                if (w < VL_ACAP + 12) s_a[w] = (w >= 1 && w <= AW) ? aw_now[t] : 0ull;
+            }
             __syncthreads();
             /* word i of revcomp(A) = reverse complement of A[LA - 32(i+1), LA - 32i); what lies beyond the read is masked by every consumer */
             for (int w = (int)lane; w < VL_ACAP + 12; w += 64) {
@@ -2278,7 +2312,80 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
             r.q0 = q[0], r.q1 = q[1], r.q2 = q[2], r.q3 = q[3];
             return r;
         };
-        u64 h0 = load_cand(0), h1 = load_cand(64);
+        /* A long candidate of a long read has no 64-byte row; its region can be as long as the shorter of the two. One such lane in a batch
+         * used to send the whole wavefront through the word-by-word compare on global memory (seg_equal2: some forty dependent loads) —
+         * with 6 % long reads 98 % of the batches had one, and that, not the short candidates, was the kernel's time. They are set aside
+         * (s_def) and compared together when 64 have gathered or the row ends: T from the staged read, B's words straight from its full
+         * row, four loads in flight per step, no early exit. */
+        u32 ndef = 0;
+        auto flush = [&]() {
+            __syncthreads();
+            const bool actd = lane < ndef;
+            const u64 h = actd ? s_def[lane] : 0ull;
+            bool ov = false;
+            if (actd) {
+                const int j = (int)HIT_J(h), LB = (int)HIT_LEN(h);
+                const u64 B = HIT_ID(h);
+                const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
+                const bool prefix_align = (suf == rev);
+                const int d = prefix_align ? j : j + k - LB;
+                const int x0 = d > 0 ? d : 0, x1 = min(LA, d + LB);
+                bool contain, overlap;
+                if (prefix_align) {
+                    contain = LA - j >= LB;       /* BG/OverlapGraph.cpp:532 */
+                    overlap = !contain && j >= 1; /* :579 */
+                } else {
+                    contain = d >= 0;           /* :547 */
+                    overlap = d <= 0 && j >= 1; /* :591 */
+                }
+                const u64 *T = rev ? s_arc + 1 : s_a + 1;
+                const int X0 = rev ? LA - x1 : x0, X1 = rev ? LA - x0 : x1;
+                const int dd = rev ? LA - LB - d : d;
+                const int w0 = X0 >> 5, nlw = ((X1 - 1) >> 5) - w0;
+                const int p = 32 * w0 - dd; /* >= -31 */
+                const int bw = p >> 5, sh = (p & 31) * 2, BW = (LB + 31) >> 5;
+                const u64 *gb = a.v.full + (u64)a.v.ovf[B] * SA;
+                auto Bw = [&](int i) { /* word i of B, zero outside (unconditional load) */
+                    const bool ok = i >= 0 && i < BW;
+                    const u64 x = gb[ok ? i : 0];
+                    return ok ? x : 0ull;
+                };
+                const u64 firstmask = ~0ull >> (2 * (X0 & 31)), lastmask = ~0ull << (62 - 2 * ((X1 - 1) & 31));
+                u64 diff = 0, fx = 0, lx = 0, blo = Bw(bw);
+                int ft = 0, lt = 0;
+                for (int t0 = 0; t0 <= nlw; t0 += 4) {
+                    u64 b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) b[u] = Bw(bw + t0 + u + 1);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int t = t0 + u;
+                        if (t <= nlw) {
+                            u64 xt = T[w0 + t] ^ ((blo << sh) | ((b[u] >> 1) >> (63 - sh)));
+                            if (t == 0) xt &= firstmask;
+                            if (t == nlw) xt &= lastmask;
+                            diff |= xt;
+                            if (xt && fx == 0) fx = xt, ft = t;
+                            if (xt) lx = xt, lt = t;
+                            blo = b[u];
+                        }
+                    }
+                }
+                const bool at_start = prefix_align != (rev != 0);
+                const bool first_clean = fx == 0 || 32 * (w0 + ft) + (__clzll((long long)fx) >> 1) >= X0 + k;
+                const bool last_clean = lx == 0 || 32 * (w0 + lt) + ((64 - __ffsll((long long)lx)) >> 1) < X1 - k;
+                if (at_start ? first_clean : last_clean) my_khits++;
+                if (diff == 0) {
+                    if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                    ov = overlap;
+                }
+            }
+            const u64 mk = __ballot(ov);
+            if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+            nkeep += __popcll(mk);
+            ndef = 0;
+            __syncthreads();
+        };
         Rows R0 = load_rows(h0);
         for (u32 i0 = 0; i0 < c; i0 += 64) {
             const u64 h2 = load_cand(i0 + 128);
@@ -2294,11 +2401,20 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                 u64 *d = s_b + 1 + lane * BST;
                 d[0] = R0.q0.x, d[1] = R0.q0.y, d[2] = R0.q1.x, d[3] = R0.q1.y, d[4] = R0.q2.x, d[5] = R0.q2.y, d[6] = R0.q3.x, d[7] = R0.q3.y;
             }
-            if (act && B >= a.v.n) { /* (a tail row's id: a long candidate, compared where it lies below) */
+            if (act && B >= a.v.n) { /* (a tail row's id: a long candidate) */
                 B = a.v.long_ids[B - a.v.n];
                 h = (h & ~(0x7FFFFFFFull << 17)) | (B << 17);
             }
-            if (act) {
+            const bool defer = act && blong && a_lds;
+            {
+                const u64 dm = __ballot(defer);
+                if (dm) { /* (wave uniform) */
+                    if (ndef + (u32)__popcll(dm) > 64u) flush();
+                    if (defer) s_def[ndef + (u32)__popcll(dm & lane_mask_lt())] = h;
+                    ndef += (u32)__popcll(dm);
+                }
+            }
+            if (act && !defer) {
                 const int j = (int)HIT_J(h);
                 const u32 suf = HIT_SUFFIX(h), rev = HIT_REV(h);
                 const bool prefix_align = (suf == rev);
@@ -2364,11 +2480,13 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
             h1 = h2;
             R0 = R1;
         }
+        if (ndef) flush();
         if (lane == 0) {
             if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
             my_raw += nkeep;
             a.meta_ord[ci].y = (u64)nkeep | ((u64)LA << 32);
         }
+    }
     }
     for (int o = 32; o > 0; o >>= 1) my_khits += __shfl_down(my_khits, o);
     if (lane == 0) {
