@@ -745,7 +745,7 @@ static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
 static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short_max)
 {
     if (c->comm || c->dist_reads || !c->reads_owned || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
-    if (S <= VERIFY_SW || n_long == 0 || n_long * 16 > n || n + n_long >= (1ull << 31)) return false;
+    if (S <= VERIFY_SW || n_long == 0 || n_long * (u64)env_int("DISCO_TWO_CLASS_ONE_IN", 5) > n || n + n_long >= (1ull << 31)) return false;
     /* the short class takes the paths of a pure short set (minimizer runs, flat verify); the long one the lists those paths keep */
     return runs_lpr_for(c, c->k - view(c).m + 1, short_max, n) != 0;
 }

@@ -2044,7 +2044,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
  * two classes of rows (DiscoView: full / ovf / long_ids / tailb). The reference has no stride: a read is as long as it is
  * (BG/HashTable.cpp:456-477 packs every read at its own length). A table with one stride pays for its longest read in every row —
  * 0.1 % reads of 600 bases made every row 192 bytes and took the staged kernels away from the other 99.9 %. So: reads of more than
- * 256 bases ("long", at most one in sixteen; otherwise the table keeps one stride) leave the 64-byte table
+ * 256 bases ("long", at most one in five; otherwise the table keeps one stride) leave the 64-byte table
  * except for their two ENDS, which is all that a short read can overlap them with: the head stays in the read's own row, the tail
  * becomes row n + j, and the suffix record of the index names that row. The short class then runs the kernels of a pure short set
  * unchanged (a tail row is a row like any other until a verified hit is written down: its id becomes the read's again). The long

@@ -144,7 +144,7 @@ uint32_t disco_stride_words(const disco_ctx *ctx);
 uint64_t disco_num_reads(const disco_ctx *ctx);
 /* Two classes of rows. The reference packs every read at its own length (BG/HashTable.cpp:456-477: no stride); a table with one stride
  * pays for its longest read in every row. When a set handed over with a stride of more than 8 words has only a few reads of more
- * than 256 bases (at most one in sixteen; single GPU, exact overlaps, a window length the minimizer runs
+ * than 256 bases (at most one in five: beyond that the rows of one stride are no worse; single GPU, exact overlaps, a window length the minimizer runs
  * are built for), the table is laid out in two classes: 64-byte rows for everybody (a long read's row holds its head; its tail gets a row
  * of its own) plus full rows for the long reads only — the short reads then run exactly the kernels of a pure short set. The uploads
  * and the device input stage pack the classes directly (the table of one stride — n rows as wide as the longest read — is never made

@@ -91,7 +91,7 @@ def test_the_table_comes_back_as_it_was_handed_over():
 
 def test_sets_that_keep_one_stride():
     # too many long reads, and a window length without minimizer runs: the one-stride paths, same results
-    for reads, mo in ((mixed_reads(14, 3000, 150, 150, 30.0, 0.2, 300, 600), 40), (mixed_reads(15, 3000, 150, 150, 30.0, 0.03, 300, 600), 80)):
+    for reads, mo in ((mixed_reads(14, 3000, 150, 150, 30.0, 0.4, 300, 600), 40), (mixed_reads(15, 3000, 150, 150, 30.0, 0.03, 300, 600), 80)):
         with buildgraph.BuildGraph(min_overlap=mo) as g:
             g.upload_ascii(reads)
             g.run_graph()

@@ -14,7 +14,7 @@ from tests.util import assert_parity
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 inexact = len(sys.argv) > 3 and sys.argv[3] == "inexact"
-tail = len(sys.argv) > 3 and sys.argv[3] == "tail"  # "runs" shapes with a tail of long reads (257..1024 bases, 0.1-6 %): the two classes of rows
+tail = len(sys.argv) > 3 and sys.argv[3] == "tail"  # "runs" shapes with a tail of long reads (257..8000 bases, 0.1-19 %): the two classes of rows
 runs = len(sys.argv) > 3 and sys.argv[3] == "runs" or tail
 fails = 0
 t0 = time.time()
@@ -46,7 +46,7 @@ for it in range(iters):
     label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} err={err} tsub={tsub}"
     try:
         long_len = int(rng.choice([257, 300, 400, 600, 1000, 1024, 1025, 2000, 8000])) if tail else 0
-        long_share = int(rng.choice([66, 300, 1300, 3900])) if tail else 0
+        long_share = int(rng.choice([66, 300, 1300, 3900, 9800, 12500])) if tail else 0  # (up to 19 %: the limit of the two classes is one in five)
         spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew, long_len=long_len, long_share=long_share)
         reads = list(readgen.generate_reads(spec))
         if tail:
