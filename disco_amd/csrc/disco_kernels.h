@@ -1196,6 +1196,16 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
  * (BG/OverlapGraph.cpp:424,449); the recorded row is the first hit in (j, bucket order).
  * Candidates that are not overlap hits are overwritten with ~0 (dropped later by edge selection).
  * ============================================================================================================== */
+/* A read B contained in A at one alignment is found twice in A's row: where B's prefix k-mer lies (the hit that is aligned by its prefix:
+ * j = the alignment's offset d) and where its suffix k-mer lies (j = d + LB - k) — unless that window is A's own last one, which the
+ * probe does not look up. Both compare the same bases; the containment key orders by (A, j, ...), so the second can never be the
+ * minimum: only the first goes to the atomicMin (half the atomics on read sets in which most reads are contained). Exact overlaps
+ * only: with substitutions allowed the prefix k-mer may be the one that carries one, and then only the second hit exists. */
+#ifndef VERIFY_EXP_ALL_CONTAIN_KEYS
+#define CONTAIN_KEY_HIT(prefix_align) (prefix_align)
+#else
+#define CONTAIN_KEY_HIT(prefix_align) true
+#endif
 struct VerifyArgs {
     DiscoView v;
     u64 *best;
@@ -1525,7 +1535,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                     const bool full_ok = region_ok && kmer_ok;
                     if (kmer_ok) my_khits++;
                     if (full_ok) {
-                        if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                        if (contain && (INEXACT || CONTAIN_KEY_HIT(prefix_align)) && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                         ov = overlap;
                     }
                     /* does B see this pair from its side? Its window there is A's end k-mer inside the overlap — the region's other
@@ -1537,7 +1547,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                         my_khits++;
                         if (INEXACT ? seg_mismatches<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev) <= a.max_subs
                                     : seg_equal<false>(ga, gb, S, LB, x0, x0 - d, x1 - x0, rev)) {
-                            if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                            if (contain && (INEXACT || CONTAIN_KEY_HIT(prefix_align)) && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                             ov = overlap;
                             if (INEXACT && ov) hidden = !seg_equal<false>(ga, gb, S, LB, hk, hk - d, k, rev);
                         }
@@ -1918,7 +1928,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             if (kmer_ok) my_khits++;
             bool ov = false;
             if (region_ok) {
-                if (contain && (LA > LB || (LA == LB && Aseg < B))) atomicMin(&a.best[B], CKEY_MAKE(Aseg, j, suf, rev));
+                if (contain && CONTAIN_KEY_HIT(prefix_align) && (LA > LB || (LA == LB && Aseg < B))) atomicMin(&a.best[B], CKEY_MAKE(Aseg, j, suf, rev));
                 ov = overlap;
             }
             /* compact the verified overlap hits to the front of their segment's row (writes never pass the candidates still to be read) */
@@ -2376,7 +2386,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                 const bool last_clean = lx == 0 || 32 * (w0 + lt) + ((64 - __ffsll((long long)lx)) >> 1) < X1 - k;
                 if (at_start ? first_clean : last_clean) my_khits++;
                 if (diff == 0) {
-                    if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                    if (contain && CONTAIN_KEY_HIT(prefix_align) && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                     ov = overlap;
                 }
             }
@@ -2469,7 +2479,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                 }
                 if (kmer_ok) my_khits++;
                 if (region_ok) {
-                    if (contain && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
+                    if (contain && CONTAIN_KEY_HIT(prefix_align) && (LA > LB || (LA == LB && A < B))) atomicMin(&a.best[B], CKEY_MAKE(A, j, suf, rev));
                     ov = overlap;
                 }
             }
