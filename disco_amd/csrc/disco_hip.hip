@@ -1911,6 +1911,9 @@ int disco_substitute_bases(disco_ctx *c, uint64_t seed, uint32_t rate_ppm)
     if (!c) return DISCO_E_ARG;
     if (c->phase != 1) return fail(c, DISCO_E_STATE, "disco_substitute_bases: call after the reads are set and before disco_build_index");
     if (rate_ppm > 1000000) return fail(c, DISCO_E_ARG, "disco_substitute_bases: rate above 10^6 ppm");
+    if (c->two_class) /* (uploaded / ingested with a tail of long reads: head, tail and full rows would have to change together) */
+        return fail(c, DISCO_E_UNSUPPORTED, "disco_substitute_bases: the table has two classes of rows (reads of more than 256 bases next to short ones); substitute "
+                                            "into generated reads, or set DISCO_NO_TWO_CLASS=1");
     HIPCHK(c, hipSetDevice(c->device));
     const u64 lo = c->comm ? c->q_lo : 0, hi = c->comm ? c->q_hi : c->n; /* multi-GPU flow: the other ranks' rows arrive by all-gather */
     if (hi > lo && rate_ppm)
@@ -1974,6 +1977,9 @@ static int two_class_alloc(disco_ctx *c, u64 n_long, int Sx, u32 short_max)
     c->S = VERIFY_SW;
     c->tailb = short_max <= 160 ? 160 : 256; /* what the staged compare of the short class moves per row (verify_flat_kernel<5 / 8>) */
     c->two_class = true;
+    if (getenv("DISCO_VERBOSE"))
+        fprintf(stderr, "[disco] two classes of rows: %llu of %llu reads are longer than 256 bases, the others up to %u: 64-byte rows + %d-word rows for those\n",
+                (unsigned long long)n_long, (unsigned long long)c->n, short_max, Sx);
     return DISCO_OK;
 }
 
@@ -2005,9 +2011,6 @@ static int two_class_convert(disco_ctx *c)
     c->d_reads = rows8;
     c->max_len_all = c->max_len;
     c->max_len = short_max;
-    if (getenv("DISCO_VERBOSE"))
-        fprintf(stderr, "[disco] two classes of rows: %llu of %llu reads are longer than 256 bases (up to %u), the others up to %u: 64-byte rows + %d-word rows for those\n",
-                (unsigned long long)n_long, (unsigned long long)c->n, c->max_len_all, short_max, Sx);
     return DISCO_OK;
 }
 

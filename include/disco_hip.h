@@ -136,7 +136,8 @@ int disco_adopt_reads(disco_ctx *ctx, const void *d_packed, uint32_t stride_word
 int disco_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
 /* substitution errors into the resident reads, in place (bench / tests of the inexact-overlap extension): every base of this
  * context's reads — of the rank's own range in the multi-GPU flow — is replaced by another one with probability rate_ppm / 10^6,
- * a pure function of (seed, read, position) (csrc/readgen.h; numpy twin: disco_amd/readgen.py). Before disco_build_index. */
+ * a pure function of (seed, read, position) (csrc/readgen.h; numpy twin: disco_amd/readgen.py). Before disco_build_index; not on an
+ * uploaded / ingested table that got two classes of rows (disco_long_rows: DISCO_E_UNSUPPORTED). */
 int disco_substitute_bases(disco_ctx *ctx, uint64_t seed, uint32_t rate_ppm);
 /* copy the packed reads / lengths back to the host (tests, writer) */
 int disco_download_reads(disco_ctx *ctx, uint64_t *packed, uint16_t *len);

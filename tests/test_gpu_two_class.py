@@ -243,3 +243,14 @@ def test_ten_million_reads_with_a_tail_equal_the_one_stride_pass(monkeypatch):
     for key in ("probes", "kmer_hits", "n_contained", "e_pre", "e_out", "cap_bind_sites", "asymmetric_pairs"):
         assert k1[key] == k2[key], key
     assert k2["cap_bind_sites"] == 0 and k2["asymmetric_pairs"] == 0  # (inside the order-independent domain: the reference's result too)
+
+
+def test_substitutions_are_refused_on_an_uploaded_table_with_two_classes():
+    reads = mixed_reads(51, 2000, 150, 150, 30.0, 0.03, 300, 600)
+    with buildgraph.BuildGraph(min_overlap=40) as g:
+        g.upload_ascii(reads)
+        assert g.long_rows > 0
+        with pytest.raises(buildgraph.DiscoError, match="two classes of rows"):
+            g.substitute_bases(3, 1000)
+        g.run_graph()  # the table is untouched
+        assert g.counters()["e_out"] > 0
