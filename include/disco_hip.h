@@ -46,7 +46,11 @@ enum {
                                          containment-type candidates first, fix the contained flags, then fetch rows only for the
                                          overlap-type candidates of non-contained reads — about half the row fetches where most
                                          reads are contained (metagenomes). Results are unchanged; disco_counters.kmer_hits and
-                                         .raw_hits then count the compared candidates only (the reference has no such counters) */
+                                         .raw_hits then count the compared candidates only (the reference has no such counters).
+                                         Round 4: since the single pass sends one containment key per alignment instead of two it is
+                                         the faster form on the shapes measured (50 M reads of 100-250 bases: 31 against 39 ms of
+                                         verify); the flag stays for read sets it still helps and is ignored on a table with two
+                                         classes of rows (disco_long_rows) */
 
 typedef struct disco_ctx disco_ctx;
 
