@@ -8,6 +8,13 @@ transitive reduction -> emission) over reads that are already resident in HBM, r
           RCCL collective inside libdisco_hip.so (disco_dist_run_graph).  value = E_pre of the whole job / max-over-ranks time.
           `python bench.py --gpus N` without a launcher starts its own N ranks (a child torch.distributed.run).
 Prints ONE JSON line on rank 0.
+
+Which timer `value` is (three walls are in the line; tests/test_gpu_bench.py asserts this mapping). The build contract of this repository
+(task statement, section "Measurement") defines it in these words: "`value` is whole-job throughput with inputs already resident in HBM
+when the timed region starts (if the boundary hands over host buffers, note the PCIe-inclusive rate in DESIGN.md — it is never `value`)".
+So:  value                  = E_pre / (HBM-resident pass), "timer": "hbm_resident"  — the contract's definition, quoted above;
+     value_host_to_host     = SURVEY.md §8(d)'s *graph* wall t_graph: pinned host buffers in -> host structs out (PCIe inclusive; DESIGN.md §5);
+     stage_drop_in.wall_s   = SURVEY.md §8(d)'s *stage* wall: buildG's argv to files closed.
 """
 from __future__ import annotations
 

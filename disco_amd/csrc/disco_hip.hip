@@ -672,25 +672,30 @@ static void free_graph_state(disco_ctx *c)
     c->n_push_r = 0;
 }
 
+/* the buffers of the long class (two classes of rows) — whatever of them exists: a failed two_class_alloc leaves some behind with
+ * two_class still false, and the next table must not find a d_ovf sized for this one */
+static void free_long_class(disco_ctx *c)
+{
+    dev_free(c, &c->d_full, c->n_long * (u64)c->S_ext);
+    dev_free(c, &c->d_ovf, c->n_alloc);
+    dev_free(c, &c->d_long_ids, c->n_long);
+    dev_free(c, &c->d_lpos, c->n_long);
+    dev_free(c, &c->d_lmeta, c->n_long);
+    dev_free(c, &c->d_linfo, c->n_long);
+    dev_free(c, &c->d_n_list, 1);
+    c->two_class = false;
+    c->n_long = c->reads_rows = 0;
+    c->S_ext = 0;
+    c->tailb = 0;
+}
+
 static void free_reads(disco_ctx *c)
 {
     if (c->reads_owned) {
         dev_free(c, &c->d_reads, (c->reads_rows ? c->reads_rows : c->n_alloc) * (u64)c->S);
         dev_free(c, &c->d_len, c->n_alloc);
     }
-    if (c->two_class) {
-        dev_free(c, &c->d_full, c->n_long * (u64)c->S_ext);
-        dev_free(c, &c->d_ovf, c->n_alloc);
-        dev_free(c, &c->d_long_ids, c->n_long);
-        dev_free(c, &c->d_lpos, c->n_long);
-        dev_free(c, &c->d_lmeta, c->n_long);
-        dev_free(c, &c->d_linfo, c->n_long);
-        dev_free(c, &c->d_n_list, 1);
-    }
-    c->two_class = false;
-    c->n_long = c->reads_rows = 0;
-    c->S_ext = 0;
-    c->tailb = 0;
+    free_long_class(c);
     c->d_reads = nullptr;
     c->d_len = nullptr;
     c->reads_owned = false;
@@ -742,9 +747,11 @@ static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
 }
 
 /* may a table of stride S (words) with n_long reads of more than 256 bases — the others at most short_max — go to two classes of rows? */
-static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short_max)
+/* will_own: the caller is about to replace the table by one the context owns (an upload, the input stage) — the flag itself is only
+ * set once the old table has been released and the new buffers exist (a table adopted from the caller must never be freed or kept) */
+static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short_max, bool will_own = false)
 {
-    if (c->comm || c->dist_reads || !c->reads_owned || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
+    if (c->comm || c->dist_reads || !(c->reads_owned || will_own) || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
     if (S <= VERIFY_SW || n_long == 0 || n_long * (u64)env_int("DISCO_TWO_CLASS_ONE_IN", 5) > n || n + n_long >= (1ull << 31)) return false;
     /* the short class takes the paths of a pure short set (minimizer runs, flat verify); the long one the lists those paths keep */
     return runs_lpr_for(c, c->k - view(c).m + 1, short_max, n) != 0;
@@ -1290,17 +1297,18 @@ static int upload_reads_impl(disco_ctx *c, const char *who, const uint64_t *pack
     /* rows are padded to a multiple of 8 words = 64 B so that a candidate row fetch touches whole, aligned HBM sectors */
     const uint32_t dstride = (stride_words + 7u) & ~7u;
     if (a_bad.load()) {
-        bool kept0 = false; /* (the context is left with no reads, as before) */
-        (void)set_reads_common(c, 0, dstride, &kept0);
+        /* the context is left with no reads: the stride of the empty table is any valid one (the bad length itself may ask for more
+         * than set_reads_common accepts, and its refusal would leave the PREVIOUS reads and graph in place) */
+        (void)set_reads_common(c, 0, VERIFY_SW, nullptr);
         return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)a_bad.load(), c->prm.min_overlap);
     }
     /* a few long reads among short ones: the chunks are unpacked per class (two classes of rows, disco_kernels.h) — the table of one
      * stride is never made on the device */
-    c->reads_owned = true;
     const u64 n_long = a_long.load();
-    const bool classes = n && two_class_ok(c, (int)dstride, n, n_long, a_smax.load());
+    const bool classes = n && two_class_ok(c, (int)dstride, n, n_long, a_smax.load(), true);
     bool kept = false;
     CHK(set_reads_common(c, n, classes ? (uint32_t)VERIFY_SW : dstride, classes ? nullptr : &kept));
+    c->reads_owned = true; /* the old table is gone (or kept, and then it was the context's own): whatever is allocated from here on is released by free_reads */
     if (classes) {
         CHK(dev_alloc(c, &c->d_reads, (n + n_long) * 8));
         CHK(dev_alloc(c, &c->d_len, n));
@@ -1591,6 +1599,8 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
             c->d_ingest = (u8 *)c->arena.base;
             c->ingest_cap = c->arena.size;
             c->arena = DevArena();
+            c->hbm_bytes += c->ingest_cap; /* (counted as one buffer again: the handover below took it out of the sum) */
+            c->hbm_peak = std::max(c->hbm_peak, c->hbm_bytes);
         }
         const bool split = !getenv("DISCO_INGEST_SHARED_ARENA") && !c->arena.base && (u64)fr + c->hits_cap * 8 + c->ingest_cap > std::max(want, c->hits_cap) * 8 + own_bytes + rest + (16ull << 30);
         if (split) {
@@ -1740,12 +1750,12 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         bool kept = false;
         /* a few long reads among short ones: the rows are packed per class straight from the text (two classes of rows, disco_kernels.h) —
          * the table of one stride, n rows as wide as the longest read, is never made */
-        c->reads_owned = true;
-        const bool classes = two_class_ok(c, (int)dstride, n_good, n_long_reads, short_max);
+        const bool classes = two_class_ok(c, (int)dstride, n_good, n_long_reads, short_max, true);
         const int src = set_reads_common(c, n_good, classes ? (uint32_t)VERIFY_SW : dstride, classes ? nullptr : &kept);
         c->d_hits = keep_hits;
         c->hits_cap = keep_cap;
         CHK(src);
+        c->reads_owned = true; /* (as in upload_reads_impl: only now) */
         if (classes) {
             CHK(dev_alloc(c, &c->d_reads, (n_good + n_long_reads) * 8));
             CHK(dev_alloc(c, &c->d_len, n_good));
@@ -1815,6 +1825,9 @@ extern "C" int disco_ingest_fasta(disco_ctx *c, const char *const *paths, int n_
         c->arena.base = (char *)c->d_ingest;
         c->arena.size = c->ingest_cap & ~(u64)255;
         c->arena.free_at[0] = c->arena.size;
+        /* what the allocator serves out of it is counted buffer by buffer (dev_alloc): the arena itself leaves the sum, or every byte of
+         * it would count twice in hbm_bytes / hbm_peak */
+        c->hbm_bytes = c->hbm_bytes >= c->ingest_cap ? c->hbm_bytes - c->ingest_cap : 0;
         c->d_ingest = nullptr;
         c->ingest_cap = 0;
     }
@@ -1964,16 +1977,22 @@ int disco_set_query_range(disco_ctx *c, uint64_t lo, uint64_t hi)
  * themselves (d_reads: [n + n_long][8]) are the caller's */
 static int two_class_alloc(disco_ctx *c, u64 n_long, int Sx, u32 short_max)
 {
-    if (!c->d_ovf) CHK(dev_alloc(c, &c->d_ovf, c->n_alloc));
-    CHK(dev_alloc(c, &c->d_full, n_long * (u64)Sx));
-    CHK(dev_alloc(c, &c->d_long_ids, n_long));
-    CHK(dev_alloc(c, &c->d_lpos, n_long));
-    CHK(dev_alloc(c, &c->d_lmeta, n_long));
-    CHK(dev_alloc(c, &c->d_linfo, n_long));
-    CHK(dev_alloc(c, &c->d_n_list, 1));
-    c->reads_rows = c->n + n_long;
+    /* (the sizes first: free_long_class accounts with them, also for what a failure below leaves behind) */
     c->n_long = n_long;
     c->S_ext = Sx;
+    int rc = DISCO_OK;
+    if (!c->d_ovf) rc = dev_alloc(c, &c->d_ovf, c->n_alloc);
+    if (rc == DISCO_OK) rc = dev_alloc(c, &c->d_full, n_long * (u64)Sx);
+    if (rc == DISCO_OK) rc = dev_alloc(c, &c->d_long_ids, n_long);
+    if (rc == DISCO_OK) rc = dev_alloc(c, &c->d_lpos, n_long);
+    if (rc == DISCO_OK) rc = dev_alloc(c, &c->d_lmeta, n_long);
+    if (rc == DISCO_OK) rc = dev_alloc(c, &c->d_linfo, n_long);
+    if (rc == DISCO_OK) rc = dev_alloc(c, &c->d_n_list, 1);
+    if (rc != DISCO_OK) {
+        free_long_class(c);
+        return rc;
+    }
+    c->reads_rows = c->n + n_long;
     c->S = VERIFY_SW;
     c->tailb = short_max <= 160 ? 160 : 256; /* what the staged compare of the short class moves per row (verify_flat_kernel<5 / 8>) */
     c->two_class = true;
@@ -2000,9 +2019,14 @@ static int two_class_convert(disco_ctx *c)
         return DISCO_OK;
     }
     u64 *rows8 = nullptr, *old = c->d_reads;
-    CHK(dev_alloc(c, &rows8, (c->n + n_long) * 8));
-    c->d_ovf = ovf;
-    CHK(two_class_alloc(c, n_long, Sx, short_max));
+    c->d_ovf = ovf; /* (the context's from here on: released with the long class, also when something below fails) */
+    int rca = dev_alloc(c, &rows8, (c->n + n_long) * 8);
+    if (rca == DISCO_OK) rca = two_class_alloc(c, n_long, Sx, short_max);
+    if (rca != DISCO_OK) { /* the table keeps its one stride */
+        dev_free(c, &rows8, (c->n + n_long) * 8);
+        free_long_class(c);
+        return rca;
+    }
     hipLaunchKernelGGL(class_split_kernel, dim3(flat_grid(c, c->n * 8)), dim3(256), 0, c->stream, (const u64 *)old, Sx, (const u16 *)c->d_len, (const u32 *)ovf, c->n, c->tailb, rows8,
                        c->d_full, c->d_long_ids);
     HIPCHK(c, hipGetLastError());

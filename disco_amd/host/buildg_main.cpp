@@ -363,6 +363,11 @@ int main(int argc, char **argv)
     double t_graph = 0, t_h2d = 0;
     t0 = Clock::now();
     auto t1 = Clock::now();
+    /* what the writer thread captures by reference comes FIRST: locals die in reverse order of declaration, so the holders below join
+     * their threads before any of these goes away on an early return */
+    bool contained_early = false, contained_ok = true, edge_text_streamed = false;
+    std::string contained_err;
+    const disco::FileTags ctags_early = mpi_names ? disco::FileTags::mpi_contained(gpus, threads) : disco::FileTags::plain(threads);
     /* (threads declared before anything that may return early: their holders join on the way out) */
     struct ThreadHolder {
         std::thread t;
@@ -372,9 +377,6 @@ int main(int argc, char **argv)
         }
     } contained_writer_holder, ctx_releaser_holder;
     std::thread &contained_writer = contained_writer_holder.t, &ctx_releaser = ctx_releaser_holder.t;
-    bool contained_early = false, contained_ok = true, edge_text_streamed = false;
-    std::string contained_err;
-    const disco::FileTags ctags_early = mpi_names ? disco::FileTags::mpi_contained(gpus, threads) : disco::FileTags::plain(threads);
     auto lap = [&](const char *what) {
         if (verbose) fprintf(stderr, "[disco host] %-28s %.3f s\n", what, secs(t1));
         t1 = Clock::now();
