@@ -112,7 +112,7 @@ ABI = [
 ]
 
 FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
-XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins", "queries", "hits")
+XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins", "queries", "hits", "keys")
 UNIQUE_ID_BYTES = 128
 DIST_GATHER_READS = 1
 DIST_KEEP_INDEX_PARTITIONED = 2
@@ -139,7 +139,7 @@ class DistInfo(C.Structure):
                 ("tr_rounds", C.c_uint32), ("tr_deferred", C.c_uint64), ("bytes_sent", C.c_uint64 * len(XCHG)),
                 ("ms", C.c_float * len(XCHG)), ("ms_total", C.c_float), ("kernel_ms", C.c_float), ("comm_ops", C.c_uint32),
                 ("host_syncs", C.c_uint32), ("device_allocs", C.c_uint32), ("device_frees", C.c_uint32), ("arena_bytes", C.c_uint64),
-                ("arena_peak", C.c_uint64), ("hbm_peak", C.c_uint64)]
+                ("arena_peak", C.c_uint64), ("hbm_peak", C.c_uint64), ("own_reads", C.c_uint64), ("placement", C.c_uint32), ("reserved_", C.c_uint32)]
 
 PHASES = ("index", "probe_kernel", "verify", "contain", "select", "csr", "twin", "trmark", "emit", "order")
 

@@ -20,13 +20,16 @@ struct RouteByBucket { /* index records {bucket << 32 | slot, record} */
     u32 G;
     __device__ __forceinline__ u32 operator()(const ulonglong2 &r) const { return (u32)(((r.x >> 32) * (u64)G) >> logT); }
 };
+/* (otab: ranks own loci — the owner of a node comes out of the table; null: id ranges of `per` nodes) */
 struct RouteByRowRequest { /* u << 1 | cls */
     u64 per;
-    __device__ __forceinline__ u32 operator()(const u32 &r) const { return (u32)((u64)(r >> 1) / per); }
+    const u8 *otab;
+    __device__ __forceinline__ u32 operator()(const u32 &r) const { return otab ? (u32)otab[r >> 1] : (u32)((u64)(r >> 1) / per); }
 };
 struct RouteByNode { /* {node id, payload} */
     u64 per;
-    __device__ __forceinline__ u32 operator()(const ulonglong2 &r) const { return (u32)(r.x / per); }
+    const u8 *otab;
+    __device__ __forceinline__ u32 operator()(const ulonglong2 &r) const { return otab ? (u32)otab[r.x] : (u32)(r.x / per); }
 };
 
 #define ROUTE_ITEMS 8 /* items per thread and tile */
@@ -101,6 +104,140 @@ __global__ void add_u64_kernel(u64 *__restrict__ p, u64 n, u64 val)
     for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] += val;
 }
 
+/* ---- ranks own loci: reads dealt to the ranks by their read-level minimizer ------------------------------------------------- */
+/* the read-level minimizer keys of the reads [lo, hi) alone (okey[i] as index_count_kernel / index_runs_kernel compute it: the smallest
+ * 32-bit order hash among all m-mers of the read). The reads are dealt by this key before anything else is computed from them: the
+ * records, runs and rows of a read are the business of the rank that gets it. One thread per read, one rolling pass. */
+__global__ void __launch_bounds__(256) read_keys_kernel(DiscoView v, u64 lo, u64 hi, u32 *__restrict__ okey)
+{
+    const u64 i = lo + (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= hi) return;
+    const u64 *__restrict__ p = v.reads + i * (u64)v.S;
+    const int L = v.len[i], m = v.m, nmm = L - m + 1;
+    const u64 mask = (1ull << (2 * m)) - 1ull;
+    const int rsh = 2 * (m - 1);
+    u64 f = 0, r = 0, word = 0;
+    int pos = 0;
+    auto next = [&]() {
+        if ((pos & 31) == 0) word = p[pos >> 5];
+        const u32 b = (u32)(word >> 62);
+        word <<= 2;
+        ++pos;
+        f = ((f << 2) | b) & mask;
+        r = (r >> 2) | ((u64)(3u - b) << rsh);
+    };
+    for (int q = 0; q < m - 1; ++q) next();
+    u32 best = 0xFFFFFFFFu;
+    for (int q = 0; q < nmm; ++q) {
+        next();
+        best = min(best, order_hash32(r < f ? r : f));
+    }
+    okey[i] = best;
+}
+
+/* owner of every read from its key (disco_key_owner) and the list of the own reads' ids: in id order inside a tile of OWN_TILE reads,
+ * the tiles in the order their blocks arrive (one counting atomic per tile; the grouping that follows re-orders the list anyway) */
+#define OWN_TILE 4096
+__global__ void __launch_bounds__(256) own_select_kernel(const u32 *__restrict__ okey, u64 n, u32 G, u32 me, u8 *__restrict__ otab, u32 *__restrict__ own_ids,
+                                                         u64 *__restrict__ n_own)
+{
+    __shared__ u32 s_w[4];
+    __shared__ u64 s_base;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (u64 t0 = (u64)blockIdx.x * OWN_TILE; t0 < n; t0 += (u64)gridDim.x * OWN_TILE) {
+        u32 mask = 0, cnt = 0;
+#pragma unroll
+        for (int q = 0; q < OWN_TILE / 256; q++) {
+            const u64 i = t0 + (u64)q * 256u + tid;
+            if (i < n) {
+                const u32 o = disco_key_owner(okey[i], G);
+                otab[i] = (u8)o;
+                if (o == me) {
+                    mask |= 1u << q;
+                    cnt++;
+                }
+            }
+        }
+        const u32 incl = wave_inclusive_add(cnt);
+        __syncthreads();
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        u32 off = incl - cnt;
+        for (u32 w = 0; w < wv; w++) off += s_w[w];
+        const u32 total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (tid == 0 && total) s_base = atomicAdd((unsigned long long *)n_own, (unsigned long long)total);
+        __syncthreads();
+        u64 at = s_base + off;
+        /* (thread t holds reads t, t + 256, ...: inside the tile the list is in id order only per thread; nobody relies on it) */
+#pragma unroll
+        for (int q = 0; q < OWN_TILE / 256; q++)
+            if (mask & (1u << q)) own_ids[at++] = (u32)(t0 + (u64)q * 256u + tid);
+    }
+}
+
+/* bucket of a key in the grouping of ONE rank's reads: the rank's share of the hash range (disco_key_owner: [me, me + 1) * 2^32 / G)
+ * stretched over all 32 bits again, so that the rank's groups spread over all its buckets as the groups of a whole job do */
+__device__ __forceinline__ u32 order_bucket_local(u32 key, u32 G, u32 me, u32 shift)
+{
+    const u32 h = key * 0x9E3779B1u;
+    const u64 lo = (((u64)me << 32) + G - 1) / G; /* smallest h with (h * G) >> 32 == me */
+    const u64 x = ((u64)h - lo) * (u64)G;
+    return (u32)(x > 0xFFFFFFFFull ? 0xFFFFFFFFull : x) >> shift;
+}
+/* the grouping (order_count_kernel / order_scatter_kernel) over a list of read ids */
+__global__ void order_count_list_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ ids, u64 nq, u32 G, u32 me, u32 shift, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; t < nq; t += (u64)gridDim.x * blockDim.x) oslot[t] = atomicAdd(&cnt[order_bucket_local(okey[ids[t]], G, me, shift)], 1u);
+}
+__global__ void order_scatter_list_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ ids, const u32 *__restrict__ oslot, const u32 *__restrict__ start, u64 nq,
+                                          u32 G, u32 me, u32 shift, const u16 *__restrict__ len, u64 *__restrict__ order)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; t < nq; t += (u64)gridDim.x * blockDim.x) {
+        const u32 id = ids[t];
+        order[(u64)start[order_bucket_local(okey[id], G, me, shift)] + oslot[t]] = ORDER_MAKE(id, len[id]);
+    }
+}
+/* ... or, where no grouping is wanted (a handful of reads, DISCO_NO_ORDER), the list as it is */
+__global__ void order_pack_list_kernel(const u32 *__restrict__ ids, u64 nq, const u16 *__restrict__ len, u64 *__restrict__ order)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; t < nq; t += (u64)gridDim.x * blockDim.x) order[t] = ORDER_MAKE(ids[t], len[ids[t]]);
+}
+
+/* a bitmap by read id <-> the list of its set bits (regime 2 with ranks that own loci: the reads that dropped a hit are scattered
+ * over the id space, so their bitmap travels as lists; one counting atomic per 64 words that hold a bit) */
+__global__ void bits_to_list_kernel(const u64 *__restrict__ bits, u64 n_words, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+{
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 w0 = w - lane; w0 < n_words; w0 += (u64)gridDim.x * blockDim.x) {
+        const u64 wi = w0 + lane;
+        u64 x = wi < n_words ? bits[wi] : 0ull;
+        const u32 c = (u32)__popcll(x);
+        const u32 incl = wave_inclusive_add(c);
+        const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (!tot) continue;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd((unsigned long long *)n_list, (unsigned long long)tot);
+        base = readlane_u64(base, 0) + (incl - c);
+        if (!list) continue; /* (counting pass) */
+        while (x) {
+            const u32 b = (u32)__ffsll((long long)x) - 1u;
+            x &= x - 1;
+            if (base < cap) list[base] = (u32)(wi * 64 + b);
+            else atomicAdd((unsigned long long *)&ctr[CTR_OVERFLOW], 1ull);
+            base++;
+        }
+    }
+}
+__global__ void list_to_bits_kernel(const u32 *__restrict__ list, u64 n, u64 *__restrict__ bits)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) atomicOr((unsigned long long *)&bits[list[i] >> 6], 1ull << (list[i] & 63u));
+}
+
 /* ---- hash-partitioned index build (the owner's side) ------------------------------------------------------------------ */
 /* records received from all ranks: count per bucket of this rank's range; the atomic hands every record its slot */
 __global__ void shard_count_kernel(ulonglong2 *__restrict__ rec, u64 n, u32 *__restrict__ bkt)
@@ -121,13 +258,15 @@ __global__ void add_u32_kernel(u32 *__restrict__ p, u64 n, u32 val)
 /* ---- neighbour rows on request (transitive reduction) -------------------------------------------------------------- */
 /* both reference words of the rank's own nodes address the node's row where edge selection left it (TR_LOCAL: 8-byte entries in
  * adj; the sweep filters by type itself) */
-__global__ void nref_local_kernel(const u64 *__restrict__ ref, u64 lo, u64 nloc, u64 *__restrict__ nref)
+__global__ void nref_local_kernel(const u64 *__restrict__ ref, OwnSet own, u64 *__restrict__ nref)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 nloc = own.count();
     for (; i < nloc; i += (u64)gridDim.x * blockDim.x) {
-        const u64 r = ref[lo + i] | TR_LOCAL;
-        nref[2 * (lo + i)] = r;
-        nref[2 * (lo + i) + 1] = r;
+        const u64 v = own.node(i);
+        const u64 r = ref[v] | TR_LOCAL;
+        nref[2 * v] = r;
+        nref[2 * v + 1] = r;
     }
 }
 
@@ -149,10 +288,10 @@ __device__ __forceinline__ void request_append(u32 rq, u32 *__restrict__ list, u
 }
 
 /* the (u, cls) a sweep from this entry needs, if u is remote and nobody on this rank has asked for it yet */
-__device__ __forceinline__ u32 request_for(u64 e, u64 lo, u64 hi, u64 *__restrict__ nref)
+__device__ __forceinline__ u32 request_for(u64 e, const OwnSet &own, u64 *__restrict__ nref)
 {
     const u64 u = ADJ_DST(e);
-    if (u >= lo && u < hi) return 0xFFFFFFFFu;
+    if (own.mine(u)) return 0xFFFFFFFFu;
     const u32 cls = (~ADJ_ORI(e)) & 1u;
     if (atomicCAS(&nref[2 * u + cls], TR_UNAVAIL, TR_REQUESTED) != TR_UNAVAIL) return 0xFFFFFFFFu;
     return ((u32)u << 1) | cls;
@@ -164,11 +303,12 @@ __device__ __forceinline__ u32 request_for(u64 e, u64 lo, u64 hi, u64 *__restric
  * nodes) and count, while they are at it, the entries on either side of the node: cls_cnt[i] = entries a sweep of class 0 uses |
  * entries a sweep of class 1 uses << 16 (BG/OverlapGraph.cpp:705-708: class 1 -> types 0/1, class 0 -> types 2/3), what the owner
  * answers a request's size from (tr_respond_deg_kernel) instead of reading the row once more. 0xFFFFFFFF: too long to count here. */
-__global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, u64 lo, u64 hi,
+/* (cls_cnt is indexed by node id minus cls_base: the own range's first id, or 0 where the own nodes are no range) */
+__global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, OwnSet own,
                                                                u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr,
-                                                               u32 *__restrict__ cls_cnt)
+                                                               u32 *__restrict__ cls_cnt, u64 cls_base)
 {
-    const u64 nloc = hi - lo;
+    const u64 nloc = own.count();
     const u32 lane = threadIdx.x & 63u, sub = lane & 7u, g0 = lane & ~7u;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     __shared__ u32 s_rq[1][128]; /* (one wavefront per workgroup) the requests of a block of 64 nodes */
@@ -201,7 +341,8 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
         for (u32 t = 0; t < 8; t++) {
             const u64 i = blk + 8 * t + (lane >> 3);
             const bool live = i < nloc;
-            const u64 rv = live ? ref[lo + i] : 0ull;
+            const u64 vme = live ? own.node(i) : 0ull;
+            const u64 rv = live ? ref[vme] : 0ull;
             const u32 d = REF_DEG(rv);
             const u64 *row = adj + REF_POS(rv);
             u32 dmax = d < 65536u ? d : 0u;
@@ -231,14 +372,14 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
                 }
             }
             if (live && sub == 0) {
-                cls_cnt[i] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
+                cls_cnt[vme - cls_base] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
                 if (d != 0 && d <= 64) {
                     /* round 1 asks without looking who else did: marking the word (a random 8-byte compare-and-swap per request,
                      * 12.5 M per rank: 2 of this kernel's 2.6 ms) saved one request in ten — two nodes of a rank that sweep the same row
                      * of another rank; now that row travels twice (nref_remote_kernel keeps either copy) */
                     const u64 u0 = ADJ_DST(e0), u2 = ADJ_DST(e2);
-                    if (u0 < lo || u0 >= hi) rqs[2 * (8 * t + (lane >> 3))] = ((u32)u0 << 1) | ((~ADJ_ORI(e0)) & 1u);
-                    if (has2 && (u2 < lo || u2 >= hi)) rqs[2 * (8 * t + (lane >> 3)) + 1] = ((u32)u2 << 1) | ((~ADJ_ORI(e2)) & 1u);
+                    if (!own.mine(u0)) rqs[2 * (8 * t + (lane >> 3))] = ((u32)u0 << 1) | ((~ADJ_ORI(e0)) & 1u);
+                    if (has2 && !own.mine(u2)) rqs[2 * (8 * t + (lane >> 3)) + 1] = ((u32)u2 << 1) | ((~ADJ_ORI(e2)) & 1u);
                 }
             }
         }
@@ -306,7 +447,7 @@ __global__ void probes_sum_kernel(const u16 *__restrict__ len, u64 lo, u64 hi, u
 
 /* round 2: the listed nodes (deferred by round 1, or beyond the register path) ask for every row they do not have */
 __global__ void __launch_bounds__(64) tr_request_all_kernel(const u64 *__restrict__ nodes, u64 n_nodes, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
-                                                            u64 lo, u64 hi, u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+                                                            OwnSet own, u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
 {
     for (u64 it = blockIdx.x; it < n_nodes; it += gridDim.x) {
         const u64 rv = ref[nodes[it]];
@@ -315,7 +456,7 @@ __global__ void __launch_bounds__(64) tr_request_all_kernel(const u64 *__restric
         for (u32 s0 = 0; s0 < d; s0 += 64) {
             const u32 s = s0 + threadIdx.x;
             u32 rq = 0xFFFFFFFFu;
-            if (s < d) rq = request_for(row[s], lo, hi, nref);
+            if (s < d) rq = request_for(row[s], own, nref);
             request_append(rq, list, n_list, cap, ctr);
         }
     }
@@ -372,21 +513,23 @@ __global__ void nref_remote_kernel(const u32 *__restrict__ req, u64 n_req, const
  * u -> w into such reads w of OTHER ranks, the owner looks the twin up and appends what is missing to its extras. Wave per own
  * node; FILL = false counts the items. */
 template <bool FILL>
-__global__ void __launch_bounds__(256) twin_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u16 *__restrict__ len, u64 lo, u64 hi,
+__global__ void __launch_bounds__(256) twin_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u16 *__restrict__ len, OwnSet own,
                                                         const u64 *__restrict__ dropbits, ulonglong2 *__restrict__ list, u64 *__restrict__ n_list, u64 cap,
                                                         u64 *ctr)
 {
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     u64 mine = 0;
-    for (u64 u = lo + wave; u < hi; u += nwaves) {
+    const u64 nloc = own.count();
+    for (u64 ui = wave; ui < nloc; ui += nwaves) {
+        const u64 u = own.node(ui);
         const u64 ru = ref[u];
         const u32 du = REF_DEG(ru), Lu = len[u];
         for (u32 p0 = 0; p0 < du; p0 += 64) {
             const u32 p = p0 + lane;
             const u64 e = p < du ? adj[REF_POS(ru) + p] & ~ADJ_FLAG : 0ull;
             const u64 w = ADJ_DST(e);
-            const bool take = p < du && (w < lo || w >= hi) && ((dropbits[w >> 6] >> (w & 63)) & 1ull);
+            const bool take = p < du && !own.mine(w) && ((dropbits[w >> 6] >> (w & 63)) & 1ull);
             const u64 mk = __ballot(take);
             if (!mk) continue;
             if (!FILL) {
@@ -434,10 +577,10 @@ __global__ void twin_recv_kernel(const ulonglong2 *__restrict__ items, u64 n_ite
  * FILL = false counts the items. */
 template <bool FILL>
 __global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, const u64 *__restrict__ half,
-                                                        const u32 *__restrict__ hcnt, const u16 *__restrict__ len, u64 lo, u64 hi,
+                                                        const u32 *__restrict__ hcnt, const u16 *__restrict__ len, OwnSet own,
                                                         ulonglong2 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
 {
-    const u64 nloc = hi - lo;
+    const u64 nloc = own.count();
     const u64 n64 = (nloc + 63) & ~63ull;
     const u32 lane = threadIdx.x & 63u;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -461,7 +604,7 @@ __global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ r
         return make_ulonglong2(ADJ_DST(e), ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lb, b, disco_twin_orient(ADJ_ORI(e)), Lb));
     };
     auto push = [&](bool have, u64 e, u64 b, u32 Lb) { /* one candidate per lane and call (the rows of nodes with many survivors) */
-        const bool take = have && ADJ_DST(e) < lo; /* else: a > b, or a on this rank (judged locally) */
+        const bool take = have && ADJ_DST(e) < b && !own.mine(ADJ_DST(e)); /* else: a > b, or a on this rank (judged locally) */
         const u64 mk = __ballot(take);
         if (!mk) return;
         if (!FILL) {
@@ -480,7 +623,7 @@ __global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ r
     };
     for (; i < n64; i += (u64)gridDim.x * blockDim.x) {
         const bool live = i < nloc;
-        const u64 b = lo + (live ? i : 0);
+        const u64 b = own.node(live ? i : 0);
         const u32 cnt = live ? hcnt[b] : 0u, Lb = live ? (u32)len[b] : 0u;
         const bool narrow = cnt <= HALF_CAP;
         u64 he[HALF_CAP];
@@ -489,7 +632,7 @@ __global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ r
         for (u32 r = 0; r < HALF_CAP; r++) {
             const bool have = narrow && r < cnt;
             he[r] = have ? half[b * HALF_CAP + r] : 0ull;
-            if (have && ADJ_DST(he[r]) < lo) takem |= 1u << r;
+            if (have && ADJ_DST(he[r]) < b && !own.mine(ADJ_DST(he[r]))) takem |= 1u << r;
         }
         {
             const u32 mycnt = (u32)__popc(takem);

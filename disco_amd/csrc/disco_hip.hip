@@ -383,6 +383,15 @@ struct disco_ctx {
     u64 dense_cap = 0;
     ulonglong2 *d_push_r = nullptr; /* received half-edge pushes (alias of d_x16b while a pass is in flight) */
     u64 n_push_r = 0;
+    /* ranks own loci: the reads — graph nodes — of a pass are dealt to the ranks by their read-level minimizer;
+     * [home_lo, home_hi) is the id range the rank's reads arrived in (and the range whose containment flags it fixes). While such a pass
+     * runs, q_lo / q_hi are POSITIONS in the rank's own list: [0, n_own) of d_order_own. */
+    bool loci = false;
+    bool runs_by_pos = false; /* d_runs is indexed by position in the processing order, not by read id */
+    u8 *d_otab = nullptr;     /* [n_alloc] owner of every read */
+    u32 *d_own_ids = nullptr; /* scratch: the own reads before they are grouped */
+    u64 own_ids_cap = 0, n_own = 0;
+    u64 home_lo = 0, home_hi = 0;
     disco_dist_info dinfo{};
 };
 
@@ -504,6 +513,19 @@ static DiscoView view(const disco_ctx *c)
     v.SL = c->two_class ? c->S_ext : 0;
     v.tailb = c->two_class ? c->tailb : 0;
     return v;
+}
+
+/* the nodes the context works on as an OwnSet: the query range, or — inside a multi-GPU pass whose ranks own loci — the own list */
+static OwnSet own_set(const disco_ctx *c)
+{
+    OwnSet o;
+    o.otab = c->loci ? c->d_otab : nullptr;
+    o.me = c->comm ? (u32)c->comm->rank : 0u;
+    o.lo = c->q_lo;
+    o.hi = c->q_hi;
+    o.list = c->loci ? c->d_order_own : nullptr;
+    o.n_own = c->loci ? c->n_own : 0;
+    return o;
 }
 
 static int env_int(const char *name, int dflt)
@@ -670,6 +692,10 @@ static void free_graph_state(disco_ctx *c)
     c->rpos_cap = c->nadj_cap = c->nadj_used = c->deg_tmp_cap = 0;
     c->d_push_r = nullptr;
     c->n_push_r = 0;
+    dev_free(c, &c->d_otab, c->n_alloc);
+    dev_free(c, &c->d_own_ids, c->own_ids_cap);
+    c->own_ids_cap = c->n_own = 0;
+    c->loci = c->runs_by_pos = false;
 }
 
 /* the buffers of the long class (two classes of rows) — whatever of them exists: a failed two_class_alloc leaves some behind with
@@ -783,6 +809,7 @@ static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, In
     }
     c->runs_lpr = 0;
     c->runs_n = 0;
+    c->runs_by_pos = false;
     const int nf = v.k - v.m + 1;
     const int lpr = c->S == VERIFY_SW ? runs_lpr_for(c, nf, c->max_len, nloc) : 0;
     if (lpr && nloc) {
@@ -2117,8 +2144,8 @@ int disco_probe(disco_ctx *c)
             else DISCO_PROBE_LAUNCH_CLASS(2);
 #undef DISCO_PROBE_LAUNCH_CLASS
         } else if (mode == 0 && use_runs) {
-            if (c->runs_lpr == 16) hipLaunchKernelGGL(probe_runs_kernel<16>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
-            else hipLaunchKernelGGL(probe_runs_kernel<32>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_lo);
+            if (c->runs_lpr == 16) hipLaunchKernelGGL(probe_runs_kernel<16>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_by_pos ? ~0ull : c->runs_lo);
+            else hipLaunchKernelGGL(probe_runs_kernel<32>, dim3(g), dim3(64), 0, c->stream, a, (const u32 *)c->d_runs, c->runs_by_pos ? ~0ull : c->runs_lo);
         } else if (mode == 0) DISCO_PROBE_MODE(0);
         else if (mode == 1) DISCO_PROBE_MODE(1);
         else { /* slow_list only exists next to probe_runs_kernel: 64-byte rows */
@@ -2195,7 +2222,9 @@ int disco_probe(disco_ctx *c)
         /* the index pass counted already (once: a retry of this loop finds the counters scanned and counts again) */
         const bool counted = c->order_counted && c->order_counted_lo == c->q_lo && c->order_counted_hi == c->q_hi && c->order_counted_bits == order_bits;
         c->order_counted = false;
-        if (own_order) {
+        if (c->loci) { /* the own list IS the processing order (grouped when the reads were dealt: dist_build_index) */
+            c->d_order_used = c->d_order_own;
+        } else if (own_order) {
             CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
             CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nq));
             CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, nq));
@@ -2390,7 +2419,9 @@ static int ensure_big_cap(disco_ctx *c, const u32 *cnt, const u64 *ref, u32 thr)
 {
     const u64 nq = c->q_hi - c->q_lo;
     CHK(zero_counter(c, CTR_ES_BIG));
-    if (nq) hipLaunchKernelGGL(count_above_kernel, dim3(flat_grid(c, nq)), dim3(256), 0, c->stream, cnt, ref, c->q_lo, c->q_hi, thr, c->d_ctr + CTR_ES_BIG);
+    /* (ranks own loci: q_lo / q_hi are positions; the rows and reference words of the other ranks' reads are zero) */
+    const u64 ilo = c->loci ? 0 : c->q_lo, ihi = c->loci ? c->n : c->q_hi;
+    if (ihi > ilo) hipLaunchKernelGGL(count_above_kernel, dim3(flat_grid(c, ihi - ilo)), dim3(256), 0, c->stream, cnt, ref, ilo, ihi, thr, c->d_ctr + CTR_ES_BIG);
     HIPCHK(c, hipGetLastError());
     CHK(read_counters(c));
     const u64 need = c->h_ctr[CTR_ES_BIG] + 1024;
@@ -2423,8 +2454,8 @@ static int select_edges(disco_ctx *c)
     a.v = view(c);
     if (!c->d_dropbits) CHK(dev_alloc(c, &c->d_dropbits, c->n_alloc / 64 + 1));
     HIPCHK(c, hipMemsetAsync(c->d_dropbits, 0, (c->n_alloc / 64 + 1) * sizeof(u64), c->stream));
-    c->drop_lo = c->q_lo;
-    c->drop_hi = c->q_hi;
+    c->drop_lo = c->loci ? 0 : c->q_lo;
+    c->drop_hi = c->loci ? 0 : c->q_hi; /* (ranks own loci: the bitmap is complete once the lists have been exchanged: dist_complete_twins) */
     a.dropbits = c->d_dropbits;
     a.hidden_flags = c->prm.max_substitutions != 0;
     a.drop_node = a.drop_key = nullptr;
@@ -2542,6 +2573,8 @@ static int twin_check_search(disco_ctx *c, u64 lo, u64 hi)
     a.adj = c->d_adj;
     a.lo = lo;
     a.hi = hi;
+    a.otab = c->loci ? c->d_otab : nullptr; /* (ranks own loci: of the nodes [lo, hi) only the own ones) */
+    a.me = c->comm ? (u32)c->comm->rank : 0u;
     a.extra_cnt = c->d_extra_cnt;
     a.n_extra = c->d_n_extra;
     /* Something was dropped — but only the lists of the reads that dropped something can lack a twin (same argument, per read):
@@ -2936,6 +2969,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             h.out_cap = c->out_cap;
             h.bump = c->d_bump;
             h.local_only = c->dist_active ? 1u : 0u;
+            h.own = own_set(c);
             const int gh = wq_grid(c, emit_half_kernel, (nq + 63) / 64, "DISCO_EMIT_WAVES");
             hipLaunchKernelGGL(emit_half_kernel, dim3(gh), dim3(64), 0, c->stream, h);
         }
@@ -2953,6 +2987,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.out_cap = c->out_cap;
         a.bump = c->d_bump;
         a.local_only = c->dist_active ? 1u : 0u;
+        a.own = own_set(c);
         HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
         if (nq && !(listed && c->n_wide == 0)) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(64), 0, c->stream, a);
         if (n_push) {
@@ -3959,6 +3994,112 @@ static int host_reduce(disco_ctx *c, u64 *vals, int n, bool take_max = false)
     return DISCO_OK;
 }
 
+/* ---- 0'. ranks own loci: the reads of the pass are dealt to the ranks by their read-level minimizer -------------------------- */
+/* Replaces needsProcessing (RMA/HashTable.cpp:1066-1087: a read is the business of the rank that owns its bucket) and the id
+ * ranges of rounds 1-4. A rank's reads used to be a random G-th of every locus: nobody's neighbours in the processing order shared
+ * candidates, rows or buckets any more (verify, probe and marking ran 1.5 x the time per read: profiles/r04_dist8_kernels.json) and
+ * nearly every neighbour row was another rank's. Now: keys of the home range (read_keys_kernel) -> all-gather of the 4-byte keys ->
+ * owner of every read = its key's share of the hash range (disco_key_owner: whole groups, no exchange of boundaries needed — the
+ * grouping hash spreads the groups evenly) -> the own reads, grouped (the rank's processing order, d_order_own). From here on q_lo /
+ * q_hi are POSITIONS of that list. Collective. */
+static int dist_deal_reads(disco_ctx *c)
+{
+    DISCO_TRACE("dist_deal_reads");
+    const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    const u64 hlo = c->home_lo, hhi = c->home_hi;
+    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n_alloc));
+    if (!c->d_otab) CHK(dev_alloc(c, &c->d_otab, c->n_alloc));
+    DiscoView v = view(c);
+    if (hhi > hlo) hipLaunchKernelGGL(read_keys_kernel, dim3((unsigned)((hhi - hlo + 255) / 256)), dim3(256), 0, c->stream, v, hlo, hhi, c->d_okey);
+    HIPCHK(c, hipGetLastError());
+    {
+        const auto t0 = HClock::now();
+        COMM_CHK(c, c->comm->all_gather(c->d_okey + (u64)r * c->per, c->d_okey, c->per * sizeof(u32), c->stream));
+        c->dinfo.bytes_sent[DISCO_X_KEYS] += (u64)(G - 1) * c->per * sizeof(u32);
+        c->dinfo.ms[DISCO_X_KEYS] += ms_since(t0);
+    }
+    /* owners and the own reads (about n / G of them: sized for the whole job once — 4 bytes per read) */
+    CHK(ensure_cap(c, &c->d_own_ids, &c->own_ids_cap, std::max<u64>(c->n, 1)));
+    if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    if (c->n) hipLaunchKernelGGL(own_select_kernel, dim3((unsigned)std::min<u64>((c->n + OWN_TILE - 1) / OWN_TILE, (u64)c->n_cu * 16)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, c->n, G, r,
+                                 c->d_otab, c->d_own_ids, c->d_list_n);
+    HIPCHK(c, hipGetLastError());
+    u64 n_own = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_own, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, counted_stream_sync(c->stream));
+    c->n_own = n_own;
+    c->loci = true;
+    c->q_lo = 0;
+    c->q_hi = n_own;
+    /* the lengths (and, for the index pass, the rows) of the own reads: most of them arrived in other ranks' ranges */
+    if (c->wait_bulk_before_verify) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bulk, 0));
+        c->wait_bulk_before_verify = false;
+    }
+    /* the processing order: the own reads grouped by key (disco_probe's grouping, over the list) */
+    CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, std::max<u64>(n_own, 1)));
+    int obits = 16;
+    ph_begin(c, DISCO_PH_ORDER);
+    if (own_order_wanted(c, n_own, &obits)) {
+        const u64 order_buckets = 1ull << obits;
+        const u32 oshift = 32u - (u32)obits;
+        CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
+        CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, n_own));
+        HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
+        hipLaunchKernelGGL(order_count_list_kernel, dim3(flat_grid(c, n_own)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, (const u32 *)c->d_own_ids, n_own, G, r, oshift, c->d_ocnt, c->d_oslot);
+        CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
+        hipLaunchKernelGGL(order_scatter_list_kernel, dim3(flat_grid(c, n_own)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, (const u32 *)c->d_own_ids, (const u32 *)c->d_oslot,
+                           (const u32 *)c->d_ocnt, n_own, G, r, oshift, (const u16 *)c->d_len, c->d_order_own);
+    } else if (n_own)
+        hipLaunchKernelGGL(order_pack_list_kernel, dim3(flat_grid(c, n_own)), dim3(256), 0, c->stream, (const u32 *)c->d_own_ids, n_own, (const u16 *)c->d_len, c->d_order_own);
+    ph_end(c, DISCO_PH_ORDER);
+    HIPCHK(c, hipGetLastError());
+    c->d_order_used = c->d_order_own;
+    c->order_counted = false;
+    c->dinfo.own_reads = n_own;
+    return DISCO_OK;
+}
+
+/* the count pass of the index over the own list (ranks own loci): records and minimizer runs by POSITION in the processing order */
+static int index_count_own_list(disco_ctx *c, const DiscoView &v, ulonglong2 *rec)
+{
+    const u64 n_own = c->n_own;
+    const int nf = v.k - v.m + 1;
+    c->runs_lpr = 0;
+    c->runs_n = 0;
+    c->runs_by_pos = false;
+    const int lpr = c->S == VERIFY_SW ? runs_lpr_for(c, nf, c->max_len, n_own) : 0;
+    if (!n_own) return DISCO_OK;
+    const dim3 grid((unsigned)((n_own + 255) / 256));
+    const u64 *list = c->d_order_own;
+    if (lpr) {
+        CHK(ensure_cap(c, &c->d_runs, &c->runs_cap, n_own * (u64)lpr));
+        c->runs_lpr = lpr;
+        c->runs_lo = 0;
+        c->runs_n = n_own;
+        c->runs_by_pos = true;
+#define DISCO_RUNS_LAUNCH(NF_)                                                                                                                              \
+    do {                                                                                                                                                  \
+        if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<false, NF_, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, c->d_runs, (u32 *)nullptr, (u32 *)nullptr, 0u, list); \
+        else hipLaunchKernelGGL((index_runs_kernel<false, NF_, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, c->d_runs, (u32 *)nullptr, (u32 *)nullptr, 0u, list);             \
+    } while (0)
+        switch (nf) {
+        case 7: DISCO_RUNS_LAUNCH(7); break;
+        case 12: DISCO_RUNS_LAUNCH(12); break;
+        case 17: DISCO_RUNS_LAUNCH(17); break;
+        case 22: DISCO_RUNS_LAUNCH(22); break;
+        default: DISCO_RUNS_LAUNCH(27); break;
+        }
+#undef DISCO_RUNS_LAUNCH
+    } else if (c->k > 64)
+        hipLaunchKernelGGL((index_count_kernel<false, true>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, (u32 *)nullptr, (u32 *)nullptr, 0u, list);
+    else
+        hipLaunchKernelGGL(index_count_kernel<false>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, (u32 *)nullptr, (u32 *)nullptr, 0u, list);
+    HIPCHK(c, hipGetLastError());
+    return DISCO_OK;
+}
+
 /* ---- 1. hash-partitioned index build ------------------------------------------------------------------------------- */
 static int dist_build_index(disco_ctx *c)
 {
@@ -3982,12 +4123,13 @@ static int dist_build_index(disco_ctx *c)
         CHK(ensure_cap(c, &c->d_bkt, &c->bkt_cap, T + 1));
         CHK(ensure_cap(c, &c->d_ent, &c->ent_cap, 2 * c->n));
     }
-    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n));
+    CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->loci ? c->n_alloc : c->n));
     CHK(ensure_cap(c, &c->d_rec, &c->rec_cap, std::max<u64>(2 * nloc, 1)));
     c->adj_imported = false;
     ph_begin(c, DISCO_PH_INDEX);
     DiscoView v = view(c);
-    CHK(launch_index_count<false>(c, v, c->d_rec, c->q_lo, c->q_hi));
+    if (c->loci) CHK(index_count_own_list(c, v, c->d_rec));
+    else CHK(launch_index_count<false>(c, v, c->d_rec, c->q_lo, c->q_hi));
     /* records -> owner of their bucket range */
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nloc, 1)));
     std::vector<u64> scnt, rcnt, matrix;
@@ -4203,7 +4345,8 @@ static int dist_mark_contained(disco_ctx *c)
 {
     DISCO_TRACE("dist_mark_contained");
     const u32 G = (u32)c->comm->world;
-    const u64 lo = c->q_lo, nloc = c->q_hi - c->q_lo, per = c->per;
+    /* (the flags of an id range are fixed by the rank whose reads arrived in it, whoever processes them: best[] is a table by read id) */
+    const u64 lo = c->home_lo, nloc = c->home_hi - c->home_lo, per = c->per;
     if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
     if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
     const auto t0 = HClock::now();
@@ -4235,7 +4378,7 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     const u32 G = (u32)c->comm->world;
     std::vector<u64> scnt, rcnt;
     CHK(ensure_cap(c, &c->d_req_s, &c->req_s_cap, std::max<u64>(n_flat, 1)));
-    RouteByRowRequest f{c->per};
+    RouteByRowRequest f{c->per, c->loci ? c->d_otab : nullptr};
     CHK(route_items(c, c->d_req_flat, n_flat, f, c->d_req_s, scnt));
     CHK(exchange_counts(c, scnt, rcnt));
     const u64 nrq = vsum(rcnt);
@@ -4245,7 +4388,7 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     CHK(ensure_cap(c, &c->d_rdeg_s, &c->rdeg_s_cap, std::max<u64>(nrq, 1)));
     CHK(ensure_cap(c, &c->d_rpos, &c->rpos_cap, std::max<u64>(std::max(nrq, n_flat), 1) + 1));
     const int rgrid = (int)std::max<u64>(std::min<u64>((nrq + 3) / 4, (u64)c->n_cu * 32), 1);
-    if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
+    if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->loci ? (u64)0 : c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
     HIPCHK(c, hipGetLastError());
     u64 total_s = 0;
     CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_s, nrq, c->d_rpos, true, &total_s)));
@@ -4283,12 +4426,13 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
 static int dist_transitive_mark(disco_ctx *c)
 {
     DISCO_TRACE("dist_transitive_mark");
-    const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
+    const u64 nloc = c->q_hi - c->q_lo; /* own nodes (an id range, or the positions of the own list) */
+    const OwnSet own = own_set(c);
     /* reference words: everything "not fetched", the own nodes' rows in place */
     CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, 2 * c->n + 2));
     ph_begin(c, DISCO_PH_CSR);
     HIPCHK(c, hipMemsetAsync(c->d_nref, 0xFF, (2 * c->n + 2) * sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(nref_local_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, lo, nloc, c->d_nref);
+    if (nloc) hipLaunchKernelGGL(nref_local_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, own, c->d_nref);
     HIPCHK(c, hipGetLastError());
     c->nadj_used = 0; /* the neighbour-row store holds fetched rows only */
     CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, 1u << 16, 0)); /* idle lanes of the row prefetch read its first 64 K entries */
@@ -4298,8 +4442,8 @@ static int dist_transitive_mark(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, 2 * nloc + 64));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    CHK(ensure_cap(c, &c->d_cls_cnt, &c->cls_cnt_cap, std::max<u64>(nloc, 1)));
-    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, lo, hi, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr, c->d_cls_cnt);
+    CHK(ensure_cap(c, &c->d_cls_cnt, &c->cls_cnt_cap, std::max<u64>(c->loci ? c->n : nloc, 1))); /* (ranks own loci: by node id; only the own nodes' slots are ever read) */
+    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, own, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr, c->d_cls_cnt, c->loci ? (u64)0 : c->q_lo);
     HIPCHK(c, hipGetLastError());
     u64 n_flat = 0;
     HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -4321,7 +4465,7 @@ static int dist_transitive_mark(disco_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     TrArgs a;
     a.v = view(c);
-    a.order = nullptr;
+    a.order = c->loci ? c->d_order_own : nullptr; /* (ranks own loci: the own nodes are the list, in the processing order of probe / verify / selection) */
     a.ref = c->d_adj_ref;
     a.adj = c->d_adj;
     a.big_list = c->d_big_list;
@@ -4368,7 +4512,7 @@ static int dist_transitive_mark(disco_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, bound + 64));
         HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-        if (n_big) hipLaunchKernelGGL(tr_request_all_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_adj, lo, hi, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
+        if (n_big) hipLaunchKernelGGL(tr_request_all_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_adj, own, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         CHK(read_counters(c));
@@ -4409,10 +4553,11 @@ static int dist_transitive_mark(disco_ctx *c)
 static int dist_push_survivors(disco_ctx *c)
 {
     DISCO_TRACE("dist_push_survivors");
-    const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo;
+    const u64 nloc = c->q_hi - c->q_lo;
+    const OwnSet own = own_set(c);
     u64 n_items = 0;
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(emit_push_kernel<false>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
+    if (nloc) hipLaunchKernelGGL(emit_push_kernel<false>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, own, (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -4420,12 +4565,12 @@ static int dist_push_survivors(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(n_items, 1)));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, lo, hi, c->d_x16b, c->d_list_n, n_items, c->d_ctr);
+    if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, own, c->d_x16b, c->d_list_n, n_items, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     CHK(read_counters(c));
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "survivor push: the fill pass produced more items than the count pass");
     std::vector<u64> scnt, rcnt;
-    RouteByNode f{c->per};
+    RouteByNode f{c->per, c->loci ? c->d_otab : nullptr};
     CHK(route_items(c, c->d_x16b, n_items, f, c->d_x16a, scnt));
     CHK(exchange_counts(c, scnt, rcnt));
     const u64 nr = vsum(rcnt);
@@ -4444,19 +4589,49 @@ static int dist_complete_twins(disco_ctx *c, bool *done, u64 *asym_total)
     DISCO_TRACE("dist_complete_twins");
     const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
     const u64 lo = c->q_lo, hi = c->q_hi, nloc = hi - lo, per = c->per;
+    const OwnSet own = own_set(c);
     *done = false;
     const auto t0 = HClock::now();
-    COMM_CHK(c, c->comm->all_gather(c->d_dropbits + (u64)r * per / 64, c->d_dropbits, per / 8, c->stream));
-    c->dinfo.bytes_sent[DISCO_X_TWINS] += (u64)(G - 1) * (per / 8);
+    if (c->loci) {
+        /* the reads that dropped something are scattered over the id space (a rank set the bits of ITS reads): their ids travel as
+         * lists, every rank sets everybody's bits */
+        const u64 n_words = (c->n + 63) / 64;
+        u64 mine = 0;
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(bits_to_list_kernel, dim3(flat_grid(c, n_words)), dim3(256), 0, c->stream, (const u64 *)c->d_dropbits, n_words, (u32 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
+        HIPCHK(c, hipMemcpyAsync(&mine, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        std::vector<u64> cnts((size_t)G);
+        COMM_CHK(c, c->comm->host_all_gather((const unsigned long long *)&mine, 1, (unsigned long long *)cnts.data(), c->stream)); /* (synchronises: `mine` is there) */
+        std::vector<size_t> off((size_t)G), cnt((size_t)G);
+        size_t tot = 0;
+        for (u32 p2 = 0; p2 < G; p2++) {
+            off[p2] = tot * sizeof(u32);
+            cnt[p2] = (size_t)cnts[p2] * sizeof(u32);
+            tot += (size_t)cnts[p2];
+        }
+        CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, std::max<u64>(tot, 1) + 64));
+        u32 *my_list = c->d_req_flat + off[r] / sizeof(u32);
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        CHK(zero_counter(c, CTR_OVERFLOW));
+        hipLaunchKernelGGL(bits_to_list_kernel, dim3(flat_grid(c, n_words)), dim3(256), 0, c->stream, (const u64 *)c->d_dropbits, n_words, my_list, c->d_list_n, (u64)cnts[r], c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        COMM_CHK(c, c->comm->all_gather_v(my_list, c->d_req_flat, off.data(), cnt.data(), c->stream));
+        if (tot) hipLaunchKernelGGL(list_to_bits_kernel, dim3(flat_grid(c, tot)), dim3(256), 0, c->stream, (const u32 *)c->d_req_flat, (u64)tot, c->d_dropbits);
+        HIPCHK(c, hipGetLastError());
+        c->dinfo.bytes_sent[DISCO_X_TWINS] += (u64)(G - 1) * cnt[r];
+    } else {
+        COMM_CHK(c, c->comm->all_gather(c->d_dropbits + (u64)r * per / 64, c->d_dropbits, per / 8, c->stream));
+        c->dinfo.bytes_sent[DISCO_X_TWINS] += (u64)(G - 1) * (per / 8);
+    }
     c->drop_lo = 0;
     c->drop_hi = c->n;
     /* pairs inside the rank: finds of the own nodes into own nodes that dropped something */
-    CHK(twin_check(c, lo, hi));
+    CHK(twin_check(c, c->loci ? 0 : lo, c->loci ? c->n : hi));
     u64 asym = c->h_ctr[CTR_ASYM];
     /* pairs across ranks: {w, twin} to the owner of w */
     u64 n_items = 0;
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(twin_push_kernel<false>, dim3(flat_grid(c, nloc * 64)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_len, lo, hi, c->d_dropbits,
+    if (nloc) hipLaunchKernelGGL(twin_push_kernel<false>, dim3(flat_grid(c, nloc * 64)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_len, own, c->d_dropbits,
                                  (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -4465,13 +4640,13 @@ static int dist_complete_twins(disco_ctx *c, bool *done, u64 *asym_total)
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(n_items, 1)));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    if (nloc) hipLaunchKernelGGL(twin_push_kernel<true>, dim3(flat_grid(c, nloc * 64)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_len, lo, hi, c->d_dropbits,
+    if (nloc) hipLaunchKernelGGL(twin_push_kernel<true>, dim3(flat_grid(c, nloc * 64)), dim3(256), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_len, own, c->d_dropbits,
                                  c->d_x16b, c->d_list_n, n_items, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     CHK(read_counters(c));
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "twin push: the fill pass produced more items than the count pass");
     std::vector<u64> scnt, rcnt;
-    RouteByNode f{per};
+    RouteByNode f{per, c->loci ? c->d_otab : nullptr};
     CHK(route_items(c, c->d_x16b, n_items, f, c->d_x16a, scnt));
     CHK(exchange_counts(c, scnt, rcnt));
     const u64 nr = vsum(rcnt);
@@ -4675,8 +4850,8 @@ static int dist_set_reads(disco_ctx *c, u64 n_total, uint32_t dstride)
     dist_range(c, n_total, &per, &lo, &hi);
     c->per = per;
     c->n_alloc = per * (u64)c->comm->world;
-    c->q_lo = lo;
-    c->q_hi = hi;
+    c->q_lo = c->home_lo = lo;
+    c->q_hi = c->home_hi = hi;
     CHK(dev_alloc(c, &c->d_reads, c->n_alloc * (u64)dstride));
     CHK(dev_alloc(c, &c->d_len, c->n_alloc));
     /* unused words of a row are zero (disco_device.h): the other ranks' rows arrive at their used words only */
@@ -4742,7 +4917,19 @@ int disco_dist_generate_reads(disco_ctx *c, const disco_genspec_abi *s)
     return dist_validate(c);
 }
 
-static int dist_run_graph_impl(disco_ctx *c, uint32_t flags);
+static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bool *retry_with_id_ranges);
+
+/* one pass; ranks own loci wherever the pass supports it — exact overlaps, fewer than 2^30 reads, the index replicated after its
+ * partitioned build (DISCO_DIST_ID_RANGES=1, every rank alike: the id ranges of rounds 1-4). A pass that ends up in the
+ * order-dependent regime (the whole adjacency to everybody: too many one-sided pairs) is redone over id ranges: the decision is taken
+ * from all-gathered numbers, so every rank takes it alike. */
+static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
+{
+    bool retry = false;
+    int rc = dist_run_graph_pass(c, flags, true, &retry);
+    if (rc == DISCO_OK && retry) rc = dist_run_graph_pass(c, flags & ~(uint32_t)DISCO_DIST_GATHER_READS, false, &retry); /* (the reads are everywhere by now) */
+    return rc;
+}
 
 int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
 {
@@ -4782,14 +4969,28 @@ static int arena_reserve(disco_ctx *c)
     return DISCO_OK;
 }
 
-static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
+static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bool *retry_with_id_ranges)
 {
     DISCO_TRACE("disco_dist_run_graph");
+    *retry_with_id_ranges = false;
     if (!c) return DISCO_E_ARG;
     if (!c->comm) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: no communicator");
     if (!c->dist_reads || c->phase < 1) return fail(c, DISCO_E_STATE, "disco_dist_run_graph: set the reads with disco_dist_upload_reads / disco_dist_generate_reads");
     HIPCHK(c, hipSetDevice(c->device));
     const u32 G = (u32)c->comm->world, r = (u32)c->comm->rank;
+    /* the pass starts from the rank's home range; inside a pass whose ranks own loci q_lo / q_hi are positions of the own list, and
+     * whichever way the pass ends they name the home range again */
+    struct HomeRange {
+        disco_ctx *c;
+        ~HomeRange()
+        {
+            c->q_lo = c->home_lo;
+            c->q_hi = c->home_hi;
+        }
+    } home_range{c};
+    c->q_lo = c->home_lo;
+    c->q_hi = c->home_hi;
+    c->loci = false;
     CHK(arena_reserve(c));
     struct PassToken { /* (in-process transport, DISCO_LOOP_SERIALIZE: one rank's compute segment on the device at a time) */
         DiscoComm *cm;
@@ -4806,10 +5007,12 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
     di.world = G;
     di.rank = r;
     di.n_reads = c->n;
-    di.own_lo = c->q_lo;
-    di.own_hi = c->q_hi;
+    di.own_lo = c->home_lo;
+    di.own_hi = c->home_hi;
+    di.own_reads = c->home_hi - c->home_lo;
     c->dist_active = true;
     c->part_index = (flags & DISCO_DIST_KEEP_INDEX_PARTITIONED) != 0 || getenv("DISCO_DIST_PARTITIONED_INDEX") != nullptr;
+    const bool want_loci = allow_loci && !c->part_index && c->prm.max_substitutions == 0 && c->n < (1ull << 30) && !getenv("DISCO_DIST_ID_RANGES") && !getenv("DISCO_DIST_FORCE_GATHER");
     c->n_push_r = 0;
     c->h_len.clear();
     /* 0. everybody gets every read — on the second communicator and stream: the index build and the probe of the own reads
@@ -4855,6 +5058,8 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
         di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (sent_row_bytes + 2);
         di.ms[DISCO_X_READS] += ms_since(t0); /* time to ISSUE it (RCCL: asynchronous; in-process transport: the copies themselves) */
     }
+    if (want_loci) CHK(dist_deal_reads(c));
+    di.placement = c->loci ? 1u : 0u;
     CHK(dist_build_index(c));
     c->contained_done = false;
     CHK(disco_probe(c));
@@ -4864,7 +5069,7 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
     u64 probes = 0;
     if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    if (c->q_hi > c->q_lo) hipLaunchKernelGGL(probes_sum_kernel, dim3(flat_grid(c, c->q_hi - c->q_lo)), dim3(256), 0, c->stream, c->d_len, c->q_lo, c->q_hi, (u32)c->k, c->d_list_n);
+    if (c->home_hi > c->home_lo) hipLaunchKernelGGL(probes_sum_kernel, dim3(flat_grid(c, c->home_hi - c->home_lo)), dim3(256), 0, c->stream, c->d_len, c->home_lo, c->home_hi, (u32)c->k, c->d_list_n);
     HIPCHK(c, hipMemcpyAsync(&probes, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     u64 g[8] = {c->adj_total, c->dropped_local, c->n_contained, c->h_ctr[CTR_CAP_SITES], c->h_ctr[CTR_KMER_HITS], probes, 0, 0};
@@ -4900,6 +5105,11 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
                 di.e_pre = t[0] / 2;
                 di.regime = 2;
             }
+        }
+        if (irregular && c->loci) { /* the gather of the whole adjacency walks id ranges: the pass is redone over them (collective decision) */
+            *retry_with_id_ranges = true;
+            c->loci = false;
+            return DISCO_OK;
         }
         if (irregular) {
             di.regime = 1;

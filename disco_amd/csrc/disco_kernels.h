@@ -122,6 +122,25 @@ struct DiscoView {
     int tailb; /* 160 or 256: the bases the staged compare of the short class moves per row */
 };
 
+/* which graph nodes are this rank's. One GPU and the id-range form of the multi-GPU flow: the range [lo, hi). "Ranks own loci"
+ * (DESIGN.md section 6): reads are dealt to the ranks by their read-level minimizer — otab[v] names the owner of read v, list holds the
+ * own reads (ORDER_MAKE entries, in the rank's processing order) — and every "is it mine" / "whose is it" of the flow goes through
+ * this instead of through id arithmetic (replaces needsProcessing, RMA/HashTable.cpp:1066-1087: work goes to the rank whose data it meets) */
+struct OwnSet {
+    const u8 *otab; /* [n] owner of every read, or null: the range */
+    u32 me;
+    u64 lo, hi;
+    const u64 *list;
+    u64 n_own;
+    __device__ __forceinline__ bool mine(u64 v) const { return otab ? otab[v] == (u8)me : (v >= lo && v < hi); }
+    __device__ __forceinline__ u64 count() const { return otab ? n_own : hi - lo; }
+    __device__ __forceinline__ u64 node(u64 i) const { return otab ? ORDER_ID(list[i]) : lo + i; }
+};
+/* owner of a read-level minimizer key among G ranks: the key's grouping hash (ORDER_BUCKET's multiplicative hash) cut into G equal
+ * ranges — reads that share their key (a group: the reads of one locus) always share their owner, and a rank's groups are a
+ * contiguous range of the grouping's buckets */
+__host__ __device__ __forceinline__ u32 disco_key_owner(u32 key, u32 G) { return (u32)(((u64)(key * 0x9E3779B1u) * (u64)G) >> 32); }
+
 /* ================================================================================================================
  * synthetic reads straight into HBM (bench / tests) — twin of readgen.h / readgen.py
  * ============================================================================================================== */
@@ -214,20 +233,24 @@ __global__ void validate_len_kernel(const u16 *__restrict__ len, u64 n, int S, i
  * (shard_count_kernel), which is what replaces the range-partitioned hashData of RMA/HashTable.cpp:95-116. */
 /* LONGCLASS (two row classes, single GPU): [lo, hi) counts the long reads; read x is long_ids[x], its row full[x][SL]; its records, key
  * and slot go where the read's would (rec is indexed by read id); the suffix record carries the id of the read's tail row, n + x */
+/* list (multi-GPU flow, ranks own loci: the own reads are no id range): position x of [lo, hi) stands for read ORDER_ID(list[x]);
+ * records, slots and keys are indexed by position */
 template <bool COUNT, bool LONGK = false, bool LONGCLASS = false>
 __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
-                                                          u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
+                                                          u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift, const u64 *__restrict__ list = nullptr)
 {
     /* rec[2i], rec[2i+1] = {bucket << 32 | slot inside the bucket, record} of the prefix / suffix k-mer of read i: the slot is
      * what the counting atomic returns, so the fill pass needs no second round of atomics */
     const u64 x = lo + (u64)blockIdx.x * 256u + threadIdx.x;
     if (x >= hi) return;
-    const u64 i = LONGCLASS ? (u64)v.long_ids[x] : x;
+    const u64 i = LONGCLASS ? (u64)v.long_ids[x] : x; /* what the records, keys and slots are indexed by */
+    const u64 lw = (!LONGCLASS && list) ? list[x] : 0ull;
+    const u64 rid = (!LONGCLASS && list) ? ORDER_ID(lw) : i; /* the read */
     if (LONGCLASS) lo = 0;
     const int S = LONGCLASS ? v.SL : v.S;
-    const u64 *__restrict__ p = LONGCLASS ? v.full + x * (u64)S : v.reads + i * (u64)S;
-    if (!LONGCLASS && v.full && v.len[i] > DISCO_SHORT_MAX) return; /* (a long read's turn comes with the LONGCLASS launch) */
-    const int L = v.len[i], k = v.k, m = v.m, nf = k - m + 1;
+    const u64 *__restrict__ p = LONGCLASS ? v.full + x * (u64)S : v.reads + rid * (u64)S;
+    if (!LONGCLASS && v.full && v.len[rid] > DISCO_SHORT_MAX) return; /* (a long read's turn comes with the LONGCLASS launch) */
+    const int L = (!LONGCLASS && list) ? ORDER_LEN(lw) : (int)v.len[rid], k = v.k, m = v.m, nf = k - m + 1;
     const int nmm = L - m + 1; /* m-mer positions (L >= k: validate_len_kernel) */
     const int sfx0 = nmm - nf; /* = L - k: first m-mer of the suffix k-mer */
     const u64 mask = (1ull << (2 * m)) - 1ull;
@@ -288,8 +311,8 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
     const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
     const u32 sp = COUNT ? atomicAdd(&bkt[bp], 1u) : 0u;
     const u32 ss = COUNT ? atomicAdd(&bkt[bs], 1u) : 0u;
-    rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
-    rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, LONGCLASS ? v.n + x : i, ts, rs, 1, L));
+    rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, rid, tp, rp, 0, L));
+    rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, LONGCLASS ? v.n + x : rid, ts, rs, 1, L));
 }
 
 /* ----------------------------------------------------------------------------------------------------------------
@@ -317,9 +340,12 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
  * is marked 0xFFFE in its first entry: probe_runs_kernel hands those to probe_kernel, which resolves ties the long way.
  * The prefix / suffix k-mer records of the read are windows 0 and L - k of the same pass.
  * The entries are staged in LDS (each thread its own CAP slots) and leave as one coalesced copy per block. */
+/* list (multi-GPU flow, ranks own loci): position i of [lo, hi) stands for read ORDER_ID(list[i]), its length rides in the entry;
+ * records, runs, keys and slots by position — probe_runs_kernel then reads the run lists in the order it walks the reads */
 template <bool COUNT, int NF, int NL>
 __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
-                                                         u32 *__restrict__ runs, u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
+                                                         u32 *__restrict__ runs, u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift,
+                                                         const u64 *__restrict__ list = nullptr)
 {
     constexpr int CAP = 32 * NL;
     __shared__ u16 s_runs[256 * CAP];
@@ -327,12 +353,14 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
     for (u32 x = tid; x < 256u * CAP / 2u; x += 256u) ((u32 *)s_runs)[x] = 0xFFFFFFFFu;
     __syncthreads();
     const u64 i = lo + (u64)blockIdx.x * 256u + tid;
+    const u64 lw = (list && i < hi) ? list[i] : 0ull;
+    const u64 rid = list ? ORDER_ID(lw) : i; /* the read behind position i */
     /* two row classes: a long read is index_count_kernel's (from its full row); here it only tells the probe to take it the long way */
-    const bool other_class = i < hi && v.full && v.len[i] > DISCO_SHORT_MAX;
+    const bool other_class = i < hi && v.full && v.len[rid] > DISCO_SHORT_MAX;
     if (other_class) s_runs[tid * CAP] = 0xFFFEu;
     if (i < hi && !other_class) {
-        const u64 *__restrict__ p = v.reads + i * v.S;
-        const int L = v.len[i], k = v.k, m = v.m;
+        const u64 *__restrict__ p = v.reads + rid * v.S;
+        const int L = list ? ORDER_LEN(lw) : (int)v.len[rid], k = v.k, m = v.m;
         const int nmm = L - m + 1; /* m-mer positions */
         const int npos = nmm - NF; /* = L - k: the probe's windows are [0, npos), window npos is the suffix k-mer */
         const u64 mask = (1ull << (2 * m)) - 1ull;
@@ -431,8 +459,8 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
         const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
         const u32 sp = COUNT ? atomicAdd(&bkt[bp], 1u) : 0u;
         const u32 ss = COUNT ? atomicAdd(&bkt[bs], 1u) : 0u;
-        rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, i, tp, rp, 0, L));
-        rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, i, ts, rs, 1, L));
+        rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, rid, tp, rp, 0, L));
+        rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, rid, ts, rs, 1, L));
     }
     __syncthreads();
     const u64 r0 = (u64)blockIdx.x * 256u;
@@ -971,6 +999,8 @@ __device__ __forceinline__ u64 shfl_u64(u64 x, u32 l)
 #ifndef PR_WAVES_PER_SIMD
 #define PR_WAVES_PER_SIMD 6 /* no register cap the kernel would feel: it needs 72 vector and ~100 scalar registers, which is 7 waves per SIMD; capped at 7 or 8 hipcc spills scalars into vector lanes and then vector registers */
 #endif
+/* runs_lo == ~0: the run lists are stored by POSITION in the processing order (multi-GPU flow, ranks own loci: index_runs_kernel ran
+ * over the order itself), not by read id */
 template <int LPR>
 __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(ProbeArgs a, const u32 *__restrict__ runs, u64 runs_lo)
 {
@@ -1013,7 +1043,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
         /* run words and rows of the group that starts at g0 (addresses clamped, loads unconditional: they are issued one group ahead) */
         auto fetch = [&](u64 g0, u32 &rw, u64 &roww) {
             const u64 it = min(g0 + slot, cend - 1);
-            rw = runs[(ORDER_ID(shfl_u64(ord_chunk, (u32)(it - cbeg))) - runs_lo) * LPR + e];
+            rw = runs[(runs_lo == ~0ull ? it : ORDER_ID(shfl_u64(ord_chunk, (u32)(it - cbeg))) - runs_lo) * LPR + e];
             const u32 rl = lane & (G * 8 - 1);
             const u64 itr = min(g0 + (rl >> 3), cend - 1);
             roww = a.v.reads[ORDER_ID(shfl_u64(ord_chunk, (u32)(itr - cbeg))) * VERIFY_SW + (rl & 7)];
@@ -3465,6 +3495,8 @@ struct TwinArgs {
     const u64 *ref; /* [n] */
     const u64 *adj;
     u64 lo, hi;     /* nodes whose lists are completed by this launch */
+    const u8 *otab; /* multi-GPU flow, ranks own loci: ... AND whose owner (otab[w]) is `me`; null: the range alone */
+    u32 me;
     u32 *extra_cnt; /* [n]                                            */
     u64 *extra_node;
     u64 *extra_key;
@@ -3538,7 +3570,7 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
                     search = false;
                 else
                     n_up++;
-            } else if (search && (w < a.lo || w >= a.hi))
+            } else if (search && (w < a.lo || w >= a.hi || (a.otab && a.otab[w] != (u8)a.me)))
                 search = false;
             if (search && a.dropbits && !(a.hidden_flags && hid) && !((a.dropbits[w >> 6] >> (w & 63)) & 1ull)) search = false;
             bool miss = false;
@@ -4158,6 +4190,7 @@ struct EmitArgs {
     /* multi-GPU flow: only pairs whose larger endpoint is owned by this rank too are judged here (the survivors of a remote w
      * are not on this rank: its owner pushes them, emit_push_recv_kernel) */
     u32 local_only;
+    OwnSet own; /* the nodes this launch emits from: the query range, or the rank's own nodes */
 };
 
 __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
@@ -4173,12 +4206,12 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
                 if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
     };
     u64 cbeg = 0, cend = 0;
-    while (wq_grab(a.v.wq, a.list ? a.n_list : a.v.q_hi - a.v.q_lo, cbeg, cend))
+    while (wq_grab(a.v.wq, a.list ? a.n_list : a.own.count(), cbeg, cend))
     for (u64 it = cbeg; it < cend; it++) {
-        const u64 v = a.list ? a.list[it] : a.v.q_lo + it;
+        const u64 v = a.list ? a.list[it] : a.own.node(it);
         /* the list can name nodes of other ranks' ranges: the order-dependent regime of the multi-GPU flow marks ALL nodes on every
          * rank (and lists their wide ones) but emits its own range only */
-        if (v < a.v.q_lo || v >= a.v.q_hi) continue;
+        if (!a.own.mine(v)) continue;
         if (a.hcnt && a.hcnt[v] <= HALF_CAP) continue;
         const u64 rv = a.ref[v];
         const u32 d = REF_DEG(rv);
@@ -4192,7 +4225,7 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
             if (s < d) {
                 e = a.adj[vs + s];
                 const u64 w = ADJ_DST(e);
-                if (v < w && !(e & ADJ_FLAG) && (!a.local_only || w < a.v.q_hi)) {
+                if (v < w && !(e & ADJ_FLAG) && (!a.local_only || a.own.mine(w))) {
                     const u32 Lw = ADJ_DLEN(e);
                     const u64 twin = ADJ_MAKE(Lw + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
                     const u32 cw = a.hcnt ? a.hcnt[w] : HALF_CAP + 1;
@@ -4247,6 +4280,7 @@ struct EmitHalfArgs {
     u64 out_cap;
     u64 *bump;
     u32 local_only; /* see EmitArgs */
+    OwnSet own;
 };
 
 __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
@@ -4260,13 +4294,13 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
             for (u32 i = chunk_used + lane; i < EMIT_CHUNK; i += 64)
                 if (chunk_base + i < a.out_cap) a.out_src[chunk_base + i] = ~0ull;
     };
-    const u64 nq = a.v.q_hi - a.v.q_lo;
+    const u64 nq = a.own.count();
     /* a work item = 64 consecutive nodes */
     u64 cbeg = 0, cend = 0;
     while (wq_grab(a.v.wq, (nq + 63) / 64, cbeg, cend))
     for (u64 blk = cbeg; blk < cend; blk++) {
-        const u64 v = a.v.q_lo + blk * 64 + lane;
-        const bool live = v < a.v.q_hi;
+        const bool live = blk * 64 + lane < nq;
+        const u64 v = a.own.node(live ? blk * 64 + lane : 0);
         const u32 cnt = live ? a.hcnt[v] : 0u;
         const u32 Lv = live ? (u32)a.v.len[v] : 0u;
 #pragma unroll
@@ -4276,7 +4310,7 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
             if (cnt <= HALF_CAP && r < cnt) { /* wide nodes (cnt > HALF_CAP) are emitted by emit_kernel */
                 e = a.half[v * HALF_CAP + r];
                 const u64 w = ADJ_DST(e);
-                if (v < w && (!a.local_only || w < a.v.q_hi)) {
+                if (v < w && (!a.local_only || a.own.mine(w))) {
                     const u64 twin = ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
                     const u32 cw = a.hcnt[w];
                     if (cw <= HALF_CAP) {

@@ -219,6 +219,7 @@ enum { /* exchanges of one pass (disco_dist_info.bytes_sent) */
     DISCO_X_TWINS,         /* regime 2 only: drop bitmap all-gather + all-to-all of {node, twin entry} into reads that dropped a hit */
     DISCO_X_QUERIES,       /* partitioned index only: all-to-all of the lookups (one per minimizer run) to the bucket's owner */
     DISCO_X_HITS,          /* partitioned index only: all-to-all of the matching records back to the read's owner             */
+    DISCO_X_KEYS,          /* ranks own loci: all-gather of the 4-byte read-level minimizer keys the reads are dealt by         */
     DISCO_X_COUNT
 };
 /* disco_dist_run_graph flags. GATHER_READS: the pass starts from range-partitioned reads. KEEP_INDEX_PARTITIONED: the index is
@@ -251,6 +252,11 @@ typedef struct disco_dist_info {
     uint32_t device_allocs, device_frees;     /* requests that reached the HIP runtime DURING the pass (0 with the arena in place)    */
     uint64_t arena_bytes, arena_peak;         /* the context's arena (one allocation before the first collective) and its high water  */
     uint64_t hbm_peak;                        /* most device memory the context's buffers held during the pass (arena or not)         */
+    /* round 5 (appended) */
+    uint64_t own_reads;                       /* reads (graph nodes) this rank processed: own_hi - own_lo over id ranges; its loci's reads otherwise */
+    uint32_t placement;                       /* 0: ranks own id ranges [own_lo, own_hi); 1: ranks own loci — reads dealt by their read-level
+                                                 minimizer (own_lo / own_hi then only name the range the rank's reads ARRIVED in)      */
+    uint32_t reserved_;
 } disco_dist_info;
 /* fills out[0..DISCO_UNIQUE_ID_BYTES) on ONE rank (ncclGetUniqueId); the caller hands it to the others (MPI_Bcast-like, any
  * side channel) */

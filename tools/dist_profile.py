@@ -18,7 +18,7 @@ from disco_amd import buildgraph, readgen  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
-out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/r04_dist8.json"
+out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/r05_dist8.json"
 passes = 3
 genome = int(n * 150 / 30.0)
 spec = readgen.GenSpec.coverage(42, n, 150, 30.0, n_contigs=max(1, genome // 5_000_000))
@@ -80,7 +80,8 @@ for info, ph, walls in res:
                   "bytes_sent": info["bytes_sent"], "exchange_host_ms": {k: round(v, 3) for k, v in info["ms"].items()},
                   "comm_ops": info["comm_ops"], "host_syncs": info["host_syncs"], "device_allocs_in_pass": info["device_allocs"],
                   "device_frees_in_pass": info["device_frees"], "arena_bytes": info["arena_bytes"], "arena_peak": info["arena_peak"],
-                  "hbm_peak": info["hbm_peak"], "pass_wall_ms_serialised": [round(w, 2) for w in walls]})
+                  "hbm_peak": info["hbm_peak"], "pass_wall_ms_serialised": [round(w, 2) for w in walls],
+                  "own_reads": info["own_reads"], "placement": "loci" if info["placement"] else "id ranges"})
 i0 = res[0][0]
 kernel_table_path = os.path.join(os.path.dirname(out_path) or ".", os.path.basename(out_path).replace(".json", "_kernels.json"))
 kernel_table = json.load(open(kernel_table_path)) if os.path.exists(kernel_table_path) else {}
@@ -102,11 +103,12 @@ out = {"what": f"{G} ranks on ONE MI355X over the in-process transport, compute 
        "per_phase": per_phase,
        "per_rank": ranks,
        "bytes_sent_per_rank_mean": {k: int(sum(r["bytes_sent"][k] for r in ranks) / G) for k in ranks[0]["bytes_sent"]},
+       "placement": ranks[0]["placement"], "own_reads_max_over_mean": round(max(r["own_reads"] for r in ranks) * G / max(1, sum(r["own_reads"] for r in ranks)), 4),
        "comm_ops_per_pass": max(r["comm_ops"] for r in ranks), "host_syncs_per_pass": max(r["host_syncs"] for r in ranks),
        "device_allocs_in_pass": max(r["device_allocs_in_pass"] for r in ranks), "device_frees_in_pass": max(r["device_frees_in_pass"] for r in ranks)}
 os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
 json.dump(out, open(out_path, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("work_inflation", "sum_phase_timers_ms_over_ranks", "comm_ops_per_pass", "host_syncs_per_pass", "device_allocs_in_pass",
+print(json.dumps({k: out[k] for k in ("placement", "own_reads_max_over_mean", "work_inflation", "sum_phase_timers_ms_over_ranks", "comm_ops_per_pass", "host_syncs_per_pass", "device_allocs_in_pass",
                                        "device_frees_in_pass", "bytes_sent_per_rank_mean")}, indent=1))
 print(json.dumps(per_phase, indent=1))
 print("single", single_wall, "arena", ranks[0]["arena_bytes"], ranks[0]["arena_peak"], "hbm_peak", ranks[0]["hbm_peak"])
