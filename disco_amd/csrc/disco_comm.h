@@ -103,6 +103,11 @@ struct RcclComm final : DiscoComm {
         rank = rk;
         world = nranks;
         DISCO_NCCL(ncclCommInitRank(&comm, nranks, id, rk));
+        /* the staging of host_all_gather now, not lazily inside a pass: with one host thread per GPU in one process (buildG --gpus N) a
+         * device allocation while peers sit in an RCCL kernel is the classic stall. 4096 values per rank cover every use of a pass
+         * (the largest: world x world counts of an all-to-all-v); a larger request still grows it, outside any collective */
+        small_cap = (size_t)(world + 1) * 4096;
+        DISCO_COMM_HIP(hipMalloc((void **)&d_small, small_cap * 8));
         return DISCO_OK;
     }
     ~RcclComm() override
@@ -120,6 +125,17 @@ struct RcclComm final : DiscoComm {
     int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
     {
         n_ops++;
+        /* blocks of one size, laid out rank after rank (the bucket-table slices whenever the world divides the table): the library's own
+         * all-gather instead of world - 1 send / receive pairs. (The record slices differ by a fraction of a per cent and stay a grouped
+         * exchange: padding them to one pitch would put slots without a record inside the LAST bucket of every slice — a bucket ends
+         * where the next one begins — and the probe walks every slot of a bucket) */
+        bool regular = true;
+        for (int p = 0; p < world; p++) regular = regular && cnt[p] == cnt[0] && off[p] == (size_t)p * cnt[0];
+        if (regular) {
+            if (cnt[0] == 0) return DISCO_OK;
+            DISCO_NCCL(ncclAllGather(send, recv, cnt[0], ncclInt8, comm, s));
+            return DISCO_OK;
+        }
         DISCO_NCCL(ncclGroupStart());
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;

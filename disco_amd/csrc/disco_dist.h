@@ -77,6 +77,18 @@ __global__ void __launch_bounds__(256) route_scatter_kernel(const T *__restrict_
     }
 }
 
+/* first slot of every segment from the counts (one wavefront; G <= 64): the routing needs no host round trip between its two kernels */
+__global__ void route_cursor_kernel(const u64 *__restrict__ cnt, u32 G, u64 *__restrict__ cursor)
+{
+    const u32 l = threadIdx.x;
+    u64 x = l < G ? cnt[l] : 0ull, incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 y = ((u64)(u32)__shfl_up((int)(u32)(incl >> 32), o) << 32) | (u32)__shfl_up((int)(u32)incl, o);
+        if ((int)l >= o) incl += y;
+    }
+    if (l < G) cursor[l] = incl - x;
+}
+
 /* ---- reads: rows travel at the words they use, not at the 64-byte stride of the table ---------------------------------- */
 /* rows [r0, r0 + nrows) of the S-stride table <-> a dense array of W words per row (W = words of the longest read of the job) */
 __global__ void pack_rows_kernel(const u64 *__restrict__ table, int S, int W, u64 r0, u64 nrows, u64 *__restrict__ dense)
@@ -87,14 +99,27 @@ __global__ void pack_rows_kernel(const u64 *__restrict__ table, int S, int W, u6
 }
 
 /* all rows but [skip_lo, skip_hi) (the rank's own, already in place); the words beyond W stay zero (the table was cleared once) */
-__global__ void unpack_rows_kernel(const u64 *__restrict__ dense, int S, int W, u64 nrows, u64 skip_lo, u64 skip_hi, u64 *__restrict__ table)
+/* (per / block_words: rank p's rows start at word p * block_words of `dense` — its block also carries its lengths behind the rows;
+ * block_words = per * W: the rows of all ranks back to back) */
+__global__ void unpack_rows_kernel(const u64 *__restrict__ dense, int S, int W, u64 nrows, u64 skip_lo, u64 skip_hi, u64 *__restrict__ table, u64 per, u64 block_words)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 total = nrows * (u64)W;
     for (; i < total; i += (u64)gridDim.x * blockDim.x) {
         const u64 r = i / W;
         if (r >= skip_lo && r < skip_hi) continue;
-        table[r * S + i % W] = dense[i];
+        table[r * S + i % W] = dense[(r / per) * block_words + (r % per) * (u64)W + i % W];
+    }
+}
+/* the lengths behind the rows of every rank's block -> len[] (all ranks but `skip`) */
+__global__ void unpack_lens_kernel(const u64 *__restrict__ dense, u64 per, u64 block_words, u64 rows_words, u32 G, u32 skip, u16 *__restrict__ len)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = per * (u64)G;
+    for (; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 p = i / per;
+        if (p == skip) continue;
+        len[i] = ((const u16 *)(dense + p * block_words + rows_words))[i % per];
     }
 }
 
@@ -133,6 +158,47 @@ __global__ void __launch_bounds__(256) read_keys_kernel(DiscoView v, u64 lo, u64
         best = min(best, order_hash32(r < f ? r : f));
     }
     okey[i] = best;
+}
+
+/* the rows of the own reads ahead of the all-gather of all reads (which only verify waits for): every rank sends the reads of its home
+ * range to the ranks that got them — {id | length << 32, the W words the job's longest read uses} — one all-to-all-v of about
+ * n / G x (W + 1) x 8 bytes per rank; the receiver puts them where the all-gather will put them again */
+template <int W>
+struct ReadItem {
+    u64 hdr;
+    u64 w[W];
+};
+template <int W>
+struct RouteByReadItem {
+    const u8 *otab;
+    __device__ __forceinline__ u32 operator()(const ReadItem<W> &r) const { return (u32)otab[(u32)r.hdr]; }
+};
+template <int W>
+__global__ void read_items_kernel(const u64 *__restrict__ reads, const u16 *__restrict__ len, int S, u64 lo, u64 hi, ReadItem<W> *__restrict__ out)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = (hi - lo) * (u64)(W + 1);
+    u64 *o = (u64 *)out;
+    for (; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 i = lo + t / (W + 1);
+        const u32 w = (u32)(t % (W + 1));
+        o[t] = w == 0 ? (i | ((u64)len[i] << 32)) : reads[i * (u64)S + (w - 1)];
+    }
+}
+template <int W>
+__global__ void read_items_place_kernel(const ReadItem<W> *__restrict__ items, u64 n_items, int S, u64 *__restrict__ reads, u16 *__restrict__ len)
+{
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = n_items * (u64)(W + 1);
+    const u64 *in = (const u64 *)items;
+    for (; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 x = t / (W + 1);
+        const u32 w = (u32)(t % (W + 1));
+        const u64 hdr = in[x * (W + 1)];
+        const u64 id = hdr & 0xFFFFFFFFull;
+        if (w == 0) len[id] = (u16)(hdr >> 32);
+        else reads[id * (u64)S + (w - 1)] = in[t];
+    }
 }
 
 /* owner of every read from its key (disco_key_owner) and the list of the own reads' ids: in id order inside a tile of OWN_TILE reads,
@@ -263,7 +329,7 @@ __global__ void nref_local_kernel(const u64 *__restrict__ ref, OwnSet own, u64 *
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 nloc = own.count();
     for (; i < nloc; i += (u64)gridDim.x * blockDim.x) {
-        const u64 v = own.node(i);
+        const u64 v = own.node_by_id(i);
         const u64 r = ref[v] | TR_LOCAL;
         nref[2 * v] = r;
         nref[2 * v + 1] = r;
@@ -353,6 +419,9 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
             u64 e0 = 0, e2 = 0;
             bool has2 = false;
             for (u32 s0 = 0; s0 < dmax; s0 += 8) {
+                /* without the counts (cls_cnt == null: the owner counts the few rows that are asked for itself) a node is done once its
+                 * two entries are found — the first entry on the other side is among the first few of the row */
+                if (!cls_cnt && !__any(live && !has2 && s0 < d && d <= 64u)) break;
                 const u32 s = s0 + sub;
                 const bool in = s < d && d < 65536u;
                 const u64 e = in ? row[s] : 0ull;
@@ -372,7 +441,7 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
                 }
             }
             if (live && sub == 0) {
-                cls_cnt[vme - cls_base] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
+                if (cls_cnt) cls_cnt[vme - cls_base] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
                 if (d != 0 && d <= 64) {
                     /* round 1 asks without looking who else did: marking the word (a random 8-byte compare-and-swap per request,
                      * 12.5 M per rank: 2 of this kernel's 2.6 ms) saved one request in ten — two nodes of a rank that sweep the same row
@@ -623,7 +692,7 @@ __global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ r
     };
     for (; i < n64; i += (u64)gridDim.x * blockDim.x) {
         const bool live = i < nloc;
-        const u64 b = own.node(live ? i : 0);
+        const u64 b = own.node_by_id(live ? i : 0);
         const u32 cnt = live ? hcnt[b] : 0u, Lb = live ? (u32)len[b] : 0u;
         const bool narrow = cnt <= HALF_CAP;
         u64 he[HALF_CAP];

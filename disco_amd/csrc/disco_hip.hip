@@ -392,6 +392,7 @@ struct disco_ctx {
     u32 *d_own_ids = nullptr; /* scratch: the own reads before they are grouped */
     u64 own_ids_cap = 0, n_own = 0;
     u64 home_lo = 0, home_hi = 0;
+    u64 home_probes = 0; /* sum of len - k over the home range */
     disco_dist_info dinfo{};
 };
 
@@ -525,6 +526,7 @@ static OwnSet own_set(const disco_ctx *c)
     o.hi = c->q_hi;
     o.list = c->loci ? c->d_order_own : nullptr;
     o.n_own = c->loci ? c->n_own : 0;
+    o.ids = c->loci ? c->d_own_ids : nullptr;
     return o;
 }
 
@@ -3926,16 +3928,11 @@ static int route_items(disco_ctx *c, const T *items, u64 n, F owner, T *out, std
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_route, G * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    u64 cur[DIST_MAX_WORLD], acc = 0;
-    for (u32 g = 0; g < G; g++) {
-        cur[g] = acc;
-        acc += cnt[g];
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_route + DIST_MAX_WORLD, cur, G * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    /* (the cursors are made on the device: the scattered segments are consumed by operations on this stream, nothing here waits for them) */
+    hipLaunchKernelGGL(route_cursor_kernel, dim3(1), dim3(64), 0, c->stream, (const u64 *)c->d_route, G, c->d_route + DIST_MAX_WORLD);
     if (n) hipLaunchKernelGGL((route_scatter_kernel<T, F>), dim3(flat_grid(c, (n + ROUTE_ITEMS - 1) / ROUTE_ITEMS)), dim3(256), 0, c->stream, items, n, owner, G,
                               c->d_route + DIST_MAX_WORLD, out);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream)); /* `cur` is a stack array */
     return DISCO_OK;
 }
 
@@ -3968,7 +3965,9 @@ static int a2a_items(disco_ctx *c, int xid, const void *send, const std::vector<
     }
     const auto t0 = HClock::now();
     COMM_CHK(c, c->comm->all_to_all_v(send, so.data(), sc.data(), recv, ro.data(), rc.data(), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* (stream ordered: whoever consumes the received blocks runs behind them on this stream. DISCO_DIST_TIME_EXCHANGES=1 waits here, so that
+     * dinfo.ms shows the exchange itself and not the time to issue it) */
+    if (getenv("DISCO_DIST_TIME_EXCHANGES")) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dinfo.ms[xid] += ms_since(t0);
     return DISCO_OK;
 }
@@ -3991,6 +3990,30 @@ static int host_reduce(disco_ctx *c, u64 *vals, int n, bool take_max = false)
         for (int p = 0; p < G; p++) a = take_max ? std::max(a, all[(size_t)p * n + i]) : a + all[(size_t)p * n + i];
         vals[i] = a;
     }
+    return DISCO_OK;
+}
+
+/* the rows and lengths of the own reads, from the ranks in whose home ranges they arrived (dist_deal_reads) */
+template <int W>
+static int dist_deal_rows(disco_ctx *c)
+{
+    typedef ReadItem<W> Item;
+    const u64 nhome = c->home_hi - c->home_lo;
+    const u64 per16 = (sizeof(Item) + 15) / 16; /* (d_x16a / d_x16b are arrays of 16-byte items) */
+    CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nhome * per16, 1)));
+    Item *items = (Item *)c->d_x16a, *sorted = (Item *)(c->d_x16a + nhome * per16);
+    if (nhome) hipLaunchKernelGGL(read_items_kernel<W>, dim3(flat_grid(c, nhome * (W + 1))), dim3(256), 0, c->stream, (const u64 *)c->d_reads, (const u16 *)c->d_len, c->S, c->home_lo, c->home_hi, items);
+    HIPCHK(c, hipGetLastError());
+    std::vector<u64> scnt, rcnt;
+    RouteByReadItem<W> f{c->d_otab};
+    CHK(route_items(c, items, nhome, f, sorted, scnt));
+    CHK(exchange_counts(c, scnt, rcnt));
+    const u64 nr = vsum(rcnt);
+    if (nr != c->n_own) return fail(c, DISCO_E_STATE, "dealt reads: %llu rows arrive for %llu own reads", (unsigned long long)nr, (unsigned long long)c->n_own);
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nr * per16, 1)));
+    CHK(a2a_items(c, DISCO_X_READS_DEALT, sorted, scnt, c->d_x16b, rcnt, sizeof(Item)));
+    if (nr) hipLaunchKernelGGL(read_items_place_kernel<W>, dim3(flat_grid(c, nr * (W + 1))), dim3(256), 0, c->stream, (const Item *)c->d_x16b, nr, c->S, c->d_reads, c->d_len);
+    HIPCHK(c, hipGetLastError());
     return DISCO_OK;
 }
 
@@ -4032,10 +4055,17 @@ static int dist_deal_reads(disco_ctx *c)
     c->loci = true;
     c->q_lo = 0;
     c->q_hi = n_own;
-    /* the lengths (and, for the index pass, the rows) of the own reads: most of them arrived in other ranks' ranges */
+    /* the lengths and — for the index pass — the rows of the own reads: most of them arrived in other ranks' ranges. They come by an
+     * all-to-all of their own, a seventh of what the all-gather of ALL reads moves (that one stays behind index build and probe: only
+     * verify waits for it; it writes the same rows once more); shapes without a built variant wait for the all-gather here */
     if (c->wait_bulk_before_verify) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bulk, 0));
-        c->wait_bulk_before_verify = false;
+        const int W = (int)((c->max_len + 31) / 32);
+        if (W <= 5 && c->S >= 5 && !getenv("DISCO_DIST_NO_DEAL_ROWS")) CHK(dist_deal_rows<5>(c));
+        else if (W <= 8 && c->S >= 8 && !getenv("DISCO_DIST_NO_DEAL_ROWS")) CHK(dist_deal_rows<8>(c));
+        else {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bulk, 0));
+            c->wait_bulk_before_verify = false;
+        }
     }
     /* the processing order: the own reads grouped by key (disco_probe's grouping, over the list) */
     CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, std::max<u64>(n_own, 1)));
@@ -4183,16 +4213,16 @@ static int dist_build_index(disco_ctx *c)
         for (u32 p = 0; p < G; p++) {
             off[p] = blo_of(p) * sizeof(u32);
             cnt[p] = (blo_of(p + 1) - blo_of(p)) * sizeof(u32);
-            if (p != r) c->dinfo.bytes_sent[DISCO_X_INDEX_SHARDS] += cnt[r];
         }
+        c->dinfo.bytes_sent[DISCO_X_INDEX_SHARDS] += (u64)(G - 1) * cnt[r]; /* (rounds 1-4 added cnt[r] inside the loop, before it was set for p < r: ranks above 0 under-reported) */
         COMM_CHK(c, c->comm->all_gather_v(c->d_bkt + blo, c->d_bkt, off.data(), cnt.data(), c->stream));
         size_t a = 0;
         for (u32 p = 0; p < G; p++) {
             off[p] = a;
             cnt[p] = shard[p] * sizeof(u64);
             a += cnt[p];
-            if (p != r) c->dinfo.bytes_sent[DISCO_X_INDEX_SHARDS] += cnt[r];
         }
+        c->dinfo.bytes_sent[DISCO_X_INDEX_SHARDS] += (u64)(G - 1) * cnt[r];
         COMM_CHK(c, c->comm->all_gather_v(c->d_ent + base, c->d_ent, off.data(), cnt.data(), c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->dinfo.ms[DISCO_X_INDEX_SHARDS] += ms_since(t0);
@@ -4388,7 +4418,8 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     CHK(ensure_cap(c, &c->d_rdeg_s, &c->rdeg_s_cap, std::max<u64>(nrq, 1)));
     CHK(ensure_cap(c, &c->d_rpos, &c->rpos_cap, std::max<u64>(std::max(nrq, n_flat), 1) + 1));
     const int rgrid = (int)std::max<u64>(std::min<u64>((nrq + 3) / 4, (u64)c->n_cu * 32), 1);
-    if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->loci ? (u64)0 : c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
+    if (nrq && c->loci) hipLaunchKernelGGL(tr_respond_kernel<false>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, c->d_rdeg_s, (const u64 *)nullptr, (u32 *)nullptr);
+    else if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
     HIPCHK(c, hipGetLastError());
     u64 total_s = 0;
     CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_s, nrq, c->d_rpos, true, &total_s)));
@@ -4407,16 +4438,26 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     CHK(ensure_cap(c, &c->d_rdata_s, &c->rdata_s_cap, std::max<u64>(total_s, 1)));
     if (nrq) hipLaunchKernelGGL(tr_respond_kernel<true>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, (u32 *)nullptr, c->d_rpos, c->d_rdata_s);
     HIPCHK(c, hipGetLastError());
-    /* degrees back (same segmentation as the requests, reversed), then the entries */
+    /* degrees back (same segmentation as the requests, reversed), then the entries. How many entries every owner sends follows from
+     * the degrees themselves: the requester sums them per segment (positions at the segment boundaries) — no exchange of counts */
     CHK(ensure_cap(c, &c->d_rdeg_r, &c->rdeg_r_cap, std::max<u64>(n_flat, 1)));
     CHK(a2a_items(c, DISCO_X_ROW_REQUESTS, c->d_rdeg_s, rcnt, c->d_rdeg_r, scnt, sizeof(u32)));
-    CHK(exchange_counts(c, ecnt_s, ecnt_r));
-    const u64 total_r = vsum(ecnt_r);
+    u64 total_r = 0;
+    CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_r, n_flat, c->d_rpos, true, &total_r))); /* (d_rpos: the owner's positions were consumed by tr_respond_kernel above) */
+    ecnt_r.assign((size_t)G, 0);
+    {
+        std::vector<u64> bpos((size_t)G + 1, 0);
+        u64 a = 0;
+        for (u32 p = 0; p < G; p++) {
+            if (n_flat) HIPCHK(c, hipMemcpyAsync(&bpos[p], c->d_rpos + a, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            a += scnt[p];
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bpos[G] = total_r;
+        for (u32 p = 0; p < G; p++) ecnt_r[p] = bpos[p + 1] - bpos[p];
+    }
     CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, c->nadj_used + total_r + 1, c->nadj_used));
     CHK(a2a_items(c, DISCO_X_ROW_DATA, c->d_rdata_s, ecnt_s, c->d_nadj32_own + c->nadj_used, ecnt_r, sizeof(u32)));
-    u64 chk = 0;
-    CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_r, n_flat, c->d_rpos, true, &chk)));
-    if (chk != total_r) return fail(c, DISCO_E_STATE, "row exchange: %llu entries announced, %llu received", (unsigned long long)chk, (unsigned long long)total_r);
     if (n_flat) hipLaunchKernelGGL(nref_remote_kernel, dim3(flat_grid(c, n_flat)), dim3(256), 0, c->stream, c->d_req_s, n_flat, c->d_rdeg_r, c->d_rpos, c->nadj_used, c->d_nref);
     HIPCHK(c, hipGetLastError());
     c->nadj_used += total_r;
@@ -4442,8 +4483,10 @@ static int dist_transitive_mark(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, 2 * nloc + 64));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    CHK(ensure_cap(c, &c->d_cls_cnt, &c->cls_cnt_cap, std::max<u64>(c->loci ? c->n : nloc, 1))); /* (ranks own loci: by node id; only the own nodes' slots are ever read) */
-    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, own, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr, c->d_cls_cnt, c->loci ? (u64)0 : c->q_lo);
+    /* ranks own loci: the two rows a node sweeps for certain are mostly the rank's own — a twelfth of the requests of the id ranges — so
+     * nothing is counted per node ahead of time any more: the owner counts the rows it is asked for (tr_respond_kernel<false>) */
+    if (!c->loci) CHK(ensure_cap(c, &c->d_cls_cnt, &c->cls_cnt_cap, std::max<u64>(nloc, 1)));
+    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, own, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr, c->loci ? (u32 *)nullptr : c->d_cls_cnt, c->q_lo);
     HIPCHK(c, hipGetLastError());
     u64 n_flat = 0;
     HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -4791,19 +4834,29 @@ int disco_comm_init(disco_ctx *c, const void *unique_id, int nranks, int rank)
     }
     int rc = cm->init(unique_id, nranks, rank);
     if (rc == DISCO_OK && bulk) { /* the id of the second communicator travels over the first one */
-        ncclUniqueId id2;
-        memset(&id2, 0, sizeof id2);
-        void *d_id = nullptr;
-        if (rank == 0 && ncclGetUniqueId(&id2) != ncclSuccess) rc = DISCO_E_HIP;
-        if (rc == DISCO_OK && hipMalloc(&d_id, sizeof id2) != hipSuccess) rc = DISCO_E_NOMEM;
-        if (rc == DISCO_OK && (hipMemcpyAsync(d_id, &id2, sizeof id2, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                               ncclBroadcast(d_id, d_id, sizeof id2, ncclInt8, 0, cm->comm, c->stream) != ncclSuccess ||
-                               hipMemcpyAsync(&id2, d_id, sizeof id2, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                               hipStreamSynchronize(c->stream) != hipSuccess))
-            rc = DISCO_E_HIP;
-        if (d_id) (void)hipFree(d_id);
-        if (rc == DISCO_OK) rc = bulk->init(&id2, nranks, rank);
-        else cm->err = "exchange of the second communicator's id failed";
+        /* Every rank takes part in the broadcast WHATEVER happened to it before: a rank that left early (rank 0 without an id, a rank
+         * without staging memory) would leave the others inside ncclBroadcast for ever. What travels is the id and a word that says
+         * whether it is one; without one, every rank — alike — goes on with the first communicator alone (the all-gather of the reads
+         * then runs on it: DISCO_DIST_ONE_COMM's path). The staging is the first communicator's own (allocated at its init). */
+        struct IdMsg {
+            ncclUniqueId id;
+            unsigned long long ok;
+        } msg;
+        static_assert(sizeof(IdMsg) <= 4096 * 8, "fits the staging of host_all_gather");
+        memset(&msg, 0, sizeof msg);
+        if (rank == 0) msg.ok = ncclGetUniqueId(&msg.id) == ncclSuccess ? 1ull : 0ull;
+        void *d_id = cm->d_small;
+        if (hipMemcpyAsync(d_id, &msg, sizeof msg, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            ncclBroadcast(d_id, d_id, sizeof msg, ncclInt8, 0, cm->comm, c->stream) != ncclSuccess ||
+            hipMemcpyAsync(&msg, d_id, sizeof msg, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = DISCO_E_HIP; /* the first communicator itself does not work: nothing to fall back to */
+            cm->err = "broadcast of the second communicator's id failed";
+        } else if (!msg.ok) {
+            if (rank == 0) fprintf(stderr, "[disco] no id for a second communicator: the reads are gathered on the first one\n");
+            delete bulk;
+            bulk = nullptr;
+        } else
+            rc = bulk->init(&msg.id, nranks, rank);
     }
     if (rc != DISCO_OK) {
         fail(c, rc, "disco_comm_init: %s %s", cm->err.c_str(), bulk ? bulk->err.c_str() : "");
@@ -4877,6 +4930,12 @@ static int dist_validate(disco_ctx *c)
     if (bad) return fail(c, DISCO_E_ARG, "%llu reads have a length outside (min_overlap=%u, min(32767, 32*stride)]", (unsigned long long)bad, c->prm.min_overlap);
     c->max_len = (u32)ext[0];
     c->min_len = 0xFFFFu - (u32)ext[1];
+    /* the k-mer probes of the home range (disco_dist_info.probes): a property of the reads, summed once here instead of in every pass */
+    if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
+    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    if (nloc) hipLaunchKernelGGL(probes_sum_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_len, c->q_lo, c->q_hi, (u32)c->k, c->d_list_n);
+    HIPCHK(c, hipMemcpyAsync(&c->home_probes, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase = 1;
     return DISCO_OK;
 }
@@ -5040,18 +5099,23 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
         if (W < c->S && !getenv("DISCO_DIST_FULL_ROWS")) {
             /* pack the own rows, all-gather the dense array, spread the other ranks' rows back over the table: 37 % fewer bytes
              * on the links at 150 bp, paid with two streaming passes on the second stream while the index is being built */
+            /* a rank's block = its rows and, behind them, its lengths (per is a multiple of 64: 2 per bytes are whole words): ONE operation */
             const u64 total_rows = c->per * (u64)G;
-            CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, total_rows * (u64)W));
-            u64 *mine = c->d_dense + (u64)r * c->per * W;
+            const u64 rows_words = c->per * (u64)W, block_words = rows_words + c->per / 4;
+            CHK(ensure_cap(c, &c->d_dense, &c->dense_cap, block_words * (u64)G));
+            u64 *mine = c->d_dense + (u64)r * block_words;
             hipLaunchKernelGGL(pack_rows_kernel, dim3(flat_grid(c, c->per * W)), dim3(256), 0, bstream, c->d_reads, c->S, W, (u64)r * c->per, c->per, mine);
-            BULK_CHK(bulk->all_gather(mine, c->d_dense, c->per * (u64)W * 8, bstream));
+            HIPCHK(c, hipMemcpyAsync(mine + rows_words, c->d_len + (u64)r * c->per, c->per * 2, hipMemcpyDeviceToDevice, bstream));
+            BULK_CHK(bulk->all_gather(mine, c->d_dense, block_words * 8, bstream));
             hipLaunchKernelGGL(unpack_rows_kernel, dim3(flat_grid(c, total_rows * W)), dim3(256), 0, bstream, c->d_dense, c->S, W, total_rows, (u64)r * c->per,
-                               (u64)(r + 1) * c->per, c->d_reads);
+                               (u64)(r + 1) * c->per, c->d_reads, c->per, block_words);
+            hipLaunchKernelGGL(unpack_lens_kernel, dim3(flat_grid(c, total_rows)), dim3(256), 0, bstream, (const u64 *)c->d_dense, c->per, block_words, rows_words, G, r, c->d_len);
             HIPCHK(c, hipGetLastError());
             sent_row_bytes = (u64)W * 8;
-        } else
+        } else {
             BULK_CHK(bulk->all_gather(c->d_reads + (u64)r * c->per * c->S, c->d_reads, c->per * row_bytes, bstream));
-        BULK_CHK(bulk->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, bstream));
+            BULK_CHK(bulk->all_gather(c->d_len + (u64)r * c->per, c->d_len, c->per * 2, bstream));
+        }
 #undef BULK_CHK
         HIPCHK(c, hipEventRecord(c->ev_bulk, bstream));
         c->wait_bulk_before_verify = true;
@@ -5066,12 +5130,8 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
     if (!c->contained_done) CHK(dist_mark_contained(c));
     CHK(select_edges(c));
     /* whole-job figures and the regime decision */
-    u64 probes = 0;
+    const u64 probes = c->home_probes; /* (dist_validate) */
     if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
-    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    if (c->home_hi > c->home_lo) hipLaunchKernelGGL(probes_sum_kernel, dim3(flat_grid(c, c->home_hi - c->home_lo)), dim3(256), 0, c->stream, c->d_len, c->home_lo, c->home_hi, (u32)c->k, c->d_list_n);
-    HIPCHK(c, hipMemcpyAsync(&probes, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     u64 g[8] = {c->adj_total, c->dropped_local, c->n_contained, c->h_ctr[CTR_CAP_SITES], c->h_ctr[CTR_KMER_HITS], probes, 0, 0};
     {
         constexpr int NV = 6;

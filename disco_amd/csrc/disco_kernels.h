@@ -132,9 +132,11 @@ struct OwnSet {
     u64 lo, hi;
     const u64 *list;
     u64 n_own;
+    const u32 *ids; /* otab != null: the own reads once more, in (nearly) ascending id order — what a kernel that streams per-node tables walks */
     __device__ __forceinline__ bool mine(u64 v) const { return otab ? otab[v] == (u8)me : (v >= lo && v < hi); }
     __device__ __forceinline__ u64 count() const { return otab ? n_own : hi - lo; }
-    __device__ __forceinline__ u64 node(u64 i) const { return otab ? ORDER_ID(list[i]) : lo + i; }
+    __device__ __forceinline__ u64 node(u64 i) const { return otab ? ORDER_ID(list[i]) : lo + i; }       /* i-th own node in processing order */
+    __device__ __forceinline__ u64 node_by_id(u64 i) const { return otab ? (u64)ids[i] : lo + i; }       /* ... in id order */
 };
 /* owner of a read-level minimizer key among G ranks: the key's grouping hash (ORDER_BUCKET's multiplicative hash) cut into G equal
  * ranges — reads that share their key (a group: the reads of one locus) always share their owner, and a rank's groups are a
@@ -4300,7 +4302,7 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
     while (wq_grab(a.v.wq, (nq + 63) / 64, cbeg, cend))
     for (u64 blk = cbeg; blk < cend; blk++) {
         const bool live = blk * 64 + lane < nq;
-        const u64 v = a.own.node(live ? blk * 64 + lane : 0);
+        const u64 v = a.own.node_by_id(live ? blk * 64 + lane : 0);
         const u32 cnt = live ? a.hcnt[v] : 0u;
         const u32 Lv = live ? (u32)a.v.len[v] : 0u;
 #pragma unroll
@@ -4310,7 +4312,10 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
             if (cnt <= HALF_CAP && r < cnt) { /* wide nodes (cnt > HALF_CAP) are emitted by emit_kernel */
                 e = a.half[v * HALF_CAP + r];
                 const u64 w = ADJ_DST(e);
-                if (v < w && (!a.local_only || a.own.mine(w))) {
+                /* (local_only, ranks own loci: no look at the owner table here — one more random fetch per edge — because hcnt is zero for
+                 * every node of another rank (cleared before the marking, written for the own nodes only): no survivor, no edge; the
+                 * owner of w pushes the pair instead. Id ranges: the range test costs nothing) */
+                if (v < w && (!a.local_only || a.own.otab || w < a.own.hi)) {
                     const u64 twin = ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lv, v, disco_twin_orient(ADJ_ORI(e)), Lv);
                     const u32 cw = a.hcnt[w];
                     if (cw <= HALF_CAP) {

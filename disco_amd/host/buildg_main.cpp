@@ -499,28 +499,75 @@ int main(int argc, char **argv)
         std::vector<RankResult> res((size_t)gpus);
         std::vector<std::thread> th;
         const std::vector<uint64_t> woff = rs.word_offsets();
+        /* Watchdog of the multi-rank stage (bench.py has its twin): every rank thread names the call it is in; when NO rank has moved for
+         * DISCO_WATCHDOG_S seconds (default 900; 0: off) — a collective one rank never entered, a link that went away — the process says
+         * where every rank stands and exits non-zero. Never a re-exec, never a silent hang: runDisco.sh does not check the status, but
+         * the missing GC=Complete line makes the next run start over. */
+        static const char *const kStage[] = {"start", "disco_comm_init", "disco_dist_upload_reads", "disco_dist_run_graph", "disco_fetch_contained", "disco_fetch_edges", "done"};
+        std::vector<std::atomic<int>> stage((size_t)gpus);
+        for (auto &st : stage) st.store(0);
+        std::atomic<bool> ranks_done{false};
+        const long wd_s = getenv("DISCO_WATCHDOG_S") ? atol(getenv("DISCO_WATCHDOG_S")) : 900;
+        std::thread watchdog([&]() {
+            if (wd_s <= 0) return;
+            std::vector<int> last((size_t)gpus, -1);
+            auto moved_at = Clock::now();
+            while (!ranks_done.load()) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                bool moved = false;
+                for (int r = 0; r < gpus; r++) {
+                    const int x = stage[(size_t)r].load();
+                    moved = moved || x != last[(size_t)r];
+                    last[(size_t)r] = x;
+                }
+                if (moved) moved_at = Clock::now();
+                else if (secs(moved_at) > (double)wd_s) {
+                    std::cout << "\nError: no rank has made progress for " << wd_s << " seconds:";
+                    for (int r = 0; r < gpus; r++) std::cout << " rank " << r << " in " << kStage[last[(size_t)r]] << ";";
+                    std::cout << " giving up (DISCO_WATCHDOG_S sets the patience)." << std::endl;
+                    _exit(3);
+                }
+            }
+        });
+        struct WatchdogJoin {
+            std::atomic<bool> &done;
+            std::thread &t;
+            ~WatchdogJoin()
+            {
+                done.store(true);
+                if (t.joinable()) t.join();
+            }
+        } watchdog_join{ranks_done, watchdog};
         for (int r = 0; r < gpus; r++)
             th.emplace_back([&, r]() {
                 RankResult &R = res[(size_t)r];
                 disco_ctx *c = ctx[(size_t)r];
+                auto at = [&](int x) { stage[(size_t)r].store(x); };
                 auto bail = [&](const char *what) {
                     R.err = std::string(what) + ": " + disco_last_error(c);
                     /* the other ranks wait for this one inside a collective: there is nothing to unwind to */
                     std::cout << "\nError (rank " << r << "): " << R.err << std::endl;
                     _exit(2);
                 };
+                at(1);
                 if (!same_device && disco_comm_init(c, uid, gpus, r) < 0) bail("disco_comm_init");
                 uint64_t lo = 0, hi = 0;
                 if (disco_dist_range(c, rs.size(), &lo, &hi) < 0) bail("disco_dist_range");
+                at(2);
                 {
                     const std::vector<uint64_t> own = rs.rows(lo, hi, woff); /* (the multi-GPU table has one stride: the rank's rows at it) */
                     if (disco_dist_upload_reads(c, own.data(), rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
                 }
+                at(3);
+                if (getenv("DISCO_TEST_STALL_RANK") && atoi(getenv("DISCO_TEST_STALL_RANK")) == r) /* (tests: a rank that never enters the pass) */
+                    for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
                 if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS | (partitioned_index ? DISCO_DIST_KEEP_INDEX_PARTITIONED : 0)) < 0) bail("disco_dist_run_graph");
                 if (disco_dist_get_info(c, &R.info) < 0) bail("disco_dist_get_info");
                 if (verbose && r == 0) fprintf(stderr, "[disco host] transport %s, %d ranks\n", disco_comm_kind(c), gpus);
+                at(4);
                 R.rows.resize(R.info.n_contained_local);
                 if (R.info.n_contained_local && disco_fetch_contained(c, R.rows.data(), R.info.n_contained_local) < 0) bail("disco_fetch_contained");
+                at(5);
                 R.n_edges = R.info.e_out_local;
                 R.edges.reset(new disco_edge[std::max<uint64_t>(R.n_edges, 1)]);
                 if (R.n_edges && disco_fetch_edges(c, R.edges.get(), R.n_edges) < 0) bail("disco_fetch_edges");
@@ -528,8 +575,10 @@ int main(int argc, char **argv)
                     R.subs.reset(new uint16_t[std::max<uint64_t>(R.n_edges, 1)]);
                     if (R.n_edges && disco_fetch_edge_substitutions(c, R.subs.get(), R.n_edges) < 0) bail("disco_fetch_edge_substitutions");
                 }
+                at(6);
             });
         for (auto &t : th) t.join();
+        ranks_done.store(true);
         t_graph = secs(t0);
         const disco_dist_info &di = res[0].info;
         n_cont = di.n_contained;

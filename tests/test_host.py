@@ -100,6 +100,29 @@ def _file_tags(threads, gpus, mpi_names):
 
 
 @pytest.mark.gpu
+def test_buildg_multi_rank_watchdog_ends_a_stalled_stage(tmp_path):
+    """round 5: a rank that never enters the pass (DISCO_TEST_STALL_RANK) leaves the others inside their first collective; after
+    DISCO_WATCHDOG_S seconds without progress on any rank buildG says where every rank stands and exits non-zero — no hang, no
+    re-exec, no GC=Complete line (the reference's MPI binaries hang for ever in MPI_Recv, MPI/OverlapGraph.cpp:218-246)"""
+    import time
+
+    build.build_host()
+    c = gu.CASES["multifile"]
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text(f"MinOverlap4BuildGraph = {c['min_overlap']}\n")
+    prefix = str(tmp_path / "g")
+    se = ",".join(os.path.join(gu.GOLD, f) for f in c["se"])
+    env = dict(os.environ, DISCO_TEST_STALL_RANK="1", DISCO_WATCHDOG_S="2")
+    t0 = time.time()
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-se", se, "-f", prefix, "-p", str(cfg), "-t", "2", "--gpus", "2", "--same-device"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, env=env, timeout=120)
+    assert p.returncode == 3, p.stdout
+    assert "no rank has made progress" in p.stdout and "rank 1 in disco_dist_run_graph" in p.stdout, p.stdout
+    assert time.time() - t0 < 60
+    assert not os.path.exists(prefix + "_CheckpointInfo.txt") or "GC=Complete" not in open(prefix + "_CheckpointInfo.txt").read()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("threads,gpus,mpi_names,part", [(1, 1, False, False), (4, 1, False, False), (3, 2, False, False), (3, 2, True, False), (2, 3, True, False),
                                                          (1, 2, True, False), (3, 3, False, True)])
 def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_names, part):
