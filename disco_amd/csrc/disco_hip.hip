@@ -51,6 +51,10 @@ static thread_local std::string g_create_error;
 using HClock = std::chrono::steady_clock;
 static float ms_since(HClock::time_point t0) { return std::chrono::duration<float, std::milli>(HClock::now() - t0).count(); }
 
+/* phase timers: the public phases (disco_phase_ms) plus one internal slot — the index phase's second bracket (ph_collect adds it to the first) */
+#define DISCO_PH_INDEX2 DISCO_PH_COUNT
+#define DISCO_PH_SLOTS (DISCO_PH_COUNT + 1)
+
 /* tracing hooks (the reference brackets its functions with CLOCKSTART / CLOCKSTOP, BG/Common.h:71-95): every
  * phase of the path is a named roctx range, so `rocprofv3 --marker-trace --kernel-trace` shows the kernels under the C-ABI call
  * and the phase that launched them; without a tool attached a range costs two calls into an empty library */
@@ -234,6 +238,7 @@ struct disco_ctx {
     /* the grouping's counting pass ran inside the index pass, for the reads [lo, hi) with 2^bits buckets (d_ocnt holds the counts,
      * d_oslot the slots): the next disco_probe over exactly that range skips its own */
     bool order_counted = false;
+    bool order_ready = false; /* ... and disco_build_index went on to the order itself (d_order_own, for [order_counted_lo, order_counted_hi)): the fill walks it */
     /* contained rows on their way to the host while the pass goes on (disco_mark_contained -> disco_fetch_contained) */
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_crows = nullptr;
@@ -345,9 +350,9 @@ struct disco_ctx {
     u64 n_out = 0;
 
     /* live kernel timing (HIP events on the stream the kernels are launched on) */
-    hipEvent_t ev0[DISCO_PH_COUNT] = {nullptr}, ev1[DISCO_PH_COUNT] = {nullptr};
-    bool ev_pending[DISCO_PH_COUNT] = {false};
-    float ph_ms[DISCO_PH_COUNT] = {0};
+    hipEvent_t ev0[DISCO_PH_SLOTS] = {nullptr}, ev1[DISCO_PH_SLOTS] = {nullptr};
+    bool ev_pending[DISCO_PH_SLOTS] = {false};
+    float ph_ms[DISCO_PH_SLOTS] = {0};
 
     int phase = 0; /* 0 none, 1 reads, 2 index, 3 probe, 4 contained, 5 edges selected, 6 symmetrized, 7 marked, 8 emitted */
 
@@ -433,12 +438,18 @@ static void ph_end(disco_ctx *c, int id)
 /* call after the stream has been synchronised */
 static void ph_collect(disco_ctx *c)
 {
-    for (int i = 0; i < DISCO_PH_COUNT; i++)
+    for (int i = 0; i < DISCO_PH_SLOTS; i++)
         if (c->ev_pending[i]) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]) == hipSuccess) c->ph_ms[i] = ms;
             c->ev_pending[i] = false;
+            if (i == DISCO_PH_INDEX) c->ph_ms[DISCO_PH_INDEX2] = 0; /* (a new index phase: its second bracket, if it has one, is collected below) */
         }
+    /* the index phase in two brackets (the grouping sits between its count pass and its fill): reported as one */
+    if (c->ph_ms[DISCO_PH_INDEX2] > 0) {
+        c->ph_ms[DISCO_PH_INDEX] += c->ph_ms[DISCO_PH_INDEX2];
+        c->ph_ms[DISCO_PH_INDEX2] = 0;
+    }
 }
 
 template <typename T>
@@ -794,7 +805,7 @@ static int index_count_plan(disco_ctx *c, const DiscoView &v, u64 lo, u64 hi, In
     pl->lo = lo;
     pl->hi = hi;
     /* the counting pass of the grouping rides along when the indexed range is the query range (always, unless a caller narrows it) */
-    c->order_counted = false;
+    c->order_counted = c->order_ready = false;
     int obits = 0;
     if (lo == c->q_lo && hi == c->q_hi && own_order_wanted(c, nloc, &obits) && !getenv("DISCO_NO_ORDER_FUSE")) {
         const u64 order_buckets = 1ull << obits;
@@ -1080,7 +1091,7 @@ int disco_create(int device, const disco_params *p, disco_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_n_big, sizeof(u32)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_slow, sizeof(u32)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_extra, sizeof(u32)));
-    for (int i = 0; i < DISCO_PH_COUNT; i++) {
+    for (int i = 0; i < DISCO_PH_SLOTS; i++) {
         CREATE_CHK(hipEventCreate(&c->ev0[i]));
         CREATE_CHK(hipEventCreate(&c->ev1[i]));
     }
@@ -1144,7 +1155,7 @@ void disco_destroy(disco_ctx *c)
         if (c->ev_unpacked[i]) (void)hipEventDestroy(c->ev_unpacked[i]);
     }
     if (c->ev_bulk) (void)hipEventDestroy(c->ev_bulk);
-    for (int i = 0; i < DISCO_PH_COUNT; i++) {
+    for (int i = 0; i < DISCO_PH_SLOTS; i++) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
@@ -1960,7 +1971,7 @@ int disco_substitute_bases(disco_ctx *c, uint64_t seed, uint32_t rate_ppm)
     const u64 lo = c->comm ? c->q_lo : 0, hi = c->comm ? c->q_hi : c->n; /* multi-GPU flow: the other ranks' rows arrive by all-gather */
     if (hi > lo && rate_ppm)
         hipLaunchKernelGGL(substitute_bases_kernel, dim3(flat_grid(c, (hi - lo) * (u64)c->S)), dim3(256), 0, c->stream, (u64)seed, rate_ppm, c->d_reads, c->d_len, c->S, lo, hi);
-    c->index_counted = c->order_counted = false; /* what an upload counted ahead was counted on the reads as they were */
+    c->index_counted = c->order_counted = c->order_ready = false; /* what an upload counted ahead was counted on the reads as they were */
     HIPCHK(c, hipGetLastError());
     return DISCO_OK;
 }
@@ -2091,6 +2102,25 @@ int disco_build_index(disco_ctx *c)
         }
     }
     CHK((scan_exclusive<u32, u32>(c, c->d_bkt, c->T + 1, c->d_bkt, false, nullptr)));
+    /* the grouping of the reads (the processing order of probe / verify / selection / marking) was counted inside the index pass: it is
+     * finished here, so that the fill can walk it (index_fill_ordered_kernel); disco_probe finds it ready */
+    c->order_ready = false;
+    if (c->order_counted && c->order_counted_lo == 0 && c->order_counted_hi == c->n && !c->two_class && !getenv("DISCO_NO_ORDERED_FILL")) {
+        const u64 order_buckets = 1ull << c->order_counted_bits;
+        CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, c->n));
+        ph_end(c, DISCO_PH_INDEX);
+        ph_begin(c, DISCO_PH_ORDER);
+        CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_okey, c->d_oslot, c->d_ocnt, 32u - (u32)c->order_counted_bits, (u64)0, c->n, c->d_len, c->d_order_own);
+        ph_end(c, DISCO_PH_ORDER);
+        ph_begin(c, DISCO_PH_INDEX2);
+        hipLaunchKernelGGL(index_fill_ordered_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->n, (const u64 *)c->d_order_own, (const ulonglong2 *)c->d_rec, (const u32 *)c->d_bkt, c->d_ent);
+        ph_end(c, DISCO_PH_INDEX2);
+        HIPCHK(c, hipGetLastError());
+        c->order_ready = true;
+        c->phase = 2;
+        return DISCO_OK;
+    }
     if (c->n) hipLaunchKernelGGL(index_fill_kernel, dim3(flat_grid(c, 2 * c->n)), dim3(256), 0, c->stream, 2 * c->n, c->d_rec, c->d_bkt, c->d_ent);
     HIPCHK(c, hipGetLastError());
     ph_end(c, DISCO_PH_INDEX);
@@ -2226,6 +2256,8 @@ int disco_probe(disco_ctx *c)
         c->order_counted = false;
         if (c->loci) { /* the own list IS the processing order (grouped when the reads were dealt: dist_build_index) */
             c->d_order_used = c->d_order_own;
+        } else if (own_order && c->order_ready && counted) { /* disco_build_index finished the grouping (its fill walks the order) */
+            c->d_order_used = c->d_order_own; /* (DISCO_PH_ORDER was timed there) */
         } else if (own_order) {
             CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
             CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, nq));
