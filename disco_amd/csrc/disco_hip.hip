@@ -238,6 +238,10 @@ struct disco_ctx {
     /* the grouping's counting pass ran inside the index pass, for the reads [lo, hi) with 2^bits buckets (d_ocnt holds the counts,
      * d_oslot the slots): the next disco_probe over exactly that range skips its own */
     bool order_counted = false;
+    /* the big-item lists are sized from counts the producing kernels leave behind (verify: rows beyond ES_CAP; edge selection: nodes
+     * beyond TR_CAP) — valid until something else changes the rows: then the counting pass (ensure_big_cap) runs as before */
+    bool es_big_counted = false, tr_big_counted = false;
+    bool contained_count_pending = false; /* disco_run_graph: n_contained is read with the next counters */
     bool order_ready = false; /* ... and disco_build_index went on to the order itself (d_order_own, for [order_counted_lo, order_counted_hi)): the fill walks it */
     /* contained rows on their way to the host while the pass goes on (disco_mark_contained -> disco_fetch_contained) */
     hipStream_t aux_stream = nullptr;
@@ -1520,12 +1524,23 @@ static void ingest_tables(FxTables *tb)
 }
 
 /* the file's bytes into d_text: host threads pread slices of a chunk into one half of a pinned ring while the other half travels */
-static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned threads)
+/* flags of the pinned staging ring (DISCO_RING_MODE: 0 the runtime's default, 1 non-coherent = cached on the host side) */
+static unsigned ring_alloc_flags()
+{
+    const int mode = env_int("DISCO_RING_MODE", 0);
+    return mode == 1 ? hipHostMallocNonCoherent : (mode == 2 ? hipHostMallocCoherent : hipHostMallocDefault);
+}
+
+/* the pinned ring, its events and the copy stream (first use). Measured, round 5: calls into the runtime from this thread — this
+ * allocation, every hipMemcpyAsync of the reader — can wait behind the helper thread's hipMalloc of the 28 GB hit buffer; that is the
+ * stage's "slow mode" (files into HBM 0.2 s or, in bursts, 0.6-1.8 s with the reader's own waits unchanged). Making the ring first moves
+ * the overlap onto the filter kernels instead (0.12 -> 0.18 s): no gain, not kept. */
+static int ingest_ring(disco_ctx *c)
 {
     const size_t HALF = 128u << 20;
     CHK(ring_back_from_rows(c));
     if (!c->h_ring) {
-        if (hipHostMalloc(&c->h_ring, 2 * HALF) != hipSuccess) {
+        if (hipHostMalloc(&c->h_ring, 2 * HALF, ring_alloc_flags()) != hipSuccess) {
             c->h_ring = nullptr;
             (void)hipGetLastError();
             return fail(c, DISCO_E_NOMEM, "disco_ingest_fasta: no pinned staging memory");
@@ -1540,33 +1555,94 @@ static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned th
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_unpacked[i], hipEventDisableTiming));
         }
     }
-    threads = std::max(1u, std::min(threads, 32u));
+    return DISCO_OK;
+}
+
+static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned threads)
+{
+    /* The file travels through a pinned ring of RING_SLOTS slots (256 MB in all, as the two halves of rounds 3-4 were): reader threads
+     * that live as long as the file — no thread is started per slot — pread piece after piece, in file order, into the next slot that is
+     * free; the main thread sends a slot to the device as soon as its pieces are in, two copies in flight, and hands a slot back when its
+     * copy is through. With two halves the readers waited for the copy of the half before last before they could start (0.8 of every
+     * 3.3 ms: `waiting for the ring` in the DISCO_VERBOSE line of round 4); with four slots reading runs ahead of the link. */
+    constexpr unsigned RING_SLOTS = 4;
+    const size_t HALF = 128u << 20, SLOT = 2 * HALF / RING_SLOTS;
+    CHK(ingest_ring(c));
+    /* (the ring's slots need an event each: ev_ring has two, the upload's ev_copied — idle here — the others) */
+    hipEvent_t ev[RING_SLOTS] = {c->ev_ring[0], c->ev_ring[1], c->ev_copied[0], c->ev_copied[1]};
+    threads = (unsigned)env_int("DISCO_INGEST_THREADS", (int)threads); /* (measurement: readers of the file, whatever -t says) */
+    threads = std::max(1u, std::min(threads, 64u));
     CHK(copy_stream_after_stream(c));
-    u64 k = 0;
-    for (u64 off = 0; off < n; off += HALF, k++) {
-        const size_t len = (size_t)std::min<u64>(HALF, n - off);
-        char *half = (char *)c->h_ring + (k & 1) * HALF;
-        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_ring[k & 1])); /* the copy out of this half two chunks ago */
-        std::atomic<bool> ok{true};
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < threads; t++)
-            th.emplace_back([&, t]() {
-                size_t p0 = len * t / threads, p1 = len * (t + 1) / threads;
-                while (p0 < p1) {
-                    const ssize_t got = pread(fd, half + p0, p1 - p0, (off_t)(off + p0));
+    const u64 n_chunks = (n + SLOT - 1) / SLOT;
+    const u64 n_pieces = n_chunks * threads;
+    std::atomic<u64> next_piece{0};
+    std::vector<std::atomic<int>> slot_free(n_chunks), pieces_in(n_chunks); /* chunk k: its slot may be written / pieces of it that are in */
+    for (u64 k = 0; k < n_chunks; k++) {
+        slot_free[k].store(k < RING_SLOTS ? 1 : 0);
+        pieces_in[k].store(0);
+    }
+    std::atomic<bool> ok{true}, stop{false};
+    auto nap = [] { std::this_thread::sleep_for(std::chrono::microseconds(30)); };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const u64 p = next_piece.fetch_add(1);
+                if (p >= n_pieces) return;
+                const u64 k = p / threads;
+                const unsigned piece = (unsigned)(p % threads);
+                while (!slot_free[k].load(std::memory_order_acquire)) {
+                    if (stop.load()) return;
+                    nap();
+                }
+                const u64 off = k * (u64)SLOT;
+                const size_t len = (size_t)std::min<u64>(SLOT, n - off);
+                char *slot = (char *)c->h_ring + (k % RING_SLOTS) * SLOT;
+                size_t p0 = len * piece / threads, p1 = len * (piece + 1) / threads;
+                while (p0 < p1 && ok.load()) {
+                    const ssize_t got = pread(fd, slot + p0, p1 - p0, (off_t)(off + p0));
                     if (got <= 0) {
                         ok.store(false);
-                        return;
+                        break;
                     }
                     p0 += (size_t)got;
                 }
-            });
-        for (auto &x : th) x.join();
+                pieces_in[k].fetch_add(1, std::memory_order_release);
+            }
+        });
+    struct Join { /* whatever happens below, the readers are told and waited for */
+        std::vector<std::thread> &th;
+        std::atomic<bool> &stop;
+        ~Join()
+        {
+            stop.store(true);
+            for (auto &x : th)
+                if (x.joinable()) x.join();
+        }
+    } join_readers{th, stop};
+    double t_fill = 0, t_copy = 0;
+    const auto t_all = HClock::now();
+    for (u64 k = 0; k < n_chunks; k++) {
+        auto tw = HClock::now();
+        while (pieces_in[k].load(std::memory_order_acquire) < (int)threads && ok.load()) nap();
+        t_fill += ms_since(tw);
         if (!ok.load()) return fail(c, DISCO_E_ARG, "disco_ingest_fasta: read error");
-        HIPCHK(c, hipMemcpyAsync(d_text + off, half, len, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->ev_ring[k & 1], c->copy_stream));
+        const u64 off = k * (u64)SLOT;
+        const size_t len = (size_t)std::min<u64>(SLOT, n - off);
+        HIPCHK(c, hipMemcpyAsync(d_text + off, (char *)c->h_ring + (k % RING_SLOTS) * SLOT, len, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(ev[k % RING_SLOTS], c->copy_stream));
+        tw = HClock::now();
+        if (k >= 1) { /* the copy before this one: through, its slot goes back to the readers (this copy is queued behind it already) */
+            HIPCHK(c, hipEventSynchronize(ev[(k - 1) % RING_SLOTS]));
+            if (k - 1 + RING_SLOTS < n_chunks) slot_free[k - 1 + RING_SLOTS].store(1, std::memory_order_release);
+        }
+        t_copy += ms_since(tw);
     }
+    auto tw = HClock::now();
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (getenv("DISCO_VERBOSE"))
+        fprintf(stderr, "[disco] file reader: %.1f MB in %llu slots of %zu MB, %u readers: waited %.1f ms for pieces, %.1f ms for copies, last copy %.1f ms, all %.1f ms\n", n / 1e6,
+                (unsigned long long)n_chunks, SLOT >> 20, threads, t_fill, t_copy, ms_since(tw), ms_since(t_all));
     return DISCO_OK;
 }
 
@@ -2226,6 +2302,8 @@ int disco_probe(disco_ctx *c)
         HIPCHK(c, hipMemsetAsync(c->d_n_slow, 0, sizeof(u32), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ctr + CTR_KMER_HITS, 0, sizeof(u64) * 4, c->stream)); /* KMER_HITS, RAW_HITS, HITS_NEEDED, OVERFLOW */
         CHK(zero_counter(c, CTR_MAX_ROW));
+        CHK(zero_counter(c, CTR_ES_BIG));
+        c->es_big_counted = c->tr_big_counted = false;
         ProbeArgs a;
         a.v = view(c);
         a.hits = c->d_hits;
@@ -2409,6 +2487,7 @@ int disco_probe(disco_ctx *c)
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));
             ph_collect(c);
+            c->es_big_counted = true; /* (h_ctr[CTR_ES_BIG]: rows with more than ES_CAP verified hits) */
             c->phase = 3;
             return DISCO_OK;
         }
@@ -2483,7 +2562,23 @@ static int select_edges(disco_ctx *c)
     CHK(zero_counter(c, CTR_ES_SLOW));
     CHK(zero_counter(c, CTR_ADJ_TOTAL));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    CHK(ensure_big_cap(c, c->d_row_cnt, nullptr, ES_CAP)); /* the kernel rewrites rows in place: it cannot be rerun after an overflow */
+    CHK(zero_counter(c, CTR_TR_BIG));
+    /* the kernel rewrites rows in place: it cannot be rerun after an overflow, so its big-row list must hold every such row — counted by
+     * verify (no pass of its own, no wait in front of the selection), or here */
+    if (c->es_big_counted && !getenv("DISCO_COUNT_BIG_ROWS")) {
+        const u64 need = c->h_ctr[CTR_ES_BIG] + 1024;
+        if (need > c->big_cap) {
+            if (need > 0xFFFFFFFFull) return fail(c, DISCO_E_CAPACITY, "more than 2^32 big rows");
+            dev_free(c, &c->d_big_list, c->big_cap);
+            dev_free(c, &c->d_big_cnt, c->big_cap);
+            c->big_cap = 0;
+            CHK(dev_alloc(c, &c->d_big_list, need));
+            CHK(dev_alloc(c, &c->d_big_cnt, need));
+            c->big_cap = (u32)need;
+        }
+    } else
+        CHK(ensure_big_cap(c, c->d_row_cnt, nullptr, ES_CAP));
+    c->es_big_counted = false;
     EdgeSelArgs a;
     a.v = view(c);
     if (!c->d_dropbits) CHK(dev_alloc(c, &c->d_dropbits, c->n_alloc / 64 + 1));
@@ -2553,6 +2648,11 @@ static int select_edges(disco_ctx *c)
     }
     c->dropped = c->dropped_local = c->h_ctr[CTR_DROPPED];
     c->n_drop_items = a.drop_node ? c->h_ctr[CTR_DROP_ITEMS] : ~0ull;
+    c->tr_big_counted = true; /* (h_ctr[CTR_TR_BIG]: nodes with more than TR_CAP finds) */
+    if (c->contained_count_pending) { /* disco_run_graph: the flags' count came back with these counters */
+        c->n_contained = c->h_ctr[CTR_N_CONTAINED];
+        c->contained_count_pending = false;
+    }
     if (getenv("DISCO_VERBOSE"))
         fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
                 (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
@@ -2701,6 +2801,7 @@ static int merge_extras(disco_ctx *c)
 {
     DISCO_TRACE("merge_extras");
     if (c->n_extra == 0) return DISCO_OK;
+    c->tr_big_counted = false; /* rows grow */
     /* a handful of extras and the rows still where edge selection left them (one GPU): move only the rows that grow into the free
      * tail of the hit buffer — 84 ms of the 272 ms pass at 50 M reads with 0.3 % errors went into rebuilding all of it for 953 extras */
     if (merge_is_sparse(c)) {
@@ -2871,6 +2972,7 @@ int disco_import_adjacency(disco_ctx *c, const void *d_deg_u32_all, const void *
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->adj_imported = true;
+    c->tr_big_counted = false;
     c->adj_span = total;
     c->half_complete = false;
     c->phase = 5;
@@ -2890,7 +2992,19 @@ int disco_transitive_mark(disco_ctx *c)
     const u64 nq = c->q_hi - c->q_lo;
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    CHK(ensure_big_cap(c, nullptr, c->d_adj_ref, TR_CAP));
+    if (c->tr_big_counted && c->q_lo == 0 && c->q_hi == c->n && !getenv("DISCO_COUNT_BIG_ROWS")) { /* edge selection counted the nodes beyond TR_CAP */
+        const u64 need = c->h_ctr[CTR_TR_BIG] + 1024;
+        if (need > c->big_cap) {
+            if (need > 0xFFFFFFFFull) return fail(c, DISCO_E_CAPACITY, "more than 2^32 big nodes");
+            dev_free(c, &c->d_big_list, c->big_cap);
+            dev_free(c, &c->d_big_cnt, c->big_cap);
+            c->big_cap = 0;
+            CHK(dev_alloc(c, &c->d_big_list, need));
+            CHK(dev_alloc(c, &c->d_big_cnt, need));
+            c->big_cap = (u32)need;
+        }
+    } else
+        CHK(ensure_big_cap(c, nullptr, c->d_adj_ref, TR_CAP));
     TrArgs a;
     a.v = view(c);
     a.ref = c->d_adj_ref;
@@ -2930,6 +3044,8 @@ int disco_transitive_mark(disco_ctx *c)
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
     HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    c->n_wide = 0;
+    if (c->use_half) HIPCHK(c, hipMemcpyAsync(&c->n_wide, c->d_n_wide, sizeof(u32), hipMemcpyDeviceToHost, c->stream)); /* (read again below if the big nodes add to it) */
     CHK(read_counters(c));
     ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking: big-node list overflow (%u nodes)", n_big);
@@ -2957,10 +3073,7 @@ int disco_transitive_mark(disco_ctx *c)
         CHK(rc2);
         if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "transitive marking (big nodes): list overflow");
     }
-    c->n_wide = 0;
-    if (c->use_half) {
-        HIPCHK(c, hipMemcpy(&c->n_wide, c->d_n_wide, sizeof(u32), hipMemcpyDeviceToHost));
-    }
+    if (n_big && c->use_half) HIPCHK(c, hipMemcpy(&c->n_wide, c->d_n_wide, sizeof(u32), hipMemcpyDeviceToHost));
     c->flags_pending = false;
     c->phase = 7;
     return DISCO_OK;
@@ -3004,6 +3117,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             h.bump = c->d_bump;
             h.local_only = c->dist_active ? 1u : 0u;
             h.own = own_set(c);
+            h.order = nullptr; /* (tried for one GPU, round 5: the nodes in processing order — 5.3 instead of 3.4 ms: the node's own entries become the random fetches) */
             const int gh = wq_grid(c, emit_half_kernel, (nq + 63) / 64, "DISCO_EMIT_WAVES");
             hipLaunchKernelGGL(emit_half_kernel, dim3(gh), dim3(64), 0, c->stream, h);
         }
@@ -3062,7 +3176,8 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             c->valid_cap = c->out_cap;
         }
         hipLaunchKernelGGL(emit_valid_kernel, dim3(flat_grid(c, c->out_used)), dim3(256), 0, c->stream, c->d_out_src, c->out_used, c->d_out_valid);
-        CHK((scan_exclusive<u8, u64>(c, c->d_out_valid, c->out_used, c->d_out_pos, true, &total)));
+        CHK((scan_exclusive<u8, u64>(c, c->d_out_valid, c->out_used, c->d_out_pos, true, nullptr)));
+        HIPCHK(c, hipMemcpyAsync(&total, c->d_total, sizeof(u64), hipMemcpyDeviceToHost, c->stream)); /* (with the phase's one wait) */
     }
     ph_end(c, DISCO_PH_EMIT);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3090,7 +3205,18 @@ int disco_run_graph(disco_ctx *c)
     auto t1 = now();
     CHK(disco_probe(c));
     auto t2 = now();
-    CHK(disco_mark_contained(c, nullptr));
+    { /* disco_mark_contained without its wait: the count of the flags comes back with edge selection's counters */
+        if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
+        if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
+        CHK(zero_counter(c, CTR_N_CONTAINED));
+        ph_begin(c, DISCO_PH_CONTAIN);
+        if (c->n) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, c->n)), dim3(256), 0, c->stream, c->d_best, c->n, c->d_contained, c->d_cbits, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        ph_end(c, DISCO_PH_CONTAIN);
+        c->contained_count_pending = true;
+        c->phase = 4;
+        c->crows_pending = c->cgrp_pending = false;
+    }
     auto t3 = now();
     CHK(disco_build_edges(c, nullptr));
     auto t4 = now();
@@ -3538,7 +3664,7 @@ int disco_write_edge_text(disco_ctx *c, const int *fds, uint32_t n_files, uint32
     const size_t HALF = 128u << 20;
     CHK(ring_back_from_rows(c));
     if (!c->h_ring) {
-        if (hipHostMalloc(&c->h_ring, 2 * HALF) != hipSuccess) {
+        if (hipHostMalloc(&c->h_ring, 2 * HALF, ring_alloc_flags()) != hipSuccess) {
             c->h_ring = nullptr;
             (void)hipGetLastError();
             return fail(c, DISCO_E_NOMEM, "disco_write_edge_text: no pinned staging memory");

@@ -1635,6 +1635,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             if (MODE != 1) {
                 if (lane == 0) {
                     if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
+                    if (nkeep > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull); /* (sizes edge selection's big-row list: no counting pass, no host round trip in front of it) */
                     my_raw += nkeep;
                 }
                 if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
@@ -1998,6 +1999,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
                     s_nk[seg] = kept;
                     my_raw += kept;
                     if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
+                    if (kept > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull);
                 }
                 carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
             }
@@ -2542,6 +2544,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
         if (ndef) flush();
         if (lane == 0) {
             if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
+            if (nkeep > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull);
             my_raw += nkeep;
             a.meta_ord[ci].y = (u64)nkeep | ((u64)LA << 32);
         }
@@ -2816,6 +2819,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
             lds_bitonic_sort(h, P, lane);
             for (u32 i = lane; i < m; i += 64) row[i] = h[i];
             if (lane == 0) a.ref[A] = REF_MAKE(rs, m);
+            if (lane == 0 && m > TR_CAP) atomicAdd(&a.v.ctr[CTR_TR_BIG], 1ull); /* (sizes the marking's big-node list) */
             n_edges += m;
             __syncthreads();
             return;
@@ -2870,6 +2874,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     __syncthreads();
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
     if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
+    if (lane == 0 && nacc > TR_CAP) atomicAdd(&a.v.ctr[CTR_TR_BIG], 1ull);
     n_edges += nacc;
     dropped += m - nacc;
     if (lane == 0 && m != nacc) atomicOr(&a.dropbits[A >> 6], 1ull << (A & 63));
@@ -4300,6 +4305,10 @@ struct EmitHalfArgs {
     u64 *bump;
     u32 local_only; /* see EmitArgs */
     OwnSet own;
+    /* one GPU: the nodes in the processing order of the pass (or null: ascending id). A node's two or three surviving neighbours are
+     * reads of its own locus: in this order their survivor lists — the 32-byte gathers of this kernel — are lists the neighbouring
+     * lanes and the wavefronts next door touch too */
+    const u64 *order;
 };
 
 __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
@@ -4319,7 +4328,7 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
     while (wq_grab(a.v.wq, (nq + 63) / 64, cbeg, cend))
     for (u64 blk = cbeg; blk < cend; blk++) {
         const bool live = blk * 64 + lane < nq;
-        const u64 v = a.own.node_by_id(live ? blk * 64 + lane : 0);
+        const u64 v = a.order ? ORDER_ID(a.order[live ? blk * 64 + lane : 0]) : a.own.node_by_id(live ? blk * 64 + lane : 0);
         const u32 cnt = live ? a.hcnt[v] : 0u;
         const u32 Lv = live ? (u32)a.v.len[v] : 0u;
 #pragma unroll
