@@ -212,12 +212,22 @@ def stage_wall(args, spec, e_pre):
         with open(os.path.join(d, "disco.cfg"), "w") as f:
             f.write(f"MinOverlap4BuildGraph = {args.min_overlap}\n")
         cores = usable_cores()
-        t0 = time.perf_counter()
-        p = subprocess.run([exe, "-se", fa, "-f", os.path.join(d, "g"), "-p", os.path.join(d, "disco.cfg"), "-t", str(cores)],
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"))
-        wall = time.perf_counter() - t0
-        if p.returncode != 0:
-            return {"failed": p.stdout[-500:]}
+        # three runs, the median reported (all three listed): on the shared boxes of this pool one run in three meets a burst of
+        # interference (other tenants' jobs on the node; the runtime's allocator lock behind the 28 GB hit buffer of a process that
+        # starts while the driver still scrubs what the previous one freed) that doubles single phases — profiles/r05_stage_runs.txt.
+        # The input is in the page cache in every run (the generator wrote it seconds ago: "input_page_cache": "warm").
+        runs = []
+        for rep in range(3):
+            for f in os.listdir(d):
+                if f.startswith("g_"):
+                    os.unlink(os.path.join(d, f))
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, "-se", fa, "-f", os.path.join(d, "g"), "-p", os.path.join(d, "disco.cfg"), "-t", str(cores)],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"))
+            runs.append((time.perf_counter() - t0, p))
+            if p.returncode != 0:
+                return {"failed": p.stdout[-500:]}
+        wall, p = sorted(runs, key=lambda x: x[0])[1]
         parts = {}
         for key, pat in (("parse_filter_pack_s", r"Function readDataset\(\) finished in ([0-9.eE+-]+)"), ("graph_s", r"\[GPU\] finished in ([0-9.eE+-]+)"),
                          ("upload_s", r"host->device ([0-9.eE+-]+)"), ("fetch_and_write_s", r"Function saveParGraphToFile\(\) finished in ([0-9.eE+-]+)"),
@@ -229,7 +239,8 @@ def stage_wall(args, spec, e_pre):
         m = re.search(r"overlaps \(pre-reduction\) : (\d+)", p.stdout)
         same = (int(m.group(1)) == e_pre) if m else None
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("g_"))
-        return {"wall_s": round(wall, 3), "overlaps_per_s": e_pre / wall, "host_threads": cores, "fasta_bytes": os.path.getsize(fa), "output_bytes": out_bytes,
+        return {"wall_s": round(wall, 3), "wall_s_runs": [round(w, 3) for w, _ in runs], "wall_s_is": "median of three runs", "input_page_cache": "warm",
+                "overlaps_per_s": e_pre / wall, "host_threads": cores, "fasta_bytes": os.path.getsize(fa), "output_bytes": out_bytes,
                 "same_overlap_count_as_the_bench_pass": same, "fasta_generation_s": round(t_gen, 2), **parts,
                 "what": "disco_amd/bin/buildG on the FASTA of the benched reads, process start to files closed (the reference's main() timer)"}
     finally:

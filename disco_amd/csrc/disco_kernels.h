@@ -3159,7 +3159,11 @@ __global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_fl
     /* a sub-chunk: consecutive reads of the chunk, as many as fit ROWS rows and NB batches of 64 hits (greedy) */
     constexpr u32 SETW = 128;
     static_assert(NB >= 1 && ROWS >= 1 && ROWS <= 8, "a row has at most 64 hits: one batch always holds a row; the jc array is cleared by one store per lane");
+#ifdef ES_EXP_SMALL_LDS /* timing experiment (tools/ab_build.py; rows of the sequential path come out wrong): what the flat kernel gains when the sequential path's work arrays leave its LDS */
+    __shared__ __attribute__((aligned(16))) u64 s_ent[ROWS * 64];
+#else
     __shared__ __attribute__((aligned(16))) u64 s_ent[ROWS * 64 > 2 * ES_CAP ? ROWS * 64 : 2 * ES_CAP]; /* row r: [64 r, 64 r + 64); old paths: their two work arrays */
+#endif
     __shared__ __attribute__((aligned(16))) u32 s_bins[ROWS * 64];  /* row r, offset o: byte o & 3 of word 64 r + (o >> 2): entries */
     __shared__ __attribute__((aligned(16))) u32 s_start[ROWS * 64]; /* ... : first position of the bin */
     __shared__ __attribute__((aligned(16))) u32 s_jc[ROWS * 32 > 128 ? ROWS * 32 : 128]; /* row r, window j: byte j & 3 of word 32 r + ((j & 127) >> 2) */
@@ -3409,7 +3413,9 @@ __global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_fl
             }
             if (!done) {
                 n_slow++;
+#ifndef ES_EXP_SMALL_LDS
                 edge_select_row<ES_CAP>(a, Ai, rs, s_ent, s_ent + ES_CAP, c0, lane, s_jc, cap_sites, dropped, n_edges);
+#endif
             }
         }
     }
@@ -3844,7 +3850,11 @@ static_assert(TR_HASH_LOAD * 64 < 2 * TR_CAP, "the register path's table (at mos
 #define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
 /* slot of a node id (< 2^31) in the marking hash: one 32-bit multiply (disco_hash64 costs two 64-bit multiplies — eight
  * quarter-rate 32-bit ones — and is evaluated for every entry of every swept row) */
+#ifdef TR_EXP_XOR_HASH /* timing experiment: two full-rate instructions instead of a quarter-rate 32-bit multiply and a shift */
+__device__ __forceinline__ u32 tr_hash(u64 id, u32 hmask) { return ((u32)id ^ ((u32)id >> 9)) & hmask; }
+#else
 __device__ __forceinline__ u32 tr_hash(u64 id, u32 hmask) { return (((u32)id * 0x9E3779B1u) >> 10) & hmask; }
+#endif
 
 template <bool N32>
 __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey, u8 *hstate, u32 *sent, u32 hmask, u32 lane)

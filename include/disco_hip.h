@@ -201,8 +201,10 @@ int disco_import_adjacency(disco_ctx *ctx, const void *d_deg_u32_all, const void
 /* ---- multi-GPU flow: one context per GPU (rank), RCCL underneath ------------------------------------------------------
  * Replaces buildG-MPI / buildG-MPIRMA (MPI/main.cpp:29-37 MPI_Init_thread + rank ranges, RMA/HashTable.cpp:95-116 range split of
  * hashData, :422-435 RMA window, :644-653,694-705 MPI_Get per bucket, :1066-1087 needsProcessing ownership,
- * MPI/OverlapGraph.cpp:218-246,473-506 gossip of marked / contained ids). Reads and graph nodes are range-partitioned
- * (rank r owns ids [r*per, (r+1)*per)), the index is BUILT hash-partitioned (records routed by all-to-all to the owner of their
+ * MPI/OverlapGraph.cpp:218-246,473-506 gossip of marked / contained ids). The reads ARRIVE range-partitioned (rank r uploads the ids
+ * [r*per, (r+1)*per)); inside a pass they — the graph nodes — are dealt to the ranks by their read-level minimizer (round 5: ranks own
+ * loci, disco_dist_info.placement; id ranges for inexact overlaps, the partitioned index and the gather-everything regime);
+ * the index is BUILT hash-partitioned (records routed by all-to-all to the owner of their
  * bucket range) and its shards exchanged; containment keys are min-reduced to the owner; the transitive reduction fetches the
  * two or three neighbour rows a node's marking sweeps ON REQUEST from their owners (all-to-all), and surviving half-edges are
  * pushed to the owner of the smaller endpoint. Every call below is COLLECTIVE: all ranks, same order. */

@@ -105,7 +105,7 @@ for it in range(iters):
         assert np.array_equal(cc1, cc3), f"{G} ranks: contained rows differ ({len(cc1)} vs {len(cc3)})"
         assert np.array_equal(ce1, ce3), f"{G} ranks: edges differ ({len(ce1)} vs {len(ce3)})"
         assert info["e_pre"] == c["e_pre"] and info["asymmetric_pairs"] == c["asymmetric_pairs"] and info["cap_bind_sites"] == c["cap_bind_sites"], (info, c)
-        print("ok  ", label, "e_pre", c["e_pre"], "e_out", c["e_out"], "contained", c["n_contained"], "regime", info["regime"], "rounds", info["tr_rounds"],
+        print("ok  ", label, "e_pre", c["e_pre"], "e_out", c["e_out"], "contained", c["n_contained"], "regime", info["regime"], "placement", "loci" if info["placement"] else "id ranges", "rounds", info["tr_rounds"],
               "deferred", info["tr_deferred"], flush=True)
     except Exception as e:
         fails += 1
