@@ -112,7 +112,7 @@ ABI = [
 ]
 
 FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
-XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins", "queries", "hits", "keys", "reads_dealt")
+XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins", "queries", "hits", "keys", "reads_dealt", "contain_keys")
 UNIQUE_ID_BYTES = 128
 DIST_GATHER_READS = 1
 DIST_KEEP_INDEX_PARTITIONED = 2

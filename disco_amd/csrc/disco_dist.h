@@ -304,6 +304,35 @@ __global__ void list_to_bits_kernel(const u32 *__restrict__ list, u64 n, u64 *__
     for (; i < n; i += (u64)gridDim.x * blockDim.x) atomicOr((unsigned long long *)&bits[list[i] >> 6], 1ull << (list[i] & 63u));
 }
 
+/* ---- containment across ranks: who IS contained is a bitmap's business, the key only matters to the row that is written at the end --- */
+/* bit i: read i has a containment key on this rank (n a multiple of 64: the table's padded size; best = DISCO_NOKEY beyond the reads) */
+__global__ void has_key_bits_kernel(const u64 *__restrict__ best, u64 n, u64 *__restrict__ bits)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 mk = __ballot(best[i] != DISCO_NOKEY);
+        if ((threadIdx.x & 63) == 0) bits[i >> 6] = mk;
+    }
+}
+/* OR of the ranks' bitmaps (rank p's at all + p * words) -> cbits of every read; byte flags and their count for the words [w0, w1)
+ * (the home range: what disco_fetch_contained walks) */
+__global__ void or_bits_kernel(const u64 *__restrict__ all, u32 G, u64 words, u64 *__restrict__ cbits, u64 w0, u64 w1, u8 *__restrict__ contained, u64 *ctr)
+{
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 cnt = 0;
+    for (; w < words; w += (u64)gridDim.x * blockDim.x) {
+        u64 x = 0;
+        for (u32 p = 0; p < G; p++) x |= all[(u64)p * words + w];
+        cbits[w] = x;
+        if (w >= w0 && w < w1 && x) {
+            cnt += (u32)__popcll(x);
+            for (u64 y = x; y; y &= y - 1) contained[w * 64 + (u64)(__ffsll((long long)y) - 1)] = 1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&ctr[CTR_N_CONTAINED], (unsigned long long)cnt);
+}
+
 /* ---- hash-partitioned index build (the owner's side) ------------------------------------------------------------------ */
 /* records received from all ranks: count per bucket of this rank's range; the atomic hands every record its slot */
 __global__ void shard_count_kernel(ulonglong2 *__restrict__ rec, u64 n, u32 *__restrict__ bkt)

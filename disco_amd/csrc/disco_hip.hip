@@ -402,6 +402,12 @@ struct disco_ctx {
     u64 own_ids_cap = 0, n_own = 0;
     u64 home_lo = 0, home_hi = 0;
     u64 home_probes = 0; /* sum of len - k over the home range */
+    /* the containment keys' reduce-scatter runs behind the pass on the second communicator (dist_mark_contained): whoever touches best[]
+     * next waits for ev_keys */
+    u64 *d_cb_all = nullptr; /* the ranks' "has a key" bitmaps, rank after rank */
+    u64 cb_all_cap = 0;
+    hipEvent_t ev_keys = nullptr, ev_keys_go = nullptr;
+    bool keys_pending = false;
     disco_dist_info dinfo{};
 };
 
@@ -543,6 +549,16 @@ static OwnSet own_set(const disco_ctx *c)
     o.n_own = c->loci ? c->n_own : 0;
     o.ids = c->loci ? c->d_own_ids : nullptr;
     return o;
+}
+
+/* best[] of the home range is final only when the reduce-scatter that runs behind the pass is through: the context's stream waits for it */
+static int settle_keys(disco_ctx *c)
+{
+    if (c->keys_pending) {
+        c->keys_pending = false;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_keys, 0));
+    }
+    return DISCO_OK;
 }
 
 static int env_int(const char *name, int dflt)
@@ -709,6 +725,8 @@ static void free_graph_state(disco_ctx *c)
     c->rpos_cap = c->nadj_cap = c->nadj_used = c->deg_tmp_cap = 0;
     c->d_push_r = nullptr;
     c->n_push_r = 0;
+    dev_free(c, &c->d_cb_all, c->cb_all_cap);
+    c->cb_all_cap = 0;
     dev_free(c, &c->d_otab, c->n_alloc);
     dev_free(c, &c->d_own_ids, c->own_ids_cap);
     c->own_ids_cap = c->n_own = 0;
@@ -1159,6 +1177,8 @@ void disco_destroy(disco_ctx *c)
         if (c->ev_unpacked[i]) (void)hipEventDestroy(c->ev_unpacked[i]);
     }
     if (c->ev_bulk) (void)hipEventDestroy(c->ev_bulk);
+    if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
+    if (c->ev_keys_go) (void)hipEventDestroy(c->ev_keys_go);
     for (int i = 0; i < DISCO_PH_SLOTS; i++) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -2212,6 +2232,7 @@ int disco_probe(disco_ctx *c)
     if (c->phase < 2) return fail(c, DISCO_E_STATE, "disco_probe: build the index first");
     HIPCHK(c, hipSetDevice(c->device));
     CHK(settle_contained_rows(c)); /* rows of the previous pass still travelling read best[] */
+    CHK(settle_keys(c));           /* ... and so does a key exchange that runs behind a multi-GPU pass */
     settle_hits_prealloc(c);
     const u64 nq = c->q_hi - c->q_lo;
     if (!c->d_best) {
@@ -3278,6 +3299,7 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
         return (int64_t)nc;
     }
     CHK(ensure_host_len(c));
+    CHK(settle_keys(c));
     u64 *pos = nullptr, *ids = nullptr, *keys = nullptr;
     std::vector<u64> hid(nc), hkey(nc);
     auto gather = [&]() -> int {
@@ -3296,6 +3318,10 @@ int64_t disco_fetch_contained(disco_ctx *c, disco_contained_row *out, uint64_t c
     dev_free(c, &ids, nc);
     dev_free(c, &keys, nc);
     CHK(grc);
+    for (u64 i = 0; i < nc; i++) /* (a key that names no read must not index the length table: fail loudly) */
+        if (CKEY_SUPER(hkey[i]) >= c->n || hid[i] >= c->n)
+            return fail(c, DISCO_E_STATE, "disco_fetch_contained: row %llu of %llu: read %llu has the key %llx (no containing read)", (unsigned long long)i, (unsigned long long)nc,
+                        (unsigned long long)hid[i], (unsigned long long)hkey[i]);
     decode([&hid](u64 i) { return hid[i]; }, hkey.data(), nullptr);
     return (int64_t)nc;
 }
@@ -4538,12 +4564,48 @@ static int dist_mark_contained(disco_ctx *c)
     if (!c->d_contained) CHK(dev_alloc(c, &c->d_contained, c->n_alloc));
     if (!c->d_cbits) CHK(dev_alloc(c, &c->d_cbits, c->n_alloc / 64 + 1));
     const auto t0 = HClock::now();
+    const u64 r = (u64)c->comm->rank;
+    /* Who is contained decides everything that follows in the pass (edge selection, the second verify pass); by WHOM — the smallest key
+     * over the ranks — only the row that is written at the end. So the pass exchanges bitmaps (every rank's "has a key" bits: n / 8
+     * bytes per rank instead of 8 n) and the keys' reduce-scatter runs behind it, on the second communicator and stream: 1.0 ms of
+     * link time at G = 8 / 50 M reads that nothing used to hide. DISCO_DIST_KEYS_ON_PATH=1 (every rank alike), one communicator: as before */
+    if (c->comm_bulk && !getenv("DISCO_DIST_ONE_COMM") && !getenv("DISCO_DIST_KEYS_ON_PATH")) {
+        const u64 words = c->n_alloc / 64;
+        CHK(ensure_cap(c, &c->d_cb_all, &c->cb_all_cap, std::max<u64>(words * G, 1)));
+        if (!c->ev_keys) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_keys_go, hipEventDisableTiming));
+        }
+        CHK(zero_counter(c, CTR_N_CONTAINED));
+        ph_begin(c, DISCO_PH_CONTAIN);
+        u64 *mine = c->d_cb_all + r * words;
+        if (c->n_alloc) hipLaunchKernelGGL(has_key_bits_kernel, dim3(flat_grid(c, c->n_alloc)), dim3(256), 0, c->stream, (const u64 *)c->d_best, c->n_alloc, mine);
+        HIPCHK(c, hipGetLastError());
+        COMM_CHK(c, c->comm->all_gather(mine, c->d_cb_all, words * 8, c->stream));
+        c->dinfo.bytes_sent[DISCO_X_CONTAIN] += (u64)(G - 1) * words * 8;
+        HIPCHK(c, hipMemsetAsync(c->d_contained, 0, std::max<u64>(c->n_alloc, 1), c->stream));
+        if (words) hipLaunchKernelGGL(or_bits_kernel, dim3(flat_grid(c, words)), dim3(256), 0, c->stream, (const u64 *)c->d_cb_all, G, words, c->d_cbits, r * per / 64, (r + 1) * per / 64, c->d_contained, c->d_ctr); /* (r per, not home_lo: a rank behind the last read has home_lo = n, in the middle of another rank's word) */
+        HIPCHK(c, hipGetLastError());
+        ph_end(c, DISCO_PH_CONTAIN);
+        /* the keys, behind everything the stream has done so far (verify wrote them) */
+        HIPCHK(c, hipEventRecord(c->ev_keys_go, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->bulk_stream, c->ev_keys_go, 0));
+        if (c->comm_bulk->reduce_scatter_min_i64(c->d_best, per, c->bulk_stream) != DISCO_OK) return fail(c, DISCO_E_HIP, "containment keys: %s", c->comm_bulk->err.c_str());
+        HIPCHK(c, hipEventRecord(c->ev_keys, c->bulk_stream));
+        c->keys_pending = true;
+        c->dinfo.bytes_sent[DISCO_X_CONTAIN_KEYS] += (u64)(G - 1) * per * 8;
+        CHK(read_counters(c));
+        ph_collect(c);
+        c->dinfo.ms[DISCO_X_CONTAIN] += ms_since(t0);
+        c->n_contained = c->h_ctr[CTR_N_CONTAINED]; /* home range: what disco_fetch_contained returns */
+        c->phase = 4;
+        return DISCO_OK;
+    }
     COMM_CHK(c, c->comm->reduce_scatter_min_i64(c->d_best, per, c->stream));
     c->dinfo.bytes_sent[DISCO_X_CONTAIN] += (u64)(G - 1) * per * 8;
     CHK(zero_counter(c, CTR_N_CONTAINED));
     ph_begin(c, DISCO_PH_CONTAIN);
     HIPCHK(c, hipMemsetAsync(c->d_contained, 0, std::max<u64>(c->n_alloc, 1), c->stream));
-    const u64 r = (u64)c->comm->rank;
     HIPCHK(c, hipMemsetAsync(c->d_cbits + r * per / 64, 0, per / 8, c->stream));
     if (nloc) hipLaunchKernelGGL(contain_flags_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_best + lo, nloc, c->d_contained + lo, c->d_cbits + lo / 64, c->d_ctr);
     HIPCHK(c, hipGetLastError());
@@ -4691,7 +4753,11 @@ static int dist_transitive_mark(disco_ctx *c)
     a.wide_cap = c->wide_cap;
     a.nref = c->d_nref;
     a.nadj32 = c->d_nadj32_own;
-    a.all_flags = 1u;
+    /* the transitive flags go into the rows of nodes with more than HALF_CAP survivors only, as on one GPU: everybody who judges an edge
+     * — the local emission, the survivor push and its receiver — reads a narrow node's survivor LIST and a wide node's row, never a narrow
+     * node's row (rounds 1-4 wrote every flag here: a quarter of this kernel's memory requests, left over from the flag exchange the
+     * push replaced). DISCO_DIST_ALL_FLAGS=1: as before */
+    a.all_flags = getenv("DISCO_DIST_ALL_FLAGS") ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
     if (nloc) hipLaunchKernelGGL((transitive_mark_kernel<false, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
@@ -5346,6 +5412,7 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
     }
     uint64_t n_out = 0;
     CHK(disco_emit_edges(c, &n_out));
+    CHK(settle_keys(c)); /* (whatever reads best[] after the pass — disco_fetch_contained — runs on this stream, behind the keys) */
     u64 tot[1] = {(u64)n_out};
     CHK(host_reduce(c, tot, 1));
     di.e_out = tot[0];

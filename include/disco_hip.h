@@ -223,6 +223,8 @@ enum { /* exchanges of one pass (disco_dist_info.bytes_sent) */
     DISCO_X_HITS,          /* partitioned index only: all-to-all of the matching records back to the read's owner             */
     DISCO_X_KEYS,          /* ranks own loci: all-gather of the 4-byte read-level minimizer keys the reads are dealt by         */
     DISCO_X_READS_DEALT,   /* ranks own loci: all-to-all of the own reads' rows, ahead of the all-gather of all reads            */
+    DISCO_X_CONTAIN_KEYS,  /* reduce-scatter(MIN) of the containment keys when it runs BEHIND the pass, on the second communicator
+                              (DISCO_X_CONTAIN then counts the bitmaps only: all-gather of every rank's "has a key" bits + the result) */
     DISCO_X_COUNT
 };
 /* disco_dist_run_graph flags. GATHER_READS: the pass starts from range-partitioned reads. KEEP_INDEX_PARTITIONED: the index is

@@ -12,7 +12,7 @@ def load(p):
 
 D, S = load(sys.argv[1]), load(sys.argv[2])
 # not part of a pass: the ranks' read generation and its checks; the in-process transport's copies (RCCL moves those bytes over xGMI)
-SETUP = ("generate_reads_kernel", "validate_len_kernel", "__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned")
+SETUP = ("generate_reads_kernel", "validate_len_kernel", "probes_sum_kernel", "__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned")
 rows = sorted(((t, c, S.get(k, (0, 0.0))[1], k) for k, (c, t) in D.items()), reverse=True)
 tot = sum(t for t, c, st, k in rows if k not in SETUP)
 single = sum(st for k, (sc, st) in S.items() if k not in SETUP)

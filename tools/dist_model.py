@@ -24,9 +24,10 @@ def ms(nbytes):  # a rank's bytes to its G - 1 peers, one link each
 
 main_kernels = (total - bulk) / G
 terms = {"keys (all-gather)": ms(b.get("keys", 0)), "own rows (all-to-all)": ms(b.get("reads_dealt", 0)), "index records (all-to-all)": ms(b["index_records"]),
-         "index slices (all-gather)": ms(b["index_shards"]), "containment keys + bitmap": ms(b["contain"]), "row requests + degrees": ms(b["row_requests"]),
+         "index slices (all-gather)": ms(b["index_shards"]), "containment (bitmaps; keys too when they are on the path)": ms(b["contain"]), "row requests + degrees": ms(b["row_requests"]),
          "row data": ms(b["row_data"]), "survivor push": ms(b["push"])}
-hidden = {"all reads (all-gather, second communicator: behind keys .. probe)": ms(b["reads"]), "its unpacking (second stream)": bulk / G}
+hidden = {"all reads (all-gather, second communicator: behind keys .. probe)": ms(b["reads"]), "its unpacking (second stream)": bulk / G,
+          "containment keys (reduce-scatter, second communicator: behind selection .. emission)": ms(b.get("contain_keys", 0))}
 host = prof["host_syncs_per_pass"] * 0.020 + prof["comm_ops_per_pass"] * 0.010
 exposed = sum(terms.values())
 t = main_kernels + exposed + host

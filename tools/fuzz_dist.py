@@ -50,6 +50,8 @@ for it in range(iters):
         mo = 40 if lmin > 48 else max(31, lmin - 8)
         part = mo == 40 and rng.random() < 0.5
     label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} G={G} two_pass_in_ranks={tp} partitioned_index={part}"
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("start", label, flush=True)
     try:
         spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
         reads = list(readgen.generate_reads(spec))
