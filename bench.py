@@ -4,8 +4,9 @@
 A step = one pass of the hot path (index build -> fused probe+verify -> containment -> edge selection -> twin check ->
 transitive reduction -> emission) over reads that are already resident in HBM, results left in HBM.
   N = 1 : the whole pass on one MI355X.
-  N > 1 : strong scaling — the same job, reads and graph nodes range-partitioned over the ranks (one per GPU), every exchange an
-          RCCL collective inside libdisco_hip.so (disco_dist_run_graph).  value = E_pre of the whole job / max-over-ranks time.
+  N > 1 : strong scaling — the same job, the reads range-partitioned in HBM when a step starts (one rank per GPU), dealt to the ranks by
+          their read-level minimizer inside the pass (ranks own loci), every exchange an RCCL collective inside libdisco_hip.so
+          (disco_dist_run_graph).  value = E_pre of the whole job / max-over-ranks time.
           `python bench.py --gpus N` without a launcher starts its own N ranks (a child torch.distributed.run).
 Prints ONE JSON line on rank 0.
 
@@ -59,7 +60,7 @@ def parse_args():
 
 
 # phase of disco_phase_ms -> the kernel(s) behind it
-PHASE_KERNELS = {"index": "index_runs_kernel + scan + index_fill_kernel", "probe_kernel": "probe_runs_kernel", "verify": "verify_flat_kernel",
+PHASE_KERNELS = {"index": "index_runs_kernel + scan + index_fill_ordered_kernel", "probe_kernel": "probe_runs_kernel", "verify": "verify_flat_kernel",
                  "contain": "contain_flags_kernel", "select": "edge_select_flat_kernel", "trmark": "transitive_mark_kernel", "emit": "emit_half_kernel"}
 
 

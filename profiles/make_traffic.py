@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 src, reads = sys.argv[1], int(sys.argv[2])
 pmc = json.load(open(src))
-PHASE_OF = {"index_runs_kernel": "index", "index_count_kernel": "index", "index_fill_kernel": "index", "scan_tile_sums_kernel": "index", "scan_sums_kernel": "index",
+PHASE_OF = {"index_runs_kernel": "index", "index_count_kernel": "index", "index_fill_kernel": "index", "index_fill_ordered_kernel": "index", "scan_tile_sums_kernel": "index", "scan_sums_kernel": "index",
             "scan_apply_kernel": "index", "probe_runs_kernel": "probe_kernel", "probe_kernel": "probe_kernel", "verify_flat_kernel": "verify",
             "verify_kernel": "verify", "contain_flags_kernel": "contain", "edge_select_kernel": "select", "edge_select_flat_kernel": "select", "transitive_mark_kernel": "trmark",
             "emit_half_kernel": "emit", "emit_kernel": "emit"}
