@@ -1,13 +1,14 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_fuzz.txt; : > $O
+O=gpurun_out/${1:-r05}_fuzz.txt; : > $O
 run() { echo "== $*" >> $O; timeout 1500 python "$@" 2>&1 | tail -2 >> $O; }
-run tools/fuzz_parity.py 150 401 runs
-run tools/fuzz_parity.py 150 402
-run tools/fuzz_parity.py 200 408 tail
-run tools/fuzz_dist.py 80 403
-run tools/fuzz_fastx.py 300 405 gpu
-run tools/fuzz_cli.py 100 404
-run tools/fuzz_parity.py 40 406 inexact
-run tools/fuzz_chains.py 40 407
-run tools/fuzz_reuse.py 60 409
+run tools/fuzz_parity.py 150 501 runs
+run tools/fuzz_parity.py 150 502
+run tools/fuzz_parity.py 200 508 tail
+run tools/fuzz_dist.py 200 503
+run tools/fuzz_dist.py 60 510 inexact
+run tools/fuzz_fastx.py 300 505 gpu
+run tools/fuzz_cli.py 100 504
+run tools/fuzz_parity.py 40 506 inexact
+run tools/fuzz_chains.py 40 507
+run tools/fuzz_reuse.py 60 509
 cat $O
