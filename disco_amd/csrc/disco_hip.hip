@@ -2324,6 +2324,7 @@ int disco_probe(disco_ctx *c)
         HIPCHK(c, hipMemsetAsync(c->d_ctr + CTR_KMER_HITS, 0, sizeof(u64) * 4, c->stream)); /* KMER_HITS, RAW_HITS, HITS_NEEDED, OVERFLOW */
         CHK(zero_counter(c, CTR_MAX_ROW));
         CHK(zero_counter(c, CTR_ES_BIG));
+        CHK(zero_counter(c, CTR_ES_MID));
         c->es_big_counted = c->tr_big_counted = false;
         ProbeArgs a;
         a.v = view(c);
@@ -2584,10 +2585,15 @@ static int select_edges(disco_ctx *c)
     CHK(zero_counter(c, CTR_ADJ_TOTAL));
     CHK(zero_counter(c, CTR_OVERFLOW));
     CHK(zero_counter(c, CTR_TR_BIG));
+    CHK(zero_counter(c, CTR_TR_MID));
     /* the kernel rewrites rows in place: it cannot be rerun after an overflow, so its big-row list must hold every such row — counted by
      * verify (no pass of its own, no wait in front of the selection), or here */
-    if (c->es_big_counted && !getenv("DISCO_COUNT_BIG_ROWS")) {
-        const u64 need = c->h_ctr[CTR_ES_BIG] + 1024;
+    /* the variant of edge_select_flat_kernel with five waves per SIMD where at most one row in a hundred has more than 64 verified hits (they
+     * go to the big-row list); DISCO_SELECT_SMALL=0 / 1 forces either */
+    const bool rows_counted = c->es_big_counted && !getenv("DISCO_COUNT_BIG_ROWS");
+    const bool select_small = rows_counted && env_int("DISCO_SELECT_SMALL", c->h_ctr[CTR_ES_MID] * 100 <= nq ? 1 : 0) != 0;
+    if (rows_counted) {
+        const u64 need = c->h_ctr[select_small ? CTR_ES_MID : CTR_ES_BIG] + 1024;
         if (need > c->big_cap) {
             if (need > 0xFFFFFFFFull) return fail(c, DISCO_E_CAPACITY, "more than 2^32 big rows");
             dev_free(c, &c->d_big_list, c->big_cap);
@@ -2637,7 +2643,8 @@ static int select_edges(disco_ctx *c)
     /* sub-chunks of up to 4 rows / 4 batches: 9.7 KB of LDS, 16 waves per CU. Larger ones fill their last batch better and repeat the
      * per-sub-chunk work less often (8 rows: 140 instead of 175 vector instructions per read) but hold 11 waves per CU, and the kernel's
      * time follows the resident waves (LDS round trips between its phases): 8 x 4: 25.4 ms, 4 x 4: 19.2 ms at 50 M reads */
-    if (nq && flat_select) hipLaunchKernelGGL((edge_select_flat_kernel<4, 4>), dim3(wq_grid(c, edge_select_flat_kernel<4, 4>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
+    if (nq && flat_select && select_small) hipLaunchKernelGGL((edge_select_flat_kernel<3, 2, true>), dim3(wq_grid(c, edge_select_flat_kernel<3, 2, true>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
+    else if (nq && flat_select) hipLaunchKernelGGL((edge_select_flat_kernel<4, 4>), dim3(wq_grid(c, edge_select_flat_kernel<4, 4>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     else if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);
     HIPCHK(c, hipGetLastError());
@@ -2646,9 +2653,15 @@ static int select_edges(disco_ctx *c)
     CHK(read_counters(c));
     ph_collect(c);
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "edge selection: big-row list overflow (%u rows)", n_big);
-    if (n_big) { /* rows of up to ES_MID hits: LDS arrays of their own */
-        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(edge_select_mid_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 8)), dim3(64), 0, c->stream, a);
+    if (n_big) { /* rows of up to ES_MID hits: LDS arrays of their own (the five-wave variant lists rows of 65 .. ES_CAP hits too: a pass with small arrays first) */
+        if (select_small) {
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL(edge_select_mid_kernel<ES_CAP>, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * env_int("DISCO_MID_BLOCKS", 32))), dim3(64), 0, c->stream, a, 0u);
+        }
+        if (!select_small || c->h_ctr[CTR_ES_BIG]) {
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL(edge_select_mid_kernel<ES_MID>, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 8)), dim3(64), 0, c->stream, a, select_small ? (u32)ES_CAP : 0u);
+        }
         HIPCHK(c, hipGetLastError());
         CHK(read_counters(c));
     }
@@ -2675,8 +2688,8 @@ static int select_edges(disco_ctx *c)
         c->contained_count_pending = false;
     }
     if (getenv("DISCO_VERBOSE"))
-        fprintf(stderr, "[disco] edge selection: %llu rows in the sequential path, %u in the global-scratch path, dropped %llu\n",
-                (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->dropped);
+        fprintf(stderr, "[disco] edge selection%s: %llu rows in the sequential path, %u in the big-row list (%llu rows of more than 64 hits), dropped %llu\n",
+                select_small ? " (five waves per SIMD)" : "", (unsigned long long)c->h_ctr[CTR_ES_SLOW], n_big, (unsigned long long)c->h_ctr[CTR_ES_MID], (unsigned long long)c->dropped);
     /* the finds stay where they are: the hit buffer IS the adjacency array of the local rows */
     c->d_adj = c->d_hits;
     c->adj_total = c->h_ctr[CTR_ADJ_TOTAL];
@@ -3013,8 +3026,12 @@ int disco_transitive_mark(disco_ctx *c)
     const u64 nq = c->q_hi - c->q_lo;
     HIPCHK(c, hipMemsetAsync(c->d_n_big, 0, sizeof(u32), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    if (c->tr_big_counted && c->q_lo == 0 && c->q_hi == c->n && !getenv("DISCO_COUNT_BIG_ROWS")) { /* edge selection counted the nodes beyond TR_CAP */
-        const u64 need = c->h_ctr[CTR_TR_BIG] + 1024;
+    /* the variant with LDS arrays for TR_CAP_SMALL neighbours (eight waves per SIMD) where at most one node in a hundred is beyond them
+     * (they go to the big-node pass); DISCO_TR_SMALL=0 / 1 forces either */
+    const bool counted_nodes = c->tr_big_counted && c->q_lo == 0 && c->q_hi == c->n && !getenv("DISCO_COUNT_BIG_ROWS");
+    const bool tr_small = env_int("DISCO_TR_SMALL", counted_nodes && c->h_ctr[CTR_TR_MID] * 100 <= nq ? 1 : 0) != 0 && counted_nodes;
+    if (counted_nodes) { /* edge selection counted the nodes beyond TR_CAP (and beyond TR_CAP_SMALL) */
+        const u64 need = c->h_ctr[tr_small ? CTR_TR_MID : CTR_TR_BIG] + 1024;
         if (need > c->big_cap) {
             if (need > 0xFFFFFFFFull) return fail(c, DISCO_E_CAPACITY, "more than 2^32 big nodes");
             dev_free(c, &c->d_big_list, c->big_cap);
@@ -3060,7 +3077,8 @@ int disco_transitive_mark(disco_ctx *c)
     /* every row needs its flags when the emission cannot rely on the survivor lists alone */
     a.all_flags = (c->adj_imported || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
-    if (nq) hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    if (nq && tr_small) hipLaunchKernelGGL((transitive_mark_kernel<false, false, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, false, TR_CAP_SMALL>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    else if (nq) hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;
@@ -4759,7 +4777,8 @@ static int dist_transitive_mark(disco_ctx *c)
      * push replaced). DISCO_DIST_ALL_FLAGS=1: as before */
     a.all_flags = getenv("DISCO_DIST_ALL_FLAGS") ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
-    if (nloc) hipLaunchKernelGGL((transitive_mark_kernel<false, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    /* (every node beyond the register path waits for the request-all round here, whatever the LDS arrays could hold: the small variant) */
+    if (nloc) hipLaunchKernelGGL((transitive_mark_kernel<false, true, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, true, TR_CAP_SMALL>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;

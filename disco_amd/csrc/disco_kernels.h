@@ -29,6 +29,10 @@
 #ifndef TR_CAP
 #define TR_CAP 256        /* transitive_mark: neighbours of one node in LDS                                     */
 #endif
+/* the marking's time follows its resident waves (24 / 28 / 32 blocks per CU: 20.0 / 19.8 / 19.0 ms at 50 M reads): where no node, or
+ * hardly any, has more than 128 neighbours — every read set of ordinary coverage — the variant with LDS arrays for 128 runs at eight
+ * waves per SIMD (2.8 KB a block), nodes beyond go to the big-node pass; else the variant for TR_CAP at six */
+#define TR_CAP_SMALL 128
 #define VERIFY_SW 8 /* device row stride (words) of the staged variants: reads up to 256 bp, 64-byte rows */
 #define ORDER_BUCKET(key, shift) (((key) * 0x9E3779B1u) >> (shift)) /* bucket of a read-level minimizer in the grouping ("processing order") */
 #define SCAN_ITEMS 16     /* elements per thread in the scan kernels                                            */
@@ -71,6 +75,8 @@ enum {
     CTR_MIN_LEN, /* ~shortest read (stored complemented so that atomicMax finds the minimum from a zeroed counter) */
     CTR_DROP_ITEMS, /* dropped hits recorded in (or, beyond its capacity, lost to) the drop list of edge selection */
     CTR_SHORT_MAX,  /* two row classes: longest read of at most 256 bases */
+    CTR_TR_MID,     /* nodes with more than TR_CAP_SMALL finds (edge selection counts them: which variant of the marking runs) */
+    CTR_ES_MID,     /* rows with more than 64 verified hits (verify counts them: which variant of edge_select_flat_kernel runs) */
     CTR_COUNT
 };
 
@@ -83,15 +89,47 @@ enum {
 #define ORDER_MAKE(id, l) ((u64)(id) | ((u64)(l) << 32))
 #define ORDER_ID(o) ((o) & 0xFFFFFFFFull)
 #define ORDER_LEN(o) ((int)((o) >> 32))
+/* the first active lane's value as a SCALAR: a value broadcast by a cross-lane shuffle is divergent to the compiler, and with it every
+ * loop bound, branch and address derived from it (counters in vector registers, exec-mask loops, saveexec around uniform branches) */
+__device__ __forceinline__ u32 uniform_u32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ u64 uniform_u64(u64 x)
+{
+    return ((u64)uniform_u32((u32)(x >> 32)) << 32) | uniform_u32((u32)x);
+}
+
 template <u32 CHUNK = WQ_CHUNK>
 __device__ __forceinline__ bool wq_grab(u64 *counter, u64 n, u64 &beg, u64 &end)
 {
     u64 b = 0;
     if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, (u64)CHUNK);
+    /* lane 0's value as a SCALAR (every lane of the wave is here): a value that comes out of a cross-lane shuffle is divergent to the
+     * compiler, and with it every loop over the chunk — counters in vector registers, exec-mask loops, wave-uniform branches through
+     * saveexec. Round 5: read as a scalar the chunk loops of all kernels are scalar loops */
+#ifdef WQ_EXP_SHFL /* timing experiment: the broadcast of rounds 1-4 (the chunk bounds divergent to the compiler) */
     b = __shfl(b, 0);
+#else
+    b = uniform_u64(b);
+#endif
     beg = b;
     end = (b + CHUNK < n) ? b + CHUNK : n;
     return b < n;
+}
+
+/* the same chunks, MULT of them per atomic: the work queue is ONE address, and returning atomics on one address are served one after
+ * the other — 12.3 ns apiece on MI355X (edge_select_mid_kernel: 80 681 one-row grabs took 0.99 ms whatever the grid). For kernels whose
+ * items are small (a row per grab). The passes over the reads take 64 (verify: 32) reads per grab — 0.8 / 1.6·10^6 grabs, 10 / 19 ms of
+ * that unit per kernel: busy half the time (verify: 87 %), yet four or eight chunks per atomic changed nothing but the tails (+0.2 .. 0.4 ms
+ * per kernel): measured and not kept. gnext / gend: the wave's allocation (zero to begin with). Chunks stay aligned to CHUNK. */
+template <u32 CHUNK = WQ_CHUNK, u32 MULT = 4>
+__device__ __forceinline__ bool wq_grab_multi(u64 *counter, u64 n, u64 &beg, u64 &end, u64 &gnext, u64 &gend)
+{
+    if (gnext >= gend) {
+        if (!wq_grab<CHUNK * MULT>(counter, n, gnext, gend)) return false;
+    }
+    beg = gnext;
+    end = beg + CHUNK < gend ? beg + CHUNK : gend;
+    gnext = end;
+    return true;
 }
 
 struct DiscoView {
@@ -1016,7 +1054,7 @@ __device__ __forceinline__ u64 shfl_u64(u64 x, u32 l)
 }
 
 #ifndef PR_WAVES_PER_SIMD
-#define PR_WAVES_PER_SIMD 6 /* no register cap the kernel would feel: it needs 72 vector and ~100 scalar registers, which is 7 waves per SIMD; capped at 7 or 8 hipcc spills scalars into vector lanes and then vector registers */
+#define PR_WAVES_PER_SIMD 8 /* rounds 3-4: 72 vector registers, seven waves, and a cap of 7 or 8 spilled; with the chunk bounds read as scalars (wq_grab, round 5) it needs 65: eight waves without a spill, 16.8 -> 16.5 ms */
 #endif
 /* runs_lo == ~0: the run lists are stored by POSITION in the processing order (multi-GPU flow, ranks own loci: index_runs_kernel ran
  * over the order itself), not by read id */
@@ -1050,7 +1088,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
             if (lm) {
                 u32 base = 0;
                 if (lane == 0) base = atomicAdd(a.rare->n_slow, (u32)__popcll(lm));
-                base = (u32)__shfl((int)base, 0);
+                base = uniform_u32(base);
                 if (lng) {
                     const u32 idx = base + (u32)__popcll(lm & lt);
                     if (idx < a.rare->slow_cap) a.rare->slow_list[idx] = ORDER_ID(ord_chunk) | ((cbeg + lane) << 32);
@@ -1093,7 +1131,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                         base = ~0ull; /* no room: this wave writes nothing any more */
                     }
                 }
-                chunk_base = shfl_u64(base, 0);
+                chunk_base = uniform_u64(base);
                 chunk_used = 0;
             }
             u64 *grow = nullptr;
@@ -1275,12 +1313,6 @@ __device__ __forceinline__ u64 extract32_padded(const u64 *row, int pos)
     const int w = pos >> 5, sh = (pos & 31) * 2;
     const u64 a = row[w], b = row[w + 1];
     return (a << sh) | ((b >> 1) >> (63 - sh));
-}
-
-__device__ __forceinline__ u32 uniform_u32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ u64 uniform_u64(u64 x)
-{
-    return ((u64)uniform_u32((u32)(x >> 32)) << 32) | uniform_u32((u32)x);
 }
 
 /* NW = 0: generic variant (any stride, rows read from global memory). NW = 5 / 8: staged variants for a row stride of
@@ -1636,6 +1668,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 if (lane == 0) {
                     if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
                     if (nkeep > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull); /* (sizes edge selection's big-row list: no counting pass, no host round trip in front of it) */
+                    if (nkeep > 64u) atomicAdd(&a.v.ctr[CTR_ES_MID], 1ull);
                     my_raw += nkeep;
                 }
                 if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
@@ -2000,6 +2033,7 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
                     my_raw += kept;
                     if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
                     if (kept > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull);
+                    if (kept > 64u) atomicAdd(&a.v.ctr[CTR_ES_MID], 1ull);
                 }
                 carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
             }
@@ -2545,6 +2579,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
         if (lane == 0) {
             if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
             if (nkeep > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull);
+            if (nkeep > 64u) atomicAdd(&a.v.ctr[CTR_ES_MID], 1ull);
             my_raw += nkeep;
             a.meta_ord[ci].y = (u64)nkeep | ((u64)LA << 32);
         }
@@ -2820,6 +2855,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
             for (u32 i = lane; i < m; i += 64) row[i] = h[i];
             if (lane == 0) a.ref[A] = REF_MAKE(rs, m);
             if (lane == 0 && m > TR_CAP) atomicAdd(&a.v.ctr[CTR_TR_BIG], 1ull); /* (sizes the marking's big-node list) */
+            if (lane == 0 && m > TR_CAP_SMALL) atomicAdd(&a.v.ctr[CTR_TR_MID], 1ull);
             n_edges += m;
             __syncthreads();
             return;
@@ -2875,6 +2911,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
     if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
     if (lane == 0 && nacc > TR_CAP) atomicAdd(&a.v.ctr[CTR_TR_BIG], 1ull);
+    if (lane == 0 && nacc > TR_CAP_SMALL) atomicAdd(&a.v.ctr[CTR_TR_MID], 1ull);
     n_edges += nacc;
     dropped += m - nacc;
     if (lane == 0 && m != nacc) atomicOr(&a.dropbits[A >> 6], 1ull << (A & 63));
@@ -3153,17 +3190,20 @@ __device__ __forceinline__ u32 pinned_copy32(u32 x)
     asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
     return y;
 }
-template <int ROWS, int NB>
-__global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_flat_kernel(EdgeSelArgs a)
+/* SMALL (round 5): the kernel's time follows its resident waves (12 / 14 / 16 blocks per CU: 23.8 / 21.4 / 19.8 ms at 50 M reads), and what
+ * held it at 16 were the two work arrays of the sequential path — sized for rows of ES_CAP hits that a read set of ordinary coverage
+ * does not have — and a dozen registers. Where rows of more than 64 verified hits are rare (verify counts them: CTR_ES_MID) they go to
+ * the big-row list (edge_select_mid_kernel<ES_CAP>), the sequential path works in arrays of 64, the sub-chunk is 3 rows x 2 batches (4 x 3
+ * would be faster still, 18.1 ms, and spills three registers with the sequential path compiled in) and the kernel holds five waves per
+ * SIMD: 18.8 ms. */
+template <int ROWS, int NB, bool SMALL = false>
+__global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) edge_select_flat_kernel(EdgeSelArgs a)
 {
+    constexpr u32 SEQ_CAP = SMALL ? 64u : (u32)ES_CAP; /* rows the sequential path takes; longer ones: the big-row list */
     /* a sub-chunk: consecutive reads of the chunk, as many as fit ROWS rows and NB batches of 64 hits (greedy) */
     constexpr u32 SETW = 128;
     static_assert(NB >= 1 && ROWS >= 1 && ROWS <= 8, "a row has at most 64 hits: one batch always holds a row; the jc array is cleared by one store per lane");
-#ifdef ES_EXP_SMALL_LDS /* timing experiment (tools/ab_build.py; rows of the sequential path come out wrong): what the flat kernel gains when the sequential path's work arrays leave its LDS */
-    __shared__ __attribute__((aligned(16))) u64 s_ent[ROWS * 64];
-#else
-    __shared__ __attribute__((aligned(16))) u64 s_ent[ROWS * 64 > 2 * ES_CAP ? ROWS * 64 : 2 * ES_CAP]; /* row r: [64 r, 64 r + 64); old paths: their two work arrays */
-#endif
+    __shared__ __attribute__((aligned(16))) u64 s_ent[ROWS * 64 > 2 * SEQ_CAP ? ROWS * 64 : 2 * SEQ_CAP]; /* row r: [64 r, 64 r + 64); old paths: their two work arrays */
     __shared__ __attribute__((aligned(16))) u32 s_bins[ROWS * 64];  /* row r, offset o: byte o & 3 of word 64 r + (o >> 2): entries */
     __shared__ __attribute__((aligned(16))) u32 s_start[ROWS * 64]; /* ... : first position of the bin */
     __shared__ __attribute__((aligned(16))) u32 s_jc[ROWS * 32 > 128 ? ROWS * 32 : 128]; /* row r, window j: byte j & 3 of word 32 r + ((j & 127) >> 2) */
@@ -3393,7 +3433,7 @@ __global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_fl
             const u32 c0 = (u32)__builtin_amdgcn_readlane((int)craw, (int)i);
             const u32 L0 = (u32)__builtin_amdgcn_readlane((int)LAme, (int)i);
             __syncthreads();
-            if (c0 > ES_CAP) {
+            if (c0 > SEQ_CAP) {
                 if (lane == 0) {
                     const u32 idx = atomicAdd(a.n_big, 1u);
                     if (idx < a.big_cap) a.big_list[idx] = Ai;
@@ -3413,9 +3453,7 @@ __global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_fl
             }
             if (!done) {
                 n_slow++;
-#ifndef ES_EXP_SMALL_LDS
-                edge_select_row<ES_CAP>(a, Ai, rs, s_ent, s_ent + ES_CAP, c0, lane, s_jc, cap_sites, dropped, n_edges);
-#endif
+                edge_select_row<(int)SEQ_CAP>(a, Ai, rs, s_ent, s_ent + SEQ_CAP, c0, lane, s_jc, cap_sites, dropped, n_edges);
             }
         }
     }
@@ -3427,22 +3465,26 @@ __global__ void __launch_bounds__(64, SELECT_FLAT_WAVES_PER_SIMD) edge_select_fl
 
 /* rows of ES_CAP+1 .. ES_MID hits (coverage of a few hundred): the big-row list again, with LDS arrays large enough for the
  * accept-all shortcut; longer rows are left to the global-scratch variant */
-__global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a)
+/* (CAP = ES_CAP, round 5: the rows of 65 .. ES_CAP hits that the five-wave variant of edge_select_flat_kernel lists — 4 KB of LDS
+ * instead of 16: the rows of the list with more than `above` and at most CAP hits) */
+template <int CAP>
+__global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a, u32 above)
 {
-    __shared__ u64 s_h[ES_MID];
-    __shared__ u64 s_t[ES_MID];
+    __shared__ u64 s_h[CAP];
+    __shared__ u64 s_t[CAP];
     __shared__ u32 s_jcnt[128];
     const u32 lane = threadIdx.x;
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
     u64 n_edges = 0;
     const u64 n_items = (u64)min(*a.n_big, a.big_cap);
     u64 cbeg = 0, cend = 0;
-    while (wq_grab<1>(a.v.wq, n_items, cbeg, cend)) {
+    u64 gnext = 0, gend = 0;
+    while (wq_grab_multi<1, 8>(a.v.wq, n_items, cbeg, cend, gnext, gend)) { /* (eight rows per atomic: a row per atomic is 12 ns per row on the one address) */
         const u64 A = a.big_list[cbeg];
         const u32 c = a.row_cnt[A];
-        if (c > ES_MID) continue;
+        if (c > (u32)CAP || c <= above) continue;
         n_slow++;
-        edge_select_row<ES_MID>(a, A, a.row_start[A], s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges);
+        edge_select_row<CAP>(a, A, a.row_start[A], s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges);
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
@@ -3846,7 +3888,7 @@ __device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
 #define TR_HASH_LOAD 4 /* slots per neighbour in the marking hash of the register path: fewer probe-loop trips (each trip of a
                           divergent loop is a dozen scalar exec-mask instructions, and this kernel is bound by its SCALAR unit) */
 #endif
-static_assert(TR_HASH_LOAD * 64 < 2 * TR_CAP, "the register path's table (at most TR_HASH_LOAD x 64 slots) must leave the last slot of s_state free: it takes the stores of the lanes without a hit");
+static_assert(TR_HASH_LOAD * 64 < 4 * TR_CAP_SMALL && TR_CAP_SMALL <= TR_CAP, "the register path's table (at most TR_HASH_LOAD x 64 four-byte slots in the space of s_hkey) needs one more slot behind it: it takes the stores of the lanes without a hit");
 #define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
 /* slot of a node id (< 2^31) in the marking hash: one 32-bit multiply (disco_hash64 costs two 64-bit multiplies — eight
  * quarter-rate 32-bit ones — and is evaluated for every entry of every swept row) */
@@ -4088,12 +4130,12 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 #ifndef TR_WAVES_PER_SIMD
 #define TR_WAVES_PER_SIMD 6
 #endif
-template <bool BIG, bool N32>
-__global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(TrArgs a)
+template <bool BIG, bool N32, int CAP = TR_CAP>
+__global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAVES_PER_SIMD) transitive_mark_kernel(TrArgs a)
 {
-    __shared__ u64 s_hkey[BIG ? 1 : 2 * TR_CAP];
-    __shared__ u32 s_ent[BIG ? 1 : TR_CAP];
-    __shared__ u8 s_state[BIG ? 1 : 2 * TR_CAP];
+    __shared__ u64 s_hkey[BIG ? 1 : 2 * CAP];
+    __shared__ u32 s_ent[BIG ? 1 : CAP];
+    __shared__ u8 s_state[BIG ? 1 : 2 * CAP];
     const u32 lane = threadIdx.x;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *hkey = s_hkey;
@@ -4184,7 +4226,7 @@ __global__ void __launch_bounds__(64, TR_WAVES_PER_SIMD) transitive_mark_kernel(
         if (n0.d != 0)
             tr_node_small<N32>(a, n0, s_hkey, s_state, lane);
         else if (n0.dfull != 0) {
-            if (!N32 && n0.dfull <= TR_CAP) { /* multi-GPU: every node beyond the register path waits for the request-all round */
+            if (!N32 && n0.dfull <= (u32)CAP) { /* multi-GPU: every node beyond the register path waits for the request-all round */
                 u32 hc = 64;
                 while (hc < 2 * n0.dfull) hc <<= 1;
                 tr_node<N32>(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
@@ -4281,7 +4323,7 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
                     close_chunk();
                     u64 base = 0;
                     if (lane == 0) base = atomicAdd(a.bump, (u64)EMIT_CHUNK);
-                    chunk_base = __shfl(base, 0);
+                    chunk_base = uniform_u64(base);
                     chunk_used = 0;
                     have_chunk = true;
                 }
@@ -4373,7 +4415,7 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
                     close_chunk();
                     u64 base = 0;
                     if (lane == 0) base = atomicAdd(a.bump, (u64)EMIT_CHUNK);
-                    chunk_base = __shfl(base, 0);
+                    chunk_base = uniform_u64(base);
                     chunk_used = 0;
                     have_chunk = true;
                 }
