@@ -576,12 +576,12 @@ static int wave_grid(const disco_ctx *c, u64 items, int per_cu = 24)
 
 /* grid for a work-queue kernel: every workgroup that can be resident (the queue balances the load), zeroes the queue */
 template <typename K>
-static int wq_grid(disco_ctx *c, K kernel, u64 items, const char *env)
+static int wq_grid(disco_ctx *c, K kernel, u64 items, const char *env, int cap = 32)
 {
     (void)hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
-    if (per_cu > 32) per_cu = 32;
+    if (per_cu > cap) per_cu = cap;
     per_cu = env_int(env, per_cu);
     u64 g = (u64)c->n_cu * per_cu;
     const u64 chunks = (items + WQ_CHUNK - 1) / WQ_CHUNK;
@@ -2491,7 +2491,9 @@ int disco_probe(disco_ctx *c)
                  * abundances (256-base rows, 15 KB of LDS per wavefront). DISCO_VERIFY_CACHE=0 forbids it */
                 const char *vce = getenv("DISCO_VERIFY_CACHE");
                 const bool vcache = vce ? atoi(vce) != 0 : true;
-                if (flat && vcache && c->max_len <= 160) hipLaunchKernelGGL((verify_flat_kernel<5, 0, true>), dim3(wq_grid(c, verify_flat_kernel<5, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
+                /* (round 5: 128 registers and 10 KB of LDS hold sixteen blocks per CU; 12 / 14 / 16 resident: 22.8 / 21.5 / 22.0 ms — the rows of
+                 * sixteen blocks' pairs no longer share the L2 as well) */
+                if (flat && vcache && c->max_len <= 160) hipLaunchKernelGGL((verify_flat_kernel<5, 0, true>), dim3(wq_grid(c, verify_flat_kernel<5, 0, true>, nq, "DISCO_VERIFY_WAVES", 14)), dim3(64), 0, c->stream, va);
                 else if (flat && vcache) hipLaunchKernelGGL((verify_flat_kernel<8, 0, true>), dim3(wq_grid(c, verify_flat_kernel<8, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat && c->max_len <= 160) hipLaunchKernelGGL(verify_flat_kernel<5>, dim3(wq_grid(c, verify_flat_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat) hipLaunchKernelGGL(verify_flat_kernel<8>, dim3(wq_grid(c, verify_flat_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
@@ -2656,7 +2658,7 @@ static int select_edges(disco_ctx *c)
     if (n_big) { /* rows of up to ES_MID hits: LDS arrays of their own (the five-wave variant lists rows of 65 .. ES_CAP hits too: a pass with small arrays first) */
         if (select_small) {
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
-            hipLaunchKernelGGL(edge_select_mid_kernel<ES_CAP>, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * env_int("DISCO_MID_BLOCKS", 32))), dim3(64), 0, c->stream, a, 0u);
+            hipLaunchKernelGGL(edge_select_mid_kernel<ES_CAP>, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, a, 0u);
         }
         if (!select_small || c->h_ctr[CTR_ES_BIG]) {
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));

@@ -1724,7 +1724,7 @@ __device__ __forceinline__ u64 pinned_copy(u64 x)
     return ((u64)hi << 32) | lo;
 }
 #ifndef VERIFY_FLAT_WAVES_PER_SIMD
-#define VERIFY_FLAT_WAVES_PER_SIMD 1
+#define VERIFY_FLAT_WAVES_PER_SIMD 4 /* round 5: the kernel's time follows its resident waves (8 / 10 / 12 blocks per CU: 29.7 / 25.3 / 22.1 ms) */
 #endif
 /* CACHE (round 4): two batches are decided TOGETHER — a candidate whose read is some other lane's candidate among the 128 takes that
  * lane's row instead of fetching it again (reads of one locus come back to back in the processing order and share four candidates in
@@ -1733,7 +1733,7 @@ __device__ __forceinline__ u64 pinned_copy(u64 x)
  * list, four lanes per row as before, only as many load instructions as the list needs; the loads of pair p + 1 are issued while pair
  * p is compared. Measured bound: with two / four lanes sharing every row verify runs 17.1 / 14.3 ms instead of 23.2. */
 template <int NW, int MODE = 0, bool CACHE = false>
-__global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_kernel(VerifyArgs a)
+__global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) verify_flat_kernel(VerifyArgs a)
 {
     constexpr int ND = 2 * NW;       /* dwords of a row */
     constexpr int BSTR = ND + 1;     /* candidate row r: dwords [1 + r BSTR, + ND); the dword in front belongs to the row before (never zero, never needed: masked) */
@@ -1749,10 +1749,13 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
     __shared__ ulonglong2 s_hdr[CH]; /* {row start, first flat index | candidates << 32} */
     __shared__ uint2 s_al[CH];       /* {read id, length} */
     __shared__ u32 s_nk[CH];         /* verified hits of the segment */
-    __shared__ u32 s_hid[CACHE ? 128 : 1];  /* CACHE: read id whose row slot s holds */
-    __shared__ u32 s_hash[CACHE ? 256 : 1]; /* ... hash of a read id -> the slot that registered it last (0xFFFFFFFF: nobody yet) */
-    __shared__ u32 s_lid[CACHE ? 128 : 1];  /* ... fetch list of the pair being decided: read ids */
-    __shared__ u8 s_lslot[CACHE ? 128 : 1]; /* ... and the slots they go to */
+    __shared__ u32 s_hid[CACHE ? 128 : 1];  /* CACHE: read id whose row slot s holds; then (s_lid) the fetch list of the pair being decided: read ids */
+    __shared__ u8 s_hash[CACHE ? 256 : 1];  /* ... hash of a read id -> the slot that registered it last */
+    __shared__ u8 s_lslot[CACHE ? 128 : 1]; /* ... the slots the entries of the fetch list go to */
+    /* (round 5: 10 240 bytes with NW = 5 — sixteen blocks per CU. The fetch list takes the place of the registrations it is made from:
+     * a block is ONE wavefront, its LDS operations happen in program order, and every lane has read the registrations it needs before
+     * the first entry of the list is written) */
+    u32 *const s_lid = s_hid;
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
@@ -1881,15 +1884,14 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             }
             const u32 idA = (u32)HIT_ID(hA), idB = (u32)HIT_ID(hB);
             const u32 hsA = (idA * 0x9E3779B1u) >> 24, hsB = (idB * 0x9E3779B1u) >> 24;
-            s_hash[lane] = 0xFFFFFFFFu; /* (every entry a lane will read is written below, by itself if by nobody else; cleared for clarity) */
-            __syncthreads();
+            __syncthreads(); /* (s_hash needs no clearing: every entry a lane reads is written below, by itself if by nobody after it) */
             if (needA) {
                 s_hid[lane] = idA;
-                s_hash[hsA] = lane;
+                s_hash[hsA] = (u8)lane;
             }
             if (needB) {
                 s_hid[64u + lane] = idB;
-                s_hash[hsB] = 64u + lane;
+                s_hash[hsB] = (u8)(64u + lane);
             }
             __syncthreads();
             slotA = lane;
@@ -2080,16 +2082,20 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
             u64 h1A = load_cand(sg1A, ftmp);
             locate(3, sg1B, ftmp);
             u64 h1B = load_cand(sg1B, ftmp);
-            ulonglong2 q[8];
+#ifndef VF_Q
+#define VF_Q 4 /* (8 — the whole list of a pair in flight — needs 145 registers: three waves per SIMD; 4: 128, four) */
+#endif
+            constexpr int Q = NW == 5 ? VF_Q : 8; /* (rows of 256 bases: LDS holds them at ten blocks per CU whatever the registers do) row quarters a lane holds in flight: 16 Q rows of the pair's fetch list; what is beyond them (Q < 8) is fetched when the pair's turn comes */
+            ulonglong2 q[Q];
 #pragma unroll
-            for (int p = 0; p < 8; p++) q[p] = make_ulonglong2(0, 0);
+            for (int p = 0; p < Q; p++) q[p] = make_ulonglong2(0, 0);
             u32 s0A = 0, s0B = 0, nm0 = 0;
             u64 lsl0 = 0;
             auto load_list = [&](u32 nmiss, u64 &lsl) { /* sixteen rows per load instruction, as many instructions as the list needs (wave uniform) */
                 lsl = 0;
                 q[0] = *list_ptr(nmiss, 0, lsl);
 #pragma unroll
-                for (int p = 1; p < 8; p++)
+                for (int p = 1; p < Q; p++)
                     if (nmiss > 16u * (u32)p) q[p] = *list_ptr(nmiss, p, lsl);
             };
             decide_pair(h0A, sg0A, lane < C, h0B, sg0B, 64u + lane < C, s0A, s0B, nm0);
@@ -2100,8 +2106,17 @@ __global__ void __launch_bounds__(64, VERIFY_FLAT_WAVES_PER_SIMD) verify_flat_ke
                 { /* the fetched rows of this pair to their slots */
                     const u32 r = lane >> 2;
 #pragma unroll
-                    for (int p = 0; p < 8; p++)
+                    for (int p = 0; p < Q; p++)
                         if (16u * (u32)p + r < nm0) put_quarter((u32)(lsl0 >> (8 * p)) & 0xFFu, q[p]);
+                    if (Q < 8 && nm0 > 16u * (u32)Q) { /* (wave uniform) the end of a long list: fetched now, in registers that are free again */
+                        u64 lsl2 = 0;
+#pragma unroll
+                        for (int p = Q; p < 8; p++)
+                            if (nm0 > 16u * (u32)p) q[p - Q] = *list_ptr(nm0, p, lsl2);
+#pragma unroll
+                        for (int p = Q; p < 8; p++)
+                            if (16u * (u32)p + r < nm0) put_quarter((u32)(lsl2 >> (8 * p)) & 0xFFu, q[p - Q]);
+                    }
                 }
                 const u64 hA = pinned_copy(h0A), hB = pinned_copy(h0B);
                 const u32 segA = sg0A, segB = sg0B, rowA = s0A, rowB = s0B;
