@@ -390,3 +390,29 @@ def test_contained_rows_grouped_on_the_device_are_the_sorted_rows():
         g.run_graph()
         rows = g.fetch_contained()
         assert g.fetch_contained_grouped() is None and len(rows) >= 300
+
+
+@pytest.mark.parametrize("sel_small,tr_small", [("0", "0"), ("1", "1"), ("1", "0"), ("0", "1")])
+@pytest.mark.parametrize("seed,n,lmin,lmax,cov", [
+    (42, 5000, 150, 150, 30.0),    # rows of more than 64 hits rare: the variants the defaults pick
+    (17, 6000, 150, 150, 100.0),   # rows of 65..256 hits everywhere: forced small, every row goes through the big-row list and its 256-entry pass
+    (29, 4000, 150, 150, 300.0),   # rows of 257..1024 hits, nodes of more than 128 / 256 neighbours: both passes over the list, big-node marking
+    (19, 5000, 100, 250, 120.0),   # mixed lengths (containment inside wide rows)
+])
+def test_variants_of_selection_and_marking_agree(monkeypatch, sel_small, tr_small, seed, n, lmin, lmax, cov):
+    """round 5: edge_select_flat_kernel<3, 2, true> (five waves per SIMD, sequential path in arrays of 64, longer rows listed) and
+    transitive_mark_kernel<., ., 128> (eight waves, nodes beyond 128 neighbours listed) are picked by counts the kernels before them leave;
+    forced either way they must give the oracle's graph on every coverage"""
+    monkeypatch.setenv("DISCO_SELECT_SMALL", sel_small)
+    monkeypatch.setenv("DISCO_TR_SMALL", tr_small)
+    reads = _gen(seed, n, lmin, cov, lmax)
+    c = assert_parity(reads, 40, f"variants{seed}")
+    assert c["e_out"] > 0
+
+
+def test_repeats_with_forced_small_variants(monkeypatch):
+    """the order-dependent regime (cap binds, duplicates: rows fail the flat kernel's tests and take its sequential path in arrays of 64)"""
+    monkeypatch.setenv("DISCO_SELECT_SMALL", "1")
+    monkeypatch.setenv("DISCO_TR_SMALL", "1")
+    test_repeats_order_dependent_regime()
+    test_high_multiplicity_rows_take_the_big_paths()
