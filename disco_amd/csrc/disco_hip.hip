@@ -2554,7 +2554,6 @@ int disco_mark_contained(disco_ctx *c, uint64_t *n_contained)
 /* the big-item lists (rows / nodes beyond the LDS capacities) must hold every such item: count them first */
 static int ensure_big_cap(disco_ctx *c, const u32 *cnt, const u64 *ref, u32 thr)
 {
-    const u64 nq = c->q_hi - c->q_lo;
     CHK(zero_counter(c, CTR_ES_BIG));
     /* (ranks own loci: q_lo / q_hi are positions; the rows and reference words of the other ranks' reads are zero) */
     const u64 ilo = c->loci ? 0 : c->q_lo, ihi = c->loci ? c->n : c->q_hi;
@@ -4506,9 +4505,10 @@ static int dist_partitioned_probe(disco_ctx *c)
     if (rc == DISCO_OK) {
         HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
         if (have_runs && nloc) make(c->d_x16a, false);
-        if (n_slow)
+        if (n_slow) {
             if (c->k > 64) hipLaunchKernelGGL(pq_slow_kernel<true>, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)slow_start, c->d_x16a + nq_fast);
             else hipLaunchKernelGGL(pq_slow_kernel<false>, dim3(flat_grid(c, n_slow, 64)), dim3(64), 0, c->stream, v, slow, n_slow, lo, r, slow_cnt, (const u64 *)slow_start, c->d_x16a + nq_fast);
+        }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DISCO_E_HIP, "dist_partitioned_probe: query kernels failed");
     }
     dev_free(c, &slow_cnt, n_slow);

@@ -1355,6 +1355,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
     const u32 lane = threadIdx.x;
     const int S = !staged ? a.v.S : (NW > VERIFY_SW ? NW : VERIFY_SW), k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
+    u32 my_big = 0, my_mid = 0; /* rows of more than ES_CAP / 64 verified hits, this wavefront's */
     if (staged) {
         for (u32 i = lane; i < 1 + 64 * BST; i += 64) s_b[i] = 0;
         if (lane < (u32)SA) {
@@ -1667,8 +1668,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
             if (MODE != 1) {
                 if (lane == 0) {
                     if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
-                    if (nkeep > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull); /* (sizes edge selection's big-row list: no counting pass, no host round trip in front of it) */
-                    if (nkeep > 64u) atomicAdd(&a.v.ctr[CTR_ES_MID], 1ull);
+                    my_big += nkeep > ES_CAP ? 1u : 0u; /* (sizes edge selection's big-row list: no counting pass, no host round trip in front of it) */
+                    my_mid += nkeep > 64u ? 1u : 0u;    /* (counted per wavefront and added once: an atomic per row on the one address is 12 ns per row — the whole of verify at 100x coverage) */
                     my_raw += nkeep;
                 }
                 if (lane == (u32)(it - cbeg)) nk_chunk = nkeep;
@@ -1688,6 +1689,8 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
     if (lane == 0) {
         if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
         if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
+        if (my_big) atomicAdd(&a.v.ctr[CTR_ES_BIG], (u64)my_big);
+        if (my_mid) atomicAdd(&a.v.ctr[CTR_ES_MID], (u64)my_mid);
     }
 }
 
@@ -1759,6 +1762,7 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
+    u32 my_big = 0, my_mid = 0; /* rows of more than ES_CAP / 64 verified hits, this wavefront's */
     u64 cbeg = 0, cend = 0;
     if (CACHE) {
         s_lid[lane] = 0u;
@@ -2034,8 +2038,8 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
                     s_nk[seg] = kept;
                     my_raw += kept;
                     if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
-                    if (kept > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull);
-                    if (kept > 64u) atomicAdd(&a.v.ctr[CTR_ES_MID], 1ull);
+                    my_big += kept > ES_CAP ? 1u : 0u; /* (per wavefront, added once at the end: see verify_kernel) */
+                    my_mid += kept > 64u ? 1u : 0u;
                 }
                 carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
             }
@@ -2143,10 +2147,14 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
     for (int o = 32; o > 0; o >>= 1) {
         my_khits += __shfl_down(my_khits, o);
         my_raw += __shfl_down(my_raw, o);
+        my_big += (u32)__shfl_down((int)my_big, o);
+        my_mid += (u32)__shfl_down((int)my_mid, o);
     }
     if (lane == 0) {
         if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
         if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
+        if (my_big) atomicAdd(&a.v.ctr[CTR_ES_BIG], (u64)my_big);
+        if (my_mid) atomicAdd(&a.v.ctr[CTR_ES_MID], (u64)my_mid);
     }
 }
 
@@ -2342,6 +2350,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
     u64 my_khits = 0, my_raw = 0;
+    u32 my_big = 0, my_mid = 0; /* rows of more than ES_CAP / 64 verified hits, this wavefront's */
     const u32 nl = *n_list;
     for (u32 i = lane; i < 1 + 64 * BST; i += 64) s_b[i] = 0;
     /* the entries are taken from the work queue four at a time: rows differ in length, and a static deal left the last wavefronts
@@ -2593,8 +2602,8 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
         if (ndef) flush();
         if (lane == 0) {
             if (c > 64) a.row_cnt[A] = nkeep; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
-            if (nkeep > ES_CAP) atomicAdd(&a.v.ctr[CTR_ES_BIG], 1ull);
-            if (nkeep > 64u) atomicAdd(&a.v.ctr[CTR_ES_MID], 1ull);
+            my_big += nkeep > ES_CAP ? 1u : 0u;
+            my_mid += nkeep > 64u ? 1u : 0u;
             my_raw += nkeep;
             a.meta_ord[ci].y = (u64)nkeep | ((u64)LA << 32);
         }
@@ -2604,6 +2613,8 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
     if (lane == 0) {
         if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
         if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
+        if (my_big) atomicAdd(&a.v.ctr[CTR_ES_BIG], (u64)my_big);
+        if (my_mid) atomicAdd(&a.v.ctr[CTR_ES_MID], (u64)my_mid);
     }
 }
 
@@ -2795,14 +2806,23 @@ __device__ __forceinline__ void record_drop(const EdgeSelArgs &a, u64 A, u32 LA,
     }
 }
 
+__device__ __forceinline__ void tr_wide_flush(const EdgeSelArgs &a, u64 tr_wide, u32 lane)
+{
+    if (lane == 0 && (u32)tr_wide) atomicAdd(&a.v.ctr[CTR_TR_BIG], (u64)(u32)tr_wide);
+    if (lane == 0 && (tr_wide >> 32)) atomicAdd(&a.v.ctr[CTR_TR_MID], tr_wide >> 32);
+}
+
 /* WCAP > 0: h / t are LDS arrays of WCAP entries (a power of two) and s_jcnt a 128-slot LDS histogram: rows of up to WCAP hits
  * may take the accept-all shortcut */
 template <int WCAP>
 /* rs: start of the row in the hit buffer (the header by position for rows of the main pass; row_start[A] — kept for rows of more
  * than 64 entries only — for the listed ones) */
 __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64 rs, u64 *h, u64 *t, u32 c, u32 lane, u32 *s_jcnt, u32 &cap_sites,
-                                                u32 &dropped, u64 &n_edges)
+                                                u32 &dropped, u64 &n_edges, u64 &tr_wide)
 {
+    /* tr_wide: nodes with more than TR_CAP (low word) / TR_CAP_SMALL (high word) finds, this wavefront's — they size the marking's
+     * big-node list and pick its variant; counted here and added once per wavefront (tr_wide_flush): an atomic per row on one address is
+     * 12 ns per row, and at coverages where every row comes this way that was most of the pass */
 #ifdef ES_EXP_STALE_ROWSTART /* tools/ab_build.py: the defect tests/test_gpu_parity.py::test_cap_binds_in_short_rows guards against */
     rs = a.row_start[A];
 #endif
@@ -2869,8 +2889,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
             lds_bitonic_sort(h, P, lane);
             for (u32 i = lane; i < m; i += 64) row[i] = h[i];
             if (lane == 0) a.ref[A] = REF_MAKE(rs, m);
-            if (lane == 0 && m > TR_CAP) atomicAdd(&a.v.ctr[CTR_TR_BIG], 1ull); /* (sizes the marking's big-node list) */
-            if (lane == 0 && m > TR_CAP_SMALL) atomicAdd(&a.v.ctr[CTR_TR_MID], 1ull);
+            tr_wide += (m > TR_CAP ? 1ull : 0ull) + (m > TR_CAP_SMALL ? 1ull << 32 : 0ull);
             n_edges += m;
             __syncthreads();
             return;
@@ -2925,8 +2944,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
     __syncthreads();
     for (u32 i = lane; i < nacc; i += 64) row[i] = t[i];
     if (lane == 0) a.ref[A] = REF_MAKE(rs, nacc);
-    if (lane == 0 && nacc > TR_CAP) atomicAdd(&a.v.ctr[CTR_TR_BIG], 1ull);
-    if (lane == 0 && nacc > TR_CAP_SMALL) atomicAdd(&a.v.ctr[CTR_TR_MID], 1ull);
+    tr_wide += (nacc > TR_CAP ? 1ull : 0ull) + (nacc > TR_CAP_SMALL ? 1ull << 32 : 0ull);
     n_edges += nacc;
     dropped += m - nacc;
     if (lane == 0 && m != nacc) atomicOr(&a.dropbits[A >> 6], 1ull << (A & 63));
@@ -3087,7 +3105,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
         __syncthreads();
     }
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
-    u64 n_edges = 0; /* wave-uniform */
+    u64 n_edges = 0, tr_wide = 0; /* wave-uniform */
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *h = BIG ? a.scratch + (u64)blockIdx.x * 2 * a.scratch_cap : s_h;
     u64 *t = BIG ? h + a.scratch_cap : s_t;
@@ -3130,7 +3148,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
                 const u64 A = a.big_list[it];
                 n_slow++;
                 if (a.row_cnt[A] <= ES_MID) continue; /* done by edge_select_mid_kernel */
-                edge_select_row<0>(a, A, a.row_start[A], h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges);
+                edge_select_row<0>(a, A, a.row_start[A], h, t, a.row_cnt[A], lane, s_jcnt, cap_sites, dropped, n_edges, tr_wide);
             }
             continue;
         }
@@ -3168,7 +3186,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
             } else if (c0 <= 64 && edge_select_row_fast(a, A, s0, L0, g0, lane, dropped, n_edges)) {
             } else {
                 n_slow++;
-                edge_select_row<ES_CAP>(a, A, s0, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges);
+                edge_select_row<ES_CAP>(a, A, s0, h, t, c0, lane, s_jcnt, cap_sites, dropped, n_edges, tr_wide);
             }
             c0 = c1; s0 = s1; L0 = L1; h0 = h1; w0 = w1;
             c1 = c2; s1 = m2.rs; L1 = m2.LA; r1 = r2;
@@ -3178,6 +3196,7 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+    tr_wide_flush(a, tr_wide, lane);
     if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
 
@@ -3228,7 +3247,7 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
     const u32 lane = threadIdx.x;
     const u32 k = (u32)a.v.k;
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
-    u64 n_edges = 0;
+    u64 n_edges = 0, tr_wide = 0;
     u64 cbeg = 0, cend = 0;
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
         const u32 n = (u32)(cend - cbeg);
@@ -3468,13 +3487,14 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
             }
             if (!done) {
                 n_slow++;
-                edge_select_row<(int)SEQ_CAP>(a, Ai, rs, s_ent, s_ent + SEQ_CAP, c0, lane, s_jc, cap_sites, dropped, n_edges);
+                edge_select_row<(int)SEQ_CAP>(a, Ai, rs, s_ent, s_ent + SEQ_CAP, c0, lane, s_jc, cap_sites, dropped, n_edges, tr_wide);
             }
         }
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+    tr_wide_flush(a, tr_wide, lane);
     if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
 
@@ -3490,7 +3510,7 @@ __global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a, u32 
     __shared__ u32 s_jcnt[128];
     const u32 lane = threadIdx.x;
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
-    u64 n_edges = 0;
+    u64 n_edges = 0, tr_wide = 0;
     const u64 n_items = (u64)min(*a.n_big, a.big_cap);
     u64 cbeg = 0, cend = 0;
     u64 gnext = 0, gend = 0;
@@ -3499,11 +3519,12 @@ __global__ void __launch_bounds__(64) edge_select_mid_kernel(EdgeSelArgs a, u32 
         const u32 c = a.row_cnt[A];
         if (c > (u32)CAP || c <= above) continue;
         n_slow++;
-        edge_select_row<CAP>(a, A, a.row_start[A], s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges);
+        edge_select_row<CAP>(a, A, a.row_start[A], s_h, s_t, c, lane, s_jcnt, cap_sites, dropped, n_edges, tr_wide);
     }
     if (lane == 0 && n_edges) atomicAdd(&a.v.ctr[CTR_ADJ_TOTAL], n_edges);
     if (lane == 0 && n_slow) atomicAdd(&a.v.ctr[CTR_ES_SLOW], (u64)n_slow);
     if (lane == 0 && cap_sites) atomicAdd(&a.v.ctr[CTR_CAP_SITES], (u64)cap_sites);
+    tr_wide_flush(a, tr_wide, lane);
     if (lane == 0 && dropped) atomicAdd(&a.v.ctr[CTR_DROPPED], (u64)dropped);
 }
 
