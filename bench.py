@@ -35,6 +35,11 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is attainable
+# vector-issue roof (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, a wavefront instruction occupies its SIMD's issue slot for 4 cycles (64 lanes on
+# 16-lane SIMDs), 2.4 GHz maximum clock (the chip holds less under load: the roof is the nominal one, like the 8 TB/s). The scalar unit of a
+# CU serves its four SIMDs in turn — one scalar instruction per SIMD every 4 cycles — so the same figure bounds SQ_INSTS_SALU.
+N_SIMDS, CYCLES_PER_WAVE_INST, CLOCK_GHZ = 1024, 4, 2.4
+ISSUE_PEAK_GINST_S = N_SIMDS / CYCLES_PER_WAVE_INST * CLOCK_GHZ  # 614.4 G wavefront-instructions / s
 
 
 def parse_args():
@@ -81,6 +86,37 @@ def algorithmic_bytes(cnt, n_reads, words_mean):
     per_phase = {"index": N * R + 2 * N * 16, "probe_kernel": N * R + Q * 8, "verify": H * R + E_pre * 16, "select": E_pre * 16, "trmark": E_pre * 16,
                  "emit": E_out * 16, "contain": C * 16}
     return sum(per_phase.values()), per_phase
+
+
+def issue_phase(t, ms, reads):
+    """one phase against the VECTOR-ISSUE roof — the roof that binds these kernels: wavefront instructions per launch from the
+    stamped counter profile (SQ_INSTS_VALU / SQ_INSTS_SALU of the phase's kernels: t = its entry in profiles/probe_traffic.json; same
+    source-fingerprint rule as `traffic`) over the issue rate of the chip, against the phase's duration measured live (ms).
+    frac = the share of the phase's time its vector instructions alone need at full issue."""
+    if not t.get("valu") or ms <= 0:
+        return None
+    floor = {u: (t.get(u) or 0.0) / (ISSUE_PEAK_GINST_S * 1e9) * 1e3 for u in ("valu", "salu")}
+    lds = t.get("lds") or 0.0
+    return {"bound": "valu_issue", "valu_insts": t["valu"], "salu_insts": t.get("salu"), "achieved": t["valu"] / (ms * 1e-3) / 1e9, "peak": ISSUE_PEAK_GINST_S,
+            "unit": "G wavefront-instructions/s", "frac": floor["valu"] / ms, "frac_salu": floor["salu"] / ms, "floor_ms": floor["valu"], "floor_ms_salu": floor["salu"],
+            "valu_insts_per_read": t["valu"] / reads, "lds_insts": lds,
+            "lds_bank_conflict_cycles_per_lds_inst": ((t.get("lds_bank_conflict") or 0.0) / lds) if lds else None}
+
+
+def issue_pass(ph_issue, ms_per_step, reads, note):
+    """the whole pass against the vector-issue roof: the instructions of every phase with a counter profile, at 4 cycles per wavefront
+    instruction on 1024 SIMDs at 2.4 GHz (0.63 of it against 0.235 of the HBM roof in round 5)"""
+    if not all(ph_issue.get(ph) for ph in ("index", "probe_kernel", "verify", "select", "trmark")):
+        return {"bound": "valu_issue", "frac": None, "source": note}
+    v_tot = sum(x["valu_insts"] for x in ph_issue.values() if x)
+    s_tot = sum((x["salu_insts"] or 0.0) for x in ph_issue.values() if x)
+    floor = v_tot / (ISSUE_PEAK_GINST_S * 1e9) * 1e3
+    return {"bound": "valu_issue", "valu_insts_per_step": v_tot, "salu_insts_per_step": s_tot, "cycles_per_wave_inst": CYCLES_PER_WAVE_INST, "simds": N_SIMDS,
+            "clock_ghz": CLOCK_GHZ, "peak": ISSUE_PEAK_GINST_S, "unit": "G wavefront-instructions/s", "achieved": v_tot / (ms_per_step * 1e-3) / 1e9,
+            "floor_ms": floor, "frac": floor / ms_per_step, "valu_insts_per_read": v_tot / reads,
+            "per_phase": {ph: {k: x[k] for k in ("valu_insts", "salu_insts", "floor_ms", "frac", "frac_salu", "valu_insts_per_read", "lds_bank_conflict_cycles_per_lds_inst")}
+                          for ph, x in ph_issue.items() if x},
+            "source": note.replace("FETCH_SIZE + WRITE_SIZE", "SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS / SQ_LDS_BANK_CONFLICT")}
 
 
 KERNEL_SOURCES = tuple(sorted("disco_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "disco_amd", "csrc")) if f.endswith((".h", ".hip"))))
@@ -424,7 +460,10 @@ def main():
         return {"bound": "hbm", "kernel": PHASE_KERNELS[ph], "phase": ph, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "peak_measured_copy": hbm_measured, "peak_measured_row_gather": gather_measured,
                 "traffic": t.get("lo"), "traffic_lo": t.get("lo"), "traffic_hi": t.get("hi"), "traffic_source": traffic_note,
-                "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": ms}
+                "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": ms, "issue": issue(ph)}
+
+    def issue(ph):
+        return issue_phase(tj.get("phases", {}).get(ph) or {}, avg_ms[ph], args.reads)
 
     out = {
         "metric": "overlaps/sec (BuildGraph stage), 150 bp reads",
@@ -463,6 +502,8 @@ def main():
         # bookkeeping kernels, launch gaps)
         "roofline_coverage_of_step": sum(avg_ms.values()) / ms_per_step if ms_per_step > 0 else None,
     }
+    # round 6: the pass against the VECTOR-ISSUE roof — the one that binds it
+    out["roofline_issue"] = issue_pass({ph: issue(ph) for ph in PHASE_KERNELS}, ms_per_step, args.reads, traffic_note)
     if not sharded and not args.no_host_to_host:
         # SURVEY.md §8(d) 'graph' wall: host buffers in, host structs out (the HBM-resident `value` never includes the copies)
         try:

@@ -16,7 +16,7 @@ BUILDG = os.path.join(HERE, "bin", "buildG")
 
 HIP_SOURCES = [os.path.join(HERE, "csrc", "disco_hip.hip")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(HERE, "csrc", f) for f in sorted(f for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))] + [
-    os.path.join(ROOT, "include", "disco_hip.h")]
+    os.path.join(ROOT, "include", "disco_hip.h"), os.path.join(ROOT, "include", "disco_hip_test.h")]
 HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("buildg_main.cpp", "fastx.cpp", "writer.cpp", "parsimple.cpp")]
 
 

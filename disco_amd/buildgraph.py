@@ -40,7 +40,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in COUNTER_NAMES]
 
 
-# every symbol include/disco_hip.h declares: (name, restype, argtypes)
+# every symbol include/disco_hip.h and include/disco_hip_test.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 ABI = [
     ("disco_abi_version", C.c_int, []),
@@ -111,6 +111,7 @@ ABI = [
     ("disco_ingest_fetch", C.c_int, [_P, _P, _P]),
 ]
 
+ABI_VERSION = 2  # DISCO_ABI_VERSION of include/disco_hip.h (tests/test_abi.py keeps the two equal)
 FLAG_TWO_PASS_VERIFY = 1  # DISCO_FLAG_TWO_PASS_VERIFY
 XCHG = ("reads", "index_records", "index_shards", "contain", "row_requests", "row_data", "push", "adjacency", "twins", "queries", "hits", "keys", "reads_dealt", "contain_keys")
 UNIQUE_ID_BYTES = 128
@@ -156,6 +157,10 @@ def load():
             raise DiscoError(f"{_LIBPATH} is missing: build it with `python -m disco_amd.build` (hipcc, gfx950). "
                              "There is no CPU fallback.")
         L = C.CDLL(_LIBPATH)
+        L.disco_abi_version.restype = C.c_int
+        if L.disco_abi_version() != ABI_VERSION:  # struct layouts below (DistInfo, ...) are those of exactly this version of include/disco_hip.h
+            raise DiscoError(f"{_LIBPATH} speaks ABI version {L.disco_abi_version()}, this mirror was written against {ABI_VERSION}: rebuild "
+                             "(`python -m disco_amd.build`)")
         for name, res, args in ABI:
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res

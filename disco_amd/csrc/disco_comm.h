@@ -91,33 +91,59 @@ struct DiscoComm {
         }                                                                                    \
     } while (0)
 
+#define DISCO_COMM_ALIVE()                                                                   \
+    do {                                                                                     \
+        if (!comm) {                                                                         \
+            err = "the communicator was aborted";                                            \
+            return DISCO_E_STATE;                                                            \
+        }                                                                                    \
+    } while (0)
+
 struct RcclComm final : DiscoComm {
     ncclComm_t comm = nullptr;
     unsigned long long *d_small = nullptr; /* staging of host_all_gather */
     size_t small_cap = 0;
     const char *kind() const override { return "rccl"; }
-    int init(const void *unique_id, int nranks, int rk)
+    /* Two steps, so that everything that can fail on ONE rank alone happens before that rank enters a collective (a rank whose
+     * staging allocation failed after ncclCommInitRank left its peers inside the next collective for ever):
+     *   prepare(): the staging of host_all_gather, device memory plus a pinned host mirror — no communication;
+     *   join():    ncclCommInitRank — collective; a rank that returns from it with an error has told its peers through the bootstrap.
+     * The staging exists before a pass starts: with one host thread per GPU in one process (buildG --gpus N) a device allocation while
+     * peers sit in an RCCL kernel is the classic stall. SMALL_VALUES per rank cover every use of a pass (the largest: world x world counts
+     * of an all-to-all-v); a larger request is an ERROR (round 6: it used to free and reallocate the staging inside the pass). */
+    static constexpr size_t SMALL_VALUES = 4096;
+    unsigned long long *h_small = nullptr; /* pinned: what the device-to-host copy of host_all_gather lands in */
+    int prepare(int nranks, int rk)
+    {
+        rank = rk;
+        world = nranks;
+        small_cap = (size_t)(world + 1) * SMALL_VALUES;
+        DISCO_COMM_HIP(hipMalloc((void **)&d_small, small_cap * 8));
+        DISCO_COMM_HIP(hipHostMalloc((void **)&h_small, small_cap * 8, hipHostMallocDefault));
+        return DISCO_OK;
+    }
+    int join(const void *unique_id)
     {
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof id);
-        rank = rk;
-        world = nranks;
-        DISCO_NCCL(ncclCommInitRank(&comm, nranks, id, rk));
-        /* the staging of host_all_gather now, not lazily inside a pass: with one host thread per GPU in one process (buildG --gpus N) a
-         * device allocation while peers sit in an RCCL kernel is the classic stall. 4096 values per rank cover every use of a pass
-         * (the largest: world x world counts of an all-to-all-v); a larger request still grows it, outside any collective */
-        small_cap = (size_t)(world + 1) * 4096;
-        DISCO_COMM_HIP(hipMalloc((void **)&d_small, small_cap * 8));
+        DISCO_NCCL(ncclCommInitRank(&comm, world, id, rank));
         return DISCO_OK;
+    }
+    int init(const void *unique_id, int nranks, int rk)
+    {
+        const int rc = prepare(nranks, rk);
+        return rc != DISCO_OK ? rc : join(unique_id);
     }
     ~RcclComm() override
     {
         if (d_small) (void)hipFree(d_small);
+        if (h_small) (void)hipHostFree(h_small);
         if (comm) (void)ncclCommDestroy(comm);
     }
     int all_gather(const void *send, void *recv, size_t bytes, hipStream_t s) override
     {
         n_ops++;
+        DISCO_COMM_ALIVE();
         if (bytes == 0) return DISCO_OK;
         DISCO_NCCL(ncclAllGather(send, recv, bytes, ncclInt8, comm, s));
         return DISCO_OK;
@@ -125,6 +151,7 @@ struct RcclComm final : DiscoComm {
     int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
     {
         n_ops++;
+        DISCO_COMM_ALIVE();
         /* blocks of one size, laid out rank after rank (the bucket-table slices whenever the world divides the table): the library's own
          * all-gather instead of world - 1 send / receive pairs. (The record slices differ by a fraction of a per cent and stay a grouped
          * exchange: padding them to one pitch would put slots without a record inside the LAST bucket of every slice — a bucket ends
@@ -151,6 +178,7 @@ struct RcclComm final : DiscoComm {
                      hipStream_t s) override
     {
         n_ops++;
+        DISCO_COMM_ALIVE();
         DISCO_NCCL(ncclGroupStart());
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
@@ -165,6 +193,7 @@ struct RcclComm final : DiscoComm {
     int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) override
     {
         n_ops++;
+        DISCO_COMM_ALIVE();
         if (per == 0) return DISCO_OK;
         DISCO_NCCL(ncclReduceScatter(buf, (long long *)buf + (size_t)rank * per, per, ncclInt64, ncclMin, comm, s));
         return DISCO_OK;
@@ -174,17 +203,18 @@ struct RcclComm final : DiscoComm {
         n_ops++;
         n_host_ops++;
         const size_t need = (size_t)(world + 1) * n;
-        if (need > small_cap) {
-            if (d_small) (void)hipFree(d_small);
-            d_small = nullptr;
-            DISCO_COMM_HIP(hipMalloc((void **)&d_small, need * 8));
-            small_cap = need;
+        if (!comm || need > small_cap) { /* (never a reallocation inside a pass: peers may be inside an RCCL kernel) */
+            err = !comm ? "host_all_gather: the communicator was aborted" : "host_all_gather: more values per rank than the staging made at init holds (RcclComm::SMALL_VALUES)";
+            return DISCO_E_CAPACITY;
         }
-        unsigned long long *d_mine = d_small + (size_t)world * n;
-        DISCO_COMM_HIP(hipMemcpyAsync(d_mine, mine, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        /* through the pinned mirror both ways: a copy out of / into pageable memory makes the runtime stage it and wait on its own */
+        unsigned long long *d_mine = d_small + (size_t)world * n, *h_mine = h_small + (size_t)world * n;
+        memcpy(h_mine, mine, (size_t)n * 8);
+        DISCO_COMM_HIP(hipMemcpyAsync(d_mine, h_mine, (size_t)n * 8, hipMemcpyHostToDevice, s));
         DISCO_NCCL(ncclAllGather(d_mine, d_small, (size_t)n * 8, ncclInt8, comm, s));
-        DISCO_COMM_HIP(hipMemcpyAsync(all, d_small, (size_t)world * n * 8, hipMemcpyDeviceToHost, s));
+        DISCO_COMM_HIP(hipMemcpyAsync(h_small, d_small, (size_t)world * n * 8, hipMemcpyDeviceToHost, s));
         DISCO_COMM_HIP(hipStreamSynchronize(s));
+        memcpy(all, h_small, (size_t)world * n * 8);
         return DISCO_OK;
     }
     int barrier(hipStream_t s) override
@@ -199,7 +229,10 @@ struct RcclComm final : DiscoComm {
     {
         if (comm) (void)ncclCommAbort(comm);
         comm = nullptr;
+        if (sibling && sibling->comm) sibling->abort(); /* the context's other communicator goes down with this one: a rank that has left a
+                                                          pass must not keep its peers inside a collective of EITHER */
     }
+    RcclComm *sibling = nullptr;
 };
 
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -255,7 +288,16 @@ struct LoopGroup {
     std::vector<const void *> ptr;                /* per rank: published buffer                */
     std::vector<std::vector<size_t>> off, cnt;    /* per rank: published per-peer offsets/counts */
     std::vector<unsigned long long> host;         /* host_all_gather scratch                   */
-    explicit LoopGroup(int w) : world(w), ptr((size_t)w), off((size_t)w), cnt((size_t)w) {}
+    /* DISCO_LOOP_ASYNC: per rank, "my send block is complete at this point of my stream" and "my pulls are through" (below) */
+    std::vector<hipEvent_t> ev_ready, ev_done;
+    explicit LoopGroup(int w) : world(w), ptr((size_t)w), off((size_t)w), cnt((size_t)w), ev_ready((size_t)w, nullptr), ev_done((size_t)w, nullptr) {}
+    ~LoopGroup()
+    {
+        for (hipEvent_t e : ev_ready)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_done)
+            if (e) (void)hipEventDestroy(e);
+    }
     bool wait()
     {
         std::unique_lock<std::mutex> lk(m);
@@ -278,10 +320,51 @@ struct LoopGroup {
     }
 };
 
+/* DISCO_LOOP_ASYNC=1 (round 6): the device-side exchanges WITHOUT any wait of the host on the device — what RCCL does: an
+ * operation is enqueued on the rank's stream, consumes what the stream produced before it, and completes in stream order; the host
+ * returns at once. The in-process form: every rank records "my send block is complete" on its stream, the ranks meet on the HOST
+ * (pointers and events change hands; nobody waits for a device), every rank makes its stream wait for its peers' events, enqueues its
+ * pulls, records "my pulls are through", and after a second meeting makes its stream wait for every peer's pulls (nobody overwrites a
+ * send block a peer still reads). A caller that reads a result without a stream dependency of its own — the assumption rounds 4-5 wrote
+ * into the flow when they took the host waits out — now reads garbage in the tests instead of on the first multi-GPU node.
+ * Not with DISCO_LOOP_SERIALIZE (that measurement hands the device from rank to rank at host waits). */
 struct LoopComm final : DiscoComm {
     std::shared_ptr<LoopGroup> g;
     const long long **d_srcs = nullptr;
+    const bool async = getenv("DISCO_LOOP_ASYNC") != nullptr && !LoopDeviceToken::get().on;
     const char *kind() const override { return "loop"; }
+    /* first half: my block is complete here (stream order), meet, wait for everybody's blocks (on the stream) */
+    int async_open(hipStream_t s)
+    {
+        hipEvent_t &er = g->ev_ready[(size_t)rank], &ed = g->ev_done[(size_t)rank];
+        if (!er && (hipEventCreateWithFlags(&er, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ed, hipEventDisableTiming) != hipSuccess))
+            return fail_abort(DISCO_E_HIP);
+        if (hipEventRecord(er, s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        if (!g->wait()) {
+            err = "loop communicator aborted by another rank";
+            return DISCO_E_STATE;
+        }
+        for (int p = 0; p < world; p++)
+            if (p != rank && hipStreamWaitEvent(s, g->ev_ready[(size_t)p], 0) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        return DISCO_OK;
+    }
+    /* second half: my pulls are enqueued; meet; nobody's stream goes on before every peer's pulls are through */
+    int async_close(hipStream_t s)
+    {
+        if (hipEventRecord(g->ev_done[(size_t)rank], s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        if (!g->wait()) {
+            err = "loop communicator aborted by another rank";
+            return DISCO_E_STATE;
+        }
+        for (int p = 0; p < world; p++)
+            if (p != rank && hipStreamWaitEvent(s, g->ev_done[(size_t)p], 0) != hipSuccess) return fail_abort(DISCO_E_HIP);
+        /* (a third meeting: the events are re-recorded by the next operation only after every peer has enqueued its waits on them) */
+        if (!g->wait()) {
+            err = "loop communicator aborted by another rank";
+            return DISCO_E_STATE;
+        }
+        return DISCO_OK;
+    }
     LoopComm(std::shared_ptr<LoopGroup> grp, int rk) : g(std::move(grp))
     {
         rank = rk;
@@ -312,6 +395,17 @@ struct LoopComm final : DiscoComm {
     int all_gather_v(const void *send, void *recv, const size_t *off, const size_t *cnt, hipStream_t s) override
     {
         n_ops++;
+        if (async) {
+            g->ptr[(size_t)rank] = send;
+            const int rc = async_open(s);
+            if (rc != DISCO_OK) return rc;
+            for (int p = 0; p < world; p++) {
+                char *dst = (char *)recv + off[p];
+                if (cnt[p] && dst != g->ptr[(size_t)p])
+                    if (hipMemcpyAsync(dst, g->ptr[(size_t)p], cnt[p], hipMemcpyDeviceToDevice, s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+            }
+            return async_close(s);
+        }
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP); /* my block is complete */
         LoopTokenPause pause;
         g->ptr[(size_t)rank] = send;
@@ -329,6 +423,23 @@ struct LoopComm final : DiscoComm {
                      hipStream_t s) override
     {
         n_ops++;
+        if (async) {
+            g->ptr[(size_t)rank] = send;
+            g->off[(size_t)rank].assign(soff, soff + world);
+            g->cnt[(size_t)rank].assign(scnt, scnt + world);
+            const int rc = async_open(s);
+            if (rc != DISCO_OK) return rc;
+            for (int p = 0; p < world; p++) {
+                const size_t n = g->cnt[(size_t)p][(size_t)rank];
+                if (n != rcnt[p]) {
+                    err = "all_to_all_v: receive count does not match the peer's send count";
+                    return fail_abort(DISCO_E_ARG);
+                }
+                if (n && hipMemcpyAsync((char *)recv + roff[p], (const char *)g->ptr[(size_t)p] + g->off[(size_t)p][(size_t)rank], n, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    return fail_abort(DISCO_E_HIP);
+            }
+            return async_close(s);
+        }
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
         LoopTokenPause pause;
         g->ptr[(size_t)rank] = send;
@@ -351,6 +462,19 @@ struct LoopComm final : DiscoComm {
     int reduce_scatter_min_i64(void *buf, size_t per, hipStream_t s) override
     {
         n_ops++;
+        if (async) {
+            g->ptr[(size_t)rank] = buf;
+            if (!d_srcs && hipMalloc((void **)&d_srcs, sizeof(void *) * (size_t)world) != hipSuccess) return fail_abort(DISCO_E_NOMEM);
+            const int rc = async_open(s);
+            if (rc != DISCO_OK) return rc;
+            if (per) {
+                /* (the table of the peers' pointers: a pageable copy is staged by the runtime before the call returns) */
+                if (hipMemcpyAsync(d_srcs, g->ptr.data(), sizeof(void *) * (size_t)world, hipMemcpyHostToDevice, s) != hipSuccess) return fail_abort(DISCO_E_HIP);
+                hipLaunchKernelGGL(loop_min_i64_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 4096)), dim3(256), 0, s, (long long *)buf, d_srcs, world,
+                                   (size_t)rank * per, per);
+            }
+            return async_close(s);
+        }
         if (hipStreamSynchronize(s) != hipSuccess) return fail_abort(DISCO_E_HIP);
         LoopTokenPause pause;
         g->ptr[(size_t)rank] = buf;

@@ -309,8 +309,15 @@ __device__ __forceinline__ u32 order_hash32(u64 c)
     /* (canonical m-mers of up to 23 bases have 46 bits: the third product is zero for them — the order of rounds 1-3; m up to 31,
      * which k above 86 needs, brings 62. WIDE = false: the caller knows that m <= 23 and saves the product) */
     u32 h = __umul24((u32)c & 0xFFFFFFu, 0x9E3779u) + __umul24((u32)(c >> 24) & 0xFFFFFFu, 0x85EBCBu) + (WIDE ? __umul24((u32)(c >> 48), 0xC2B2AEu) : 0u) + 0x7F4A7C15u;
+#ifdef ORDER_HASH_MUL32 /* rounds 1-5: xor-shift and one 32-bit multiply (quarter rate: four issue slots) */
     h ^= h >> 15;
     return h * 0x2C1B3C6Du;
+#else
+    /* round 6: the mix as two more full-rate 24-bit multiplies — the low 24 bits and the high 24 bits of the fold, each spread upwards by
+     * an odd constant (three issue slots instead of six; the order is internal: any strand-symmetric hash that is unrelated to the base
+     * composition gives the same graph, and index, probe and the multi-GPU key pass all take it from here) */
+    return __umul24(h & 0xFFFFFFu, 0xC1B3C7u) + __umul24(h >> 8, 0x9E3779u);
+#endif
 }
 template <bool NB = false>
 __device__ __forceinline__ u32 mmer_order(const u64 *p, int S, int pos, int m)

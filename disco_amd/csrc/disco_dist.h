@@ -133,29 +133,46 @@ __global__ void add_u64_kernel(u64 *__restrict__ p, u64 n, u64 val)
 /* the read-level minimizer keys of the reads [lo, hi) alone (okey[i] as index_count_kernel / index_runs_kernel compute it: the smallest
  * 32-bit order hash among all m-mers of the read). The reads are dealt by this key before anything else is computed from them: the
  * records, runs and rows of a read are the business of the rank that gets it. One thread per read, one rolling pass. */
+template <bool FIXED_M>
 __global__ void __launch_bounds__(256) read_keys_kernel(DiscoView v, u64 lo, u64 hi, u32 *__restrict__ okey)
 {
     const u64 i = lo + (u64)blockIdx.x * 256u + threadIdx.x;
     if (i >= hi) return;
     const u64 *__restrict__ p = v.reads + i * (u64)v.S;
-    const int L = v.len[i], m = v.m, nmm = L - m + 1;
-    const u64 mask = (1ull << (2 * m)) - 1ull;
-    const int rsh = 2 * (m - 1);
-    u64 f = 0, r = 0, word = 0;
-    int pos = 0;
-    auto next = [&]() {
-        if ((pos & 31) == 0) word = p[pos >> 5];
-        const u32 b = (u32)(word >> 62);
-        word <<= 2;
-        ++pos;
-        f = ((f << 2) | b) & mask;
-        r = (r >> 2) | ((u64)(3u - b) << rsh);
-    };
-    for (int q = 0; q < m - 1; ++q) next();
+    const int L = v.len[i];
     u32 best = 0xFFFFFFFFu;
-    for (int q = 0; q < nmm; ++q) {
-        next();
-        best = min(best, order_hash32(r < f ? r : f));
+    if (FIXED_M) { /* m = RUNS_M (every k from 23 to 86): index_runs_kernel's rolling pass on 32-bit halves */
+        constexpr int m = RUNS_M;
+        const int nmm = L - m + 1;
+        MmerRoll<m> roll(p, v.S);
+        for (int q = 0; q < m - 1; ++q) roll.step();
+        int nmax = nmm; /* every thread of the wavefront walks the same positions (the longest read's); a shorter read masks what it keeps */
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+        nmax = (int)uniform_u32((u32)nmax);
+        for (int q = 0; q < nmax; ++q) {
+            roll.step();
+            const u32 h = roll.hash();
+            best = min(best, q < nmm ? h : 0xFFFFFFFFu);
+        }
+    } else {
+        const int m = v.m, nmm = L - m + 1;
+        const u64 mask = (1ull << (2 * m)) - 1ull;
+        const int rsh = 2 * (m - 1);
+        u64 f = 0, r = 0, word = 0;
+        int pos = 0;
+        auto next = [&]() {
+            if ((pos & 31) == 0) word = p[pos >> 5];
+            const u32 b = (u32)(word >> 62);
+            word <<= 2;
+            ++pos;
+            f = ((f << 2) | b) & mask;
+            r = (r >> 2) | ((u64)(3u - b) << rsh);
+        };
+        for (int q = 0; q < m - 1; ++q) next();
+        for (int q = 0; q < nmm; ++q) {
+            next();
+            best = min(best, order_hash32(r < f ? r : f));
+        }
     }
     okey[i] = best;
 }

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/disco_hip.h"
+#include "../../include/disco_hip_test.h"
 #include "disco_kernels.h"
 #include "disco_dist.h"
 
@@ -641,6 +642,13 @@ static int scan_exclusive(disco_ctx *c, const InT *in, u64 n, OutT *out, bool wr
 
 static void free_graph_state(disco_ctx *c)
 {
+    /* a key exchange that still runs behind a pass (second communicator, bulk_stream) reads and writes best[]: it is through before the
+     * buffer goes back to the arena — a pass that failed after the exchange was issued, or new reads right after a pass, used to free
+     * it under the collective */
+    if (c->keys_pending) {
+        c->keys_pending = false;
+        if (c->ev_keys) (void)hipEventSynchronize(c->ev_keys);
+    }
     dev_free(c, &c->d_bkt, c->bkt_cap);
     dev_free(c, &c->d_ent, c->ent_cap);
     dev_free(c, &c->d_rec, c->rec_cap);
@@ -796,7 +804,7 @@ static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
     /* (index_runs_kernel keeps a block of NF order words in registers: one instantiation per window length — the reference's default
      * min-overlap 30 (NF 7), 35, BASELINE's 40 (NF 17), 45, 50) */
     const bool nf_built = nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27;
-    if (nf_built && max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
+    if (nf_built && view(c).m == RUNS_M && max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
         const u32 maxwin = max_len - (u32)c->k;
         /* a read of W windows has about 2 W / (NF + 1) runs: 32 entries where that stays below 20 (room for the spread), else 64 */
         const u32 expect = 2u * maxwin / (u32)(nf + 1);
@@ -4236,7 +4244,10 @@ static int dist_deal_reads(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_okey, &c->okey_cap, c->n_alloc));
     if (!c->d_otab) CHK(dev_alloc(c, &c->d_otab, c->n_alloc));
     DiscoView v = view(c);
-    if (hhi > hlo) hipLaunchKernelGGL(read_keys_kernel, dim3((unsigned)((hhi - hlo + 255) / 256)), dim3(256), 0, c->stream, v, hlo, hhi, c->d_okey);
+    if (hhi > hlo) {
+        if (v.m == RUNS_M) hipLaunchKernelGGL(read_keys_kernel<true>, dim3((unsigned)((hhi - hlo + 255) / 256)), dim3(256), 0, c->stream, v, hlo, hhi, c->d_okey);
+        else hipLaunchKernelGGL(read_keys_kernel<false>, dim3((unsigned)((hhi - hlo + 255) / 256)), dim3(256), 0, c->stream, v, hlo, hhi, c->d_okey);
+    }
     HIPCHK(c, hipGetLastError());
     {
         const auto t0 = HClock::now();
@@ -5077,31 +5088,55 @@ int disco_comm_init(disco_ctx *c, const void *unique_id, int nranks, int rank)
         delete bulk;
         return fail(c, DISCO_E_NOMEM, "disco_comm_init: out of host memory");
     }
-    int rc = cm->init(unique_id, nranks, rank);
-    if (rc == DISCO_OK && bulk) { /* the id of the second communicator travels over the first one */
-        /* Every rank takes part in the broadcast WHATEVER happened to it before: a rank that left early (rank 0 without an id, a rank
-         * without staging memory) would leave the others inside ncclBroadcast for ever. What travels is the id and a word that says
-         * whether it is one; without one, every rank — alike — goes on with the first communicator alone (the all-gather of the reads
-         * then runs on it: DISCO_DIST_ONE_COMM's path). The staging is the first communicator's own (allocated at its init). */
+    /* Order of the steps (round 6): everything that can fail on ONE rank alone — allocations — happens before that rank enters
+     * a collective; every decision about the second communicator is taken from values ALL ranks hold (a broadcast, then an all-gather of
+     * the ranks' own status), so the ranks keep or drop it together; no rank is ever left waiting inside a collective its peer skipped. */
+    int rc = cm->prepare(nranks, rank);                         /* local */
+    int bulk_ready = (bulk && bulk->prepare(nranks, rank) == DISCO_OK) ? 1 : 0; /* local; a failure only costs the second communicator */
+    if (rc == DISCO_OK) rc = cm->join(unique_id);               /* collective (the launcher's rendezvous: MPI_Init's role) */
+    if (rc == DISCO_OK && !one_comm) { /* the id of the second communicator travels over the first one */
         struct IdMsg {
             ncclUniqueId id;
             unsigned long long ok;
         } msg;
-        static_assert(sizeof(IdMsg) <= 4096 * 8, "fits the staging of host_all_gather");
+        static_assert(sizeof(IdMsg) <= RcclComm::SMALL_VALUES * 8, "fits the staging of host_all_gather");
         memset(&msg, 0, sizeof msg);
         if (rank == 0) msg.ok = ncclGetUniqueId(&msg.id) == ncclSuccess ? 1ull : 0ull;
         void *d_id = cm->d_small;
-        if (hipMemcpyAsync(d_id, &msg, sizeof msg, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        memcpy(cm->h_small, &msg, sizeof msg);
+        if (hipMemcpyAsync(d_id, cm->h_small, sizeof msg, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             ncclBroadcast(d_id, d_id, sizeof msg, ncclInt8, 0, cm->comm, c->stream) != ncclSuccess ||
-            hipMemcpyAsync(&msg, d_id, sizeof msg, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            hipMemcpyAsync(cm->h_small, d_id, sizeof msg, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             rc = DISCO_E_HIP; /* the first communicator itself does not work: nothing to fall back to */
             cm->err = "broadcast of the second communicator's id failed";
-        } else if (!msg.ok) {
-            if (rank == 0) fprintf(stderr, "[disco] no id for a second communicator: the reads are gathered on the first one\n");
-            delete bulk;
-            bulk = nullptr;
-        } else
-            rc = bulk->init(&msg.id, nranks, rank);
+        } else {
+            memcpy(&msg, cm->h_small, sizeof msg);
+            /* is everybody able to join it? (rank 0 has an id, every rank its staging) — one all-gather of one word */
+            unsigned long long mine = (msg.ok && bulk_ready) ? 1ull : 0ull, all[DIST_MAX_WORLD];
+            rc = cm->host_all_gather(&mine, 1, all, c->stream);
+            bool everybody = rc == DISCO_OK;
+            for (int p = 0; everybody && p < nranks; p++) everybody = all[p] != 0ull;
+            if (rc == DISCO_OK && everybody) {
+                const int rb = bulk->join(&msg.id); /* collective */
+                /* ... and did everybody get in? Keep it or drop it TOGETHER */
+                mine = rb == DISCO_OK ? 1ull : 0ull;
+                rc = cm->host_all_gather(&mine, 1, all, c->stream);
+                for (int p = 0; rc == DISCO_OK && everybody && p < nranks; p++) everybody = all[p] != 0ull;
+            }
+            if (rc == DISCO_OK && !everybody) {
+                if (rank == 0) fprintf(stderr, "[disco] no second communicator on every rank: the reads are gathered on the first one\n");
+                delete bulk;
+                bulk = nullptr;
+            }
+        }
+    }
+    if (one_comm) {
+        delete bulk;
+        bulk = nullptr;
+    }
+    if (rc == DISCO_OK && bulk) { /* abort() of either takes both down */
+        cm->sibling = bulk;
+        bulk->sibling = cm;
     }
     if (rc != DISCO_OK) {
         fail(c, rc, "disco_comm_init: %s %s", cm->err.c_str(), bulk ? bulk->err.c_str() : "");

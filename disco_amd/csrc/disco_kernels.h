@@ -355,6 +355,42 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
     rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, LONGCLASS ? v.n + x : rid, ts, rs, 1, L));
 }
 
+/* the rolling canonical m-mer of a 2-bit packed row on 32-bit halves, M a constant (odd, 2 M bits = one dword + 2 M - 32 bits): the
+ * forward m-mer f and the reverse complement r of the M bases that end at the current position, every thread of the wavefront at the
+ * SAME position (the dword switch is a scalar branch, the base leaves the current dword through a bit-field extract with a scalar offset) */
+#define RUNS_M 23 /* minimizer length of the paths built on MmerRoll (disco_minimizer_len gives 23 for every k from 23 to 86) */
+template <int M>
+struct MmerRoll {
+    static_assert(M > 16 && M <= 24 && (M & 1), "two dwords, the high one partly used; a 24-bit fold in order_hash32<false>");
+    const u64 *__restrict__ p;
+    int last_word;
+    int pos = 0; /* bases consumed (wave uniform) */
+    u64 word = 0;
+    u32 cw = 0;
+    u32 flo = 0, fhi = 0, rlo = 0, rhi = 0;
+    bool st = false;
+    u32 clo = 0, chi = 0;
+    __device__ __forceinline__ MmerRoll(const u64 *row, int S) : p(row), last_word(S - 1) {}
+    __device__ __forceinline__ void step()
+    {
+        if ((pos & 15) == 0) {
+            if ((pos & 31) == 0) word = p[min(pos >> 5, last_word)];
+            cw = (pos & 16) ? (u32)word : (u32)(word >> 32);
+        }
+        const u32 b = __builtin_amdgcn_ubfe(cw, (u32)(30 - 2 * (pos & 15)), 2u);
+        ++pos;
+        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30u) & ((1u << (2 * M - 32)) - 1u);
+        flo = (flo << 2) | b;
+        rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2u);
+        rhi = (rhi >> 2) | ((b ^ 3u) << (2 * M - 34));
+        st = (((u64)rhi << 32) | rlo) < (((u64)fhi << 32) | flo); /* the reverse complement is the canonical one (M odd: never equal) */
+        clo = st ? rlo : flo;
+        chi = st ? rhi : fhi;
+    }
+    __device__ __forceinline__ u32 hash() const { return order_hash32<false>(((u64)chi << 32) | clo); }
+    __device__ __forceinline__ u32 strand() const { return st ? 1u : 0u; }
+};
+
 /* ----------------------------------------------------------------------------------------------------------------
  * index_runs_kernel — index_count_kernel's rolling pass, which additionally hands the probe every read's MINIMIZER RUNS, so
  * that probe_runs_kernel starts at the bucket lookups instead of re-deriving, wave per read, what this pass walks anyway
@@ -389,6 +425,7 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
 {
     constexpr int CAP = 32 * NL;
     __shared__ u16 s_runs[256 * CAP];
+    __shared__ u32 s_x[3 * 256]; /* the suffix k-mer's window: its two minima and their base, per thread */
     const u32 tid = threadIdx.x;
     for (u32 x = tid; x < 256u * CAP / 2u; x += 256u) ((u32 *)s_runs)[x] = 0xFFFFFFFFu;
     __syncthreads();
@@ -400,49 +437,44 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
     if (other_class) s_runs[tid * CAP] = 0xFFFEu;
     if (i < hi && !other_class) {
         const u64 *__restrict__ p = v.reads + rid * v.S;
-        const int L = list ? ORDER_LEN(lw) : (int)v.len[rid], k = v.k, m = v.m;
+        const int L = list ? ORDER_LEN(lw) : (int)v.len[rid], k = v.k;
+        constexpr int m = RUNS_M; /* (the host takes this path for m = RUNS_M only: runs_lpr_for) */
         const int nmm = L - m + 1; /* m-mer positions */
         const int npos = nmm - NF; /* = L - k: the probe's windows are [0, npos), window npos is the suffix k-mer */
-        const u64 mask = (1ull << (2 * m)) - 1ull;
-        const int rsh = 2 * (m - 1);
-        u64 f = 0, r = 0, word = 0;
-        int pos = 0;
-        auto next = [&]() {
-            if ((pos & 31) == 0) word = p[pos >> 5];
-            const u32 b = (u32)(word >> 62);
-            word <<= 2;
-            ++pos;
-            f = ((f << 2) | b) & mask;
-            r = (r >> 2) | ((u64)(3u - b) << rsh);
-        };
+        /* round 6: the rolling pass on 32-bit halves with the minimizer length a constant (the masks and the place of the entering
+         * complement were run-time values: 64-bit shifts by a register, two ANDs), the base taken out of the current dword by a SCALAR
+         * offset (every thread of a wavefront is at the same base: the position never depends on the lane — reads shorter than the
+         * longest only mask what they keep), and a mix of two 24-bit multiplies behind the fold (order_hash32): 27 -> 21 vector
+         * instructions per m-mer and thread in this part of the kernel, which is bound by vector issue outright */
+        MmerRoll<m> roll(p, v.S);
         u32 best = 0xFFFFFFFFu;
-        auto order_word = [&]() {
-            next();
-            const bool st = r < f;
-            const u32 h = order_hash32<false>(st ? r : f); /* (a window length the runs are built for means k <= 49: m <= 23) */
-            best = min(best, h);
-            return (h & ~0x1FFu) | (u32)st;
-        };
-        for (int q = 0; q < m - 1; ++q) next();
-        u32 hc[NF], s1[NF], s2[NF];
+        for (int q = 0; q < m - 1; ++q) roll.step();
+        u32 s1[NF], s2[NF]; /* suffix minima of the block before; slot t is free for the block's own order word once step t - 1 has read it */
 #pragma unroll
         for (int t = 0; t < NF; ++t) s1[t] = s2[t] = 0xFFFFFFFFu;
         u16 *my = s_runs + tid * CAP;
-        u32 cnt = 0, last = 0xFFFFFFFFu, tie = 0;
-        u32 P1 = 0, P2 = 0, X1 = 0, X2 = 0, Xbase = 0;
-        /* window w (wave uniform: every thread walks the same positions) with minima m1 / m2 over positions relative to `base` */
-        auto window = [&](int w, u32 m1, u32 m2, int base) {
+        u32 cnt = 0, lastm = 0xFFFFFFFFu, tie = 0;
+        u32 P1 = 0, P2 = 0;
+        u32 *sx = s_x + tid;
+        /* window w (wave uniform: every thread walks the same positions) with minima m1 / m2 over positions relative to `base`; tw = w - base */
+        auto window = [&](int w, u32 m1, u32 m2, int base, int tw) {
             if (w <= npos) {
-                if (w == npos) { /* the suffix k-mer: its record; not one of the probe's windows */
-                    X1 = m1;
-                    X2 = m2;
-                    Xbase = (u32)base;
+                if (w == npos) { /* the suffix k-mer: its record; not one of the probe's windows. (Through LDS: as register values the three
+                                    would be merged with their old selves behind EVERY window — six copies per window and thread) */
+                    sx[0] = m1;
+                    sx[256] = m2;
+                    sx[512] = (u32)base;
                 } else {
                     tie |= (m1 ^ m2) ^ 0xFEu;
-                    const u32 prel = (u32)base + ((m1 >> 1) & 0x7Fu);
-                    if (prel != last) {
-                        last = prel;
-                        if (cnt < (u32)CAP) my[cnt] = (u16)(((u32)w << 6) | ((prel - (u32)w) << 1) | (m1 & 1u));
+                    /* a new occurrence: another hash or another position than the window before had (lastm holds that window's minimum with
+                     * its position relative to THIS block: re-based at every block; an occurrence that has left the windows for good
+                     * borrows from its hash bits there and matches nothing) */
+                    if (((m1 ^ lastm) >> 1) != 0u) {
+                        lastm = m1;
+                        /* first window << 6 | (occurrence - first window) << 1 | strand: the low byte of the minimum is position << 1 | strand
+                         * (bit 8 is never set), the rest is the same for every thread. A list that overflows is marked unusable below: its
+                         * last slot may take whatever comes */
+                        my[cnt < (u32)CAP ? cnt : (u32)CAP - 1u] = (u16)((m1 & 0xFFu) + (((u32)w << 6) - 2u * (u32)tw));
                         ++cnt;
                     }
                 }
@@ -452,21 +484,26 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
         int q = 0;
         for (int b = 0; b < nblk; ++b) {
             const int base = (b - 1) * NF;
-            if (b >= 1) window(base, s1[0], s2[0], base); /* the window that IS block b - 1 */
+            lastm -= (u32)NF << 1;
+            if (b >= 1) window(base, s1[0], s2[0], base, 0); /* the window that IS block b - 1 */
             if (b == 1) {
                 P1 = s1[0]; /* window 0: the prefix k-mer's record */
                 P2 = s2[0];
             }
             u32 p1 = 0xFFFFFFFFu, p2 = 0xFFFFFFFFu;
+            u32 hc[NF];
 #pragma unroll
             for (int t = 0; t < NF; ++t) {
-                u32 o = 0xFFFFFFFFu; /* past the read: never a minimum (a window the probe uses never reaches there) */
-                if (q < nmm) o = order_word();
+                /* past the read the order word is whatever the row holds there: never part of a window the probe uses, and kept out of the read's key */
+                roll.step();
+                const u32 h = roll.hash();
+                best = min(best, q < nmm ? h : 0xFFFFFFFFu);
+                const u32 o = (h & ~0x1FFu) | roll.strand();
                 ++q;
                 hc[t] = o;
                 p1 = min(p1, o | ((u32)(NF + t) << 1));
                 p2 = min(p2, o | ((u32)(127 - (NF + t)) << 1));
-                if (t + 1 < NF && b >= 1) window(base + t + 1, min(s1[t + 1], p1), min(s2[t + 1], p2), base);
+                if (t + 1 < NF && b >= 1) window(base + t + 1, min(s1[t + 1], p1), min(s2[t + 1], p2), base, t + 1);
             }
             u32 a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
 #pragma unroll
@@ -478,7 +515,9 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
             }
         }
         if (okey) okey[i] = best;
+#if !defined(INDEX_EXP_NOATOMIC)
         if (ocnt) oslot[i - lo] = atomicAdd(&ocnt[ORDER_BUCKET(best, oshift)], 1u); /* the grouping's counting pass (order_count_kernel), fused */
+#endif
         if ((tie & ~1u) != 0 || cnt > (u32)CAP) my[0] = 0xFFFEu; /* (bit 0 of m1 ^ m2: the two strands of a tie may differ) */
         /* the two end k-mers' records: window_minimizer's rule on the minima of windows 0 and npos */
         auto resolve = [&](u32 k1, u32 k2, int wbase, int j0, u32 &t, u32 &rev) {
@@ -495,14 +534,21 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
         };
         u32 tp, rp, ts, rs;
         const u64 kp = resolve(P1, P2, 0, 0, tp, rp);
-        const u64 ks = resolve(X1, X2, (int)Xbase, npos, ts, rs);
+        const u64 ks = resolve(sx[0], sx[256], (int)sx[512], npos, ts, rs);
         const u64 bp = kp >> v.bshift, bs = ks >> v.bshift;
+#if defined(INDEX_EXP_NOATOMIC) /* timing experiment (results are wrong): the pass without its three counting atomics */
+        const u32 sp = 0u, ss = 0u;
+#else
         const u32 sp = COUNT ? atomicAdd(&bkt[bp], 1u) : 0u;
         const u32 ss = COUNT ? atomicAdd(&bkt[bs], 1u) : 0u;
+#endif
         rec[2 * (i - lo)] = make_ulonglong2((bp << 32) | sp, PAY_MAKE(kp, rid, tp, rp, 0, L));
         rec[2 * (i - lo) + 1] = make_ulonglong2((bs << 32) | ss, PAY_MAKE(ks, rid, ts, rs, 1, L));
     }
     __syncthreads();
+#if defined(INDEX_EXP_NORUNS) /* timing experiment (results are wrong): the run lists stay in LDS */
+    if (tid != 9999u) return;
+#endif
     const u64 r0 = (u64)blockIdx.x * 256u;
     const u64 nr = (hi - lo) - r0 < 256u ? (hi - lo) - r0 : 256u;
     u32 *__restrict__ dst = runs + r0 * (CAP / 2);
@@ -1068,6 +1114,9 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
     __shared__ u32 s_occ[128]; /* the group's runs, compacted: slot << 29 | strand << 22 | (occurrence - first) << 17 | end << 8 | first window */
     __shared__ u32 s_o_fp[64], s_o_start[64], s_o_excl[64], s_o_desc[64]; /* current batch of lookups with records */
     __shared__ u8 s_mark[PR_MARKCAP];
+#if defined(VERIFY_EXP_HALF)
+    __shared__ u32 s_len_exp[G];
+#endif
     const u32 lane = threadIdx.x;
     const int k = a.v.k, m = a.v.m, nf = k - m + 1;
     const u32 slot = lane / LPR, e = lane % LPR;
@@ -1120,6 +1169,9 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
             __syncthreads();
             if (lane < (u32)(G * 8)) s_rows[(lane >> 3) * RS + (lane & 7)] = pre_row;
             if (e == 0) s_id[slot] = sv ? A : 0xFFFFFFFFu;
+#if defined(VERIFY_EXP_HALF)
+            if (e == 0) s_len_exp[slot] = (u32)LA;
+#endif
             fetch(g0 + G, pre_rw, pre_row);
             if (PR_CHUNK - chunk_used < PR_RESERVE) {
                 u64 base = 0;
@@ -1223,8 +1275,17 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                     const int t = (int)PAY_T(pay);
                     /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k - m - t before */
                     const int w = rv ? prel - (nf - 1 - t) : prel - t;
-                    const bool take = in && PAY_FP(pay) == s_o_fp[lo] && (u32)PAY_ID(pay) != s_id[dslot] /* self: BG/OverlapGraph.cpp:421,655 */
-                                      && w >= wst && w < wen;
+                    bool take = in && PAY_FP(pay) == s_o_fp[lo] && (u32)PAY_ID(pay) != s_id[dslot] /* self: BG/OverlapGraph.cpp:421,655 */
+                                && w >= wst && w < wen;
+#if defined(VERIFY_EXP_HALF) /* timing experiment (results are wrong): the reference compares a pair once and inserts the twin (BG/OverlapGraph.cpp:614-626,
+                                652-653); here every overlap is compared from both sides. What half the overlap-type candidates would leave of probe
+                                + verify: those into a read of smaller id are dropped (containment-type candidates stay: verify's MODE 1 rule) */
+                    {
+                        const int LAx = (int)s_len_exp[dslot], LBx = (int)PAY_LEN(pay);
+                        const bool cont = (PAY_SUFFIX(pay) == (PAY_REV(pay) ^ rv)) ? (LAx - w >= LBx) : (w + k - LBx >= 0);
+                        take = take && (cont || (u32)PAY_ID(pay) > s_id[dslot]);
+                    }
+#endif
                     const u64 mm = __ballot(take);
                     if (take) {
                         const u32 pos = nrow + (u32)__popcll(mm & lt);
@@ -1726,6 +1787,12 @@ __device__ __forceinline__ u64 pinned_copy(u64 x)
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"((u32)x), "v"((u32)(x >> 32)));
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u32 pinned_copy32(u32 x)
+{
+    u32 y;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
 #ifndef VERIFY_FLAT_WAVES_PER_SIMD
 #define VERIFY_FLAT_WAVES_PER_SIMD 4 /* round 5: the kernel's time follows its resident waves (8 / 10 / 12 blocks per CU: 29.7 / 25.3 / 22.1 ms) */
 #endif
@@ -1970,8 +2037,16 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
             const int bitpos = 2 * (16 * W0 - dd);             /* >= -30: B's bit under the first bit of T's dword W0 */
             const int i0 = (bitpos - 1) >> 5;
             const u32 sh = (u32)(32 * i0 + 32 - bitpos);
+#if defined(VERIFY_EXP_NOCONFLICT) /* timing experiment (tools/ab_build.py; results are wrong): every LDS read of the compare at a lane-private
+                                      address — rows of an odd stride, one per lane: no two lanes of a 32-lane group on one bank */
+            const u32 *bp = s_b + 1 + lane * BSTR;
+            const u32 *tp = s_t + 1 + (lane & (CH - 1u)) * TSTR;
+            const int nlx = (int)pinned_copy32(0u); /* (opaque zero: the three reads at [nl] stay reads of their own) */
+#else
             const u32 *bp = s_b + 1 + myrow * BSTR + i0;
             const u32 *tp = s_t + 1 + seg * TSTR + (rev ? ND : 0) + W0;
+            const int nlx = nl;
+#endif
             const u32 fm = ~0u >> (2 * (X0 & 15)), lm = ~0u << (30 - 2 * ((X1 - 1) & 15));
             u32 bd[ND + 1], td[ND];
 #pragma unroll
@@ -1987,10 +2062,10 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
                 diff |= t < nl ? x : 0u;
             }
             { /* the last one, wherever it is */
-                const u32 x = __builtin_amdgcn_alignbit(bp[nl], bp[nl + 1], sh) ^ tp[nl];
+                const u32 x = __builtin_amdgcn_alignbit(bp[nlx], bp[nlx + 1], sh) ^ tp[nlx];
                 diff |= x & (nl == 0 ? (lm & fm) : lm);
             }
-#if defined(VERIFY_EXP_NOROWS) || defined(VERIFY_EXP_SHAREROWS)
+#if defined(VERIFY_EXP_NOROWS) || defined(VERIFY_EXP_SHAREROWS) || defined(VERIFY_EXP_NOCONFLICT)
             diff = 0;
 #endif
             const bool region_ok = act && diff == 0;
@@ -3218,12 +3293,6 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
 #ifndef SELECT_FLAT_WAVES_PER_SIMD
 #define SELECT_FLAT_WAVES_PER_SIMD 1
 #endif
-__device__ __forceinline__ u32 pinned_copy32(u32 x)
-{
-    u32 y;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
 /* SMALL (round 5): the kernel's time follows its resident waves (12 / 14 / 16 blocks per CU: 23.8 / 21.4 / 19.8 ms at 50 M reads), and what
  * held it at 16 were the two work arrays of the sequential path — sized for rows of ES_CAP hits that a read set of ordinary coverage
  * does not have — and a dozen registers. Where rows of more than 64 verified hits are rare (verify counts them: CTR_ES_MID) they go to

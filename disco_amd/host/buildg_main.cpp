@@ -150,6 +150,11 @@ int main(int argc, char **argv)
     std::cout << "Software: Disco Assembler BuildGraph, MI355X-native drop-in (disco_amd)\n";
     auto t_main = Clock::now();
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); /* hosts with dmabuf IPC only: RCCL's buffer sharing needs it; before any HIP call */
+    if (disco_abi_version() != DISCO_ABI_VERSION) { /* the struct layouts this file was compiled against are those of exactly one version */
+        std::cerr << "buildG: libdisco_hip.so speaks ABI version " << disco_abi_version() << ", this executable was built against " << DISCO_ABI_VERSION
+                  << " (include/disco_hip.h): rebuild both (python -m disco_amd.build)" << std::endl;
+        return 2;
+    }
     std::vector<std::string> pe, se;
     std::string prefix, cfg;
     int threads = omp_get_max_threads(), gpu = 0, gpus = 1;
@@ -687,10 +692,17 @@ int main(int argc, char **argv)
      * GB of device memory, its streams and events, the libraries' static state: 0.15-0.2 s at config 3 that produce nothing (the
      * driver takes everything back when the process ends, whichever way it ends). DISCO_ORDERLY_EXIT=1 keeps the long way (leak
      * checkers, tests that want the destructors to run). */
-    const bool orderly = getenv("DISCO_ORDERLY_EXIT") != nullptr;
-    if (orderly && ctx_releaser.joinable()) ctx_releaser.join();
+    /* round 6: the orderly way is the DEFAULT whenever somebody may be listening at exit — a profiler or tracer preloaded into the
+     * process (rocprofv3 / roctx write their output from atexit handlers and tool finalizers: `rocprofv3 --marker-trace -- buildG ...` of
+     * DESIGN.md section 1 lost its trace to the quick exit), LD_PRELOAD in general, coverage and sanitizer runtimes, DISCO_TRACE — and the
+     * releaser thread is JOINED before either exit: leaving through _exit while it sits inside disco_destroy / hipFree raced the runtime's
+     * own teardown. DISCO_QUICK_EXIT=1 forces the short way, DISCO_ORDERLY_EXIT=1 the long one. */
+    const bool tool_attached = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") || getenv("LD_PRELOAD") ||
+                               getenv("DISCO_TRACE") || getenv("GCOV_PREFIX") || getenv("ASAN_OPTIONS") || getenv("TSAN_OPTIONS") || getenv("UBSAN_OPTIONS");
+    const bool orderly = getenv("DISCO_ORDERLY_EXIT") != nullptr || (tool_attached && !getenv("DISCO_QUICK_EXIT"));
     std::cout << "Function saveParGraphToFile() finished in " << secs(t0) << " Seconds." << std::endl;
     std::cout << "Function main() finished in " << secs(t_main) << " Seconds." << std::endl;
+    if (ctx_releaser.joinable()) ctx_releaser.join(); /* (0.07 s of hipFree at config 3, nearly all of it behind the writers by now) */
     if (!orderly) {
         std::cout.flush();
         std::cerr.flush();

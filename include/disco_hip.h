@@ -29,7 +29,11 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 1
+/* 2 (round 6): disco_dist_info grew in the MIDDLE in round 5 (DISCO_X_COUNT 11 -> 14: every field behind bytes_sent[] moved) under the
+ * number 1; the number now says so, and buildG / disco_amd/buildgraph.py refuse a library whose number is not the header's they were
+ * written against. The bench / test-only entry points (synthetic reads, substitution errors, the two bandwidth probes) moved to
+ * include/disco_hip_test.h — same library, not part of what a BuildGraph host binds. */
+#define DISCO_ABI_VERSION 2
 
 enum {
     DISCO_OK = 0,
@@ -64,12 +68,6 @@ typedef struct disco_params {
                                     bases; pairs found from one side only are completed by the twin pass (order-dependent regime) */
 } disco_params;
 
-/* synthetic reads, see disco_amd/csrc/readgen.h (replaces bbmap/randomreads.sh for the BASELINE configs) */
-typedef struct disco_genspec_abi {
-    uint64_t seed, n_reads, contig_len;
-    uint32_t n_contigs, len_min, len_max, skew; /* skew bit 0: metagenome-like contig abundances; bits 1-15 / 16-31: length of a tail of
-                                                   long reads and their share of the reads in 1 / 65536 (csrc/readgen.h) */
-} disco_genspec_abi;
 
 /* one row of <prefix>_<t>_containedReads.txt (BG/OverlapGraph.cpp:438-447) in read ids */
 typedef struct disco_contained_row {
@@ -136,13 +134,6 @@ int disco_upload_reads(disco_ctx *ctx, const uint64_t *packed, uint32_t stride_w
 int disco_upload_reads_ragged(disco_ctx *ctx, const uint64_t *words, const uint16_t *len, uint64_t n);
 /* use reads that are already resident in HBM (caller-owned device pointers, must outlive the context's use) */
 int disco_adopt_reads(disco_ctx *ctx, const void *d_packed, uint32_t stride_words, const void *d_len, uint64_t n);
-/* generate synthetic reads directly in HBM (bench / tests) */
-int disco_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
-/* substitution errors into the resident reads, in place (bench / tests of the inexact-overlap extension): every base of this
- * context's reads — of the rank's own range in the multi-GPU flow — is replaced by another one with probability rate_ppm / 10^6,
- * a pure function of (seed, read, position) (csrc/readgen.h; numpy twin: disco_amd/readgen.py). Before disco_build_index; not on an
- * uploaded / ingested table that got two classes of rows (disco_long_rows: DISCO_E_UNSUPPORTED). */
-int disco_substitute_bases(disco_ctx *ctx, uint64_t seed, uint32_t rate_ppm);
 /* copy the packed reads / lengths back to the host (tests, writer) */
 int disco_download_reads(disco_ctx *ctx, uint64_t *packed, uint16_t *len);
 uint32_t disco_stride_words(const disco_ctx *ctx);
@@ -280,7 +271,6 @@ const char *disco_comm_kind(const disco_ctx *ctx);
 int disco_dist_range(const disco_ctx *ctx, uint64_t n_total, uint64_t *lo, uint64_t *hi);
 /* this rank's reads = rows [lo, hi) of the job's n_total reads (replaces the per-rank file pass of MPI/Dataset.cpp:153-170) */
 int disco_dist_upload_reads(disco_ctx *ctx, const uint64_t *packed_own, uint32_t stride_words, const uint16_t *len_own, uint64_t n_total);
-int disco_dist_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
 /* one whole pass; afterwards disco_fetch_edges / disco_fetch_contained / disco_fetch_edge_files return THIS rank's share */
 int disco_dist_run_graph(disco_ctx *ctx, uint32_t flags);
 int disco_dist_get_info(disco_ctx *ctx, disco_dist_info *out);
@@ -403,16 +393,6 @@ int disco_fetch_chains(disco_ctx *ctx, disco_chain_edge *comp, disco_chain_link 
 
 /* device-to-device copy on the context's stream (staging for caller-side collectives) */
 int disco_memcpy_d2d(disco_ctx *ctx, void *dst, const void *src, uint64_t bytes);
-/* attainable HBM bandwidth on this device (SURVEY.md §8d "Roofline that bounds the path": nominal AND measured): a
- * streaming copy kernel over two scratch buffers of `bytes` each, `reps` timed launches after one warm-up;
- * *gb_per_s = read + written bytes per second / 1e9 of the best launch. Measurement aid for bench.py, no reference
- * counterpart. */
-int disco_measure_hbm(disco_ctx *ctx, uint64_t bytes, int reps, double *gb_per_s);
-/* attainable bandwidth of the access pattern that dominates the path — one random, 64-byte aligned 64-byte row per lane
- * out of a table of `bytes` (the candidate-row fetch of verify, the bucket walk of probe): *gb_per_s = 64 B x rows
- * fetched per second / 1e9 of the best of `reps` launches. The ceiling the gather-bound kernels are priced against in
- * DESIGN.md, next to the nominal and the streaming figure. */
-int disco_measure_gather(disco_ctx *ctx, uint64_t bytes, int reps, double *gb_per_s);
 
 #ifdef __cplusplus
 }

@@ -23,10 +23,16 @@ for k, v in pmc.items():
         continue
     # (the scans also serve the grouping: rocprofv3's per-kernel sums cannot tell them apart — a few hundred MB either way)
     f, w = v.get("FETCH_SIZE", 0.0) * 1024.0, v.get("WRITE_SIZE", 0.0) * 1024.0
-    p = phases.setdefault(ph, {"fetch": 0.0, "write": 0.0, "kernels": []})
+    p = phases.setdefault(ph, {"fetch": 0.0, "write": 0.0, "kernels": [], "valu": 0.0, "salu": 0.0, "lds": 0.0, "lds_bank_conflict": 0.0})
     p["fetch"] += f
     p["write"] += w
     p["kernels"].append(k)
+    # round 6: the instruction side of the same profile — wave-level instructions per launch (SQ_INSTS_*: one count per wavefront
+    # instruction), and the extra LDS cycles bank conflicts cost — for the issue roofline of bench.py
+    p["valu"] += v.get("SQ_INSTS_VALU", 0.0)
+    p["salu"] += v.get("SQ_INSTS_SALU", 0.0)
+    p["lds"] += v.get("SQ_INSTS_LDS", 0.0)
+    p["lds_bank_conflict"] += v.get("SQ_LDS_BANK_CONFLICT", 0.0)
 for p in phases.values():
     p["lo"] = p["fetch"] + p["write"]        # FETCH_SIZE as counted (a pure 64-byte row gather calibrates at 1.014 x)
     p["hi"] = 2.0 * p["fetch"] + p["write"]  # ... doubled (a wide coalesced stream calibrates at 0.500 x)

@@ -8,11 +8,20 @@ from disco_amd import build, buildgraph
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    h = open(os.path.join(ROOT, "include", "disco_hip.h")).read()
-    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|int64_t|uint32_t|uint64_t|char)\s*\*?\s*(disco_\w+)\s*\(", h, flags=re.M)
+HEADERS = ("disco_hip.h", "disco_hip_test.h")  # the boundary a BuildGraph host binds; the bench / test-only entry points of the same library
+
+
+def declared_functions(headers=HEADERS):
+    names = []
+    for f in headers:
+        h = open(os.path.join(ROOT, "include", f)).read()
+        h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+        names += re.findall(r"^\s*(?:const\s+)?(?:int|void|int64_t|uint32_t|uint64_t|char)\s*\*?\s*(disco_\w+)\s*\(", h, flags=re.M)
     return sorted(set(names))
+
+
+def header_abi_version():
+    return int(re.search(r"^#define DISCO_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "disco_hip.h")).read(), flags=re.M).group(1))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -22,8 +31,44 @@ def test_library_builds_and_exports_every_declared_symbol():
     decl = declared_functions()
     assert len(decl) >= 30, decl
     missing = [n for n in decl if not hasattr(L, n)]
-    assert not missing, f"declared in disco_hip.h but not exported: {missing}"
-    assert L.disco_abi_version() == 1
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    # round 6: version 2 — disco_dist_info grew in the middle in round 5; library, header and the Python mirror carry ONE number, and the
+    # mirror / buildG refuse a library that answers another
+    assert L.disco_abi_version() == header_abi_version() == buildgraph.ABI_VERSION == 2
+
+
+def test_test_only_entry_points_live_in_their_own_header():
+    """what bench.py and the tests need beyond the reference's interface (synthetic reads, substitutions, bandwidth probes) is declared in
+    include/disco_hip_test.h, not in the boundary header a BuildGraph host binds"""
+    product, test_only = declared_functions(("disco_hip.h",)), declared_functions(("disco_hip_test.h",))
+    assert set(test_only) == {"disco_generate_reads", "disco_substitute_bases", "disco_dist_generate_reads", "disco_measure_hbm", "disco_measure_gather"}
+    assert not set(product) & set(test_only)
+    for host in ("buildg_main.cpp", "writer.cpp", "parsimple.cpp", "fastx.cpp"):  # the drop-in executable binds the product header only
+        txt = open(os.path.join(ROOT, "disco_amd", "host", host)).read()
+        assert "disco_hip_test.h" not in txt and not any(n + "(" in txt for n in test_only), host
+
+
+def test_dist_info_mirror_matches_the_header_layout(tmp_path):
+    """sizeof / offsetof of disco_dist_info as a C compiler lays it out == the ctypes mirror (the struct grew in the middle once: ADVICE r5)"""
+    import subprocess
+
+    src = tmp_path / "lay.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "disco_hip.h"
+int main(void)
+{
+    printf("%zu %zu %zu %zu %zu %zu %d\n", sizeof(disco_dist_info), offsetof(disco_dist_info, bytes_sent), offsetof(disco_dist_info, ms),
+           offsetof(disco_dist_info, ms_total), offsetof(disco_dist_info, hbm_peak), offsetof(disco_dist_info, placement), (int)DISCO_X_COUNT);
+    return 0;
+}
+''')
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.split()]
+    D = buildgraph.DistInfo
+    assert got == [ctypes.sizeof(D), D.bytes_sent.offset, D.ms.offset, D.ms_total.offset, D.hbm_peak.offset, D.placement.offset, len(buildgraph.XCHG)]
 
 
 def test_python_mirror_binds_the_same_set():

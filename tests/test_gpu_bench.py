@@ -49,6 +49,13 @@ def test_bench_line_has_the_contract_fields():
             assert k in e, (e["phase"], k)
     assert abs(sum(e["algorithmic_bytes_per_launch"] for e in entries) - d["config"]["algorithmic_bytes_per_step"]) < 1.0
     assert 0.2 < d["roofline_coverage_of_step"] <= 1.05
+    # round 6: the vector-issue roof beside the HBM one, per phase and for the pass. The instruction counts come from the stamped counter
+    # profile of the BENCHED workload (50 M reads): at this test's size the entry says so instead of quoting them
+    ri = d["roofline_issue"]
+    assert ri["bound"] == "valu_issue" and "source" in ri
+    assert ri["frac"] is None and "another workload" in ri["source"]
+    for e in entries:
+        assert "issue" in e and e["issue"] is None, e["phase"]
 
 
 def test_bench_stage_wall_through_the_drop_in_executable():
@@ -74,6 +81,8 @@ def test_bench_refuses_more_ranks_than_gpus():
 def test_bench_sharded_code_path_with_one_rank():
     d = _run(["--force-distributed", "--no-cpu-baseline"])
     assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["config"]["e_out"] > 0
+    # the RCCL transport itself, not the in-process stand-in (a silent fall-back to LoopComm would keep everything else green)
+    assert d["config"]["exchanges_rank0"]["transport"] == "rccl", d["config"]["exchanges_rank0"]
 
 
 def test_bench_illumina_like_variant():

@@ -7,7 +7,7 @@ import pytest
 from disco_amd import readgen
 from tests import golden_util as gu
 from tests.dist_util import run_ranks, run_ranks_reads
-from tests.util import canon_hip, run_hip_reads
+from tests.util import canon_hip, run_hip_reads, run_oracle_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,29 @@ def test_ranks_equal_reference(name, G):
         assert sum(i["bytes_sent"]["index_records"] for i in infos) > 0
         assert sum(i["bytes_sent"]["row_data"] for i in infos) > 0
         assert sum(i["bytes_sent"]["keys"] for i in infos) > 0
+
+
+@pytest.mark.parametrize("name,G,extra", [("u150_5k", 2, {}), ("mixed_4k", 3, {}), ("contigs_20k", 8, {}), ("k30_6k", 4, {}), ("contigs_20k", 4, {"DISCO_DIST_ONE_COMM": "1"}),
+                                          ("contigs_20k", 3, {"DISCO_DIST_KEYS_ON_PATH": "1"}), ("mixed_4k", 4, {"DISCO_DIST_ID_RANGES": "1"}),
+                                          ("repeats_8k", 3, {}), ("u150_5k", 4, {"DISCO_DIST_PARTITIONED_INDEX": "1"})])
+def test_ranks_without_host_waits_in_the_transport(name, G, extra, monkeypatch):
+    """DISCO_LOOP_ASYNC=1 (round 6): the in-process transport enqueues its exchanges on the ranks' streams with events between them and
+    never waits for a device — RCCL's behaviour. Rounds 4-5 took host waits out of the flow (no sync behind an all-to-all, counts derived
+    instead of exchanged, two communicators at once) and the blocking transport could not see a missing stream dependency; this one
+    does: the same fixtures, two passes, the reference's digests"""
+    monkeypatch.setenv("DISCO_LOOP_ASYNC", "1")
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G, passes=2)
+    ce, cc = canon_hip(edges, rows, fidx)
+    if name == "repeats_8k":  # outside the reference's parity domain (the cap binds): the oracle is the checker
+        oe, orows, _ = run_oracle_reads(reads, mo, count_hits=False)
+        oce, occ = canon_hip(oe, orows, fidx)
+        assert np.array_equal(ce, oce) and np.array_equal(cc, occ)
+    else:
+        gu.check_against_golden(name, ce, cc)
+    assert info["world"] == G
 
 
 @pytest.mark.parametrize("name,G", [("u150_5k", 3), ("mixed_4k", 4), ("contigs_20k", 8), ("long_2k", 2)])
