@@ -393,8 +393,11 @@ def main():
         g.synchronize()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    first_pass_info = None
+    for w in range(args.warmup):
         step()
+        if sharded and w == 0:  # the first pass of a multi-rank context waits behind every exchange (first contact): its table shows the exchanges themselves
+            first_pass_info = g.dist_info()
         kick()
     kern_ms = {k: [] for k in PHASE_KERNELS}
     fence()
@@ -524,7 +527,12 @@ def main():
         out["config"]["exchanges_rank0"] = {"regime": {0: "regular", 2: "regular after twin completion across ranks"}.get(info["regime"], "order-dependent (adjacency gathered)"),
                                             "transport": g.transport, "tr_rounds": info["tr_rounds"], "tr_deferred": info["tr_deferred"],
                                             "bytes_sent": info["bytes_sent"], "ms": {k: round(v, 3) for k, v in info["ms"].items()},
-                                            "ms_pass": round(info["ms_total"], 3)}
+                                            "ms_pass": round(info["ms_total"], 3),
+                                            "ms_is": "host time to ISSUE each exchange in the last timed pass (stream ordered: nothing waits behind them)"}
+        if first_pass_info is not None:
+            out["config"]["exchanges_rank0"]["first_pass_ms"] = {k: round(v, 3) for k, v in first_pass_info["ms"].items()}
+            out["config"]["exchanges_rank0"]["first_pass_ms_is"] = ("the untimed first (warm-up) pass waits behind every all-to-all on multi-rank RCCL: the exchanges "
+                                                                    "themselves, link time included (DISCO_DIST_NO_FIRST_CONTACT=1 takes the waits away)")
     g.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

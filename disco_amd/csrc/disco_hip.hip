@@ -410,6 +410,11 @@ struct disco_ctx {
     hipEvent_t ev_keys = nullptr, ev_keys_go = nullptr;
     bool keys_pending = false;
     disco_dist_info dinfo{};
+    /* wait behind every all-to-all so that dinfo.ms shows the exchange and not its issue: DISCO_DIST_TIME_EXCHANGES=1, and — first contact
+     *  — the FIRST pass of a context over RCCL with more than one rank (the pass a bench warms up with, the pass a watchdog
+     * report is about: a stall then names the exchange it sits in); DISCO_DIST_NO_FIRST_CONTACT=1 takes that away */
+    bool time_exchanges = false;
+    unsigned dist_passes = 0;
 };
 
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -579,7 +584,7 @@ static int wave_grid(const disco_ctx *c, u64 items, int per_cu = 24)
 template <typename K>
 static int wq_grid(disco_ctx *c, K kernel, u64 items, const char *env, int cap = 32)
 {
-    (void)hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream);
+    (void)hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
     if (per_cu > cap) per_cu = cap;
@@ -1116,7 +1121,7 @@ int disco_create(int device, const disco_params *p, disco_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_ctr, sizeof(u64) * CTR_COUNT));
     CREATE_CHK(hipMemset(c->d_ctr, 0, sizeof(u64) * CTR_COUNT));
     CREATE_CHK(hipMalloc((void **)&c->d_total, sizeof(u64)));
-    CREATE_CHK(hipMalloc((void **)&c->d_wq, sizeof(u64)));
+    CREATE_CHK(hipMalloc((void **)&c->d_wq, sizeof(u64) * WQ_WORDS)); /* (WQ_NQ sub-queues, a 128-byte slot each: wq_grab_split) */
     CREATE_CHK(hipMalloc((void **)&c->d_bump, sizeof(u64)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_big, sizeof(u32)));
     CREATE_CHK(hipMalloc((void **)&c->d_n_slow, sizeof(u32)));
@@ -2393,7 +2398,7 @@ int disco_probe(disco_ctx *c)
         c->order_q_lo = c->q_lo; /* (the range the order in d_order_used belongs to: later phases of the pass walk it too) */
         c->order_q_hi = c->q_hi;
         ph_begin(c, DISCO_PH_PROBE_KERNEL);
-        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
         const bool partitioned = c->dist_active && c->part_index; /* the lookups travel to the buckets' owners (collective) */
         if (partitioned) CHK(dist_partitioned_probe(c));
         else if (nq) {
@@ -2410,7 +2415,7 @@ int disco_probe(disco_ctx *c)
         if (partitioned) c->h_ctr[CTR_HITS_NEEDED] = c->hits_used;
         if (!c->h_ctr[CTR_OVERFLOW] && n_slow) { /* reads without a usable run list, the long way (they may add big rows) */
             int g2 = wave_grid(c, (n_slow + WQ_CHUNK - 1) / WQ_CHUNK, 24);
-            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             launch_probe(a, 2, g2);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(&n_big, c->d_n_big, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -2419,7 +2424,7 @@ int disco_probe(disco_ctx *c)
         if (!partitioned) c->slow_rows = n_slow;
         if (!c->h_ctr[CTR_OVERFLOW] && n_big) {
             int g2 = wave_grid(c, (n_big + WQ_CHUNK - 1) / WQ_CHUNK, 8);
-            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             launch_probe(a, 1, g2);
             HIPCHK(c, hipGetLastError());
             CHK(read_counters(c));
@@ -2500,8 +2505,9 @@ int disco_probe(disco_ctx *c)
                 const char *vce = getenv("DISCO_VERIFY_CACHE");
                 const bool vcache = vce ? atoi(vce) != 0 : true;
                 /* (round 5: 128 registers and 10 KB of LDS hold sixteen blocks per CU; 12 / 14 / 16 resident: 22.8 / 21.5 / 22.0 ms — the rows of
-                 * sixteen blocks' pairs no longer share the L2 as well) */
-                if (flat && vcache && c->max_len <= 160) hipLaunchKernelGGL((verify_flat_kernel<5, 0, true>), dim3(wq_grid(c, verify_flat_kernel<5, 0, true>, nq, "DISCO_VERIFY_WAVES", 14)), dim3(64), 0, c->stream, va);
+                 * sixteen blocks' pairs no longer shared the L2 as well. Round 6: with the work queue split by XCD (wq_grab_split: an XCD's waves
+                 * work through one contiguous eighth of the processing order) 12 / 14 / 16: 22.7 / 20.8 / 19.8 ms — all sixteen) */
+                if (flat && vcache && c->max_len <= 160) hipLaunchKernelGGL((verify_flat_kernel<5, 0, true>), dim3(wq_grid(c, verify_flat_kernel<5, 0, true>, nq, "DISCO_VERIFY_WAVES", 16)), dim3(64), 0, c->stream, va);
                 else if (flat && vcache) hipLaunchKernelGGL((verify_flat_kernel<8, 0, true>), dim3(wq_grid(c, verify_flat_kernel<8, 0, true>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat && c->max_len <= 160) hipLaunchKernelGGL(verify_flat_kernel<5>, dim3(wq_grid(c, verify_flat_kernel<5>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
                 else if (flat) hipLaunchKernelGGL(verify_flat_kernel<8>, dim3(wq_grid(c, verify_flat_kernel<8>, nq, "DISCO_VERIFY_WAVES")), dim3(64), 0, c->stream, va);
@@ -2664,11 +2670,11 @@ static int select_edges(disco_ctx *c)
     if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_CAPACITY, "edge selection: big-row list overflow (%u rows)", n_big);
     if (n_big) { /* rows of up to ES_MID hits: LDS arrays of their own (the five-wave variant lists rows of 65 .. ES_CAP hits too: a pass with small arrays first) */
         if (select_small) {
-            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             hipLaunchKernelGGL(edge_select_mid_kernel<ES_CAP>, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, a, 0u);
         }
         if (!select_small || c->h_ctr[CTR_ES_BIG]) {
-            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             hipLaunchKernelGGL(edge_select_mid_kernel<ES_MID>, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 8)), dim3(64), 0, c->stream, a, select_small ? (u32)ES_CAP : 0u);
         }
         HIPCHK(c, hipGetLastError());
@@ -2681,7 +2687,7 @@ static int select_edges(disco_ctx *c)
         CHK(dev_alloc(c, &scratch, (u64)g2 * 2 * cap));
         a.scratch = scratch;
         a.scratch_cap = cap;
-        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
         hipLaunchKernelGGL(edge_select_kernel<true>, dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
         int rc = read_counters(c);
@@ -3112,7 +3118,7 @@ int disco_transitive_mark(disco_ctx *c)
         CHK(dev_alloc(c, &scratch, (u64)g2 * per));
         a.scratch = (u64 *)scratch;
         a.hcap = hcap;
-        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
         hipLaunchKernelGGL((transitive_mark_kernel<true, false>), dim3(g2), dim3(64), 0, c->stream, a);
         hipError_t e = hipGetLastError();
         const int rc2 = read_counters(c); /* synchronises; the big pass may have raised CTR_OVERFLOW */
@@ -3184,7 +3190,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
         a.bump = c->d_bump;
         a.local_only = c->dist_active ? 1u : 0u;
         a.own = own_set(c);
-        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
         if (nq && !(listed && c->n_wide == 0)) hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(64), 0, c->stream, a);
         if (n_push) {
             EmitRecvArgs pr;
@@ -3199,7 +3205,7 @@ int disco_emit_edges(disco_ctx *c, uint64_t *n_out)
             pr.out_cap = c->out_cap;
             pr.bump = c->d_bump;
             pr.wq = c->d_wq;
-            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             hipLaunchKernelGGL(emit_push_recv_kernel, dim3(grid_push), dim3(64), 0, c->stream, pr);
         }
         HIPCHK(c, hipGetLastError());
@@ -4178,7 +4184,7 @@ static int a2a_items(disco_ctx *c, int xid, const void *send, const std::vector<
     COMM_CHK(c, c->comm->all_to_all_v(send, so.data(), sc.data(), recv, ro.data(), rc.data(), c->stream));
     /* (stream ordered: whoever consumes the received blocks runs behind them on this stream. DISCO_DIST_TIME_EXCHANGES=1 waits here, so that
      * dinfo.ms shows the exchange itself and not the time to issue it) */
-    if (getenv("DISCO_DIST_TIME_EXCHANGES")) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->time_exchanges) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dinfo.ms[xid] += ms_since(t0);
     return DISCO_OK;
 }
@@ -4831,7 +4837,7 @@ static int dist_transitive_mark(disco_ctx *c)
             a.scratch = (u64 *)scratch;
             a.hcap = hcap;
             a.nadj32 = c->d_nadj32_own; /* the store may have moved */
-            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             hipLaunchKernelGGL((transitive_mark_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
             hipError_t e = hipGetLastError();
             int rc = read_counters(c);
@@ -5272,7 +5278,11 @@ static int dist_run_graph_impl(disco_ctx *c, uint32_t flags)
 
 int disco_dist_run_graph(disco_ctx *c, uint32_t flags)
 {
+    if (c && c->comm)
+        c->time_exchanges = getenv("DISCO_DIST_TIME_EXCHANGES") != nullptr ||
+                            (c->dist_passes == 0 && c->comm->world > 1 && !strcmp(c->comm->kind(), "rccl") && !getenv("DISCO_DIST_NO_FIRST_CONTACT"));
     const int rc = dist_run_graph_impl(c, flags);
+    if (c) c->dist_passes++;
     if (rc != DISCO_OK && c && c->comm && rc != DISCO_E_ARG && rc != DISCO_E_STATE) {
         /* this rank leaves the pass early: whoever waits for it inside a collective must not wait forever */
         c->comm->abort();

@@ -132,6 +132,44 @@ __device__ __forceinline__ bool wq_grab_multi(u64 *counter, u64 n, u64 &beg, u64
     return true;
 }
 
+/* round 6: the queue as WQ_NQ sub-queues, one counter each in a 128-byte slot of its own. The one address of wq_grab serves a returning
+ * atomic per 12.3 ns: with 32 reads per grab (verify) that unit alone needs 19 of the kernel's 21.7 ms (an EMPTY verify — no candidate
+ * touched — still took 18.9 ms: gpurun_out r6_run6; with four chunks per atomic 4.8), so every wave stands in line for it. Sub-queue q
+ * covers the q-th of WQ_NQ contiguous ranges of the chunks; a workgroup starts at sub-queue blockIdx % WQ_NQ (workgroups go to the eight
+ * XCDs in turn: an XCD's waves work through one contiguous eighth of the processing order and its L2 sees that eighth's rows) and moves
+ * on to the next one when its own is exhausted — every chunk is handed out exactly once, the tail is shared by everybody. No register
+ * lives across chunks but the sub-queue's number. Counters: wq[16 q]; the host clears all of them (WQ_WORDS). */
+#define WQ_NQ 8u
+#define WQ_WORDS (16u * WQ_NQ)
+struct WqSplit {
+    u32 qi = 0; /* sub-queues this wave has left behind (wave uniform) */
+};
+template <u32 CHUNK = WQ_CHUNK>
+__device__ __forceinline__ bool wq_grab_split(u64 *counters, u64 n, u64 &beg, u64 &end, WqSplit &st)
+{
+    /* (32-bit chunk arithmetic: a launch has fewer than 2^32 chunks; one vector register for the atomic's result) */
+    const u32 nchunks = (u32)((n + CHUNK - 1u) / CHUNK);
+    const u32 per = (nchunks + WQ_NQ - 1u) / WQ_NQ; /* chunks of a sub-queue (the last ones may hold fewer) */
+    while (st.qi < WQ_NQ) {
+        const u32 q = ((u32)blockIdx.x + st.qi) % WQ_NQ;
+        const u32 first = q * per;
+        const u32 mine = first < nchunks ? (nchunks - first < per ? nchunks - first : per) : 0u;
+        u32 b = mine; /* (an empty sub-queue is not asked) */
+        if (mine) {
+            u32 t = 0;
+            if ((threadIdx.x & 63) == 0) t = atomicAdd((u32 *)&counters[16u * q], 1u);
+            b = uniform_u32(t);
+        }
+        if (b < mine) {
+            beg = (u64)(first + b) * CHUNK;
+            end = beg + CHUNK < n ? beg + CHUNK : n;
+            return true;
+        }
+        st.qi++;
+    }
+    return false;
+}
+
 struct DiscoView {
     const u64 *reads; /* [n][S] */
     const u16 *len;   /* [n]    */
@@ -1127,7 +1165,12 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
     u32 my_maxrow = 0;
     for (u32 x = lane; x < PR_MARKCAP / 8; x += 64) ((u64 *)s_mark)[x] = 0ull;
     u64 cbeg = 0, cend = 0;
+#if defined(WQ_SPLIT_ALL)
+    WqSplit wqs;
+    while (wq_grab_split(a.v.wq, nq, cbeg, cend, wqs)) {
+#else
     while (wq_grab(a.v.wq, nq, cbeg, cend)) {
+#endif
         const u64 ci = min(cbeg + lane, cend - 1);
         const u64 ord_chunk = a.order ? a.order[ci] : ORDER_MAKE(a.v.q_lo + ci, a.v.len[a.v.q_lo + ci]);
         if (a.v.full) { /* two classes of rows: the chunk's long reads go to the list pass — ONE counting atomic per chunk (one per read, on the one
@@ -1828,8 +1871,11 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
     u32 *const s_lid = s_hid;
     const u32 lane = threadIdx.x;
     const int k = a.v.k;
-    u64 my_khits = 0, my_raw = 0;
-    u32 my_big = 0, my_mid = 0; /* rows of more than ES_CAP / 64 verified hits, this wavefront's */
+    /* the wavefront's counters as SCALARS (round 6: six vector registers of per-lane accumulators in a kernel that lives at the edge of
+     * its 128): k-mer hits by ballot + population count per batch; verified hits and the rows of more than ES_CAP / 64 of them from the
+     * chunk's counts (s_nk), once per chunk */
+    u64 w_khits = 0, w_raw = 0;
+    u32 w_big = 0, w_mid = 0;
     u64 cbeg = 0, cend = 0;
     if (CACHE) {
         s_lid[lane] = 0u;
@@ -1843,7 +1889,15 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
         const bool contain = (HIT_SUFFIX(h) == HIT_REV(h)) ? (LA - j >= LB) : (j + k - LB >= 0);
         return MODE == 1 ? contain : (!contain && j >= 1);
     };
+#if defined(VF_GRAB_MULT) /* experiment: VF_GRAB_MULT chunks per atomic of the work queue (its one address serves a returning atomic per 12.3 ns) */
+    u64 gnext = 0, gend = 0;
+    while (wq_grab_multi<CH, VF_GRAB_MULT>(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend, gnext, gend)) {
+#elif defined(WQ_EXP_ONE_QUEUE)
     while (wq_grab<CH>(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
+#else
+    WqSplit wqs;
+    while (wq_grab_split<CH>(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend, wqs)) {
+#endif
         const u32 n = (u32)(cend - cbeg);
         const u64 ci = cbeg + (lane < n ? lane : 0u);
         const u64 ordw = a.order ? a.order[ci] : a.v.q_lo + ci;
@@ -1887,7 +1941,11 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
         }
         __syncthreads();
 
+#if defined(VERIFY_EXP_NOBATCH) /* timing experiment (results are wrong): the chunk's fixed part alone — grab, headers, own rows, reverse complements */
+        const u32 nb = 0;
+#else
         const u32 nb = (C + 63u) >> 6;
+#endif
         u32 sscan = 0; /* wave uniform (kept in a scalar register: readfirstlane): the last segment that starts at or before the first lane of the next batch to be located */
         /* flat index (clamped to the chunk's last candidate: idle lanes repeat it, a line the wave touches anyway) and segment of this
          * lane in batch b: a scalar walk over the segment starts inside the batch */
@@ -2089,7 +2147,7 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
                     kmer_ok = at_start ? fpos >= X0 + k : lpos < X1 - k;
                 }
             }
-            if (kmer_ok) my_khits++;
+            w_khits += (u32)__popcll(__ballot(kmer_ok));
             bool ov = false;
             if (region_ok) {
                 if (contain && CONTAIN_KEY_HIT(prefix_align) && (LA > LB || (LA == LB && Aseg < B))) atomicMin(&a.best[B], CKEY_MAKE(Aseg, j, suf, rev));
@@ -2111,10 +2169,7 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
                 const bool last = valid && (64u * b + lane - Pseg == cseg - 1u); /* the segment ends on this lane */
                 if (last) {
                     s_nk[seg] = kept;
-                    my_raw += kept;
                     if (cseg > 64u) a.row_cnt[Aseg] = kept; /* (rows of up to 64 candidates have no entry there: probe_kernel) */
-                    my_big += kept > ES_CAP ? 1u : 0u; /* (per wavefront, added once at the end: see verify_kernel) */
-                    my_mid += kept > 64u ? 1u : 0u;
                 }
                 carry = (u32)__builtin_amdgcn_readlane((int)(last ? 0u : kept), 63);
             }
@@ -2211,25 +2266,29 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
                 locate(b + 5, sg1B, ftmp);
                 h1B = load_cand(sg1B, ftmp);
                 __syncthreads();
+#if defined(VERIFY_EXP_NOCOMPUTE) /* timing experiment (results are wrong): candidates, fetch decisions, row fetches and staging without the compare */
+                w_khits += (u32)__popcll(__ballot(((hA ^ hB ^ segA ^ segB ^ rowA ^ rowB) & 1ull) != 0));
+#else
                 compute(b, hA, segA, rowA);
                 if (b + 1u < nb) compute(b + 1u, hB, segB, rowB);
+#endif
             }
         }
         __syncthreads();
         /* the counts of the whole chunk in one coalesced store: {row start, verified hits | length << 32} by position in the order */
-        if (MODE != 1 && lane < n) a.meta_ord[cbeg + lane].y = (u64)s_nk[lane] | (meta.y & 0xFFFFFFFF00000000ull);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        my_khits += __shfl_down(my_khits, o);
-        my_raw += __shfl_down(my_raw, o);
-        my_big += (u32)__shfl_down((int)my_big, o);
-        my_mid += (u32)__shfl_down((int)my_mid, o);
+        if (MODE != 1) {
+            const u32 nk = lane < n ? s_nk[lane] : 0u; /* (n <= CH) */
+            if (lane < n) a.meta_ord[cbeg + lane].y = (u64)nk | (meta.y & 0xFFFFFFFF00000000ull);
+            w_raw += (u32)__builtin_amdgcn_readlane((int)wave_inclusive_add(nk), 63);
+            w_big += (u32)__popcll(__ballot(nk > ES_CAP)); /* (sizes edge selection's big-row list: no counting pass in front of it; added once per wavefront) */
+            w_mid += (u32)__popcll(__ballot(nk > 64u));
+        }
     }
     if (lane == 0) {
-        if (my_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], my_khits);
-        if (my_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], my_raw);
-        if (my_big) atomicAdd(&a.v.ctr[CTR_ES_BIG], (u64)my_big);
-        if (my_mid) atomicAdd(&a.v.ctr[CTR_ES_MID], (u64)my_mid);
+        if (w_khits) atomicAdd(&a.v.ctr[CTR_KMER_HITS], w_khits);
+        if (w_raw) atomicAdd(&a.v.ctr[CTR_RAW_HITS], w_raw);
+        if (w_big) atomicAdd(&a.v.ctr[CTR_ES_BIG], (u64)w_big);
+        if (w_mid) atomicAdd(&a.v.ctr[CTR_ES_MID], (u64)w_mid);
     }
 }
 
@@ -3318,7 +3377,12 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
     u32 cap_sites = 0, dropped = 0, n_slow = 0;
     u64 n_edges = 0, tr_wide = 0;
     u64 cbeg = 0, cend = 0;
+#if defined(WQ_SPLIT_ALL)
+    WqSplit wqs;
+    while (wq_grab_split(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend, wqs)) {
+#else
     while (wq_grab(a.v.wq, a.v.q_hi - a.v.q_lo, cbeg, cend)) {
+#endif
         const u32 n = (u32)(cend - cbeg);
         const u64 ci = cbeg + (lane < n ? lane : 0u);
         const u64 ordw = a.order ? a.order[ci] : a.v.q_lo + ci;
@@ -4304,7 +4368,12 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
             r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
         }
     };
+#if defined(WQ_SPLIT_ALL)
+    WqSplit wqs;
+    while (BIG ? wq_grab<1>(a.v.wq, n_items, cbeg, cend) : wq_grab_split(a.v.wq, n_items, cbeg, cend, wqs)) { /* big nodes: one per grab */
+#else
     while (BIG ? wq_grab<1>(a.v.wq, n_items, cbeg, cend) : wq_grab(a.v.wq, n_items, cbeg, cend)) { /* big nodes: one per grab */
+#endif
     if (BIG) {
         for (u64 it = cbeg; it < cend; it++) {
             const u64 v = a.big_list[it];

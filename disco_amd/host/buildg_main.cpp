@@ -13,7 +13,10 @@
  */
 #include <omp.h>
 
+#include <sys/prctl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -234,6 +237,39 @@ int main(int argc, char **argv)
     if (gc) { /* BG/main.cpp:48-52 */
         std::cout << "Graph already exists. Using previously built graph...\nExiting graph construction." << std::endl;
         return 0;
+    }
+    /* ---- buildG --gpus N: a launcher that never touches the GPU, and the stage as its child (round 6) --------------------------------
+     * Matches the role of mpirun in front of buildG-MPI (MPI/main.cpp:29-37; runDisco-MPI.sh:214-258): the process the user started owns
+     * no device state, so it can start the stage again. When the stage's watchdog ends it (exit 3: no rank moved for DISCO_WATCHDOG_S
+     * seconds — on first contact with a node that most likely means the two communicators of a context did not progress side by side),
+     * the launcher starts ONE fresh child with DISCO_DIST_ONE_COMM=1 (every exchange on one communicator, one stream: the conservative
+     * mode) before giving up. Never a re-exec of a process that has initialised the GPU; nothing was written that a second try could
+     * trip over (the files appear after the pass, the checkpoint's GC=Complete line last). DISCO_NO_RETRY=1: one try only. */
+    if (gpus > 1 && !getenv("DISCO_BUILDG_CHILD")) {
+        std::cout.flush();
+        auto run_child = [&](const char *attempt, bool one_comm) -> int {
+            const pid_t pid = fork(); /* (single-threaded up to here: no thread pool, no GPU runtime thread) */
+            if (pid < 0) return -1;
+            if (pid == 0) {
+                prctl(PR_SET_PDEATHSIG, SIGTERM); /* the stage does not outlive its launcher */
+                setenv("DISCO_BUILDG_CHILD", attempt, 1);
+                if (one_comm) setenv("DISCO_DIST_ONE_COMM", "1", 1);
+                execv("/proc/self/exe", argv);
+                perror("buildG: execv");
+                _exit(127);
+            }
+            int st = 0;
+            while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {
+            }
+            return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        };
+        int rc = run_child("1", false);
+        if (rc == 3 && !getenv("DISCO_NO_RETRY") && !getenv("DISCO_DIST_ONE_COMM")) {
+            std::cout << "\nThe multi-GPU stage made no progress and was ended by its watchdog; starting it ONCE more with one communicator "
+                         "(DISCO_DIST_ONE_COMM=1)." << std::endl;
+            rc = run_child("2", true);
+        }
+        return rc < 0 ? die("fork failed") : rc;
     }
 
     /* ---- reads -------------------------------------------------------------------------------------------------- */
@@ -508,7 +544,8 @@ int main(int argc, char **argv)
          * DISCO_WATCHDOG_S seconds (default 900; 0: off) — a collective one rank never entered, a link that went away — the process says
          * where every rank stands and exits non-zero. Never a re-exec, never a silent hang: runDisco.sh does not check the status, but
          * the missing GC=Complete line makes the next run start over. */
-        static const char *const kStage[] = {"start", "disco_comm_init", "disco_dist_upload_reads", "disco_dist_run_graph", "disco_fetch_contained", "disco_fetch_edges", "done"};
+        static const char *const kStage[] = {"start", "disco_comm_init", "disco_dist_upload_reads", "front of disco_dist_run_graph (never entered it)", "disco_dist_run_graph",
+                                             "disco_fetch_contained", "disco_fetch_edges", "done"};
         std::vector<std::atomic<int>> stage((size_t)gpus);
         for (auto &st : stage) st.store(0);
         std::atomic<bool> ranks_done{false};
@@ -564,15 +601,18 @@ int main(int argc, char **argv)
                     if (disco_dist_upload_reads(c, own.data(), rs.stride_words, rs.len.data() + lo, rs.size()) < 0) bail("disco_dist_upload_reads");
                 }
                 at(3);
-                if (getenv("DISCO_TEST_STALL_RANK") && atoi(getenv("DISCO_TEST_STALL_RANK")) == r) /* (tests: a rank that never enters the pass) */
+                /* (tests: a rank that never enters the pass; DISCO_TEST_STALL_FIRST_TRY: in the launcher's first child only) */
+                if (getenv("DISCO_TEST_STALL_RANK") && atoi(getenv("DISCO_TEST_STALL_RANK")) == r &&
+                    (!getenv("DISCO_TEST_STALL_FIRST_TRY") || !getenv("DISCO_BUILDG_CHILD") || !strcmp(getenv("DISCO_BUILDG_CHILD"), "1")))
                     for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+                at(4);
                 if (disco_dist_run_graph(c, DISCO_DIST_GATHER_READS | (partitioned_index ? DISCO_DIST_KEEP_INDEX_PARTITIONED : 0)) < 0) bail("disco_dist_run_graph");
                 if (disco_dist_get_info(c, &R.info) < 0) bail("disco_dist_get_info");
                 if (verbose && r == 0) fprintf(stderr, "[disco host] transport %s, %d ranks\n", disco_comm_kind(c), gpus);
-                at(4);
+                at(5);
                 R.rows.resize(R.info.n_contained_local);
                 if (R.info.n_contained_local && disco_fetch_contained(c, R.rows.data(), R.info.n_contained_local) < 0) bail("disco_fetch_contained");
-                at(5);
+                at(6);
                 R.n_edges = R.info.e_out_local;
                 R.edges.reset(new disco_edge[std::max<uint64_t>(R.n_edges, 1)]);
                 if (R.n_edges && disco_fetch_edges(c, R.edges.get(), R.n_edges) < 0) bail("disco_fetch_edges");
@@ -580,7 +620,7 @@ int main(int argc, char **argv)
                     R.subs.reset(new uint16_t[std::max<uint64_t>(R.n_edges, 1)]);
                     if (R.n_edges && disco_fetch_edge_substitutions(c, R.subs.get(), R.n_edges) < 0) bail("disco_fetch_edge_substitutions");
                 }
-                at(6);
+                at(7);
             });
         for (auto &t : th) t.join();
         ranks_done.store(true);

@@ -117,9 +117,34 @@ def test_buildg_multi_rank_watchdog_ends_a_stalled_stage(tmp_path):
     p = subprocess.run([os.path.join(BIN, "buildG"), "-se", se, "-f", prefix, "-p", str(cfg), "-t", "2", "--gpus", "2", "--same-device"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, env=env, timeout=120)
     assert p.returncode == 3, p.stdout
-    assert "no rank has made progress" in p.stdout and "rank 1 in disco_dist_run_graph" in p.stdout, p.stdout
+    # the stalled rank stands IN FRONT of the pass (it never entered it: ADVICE r5), the other one inside its first collective
+    assert "no rank has made progress" in p.stdout and "rank 1 in front of disco_dist_run_graph" in p.stdout and "rank 0 in disco_dist_run_graph" in p.stdout, p.stdout
+    # round 6: the launcher — a process that never touched the GPU — started the stage ONCE more with one communicator before giving up
+    assert p.stdout.count("no rank has made progress") == 2 and "starting it ONCE more with one communicator" in p.stdout, p.stdout
     assert time.time() - t0 < 60
     assert not os.path.exists(prefix + "_CheckpointInfo.txt") or "GC=Complete" not in open(prefix + "_CheckpointInfo.txt").read()
+
+
+@pytest.mark.gpu
+def test_buildg_launcher_retries_a_stalled_first_try_and_delivers(tmp_path):
+    """the first child stalls (DISCO_TEST_STALL_FIRST_TRY), its watchdog ends it, the launcher's second child — DISCO_DIST_ONE_COMM=1 — builds
+    the graph: exit 0, the reference's files"""
+    build.build_host()
+    c = gu.CASES["multifile"]
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text(f"MinOverlap4BuildGraph = {c['min_overlap']}\n")
+    prefix = str(tmp_path / "g")
+    pe = ",".join(os.path.join(gu.GOLD, f) for f in c["pe"])
+    se = ",".join(os.path.join(gu.GOLD, f) for f in c["se"])
+    env = dict(os.environ, DISCO_TEST_STALL_RANK="0", DISCO_TEST_STALL_FIRST_TRY="1", DISCO_WATCHDOG_S="2", DISCO_VERBOSE="1")
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-pe", pe, "-se", se, "-f", prefix, "-p", str(cfg), "-t", "2", "--gpus", "2", "--same-device"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, env=env, timeout=180)
+    assert p.returncode == 0, p.stdout
+    assert p.stdout.count("no rank has made progress") == 1 and "starting it ONCE more with one communicator" in p.stdout, p.stdout
+    edges = refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt")))
+    cont = refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt")))
+    gu.check_against_golden("multifile", edges, cont)
+    assert "GC=Complete" in open(prefix + "_CheckpointInfo.txt").read()
 
 
 @pytest.mark.gpu
