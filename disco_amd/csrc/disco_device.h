@@ -85,6 +85,16 @@ __host__ __device__ __forceinline__ void disco_map_type(u32 type, u32 len1, u32 
     }
 }
 
+/* the same map straight from a record's two bits, without a branch (the switch compiles to three nested exec-mask regions per hit: round 6).
+ * (suffix, rev) -> type -> orient: (0,0) -> 0 -> 3 ; (1,0) -> 1 -> 0 ; (1,1) -> 2 -> 2 ; (0,1) -> 3 -> 1, i.e. bit 1 = (suffix == rev),
+ * bit 0 = !suffix; the offset is j where suffix == rev (types 0, 2: ovl = len1 - j) and len1 - (k + j) otherwise */
+__host__ __device__ __forceinline__ void disco_map_hit(u32 is_suffix, u32 rev, u32 len1, u32 k, u32 j, u32 *orient, u32 *offset)
+{
+    const u32 same = (is_suffix ^ rev ^ 1u) & 1u;
+    *orient = (same << 1) | ((is_suffix ^ 1u) & 1u);
+    *offset = same ? j : len1 - (k + j);
+}
+
 /* twinEdgeOrientation, BG/OverlapGraph.cpp:770-784 */
 __host__ __device__ __forceinline__ u32 disco_twin_orient(u32 o) { return o == 0 ? 3u : (o == 3 ? 0u : o); }
 

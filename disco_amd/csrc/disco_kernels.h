@@ -3427,7 +3427,6 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
         u32 segH[NB]; /* their read of the chunk | valid << 6 */
         auto stageA = [&](const Sub &sb) {
             const u32 base = sb.base, end = sb.end, r0 = sb.r0;
-            u32 sscan = r0;
 #pragma unroll
             for (int i = 0; i < NB; i++) {
                 u32 f = base + 64u * (u32)i + lane;
@@ -3436,17 +3435,14 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
                 u64 addr = (cbeg & 0xFFFFull) + lane; /* nothing to load: some line of the hit buffer (it has more than 65536 slots) */
                 if (base + 64u * (u32)i < end) {      /* (wave uniform) */
                     f = valid ? f : end - 1u;
-                    u32 fl = base + 64u * (u32)i + 63u;
-                    fl = fl < end ? fl : end - 1u;
-                    seg = sscan;
-                    u32 s2 = (u32)__builtin_amdgcn_readfirstlane((int)sscan) + 1u;
-                    while (s2 < sb.r1) {
-                        const u32 Ps = (u32)__builtin_amdgcn_readlane((int)P, (int)s2);
-                        if (Ps > fl) break;
-                        seg = f >= Ps ? s2 : seg;
-                        s2++;
+                    /* the read of flat index f: the sub-chunk has at most ROWS of them — one compare per row start, no loop (round 6: the scalar
+                     * walk over the boundaries was a loop of cross-lane reads and branches per batch) */
+                    seg = r0;
+#pragma unroll
+                    for (u32 r = 1; r < (u32)ROWS; r++) {
+                        const u32 Ps = Pat(r0 + r < sb.r1 ? r0 + r : 64u); /* (rows beyond the sub-chunk: the chunk's total — never reached by f) */
+                        seg += (r0 + r < sb.r1 && f >= Ps) ? 1u : 0u;
                     }
-                    sscan = s2 - 1u;
                     const ulonglong2 hd = s_hdr[seg];
                     addr = hd.x + (u64)(f - (u32)hd.y);
                 }
@@ -3465,11 +3461,17 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
                 const u32 id = valid ? (u32)HIT_ID(h) : 0u;
                 const u32 LA = (u32)(s_hdr[seg].y >> 32);
                 u32 orient, off;
-                disco_map_type(disco_hit_type(HIT_SUFFIX(h), HIT_REV(h)), LA, k, HIT_J(h), &orient, &off);
+                disco_map_hit(HIT_SUFFIX(h), HIT_REV(h), LA, k, HIT_J(h), &orient, &off);
                 /* (the window's low 7 bits — all the row's cap test needs — ride along in seg1) */
                 ent1[i] = ADJ_MAKE(off, id, orient, HIT_LEN(h));
                 seg1[i] = segH[i] | ((HIT_J(h) & 127u) << 8);
+#if defined(SEL_EXP) && SEL_EXP == 4 /* timing experiment (results are wrong): without the gather of the destination's contained word */
+                CW1[i] = 0u;
+#elif defined(SEL_EXP) && SEL_EXP == 5 /* ... with the gathers coalesced (a word near the lane's own): what the pipeline costs when they all hit */
+                CW1[i] = ((const u32 *)a.contained)[(lane + 64u * (u32)i) & 1023u];
+#else
                 CW1[i] = ((const u32 *)a.contained)[id >> 5];
+#endif
             }
         };
         Sub sC = sub_from(0), sB = sub_from(sC.r1), sA = sub_from(sB.r1);
@@ -3491,6 +3493,15 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
             const u32 r0 = sC.r0, base = sC.base, end = sC.end;
             if (end == base) continue;
             const u32 nbat = (end - base + 63u) >> 6;
+#if defined(SEL_EXP) && SEL_EXP == 3 /* timing experiment (results are wrong): the load pipeline alone — hits, entries, contained words */
+            {
+                u32 acc = 0;
+#pragma unroll
+                for (int i = 0; i < NB; i++) acc ^= (u32)ent[i] ^ segm[i] ^ cwd[i];
+                if (acc == 0x12345u) a.hits[s_hdr[0].x] = acc;
+                continue;
+            }
+#endif
             __syncthreads();
             {
                 const uint4 z = make_uint4(0u, 0u, 0u, 0u), f = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -3514,20 +3525,27 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
                     const u32 jw = (segm[i] >> 8) & 127u;
                     const u32 off = ADJ_OFF(ent[i]);
                     u32 rank = 0;
-                    if (ok) {
-                        bool bad = false;
+                    bool dup = false;
+#if !defined(SEL_EXP) || SEL_EXP != 1
+                    { /* "no destination twice": a wave-uniform probe loop (one trip for nearly every entry) with the compare-and-swap predicated
+                       * — the divergent loop with its two exits cost a dozen scalar exec-mask instructions per trip (round 6) */
                         u32 idx = (id * 0x9E3779B1u) >> 25; /* SETW = 128 slots */
-                        for (;;) {
-                            const u32 old = atomicCAS(&s_set[rl * SETW + idx], 0xFFFFFFFFu, id);
-                            if (old == 0xFFFFFFFFu) break;
-                            if (old == id) { /* a second hit to this destination (BG/OverlapGraph.cpp:656): the consumption order decides */
-                                bad = true;
-                                break;
-                            }
+                        bool pend = ok;
+                        do {
+                            u32 old = 0xFFFFFFFFu;
+                            if (pend) old = atomicCAS(&s_set[rl * SETW + idx], 0xFFFFFFFFu, id);
+                            dup = dup || (pend && old == id); /* a second hit to this destination (BG/OverlapGraph.cpp:656): the consumption order decides */
+                            pend = pend && old != 0xFFFFFFFFu && old != id;
                             idx = (idx + 1u) & (SETW - 1u);
-                        }
+                        } while (__any(pend));
+                    }
+#endif
+                    if (ok) {
+                        bool bad = dup;
+#if !defined(SEL_EXP) || SEL_EXP != 1 /* (1: timing experiment, results wrong where a row has a destination twice or a k-mer over the cap: without the two tests) */
                         const u32 jold = atomicAdd(&s_jc[rl * 32u + (jw >> 2)], 1u << (8u * (jw & 3u)));
                         bad |= ((jold >> (8u * (jw & 3u))) & 0xFFu) >= a.max_per_kmer; /* (windows 128 apart share a counter: conservative) */
+#endif
                         if (bad) s_flag[rl] = 1u;
                         const u32 bold = atomicAdd(&s_bins[rl * 64u + (off >> 2)], 1u << (8u * (off & 3u)));
                         rank = (bold >> (8u * (off & 3u))) & 0xFFu;
@@ -3553,6 +3571,15 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
                 if (lane == r0 + r) nacc_me = tot;
             }
             __syncthreads();
+#if defined(SEL_EXP) && SEL_EXP == 2 /* timing experiment (results are wrong): rows leave unsorted — without steps 3 and 4 */
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+                if ((u32)i < nbat && (segm[i] & 64u)) {
+                    const u32 seg = segm[i] & 63u;
+                    a.hits[s_hdr[seg].x + (base + 64u * (u32)i + lane - (u32)s_hdr[seg].y)] = ent[i];
+                }
+            continue;
+#endif
             /* 3. entries to their bins' places (arrival order inside a bin); segm: read | go << 6 | arrival rank << 8 | bin size << 16 | first position << 24 */
 #pragma unroll
             for (int i = 0; i < NB; i++) {
@@ -4193,6 +4220,10 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     bool deferred = false;
     __syncthreads();
     u32 sent = 0;
+#if defined(TR_EXP) && TR_EXP == 2 /* timing experiment (results are wrong): the pipeline and the output alone — no hash, no sweeps */
+    sent = lane;
+    if (p0 != 0x123456789ull || p2 != 0x123456789ull) ht[lane] = 0u;
+#else
     if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
         const u32 id = (u32)ADJ_DST(e);
         u32 idx = tr_hash(id, hmask);
@@ -4203,12 +4234,16 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         }
         sent = idx;
     }
+#endif
     __syncthreads();
     /* BG/OverlapGraph.cpp:693-696: walk the list in order, sweeping only neighbours that are still INPLAY when their turn
      * comes. States only ever go INPLAY -> ELIMINATED, so "the next INPLAY slot after the one just swept, judged with the
      * states as they are now" is exactly the sequential loop — found with one ballot instead of one LDS read per slot. */
     int cur = -1;
     for (;;) {
+#if defined(TR_EXP) && TR_EXP >= 1 /* timing experiment (results are wrong): pipeline, hash build and output without the sweeps (2: without the hash too) */
+        if (p0 != 0x123456789ull || p2 != 0x123456789ull) break;
+#endif
         const bool inplay = (lane < d) && !(ht[sent] >> 31);
         u64 mk = __ballot(inplay);
         if (cur >= 0) mk &= ~((2ull << cur) - 1ull); /* slots after cur */
