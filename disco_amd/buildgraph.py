@@ -94,6 +94,7 @@ ABI = [
     ("disco_fetch_chains", C.c_int, [_P, _P, _P, _P]),
     ("disco_set_query_order", C.c_int, [_P, _P]),
     ("disco_get_query_order", C.c_int, [_P, C.POINTER(_P)]),
+    ("disco_probe_run_words", C.c_int, [_P]),
     ("disco_measure_hbm", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_measure_gather", C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("disco_comm_unique_id", C.c_int, [_P, C.c_size_t]),
@@ -435,6 +436,10 @@ class BuildGraph:
 
     def set_query_order(self, d_order_ptr: int):
         self._chk(self.L.disco_set_query_order(self._h, _P(d_order_ptr)))
+
+    def probe_run_words(self) -> int:
+        """32-bit words of minimizer runs per read the last index build left for the probe (16 / 32), or 0: round 2's probe"""
+        return int(self.L.disco_probe_run_words(self._h))
 
     def measure_hbm(self, nbytes: int = 4 << 30, reps: int = 5) -> float:
         """attainable HBM bandwidth in GB/s (read + write bytes of a streaming copy kernel)"""

@@ -154,6 +154,18 @@ __global__ void __launch_bounds__(256) read_keys_kernel(DiscoView v, u64 lo, u64
             const u32 h = roll.hash();
             best = min(best, q < nmm ? h : 0xFFFFFFFFu);
         }
+    } else if (v.m > 16) { /* any other length of two dwords: the same pass with the length as a run-time value */
+        const int m = v.m, nmm = L - m + 1;
+        MmerRoll<0> roll(p, v.S, m);
+        for (int q = 0; q < m - 1; ++q) roll.step();
+        int nmax = nmm;
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+        nmax = (int)uniform_u32((u32)nmax);
+        for (int q = 0; q < nmax; ++q) {
+            roll.step();
+            const u32 h = roll.hash();
+            best = min(best, q < nmm ? h : 0xFFFFFFFFu);
+        }
     } else {
         const int m = v.m, nmm = L - m + 1;
         const u64 mask = (1ull << (2 * m)) - 1ull;
@@ -915,8 +927,8 @@ __global__ void __launch_bounds__(256) pq_make_kernel(DiscoView v, const u32 *__
             const u32 si = atomicAdd(n_slow, 1u);
             if (si < slow_cap) slow[si] = (u32)ri;
         }
-        const u32 wend0 = v1 ? (e1 >> 6) : npos;
-        const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? (nx >> 6) : npos;
+        const u32 wend0 = v1 ? RUN_W(e1) : npos;
+        const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? RUN_W(nx) : npos;
         const u64 m0 = __ballot(v0), m1 = __ballot(v1);
         const u32 cnt = (u32)__popcll(m0) + (u32)__popcll(m1);
         if (cnt == 0) continue;
@@ -928,7 +940,7 @@ __global__ void __launch_bounds__(256) pq_make_kernel(DiscoView v, const u32 *__
         const u64 pos = wbase + (u32)__popcll(m0 & lt) + (u32)__popcll(m1 & lt);
         const u64 *row = v.reads + A * v.S;
         auto emit = [&](u64 where, u32 en, u32 wend) {
-            const u32 wstart = en >> 6, delta = (en >> 1) & 31u, rev = en & 1u;
+            const u32 wstart = RUN_W(en), delta = RUN_DELTA(en), rev = RUN_STRAND(en);
             const u64 key = mmer_key(row, v.S, (int)(wstart + delta), v.m);
             out[where] = make_ulonglong2(((key >> v.bshift) << 32) | (u64)(u32)ri, PQ_Y(my_rank, KEY_FP(key), rev, delta, wend, wstart));
         };

@@ -808,8 +808,12 @@ static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
     int lpr = 0;
     /* (index_runs_kernel keeps a block of NF order words in registers: one instantiation per window length — the reference's default
      * min-overlap 30 (NF 7), 35, BASELINE's 40 (NF 17), 45, 50) */
-    const bool nf_built = nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27;
-    if (nf_built && view(c).m == RUNS_M && max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
+    /* round 6: every other window of 2 .. 64 m-mers — any min-overlap up to 95, k above 64 and minimizers of up to 31 bases included —
+     * takes the instantiation with a run-time window length (DISCO_NO_GENERIC_RUNS=1: round 2's probe for those, as before) */
+    const int m = view(c).m;
+    const bool nf_built = (nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27) && m == RUNS_M;
+    const bool nf_generic = nf >= 2 && nf <= 64 && m > 16 && m <= 31 && !getenv("DISCO_NO_GENERIC_RUNS");
+    if ((nf_built || nf_generic) && max_len > (u32)c->k && !getenv("DISCO_NO_RUNS")) {
         const u32 maxwin = max_len - (u32)c->k;
         /* a read of W windows has about 2 W / (NF + 1) runs: 32 entries where that stays below 20 (room for the spread), else 64 */
         const u32 expect = 2u * maxwin / (u32)(nf + 1);
@@ -886,14 +890,35 @@ static int index_count_chunk(disco_ctx *c, const DiscoView &v, const IndexCountP
         if (pl.lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, NF_, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift); \
         else hipLaunchKernelGGL((index_runs_kernel<COUNT, NF_, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);             \
     } while (0)
-        switch (pl.nf) {
-        case 7: DISCO_RUNS_LAUNCH(7); break;
-        case 12: DISCO_RUNS_LAUNCH(12); break;
-        case 17: DISCO_RUNS_LAUNCH(17); break;
-        case 22: DISCO_RUNS_LAUNCH(22); break;
-        default: DISCO_RUNS_LAUNCH(27); break;
-        }
+#define DISCO_RUNS_LAUNCH_RT(NFMAX_, LONGK_)                                                                                                                 \
+    do {                                                                                                                                                  \
+        if (pl.lpr == 16) hipLaunchKernelGGL((index_runs_kernel<COUNT, 0, 1, NFMAX_, LONGK_>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift); \
+        else hipLaunchKernelGGL((index_runs_kernel<COUNT, 0, 2, NFMAX_, LONGK_>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, runs, pl.ocnt, oslot, pl.oshift);             \
+    } while (0)
+        const bool built = v.m == RUNS_M && (pl.nf == 7 || pl.nf == 12 || pl.nf == 17 || pl.nf == 22 || pl.nf == 27);
+        if (!built) { /* the window length as a run-time value: arrays for 32 or 64 m-mers */
+            /* (the arrays are registers: an instantiation per size class keeps the waves per SIMD near the specialised kernels' — windows of 10
+             * in arrays for 32 ran 9.8 ms at 20 M reads, in arrays for 12: 6.7) */
+            if (c->k > 64) {
+                if (pl.nf <= 48) DISCO_RUNS_LAUNCH_RT(48, true);
+                else DISCO_RUNS_LAUNCH_RT(64, true);
+            } else if (pl.nf <= 8) DISCO_RUNS_LAUNCH_RT(8, false);
+            else if (pl.nf <= 12) DISCO_RUNS_LAUNCH_RT(12, false);
+            else if (pl.nf <= 16) DISCO_RUNS_LAUNCH_RT(16, false);
+            else if (pl.nf <= 24) DISCO_RUNS_LAUNCH_RT(24, false);
+            else if (pl.nf <= 32) DISCO_RUNS_LAUNCH_RT(32, false);
+            else if (pl.nf <= 48) DISCO_RUNS_LAUNCH_RT(48, false);
+            else DISCO_RUNS_LAUNCH_RT(64, false);
+        } else
+            switch (pl.nf) {
+            case 7: DISCO_RUNS_LAUNCH(7); break;
+            case 12: DISCO_RUNS_LAUNCH(12); break;
+            case 17: DISCO_RUNS_LAUNCH(17); break;
+            case 22: DISCO_RUNS_LAUNCH(22); break;
+            default: DISCO_RUNS_LAUNCH(27); break;
+            }
 #undef DISCO_RUNS_LAUNCH
+#undef DISCO_RUNS_LAUNCH_RT
     } else
         if (c->k > 64) hipLaunchKernelGGL((index_count_kernel<COUNT, true>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
         else hipLaunchKernelGGL(index_count_kernel<COUNT>, grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, c->d_okey, a, b, pl.ocnt, oslot, pl.oshift);
@@ -4334,14 +4359,33 @@ static int index_count_own_list(disco_ctx *c, const DiscoView &v, ulonglong2 *re
         if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<false, NF_, 1>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, c->d_runs, (u32 *)nullptr, (u32 *)nullptr, 0u, list); \
         else hipLaunchKernelGGL((index_runs_kernel<false, NF_, 2>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, c->d_runs, (u32 *)nullptr, (u32 *)nullptr, 0u, list);             \
     } while (0)
-        switch (nf) {
-        case 7: DISCO_RUNS_LAUNCH(7); break;
-        case 12: DISCO_RUNS_LAUNCH(12); break;
-        case 17: DISCO_RUNS_LAUNCH(17); break;
-        case 22: DISCO_RUNS_LAUNCH(22); break;
-        default: DISCO_RUNS_LAUNCH(27); break;
-        }
+#define DISCO_RUNS_LAUNCH_RT(NFMAX_, LONGK_)                                                                                                                 \
+    do {                                                                                                                                                  \
+        if (lpr == 16) hipLaunchKernelGGL((index_runs_kernel<false, 0, 1, NFMAX_, LONGK_>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, c->d_runs, (u32 *)nullptr, (u32 *)nullptr, 0u, list); \
+        else hipLaunchKernelGGL((index_runs_kernel<false, 0, 2, NFMAX_, LONGK_>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, c->d_runs, (u32 *)nullptr, (u32 *)nullptr, 0u, list);             \
+    } while (0)
+        const bool built = v.m == RUNS_M && (nf == 7 || nf == 12 || nf == 17 || nf == 22 || nf == 27);
+        if (!built) {
+            if (c->k > 64) {
+                if (nf <= 48) DISCO_RUNS_LAUNCH_RT(48, true);
+                else DISCO_RUNS_LAUNCH_RT(64, true);
+            } else if (nf <= 8) DISCO_RUNS_LAUNCH_RT(8, false);
+            else if (nf <= 12) DISCO_RUNS_LAUNCH_RT(12, false);
+            else if (nf <= 16) DISCO_RUNS_LAUNCH_RT(16, false);
+            else if (nf <= 24) DISCO_RUNS_LAUNCH_RT(24, false);
+            else if (nf <= 32) DISCO_RUNS_LAUNCH_RT(32, false);
+            else if (nf <= 48) DISCO_RUNS_LAUNCH_RT(48, false);
+            else DISCO_RUNS_LAUNCH_RT(64, false);
+        } else
+            switch (nf) {
+            case 7: DISCO_RUNS_LAUNCH(7); break;
+            case 12: DISCO_RUNS_LAUNCH(12); break;
+            case 17: DISCO_RUNS_LAUNCH(17); break;
+            case 22: DISCO_RUNS_LAUNCH(22); break;
+            default: DISCO_RUNS_LAUNCH(27); break;
+            }
 #undef DISCO_RUNS_LAUNCH
+#undef DISCO_RUNS_LAUNCH_RT
     } else if (c->k > 64)
         hipLaunchKernelGGL((index_count_kernel<false, true>), grid, dim3(256), 0, c->stream, v, c->d_bkt, rec, (u32 *)nullptr, (u64)0, n_own, (u32 *)nullptr, (u32 *)nullptr, 0u, list);
     else
@@ -5166,6 +5210,7 @@ int disco_comm_init_local(disco_ctx *const *ctxs, int nranks)
     return DISCO_OK;
 }
 
+int disco_probe_run_words(const disco_ctx *c) { return c ? c->runs_lpr : 0; }
 int disco_comm_rank(const disco_ctx *c) { return (c && c->comm) ? c->comm->rank : 0; }
 int disco_comm_world(const disco_ctx *c) { return (c && c->comm) ? c->comm->world : 1; }
 const char *disco_comm_kind(const disco_ctx *c) { return (c && c->comm) ? c->comm->kind() : "none"; }

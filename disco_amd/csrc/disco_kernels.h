@@ -396,19 +396,22 @@ __global__ void __launch_bounds__(256) index_count_kernel(DiscoView v, u32 *__re
 /* the rolling canonical m-mer of a 2-bit packed row on 32-bit halves, M a constant (odd, 2 M bits = one dword + 2 M - 32 bits): the
  * forward m-mer f and the reverse complement r of the M bases that end at the current position, every thread of the wavefront at the
  * SAME position (the dword switch is a scalar branch, the base leaves the current dword through a bit-field extract with a scalar offset) */
-#define RUNS_M 23 /* minimizer length of the paths built on MmerRoll (disco_minimizer_len gives 23 for every k from 23 to 86) */
+#define RUNS_M 23 /* minimizer length of the specialised instantiations (disco_minimizer_len gives 23 for every k from 23 to 86) */
+/* M = 0: the length is a run-time value (17 .. 31: k above 86 takes minimizers of up to 31 bases) — the mask and the place of the entering
+ * complement are then scalar operands of the same instructions, and the fold of order_hash32 takes its third product */
 template <int M>
 struct MmerRoll {
-    static_assert(M > 16 && M <= 24 && (M & 1), "two dwords, the high one partly used; a 24-bit fold in order_hash32<false>");
+    static_assert(M == 0 || (M > 16 && M <= 24 && (M & 1)), "two dwords, the high one partly used; a 24-bit fold in order_hash32<false>");
     const u64 *__restrict__ p;
     int last_word;
+    u32 himask, rsh; /* (M = 0) */
     int pos = 0; /* bases consumed (wave uniform) */
     u64 word = 0;
     u32 cw = 0;
     u32 flo = 0, fhi = 0, rlo = 0, rhi = 0;
     bool st = false;
     u32 clo = 0, chi = 0;
-    __device__ __forceinline__ MmerRoll(const u64 *row, int S) : p(row), last_word(S - 1) {}
+    __device__ __forceinline__ MmerRoll(const u64 *row, int S, int m = M) : p(row), last_word(S - 1), himask((1u << (2 * m - 32)) - 1u), rsh((u32)(2 * m - 34)) {}
     __device__ __forceinline__ void step()
     {
         if ((pos & 15) == 0) {
@@ -417,17 +420,29 @@ struct MmerRoll {
         }
         const u32 b = __builtin_amdgcn_ubfe(cw, (u32)(30 - 2 * (pos & 15)), 2u);
         ++pos;
-        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30u) & ((1u << (2 * M - 32)) - 1u);
+        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30u) & (M ? ((1u << (2 * (M ? M : 17) - 32)) - 1u) : himask);
         flo = (flo << 2) | b;
         rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2u);
-        rhi = (rhi >> 2) | ((b ^ 3u) << (2 * M - 34));
+        rhi = (rhi >> 2) | ((b ^ 3u) << (M ? (u32)(2 * (M ? M : 17) - 34) : rsh));
         st = (((u64)rhi << 32) | rlo) < (((u64)fhi << 32) | flo); /* the reverse complement is the canonical one (M odd: never equal) */
         clo = st ? rlo : flo;
         chi = st ? rhi : fhi;
     }
-    __device__ __forceinline__ u32 hash() const { return order_hash32<false>(((u64)chi << 32) | clo); }
+    __device__ __forceinline__ u32 hash() const { return order_hash32<M == 0>(((u64)chi << 32) | clo); }
     __device__ __forceinline__ u32 strand() const { return st ? 1u : 0u; }
 };
+/* a read's run entry (16 bits): first window << 7 | (occurrence - first window) << 1 | strand — windows below 256, a window of at most 64
+ * m-mers (round 6: six bits for the offset; five, for NF <= 32, before); 0xFFFF: unused, 0xFFFE in the first entry: no usable list */
+#define RUN_W(e) ((u32)(e) >> 7)
+#define RUN_DELTA(e) (((u32)(e) >> 1) & 63u)
+#define RUN_STRAND(e) ((u32)(e)&1u)
+/* ... and as probe_runs_kernel holds it in LDS: slot << 29 | strand << 23 | (occurrence - first) << 17 | end << 8 | first window */
+#define OCC_MAKE(slot, e, wend) (((u32)(slot) << 29) | (RUN_STRAND(e) << 23) | (RUN_DELTA(e) << 17) | ((u32)(wend) << 8) | RUN_W(e))
+#define OCC_SLOT(d) ((u32)(d) >> 29)
+#define OCC_STRAND(d) (((u32)(d) >> 23) & 1u)
+#define OCC_DELTA(d) (((u32)(d) >> 17) & 63u)
+#define OCC_END(d) (((u32)(d) >> 8) & 0x1FFu)
+#define OCC_FIRST(d) ((u32)(d)&0xFFu)
 
 /* ----------------------------------------------------------------------------------------------------------------
  * index_runs_kernel — index_count_kernel's rolling pass, which additionally hands the probe every read's MINIMIZER RUNS, so
@@ -456,11 +471,16 @@ struct MmerRoll {
  * The entries are staged in LDS (each thread its own CAP slots) and leave as one coalesced copy per block. */
 /* list (multi-GPU flow, ranks own loci): position i of [lo, hi) stands for read ORDER_ID(list[i]), its length rides in the entry;
  * records, runs, keys and slots by position — probe_runs_kernel then reads the run lists in the order it walks the reads */
-template <bool COUNT, int NF, int NL>
+/* NF = 0 (round 6): the window length is a run-time value nf <= NFMAX — every min-overlap the specialised instantiations (NF = 7, 12, 17,
+ * 22, 27: min-overlap 30 .. 50) do not cover, k above 64 (LONGK: the three-word k-mer comparison of the rare tied end k-mer) and
+ * minimizers of up to 31 bases included. The block's arrays hold NFMAX words, the loops over a block are unrolled NFMAX times with a
+ * SCALAR test per position (every thread of the wavefront is at the same position of the same block), so the work follows nf, not NFMAX. */
+template <bool COUNT, int NF, int NL, int NFMAX = NF, bool LONGK = false>
 __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__restrict__ bkt, ulonglong2 *__restrict__ rec, u32 *__restrict__ okey, u64 lo, u64 hi,
                                                          u32 *__restrict__ runs, u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift,
                                                          const u64 *__restrict__ list = nullptr)
 {
+    static_assert(NF == 0 || NF == NFMAX, "a specialised instantiation holds exactly its window");
     constexpr int CAP = 32 * NL;
     __shared__ u16 s_runs[256 * CAP];
     __shared__ u32 s_x[3 * 256]; /* the suffix k-mer's window: its two minima and their base, per thread */
@@ -476,20 +496,21 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
     if (i < hi && !other_class) {
         const u64 *__restrict__ p = v.reads + rid * v.S;
         const int L = list ? ORDER_LEN(lw) : (int)v.len[rid], k = v.k;
-        constexpr int m = RUNS_M; /* (the host takes this path for m = RUNS_M only: runs_lpr_for) */
+        const int m = NF ? RUNS_M : v.m; /* (the host takes a specialised instantiation for m = RUNS_M only: runs_lpr_for) */
+        const int nf = NF ? NF : k - m + 1; /* (wave uniform) */
         const int nmm = L - m + 1; /* m-mer positions */
-        const int npos = nmm - NF; /* = L - k: the probe's windows are [0, npos), window npos is the suffix k-mer */
+        const int npos = nmm - nf; /* = L - k: the probe's windows are [0, npos), window npos is the suffix k-mer */
         /* round 6: the rolling pass on 32-bit halves with the minimizer length a constant (the masks and the place of the entering
          * complement were run-time values: 64-bit shifts by a register, two ANDs), the base taken out of the current dword by a SCALAR
          * offset (every thread of a wavefront is at the same base: the position never depends on the lane — reads shorter than the
          * longest only mask what they keep), and a mix of two 24-bit multiplies behind the fold (order_hash32): 27 -> 21 vector
          * instructions per m-mer and thread in this part of the kernel, which is bound by vector issue outright */
-        MmerRoll<m> roll(p, v.S);
+        MmerRoll<NF ? RUNS_M : 0> roll(p, v.S, m);
         u32 best = 0xFFFFFFFFu;
         for (int q = 0; q < m - 1; ++q) roll.step();
-        u32 s1[NF], s2[NF]; /* suffix minima of the block before; slot t is free for the block's own order word once step t - 1 has read it */
-#pragma unroll
-        for (int t = 0; t < NF; ++t) s1[t] = s2[t] = 0xFFFFFFFFu;
+        u32 s1[NFMAX], s2[NFMAX]; /* suffix minima of the block before */
+#pragma clang loop unroll(full)
+        for (int t = 0; t < NFMAX; ++t) s1[t] = s2[t] = 0xFFFFFFFFu;
         u16 *my = s_runs + tid * CAP;
         u32 cnt = 0, lastm = 0xFFFFFFFFu, tie = 0;
         u32 P1 = 0, P2 = 0;
@@ -509,43 +530,46 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
                      * borrows from its hash bits there and matches nothing) */
                     if (((m1 ^ lastm) >> 1) != 0u) {
                         lastm = m1;
-                        /* first window << 6 | (occurrence - first window) << 1 | strand: the low byte of the minimum is position << 1 | strand
+                        /* first window << 7 | (occurrence - first window) << 1 | strand: the low byte of the minimum is position << 1 | strand
                          * (bit 8 is never set), the rest is the same for every thread. A list that overflows is marked unusable below: its
                          * last slot may take whatever comes */
-                        my[cnt < (u32)CAP ? cnt : (u32)CAP - 1u] = (u16)((m1 & 0xFFu) + (((u32)w << 6) - 2u * (u32)tw));
+                        my[cnt < (u32)CAP ? cnt : (u32)CAP - 1u] = (u16)((m1 & 0xFFu) + (((u32)w << 7) - 2u * (u32)tw)); /* (RUN_W / RUN_DELTA / RUN_STRAND) */
                         ++cnt;
                     }
                 }
             }
         };
-        const int nblk = npos / NF + 2; /* window npos lies in block npos / NF and is complete once the next block has gone by */
+        const int nblk = npos / nf + 2; /* window npos lies in block npos / nf and is complete once the next block has gone by */
         int q = 0;
         for (int b = 0; b < nblk; ++b) {
-            const int base = (b - 1) * NF;
-            lastm -= (u32)NF << 1;
+            const int base = (b - 1) * nf;
+            lastm -= (u32)nf << 1;
             if (b >= 1) window(base, s1[0], s2[0], base, 0); /* the window that IS block b - 1 */
             if (b == 1) {
                 P1 = s1[0]; /* window 0: the prefix k-mer's record */
                 P2 = s2[0];
             }
             u32 p1 = 0xFFFFFFFFu, p2 = 0xFFFFFFFFu;
-            u32 hc[NF];
-#pragma unroll
-            for (int t = 0; t < NF; ++t) {
-                /* past the read the order word is whatever the row holds there: never part of a window the probe uses, and kept out of the read's key */
-                roll.step();
-                const u32 h = roll.hash();
-                best = min(best, q < nmm ? h : 0xFFFFFFFFu);
-                const u32 o = (h & ~0x1FFu) | roll.strand();
-                ++q;
-                hc[t] = o;
-                p1 = min(p1, o | ((u32)(NF + t) << 1));
-                p2 = min(p2, o | ((u32)(127 - (NF + t)) << 1));
-                if (t + 1 < NF && b >= 1) window(base + t + 1, min(s1[t + 1], p1), min(s2[t + 1], p2), base, t + 1);
+            u32 hc[NFMAX];
+#pragma clang loop unroll(full)
+            for (int t = 0; t < NFMAX; ++t) {
+                if (NF != 0 || t < nf) { /* (scalar; a guard, not an exit: a loop with one exit is unrolled whatever its size, and the arrays stay registers) */
+                    /* past the read the order word is whatever the row holds there: never part of a window the probe uses, and kept out of the read's key */
+                    roll.step();
+                    const u32 h = roll.hash();
+                    best = min(best, q < nmm ? h : 0xFFFFFFFFu);
+                    const u32 o = (h & ~0x1FFu) | roll.strand();
+                    ++q;
+                    hc[t] = o;
+                    p1 = min(p1, o | ((u32)(nf + t) << 1));
+                    p2 = min(p2, o | ((u32)(127 - (nf + t)) << 1));
+                    if (t + 1 < nf && b >= 1) window(base + t + 1, min(s1[t + 1 < NFMAX ? t + 1 : 0], p1), min(s2[t + 1 < NFMAX ? t + 1 : 0], p2), base, t + 1);
+                }
             }
             u32 a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int t = NF - 1; t >= 0; --t) {
+#pragma clang loop unroll(full)
+            for (int t = NFMAX - 1; t >= 0; --t) {
+                if (NF == 0 && t >= nf) continue; /* (scalar) */
                 a1 = min(a1, hc[t] | ((u32)t << 1));
                 a2 = min(a2, hc[t] | ((u32)(127 - t) << 1));
                 s1[t] = a1;
@@ -564,10 +588,10 @@ __global__ void __launch_bounds__(256) index_runs_kernel(DiscoView v, u32 *__res
             if (ffirst == flast)
                 rev = k1 & 1u;
             else {
-                rev = kmer_is_rev(p, v.S, j0, k);
+                rev = kmer_is_rev<false, LONGK>(p, v.S, j0, k);
                 fsel = rev ? flast : ffirst;
             }
-            t = rev ? (u32)(NF - 1 - fsel) : (u32)fsel;
+            t = rev ? (u32)(nf - 1 - fsel) : (u32)fsel;
             return mmer_key(p, v.S, j0 + fsel, m);
         };
         u32 tp, rp, ts, rs;
@@ -1149,7 +1173,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
     constexpr int RS = VERIFY_SW + 1; /* words of a staged row (+ one readable word for the branch-free extract) */
     __shared__ u64 s_rows[G * RS];
     __shared__ u32 s_id[G];
-    __shared__ u32 s_occ[128]; /* the group's runs, compacted: slot << 29 | strand << 22 | (occurrence - first) << 17 | end << 8 | first window */
+    __shared__ u32 s_occ[128]; /* the group's runs, compacted: OCC_MAKE */
     __shared__ u32 s_o_fp[64], s_o_start[64], s_o_excl[64], s_o_desc[64]; /* current batch of lookups with records */
     __shared__ u8 s_mark[PR_MARKCAP];
 #if defined(VERIFY_EXP_HALF)
@@ -1241,12 +1265,12 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
             const bool myslow = (slowm >> (slot * LPR)) & 1ull;
             const bool v0 = sv && !myslow && e0 < 0xFFFEu, v1 = sv && !myslow && e1 < 0xFFFEu;
             const u32 nx = (u32)__shfl_down((int)e0, 1); /* the entry after e1 */
-            const u32 wend0 = v1 ? (e1 >> 6) : npos;
-            const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? (nx >> 6) : npos;
+            const u32 wend0 = v1 ? RUN_W(e1) : npos;
+            const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? RUN_W(nx) : npos;
             const u64 m0 = __ballot(v0), m1 = __ballot(v1);
             const u32 below = (u32)__popcll(m0 & lt) + (u32)__popcll(m1 & lt);
-            if (v0) s_occ[below] = (slot << 29) | ((e0 & 1u) << 22) | (((e0 >> 1) & 31u) << 17) | (wend0 << 8) | (e0 >> 6);
-            if (v1) s_occ[below + 1] = (slot << 29) | ((e1 & 1u) << 22) | (((e1 >> 1) & 31u) << 17) | (wend1 << 8) | (e1 >> 6);
+            if (v0) s_occ[below] = OCC_MAKE(slot, e0, wend0);
+            if (v1) s_occ[below + 1] = OCC_MAKE(slot, e1, wend1);
             const u32 n_occ = (u32)__popcll(m0) + (u32)__popcll(m1);
             if (sv && e == 0 && myslow && !(a.v.full && LA > DISCO_SHORT_MAX)) { /* ties / too many runs: probe_kernel<2> does this read (long reads: listed with their chunk, above) */
                 const u32 idx = atomicAdd(a.rare->n_slow, 1u);
@@ -1265,8 +1289,8 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                 u32 d = 0, st = 0, cnt = 0, fp = 0;
                 if (oi < n_occ) {
                     d = s_occ[oi];
-                    const int prel = (int)(d & 0xFFu) + (int)((d >> 17) & 31u);
-                    const u64 key = mmer_key<true>(s_rows + (d >> 29) * RS, RS, prel, m);
+                    const int prel = (int)OCC_FIRST(d) + (int)OCC_DELTA(d);
+                    const u64 key = mmer_key<true>(s_rows + OCC_SLOT(d) * RS, RS, prel, m);
                     const u64 b = key >> a.v.bshift;
                     uint2 se;
                     __builtin_memcpy(&se, a.v.bkt + b, sizeof se); /* bkt[b], bkt[b + 1] */
@@ -1313,8 +1337,8 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                     const u32 dd = s_o_desc[lo];
                     u64 pay = 0;
                     if (in) pay = a.v.ent[s_o_start[lo] + (idx - s_o_excl[lo])];
-                    const u32 dslot = dd >> 29, rv = (dd >> 22) & 1u;
-                    const int wst = (int)(dd & 0xFFu), wen = (int)((dd >> 8) & 0x1FFu), prel = wst + (int)((dd >> 17) & 31u);
+                    const u32 dslot = OCC_SLOT(dd), rv = OCC_STRAND(dd);
+                    const int wst = (int)OCC_FIRST(dd), wen = (int)OCC_END(dd), prel = wst + (int)OCC_DELTA(dd);
                     const int t = (int)PAY_T(pay);
                     /* a window in canonical-forward orientation starts t before the occurrence, a reversed one k - m - t before */
                     const int w = rv ? prel - (nf - 1 - t) : prel - t;
@@ -4312,7 +4336,11 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         __syncthreads();
         return;
     }
+#if defined(TR_EXP) && TR_EXP >= 1 /* (the experiments leave the first two entries as survivors: the output side as on real data) */
+    const bool fl = lane < d && lane >= 2u && (ht[sent & 63u] != 0x12345u);
+#else
     const bool fl = lane < d && (ht[sent] >> 31);
+#endif
     const bool fr = lane < d && !fl;
     const u64 mk = __ballot(fr);
     if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;

@@ -30,6 +30,11 @@ int disco_substitute_bases(disco_ctx *ctx, uint64_t seed, uint32_t rate_ppm);
 /* every rank generates ITS range of the job's reads (multi-GPU bench: the inputs are range-partitioned in HBM when a step starts) */
 int disco_dist_generate_reads(disco_ctx *ctx, const disco_genspec_abi *spec);
 
+/* which probe the last disco_build_index prepared: the 32-bit words of minimizer runs a read got (16 or 32: probe_runs_kernel walks the run
+ * lists the index pass left), or 0: no run lists for this shape — round 2's probe derives the windows' minimizers itself. Tests only
+ * (round 6: every window of 2 .. 64 m-mers over reads of up to 256 bases has run lists; before, min-overlap 30 / 35 / 40 / 45 / 50 only) */
+int disco_probe_run_words(const disco_ctx *ctx);
+
 /* attainable HBM bandwidth on this device (SURVEY.md §8d "Roofline that bounds the path": nominal AND measured): a
  * streaming copy kernel over two scratch buffers of `bytes` each, `reps` timed launches after one warm-up;
  * *gb_per_s = read + written bytes per second / 1e9 of the best launch. Measurement aid for bench.py, no reference

@@ -41,7 +41,7 @@ def test_test_only_entry_points_live_in_their_own_header():
     """what bench.py and the tests need beyond the reference's interface (synthetic reads, substitutions, bandwidth probes) is declared in
     include/disco_hip_test.h, not in the boundary header a BuildGraph host binds"""
     product, test_only = declared_functions(("disco_hip.h",)), declared_functions(("disco_hip_test.h",))
-    assert set(test_only) == {"disco_generate_reads", "disco_substitute_bases", "disco_dist_generate_reads", "disco_measure_hbm", "disco_measure_gather"}
+    assert set(test_only) == {"disco_generate_reads", "disco_substitute_bases", "disco_dist_generate_reads", "disco_measure_hbm", "disco_measure_gather", "disco_probe_run_words"}
     assert not set(product) & set(test_only)
     for host in ("buildg_main.cpp", "writer.cpp", "parsimple.cpp", "fastx.cpp"):  # the drop-in executable binds the product header only
         txt = open(os.path.join(ROOT, "disco_amd", "host", host)).read()

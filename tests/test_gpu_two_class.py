@@ -89,14 +89,28 @@ def test_the_table_comes_back_as_it_was_handed_over():
         g.run_graph()
 
 
-def test_sets_that_keep_one_stride():
-    # too many long reads, and a window length without minimizer runs: the one-stride paths, same results
-    for reads, mo in ((mixed_reads(14, 3000, 150, 150, 30.0, 0.4, 300, 600), 40), (mixed_reads(15, 3000, 150, 150, 30.0, 0.03, 300, 600), 80)):
+def test_sets_that_keep_one_stride(monkeypatch):
+    # too many long reads, and a window length without minimizer runs (round 6: only with DISCO_NO_GENERIC_RUNS=1 — every window of up to
+    # 64 m-mers has run lists otherwise): the one-stride paths, same results
+    for reads, mo, env in ((mixed_reads(14, 3000, 150, 150, 30.0, 0.4, 300, 600), 40, None), (mixed_reads(15, 3000, 150, 150, 30.0, 0.03, 300, 600), 80, "DISCO_NO_GENERIC_RUNS")):
+        if env:
+            monkeypatch.setenv(env, "1")
         with buildgraph.BuildGraph(min_overlap=mo) as g:
             g.upload_ascii(reads)
             g.run_graph()
             assert g.long_rows == 0
         assert_parity(reads, mo, "one stride kept")
+
+
+def test_two_classes_with_three_word_kmers():
+    """round 6: min-overlap 80 (k = 79, windows of 57 m-mers) has run lists now, so a set with a few long reads gets two classes of rows there
+    too — the long class through the three-word variants of its kernels"""
+    reads = mixed_reads(15, 3000, 150, 150, 30.0, 0.03, 300, 600)
+    with buildgraph.BuildGraph(min_overlap=80) as g:
+        g.upload_ascii(reads)
+        g.run_graph()
+        assert g.long_rows == sum(len(r) > 256 for r in reads) > 0 and g.probe_run_words() > 0
+    assert_parity(reads, 80, "two classes, k = 79")
 
 
 def test_generated_long_tail_on_the_device():
