@@ -150,9 +150,49 @@ struct RankResult {
 
 int main(int argc, char **argv)
 {
-    std::cout << "Software: Disco Assembler BuildGraph, MI355X-native drop-in (disco_amd)\n";
     auto t_main = Clock::now();
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); /* hosts with dmabuf IPC only: RCCL's buffer sharing needs it; before any HIP call */
+    int launcher_gpus = 1; /* (a first look at the arguments for --gpus only; the real parse, with its messages, is the child's) */
+    for (int i = 1; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "--gpus")) launcher_gpus = atoi(argv[i + 1]);
+    /* ---- buildG --gpus N: a launcher that never touches the GPU, and the stage as its child (round 6) --------------------------------
+     * Matches the role of mpirun in front of buildG-MPI (MPI/main.cpp:29-37; runDisco-MPI.sh:214-258): the process the user started owns
+     * no device state, so it can start the stage again. When the stage's watchdog ends it (exit 3: no rank moved for DISCO_WATCHDOG_S
+     * seconds — on first contact with a node that most likely means the two communicators of a context did not progress side by side),
+     * the launcher starts ONE fresh child with DISCO_DIST_ONE_COMM=1 (every exchange on one communicator, one stream: the conservative
+     * mode) before giving up. Never a re-exec of a process that has initialised the GPU; nothing was written that a second try could
+     * trip over (the files appear after the pass, the checkpoint's GC=Complete line last). DISCO_NO_RETRY=1: one try only. */
+    if (launcher_gpus > 1 && !getenv("DISCO_BUILDG_CHILD")) { /* (nothing printed yet: the child prints the stage's whole log, once) */
+        std::cout.flush();
+        auto run_child = [&](const char *attempt, bool one_comm) -> int {
+            const pid_t pid = fork(); /* (single-threaded up to here: no thread pool, no GPU runtime thread) */
+            if (pid < 0) return -1;
+            if (pid == 0) {
+                prctl(PR_SET_PDEATHSIG, SIGTERM); /* the stage does not outlive its launcher */
+                setenv("DISCO_BUILDG_CHILD", attempt, 1);
+                if (one_comm) setenv("DISCO_DIST_ONE_COMM", "1", 1);
+                execv("/proc/self/exe", argv);
+                perror("buildG: execv");
+                _exit(127);
+            }
+            int st = 0;
+            while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {
+            }
+            return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        };
+        int rc = run_child("1", false);
+        if (rc == 3 && !getenv("DISCO_NO_RETRY") && !getenv("DISCO_DIST_ONE_COMM")) {
+            std::cout << "\nThe multi-GPU stage made no progress and was ended by its watchdog; starting it ONCE more with one communicator "
+                         "(DISCO_DIST_ONE_COMM=1)." << std::endl;
+            rc = run_child("2", true);
+        }
+        if (rc < 0) {
+            std::cerr << "buildG: fork failed" << std::endl;
+            return 1;
+        }
+        return rc;
+    }
+    std::cout << "Software: Disco Assembler BuildGraph, MI355X-native drop-in (disco_amd)\n";
     if (disco_abi_version() != DISCO_ABI_VERSION) { /* the struct layouts this file was compiled against are those of exactly one version */
         std::cerr << "buildG: libdisco_hip.so speaks ABI version " << disco_abi_version() << ", this executable was built against " << DISCO_ABI_VERSION
                   << " (include/disco_hip.h): rebuild both (python -m disco_amd.build)" << std::endl;
@@ -237,39 +277,6 @@ int main(int argc, char **argv)
     if (gc) { /* BG/main.cpp:48-52 */
         std::cout << "Graph already exists. Using previously built graph...\nExiting graph construction." << std::endl;
         return 0;
-    }
-    /* ---- buildG --gpus N: a launcher that never touches the GPU, and the stage as its child (round 6) --------------------------------
-     * Matches the role of mpirun in front of buildG-MPI (MPI/main.cpp:29-37; runDisco-MPI.sh:214-258): the process the user started owns
-     * no device state, so it can start the stage again. When the stage's watchdog ends it (exit 3: no rank moved for DISCO_WATCHDOG_S
-     * seconds — on first contact with a node that most likely means the two communicators of a context did not progress side by side),
-     * the launcher starts ONE fresh child with DISCO_DIST_ONE_COMM=1 (every exchange on one communicator, one stream: the conservative
-     * mode) before giving up. Never a re-exec of a process that has initialised the GPU; nothing was written that a second try could
-     * trip over (the files appear after the pass, the checkpoint's GC=Complete line last). DISCO_NO_RETRY=1: one try only. */
-    if (gpus > 1 && !getenv("DISCO_BUILDG_CHILD")) {
-        std::cout.flush();
-        auto run_child = [&](const char *attempt, bool one_comm) -> int {
-            const pid_t pid = fork(); /* (single-threaded up to here: no thread pool, no GPU runtime thread) */
-            if (pid < 0) return -1;
-            if (pid == 0) {
-                prctl(PR_SET_PDEATHSIG, SIGTERM); /* the stage does not outlive its launcher */
-                setenv("DISCO_BUILDG_CHILD", attempt, 1);
-                if (one_comm) setenv("DISCO_DIST_ONE_COMM", "1", 1);
-                execv("/proc/self/exe", argv);
-                perror("buildG: execv");
-                _exit(127);
-            }
-            int st = 0;
-            while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {
-            }
-            return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-        };
-        int rc = run_child("1", false);
-        if (rc == 3 && !getenv("DISCO_NO_RETRY") && !getenv("DISCO_DIST_ONE_COMM")) {
-            std::cout << "\nThe multi-GPU stage made no progress and was ended by its watchdog; starting it ONCE more with one communicator "
-                         "(DISCO_DIST_ONE_COMM=1)." << std::endl;
-            rc = run_child("2", true);
-        }
-        return rc < 0 ? die("fork failed") : rc;
     }
 
     /* ---- reads -------------------------------------------------------------------------------------------------- */
