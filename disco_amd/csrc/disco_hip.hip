@@ -180,6 +180,7 @@ struct disco_ctx {
     /* two classes of rows (disco_kernels.h, "two classes of rows"): made by two_class_convert at the first index build over a table whose
      * stride a few long reads forced; c->S is 8 from then on and S_ext what the caller gave (disco_stride_words, disco_download_reads) */
     bool two_class = false;
+    bool dist_two_class = false; /* set by a multi-GPU pass around its two_class_convert (round 6) */
     int S_ext = 0;
     u64 n_long = 0;
     u64 reads_rows = 0; /* rows d_reads was allocated with (two classes: n + n_long) */
@@ -829,7 +830,8 @@ static int runs_lpr_for(const disco_ctx *c, int nf, u32 max_len, u64 nloc)
  * set once the old table has been released and the new buffers exist (a table adopted from the caller must never be freed or kept) */
 static bool two_class_ok(const disco_ctx *c, int S, u64 n, u64 n_long, u32 short_max, bool will_own = false)
 {
-    if (c->comm || c->dist_reads || !(c->reads_owned || will_own) || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
+    /* (a context with a communicator: only where its pass asks for it — dist_two_class, after the gather of the reads, over id ranges) */
+    if (((c->comm || c->dist_reads) && !c->dist_two_class) || !(c->reads_owned || will_own) || c->prm.max_substitutions || getenv("DISCO_NO_TWO_CLASS")) return false;
     if (S <= VERIFY_SW || n_long == 0 || n_long * (u64)env_int("DISCO_TWO_CLASS_ONE_IN", 5) > n || n + n_long >= (1ull << 31)) return false;
     /* the short class takes the paths of a pure short set (minimizer runs, flat verify); the long one the lists those paths keep */
     return runs_lpr_for(c, c->k - view(c).m + 1, short_max, n) != 0;
@@ -4423,7 +4425,27 @@ static int dist_build_index(disco_ctx *c)
     ph_begin(c, DISCO_PH_INDEX);
     DiscoView v = view(c);
     if (c->loci) CHK(index_count_own_list(c, v, c->d_rec));
-    else CHK(launch_index_count<false>(c, v, c->d_rec, c->q_lo, c->q_hi));
+    else {
+        IndexCountPlan pl;
+        CHK(index_count_plan(c, v, c->q_lo, c->q_hi, &pl));
+        CHK(index_count_chunk<false>(c, v, pl, c->d_rec, c->q_lo, c->q_hi));
+        if (c->two_class && nloc) {
+            /* the long reads of the rank's range — long_ids is ascending, ovf[i] counts the long reads in front of read i: they are the
+             * x in [ovf[q_lo], ovf[q_hi]) — from their full rows; records by read id from q_lo (the kernel indexes rec by read id) */
+            u32 xb[2] = {0, (u32)c->n_long};
+            HIPCHK(c, hipMemcpyAsync(&xb[0], c->d_ovf + c->q_lo, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            if (c->q_hi < c->n) HIPCHK(c, hipMemcpyAsync(&xb[1], c->d_ovf + c->q_hi, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (xb[1] > xb[0]) {
+                const dim3 g((unsigned)((xb[1] - xb[0] + 255) / 256));
+                ulonglong2 *rec_by_id = c->d_rec - 2 * (ptrdiff_t)c->q_lo; /* rec_by_id[2 i] = the record of read i (never touched outside [q_lo, q_hi)) */
+                u32 *oslot_by_id = pl.oslot ? pl.oslot - (ptrdiff_t)c->q_lo : nullptr; /* (the grouping's slots: by read id too) */
+                if (c->k > 64) hipLaunchKernelGGL((index_count_kernel<false, true, true>), g, dim3(256), 0, c->stream, v, c->d_bkt, rec_by_id, c->d_okey, (u64)xb[0], (u64)xb[1], pl.ocnt, oslot_by_id, pl.oshift);
+                else hipLaunchKernelGGL((index_count_kernel<false, false, true>), g, dim3(256), 0, c->stream, v, c->d_bkt, rec_by_id, c->d_okey, (u64)xb[0], (u64)xb[1], pl.ocnt, oslot_by_id, pl.oshift);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+    }
     /* records -> owner of their bucket range */
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(2 * nloc, 1)));
     std::vector<u64> scnt, rcnt, matrix;
@@ -5406,7 +5428,16 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
     di.own_reads = c->home_hi - c->home_lo;
     c->dist_active = true;
     c->part_index = (flags & DISCO_DIST_KEEP_INDEX_PARTITIONED) != 0 || getenv("DISCO_DIST_PARTITIONED_INDEX") != nullptr;
-    const bool want_loci = allow_loci && !c->part_index && c->prm.max_substitutions == 0 && c->n < (1ull << 30) && !getenv("DISCO_DIST_ID_RANGES") && !getenv("DISCO_DIST_FORCE_GATHER");
+    /* Round 6 — two classes of rows under a communicator (the reference packs every read at its own length,
+     * BG/HashTable.cpp:456-477): a job whose table is wider than 64 bytes because of a FEW long reads (buildG --gpus N on a set with one
+     * 600 bp read used to pay the generic probe and the wide-row verify for everybody: 1.6 x) gets 64-byte rows on every rank — each rank
+     * converts its replica once the gather of the reads is through (two_class_convert: one pass over the table; the same decision on
+     * every rank, from the same table), the pass runs over id ranges (the own reads' index pass needs the converted table, i.e. the whole
+     * gather: nothing is dealt ahead), the long reads of a rank's range take the long class's kernels as on one GPU. Every rank decides
+     * alike: the shape of the JOB (stride, longest read: dist_validate reduced them). DISCO_DIST_NO_TWO_CLASS=1: one stride, as before. */
+    const bool ragged_job = !c->part_index && c->prm.max_substitutions == 0 && !getenv("DISCO_DIST_NO_TWO_CLASS") && !getenv("DISCO_NO_TWO_CLASS") &&
+                            (c->two_class || (c->S > VERIFY_SW && c->max_len > (u32)DISCO_SHORT_MAX));
+    const bool want_loci = allow_loci && !ragged_job && !c->part_index && c->prm.max_substitutions == 0 && c->n < (1ull << 30) && !getenv("DISCO_DIST_ID_RANGES") && !getenv("DISCO_DIST_FORCE_GATHER");
     c->n_push_r = 0;
     c->h_len.clear();
     /* 0. everybody gets every read — on the second communicator and stream: the index build and the probe of the own reads
@@ -5420,7 +5451,7 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
     const bool one_comm = c->comm_bulk == nullptr || getenv("DISCO_DIST_ONE_COMM") != nullptr;
     DiscoComm *const bulk = one_comm ? c->comm : c->comm_bulk;
     const hipStream_t bstream = one_comm ? c->stream : c->bulk_stream;
-    if (flags & DISCO_DIST_GATHER_READS) {
+    if ((flags & DISCO_DIST_GATHER_READS) && !c->two_class) { /* (a table that has its two classes is complete: an earlier pass gathered it) */
         const auto t0 = HClock::now();
         const u64 row_bytes = (u64)c->S * 8;
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* the own rows are in place */
@@ -5456,6 +5487,13 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
         c->wait_bulk_before_verify = true;
         di.bytes_sent[DISCO_X_READS] += (u64)(G - 1) * c->per * (sent_row_bytes + 2);
         di.ms[DISCO_X_READS] += ms_since(t0); /* time to ISSUE it (RCCL: asynchronous; in-process transport: the copies themselves) */
+    }
+    if (ragged_job && !c->two_class) {
+        if (c->wait_bulk_before_verify) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bulk, 0)); /* the whole table, then its two classes */
+        c->dist_two_class = true;
+        const int rc2 = two_class_convert(c);
+        c->dist_two_class = false;
+        CHK(rc2);
     }
     if (want_loci) CHK(dist_deal_reads(c));
     di.placement = c->loci ? 1u : 0u;

@@ -10,7 +10,7 @@ import numpy as np
 from disco_amd import buildgraph
 
 
-def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flags=0, max_substitutions=0, subs_out=None, partitioned_index=False):
+def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flags=0, max_substitutions=0, subs_out=None, partitioned_index=False, inspect=None):
     """setup(g) puts this rank's reads into context g (collective calls allowed). Returns (edges of all ranks, contained
     rows of all ranks, info of rank 0, infos); subs_out: a list that receives the substitutions of the edges, in their order"""
     gs = [buildgraph.BuildGraph(min_overlap=min_overlap, device=device, flags=flags, max_substitutions=max_substitutions) for _ in range(G)]
@@ -24,6 +24,8 @@ def run_ranks(G, min_overlap, setup, device=0, gather_reads=True, passes=1, flag
             for _ in range(passes):
                 g.dist_run_graph(gather_reads, partitioned_index)
             out[r] = (g.fetch_edges(), g.fetch_contained(), g.dist_info(), g.fetch_edge_substitutions() if subs_out is not None else None)
+            if inspect is not None:  # (a dict: rank -> whatever the caller reads off the rank's context)
+                inspect[r] = {"long_rows": g.long_rows, "probe_run_words": g.probe_run_words()}
         except Exception as e:  # pragma: no cover
             errors.append((r, repr(e)))
 

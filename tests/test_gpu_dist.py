@@ -354,3 +354,45 @@ def test_a_pass_allocates_nothing_and_reports_what_it_did():
         assert i["arena_bytes"] > 0 and 0 < i["arena_peak"] <= i["arena_bytes"] and i["hbm_peak"] >= i["arena_peak"]
         assert 10 <= i["comm_ops"] <= 24 and 10 <= i["host_syncs"] <= 45 and i["kernel_ms"] > 0, i  # (round 4: 23 / 52 at this shape)
     assert info["e_out"] == len(edges) > 0
+
+
+@pytest.mark.parametrize("G", [2, 3, 4])
+def test_ranks_with_a_tail_of_long_reads_keep_64_byte_rows(G):
+    """round 6: two classes of rows under a communicator. tail_20k — 20 000 reads, 1 % of them 600 bp — used to put every
+    rank on a 24-word stride (the generic probe, the wide-row verify); now every rank converts its replica once the gather is through and
+    runs the 64-byte kernels, the long reads of its range through the long class. Two passes (the second finds the table converted);
+    the REAL reference's files"""
+    reads, fidx, mo = gu.case_inputs("tail_20k")
+    seen = {}
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G, passes=2, inspect=seen)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden("tail_20k", ce, cc)
+    n_long = sum(len(r) > 256 for r in reads)
+    assert all(seen[r]["long_rows"] == n_long > 100 and seen[r]["probe_run_words"] > 0 for r in range(G)), seen
+    assert all(i["placement"] == 0 for i in infos)  # over id ranges: the own reads' index pass needs the converted table
+
+
+def test_ranks_with_long_reads_one_stride_on_request(monkeypatch):
+    """DISCO_DIST_NO_TWO_CLASS=1: the table of rounds 1-5 (one stride for everybody) — same files"""
+    monkeypatch.setenv("DISCO_DIST_NO_TWO_CLASS", "1")
+    reads, fidx, mo = gu.case_inputs("tail_20k")
+    seen = {}
+    edges, rows, info, infos = run_ranks_reads(reads, mo, 3, inspect=seen)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden("tail_20k", ce, cc)
+    assert all(seen[r]["long_rows"] == 0 for r in range(3))
+
+
+def test_ranks_two_classes_without_host_waits_and_with_three_word_kmers(monkeypatch):
+    """the same flow over the transport without host waits, and at min-overlap 80 (k = 79) on a generated set: the single-GPU pass's result"""
+    from tests.test_gpu_two_class import mixed_reads
+
+    monkeypatch.setenv("DISCO_LOOP_ASYNC", "1")
+    reads = mixed_reads(21, 4000, 150, 150, 30.0, 0.02, 300, 700)
+    for mo in (40, 80):
+        e1, r1, c1 = run_hip_reads(reads, mo)
+        seen = {}
+        edges, rows, info, _ = run_ranks_reads(reads, mo, 4, inspect=seen)
+        a, b = canon_hip(edges, rows), canon_hip(e1, r1)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), mo
+        assert all(seen[r]["long_rows"] > 0 for r in range(4)) and info["e_out"] == c1["e_out"]
