@@ -129,6 +129,27 @@ __global__ void add_u64_kernel(u64 *__restrict__ p, u64 n, u64 val)
     for (; i < n; i += (u64)gridDim.x * blockDim.x) p[i] += val;
 }
 
+/* the long reads of [lo, hi) — more than DISCO_SHORT_MAX bases — and the longest of the others: what decides whether the job gets two classes
+ * of rows (every rank reduces these over the ranks and decides alike) */
+__global__ void long_stats_kernel(const u16 *__restrict__ len, u64 lo, u64 hi, u64 *__restrict__ out)
+{
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 n_long = 0, smax = 0;
+    for (; i < hi; i += (u64)gridDim.x * blockDim.x) {
+        const u32 L = len[i];
+        if (L > (u32)DISCO_SHORT_MAX) n_long++;
+        else smax = L > smax ? L : smax;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        n_long += (u32)__shfl_down((int)n_long, o);
+        smax = max(smax, (u32)__shfl_down((int)smax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_long) atomicAdd(&out[0], (u64)n_long);
+        atomicMax(&out[1], (u64)smax);
+    }
+}
+
 /* ---- ranks own loci: reads dealt to the ranks by their read-level minimizer ------------------------------------------------- */
 /* the read-level minimizer keys of the reads [lo, hi) alone (okey[i] as index_count_kernel / index_runs_kernel compute it: the smallest
  * 32-bit order hash among all m-mers of the read). The reads are dealt by this key before anything else is computed from them: the

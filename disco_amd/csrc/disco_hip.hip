@@ -181,6 +181,8 @@ struct disco_ctx {
      * stride a few long reads forced; c->S is 8 from then on and S_ext what the caller gave (disco_stride_words, disco_download_reads) */
     bool two_class = false;
     bool dist_two_class = false; /* set by a multi-GPU pass around its two_class_convert (round 6) */
+    u64 job_n_long = 0;          /* ... reads of more than 256 bases in the whole job, and the longest of the others (dist_validate) */
+    u32 job_short_max = 0;
     int S_ext = 0;
     u64 n_long = 0;
     u64 reads_rows = 0; /* rows d_reads was allocated with (two classes: n + n_long) */
@@ -5289,6 +5291,22 @@ static int dist_validate(disco_ctx *c)
     if (nloc) hipLaunchKernelGGL(probes_sum_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_len, c->q_lo, c->q_hi, (u32)c->k, c->d_list_n);
     HIPCHK(c, hipMemcpyAsync(&c->home_probes, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* round 6: the job's long reads and the longest of the others (two classes of rows under a communicator: every rank decides alike) */
+    c->job_n_long = 0;
+    c->job_short_max = c->max_len;
+    if (c->max_len > (u32)DISCO_SHORT_MAX) {
+        u64 *d_ls = nullptr, hls[2] = {0, 0};
+        CHK(dev_alloc(c, &d_ls, 2));
+        HIPCHK(c, hipMemsetAsync(d_ls, 0, 2 * sizeof(u64), c->stream));
+        if (nloc) hipLaunchKernelGGL(long_stats_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, (const u16 *)c->d_len, c->q_lo, c->q_hi, d_ls);
+        HIPCHK(c, hipMemcpyAsync(hls, d_ls, sizeof hls, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c, &d_ls, 2);
+        CHK(host_reduce(c, &hls[0], 1));
+        CHK(host_reduce(c, &hls[1], 1, true));
+        c->job_n_long = hls[0];
+        c->job_short_max = (u32)hls[1];
+    }
     c->phase = 1;
     return DISCO_OK;
 }
@@ -5435,8 +5453,15 @@ static int dist_run_graph_pass(disco_ctx *c, uint32_t flags, bool allow_loci, bo
      * every rank, from the same table), the pass runs over id ranges (the own reads' index pass needs the converted table, i.e. the whole
      * gather: nothing is dealt ahead), the long reads of a rank's range take the long class's kernels as on one GPU. Every rank decides
      * alike: the shape of the JOB (stride, longest read: dist_validate reduced them). DISCO_DIST_NO_TWO_CLASS=1: one stride, as before. */
-    const bool ragged_job = !c->part_index && c->prm.max_substitutions == 0 && !getenv("DISCO_DIST_NO_TWO_CLASS") && !getenv("DISCO_NO_TWO_CLASS") &&
-                            (c->two_class || (c->S > VERIFY_SW && c->max_len > (u32)DISCO_SHORT_MAX));
+    bool ragged_job = false;
+    if (!c->part_index && c->prm.max_substitutions == 0 && !getenv("DISCO_DIST_NO_TWO_CLASS") && !getenv("DISCO_NO_TWO_CLASS")) {
+        if (c->two_class) ragged_job = true;
+        else if (c->S > VERIFY_SW && c->job_n_long) { /* the test of a single GPU (at most one long read in five, run lists for the others), on the JOB's figures */
+            c->dist_two_class = true;
+            ragged_job = two_class_ok(c, c->S, c->n, c->job_n_long, c->job_short_max);
+            c->dist_two_class = false;
+        }
+    }
     const bool want_loci = allow_loci && !ragged_job && !c->part_index && c->prm.max_substitutions == 0 && c->n < (1ull << 30) && !getenv("DISCO_DIST_ID_RANGES") && !getenv("DISCO_DIST_FORCE_GATHER");
     c->n_push_r = 0;
     c->h_len.clear();

@@ -148,6 +148,29 @@ def test_buildg_launcher_retries_a_stalled_first_try_and_delivers(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_buildg_multi_rank_on_a_set_with_a_few_long_reads(tmp_path, gpus):
+    """round 6: `buildG --gpus N` on a set with 1 % reads of 600 bp (tail_20k, the REAL reference's files as the fixture): every rank runs the
+    64-byte-row kernels (two classes of rows under a communicator) — the log says so — and the files are the reference's"""
+    from disco_amd import readgen
+
+    build.build_host()
+    reads, fidx, mo = gu.case_inputs("tail_20k")
+    fa = tmp_path / "tail.fasta"
+    readgen.write_fasta(str(fa), reads)
+    cfg = tmp_path / "disco.cfg"
+    cfg.write_text(f"MinOverlap4BuildGraph = {mo}\n")
+    prefix = str(tmp_path / "g")
+    p = subprocess.run([os.path.join(BIN, "buildG"), "-se", str(fa), "-f", prefix, "-p", str(cfg), "-t", "2", "--gpus", str(gpus), "--same-device"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DISCO_VERBOSE="1"), timeout=300)
+    assert p.returncode == 0, p.stdout
+    assert p.stdout.count("two classes of rows") == gpus, p.stdout  # one line per rank's context
+    edges = refrun.parse_pargraph(sorted(glob.glob(prefix + "_*_parGraph.txt")))
+    cont = refrun.parse_contained(sorted(glob.glob(prefix + "_*_containedReads.txt")))
+    gu.check_against_golden("tail_20k", edges, cont)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("threads,gpus,mpi_names,part", [(1, 1, False, False), (4, 1, False, False), (3, 2, False, False), (3, 2, True, False), (2, 3, True, False),
                                                          (1, 2, True, False), (3, 3, False, True)])
 def test_buildg_cli_multifile_matches_reference(tmp_path, threads, gpus, mpi_names, part):

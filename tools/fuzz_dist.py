@@ -23,6 +23,7 @@ from tests.util import assert_parity, canon_hip, run_hip_reads  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 inexact = len(sys.argv) > 3 and sys.argv[3] == "inexact"
+tail = len(sys.argv) > 3 and sys.argv[3] == "tail"  # round 6: reads of up to 256 bases with a tail of long ones — two classes of rows under a communicator
 fails = 0
 t0 = time.time()
 for it in range(iters):
@@ -49,13 +50,27 @@ for it in range(iters):
         lmax = lmin if rng.random() < 0.3 else int(min(256, lmin + rng.integers(1, 2 * lmin)))
         mo = 40 if lmin > 48 else max(31, lmin - 8)
         part = mo == 40 and rng.random() < 0.5
-    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} G={G} two_pass_in_ranks={tp} partitioned_index={part}"
+    long_len = long_share = 0
+    if tail:
+        lmin = int(rng.choice([45, 60, 100, 150, 151, 200, 256]))
+        lmax = lmin if rng.random() < 0.3 else int(min(256, lmin + rng.integers(1, 2 * lmin)))
+        mo = int(rng.choice([33, 40, 40, 58, 66, 80])) if lmin > 100 else max(31, lmin - 8)
+        part = False
+        long_len = int(rng.choice([257, 300, 400, 600, 1000, 1024, 1025, 2000]))
+        long_share = int(rng.choice([66, 300, 1300, 3900, 9800]))
+        n = min(n, 4000)
+        if rng.random() < 0.5:
+            os.environ["DISCO_LOOP_ASYNC"] = "1"
+        else:
+            os.environ.pop("DISCO_LOOP_ASYNC", None)
+    label = f"it{it} seed={seed} n={n} len={lmin}-{lmax} mo={mo} cov={cov} nc={nc} skew={skew} G={G} two_pass_in_ranks={tp} partitioned_index={part}" + (
+        f" long={long_len} share={long_share}/65536 async={os.environ.get('DISCO_LOOP_ASYNC', '0')}" if tail else "")
     if os.environ.get("FUZZ_VERBOSE"):
         print("start", label, flush=True)
     try:
-        spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew)
+        spec = readgen.GenSpec.coverage(seed, n, lmin, cov, n_contigs=nc, len_max=lmax, skew=skew, long_len=long_len, long_share=long_share)
         reads = list(readgen.generate_reads(spec))
-        if rng.random() < 0.25:  # repeats: the cap binds, one-sided pairs -> the order-dependent regime (adjacency gathered)
+        if not tail and rng.random() < 0.25:  # repeats: the cap binds, one-sided pairs -> the order-dependent regime (adjacency gathered)
             r3 = np.random.default_rng(seed + 1)
             rep = "".join(r3.choice(list("ACGT"), int(r3.integers(60, 400))))
             genome = "".join("".join(r3.choice(list("ACGT"), int(r3.integers(30, 300)))) + rep for _ in range(int(r3.integers(3, 40))))
