@@ -18,7 +18,9 @@ lmax = int(sys.argv[4]) if len(sys.argv) > 4 else lmin
 cov = float(sys.argv[5]) if len(sys.argv) > 5 else 30.0
 passes = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 genome = int(n * (lmin + lmax) / 2 / cov)
-spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=max(1, genome // 5_000_000), len_max=lmax)
+# LONG_SHARE=s LONG_LEN=l: s / 65536 of the reads have l bases instead (two classes of rows under a communicator; DISCO_DIST_NO_TWO_CLASS=1: one stride)
+spec = readgen.GenSpec.coverage(42, n, lmin, cov, n_contigs=max(1, genome // 5_000_000), len_max=lmax, long_len=int(os.environ.get("LONG_LEN", "600")) if os.environ.get("LONG_SHARE") else 0,
+                                long_share=int(os.environ.get("LONG_SHARE", "0")))
 t0 = time.time()
 ppm = int(os.environ.get("ERRORS_PPM", "0"))
 
@@ -30,6 +32,7 @@ def setup(g):
 
 
 edges, rows, info, infos = run_ranks(G, 40, setup, passes=passes, partitioned_index=bool(os.environ.get("PARTITIONED_INDEX")))
+print(f"kernel ms over the ranks, last pass: {sum(i['kernel_ms'] for i in infos):.1f}; pass wall of rank 0: {info['ms_total']:.1f} ms")
 print(f"wall {time.time() - t0:.2f} s; e_pre {info['e_pre']} e_out {info['e_out']} contained {info['n_contained']} regime {info['regime']} "
       f"tr_rounds {info['tr_rounds']} deferred {info['tr_deferred']} asymmetric_pairs {info['asymmetric_pairs']} dropped {info['dropped_hits']}")
 for i in infos:
