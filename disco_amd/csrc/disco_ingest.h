@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
         /* counters packed into words (a dynamically indexed local array would live in scratch memory): A | C << 32, G | T << 32, the six
          * dimers of two different letters — their occurrences cannot overlap, so plain counts — AC | AG << 21 | AT << 42, CG | CT << 21 | GT << 42 */
         u64 acgt01 = 0, acgt23 = 0, dimA = 0, dimB = 0, other = 0;
+        u32 aa = 0; /* "AA" adjacencies (round 6: the bound that keeps TAA / CAA / GAA off the greedy scan, below) */
         u64 head = 0, tail = 0;
         u32 prev = 4;
         /* FASTA: the newlines inside [sb, se) are not part of the sequence (BG/Dataset.cpp:270-281). W = bases on the first line; the
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
                 if (prev == 0) dimA += 1ull << (21 * (c - 1));
                 else dimB += 1ull << (21 * (prev + c - 3));
             }
+            aa += (c == 0 && prev == 0) ? 1u : 0u;
             tail = ((tail << 2) | (c & 3u)) & ((1ull << 58) - 1ull);
             if (L == 28) head = tail;
             prev = c;
@@ -277,13 +279,29 @@ __global__ void __launch_bounds__(256) fx_filter_kernel(FxFilterArgs a, FxTables
                 if (skip) continue;
                 u64 covered;
                 const u32 x = fx_code(tb.motif[mi][0]), y = fx_code(tb.motif[mi][1]);
+                /* round 6: a second exact bound before the greedy scan — every occurrence of the motif contains each of its adjacent letter
+                 * pairs, and occurrences that do not overlap contain DIFFERENT adjacencies of the read: hits <= the read's count of any pair
+                 * inside the motif. The pass above counts the six pairs of two different ascending letters and "AA": one of them lies inside
+                 * every trimer of the table (AAT ATA AAC ACA AAG AGA: AT / AC / AG; TAA CAA GAA: AA). The base-count bound alone let one read
+                 * in a hundred through per motif — a 0.9 % tail of the binomial — i.e. nearly every WAVEFRONT took the scan for some lane:
+                 * 87 ms of the stage at 50 M reads, thirty times the pass that counts. */
+                if (ml >= 3) {
+                    u64 pair_bound = ~0ull;
+                    for (u32 t = 0; t + 1 < ml; t++) {
+                        const u32 p0 = fx_code(tb.motif[mi][t]), p1 = fx_code(tb.motif[mi][t + 1]);
+                        if (p0 < p1 && p1 < 4) pair_bound = min(pair_bound, (u64)dim[p0 == 0 ? p1 - 1 : (p0 == 1 ? p1 + 1 : 5)]);
+                        else if (p0 == 0 && p1 == 0) pair_bound = min(pair_bound, (u64)aa);
+                    }
+                    if (pair_bound != ~0ull && pair_bound * ml < thr) continue;
+                }
                 if (ml == 2 && x < y && y < 4) {
                     covered = 2ull * dim[x == 0 ? y - 1 : (x == 1 ? y + 1 : 5)];
                 } else { /* left to right, non-overlapping: BG/Common.h:173-183 */
                     u64 hits = 0;
+                    const bool one_line = wrap == (u32)L; /* (no newline inside the sequence: byte = sb + base, no division per byte) */
                     for (u64 q = 0; q + ml <= L;) {
                         bool eq = true;
-                        for (u32 t = 0; t < ml && eq; t++) eq = fx_upper(tx.at(fx_raw_of(tx, sb, wrap, (u32)(q + t)))) == tb.motif[mi][t];
+                        for (u32 t = 0; t < ml && eq; t++) eq = fx_upper(tx.at(one_line ? sb + q + t : fx_raw_of(tx, sb, wrap, (u32)(q + t)))) == tb.motif[mi][t];
                         if (eq) {
                             hits++;
                             q += ml;
