@@ -1293,7 +1293,12 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                     const u64 key = mmer_key<true>(s_rows + OCC_SLOT(d) * RS, RS, prel, m);
                     const u64 b = key >> a.v.bshift;
                     uint2 se;
+#if defined(PR_EXP) && PR_EXP == 3 /* timing experiment (results are wrong): the bucket bounds from one line */
+                    __builtin_memcpy(&se, a.v.bkt + (b & 7u), sizeof se);
+                    se.y = se.x + 3u;
+#else
                     __builtin_memcpy(&se, a.v.bkt + b, sizeof se); /* bkt[b], bkt[b + 1] */
+#endif
                     st = se.x;
                     cnt = se.y - se.x;
                     fp = KEY_FP(key);
@@ -1336,7 +1341,11 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                     if (!in) lo = 0;
                     const u32 dd = s_o_desc[lo];
                     u64 pay = 0;
+#if defined(PR_EXP) && PR_EXP == 2 /* timing experiment (results are wrong): the records from ONE line instead of the buckets' */
+                    if (in) pay = a.v.ent[lane];
+#else
                     if (in) pay = a.v.ent[s_o_start[lo] + (idx - s_o_excl[lo])];
+#endif
                     const u32 dslot = OCC_SLOT(dd), rv = OCC_STRAND(dd);
                     const int wst = (int)OCC_FIRST(dd), wen = (int)OCC_END(dd), prel = wst + (int)OCC_DELTA(dd);
                     const int t = (int)PAY_T(pay);
@@ -3595,15 +3604,6 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
                 if (lane == r0 + r) nacc_me = tot;
             }
             __syncthreads();
-#if defined(SEL_EXP) && SEL_EXP == 2 /* timing experiment (results are wrong): rows leave unsorted — without steps 3 and 4 */
-#pragma unroll
-            for (int i = 0; i < NB; i++)
-                if ((u32)i < nbat && (segm[i] & 64u)) {
-                    const u32 seg = segm[i] & 63u;
-                    a.hits[s_hdr[seg].x + (base + 64u * (u32)i + lane - (u32)s_hdr[seg].y)] = ent[i];
-                }
-            continue;
-#endif
             /* 3. entries to their bins' places (arrival order inside a bin); segm: read | go << 6 | arrival rank << 8 | bin size << 16 | first position << 24 */
 #pragma unroll
             for (int i = 0; i < NB; i++) {
