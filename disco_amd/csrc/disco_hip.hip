@@ -2687,7 +2687,13 @@ static int select_edges(disco_ctx *c)
     /* sub-chunks of up to 4 rows / 4 batches: 9.7 KB of LDS, 16 waves per CU. Larger ones fill their last batch better and repeat the
      * per-sub-chunk work less often (8 rows: 140 instead of 175 vector instructions per read) but hold 11 waves per CU, and the kernel's
      * time follows the resident waves (LDS round trips between its phases): 8 x 4: 25.4 ms, 4 x 4: 19.2 ms at 50 M reads */
-    if (nq && flat_select && select_small) hipLaunchKernelGGL((edge_select_flat_kernel<3, 2, true>), dim3(wq_grid(c, edge_select_flat_kernel<3, 2, true>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
+    /* (round 6: sub-chunks of 4 rows x 3 batches — 16.35 against 17.1 ms with 3 x 2; in round 5 that shape spilled three registers with the
+     * sequential path compiled in, the branch-free load pipeline made room; 4 x 4, 5 x 3 and 5 x 4 still spill 12 / 3 / 17) */
+#ifndef SEL_SMALL_ROWS
+#define SEL_SMALL_ROWS 4
+#define SEL_SMALL_NB 3
+#endif
+    if (nq && flat_select && select_small) hipLaunchKernelGGL((edge_select_flat_kernel<SEL_SMALL_ROWS, SEL_SMALL_NB, true>), dim3(wq_grid(c, edge_select_flat_kernel<SEL_SMALL_ROWS, SEL_SMALL_NB, true>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     else if (nq && flat_select) hipLaunchKernelGGL((edge_select_flat_kernel<4, 4>), dim3(wq_grid(c, edge_select_flat_kernel<4, 4>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     else if (nq) hipLaunchKernelGGL(edge_select_kernel<false>, dim3(wq_grid(c, edge_select_kernel<false>, nq, "DISCO_SELECT_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_SELECT);
