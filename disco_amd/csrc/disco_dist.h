@@ -21,10 +21,10 @@ struct RouteByBucket { /* index records {bucket << 32 | slot, record} */
     __device__ __forceinline__ u32 operator()(const ulonglong2 &r) const { return (u32)(((r.x >> 32) * (u64)G) >> logT); }
 };
 /* (otab: ranks own loci — the owner of a node comes out of the table; null: id ranges of `per` nodes) */
-struct RouteByRowRequest { /* u << 1 | cls */
+struct RouteByRowRequest { /* the node whose row is asked for */
     u64 per;
     const u8 *otab;
-    __device__ __forceinline__ u32 operator()(const u32 &r) const { return otab ? (u32)otab[r >> 1] : (u32)((u64)(r >> 1) / per); }
+    __device__ __forceinline__ u32 operator()(const u32 &r) const { return otab ? (u32)otab[r] : (u32)((u64)r / per); }
 };
 struct RouteByNode { /* {node id, payload} */
     u64 per;
@@ -251,26 +251,41 @@ __global__ void read_items_place_kernel(const ReadItem<W> *__restrict__ items, u
     }
 }
 
+/* bucket of a key in the grouping of ONE rank's reads: the rank's share of the hash range (disco_key_owner: [me, me + 1) * 2^32 / G)
+ * stretched over all 32 bits again, so that the rank's groups spread over all its buckets as the groups of a whole job do */
+__device__ __forceinline__ u32 order_bucket_local(u32 key, u32 G, u32 me, u32 shift)
+{
+    const u32 h = key * 0x9E3779B1u;
+    const u64 lo = (((u64)me << 32) + G - 1) / G; /* smallest h with (h * G) >> 32 == me */
+    const u64 x = ((u64)h - lo) * (u64)G;
+    return (u32)(x > 0xFFFFFFFFull ? 0xFFFFFFFFull : x) >> shift;
+}
 /* owner of every read from its key (disco_key_owner) and the list of the own reads' ids: in id order inside a tile of OWN_TILE reads,
  * the tiles in the order their blocks arrive (one counting atomic per tile; the grouping that follows re-orders the list anyway) */
+/* ocnt != null: the counting pass of the grouping rides along (order_count_list_kernel's: the own read's slot in its bucket, by its
+ * position in the list) — the key is in a register here, and the list need not be walked once more */
 #define OWN_TILE 4096
 __global__ void __launch_bounds__(256) own_select_kernel(const u32 *__restrict__ okey, u64 n, u32 G, u32 me, u8 *__restrict__ otab, u32 *__restrict__ own_ids,
-                                                         u64 *__restrict__ n_own)
+                                                         u64 *__restrict__ n_own, u32 *__restrict__ ocnt, u32 *__restrict__ oslot, u32 oshift)
 {
     __shared__ u32 s_w[4];
     __shared__ u64 s_base;
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     for (u64 t0 = (u64)blockIdx.x * OWN_TILE; t0 < n; t0 += (u64)gridDim.x * OWN_TILE) {
         u32 mask = 0, cnt = 0;
+        u32 slot[OWN_TILE / 256];
 #pragma unroll
         for (int q = 0; q < OWN_TILE / 256; q++) {
             const u64 i = t0 + (u64)q * 256u + tid;
+            slot[q] = 0;
             if (i < n) {
-                const u32 o = disco_key_owner(okey[i], G);
+                const u32 key = okey[i];
+                const u32 o = disco_key_owner(key, G);
                 otab[i] = (u8)o;
                 if (o == me) {
                     mask |= 1u << q;
                     cnt++;
+                    if (ocnt) slot[q] = atomicAdd(&ocnt[order_bucket_local(key, G, me, oshift)], 1u);
                 }
             }
         }
@@ -287,19 +302,13 @@ __global__ void __launch_bounds__(256) own_select_kernel(const u32 *__restrict__
         /* (thread t holds reads t, t + 256, ...: inside the tile the list is in id order only per thread; nobody relies on it) */
 #pragma unroll
         for (int q = 0; q < OWN_TILE / 256; q++)
-            if (mask & (1u << q)) own_ids[at++] = (u32)(t0 + (u64)q * 256u + tid);
+            if (mask & (1u << q)) {
+                if (ocnt) oslot[at] = slot[q];
+                own_ids[at++] = (u32)(t0 + (u64)q * 256u + tid);
+            }
     }
 }
 
-/* bucket of a key in the grouping of ONE rank's reads: the rank's share of the hash range (disco_key_owner: [me, me + 1) * 2^32 / G)
- * stretched over all 32 bits again, so that the rank's groups spread over all its buckets as the groups of a whole job do */
-__device__ __forceinline__ u32 order_bucket_local(u32 key, u32 G, u32 me, u32 shift)
-{
-    const u32 h = key * 0x9E3779B1u;
-    const u64 lo = (((u64)me << 32) + G - 1) / G; /* smallest h with (h * G) >> 32 == me */
-    const u64 x = ((u64)h - lo) * (u64)G;
-    return (u32)(x > 0xFFFFFFFFull ? 0xFFFFFFFFull : x) >> shift;
-}
 /* the grouping (order_count_kernel / order_scatter_kernel) over a list of read ids */
 __global__ void order_count_list_kernel(const u32 *__restrict__ okey, const u32 *__restrict__ ids, u64 nq, u32 G, u32 me, u32 shift, u32 *__restrict__ cnt, u32 *__restrict__ oslot)
 {
@@ -401,19 +410,10 @@ __global__ void add_u32_kernel(u32 *__restrict__ p, u64 n, u32 val)
 }
 
 /* ---- neighbour rows on request (transitive reduction) -------------------------------------------------------------- */
-/* both reference words of the rank's own nodes address the node's row where edge selection left it (TR_LOCAL: 8-byte entries in
- * adj; the sweep filters by type itself) */
-__global__ void nref_local_kernel(const u64 *__restrict__ ref, OwnSet own, u64 *__restrict__ nref)
-{
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 nloc = own.count();
-    for (; i < nloc; i += (u64)gridDim.x * blockDim.x) {
-        const u64 v = own.node_by_id(i);
-        const u64 r = ref[v] | TR_LOCAL;
-        nref[2 * v] = r;
-        nref[2 * v + 1] = r;
-    }
-}
+/* Round 6: a fetched row is the WHOLE row of the other rank's node, kept as 8-byte entries behind the rank's own rows in the same array,
+ * under the node's ONE reference word ref[u] (0 = not fetched; asked[]: one bit per node, set by the first request for it) — the marking
+ * kernel reads it as it reads an own row (TrArgs). Rounds 2-5 fetched the entries of one class (u, cls) as 4-byte entries into a store of their own behind two
+ * reference words per node: the marking variant that read both kinds of rows cost 5.5 ms more than the plain kernel at 50 M reads. */
 
 /* append the lanes' requests (0xFFFFFFFF = none) to the list: one atomic per wavefront */
 __device__ __forceinline__ void request_append(u32 rq, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
@@ -432,33 +432,32 @@ __device__ __forceinline__ void request_append(u32 rq, u32 *__restrict__ list, u
     }
 }
 
-/* the (u, cls) a sweep from this entry needs, if u is remote and nobody on this rank has asked for it yet */
-__device__ __forceinline__ u32 request_for(u64 e, const OwnSet &own, u64 *__restrict__ nref)
+/* the node whose row a sweep from this entry needs, if it is another rank's and nobody on this rank has asked for it yet: a test-and-set
+ * on a bitmap by node (n / 8 bytes: it lives in the L2; rounds 2-4 marked an 8-byte word of a table of 16 n bytes, and round 5 asked without
+ * looking). ROUND2: rows that round 1 brought are there (ref[u] != 0) */
+template <bool ROUND2>
+__device__ __forceinline__ u32 request_for(u64 e, const OwnSet &own, const u64 *__restrict__ ref, u32 *__restrict__ asked)
 {
     const u64 u = ADJ_DST(e);
     if (own.mine(u)) return 0xFFFFFFFFu;
-    const u32 cls = (~ADJ_ORI(e)) & 1u;
-    if (atomicCAS(&nref[2 * u + cls], TR_UNAVAIL, TR_REQUESTED) != TR_UNAVAIL) return 0xFFFFFFFFu;
-    return ((u32)u << 1) | cls;
+    if (ROUND2 && ref[u] != TR_UNAVAIL) return 0xFFFFFFFFu;
+    const u32 bit = 1u << (u & 31u);
+    if (atomicOr(&asked[u >> 5], bit) & bit) return 0xFFFFFFFFu;
+    return (u32)u;
 }
 
 /* round 1: every register-resident node (degree <= 64) asks for the two rows its marking sweeps for certain — slot 0 and the
- * first slot on the other side of the node (exactly transitive_mark_kernel's speculative pair). Eight lanes per node read its row 64
- * bytes at a time (round 4; one lane per node walked its row entry by entry, a sector per step: 2.5 ms per rank at 8 x 6.25 M
- * nodes) and count, while they are at it, the entries on either side of the node: cls_cnt[i] = entries a sweep of class 0 uses |
- * entries a sweep of class 1 uses << 16 (BG/OverlapGraph.cpp:705-708: class 1 -> types 0/1, class 0 -> types 2/3), what the owner
- * answers a request's size from (tr_respond_deg_kernel) instead of reading the row once more. 0xFFFFFFFF: too long to count here. */
-/* (cls_cnt is indexed by node id minus cls_base: the own range's first id, or 0 where the own nodes are no range) */
-__global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restrict__ ref, const u64 *__restrict__ adj, OwnSet own,
-                                                               u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr,
-                                                               u32 *__restrict__ cls_cnt, u64 cls_base)
+ * first slot on the other side of the node (exactly transitive_mark_kernel's speculative pair). One lane per node; the row's first eight
+ * entries — a 64-byte line or two — are loaded at once (the first entry on the other side is among the first few; a loop that walks the row
+ * entry by entry is a chain of dependent loads per lane: 2.3 ms per rank at 8 x 6.25 M nodes), the rare row without one among them is
+ * walked */
+__global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restrict__ adj, OwnSet own, const u64 *__restrict__ ref, u32 *__restrict__ asked,
+                                                               u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
 {
     const u64 nloc = own.count();
-    const u32 lane = threadIdx.x & 63u, sub = lane & 7u, g0 = lane & ~7u;
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    __shared__ u32 s_rq[1][128]; /* (one wavefront per workgroup) the requests of a block of 64 nodes */
-    /* ... collected over many blocks and appended 2048 at a time: the list's counter is ONE address, and an atomic per block of 64 nodes
-     * (195 000 per rank) was 2.3 of this kernel's 2.6 ms */
+    const u32 lane = threadIdx.x;
+    /* the requests are collected over many blocks of 64 nodes and appended 2048 at a time: the list's counter is ONE address, and an atomic
+     * per block of 64 nodes (195 000 per rank) is 2.3 ms per rank */
     __shared__ u32 s_out[2048 + 128];
     u32 n_out = 0; /* wave uniform */
     auto flush = [&]() {
@@ -478,90 +477,47 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
         if (has) s_out[n_out + __popcll(mk & lane_mask_lt())] = rq;
         n_out += (u32)__popcll(mk);
     };
-    u32 *rqs = s_rq[0];
-    for (u64 blk = wave * 64; blk < nloc; blk += nwaves * 64) { /* (wave uniform: 64 nodes per wavefront and trip, eight at a time) */
-        rqs[lane] = 0xFFFFFFFFu;
-        rqs[lane + 64] = 0xFFFFFFFFu;
-        __syncthreads();
-        for (u32 t = 0; t < 8; t++) {
-            const u64 i = blk + 8 * t + (lane >> 3);
-            const bool live = i < nloc;
-            const u64 vme = live ? own.node(i) : 0ull;
-            const u64 rv = live ? ref[vme] : 0ull;
-            const u32 d = REF_DEG(rv);
+    for (u64 blk = (u64)blockIdx.x * 64; blk < nloc; blk += (u64)gridDim.x * 64) { /* (wave uniform) */
+        const u64 i = blk + lane;
+        u32 rq0 = 0xFFFFFFFFu, rq2 = 0xFFFFFFFFu;
+        const u64 rv = i < nloc ? ref[own.node(i)] : 0ull;
+        const u32 d = REF_DEG(rv);
+        if (d != 0 && d <= 64) {
             const u64 *row = adj + REF_POS(rv);
-            u32 dmax = d < 65536u ? d : 0u;
-            dmax = max(dmax, (u32)__shfl_xor((int)dmax, 8));
-            dmax = max(dmax, (u32)__shfl_xor((int)dmax, 16));
-            dmax = max(dmax, (u32)__shfl_xor((int)dmax, 32));
-            u32 n_side0 = 0, n_side1 = 0, side0 = 0;
-            u64 e0 = 0, e2 = 0;
+            u64 e[8];
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) e[s] = row[s < d ? s : d - 1];
+            const u32 side0 = ADJ_ORI(e[0]) >> 1;
+            u64 e2 = 0;
             bool has2 = false;
-            for (u32 s0 = 0; s0 < dmax; s0 += 8) {
-                /* without the counts (cls_cnt == null: the owner counts the few rows that are asked for itself) a node is done once its
-                 * two entries are found — the first entry on the other side is among the first few of the row */
-                if (!cls_cnt && !__any(live && !has2 && s0 < d && d <= 64u)) break;
-                const u32 s = s0 + sub;
-                const bool in = s < d && d < 65536u;
-                const u64 e = in ? row[s] : 0ull;
-                if (s0 == 0) {
-                    e0 = shfl_u64(e, g0);
-                    side0 = ADJ_ORI(e0) >> 1;
-                }
-                const u32 side = ADJ_ORI(e) >> 1;
-                const u32 m1 = (u32)(__ballot(in && side == 1u) >> g0) & 0xFFu, m0 = (u32)(__ballot(in && side == 0u) >> g0) & 0xFFu;
-                n_side1 += (u32)__popc(m1);
-                n_side0 += (u32)__popc(m0);
-                const u32 mo = side0 ? m0 : m1; /* entries on the other side than slot 0 */
-                const u64 cand = shfl_u64(e, g0 + (mo ? (u32)__ffs((int)mo) - 1u : 0u));
-                if (!has2 && mo) {
-                    e2 = cand;
+#pragma unroll
+            for (int s = 7; s >= 1; s--) /* (descending: the first one wins) */
+                if ((u32)s < d && (ADJ_ORI(e[s]) >> 1) != side0) {
+                    e2 = e[s];
                     has2 = true;
                 }
-            }
-            if (live && sub == 0) {
-                if (cls_cnt) cls_cnt[vme - cls_base] = d < 65536u ? (n_side1 | (n_side0 << 16)) : 0xFFFFFFFFu;
-                if (d != 0 && d <= 64) {
-                    /* round 1 asks without looking who else did: marking the word (a random 8-byte compare-and-swap per request,
-                     * 12.5 M per rank: 2 of this kernel's 2.6 ms) saved one request in ten — two nodes of a rank that sweep the same row
-                     * of another rank; now that row travels twice (nref_remote_kernel keeps either copy) */
-                    const u64 u0 = ADJ_DST(e0), u2 = ADJ_DST(e2);
-                    if (!own.mine(u0)) rqs[2 * (8 * t + (lane >> 3))] = ((u32)u0 << 1) | ((~ADJ_ORI(e0)) & 1u);
-                    if (has2 && !own.mine(u2)) rqs[2 * (8 * t + (lane >> 3)) + 1] = ((u32)u2 << 1) | ((~ADJ_ORI(e2)) & 1u);
+            if (!has2)
+                for (u32 s = 8; s < d; s++) {
+                    const u64 x = row[s];
+                    if ((ADJ_ORI(x) >> 1) != side0) {
+                        e2 = x;
+                        has2 = true;
+                        break;
+                    }
                 }
-            }
+            rq0 = request_for<false>(e[0], own, ref, asked);
+            if (has2) rq2 = request_for<false>(e2, own, ref, asked);
         }
-        __syncthreads();
-        stash(rqs[lane]);
-        stash(rqs[lane + 64]);
-        __syncthreads();
+        stash(rq0);
+        stash(rq2);
         if (n_out > 2048) {
+            __syncthreads();
             flush();
             __syncthreads();
         }
     }
     __syncthreads();
     flush();
-}
-
-/* the owner's side: how many entries the answer to request i has — from the counts tr_request_first_kernel left for every own
- * node (rows too long for them: counted here, by the one lane) */
-__global__ void tr_respond_deg_kernel(const u32 *__restrict__ req, u64 n_req, const u32 *__restrict__ cls_cnt, u64 lo, const u64 *__restrict__ ref,
-                                      const u64 *__restrict__ adj, u32 *__restrict__ deg)
-{
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < n_req; i += (u64)gridDim.x * blockDim.x) {
-        const u32 rq = req[i], cls = rq & 1u;
-        const u32 cc = cls_cnt[(u64)(rq >> 1) - lo];
-        u32 n = (cc >> (16u * cls)) & 0xFFFFu;
-        if (cc == 0xFFFFFFFFu) {
-            const u64 rv = ref[rq >> 1];
-            const u64 *row = adj + REF_POS(rv);
-            n = 0;
-            for (u32 s = 0; s < REF_DEG(rv); s++) n += (ADJ_ORI(row[s]) >> 1) != cls ? 1u : 0u;
-        }
-        deg[i] = n;
-    }
 }
 
 /* sum of the degrees of the listed nodes (upper bound of what the request-all round can ask for) */
@@ -594,8 +550,8 @@ __global__ void probes_sum_kernel(const u16 *__restrict__ len, u64 lo, u64 hi, u
 }
 
 /* round 2: the listed nodes (deferred by round 1, or beyond the register path) ask for every row they do not have */
-__global__ void __launch_bounds__(64) tr_request_all_kernel(const u64 *__restrict__ nodes, u64 n_nodes, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
-                                                            OwnSet own, u64 *__restrict__ nref, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
+__global__ void __launch_bounds__(64) tr_request_all_kernel(const u64 *__restrict__ nodes, u64 n_nodes, const u64 *__restrict__ adj, OwnSet own, const u64 *__restrict__ ref,
+                                                            u32 *__restrict__ asked, u32 *__restrict__ list, u64 *__restrict__ n_list, u64 cap, u64 *ctr)
 {
     for (u64 it = blockIdx.x; it < n_nodes; it += gridDim.x) {
         const u64 rv = ref[nodes[it]];
@@ -604,55 +560,49 @@ __global__ void __launch_bounds__(64) tr_request_all_kernel(const u64 *__restric
         for (u32 s0 = 0; s0 < d; s0 += 64) {
             const u32 s = s0 + threadIdx.x;
             u32 rq = 0xFFFFFFFFu;
-            if (s < d) rq = request_for(row[s], own, nref);
+            if (s < d) rq = request_for<true>(row[s], own, ref, asked);
             request_append(rq, list, n_list, cap, ctr);
         }
     }
 }
 
-/* the owner's side: entries of row(u) a sweep of class cls uses (BG/OverlapGraph.cpp:705-708: cls 1 -> types 0/1, cls 0 ->
- * types 2/3), counted (FILL = false) or written as 4-byte entries at out + pos[i] (FILL = true); one wavefront per request */
-template <bool FILL>
-__global__ void __launch_bounds__(64) tr_respond_kernel(const u32 *__restrict__ req, u64 n_req, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
-                                                        u32 *__restrict__ deg, const u64 *__restrict__ pos, u32 *__restrict__ out)
+/* the owner's side: the degree of every requested row ... */
+__global__ void tr_respond_deg_kernel(const u32 *__restrict__ req, u64 n_req, const u64 *__restrict__ ref, u32 *__restrict__ deg)
 {
-    /* four requests per wavefront, sixteen lanes each (round 4; a request's row has about 36 entries, half of them of its class: one
-     * request per wavefront kept 4 of 5 lanes idle and paid its three dependent loads one request at a time) */
-    const u32 lane = threadIdx.x, sub = lane & 15u, g0 = lane & ~15u;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n_req; i += (u64)gridDim.x * blockDim.x) deg[i] = REF_DEG(ref[req[i]]);
+}
+/* ... and its entries as 4 bytes each (destination and orientation: all a sweep reads of a neighbour's row, BG/OverlapGraph.cpp:698-708)
+ * at out + pos[i]; four requests per wavefront, sixteen lanes each */
+__global__ void __launch_bounds__(64) tr_respond_kernel(const u32 *__restrict__ req, u64 n_req, const u64 *__restrict__ ref, const u64 *__restrict__ adj,
+                                                        const u64 *__restrict__ pos, u32 *__restrict__ out)
+{
+    const u32 lane = threadIdx.x, sub = lane & 15u;
     for (u64 i0 = (u64)blockIdx.x * 4; i0 < n_req; i0 += (u64)gridDim.x * 4) {
         const u64 i = i0 + (lane >> 4);
-        const bool live = i < n_req;
-        const u32 rq = live ? req[i] : 0u;
-        const u64 rv = live ? ref[rq >> 1] : 0ull;
-        const u32 cls = rq & 1u, d = live ? REF_DEG(rv) : 0u;
+        if (i >= n_req) continue;
+        const u64 rv = ref[req[i]];
+        const u32 d = REF_DEG(rv);
         const u64 *row = adj + REF_POS(rv);
-        u32 dmax = d;
-        dmax = max(dmax, (u32)__shfl_xor((int)dmax, 16));
-        dmax = max(dmax, (u32)__shfl_xor((int)dmax, 32));
-        u32 n = 0;
-        const u64 base = (FILL && live) ? pos[i] : 0ull;
-        for (u32 s0 = 0; s0 < dmax; s0 += 16) {
-            const u32 s = s0 + sub;
-            u64 e = 0;
-            bool ok = false;
-            if (s < d) {
-                e = row[s];
-                ok = (ADJ_ORI(e) >> 1) != cls;
-            }
-            const u32 mk = (u32)(__ballot(ok) >> g0) & 0xFFFFu;
-            if (FILL && ok) out[base + n + (u32)__popc(mk & ((1u << sub) - 1u))] = NBR32_MAKE(e);
-            n += (u32)__popc(mk);
-        }
-        if (!FILL && live && sub == 0) deg[i] = n;
+        u32 *o = out + pos[i];
+        for (u32 s = sub; s < d; s += 16) o[s] = NBR32_MAKE(row[s]);
     }
 }
 
-/* the requester's side: reference words of the rows that came back (pos = exclusive scan of the received degrees) */
-__global__ void nref_remote_kernel(const u32 *__restrict__ req, u64 n_req, const u32 *__restrict__ deg, const u64 *__restrict__ pos, u64 base,
-                                   u64 *__restrict__ nref)
+/* the requester's side: the rows that came back (pos = exclusive scan of the received degrees) go behind the own rows as 8-byte entries
+ * (offset and length fields 0: never read of a neighbour's row), the nodes' reference words address them */
+__global__ void __launch_bounds__(64) rows_place_kernel(const u32 *__restrict__ req, u64 n_req, const u32 *__restrict__ deg, const u64 *__restrict__ pos,
+                                                        const u32 *__restrict__ in, u64 base, u64 *__restrict__ adj, u64 *__restrict__ ref)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < n_req; i += (u64)gridDim.x * blockDim.x) nref[2 * (u64)(req[i] >> 1) + (req[i] & 1u)] = REF_MAKE(base + pos[i], deg[i]);
+    const u32 lane = threadIdx.x, sub = lane & 15u;
+    for (u64 i0 = (u64)blockIdx.x * 4; i0 < n_req; i0 += (u64)gridDim.x * 4) {
+        const u64 i = i0 + (lane >> 4);
+        if (i >= n_req) continue;
+        const u32 d = deg[i];
+        const u64 p = pos[i];
+        for (u32 s = sub; s < d; s += 16) adj[base + p + s] = NBR32_ENTRY(in[p + s]);
+        if (sub == 0 && d) ref[req[i]] = REF_MAKE(base + p, d); /* (an empty row cannot be a neighbour's: the marking fails loudly) */
+    }
 }
 
 /* ---- twin completion across ranks (some read dropped a verified hit: real data at their repeats) --------------------------- */

@@ -288,13 +288,11 @@ struct disco_ctx {
     bool index_counted = false; /* disco_upload_reads ran the index's count pass behind its copies: disco_build_index starts at the scan */
     u64 order_counted_lo = 0, order_counted_hi = 0;
     int order_counted_bits = 0;
-    u32 *d_cls_cnt = nullptr; /* multi-GPU flow, own nodes: entries on either side of the node (tr_request_first_kernel) */
-    u64 cls_cnt_cap = 0;
+    u32 *d_asked = nullptr; /* multi-GPU flow: one bit per node — its row has been asked for in this pass (tr_request_*_kernel) */
+    u64 asked_cap = 0;
     u64 order_q_lo = 0, order_q_hi = 0;
     ulonglong2 *d_meta_ord = nullptr; /* per-read headers by position in the processing order (probe -> verify) */
     u64 meta_cap = 0;
-    u64 *d_nref = nullptr; /* multi-GPU flow: reference words nref[2u + cls] of the neighbour-row store */
-    u64 nref_cap = 0;
     u64 dropped_local = 0;
     ProbeRare h_probe_rare;
     ProbeRare *d_probe_rare = nullptr;
@@ -387,8 +385,8 @@ struct disco_ctx {
     u64 rdeg_s_cap = 0, rdeg_r_cap = 0, rdata_s_cap = 0;
     u64 *d_rpos = nullptr;
     u64 rpos_cap = 0;
-    u32 *d_nadj32_own = nullptr; /* neighbour-row store: own rows | rows fetched in round 1 | round 2 */
-    u64 nadj_cap = 0, nadj_used = 0;
+    u32 *d_nadj32_own = nullptr; /* rows fetched from other ranks as they arrive (4-byte entries), before rows_place_kernel puts them behind the own rows */
+    u64 nadj_cap = 0, nadj_used = 0; /* nadj_used: entries of fetched rows behind the own rows so far */
     u32 *d_deg_tmp = nullptr;
     u64 deg_tmp_cap = 0;
     u64 *d_list_n = nullptr; /* length of the flat list being built */
@@ -684,12 +682,10 @@ static void free_graph_state(disco_ctx *c)
     dev_free(c, &c->d_adj_spare, c->adj_spare_cap);
     dev_free(c, &c->d_start_tmp, c->start_cap);
     c->start_cap = 0;
-    dev_free(c, &c->d_nref, c->nref_cap);
-    c->nref_cap = 0;
     dev_free(c, &c->d_ocnt, c->ocnt_cap);
     dev_free(c, &c->d_okey, c->okey_cap);
     dev_free(c, &c->d_meta_ord, c->meta_cap);
-    dev_free(c, &c->d_cls_cnt, c->cls_cnt_cap);
+    dev_free(c, &c->d_asked, c->asked_cap);
     c->meta_cap = 0;
     dev_free(c, &c->d_oslot, c->oslot_cap);
     dev_free(c, &c->d_order_own, c->order_cap);
@@ -3121,13 +3117,15 @@ int disco_transitive_mark(disco_ctx *c)
     a.wide_list = c->d_wide;
     a.n_wide = c->d_n_wide;
     a.wide_cap = c->wide_cap;
-    a.nref = nullptr;
-    a.nadj32 = nullptr;
     a.order = (c->d_order_used && c->order_q_lo == c->q_lo && c->order_q_hi == c->q_hi && !c->adj_imported && !getenv("DISCO_TR_NO_ORDER")) ? c->d_order_used : nullptr;
     /* every row needs its flags when the emission cannot rely on the survivor lists alone */
     a.all_flags = (c->adj_imported || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
+#if defined(TR_EXP_DEFER_SINGLE) /* timing experiment: the multi-rank variant of the kernel on one GPU's nodes */
+    if (nq && tr_small) hipLaunchKernelGGL((transitive_mark_kernel<false, true, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, true, TR_CAP_SMALL>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+#else
     if (nq && tr_small) hipLaunchKernelGGL((transitive_mark_kernel<false, false, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, false, TR_CAP_SMALL>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+#endif
     else if (nq) hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
@@ -4300,8 +4298,19 @@ static int dist_deal_reads(disco_ctx *c)
     CHK(ensure_cap(c, &c->d_own_ids, &c->own_ids_cap, std::max<u64>(c->n, 1)));
     if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+    /* the grouping of the own reads (the rank's processing order) counts its buckets in the same pass: how many buckets follows from
+     * the number of own reads, which this pass produces — it is taken from the job's share n / G instead (the keys spread the reads to
+     * 0.3 %); the number of buckets shapes the order, never a result */
+    int obits = 16;
+    const bool order_own = own_order_wanted(c, std::max<u64>(c->n / G, 1), &obits) && !getenv("DISCO_DIST_ORDER_TWO_PASSES");
+    const u32 oshift = 32u - (u32)obits;
+    if (order_own) {
+        CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, (1ull << obits) + 1));
+        CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, std::max<u64>(c->n, 1))); /* (about n / G are used: sized like the list of own ids) */
+        HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, ((1ull << obits) + 1) * sizeof(u32), c->stream));
+    }
     if (c->n) hipLaunchKernelGGL(own_select_kernel, dim3((unsigned)std::min<u64>((c->n + OWN_TILE - 1) / OWN_TILE, (u64)c->n_cu * 16)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, c->n, G, r,
-                                 c->d_otab, c->d_own_ids, c->d_list_n);
+                                 c->d_otab, c->d_own_ids, c->d_list_n, order_own ? c->d_ocnt : (u32 *)nullptr, order_own ? c->d_oslot : (u32 *)nullptr, oshift);
     HIPCHK(c, hipGetLastError());
     u64 n_own = 0;
     HIPCHK(c, hipMemcpyAsync(&n_own, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -4324,15 +4333,19 @@ static int dist_deal_reads(disco_ctx *c)
     }
     /* the processing order: the own reads grouped by key (disco_probe's grouping, over the list) */
     CHK(ensure_cap(c, &c->d_order_own, &c->order_cap, std::max<u64>(n_own, 1)));
-    int obits = 16;
     ph_begin(c, DISCO_PH_ORDER);
-    if (own_order_wanted(c, n_own, &obits)) {
-        const u64 order_buckets = 1ull << obits;
-        const u32 oshift = 32u - (u32)obits;
-        CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
-        CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, n_own));
-        HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
-        hipLaunchKernelGGL(order_count_list_kernel, dim3(flat_grid(c, n_own)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, (const u32 *)c->d_own_ids, n_own, G, r, oshift, c->d_ocnt, c->d_oslot);
+    int obits2 = 16;
+    const bool order_two = !order_own && own_order_wanted(c, n_own, &obits2); /* (DISCO_DIST_ORDER_TWO_PASSES: the counting pass of rounds 5 as a pass of its own) */
+    if ((order_own && n_own) || order_two) {
+        const int ob = order_own ? obits : obits2;
+        const u64 order_buckets = 1ull << ob;
+        const u32 oshift = 32u - (u32)ob;
+        if (order_two) {
+            CHK(ensure_cap(c, &c->d_ocnt, &c->ocnt_cap, order_buckets + 1));
+            CHK(ensure_cap(c, &c->d_oslot, &c->oslot_cap, n_own));
+            HIPCHK(c, hipMemsetAsync(c->d_ocnt, 0, (order_buckets + 1) * sizeof(u32), c->stream));
+            hipLaunchKernelGGL(order_count_list_kernel, dim3(flat_grid(c, n_own)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, (const u32 *)c->d_own_ids, n_own, G, r, oshift, c->d_ocnt, c->d_oslot);
+        }
         CHK((scan_exclusive<u32, u32>(c, c->d_ocnt, order_buckets + 1, c->d_ocnt, false, nullptr)));
         hipLaunchKernelGGL(order_scatter_list_kernel, dim3(flat_grid(c, n_own)), dim3(256), 0, c->stream, (const u32 *)c->d_okey, (const u32 *)c->d_own_ids, (const u32 *)c->d_oslot,
                            (const u32 *)c->d_ocnt, n_own, G, r, oshift, (const u16 *)c->d_len, c->d_order_own);
@@ -4732,6 +4745,28 @@ static int dist_mark_contained(disco_ctx *c)
 }
 
 /* ---- 5. neighbour rows on request ------------------------------------------------------------------------------------ */
+/* room for `need` more entries of fetched rows behind the rank's own rows (and behind the nadj_used entries fetched so far) in the array
+ * that holds them — the hit buffer (64 slots per read allotted, 36 used at 30 x: the tail is there) or the merged rows; *base = where they go */
+static int adj_tail_reserve(disco_ctx *c, u64 need, u64 *base)
+{
+    const bool in_hits = c->d_adj == c->d_hits;
+    const u64 used = (in_hits ? c->hits_used : c->adj_total) + c->nadj_used;
+    if (in_hits) {
+        if (used + need > c->hits_cap) {
+            CHK(ensure_cap_keep(c, &c->d_hits, &c->hits_cap, used + need, used));
+            c->d_adj = c->d_hits;
+        }
+    } else {
+        if (c->d_adj != c->d_adj_own) return fail(c, DISCO_E_STATE, "neighbour rows: the adjacency is in neither of the buffers that can grow");
+        if (used + need > c->adj_cap) {
+            CHK(ensure_cap_keep(c, &c->d_adj_own, &c->adj_cap, used + need, used));
+            c->d_adj = c->d_adj_own;
+        }
+    }
+    *base = used;
+    return DISCO_OK;
+}
+
 /* one request round: the flat list of (u, cls) requests in d_req_flat -> rows appended to the neighbour-row store, nref set */
 static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
 {
@@ -4745,12 +4780,11 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
     const u64 nrq = vsum(rcnt);
     CHK(ensure_cap(c, &c->d_req_r, &c->req_r_cap, std::max<u64>(nrq, 1)));
     CHK(a2a_items(c, DISCO_X_ROW_REQUESTS, c->d_req_s, scnt, c->d_req_r, rcnt, sizeof(u32)));
-    /* the owner's side: class-filtered degree of every requested row, positions, entries */
+    /* the owner's side: degree of every requested row, positions, entries */
     CHK(ensure_cap(c, &c->d_rdeg_s, &c->rdeg_s_cap, std::max<u64>(nrq, 1)));
     CHK(ensure_cap(c, &c->d_rpos, &c->rpos_cap, std::max<u64>(std::max(nrq, n_flat), 1) + 1));
     const int rgrid = (int)std::max<u64>(std::min<u64>((nrq + 3) / 4, (u64)c->n_cu * 32), 1);
-    if (nrq && c->loci) hipLaunchKernelGGL(tr_respond_kernel<false>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, c->d_rdeg_s, (const u64 *)nullptr, (u32 *)nullptr);
-    else if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_cls_cnt, c->q_lo, c->d_adj_ref, c->d_adj, c->d_rdeg_s);
+    if (nrq) hipLaunchKernelGGL(tr_respond_deg_kernel, dim3(flat_grid(c, nrq)), dim3(256), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_rdeg_s);
     HIPCHK(c, hipGetLastError());
     u64 total_s = 0;
     CHK((scan_exclusive<u32, u64>(c, c->d_rdeg_s, nrq, c->d_rpos, true, &total_s)));
@@ -4767,7 +4801,7 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
         for (u32 p = 0; p < G; p++) ecnt_s[p] = bpos[p + 1] - bpos[p];
     }
     CHK(ensure_cap(c, &c->d_rdata_s, &c->rdata_s_cap, std::max<u64>(total_s, 1)));
-    if (nrq) hipLaunchKernelGGL(tr_respond_kernel<true>, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, (u32 *)nullptr, c->d_rpos, c->d_rdata_s);
+    if (nrq) hipLaunchKernelGGL(tr_respond_kernel, dim3(rgrid), dim3(64), 0, c->stream, c->d_req_r, nrq, c->d_adj_ref, c->d_adj, c->d_rpos, c->d_rdata_s);
     HIPCHK(c, hipGetLastError());
     /* degrees back (same segmentation as the requests, reversed), then the entries. How many entries every owner sends follows from
      * the degrees themselves: the requester sums them per segment (positions at the segment boundaries) — no exchange of counts */
@@ -4787,9 +4821,14 @@ static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
         bpos[G] = total_r;
         for (u32 p = 0; p < G; p++) ecnt_r[p] = bpos[p + 1] - bpos[p];
     }
-    CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, c->nadj_used + total_r + 1, c->nadj_used));
-    CHK(a2a_items(c, DISCO_X_ROW_DATA, c->d_rdata_s, ecnt_s, c->d_nadj32_own + c->nadj_used, ecnt_r, sizeof(u32)));
-    if (n_flat) hipLaunchKernelGGL(nref_remote_kernel, dim3(flat_grid(c, n_flat)), dim3(256), 0, c->stream, c->d_req_s, n_flat, c->d_rdeg_r, c->d_rpos, c->nadj_used, c->d_nref);
+    /* the rows that arrive (4-byte entries) ... */
+    CHK(ensure_cap(c, &c->d_nadj32_own, &c->nadj_cap, std::max<u64>(total_r, 1)));
+    CHK(a2a_items(c, DISCO_X_ROW_DATA, c->d_rdata_s, ecnt_s, c->d_nadj32_own, ecnt_r, sizeof(u32)));
+    /* ... go behind the own rows, as 8-byte entries under the nodes' reference words */
+    u64 base = 0;
+    CHK(adj_tail_reserve(c, total_r, &base));
+    if (n_flat) hipLaunchKernelGGL(rows_place_kernel, dim3((int)std::max<u64>(std::min<u64>((n_flat + 3) / 4, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_req_s, n_flat, c->d_rdeg_r, c->d_rpos,
+                                   (const u32 *)c->d_nadj32_own, base, c->d_adj, c->d_adj_ref);
     HIPCHK(c, hipGetLastError());
     c->nadj_used += total_r;
     return DISCO_OK;
@@ -4800,24 +4839,19 @@ static int dist_transitive_mark(disco_ctx *c)
     DISCO_TRACE("dist_transitive_mark");
     const u64 nloc = c->q_hi - c->q_lo; /* own nodes (an id range, or the positions of the own list) */
     const OwnSet own = own_set(c);
-    /* reference words: everything "not fetched", the own nodes' rows in place */
-    CHK(ensure_cap(c, &c->d_nref, &c->nref_cap, 2 * c->n + 2));
-    ph_begin(c, DISCO_PH_CSR);
-    HIPCHK(c, hipMemsetAsync(c->d_nref, 0xFF, (2 * c->n + 2) * sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(nref_local_kernel, dim3(flat_grid(c, nloc)), dim3(256), 0, c->stream, c->d_adj_ref, own, c->d_nref);
-    HIPCHK(c, hipGetLastError());
-    c->nadj_used = 0; /* the neighbour-row store holds fetched rows only */
-    CHK(ensure_cap_keep(c, &c->d_nadj32_own, &c->nadj_cap, 1u << 16, 0)); /* idle lanes of the row prefetch read its first 64 K entries */
-    ph_end(c, DISCO_PH_CSR);
+    /* the reference words of other ranks' nodes are 0 = "not fetched" (edge selection cleared the table and wrote the own nodes' words; a
+     * merge rebuilt it from degrees: 0 for every node of another rank); one bit per node: somebody on this rank has asked for its row */
+    CHK(ensure_cap(c, &c->d_asked, &c->asked_cap, c->n / 32 + 2));
+    HIPCHK(c, hipMemsetAsync(c->d_asked, 0, (c->n / 32 + 2) * sizeof(u32), c->stream));
+    c->nadj_used = 0; /* fetched rows: behind the own rows (adj_tail_reserve) */
     /* round 1: slot 0 and the first slot on the other side of every register-resident node */
     if (!c->d_list_n) CHK(dev_alloc(c, &c->d_list_n, 1));
     CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, 2 * nloc + 64));
     HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
     CHK(zero_counter(c, CTR_OVERFLOW));
-    /* ranks own loci: the two rows a node sweeps for certain are mostly the rank's own — a twelfth of the requests of the id ranges — so
-     * nothing is counted per node ahead of time any more: the owner counts the rows it is asked for (tr_respond_kernel<false>) */
-    if (!c->loci) CHK(ensure_cap(c, &c->d_cls_cnt, &c->cls_cnt_cap, std::max<u64>(nloc, 1)));
-    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, own, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr, c->loci ? (u32 *)nullptr : c->d_cls_cnt, c->q_lo);
+    ph_begin(c, DISCO_PH_CSR);
+    if (nloc) hipLaunchKernelGGL(tr_request_first_kernel, dim3((int)std::max<u64>(std::min<u64>((nloc + 63) / 64, (u64)c->n_cu * 32), 1)), dim3(64), 0, c->stream, (const u64 *)c->d_adj, own, (const u64 *)c->d_adj_ref, c->d_asked, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
+    ph_end(c, DISCO_PH_CSR);
     HIPCHK(c, hipGetLastError());
     u64 n_flat = 0;
     HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -4862,8 +4896,6 @@ static int dist_transitive_mark(disco_ctx *c)
     a.wide_list = c->d_wide;
     a.n_wide = c->d_n_wide;
     a.wide_cap = c->wide_cap;
-    a.nref = c->d_nref;
-    a.nadj32 = c->d_nadj32_own;
     /* the transitive flags go into the rows of nodes with more than HALF_CAP survivors only, as on one GPU: everybody who judges an edge
      * — the local emission, the survivor push and its receiver — reads a narrow node's survivor LIST and a wide node's row, never a narrow
      * node's row (rounds 1-4 wrote every flag here: a quarter of this kernel's memory requests, left over from the flag exchange the
@@ -4891,7 +4923,7 @@ static int dist_transitive_mark(disco_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         CHK(ensure_cap(c, &c->d_req_flat, &c->req_flat_cap, bound + 64));
         HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-        if (n_big) hipLaunchKernelGGL(tr_request_all_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, c->d_big_list, (u64)n_big, c->d_adj_ref, c->d_adj, own, c->d_nref, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
+        if (n_big) hipLaunchKernelGGL(tr_request_all_kernel, dim3((int)std::min<u64>(n_big, (u64)c->n_cu * 32)), dim3(64), 0, c->stream, c->d_big_list, (u64)n_big, (const u64 *)c->d_adj, own, (const u64 *)c->d_adj_ref, c->d_asked, c->d_req_flat, c->d_list_n, c->req_flat_cap, c->d_ctr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&n_flat, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         CHK(read_counters(c));
@@ -4910,7 +4942,7 @@ static int dist_transitive_mark(disco_ctx *c)
             CHK(dev_alloc(c, &scratch, (u64)g2 * perb));
             a.scratch = (u64 *)scratch;
             a.hcap = hcap;
-            a.nadj32 = c->d_nadj32_own; /* the store may have moved */
+            a.adj = c->d_adj; /* the array may have moved (adj_tail_reserve) */
             HIPCHK(c, hipMemsetAsync(c->d_wq, 0, sizeof(u64) * WQ_WORDS, c->stream));
             hipLaunchKernelGGL((transitive_mark_kernel<true, true>), dim3(g2), dim3(64), 0, c->stream, a);
             hipError_t e = hipGetLastError();
@@ -4935,19 +4967,24 @@ static int dist_push_survivors(disco_ctx *c)
     const u64 nloc = c->q_hi - c->q_lo;
     const OwnSet own = own_set(c);
     u64 n_items = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    if (nloc) hipLaunchKernelGGL(emit_push_kernel<false>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, own, (ulonglong2 *)nullptr, c->d_list_n, (u64)0, c->d_ctr);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(n_items, 1)));
+    /* the items (survivors whose smaller endpoint is another rank's: 400 000 per rank at 8 x 6.25 M nodes) are written in ONE pass into
+     * the room the exchange buffer has anyway (the index records went through it: two per own read) — rounds 1-5 counted them first, a
+     * second walk over every own node's survivors and a host round trip. A list that does not fit (the counter of lost items says so)
+     * is counted and written again, as before */
+    CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nloc / 4, 1u << 16)));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const u64 cap = attempt ? n_items : c->x16b_cap;
+        HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
+        CHK(zero_counter(c, CTR_OVERFLOW));
+        if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, own, c->d_x16b, c->d_list_n, cap, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&n_items, c->d_list_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        CHK(read_counters(c)); /* (synchronises: n_items is there) */
+        if (!c->h_ctr[CTR_OVERFLOW]) break;
+        if (attempt) return fail(c, DISCO_E_STATE, "survivor push: the second pass produced more items than the first counted");
+        CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(n_items, 1))); /* (the counter counted every item, lost or not) */
+    }
     CHK(ensure_cap(c, &c->d_x16a, &c->x16a_cap, std::max<u64>(n_items, 1)));
-    HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
-    CHK(zero_counter(c, CTR_OVERFLOW));
-    if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, own, c->d_x16b, c->d_list_n, n_items, c->d_ctr);
-    HIPCHK(c, hipGetLastError());
-    CHK(read_counters(c));
-    if (c->h_ctr[CTR_OVERFLOW]) return fail(c, DISCO_E_STATE, "survivor push: the fill pass produced more items than the count pass");
     std::vector<u64> scnt, rcnt;
     RouteByNode f{c->per, c->loci ? c->d_otab : nullptr};
     CHK(route_items(c, c->d_x16b, n_items, f, c->d_x16a, scnt));

@@ -4068,13 +4068,13 @@ struct TrArgs {
     u32 big_cap;
     u64 *scratch;  /* BIG variant: per block hkey[hcap] | ent(u32)[hcap] | state(u8)[hcap] */
     u64 hcap;      /* power of two >= 2 * max degree */
-    /* N32 variants (multi-GPU flow): the rows of the NEIGHBOURS come from a store of 4-byte entries with its own reference
-     * words nref[2u + cls], cls = which half of u's row the sweep from v uses (1: v enters u reversed, types 0/1 of u's entries
-     * count; 0: types 2/3). The rank's own nodes have their whole row behind both words; a remote (u, cls) has the entries of
-     * that class only, fetched on request from u's owner (tr_request_*_kernel), or TR_UNAVAIL: not fetched. A node whose sweep
-     * needs an unavailable row goes to big_list and is redone after the second request round. ref / adj hold the own rows. */
-    const u64 *nref;
-    const u32 *nadj32;
+    /* DEFER variants (multi-GPU flow): ref / adj hold the rank's own rows and, behind them in the same array, the rows of other ranks'
+     * nodes that were fetched on request from their owners (tr_request_*_kernel; whole rows, expanded to 8-byte entries on arrival:
+     * rows_place_kernel) — ONE reference word per node and one kind of entry, exactly what the single-GPU kernel reads (rounds 2-5 kept
+     * the fetched rows as 4-byte entries behind two reference words per node, nref[2u + cls]: the variant cost 5.5 ms more than the
+     * plain kernel for the same nodes with ONE rank, profiles/r06_experiments.txt F). A node of another rank whose row was not fetched
+     * has degree 0 in ref — no node that appears in a row has an empty row of its own (the lists are symmetric when the marking runs) —
+     * and a node whose sweep needs such a row goes to big_list and is redone after the request-all round. */
     /* 0: the transitive flag is written into the rows of nodes with more than HALF_CAP survivors only — everybody else's result
      * IS its survivor list, and rewriting 34 of 36 entries per node was a quarter of this kernel's memory requests (single GPU
      * with survivor lists); 1: every row gets its flags (sharded flows: the flag exchange may need all of them) */
@@ -4084,31 +4084,13 @@ struct TrArgs {
     const u64 *order;
 };
 
-#define TR_UNAVAIL 0xFFFFFFFFFFFFFFFFull   /* nref word: row not fetched (degree field 0xFFFFFF, never a real degree) */
-#define TR_REQUESTED 0xFFFFFFFFFFFFFFFEull /* nref word: requested in the current round                              */
-#define TR_NODEG 0xFFFFFFu
-template <bool N32>
-__device__ __forceinline__ u64 tr_nref(const TrArgs &a, u64 u, u32 cls) { return N32 ? a.nref[2 * u + cls] : a.ref[u]; }
-/* N32: a reference word with TR_LOCAL set addresses the rank's OWN row in adj (8-byte entries, read in place: exporting the own
- * rows into the 4-byte store cost more than the marking of a whole rank at 8 GPUs); without it, a fetched row in nadj32 */
-#define TR_LOCAL (1ull << 39)
-#define TR_LOCAL_POS(pos) ((pos) & (TR_LOCAL - 1ull))
-template <bool N32>
-__device__ __forceinline__ u64 tr_nent(const TrArgs &a, u64 pos)
-{
-    if (N32) {
-        if (pos & TR_LOCAL) return a.adj[TR_LOCAL_POS(pos)];
-        const u32 x = a.nadj32[pos];
-        return NBR32_ENTRY(x);
-    }
-    return a.adj[pos];
-}
+#define TR_UNAVAIL 0ull /* reference word of another rank's node: row not fetched (degree 0) */
 
 #ifndef TR_HASH_LOAD
 #define TR_HASH_LOAD 4 /* slots per neighbour in the marking hash of the register path: fewer probe-loop trips (each trip of a
                           divergent loop is a dozen scalar exec-mask instructions, and this kernel is bound by its SCALAR unit) */
 #endif
-static_assert(TR_HASH_LOAD * 64 < 4 * TR_CAP_SMALL && TR_CAP_SMALL <= TR_CAP, "the register path's table (at most TR_HASH_LOAD x 64 four-byte slots in the space of s_hkey) needs one more slot behind it: it takes the stores of the lanes without a hit");
+static_assert(TR_HASH_LOAD * 64 + 1 < 4 * TR_CAP_SMALL && TR_CAP_SMALL <= TR_CAP, "the register path's table (at most TR_HASH_LOAD x 64 four-byte slots in the space of s_hkey) needs two more slots behind it: one takes the stores of the lanes without a hit, one holds the multi-rank variant's verdict on the node");
 #define TR_EMPTY 0xFFFFFFFFFFFFFFFFull
 /* slot of a node id (< 2^31) in the marking hash: one 32-bit multiply (disco_hash64 costs two 64-bit multiplies — eight
  * quarter-rate 32-bit ones — and is evaluated for every entry of every swept row) */
@@ -4118,7 +4100,7 @@ __device__ __forceinline__ u32 tr_hash(u64 id, u32 hmask) { return ((u32)id ^ ((
 __device__ __forceinline__ u32 tr_hash(u64 id, u32 hmask) { return (((u32)id * 0x9E3779B1u) >> 10) & hmask; }
 #endif
 
-template <bool N32>
+template <bool DEFER>
 __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey, u8 *hstate, u32 *sent, u32 hmask, u32 lane)
 {
     const u64 vs = REF_POS(a.ref[v]);
@@ -4155,15 +4137,14 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
             const u64 u = ADJ_DST(e1);
             const u32 type1 = ADJ_ORI(e1);
             const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
-            const u64 ru = tr_nref<N32>(a, u, in1 ? 1u : 0u);
+            const u64 ru = a.ref[u];
             const u64 us = REF_POS(ru);
             u32 du = REF_DEG(ru);
-            if (N32 && du == TR_NODEG) { /* cannot happen after the request-all round: fail loudly */
+            if (DEFER && du == 0) { /* cannot happen after the request-all round: fail loudly */
                 if (lane == 0) atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-                du = 0;
             }
             for (u32 t = lane; t < du; t += 64) {        /* :698 */
-                const u64 e2 = tr_nent<N32>(a, us + t);
+                const u64 e2 = a.adj[us + t];
                 const u32 type2 = ADJ_ORI(e2);
                 const bool ok = in1 ? (type2 == 0 || type2 == 1) : (type2 == 2 || type2 == 3); /* :705-708 */
                 if (!ok) continue;
@@ -4221,7 +4202,7 @@ struct TrNodeRegs {
     u64 p0, p2; /* lane's entry of their rows */
 };
 
-template <bool N32>
+template <bool DEFER>
 __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs &nd, u64 *hkey, u8 *hstate, u32 lane)
 {
     const u32 d = nd.d;
@@ -4239,9 +4220,14 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     const u32 s2 = nd.s2;
     const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
     const u32 d0 = REF_DEG(nd.r0), d2 = REF_DEG(nd.r2);
-    const u64 p0 = (lane < d0 && d0 != TR_NODEG) ? ((N32 && !(st0 & TR_LOCAL)) ? NBR32_ENTRY((u32)nd.p0) : nd.p0) : 0ull;
-    const u64 p2 = (lane < d2 && d2 != TR_NODEG) ? ((N32 && !(st2 & TR_LOCAL)) ? NBR32_ENTRY((u32)nd.p2) : nd.p2) : 0ull;
-    bool deferred = false;
+    const u64 p0 = lane < d0 ? nd.p0 : 0ull;
+    const u64 p2 = lane < d2 ? nd.p2 : 0ull;
+    /* DEFER: a row that is not there has degree 0 (another rank's, not fetched); a node that sweeps one is redone after the request-all
+     * round. The two speculative rows are judged here, once per node and whether the second will be swept or not (round 1 asked for
+     * both), a third sweep's where it happens. The verdict lives in the LDS word behind the spare slot and is read back as a VECTOR value
+     * where the results are written: a scalar flag that lives across the sweep loop, with an exit in front of the output, made this
+     * variant 1.2 ms slower than the plain kernel for the same nodes (profiles/r06_experiments.txt F) */
+    if (DEFER) ht[hc + 1] = (d0 == 0 || d2 == 0) ? 1u : 0u;
     __syncthreads();
     u32 sent = 0;
 #if defined(TR_EXP) && TR_EXP == 2 /* timing experiment (results are wrong): the pipeline and the output alone — no hash, no sweeps */
@@ -4298,57 +4284,43 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
             if (du > 64)
                 for (u32 t0 = 64; t0 < du; t0 += 64) {
                     const bool act = t0 + lane < du;
-                    mark(act, act ? tr_nent<N32>(a, us + t0 + lane) : 0ull);
+                    mark(act, act ? a.adj[us + t0 + lane] : 0ull);
                 }
         };
         /* three copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
          * lands on the common path and drains the kernel's prefetch pipeline */
-        if (i == 0) {
-            if (N32 && d0 == TR_NODEG) {
-                deferred = true;
-                break;
-            }
-            sweep(st0, d0, p0);
-        } else if (i == s2) {
-            if (N32 && d2 == TR_NODEG) {
-                deferred = true;
-                break;
-            }
-            sweep(st2, d2, p2);
-        } else {
-            const u64 ru = tr_nref<N32>(a, ADJ_DST(e1), in1 ? 1u : 0u);
+        /* DEFER: a row that is not there (degree 0: another rank's, not fetched — a third sweep's, mostly) sweeps nothing; the node is
+         * redone after the request-all round. No early exit: the loop keeps the shape of the single-GPU kernel */
+        if (i == 0) sweep(st0, d0, p0);
+        else if (i == s2) sweep(st2, d2, p2);
+        else {
+            const u64 ru = a.ref[ADJ_DST(e1)];
             const u64 us = REF_POS(ru);
             const u32 du = REF_DEG(ru);
-            if (N32 && du == TR_NODEG) { /* a third sweep whose row was not requested: redo the node after the second round */
-                deferred = true;
-                break;
-            }
-            sweep(us, du, (lane < du) ? tr_nent<N32>(a, us + lane) : 0ull);
+            if (DEFER && du == 0) ht[hc + 1] = 1u; /* a third sweep whose row was not requested */
+            sweep(us, du, (lane < du) ? a.adj[us + lane] : 0ull);
         }
         __syncthreads();
     }
-    if (N32 && deferred) {
-        if (lane == 0) {
-            const u32 idx = atomicAdd(a.n_big, 1u);
-            if (idx < a.big_cap) a.big_list[idx] = nd.v;
-            else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
-        }
-        __syncthreads();
-        return;
+    const bool keep = !DEFER || ht[hc + 1] == 0u; /* (the same for every lane) */
+    if (DEFER && !keep && lane == 0) {
+        const u32 idx = atomicAdd(a.n_big, 1u);
+        if (idx < a.big_cap) a.big_list[idx] = nd.v;
+        else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
     }
 #if defined(TR_EXP) && TR_EXP >= 1 /* (the experiments leave the first two entries as survivors: the output side as on real data) */
     const bool fl = lane < d && lane >= 2u && (ht[sent & 63u] != 0x12345u);
 #else
-    const bool fl = lane < d && (ht[sent] >> 31);
+    const bool fl = keep && lane < d && (ht[sent] >> 31);
 #endif
-    const bool fr = lane < d && !fl;
+    const bool fr = keep && lane < d && !fl;
     const u64 mk = __ballot(fr);
     if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
     if (a.half && fr) {
         const u32 r = __popcll(mk & lane_mask_lt());
         if (r < HALF_CAP) a.half[nd.v * HALF_CAP + r] = e;
     }
-    if (a.hcnt && lane == 0) {
+    if (a.hcnt && lane == 0 && keep) {
         const u32 nfree = __popcll(mk);
         a.hcnt[nd.v] = nfree;
         if (nfree > HALF_CAP) {
@@ -4362,7 +4334,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 #ifndef TR_WAVES_PER_SIMD
 #define TR_WAVES_PER_SIMD 6
 #endif
-template <bool BIG, bool N32, int CAP = TR_CAP>
+template <bool BIG, bool DEFER, int CAP = TR_CAP>
 __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAVES_PER_SIMD) transitive_mark_kernel(TrArgs a)
 {
     __shared__ u64 s_hkey[BIG ? 1 : 2 * CAP];
@@ -4385,7 +4357,6 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
      *   v; side = strand of v in the edge, bit 1), node t+1: their rows, node t: the sweep.
      * Every pipelined load is unconditional (clamped address): a load under an exec-mask branch makes the number of loads in
      * flight unknown to the compiler, which then drains the pipeline at the next use. */
-    const u64 n_nodes = a.v.n;
     u64 cbeg = 0, cend = 0;
     u64 rv_chunk = 0, v_chunk = 0;
     auto stage_row = [&](u64 it) { /* needs rv_chunk */
@@ -4407,29 +4378,18 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         const u32 side0 = ADJ_ORI(readlane_u64(r.e, 0)) >> 1;
         const u64 om = __ballot(lane < r.d && (ADJ_ORI(r.e) >> 1) != side0);
         r.s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
+        /* (no clamps: a destination is a read of the table by construction, and a node without entries — r.e is 0 in every lane — looks at
+         * node 0's word, which stage_rows ignores: every scalar instruction of this per-node path is 0.08 ms at 50 M nodes) */
         const u64 e0 = readlane_u64(r.e, 0), e2 = readlane_u64(r.e, r.s2);
-        const u64 u0 = r.d ? ADJ_DST(e0) : r.v, u2 = r.d ? ADJ_DST(e2) : r.v;
-        r.r0 = tr_nref<N32>(a, u0 < n_nodes ? u0 : r.v, (~ADJ_ORI(e0)) & 1u); /* cls = 1 for types 0 and 2 */
-        r.r2 = tr_nref<N32>(a, u2 < n_nodes ? u2 : r.v, (~ADJ_ORI(e2)) & 1u);
+        r.r0 = a.ref[ADJ_DST(e0)];
+        r.r2 = a.ref[ADJ_DST(e2)];
     };
     auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 (broadcast loads: scalar from here on) */
         r.r0 = uniform_u64(r.r0);
         r.r2 = uniform_u64(r.r2);
-        const u32 d0 = (r.d && REF_DEG(r.r0) != TR_NODEG) ? REF_DEG(r.r0) : 0u, d2 = (r.d && REF_DEG(r.r2) != TR_NODEG) ? REF_DEG(r.r2) : 0u;
-        /* raw words only: N32 entries are expanded where they are consumed (nothing is computed from a loaded value in the
-         * iteration that issues the load) */
-        if (N32) {
-            /* wave-uniform choice (r0 / r2 are scalars): exactly one load per row on either side of the branch, so the number of
-             * loads in flight stays known */
-            const u64 q0 = REF_POS(r.r0), q2 = REF_POS(r.r2);
-            if (d0 && (q0 & TR_LOCAL)) r.p0 = a.adj[TR_LOCAL_POS(q0) + (lane < d0 ? lane : 0u)];
-            else r.p0 = a.nadj32[d0 ? q0 + (lane < d0 ? lane : 0u) : (r.vs & 0xFFFFull)];
-            if (d2 && (q2 & TR_LOCAL)) r.p2 = a.adj[TR_LOCAL_POS(q2) + (lane < d2 ? lane : 0u)];
-            else r.p2 = a.nadj32[d2 ? q2 + (lane < d2 ? lane : 0u) : (r.vs & 0xFFFFull)];
-        } else {
-            r.p0 = a.adj[d0 ? REF_POS(r.r0) + (lane < d0 ? lane : 0u) : r.vs];
-            r.p2 = a.adj[d2 ? REF_POS(r.r2) + (lane < d2 ? lane : 0u) : r.vs];
-        }
+        const u32 d0 = r.d ? REF_DEG(r.r0) : 0u, d2 = r.d ? REF_DEG(r.r2) : 0u;
+        r.p0 = a.adj[REF_POS(r.r0) + (lane < d0 ? lane : 0u)]; /* (d0 = 0: the first entry of whatever row the word names — a valid address, never used) */
+        r.p2 = a.adj[REF_POS(r.r2) + (lane < d2 ? lane : 0u)];
     };
 #if defined(WQ_SPLIT_ALL)
     WqSplit wqs;
@@ -4442,7 +4402,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
             const u64 v = a.big_list[it];
             const u32 d = REF_DEG(a.ref[v]);
             if (d == 0) continue;
-            tr_node<N32>(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
+            tr_node<DEFER>(a, v, d, hkey, hstate, sent, (u32)a.hcap - 1, lane);
         }
         continue;
     }
@@ -4461,12 +4421,12 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         TrNodeRegs n3 = stage_row(it + 3);
         const u64 v = n0.v;
         if (n0.d != 0)
-            tr_node_small<N32>(a, n0, s_hkey, s_state, lane);
+            tr_node_small<DEFER>(a, n0, s_hkey, s_state, lane);
         else if (n0.dfull != 0) {
-            if (!N32 && n0.dfull <= (u32)CAP) { /* multi-GPU: every node beyond the register path waits for the request-all round */
+            if (!DEFER && n0.dfull <= (u32)CAP) { /* multi-GPU: every node beyond the register path waits for the request-all round */
                 u32 hc = 64;
                 while (hc < 2 * n0.dfull) hc <<= 1;
-                tr_node<N32>(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
+                tr_node<DEFER>(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
             } else if (lane == 0) {
                 u32 idx = atomicAdd(a.n_big, 1u);
                 if (idx < a.big_cap) a.big_list[idx] = v;
