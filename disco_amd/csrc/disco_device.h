@@ -115,6 +115,9 @@ __device__ __forceinline__ u64 lane_mask_lt()
     u32 l = __lane_id();
     return l ? (~0ull >> (64 - l)) : 0ull;
 }
+/* how many bits of a wave mask are set below this lane: v_mbcnt_lo + v_mbcnt_hi (the compiler does not find them in
+ * __popcll(mask & lane_mask_lt()): it builds the mask with a 64-bit shift and two selects — nine vector instructions) */
+__device__ __forceinline__ u32 rank_below(u64 mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
 
 /* inclusive minimum scans inside the 16-lane rows of a wavefront (DPP row shifts; a lane without a source keeps ~0):
  * row_prefix_min: lane i gets the minimum over its row's lanes <= i; row_suffix_min: over its row's lanes >= i */

@@ -426,7 +426,7 @@ __device__ __forceinline__ void request_append(u32 rq, u32 *__restrict__ list, u
     if ((threadIdx.x & 63) == leader) base = atomicAdd(n_list, (u64)__popcll(mk));
     base = readlane_u64(base, leader);
     if (has) {
-        const u64 pos = base + __popcll(mk & lane_mask_lt());
+        const u64 pos = base + rank_below(mk);
         if (pos < cap) list[pos] = rq;
         else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
     }
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(64) tr_request_first_kernel(const u64 *__restr
     auto stash = [&](u32 rq) {
         const bool has = rq != 0xFFFFFFFFu;
         const u64 mk = __ballot(has);
-        if (has) s_out[n_out + __popcll(mk & lane_mask_lt())] = rq;
+        if (has) s_out[n_out + rank_below(mk)] = rq;
         n_out += (u32)__popcll(mk);
     };
     for (u64 blk = (u64)blockIdx.x * 64; blk < nloc; blk += (u64)gridDim.x * 64) { /* (wave uniform) */
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(256) twin_push_kernel(const u64 *__restrict__ 
             if (lane == leader) base = atomicAdd(n_list, (u64)__popcll(mk));
             base = readlane_u64(base, leader);
             if (take) {
-                const u64 q = base + __popcll(mk & lane_mask_lt());
+                const u64 q = base + rank_below(mk);
                 if (q < cap) list[q] = make_ulonglong2(w, ADJ_MAKE(ADJ_DLEN(e) + ADJ_OFF(e) - Lu, u, disco_twin_orient(ADJ_ORI(e)), Lu));
                 else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
             }
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(64) emit_push_kernel(const u64 *__restrict__ r
         if (lane == leader) base = atomicAdd(n_list, (u64)__popcll(mk));
         base = readlane_u64(base, leader);
         if (take) {
-            const u64 p = base + __popcll(mk & lane_mask_lt());
+            const u64 p = base + rank_below(mk);
             if (p < cap) list[p] = item_of(e, b, Lb);
             else atomicAdd(&ctr[CTR_OVERFLOW], 1ull);
         }
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(64) emit_push_recv_kernel(EmitRecvArgs a)
                     have_chunk = true;
                 }
                 if (keep) {
-                    const u64 pos = chunk_base + chunk_used + __popcll(mk & lane_mask_lt());
+                    const u64 pos = chunk_base + chunk_used + rank_below(mk);
                     if (pos < a.out_cap) {
                         a.out_src[pos] = v;
                         a.out_ent[pos] = twin;

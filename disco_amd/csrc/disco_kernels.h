@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(64, (LONGK || LONGCLASS) ? PROBE_WAVES_PER_SIM
         auto push = [&](bool take, u64 pay, u32 rev, int jj) {
             const u64 mm = __ballot(take);
             if (take) {
-                const u32 pos = nrow + __popcll(mm & lane_mask_lt());
+                const u32 pos = nrow + rank_below(mm);
                 if (pos < want) grow[pos] = HIT_MAKE(jj, PAY_ID(pay), PAY_SUFFIX(pay), rev, PAY_LEN(pay));
             }
             nrow += __popcll(mm);
@@ -1020,7 +1020,7 @@ __global__ void __launch_bounds__(64, (LONGK || LONGCLASS) ? PROBE_WAVES_PER_SIM
                 const int w = ws + (int)lane;
                 const bool isl = (w < nw) && s_first[s_wp[w] & 0x7FFFu] == (u32)w;
                 const u64 lm = __ballot(isl);
-                if (isl) s_lead[nlead + __popcll(lm & lane_mask_lt())] = (u16)w;
+                if (isl) s_lead[nlead + rank_below(lm)] = (u16)w;
                 nlead += __popcll(lm);
             }
             __syncthreads();
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(64, (LONGK || LONGCLASS) ? PROBE_WAVES_PER_SIM
                 s_mark[lane] = 0;
                 __syncthreads();
                 if (cnt > 0) {
-                    const u32 r = __popcll(nz & lane_mask_lt());
+                    const u32 r = rank_below(nz);
                     s_occ_fp[r] = fp_o;
                     s_occ_prel[r] = prel_o;
                     s_occ_start[r] = s;
@@ -1182,7 +1182,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
     const u32 lane = threadIdx.x;
     const int k = a.v.k, m = a.v.m, nf = k - m + 1;
     const u32 slot = lane / LPR, e = lane % LPR;
-    const u64 lt = lane_mask_lt(), le = lt | (1ull << lane);
+    const u64 le = lane_mask_lt() | (1ull << lane);
     const u64 nq = a.v.q_hi - a.v.q_lo;
     u64 chunk_base = 0;
     u32 chunk_used = PR_CHUNK;
@@ -1206,7 +1206,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                 if (lane == 0) base = atomicAdd(a.rare->n_slow, (u32)__popcll(lm));
                 base = uniform_u32(base);
                 if (lng) {
-                    const u32 idx = base + (u32)__popcll(lm & lt);
+                    const u32 idx = base + rank_below(lm);
                     if (idx < a.rare->slow_cap) a.rare->slow_list[idx] = ORDER_ID(ord_chunk) | ((cbeg + lane) << 32);
                     else atomicAdd(&a.rare->ctr[CTR_OVERFLOW], 1ull);
                     a.meta_ord[cbeg + lane] = make_ulonglong2(0ull, (u64)ORDER_LEN(ord_chunk) << 32);
@@ -1268,7 +1268,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
             const u32 wend0 = v1 ? RUN_W(e1) : npos;
             const u32 wend1 = (e + 1 < (u32)LPR && nx < 0xFFFEu) ? RUN_W(nx) : npos;
             const u64 m0 = __ballot(v0), m1 = __ballot(v1);
-            const u32 below = (u32)__popcll(m0 & lt) + (u32)__popcll(m1 & lt);
+            const u32 below = rank_below(m0) + rank_below(m1);
             if (v0) s_occ[below] = OCC_MAKE(slot, e0, wend0);
             if (v1) s_occ[below + 1] = OCC_MAKE(slot, e1, wend1);
             const u32 n_occ = (u32)__popcll(m0) + (u32)__popcll(m1);
@@ -1310,7 +1310,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
                 const u32 excl = incl - cnt;
                 __syncthreads();
                 if (cnt > 0) { /* only the buckets that hold records keep a slot: their starts in the concatenated list increase strictly */
-                    const u32 r = (u32)__popcll(nz & lt);
+                    const u32 r = rank_below(nz);
                     s_o_fp[r] = fp;
                     s_o_start[r] = st;
                     s_o_excl[r] = excl;
@@ -1364,7 +1364,7 @@ __global__ void __launch_bounds__(64, PR_WAVES_PER_SIMD) probe_runs_kernel(Probe
 #endif
                     const u64 mm = __ballot(take);
                     if (take) {
-                        const u32 pos = nrow + (u32)__popcll(mm & lt);
+                        const u32 pos = nrow + rank_below(mm);
                         if (pos < want) grow[pos] = HIT_MAKE(w, PAY_ID(pay), PAY_SUFFIX(pay), PAY_REV(pay) ^ rv, PAY_LEN(pay));
                     }
                     nrow += (u32)__popcll(mm);
@@ -1775,7 +1775,7 @@ __global__ void __launch_bounds__(64, VERIFY_WAVES_PER_SIMD) verify_kernel(Verif
                 /* compact the verified overlap hits to the front of the row (writes never pass the reads of this iteration) */
                 if (MODE != 1) { /* the containment pass leaves the candidate list as it is */
                     const u64 mk = __ballot(ov);
-                    if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = INEXACT && hidden ? h | HIT_HIDDEN_BIT : h;
+                    if (ov) row[nkeep + rank_below(mk)] = INEXACT && hidden ? h | HIT_HIDDEN_BIT : h;
                     nkeep += __popcll(mk);
                 }
                 __syncthreads();
@@ -2070,12 +2070,12 @@ __global__ void __launch_bounds__(64, NW == 5 ? VERIFY_FLAT_WAVES_PER_SIMD : 1) 
             const u64 mA = __ballot(fA), mB = __ballot(fB);
             const u32 nA = (u32)__popcll(mA);
             if (fA) {
-                const u32 r = (u32)__popcll(mA & lane_mask_lt());
+                const u32 r = (u32)rank_below(mA);
                 s_lid[r] = idA;
                 s_lslot[r] = (u8)lane;
             }
             if (fB) {
-                const u32 r = nA + (u32)__popcll(mB & lane_mask_lt());
+                const u32 r = nA + (u32)rank_below(mB);
                 s_lid[r] = idB;
                 s_lslot[r] = (u8)(64u + lane);
             }
@@ -2481,7 +2481,7 @@ __global__ void __launch_bounds__(256) class_take_rows_kernel(ulonglong2 *__rest
             __syncthreads();
             if (lane == 0) s_w[wv] = (u32)__popcll(tm);
             __syncthreads();
-            u32 off = (u32)__popcll(tm & lane_mask_lt());
+            u32 off = (u32)rank_below(tm);
             for (u32 w = 0; w < wv; w++) off += s_w[w];
             if (take) {
                 const u32 x = at + off;
@@ -2667,7 +2667,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                 }
             }
             const u64 mk = __ballot(ov);
-            if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+            if (ov) row[nkeep + rank_below(mk)] = h;
             nkeep += __popcll(mk);
             ndef = 0;
             __syncthreads();
@@ -2696,7 +2696,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                 const u64 dm = __ballot(defer);
                 if (dm) { /* (wave uniform) */
                     if (ndef + (u32)__popcll(dm) > 64u) flush();
-                    if (defer) s_def[ndef + (u32)__popcll(dm & lane_mask_lt())] = h;
+                    if (defer) s_def[ndef + (u32)rank_below(dm)] = h;
                     ndef += (u32)__popcll(dm);
                 }
             }
@@ -2760,7 +2760,7 @@ __global__ void __launch_bounds__(64) verify_long_kernel(VerifyArgs a, const u32
                 }
             }
             const u64 mk = __ballot(ov);
-            if (ov) row[nkeep + __popcll(mk & lane_mask_lt())] = h;
+            if (ov) row[nkeep + rank_below(mk)] = h;
             nkeep += __popcll(mk);
             h0 = h1;
             h1 = h2;
@@ -3006,7 +3006,7 @@ __device__ __forceinline__ void edge_select_row(const EdgeSelArgs &a, u64 A, u64
             keep = (hit != ~0ull) && !is_contained(a.contained, HIT_ID(hit));
         }
         u64 mk = __ballot(keep);
-        if (keep) h[m + __popcll(mk & lane_mask_lt())] = hit;
+        if (keep) h[m + rank_below(mk)] = hit;
         m += __popcll(mk);
     }
     __syncthreads();
@@ -3880,7 +3880,7 @@ __global__ void __launch_bounds__(256) twin_check_kernel(TwinArgs a)
                 const u32 cnt = (u32)__popcll(mk);
                 if (pend + cnt > TW_PEND) flush();
                 if (put) {
-                    const u32 pos = pend + (u32)__popcll(mk & lane_mask_lt());
+                    const u32 pos = pend + (u32)rank_below(mk);
                     s_node[wv][pos] = w;
                     s_key[wv][pos] = twin;
                 }
@@ -3992,7 +3992,7 @@ __global__ void __launch_bounds__(64) merge_sparse_kernel(const u64 *__restrict_
             const u32 t = t0 + lane;
             const bool mine = t < n_extra && EXTRA_NODE(extra_node[t]) == v;
             const u64 mk = __ballot(mine);
-            if (mine) up[at + __popcll(mk & lane_mask_lt())] = extra_key[t];
+            if (mine) up[at + rank_below(mk)] = extra_key[t];
             at += __popcll(mk);
         }
         __syncthreads();
@@ -4171,7 +4171,7 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
         if (fl) row[s] |= ADJ_FLAG;
         const u64 mk = __ballot(fr);
         if (a.half && fr) {
-            const u32 r = nfree + __popcll(mk & lane_mask_lt());
+            const u32 r = nfree + rank_below(mk);
             if (r < HALF_CAP) a.half[v * HALF_CAP + r] = row[s] & ~ADJ_FLAG;
         }
         nfree += __popcll(mk);
@@ -4207,15 +4207,18 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 {
     const u32 d = nd.d;
     const u64 e = nd.e;
-    u32 hc = 64;
-    while (hc < TR_HASH_LOAD * d) hc <<= 1; /* d <= 64: at most 4 * 64 of the 2 * TR_CAP slots */
-    const u32 hmask = hc - 1;
+    /* the table has TR_HASH_LOAD x 64 slots whatever the degree (d <= 64): its size and mask are immediates and it is cleared by ONE
+     * 16-byte store per lane — sizing it by the degree was a scalar loop and a masked clearing loop per node, twenty scalar instructions
+     * of a kernel that runs out of scalar issue (0.08 ms each at 50 M nodes) */
+    constexpr u32 hc = TR_HASH_LOAD * 64;
+    constexpr u32 hmask = hc - 1;
+    static_assert(hc == 256, "one uint4 per lane clears the table");
     /* round 4: a slot is ONE 32-bit word — the node id (below 2^31) with the ELIMINATED state in bit 31, 0xFFFFFFFF = free — in the
      * space of hkey: the table is cleared by one 16-byte store per lane (8-byte keys and a byte array of states took eight stores), a
      * probe reads and a mark writes one word */
     u32 *ht = (u32 *)hkey;
     (void)hstate;
-    for (u32 i = lane; i < hc / 4; i += 64) ((uint4 *)ht)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    ((uint4 *)ht)[lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
     /* speculative rows (fetched by the pipeline of the kernel): slot 0 and the first slot on the other side of v */
     const u32 s2 = nd.s2;
     const u64 st0 = REF_POS(nd.r0), st2 = REF_POS(nd.r2);
@@ -4249,26 +4252,27 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     /* BG/OverlapGraph.cpp:693-696: walk the list in order, sweeping only neighbours that are still INPLAY when their turn
      * comes. States only ever go INPLAY -> ELIMINATED, so "the next INPLAY slot after the one just swept, judged with the
      * states as they are now" is exactly the sequential loop — found with one ballot instead of one LDS read per slot. */
-    int cur = -1;
+    u64 todo = ~0ull; /* the slots behind the one swept last */
     for (;;) {
 #if defined(TR_EXP) && TR_EXP >= 1 /* timing experiment (results are wrong): pipeline, hash build and output without the sweeps (2: without the hash too) */
         if (p0 != 0x123456789ull || p2 != 0x123456789ull) break;
 #endif
-        const bool inplay = (lane < d) && !(ht[sent] >> 31);
-        u64 mk = __ballot(inplay);
-        if (cur >= 0) mk &= ~((2ull << cur) - 1ull); /* slots after cur */
+        /* (every lane reads a slot — `sent` is 0 beyond the list —: a read under the exec mask of lane < d is three scalar instructions
+         * per trip, and every scalar instruction of this per-node path is 0.08 ms at 50 M nodes) */
+        const u32 hs = ht[sent];
+        const bool inplay = (lane < d) & ((hs >> 31) == 0u);
+        const u64 mk = __ballot(inplay) & todo;
         if (!mk) break;
         const u32 i = (u32)__ffsll((long long)mk) - 1u;
-        cur = (int)i;
+        todo = ~1ull << i;
         const u64 e1 = readlane_u64(e, i);
-        const u32 type1 = ADJ_ORI(e1);
-        const bool in1 = (type1 == 0 || type1 == 2); /* v enters u reversed */
+        const u32 want = ADJ_ORI(e1) & 1u; /* BG/OverlapGraph.cpp:705-708: v enters u reversed (types 0 and 2) -> u's entries of types 0/1 count (type >> 1 == 0), else types 2/3 */
         /* every lane calls: the probe loop is wave-uniform (one trip for nearly every entry at four slots per neighbour), the
          * ELIMINATED store goes to a spare slot for the lanes without a hit — a divergent loop with early exits costs a dozen
          * scalar exec-mask instructions per trip, and the scalar unit is what this kernel runs out of */
         auto mark = [&](bool act, u64 e2) {
             const u32 type2 = ADJ_ORI(e2);
-            bool pend = act && ((type2 >> 1) == (in1 ? 0u : 1u)); /* :705-708: in1 -> types 0/1, else types 2/3 */
+            bool pend = act && ((type2 >> 1) == want);
             const u32 w = (u32)ADJ_DST(e2); /* ids are below 2^31: the low word of a slot identifies the node, 0xFFFFFFFF = empty */
             u32 idx = tr_hash(w, hmask);
             do {
@@ -4277,7 +4281,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
                 ht[hit ? idx : hc] = kk | 0x80000000u; /* ELIMINATED; slot hc is never a table slot: it takes the stores of the lanes without a hit */
                 pend = pend && !hit && kk != 0xFFFFFFFFu;
                 idx = (idx + 1) & hmask;
-            } while (__any(pend));
+            } while (__ballot(pend) != 0ull);
         };
         auto sweep = [&](u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
             mark(lane < du, pre);
@@ -4311,13 +4315,14 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 #if defined(TR_EXP) && TR_EXP >= 1 /* (the experiments leave the first two entries as survivors: the output side as on real data) */
     const bool fl = lane < d && lane >= 2u && (ht[sent & 63u] != 0x12345u);
 #else
-    const bool fl = keep && lane < d && (ht[sent] >> 31);
+    const u32 hs_end = ht[sent];
+    const bool fl = keep & (lane < d) & ((hs_end >> 31) != 0u);
 #endif
-    const bool fr = keep && lane < d && !fl;
+    const bool fr = keep & (lane < d) & !fl;
     const u64 mk = __ballot(fr);
     if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
     if (a.half && fr) {
-        const u32 r = __popcll(mk & lane_mask_lt());
+        const u32 r = rank_below(mk);
         if (r < HALF_CAP) a.half[nd.v * HALF_CAP + r] = e;
     }
     if (a.hcnt && lane == 0 && keep) {
@@ -4357,6 +4362,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
      *   v; side = strand of v in the edge, bit 1), node t+1: their rows, node t: the sweep.
      * Every pipelined load is unconditional (clamped address): a load under an exec-mask branch makes the number of loads in
      * flight unknown to the compiler, which then drains the pipeline at the next use. */
+    const u32 n_last = (u32)(a.v.n - 1);
     u64 cbeg = 0, cend = 0;
     u64 rv_chunk = 0, v_chunk = 0;
     auto stage_row = [&](u64 it) { /* needs rv_chunk */
@@ -4374,20 +4380,21 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         return r;
     };
     auto stage_refs = [&](TrNodeRegs &r) { /* needs r.e */
-        r.e = (lane < r.d) ? (r.e & ~ADJ_FLAG) : 0ull;
+        r.e &= ~ADJ_FLAG; /* (lanes beyond the list hold the row's first entry — stage_row's clamped load: a real entry, read by nobody) */
         const u32 side0 = ADJ_ORI(readlane_u64(r.e, 0)) >> 1;
         const u64 om = __ballot(lane < r.d && (ADJ_ORI(r.e) >> 1) != side0);
         r.s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
-        /* (no clamps: a destination is a read of the table by construction, and a node without entries — r.e is 0 in every lane — looks at
-         * node 0's word, which stage_rows ignores: every scalar instruction of this per-node path is 0.08 ms at 50 M nodes) */
+        /* (a node without entries holds whatever lies at its row's position — an entry of another row, or nothing at all behind the
+         * last row: one 32-bit minimum keeps the look-up inside the table; rounds 4-5 compared and selected 64-bit values, six scalar
+         * instructions per look-up, and every scalar instruction of this per-node path is 0.08 ms at 50 M nodes) */
         const u64 e0 = readlane_u64(r.e, 0), e2 = readlane_u64(r.e, r.s2);
-        r.r0 = a.ref[ADJ_DST(e0)];
-        r.r2 = a.ref[ADJ_DST(e2)];
+        r.r0 = a.ref[min((u32)ADJ_DST(e0), n_last)];
+        r.r2 = a.ref[min((u32)ADJ_DST(e2), n_last)];
     };
     auto stage_rows = [&](TrNodeRegs &r) { /* needs r.r0, r.r2 (broadcast loads: scalar from here on) */
         r.r0 = uniform_u64(r.r0);
         r.r2 = uniform_u64(r.r2);
-        const u32 d0 = r.d ? REF_DEG(r.r0) : 0u, d2 = r.d ? REF_DEG(r.r2) : 0u;
+        const u32 d0 = REF_DEG(r.r0), d2 = REF_DEG(r.r2);
         r.p0 = a.adj[REF_POS(r.r0) + (lane < d0 ? lane : 0u)]; /* (d0 = 0: the first entry of whatever row the word names — a valid address, never used) */
         r.p2 = a.adj[REF_POS(r.r2) + (lane < d2 ? lane : 0u)];
     };
@@ -4525,7 +4532,7 @@ __global__ void __launch_bounds__(64) emit_kernel(EmitArgs a)
                     have_chunk = true;
                 }
                 if (keep) {
-                    const u64 pos = chunk_base + chunk_used + __popcll(mk & lane_mask_lt());
+                    const u64 pos = chunk_base + chunk_used + rank_below(mk);
                     if (pos < a.out_cap) {
                         a.out_src[pos] = v;
                         a.out_ent[pos] = e & ~ADJ_FLAG;
@@ -4617,7 +4624,7 @@ __global__ void __launch_bounds__(64) emit_half_kernel(EmitHalfArgs a)
                     have_chunk = true;
                 }
                 if (keep) {
-                    const u64 pos = chunk_base + chunk_used + __popcll(mk & lane_mask_lt());
+                    const u64 pos = chunk_base + chunk_used + rank_below(mk);
                     if (pos < a.out_cap) {
                         a.out_src[pos] = v;
                         a.out_ent[pos] = e;
