@@ -4252,7 +4252,8 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     /* BG/OverlapGraph.cpp:693-696: walk the list in order, sweeping only neighbours that are still INPLAY when their turn
      * comes. States only ever go INPLAY -> ELIMINATED, so "the next INPLAY slot after the one just swept, judged with the
      * states as they are now" is exactly the sequential loop — found with one ballot instead of one LDS read per slot. */
-    u64 todo = ~0ull; /* the slots behind the one swept last */
+    const u64 dmask = d >= 64u ? ~0ull : (1ull << d) - 1ull; /* the list's lanes, as a scalar mask: folding lane < d into every vote is a vector compare, a select and a scalar and per vote */
+    u64 todo = dmask; /* the slots behind the one swept last */
     for (;;) {
 #if defined(TR_EXP) && TR_EXP >= 1 /* timing experiment (results are wrong): pipeline, hash build and output without the sweeps (2: without the hash too) */
         if (p0 != 0x123456789ull || p2 != 0x123456789ull) break;
@@ -4260,11 +4261,10 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         /* (every lane reads a slot — `sent` is 0 beyond the list —: a read under the exec mask of lane < d is three scalar instructions
          * per trip, and every scalar instruction of this per-node path is 0.08 ms at 50 M nodes) */
         const u32 hs = ht[sent];
-        const bool inplay = (lane < d) & ((hs >> 31) == 0u);
-        const u64 mk = __ballot(inplay) & todo;
+        const u64 mk = __ballot((hs >> 31) == 0u) & todo;
         if (!mk) break;
         const u32 i = (u32)__ffsll((long long)mk) - 1u;
-        todo = ~1ull << i;
+        todo = dmask & (~1ull << i);
         const u64 e1 = readlane_u64(e, i);
         const u32 want = ADJ_ORI(e1) & 1u; /* BG/OverlapGraph.cpp:705-708: v enters u reversed (types 0 and 2) -> u's entries of types 0/1 count (type >> 1 == 0), else types 2/3 */
         /* every lane calls: the probe loop is wave-uniform (one trip for nearly every entry at four slots per neighbour), the
@@ -4345,6 +4345,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
     __shared__ u64 s_hkey[BIG ? 1 : 2 * CAP];
     __shared__ u32 s_ent[BIG ? 1 : CAP];
     __shared__ u8 s_state[BIG ? 1 : 2 * CAP];
+    __shared__ u64 s_mid[(BIG || DEFER) ? 1 : 64]; /* the chunk's nodes beyond the register path (a chunk has at most 64 nodes) */
     const u32 lane = threadIdx.x;
     const u64 n_items = BIG ? (u64)min(*a.n_big, a.big_cap) : (a.v.q_hi - a.v.q_lo);
     u64 *hkey = s_hkey;
@@ -4365,12 +4366,13 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
     const u32 n_last = (u32)(a.v.n - 1);
     u64 cbeg = 0, cend = 0;
     u64 rv_chunk = 0, v_chunk = 0;
-    auto stage_row = [&](u64 it) { /* needs rv_chunk */
+    u32 ccnt = 0; /* nodes of the chunk */
+    auto stage_row = [&](u32 t) { /* node t of the chunk (32-bit: 64-bit compares and selects are vector instructions or scalar pairs); needs rv_chunk */
         TrNodeRegs r;
-        const bool ok = it < cend;
-        const u64 itc = ok ? it : cend - 1;
-        const u64 rv = readlane_u64(rv_chunk, (u32)(itc - cbeg));
-        r.v = readlane_u64(v_chunk, (u32)(itc - cbeg));
+        const bool ok = t < ccnt;
+        const u32 tc = ok ? t : ccnt - 1u;
+        const u64 rv = readlane_u64(rv_chunk, tc);
+        r.v = readlane_u64(v_chunk, tc);
         r.vs = REF_POS(rv);
         r.dfull = ok ? REF_DEG(rv) : 0u;
         r.d = (r.dfull <= 64) ? r.dfull : 0u;
@@ -4382,7 +4384,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
     auto stage_refs = [&](TrNodeRegs &r) { /* needs r.e */
         r.e &= ~ADJ_FLAG; /* (lanes beyond the list hold the row's first entry — stage_row's clamped load: a real entry, read by nobody) */
         const u32 side0 = ADJ_ORI(readlane_u64(r.e, 0)) >> 1;
-        const u64 om = __ballot(lane < r.d && (ADJ_ORI(r.e) >> 1) != side0);
+        const u64 om = __ballot((ADJ_ORI(r.e) >> 1) != side0); /* (no lane < d: the lanes beyond the list hold entry 0) */
         r.s2 = om ? (u32)__ffsll((long long)om) - 1u : 0u;
         /* (a node without entries holds whatever lies at its row's position — an entry of another row, or nothing at all behind the
          * last row: one 32-bit minimum keeps the look-up inside the table; rounds 4-5 compared and selected 64-bit values, six scalar
@@ -4418,31 +4420,49 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         v_chunk = a.order ? ORDER_ID(a.order[ic]) : a.v.q_lo + ic;
         rv_chunk = a.ref[v_chunk];
     }
-    TrNodeRegs n0 = stage_row(cbeg), n1 = stage_row(cbeg + 1), n2 = stage_row(cbeg + 2);
+    ccnt = (u32)(cend - cbeg);
+    TrNodeRegs n0 = stage_row(0), n1 = stage_row(1), n2 = stage_row(2), n3;
     stage_refs(n0);
     stage_refs(n1);
     stage_rows(n0);
-    for (u64 it = cbeg; it < cend; it++) {
-        stage_rows(n1);
-        stage_refs(n2);
-        TrNodeRegs n3 = stage_row(it + 3);
-        const u64 v = n0.v;
-        if (n0.d != 0)
-            tr_node_small<DEFER>(a, n0, s_hkey, s_state, lane);
-        else if (n0.dfull != 0) {
-            if (!DEFER && n0.dfull <= (u32)CAP) { /* multi-GPU: every node beyond the register path waits for the request-all round */
-                u32 hc = 64;
-                while (hc < 2 * n0.dfull) hc <<= 1;
-                tr_node<DEFER>(a, v, n0.dfull, hkey, hstate, sent, hc - 1, lane);
+    /* one step: node A is processed while B's speculative rows, C's reference words and D's row (node it + 3) are fetched. The four
+     * register sets take the four roles in turn — four copies of the step per trip of the loop — instead of being handed down the line
+     * after every node (n0 = n1, n1 = n2, n2 = n3: some twenty-five moves per node, most of them scalar, in a kernel where a scalar
+     * instruction per node is 0.08 ms) */
+    u32 n_mid = 0; /* wave uniform */
+    auto step = [&](TrNodeRegs &A, TrNodeRegs &B, TrNodeRegs &C, TrNodeRegs &D, u32 t) {
+        stage_rows(B);
+        stage_refs(C);
+        D = stage_row(t + 3);
+        if (A.d != 0)
+            tr_node_small<DEFER>(a, A, s_hkey, s_state, lane);
+        else if (A.dfull != 0) {
+            if (!DEFER && A.dfull <= (u32)CAP) { /* (multi-GPU: every node beyond the register path waits for the request-all round) */
+                if (lane == 0) s_mid[n_mid] = A.v; /* the LDS arrays' path: behind the chunk's loop, ONE copy of it */
+                n_mid++;
             } else if (lane == 0) {
                 u32 idx = atomicAdd(a.n_big, 1u);
-                if (idx < a.big_cap) a.big_list[idx] = v;
+                if (idx < a.big_cap) a.big_list[idx] = A.v;
                 else atomicAdd(&a.v.ctr[CTR_OVERFLOW], 1ull);
             }
         }
-        n0 = n1;
-        n1 = n2;
-        n2 = n3;
+    };
+    for (u32 t = 0; t < ccnt; t += 4) { /* (nodes beyond the chunk's end have degree 0: stage_row) */
+        step(n0, n1, n2, n3, t);
+        step(n1, n2, n3, n0, t + 1);
+        step(n2, n3, n0, n1, t + 2);
+        step(n3, n0, n1, n2, t + 3);
+    }
+    if (!DEFER && n_mid) { /* nodes of 65 .. CAP neighbours (wave uniform) */
+        __syncthreads();
+        for (u32 x = 0; x < n_mid; x++) {
+            const u64 v = s_mid[x];
+            const u32 dv = REF_DEG(a.ref[v]);
+            u32 hc = 64;
+            while (hc < 2 * dv) hc <<= 1;
+            tr_node<DEFER>(a, v, dv, hkey, hstate, sent, hc - 1, lane);
+        }
+        __syncthreads();
     }
     }
 }
