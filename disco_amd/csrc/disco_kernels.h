@@ -4270,18 +4270,27 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
         /* every lane calls: the probe loop is wave-uniform (one trip for nearly every entry at four slots per neighbour), the
          * ELIMINATED store goes to a spare slot for the lanes without a hit — a divergent loop with early exits costs a dozen
          * scalar exec-mask instructions per trip, and the scalar unit is what this kernel runs out of */
+        /* The votes of the probe loop are kept as SCALAR masks (pending lanes, hits, free slots): the loop condition is the scalar
+         * and-not's own condition code, and the lanes without a hit store to the spare slot through a select on the hit mask itself
+         * (written as one v_cndmask: the compiler has no way from a scalar mask back to a per-lane condition but shifts and compares).
+         * Round 5's form — per-lane booleans and a vote per trip — was 18 instructions a trip, this one is 13; addresses are kept as byte
+         * offsets (slot << 2) */
         auto mark = [&](bool act, u64 e2) {
             const u32 type2 = ADJ_ORI(e2);
-            bool pend = act && ((type2 >> 1) == want);
+            u64 pm = __ballot(act && ((type2 >> 1) == want)); /* :705-708 */
             const u32 w = (u32)ADJ_DST(e2); /* ids are below 2^31: the low word of a slot identifies the node, 0xFFFFFFFF = empty */
-            u32 idx = tr_hash(w, hmask);
+            u32 off = tr_hash(w, hmask) << 2;
+            const u32 spare = hc << 2; /* slot hc is never a table slot: it takes the stores of the lanes without a hit */
             do {
-                const u32 kk = ht[idx];
-                const bool hit = pend && (kk & 0x7FFFFFFFu) == w; /* (a free slot's low bits are no id) */
-                ht[hit ? idx : hc] = kk | 0x80000000u; /* ELIMINATED; slot hc is never a table slot: it takes the stores of the lanes without a hit */
-                pend = pend && !hit && kk != 0xFFFFFFFFu;
-                idx = (idx + 1) & hmask;
-            } while (__ballot(pend) != 0ull);
+                const u32 kk = *(const u32 *)((const u8 *)ht + off);
+                const u64 hm = __ballot((kk & 0x7FFFFFFFu) == w) & pm; /* (a free slot's low bits are no id) */
+                const u64 fm = __ballot(kk == 0xFFFFFFFFu);
+                u32 woff;
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(woff) : "v"(spare), "v"(off), "s"(hm));
+                *(u32 *)((u8 *)ht + woff) = kk | 0x80000000u; /* ELIMINATED */
+                pm &= ~(hm | fm);
+                off = (off + 4u) & (hmask << 2);
+            } while (pm != 0ull);
         };
         auto sweep = [&](u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
             mark(lane < du, pre);
