@@ -4192,7 +4192,7 @@ __device__ __forceinline__ void tr_node(const TrArgs &a, u64 v, u32 d, u64 *hkey
  * processed. The sequential INPLAY/ELIMINATED logic is unchanged; a speculative row is simply not used if its neighbour
  * turns out to be eliminated. */
 struct TrNodeRegs {
-    u64 v;
+    u32 v; /* (ids are below 2^31: ADJ_DST) */
     u64 vs;
     u32 d;      /* 0: nothing to do or not a register-resident node (no prefetch) */
     u32 dfull;  /* the node's degree */
@@ -4332,7 +4332,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
     if (a.half && fr) {
         const u32 r = rank_below(mk);
-        if (r < HALF_CAP) a.half[nd.v * HALF_CAP + r] = e;
+        if (r < HALF_CAP) a.half[(u64)nd.v * HALF_CAP + r] = e;
     }
     if (a.hcnt && lane == 0 && keep) {
         const u32 nfree = __popcll(mk);
@@ -4374,14 +4374,15 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
      * flight unknown to the compiler, which then drains the pipeline at the next use. */
     const u32 n_last = (u32)(a.v.n - 1);
     u64 cbeg = 0, cend = 0;
-    u64 rv_chunk = 0, v_chunk = 0;
+    u64 rv_chunk = 0;
+    u32 v_chunk = 0;
     u32 ccnt = 0; /* nodes of the chunk */
     auto stage_row = [&](u32 t) { /* node t of the chunk (32-bit: 64-bit compares and selects are vector instructions or scalar pairs); needs rv_chunk */
         TrNodeRegs r;
         const bool ok = t < ccnt;
         const u32 tc = ok ? t : ccnt - 1u;
         const u64 rv = readlane_u64(rv_chunk, tc);
-        r.v = readlane_u64(v_chunk, tc);
+        r.v = (u32)__builtin_amdgcn_readlane((int)v_chunk, (int)tc);
         r.vs = REF_POS(rv);
         r.dfull = ok ? REF_DEG(rv) : 0u;
         r.d = (r.dfull <= 64) ? r.dfull : 0u;
@@ -4426,7 +4427,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
     }
     {
         const u64 idx = cbeg + lane, ic = idx < cend ? idx : cend - 1;
-        v_chunk = a.order ? ORDER_ID(a.order[ic]) : a.v.q_lo + ic;
+        v_chunk = (u32)(a.order ? ORDER_ID(a.order[ic]) : a.v.q_lo + ic);
         rv_chunk = a.ref[v_chunk];
     }
     ccnt = (u32)(cend - cbeg);
