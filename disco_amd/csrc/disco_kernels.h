@@ -3402,7 +3402,7 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
     __shared__ __attribute__((aligned(16))) u32 s_bins[ROWS * 64];  /* row r, offset o: byte o & 3 of word 64 r + (o >> 2): entries */
     __shared__ __attribute__((aligned(16))) u32 s_start[ROWS * 64]; /* ... : first position of the bin */
     __shared__ __attribute__((aligned(16))) u32 s_jc[ROWS * 32 > 128 ? ROWS * 32 : 128]; /* row r, window j: byte j & 3 of word 32 r + ((j & 127) >> 2) */
-    __shared__ __attribute__((aligned(16))) u32 s_set[ROWS * SETW]; /* row r: destinations seen (0xFFFFFFFF = free) */
+    __shared__ __attribute__((aligned(16))) u32 s_set[ROWS * SETW + 64]; /* row r: destinations seen (0xFFFFFFFF = free); behind them a spare word per lane */
     __shared__ u32 s_flag[ROWS];                                    /* row r must be done the old way */
     __shared__ ulonglong2 s_hdr[64];                                /* read i of the chunk: {row start, first flat index | length << 32} */
     const u32 lane = threadIdx.x;
@@ -3560,17 +3560,26 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
                     u32 rank = 0;
                     bool dup = false;
 #if !defined(SEL_EXP) || SEL_EXP != 1
-                    { /* "no destination twice": a wave-uniform probe loop (one trip for nearly every entry) with the compare-and-swap predicated
-                       * — the divergent loop with its two exits cost a dozen scalar exec-mask instructions per trip (round 6) */
+                    { /* "no destination twice": a wave-uniform probe loop (one trip for nearly every entry). Round 6, second form: the votes
+                       * are SCALAR masks (pending lanes, duplicates), the loop ends on the and-not's condition code, and a lane that is not
+                       * pending swaps at a spare word of its own instead of being masked out (a compare-and-swap under the exec mask and the
+                       * merging of three per-lane booleans behind it were 27 instructions a trip; this is 14) */
                         u32 idx = (id * 0x9E3779B1u) >> 25; /* SETW = 128 slots */
-                        bool pend = ok;
+                        u64 pm = __ballot(ok), dupm = 0ull;
+                        const u32 spare = (u32)(ROWS * SETW) + lane; /* s_set has 64 words behind the rows' sets */
                         do {
-                            u32 old = 0xFFFFFFFFu;
-                            if (pend) old = atomicCAS(&s_set[rl * SETW + idx], 0xFFFFFFFFu, id);
-                            dup = dup || (pend && old == id); /* a second hit to this destination (BG/OverlapGraph.cpp:656): the consumption order decides */
-                            pend = pend && old != 0xFFFFFFFFu && old != id;
+                            u32 slot;
+                            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(slot) : "v"(spare), "v"(rl * SETW + idx), "s"(pm));
+                            const u32 old = atomicCAS(&s_set[slot], 0xFFFFFFFFu, id);
+                            const u64 hm = __ballot(old == id) & pm; /* a second hit to this destination (BG/OverlapGraph.cpp:656): the consumption order decides */
+                            const u64 fm = __ballot(old == 0xFFFFFFFFu);
+                            dupm |= hm;
+                            pm &= ~(hm | fm);
                             idx = (idx + 1u) & (SETW - 1u);
-                        } while (__any(pend));
+                        } while (pm != 0ull);
+                        u32 dupv;
+                        asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(dupv) : "s"(dupm));
+                        dup = dupv != 0u;
                     }
 #endif
                     if (ok) {
