@@ -14,7 +14,9 @@ G = prof["ranks"]
 k = ktab["kernels"]
 single = ktab["single_gpu_ms"]
 total = ktab["sum_over_ranks_ms"]
-bulk = sum(v["ranks_ms"] for n, v in k.items() if n.startswith(("unpack_rows_kernel", "pack_rows_kernel", "unpack_lens_kernel")))
+# kernels of the SECOND stream (behind keys .. probe / behind selection .. emission): the packing of the gathered reads, and the reduction of the
+# containment keys (loop_min_i64_kernel: the in-process transport's stand-in for the reduction RCCL does in its own kernels)
+bulk = sum(v["ranks_ms"] for n, v in k.items() if n.startswith(("unpack_rows_kernel", "pack_rows_kernel", "unpack_lens_kernel", "loop_min_i64_kernel")))
 b = prof["bytes_sent_per_rank_mean"]
 
 
