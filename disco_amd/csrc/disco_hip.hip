@@ -3121,10 +3121,12 @@ int disco_transitive_mark(disco_ctx *c)
     /* every row needs its flags when the emission cannot rely on the survivor lists alone */
     a.all_flags = (c->adj_imported || !c->use_half || c->q_lo != 0 || c->q_hi != c->n) ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
+    const bool lists = a.half && a.hcnt && !a.all_flags; /* the survivor lists are the result: the variant compiled for it */
 #if defined(TR_EXP_DEFER_SINGLE) /* timing experiment: the multi-rank variant of the kernel on one GPU's nodes */
     if (nq && tr_small) hipLaunchKernelGGL((transitive_mark_kernel<false, true, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, true, TR_CAP_SMALL>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
 #else
-    if (nq && tr_small) hipLaunchKernelGGL((transitive_mark_kernel<false, false, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, false, TR_CAP_SMALL>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    if (nq && tr_small && lists) hipLaunchKernelGGL((transitive_mark_kernel<false, false, TR_CAP_SMALL, true>), dim3(wq_grid(c, transitive_mark_kernel<false, false, TR_CAP_SMALL, true>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    else if (nq && tr_small) hipLaunchKernelGGL((transitive_mark_kernel<false, false, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, false, TR_CAP_SMALL>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
 #endif
     else if (nq) hipLaunchKernelGGL((transitive_mark_kernel<false, false>), dim3(wq_grid(c, transitive_mark_kernel<false, false>, nq, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
@@ -4903,7 +4905,8 @@ static int dist_transitive_mark(disco_ctx *c)
     a.all_flags = getenv("DISCO_DIST_ALL_FLAGS") ? 1u : 0u;
     ph_begin(c, DISCO_PH_TRMARK);
     /* (every node beyond the register path waits for the request-all round here, whatever the LDS arrays could hold: the small variant) */
-    if (nloc) hipLaunchKernelGGL((transitive_mark_kernel<false, true, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, true, TR_CAP_SMALL>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    if (nloc && !a.all_flags) hipLaunchKernelGGL((transitive_mark_kernel<false, true, TR_CAP_SMALL, true>), dim3(wq_grid(c, transitive_mark_kernel<false, true, TR_CAP_SMALL, true>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
+    else if (nloc) hipLaunchKernelGGL((transitive_mark_kernel<false, true, TR_CAP_SMALL>), dim3(wq_grid(c, transitive_mark_kernel<false, true, TR_CAP_SMALL>, nloc, "DISCO_TR_WAVES")), dim3(64), 0, c->stream, a);
     ph_end(c, DISCO_PH_TRMARK);
     HIPCHK(c, hipGetLastError());
     u32 n_big = 0;

@@ -3391,8 +3391,11 @@ __global__ void __launch_bounds__(64, SELECT_WAVES_PER_SIMD) edge_select_kernel(
  * the big-row list (edge_select_mid_kernel<ES_CAP>), the sequential path works in arrays of 64, the sub-chunk is 3 rows x 2 batches (4 x 3
  * would be faster still, 18.1 ms, and spills three registers with the sequential path compiled in) and the kernel holds five waves per
  * SIMD: 18.8 ms. */
+#ifndef SELECT_SMALL_WAVES
+#define SELECT_SMALL_WAVES 5
+#endif
 template <int ROWS, int NB, bool SMALL = false>
-__global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) edge_select_flat_kernel(EdgeSelArgs a)
+__global__ void __launch_bounds__(64, SMALL ? SELECT_SMALL_WAVES : SELECT_FLAT_WAVES_PER_SIMD) edge_select_flat_kernel(EdgeSelArgs a)
 {
     constexpr u32 SEQ_CAP = SMALL ? 64u : (u32)ES_CAP; /* rows the sequential path takes; longer ones: the big-row list */
     /* a sub-chunk: consecutive reads of the chunk, as many as fit ROWS rows and NB batches of 64 hits (greedy) */
@@ -3652,6 +3655,9 @@ __global__ void __launch_bounds__(64, SMALL ? 5 : SELECT_FLAT_WAVES_PER_SIMD) ed
             n_edges += (u32)__builtin_amdgcn_readlane((int)t, 63);
         }
         /* rows with a destination twice, a k-mer over the cap, or more than 64 hits: as edge_select_kernel does them */
+#ifdef SEL_EXP_NOSLOW /* experiment (rows of the old paths are lost): what the kernel needs without their code */
+        slowmask = 0;
+#endif
         while (slowmask) {
             const u32 i = (u32)__ffsll((long long)slowmask) - 1u;
             slowmask &= slowmask - 1ull;
@@ -4211,7 +4217,9 @@ struct TrNodeRegs {
     u64 p0, p2; /* lane's entry of their rows */
 };
 
-template <bool DEFER>
+/* LISTS: the survivor lists are the result (half and hcnt are there, all_flags is 0: what every pass over a whole table does) — known when
+ * the kernel is compiled instead of asked of three arguments per node */
+template <bool DEFER, bool LISTS>
 __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs &nd, u64 *hkey, u8 *hstate, u32 lane)
 {
     const u32 d = nd.d;
@@ -4246,7 +4254,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
     sent = lane;
     if (p0 != 0x123456789ull || p2 != 0x123456789ull) ht[lane] = 0u;
 #else
-    if (lane < d) { /* markedNodes->insert(dst, INPLAY) */
+    { /* markedNodes->insert(dst, INPLAY). Every lane inserts: the lanes beyond the list hold entry 0 (stage_row's clamped load) and find it there */
         const u32 id = (u32)ADJ_DST(e);
         u32 idx = tr_hash(id, hmask);
         for (;;) {
@@ -4262,65 +4270,68 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
      * comes. States only ever go INPLAY -> ELIMINATED, so "the next INPLAY slot after the one just swept, judged with the
      * states as they are now" is exactly the sequential loop — found with one ballot instead of one LDS read per slot. */
     const u64 dmask = d >= 64u ? ~0ull : (1ull << d) - 1ull; /* the list's lanes, as a scalar mask: folding lane < d into every vote is a vector compare, a select and a scalar and per vote */
+    /* The votes of the probe loop are kept as SCALAR masks (pending lanes, hits, free slots): the loop condition is the scalar
+     * and-not's own condition code, and the lanes without a hit store to the spare slot through a select on the hit mask itself
+     * (written as one v_cndmask: the compiler has no way from a scalar mask back to a per-lane condition but shifts and compares).
+     * Round 5's form — per-lane booleans and a vote per trip — was 18 instructions a trip, this one is 14; addresses are kept as byte
+     * offsets (slot << 2). Every lane calls: the loop is wave-uniform (one trip for nearly every entry at four slots per neighbour).
+     * want: BG/OverlapGraph.cpp:705-708 — v enters u reversed (types 0 and 2) -> u's entries of types 0/1 count (type >> 1 == 0), else 2/3 */
+    auto mark = [&](u32 want, bool act, u64 e2) {
+        const u32 type2 = ADJ_ORI(e2);
+        u64 pm = __ballot(act && ((type2 >> 1) == want));
+        const u32 w = (u32)ADJ_DST(e2); /* ids are below 2^31: the low word of a slot identifies the node, 0xFFFFFFFF = empty */
+        u32 off = tr_hash(w, hmask) << 2;
+        const u32 spare = hc << 2; /* slot hc is never a table slot: it takes the stores of the lanes without a hit */
+        do {
+            const u32 kk = *(const u32 *)((const u8 *)ht + off);
+            const u64 hm = __ballot((kk & 0x7FFFFFFFu) == w) & pm; /* (a free slot's low bits are no id) */
+            const u64 fm = __ballot(kk == 0xFFFFFFFFu);
+            u32 woff;
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(woff) : "v"(spare), "v"(off), "s"(hm));
+            *(u32 *)((u8 *)ht + woff) = kk | 0x80000000u; /* ELIMINATED */
+            pm &= ~(hm | fm);
+            off = (off + 4u) & (hmask << 2);
+        } while (pm != 0ull);
+    };
+    auto sweep = [&](u32 want, u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
+        mark(want, lane < du, pre);
+        if (du > 64)
+            for (u32 t0 = 64; t0 < du; t0 += 64) {
+                const bool act = t0 + lane < du;
+                mark(want, act, act ? a.adj[us + t0 + lane] : 0ull);
+            }
+    };
     u64 todo = dmask; /* the slots behind the one swept last */
+#if !(defined(TR_EXP) && TR_EXP >= 1)
+    /* slot 0 is INPLAY when the walk starts (nothing has been eliminated yet): its sweep needs no vote */
+    sweep(ADJ_ORI((u64)(u32)__builtin_amdgcn_readlane((int)(u32)e, 0)) & 1u, st0, d0, p0);
+    todo = dmask & ~1ull;
+    __syncthreads();
+#endif
     for (;;) {
 #if defined(TR_EXP) && TR_EXP >= 1 /* timing experiment (results are wrong): pipeline, hash build and output without the sweeps (2: without the hash too) */
         if (p0 != 0x123456789ull || p2 != 0x123456789ull) break;
 #endif
-        /* (every lane reads a slot — `sent` is 0 beyond the list —: a read under the exec mask of lane < d is three scalar instructions
-         * per trip, and every scalar instruction of this per-node path is 0.08 ms at 50 M nodes) */
+        /* (every lane reads a slot: a read under the exec mask of lane < d is three scalar instructions per trip, and every scalar
+         * instruction of this per-node path is 0.08 ms at 50 M nodes) */
         const u32 hs = ht[sent];
         const u64 mk = __ballot((hs >> 31) == 0u) & todo;
         if (!mk) break;
         const u32 i = (u32)__ffsll((long long)mk) - 1u;
         todo = dmask & (~1ull << i);
         const u64 e1 = readlane_u64(e, i);
-        const u32 want = ADJ_ORI(e1) & 1u; /* BG/OverlapGraph.cpp:705-708: v enters u reversed (types 0 and 2) -> u's entries of types 0/1 count (type >> 1 == 0), else types 2/3 */
-        /* every lane calls: the probe loop is wave-uniform (one trip for nearly every entry at four slots per neighbour), the
-         * ELIMINATED store goes to a spare slot for the lanes without a hit — a divergent loop with early exits costs a dozen
-         * scalar exec-mask instructions per trip, and the scalar unit is what this kernel runs out of */
-        /* The votes of the probe loop are kept as SCALAR masks (pending lanes, hits, free slots): the loop condition is the scalar
-         * and-not's own condition code, and the lanes without a hit store to the spare slot through a select on the hit mask itself
-         * (written as one v_cndmask: the compiler has no way from a scalar mask back to a per-lane condition but shifts and compares).
-         * Round 5's form — per-lane booleans and a vote per trip — was 18 instructions a trip, this one is 13; addresses are kept as byte
-         * offsets (slot << 2) */
-        auto mark = [&](bool act, u64 e2) {
-            const u32 type2 = ADJ_ORI(e2);
-            u64 pm = __ballot(act && ((type2 >> 1) == want)); /* :705-708 */
-            const u32 w = (u32)ADJ_DST(e2); /* ids are below 2^31: the low word of a slot identifies the node, 0xFFFFFFFF = empty */
-            u32 off = tr_hash(w, hmask) << 2;
-            const u32 spare = hc << 2; /* slot hc is never a table slot: it takes the stores of the lanes without a hit */
-            do {
-                const u32 kk = *(const u32 *)((const u8 *)ht + off);
-                const u64 hm = __ballot((kk & 0x7FFFFFFFu) == w) & pm; /* (a free slot's low bits are no id) */
-                const u64 fm = __ballot(kk == 0xFFFFFFFFu);
-                u32 woff;
-                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(woff) : "v"(spare), "v"(off), "s"(hm));
-                *(u32 *)((u8 *)ht + woff) = kk | 0x80000000u; /* ELIMINATED */
-                pm &= ~(hm | fm);
-                off = (off + 4u) & (hmask << 2);
-            } while (pm != 0ull);
-        };
-        auto sweep = [&](u64 us, u32 du, u64 pre) { /* :698 ; the first 64 entries of the row are in registers */
-            mark(lane < du, pre);
-            if (du > 64)
-                for (u32 t0 = 64; t0 < du; t0 += 64) {
-                    const bool act = t0 + lane < du;
-                    mark(act, act ? a.adj[us + t0 + lane] : 0ull);
-                }
-        };
-        /* three copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
+        const u32 want = ADJ_ORI(e1) & 1u;
+        /* two copies on purpose: the row fetched on the spot must be consumed inside its own branch, or the wait for it
          * lands on the common path and drains the kernel's prefetch pipeline */
         /* DEFER: a row that is not there (degree 0: another rank's, not fetched — a third sweep's, mostly) sweeps nothing; the node is
          * redone after the request-all round. No early exit: the loop keeps the shape of the single-GPU kernel */
-        if (i == 0) sweep(st0, d0, p0);
-        else if (i == s2) sweep(st2, d2, p2);
+        if (i == s2) sweep(want, st2, d2, p2);
         else {
             const u64 ru = a.ref[ADJ_DST(e1)];
             const u64 us = REF_POS(ru);
             const u32 du = REF_DEG(ru);
             if (DEFER && du == 0) ht[hc + 1] = 1u; /* a third sweep whose row was not requested */
-            sweep(us, du, (lane < du) ? a.adj[us + lane] : 0ull);
+            sweep(want, us, du, (lane < du) ? a.adj[us + lane] : 0ull);
         }
         __syncthreads();
     }
@@ -4338,12 +4349,12 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 #endif
     const bool fr = keep & (lane < d) & !fl;
     const u64 mk = __ballot(fr);
-    if (fl && (a.all_flags || !a.half || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
-    if (a.half && fr) {
+    if (fl && ((!LISTS && (a.all_flags || !a.half)) || __popcll(mk) > HALF_CAP)) a.adj[nd.vs + lane] = e | ADJ_FLAG;
+    if ((LISTS || a.half) && fr) {
         const u32 r = rank_below(mk);
         if (r < HALF_CAP) a.half[(u64)nd.v * HALF_CAP + r] = e;
     }
-    if (a.hcnt && lane == 0 && keep) {
+    if ((LISTS || a.hcnt) && lane == 0 && keep) {
         const u32 nfree = __popcll(mk);
         a.hcnt[nd.v] = nfree;
         if (nfree > HALF_CAP) {
@@ -4357,7 +4368,7 @@ __device__ __forceinline__ void tr_node_small(const TrArgs &a, const TrNodeRegs 
 #ifndef TR_WAVES_PER_SIMD
 #define TR_WAVES_PER_SIMD 6
 #endif
-template <bool BIG, bool DEFER, int CAP = TR_CAP>
+template <bool BIG, bool DEFER, int CAP = TR_CAP, bool LISTS = false>
 __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAVES_PER_SIMD) transitive_mark_kernel(TrArgs a)
 {
     __shared__ u64 s_hkey[BIG ? 1 : 2 * CAP];
@@ -4382,6 +4393,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
      * Every pipelined load is unconditional (clamped address): a load under an exec-mask branch makes the number of loads in
      * flight unknown to the compiler, which then drains the pipeline at the next use. */
     const u32 n_last = (u32)(a.v.n - 1);
+    const u32 lane8 = lane << 3;
     u64 cbeg = 0, cend = 0;
     u64 rv_chunk = 0;
     u32 v_chunk = 0;
@@ -4395,7 +4407,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         r.vs = REF_POS(rv);
         r.dfull = ok ? REF_DEG(rv) : 0u;
         r.d = (r.dfull <= 64) ? r.dfull : 0u;
-        r.e = a.adj[r.vs + (lane < r.d ? lane : 0u)];
+        r.e = *(const u64 *)((const u8 *)(a.adj + r.vs) + (lane < r.d ? lane8 : 0u)); /* (the lane's byte offset is a constant register: no shift per load) */
         r.s2 = 0;
         r.r0 = r.r2 = r.p0 = r.p2 = 0;
         return r;
@@ -4416,8 +4428,8 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         r.r0 = uniform_u64(r.r0);
         r.r2 = uniform_u64(r.r2);
         const u32 d0 = REF_DEG(r.r0), d2 = REF_DEG(r.r2);
-        r.p0 = a.adj[REF_POS(r.r0) + (lane < d0 ? lane : 0u)]; /* (d0 = 0: the first entry of whatever row the word names — a valid address, never used) */
-        r.p2 = a.adj[REF_POS(r.r2) + (lane < d2 ? lane : 0u)];
+        r.p0 = *(const u64 *)((const u8 *)(a.adj + REF_POS(r.r0)) + (lane < d0 ? lane8 : 0u)); /* (d0 = 0: the first entry of whatever row the word names — a valid address, never used) */
+        r.p2 = *(const u64 *)((const u8 *)(a.adj + REF_POS(r.r2)) + (lane < d2 ? lane8 : 0u));
     };
 #if defined(WQ_SPLIT_ALL)
     WqSplit wqs;
@@ -4454,7 +4466,7 @@ __global__ void __launch_bounds__(64, (CAP == TR_CAP_SMALL && !BIG) ? 8 : TR_WAV
         stage_refs(C);
         D = stage_row(t + 3);
         if (A.d != 0)
-            tr_node_small<DEFER>(a, A, s_hkey, s_state, lane);
+            tr_node_small<DEFER, LISTS>(a, A, s_hkey, s_state, lane);
         else if (A.dfull != 0) {
             if (!DEFER && A.dfull <= (u32)CAP) { /* (multi-GPU: every node beyond the register path waits for the request-all round) */
                 if (lane == 0) s_mid[n_mid] = A.v; /* the LDS arrays' path: behind the chunk's loop, ONE copy of it */
