@@ -4753,23 +4753,35 @@ static int adj_tail_reserve(disco_ctx *c, u64 need, u64 *base)
 {
     const bool in_hits = c->d_adj == c->d_hits;
     const u64 used = (in_hits ? c->hits_used : c->adj_total) + c->nadj_used;
+    /* test hook: the array counts as full — every call with something to place moves it (the path a probe that sizes the buffer exactly takes) */
+    const bool tight = getenv("DISCO_TEST_TIGHT_TAIL") != nullptr && need != 0;
+    auto move_to_larger = [&](u64 **p, u64 *cap) -> int { /* (ensure_cap_keep's steps, for an array that is large enough on paper) */
+        u64 *q = nullptr;
+        const u64 ncap = used + need + (used + need) / 8;
+        CHK(dev_alloc(c, &q, ncap));
+        if (used) HIPCHK(c, hipMemcpyAsync(q, *p, used * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c, p, *cap);
+        *p = q;
+        *cap = ncap;
+        return DISCO_OK;
+    };
     if (in_hits) {
-        if (used + need > c->hits_cap) {
-            CHK(ensure_cap_keep(c, &c->d_hits, &c->hits_cap, used + need, used));
-            c->d_adj = c->d_hits;
-        }
+        if (tight) CHK(move_to_larger(&c->d_hits, &c->hits_cap));
+        else if (used + need > c->hits_cap) CHK(ensure_cap_keep(c, &c->d_hits, &c->hits_cap, used + need, used));
+        c->d_adj = c->d_hits;
     } else {
         if (c->d_adj != c->d_adj_own) return fail(c, DISCO_E_STATE, "neighbour rows: the adjacency is in neither of the buffers that can grow");
-        if (used + need > c->adj_cap) {
-            CHK(ensure_cap_keep(c, &c->d_adj_own, &c->adj_cap, used + need, used));
-            c->d_adj = c->d_adj_own;
-        }
+        if (tight) CHK(move_to_larger(&c->d_adj_own, &c->adj_cap));
+        else if (used + need > c->adj_cap) CHK(ensure_cap_keep(c, &c->d_adj_own, &c->adj_cap, used + need, used));
+        c->d_adj = c->d_adj_own;
     }
     *base = used;
     return DISCO_OK;
 }
 
-/* one request round: the flat list of (u, cls) requests in d_req_flat -> rows appended to the neighbour-row store, nref set */
+/* ---- 5. neighbour rows on request (the exchange) ---------------------------------------------------------------------- */
+/* one request round: the flat list of requested nodes in d_req_flat -> their rows behind the own rows (rows_place_kernel), their reference words set */
 static int dist_fetch_rows(disco_ctx *c, u64 n_flat)
 {
     DISCO_TRACE("dist_fetch_rows");

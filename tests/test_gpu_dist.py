@@ -52,6 +52,27 @@ def test_ranks_without_host_waits_in_the_transport(name, G, extra, monkeypatch):
     assert info["world"] == G
 
 
+@pytest.mark.parametrize("name,G,extra", [("contigs_20k", 4, {}), ("mixed_4k", 3, {"DISCO_DIST_ID_RANGES": "1"}), ("repeats_8k", 3, {}), ("u150_5k", 2, {"DISCO_LOOP_ASYNC": "1"})])
+def test_fetched_rows_when_the_adjacency_array_has_to_move(name, G, extra, monkeypatch):
+    """round 6: the rows fetched from other ranks go behind the rank's own rows in the same array (one reference word per node, one kind
+    of entry for the marking kernel). The hit buffer has the room by construction (64 slots per read allotted); DISCO_TEST_TIGHT_TAIL=1
+    makes every placement MOVE the array first — the path a buffer sized exactly (the partitioned probe, a merged adjacency) takes — in
+    both request rounds, both ownerships, and the regime whose rows were rebuilt by the merge of the twins"""
+    monkeypatch.setenv("DISCO_TEST_TIGHT_TAIL", "1")
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G, passes=2)
+    ce, cc = canon_hip(edges, rows, fidx)
+    if name == "repeats_8k":  # outside the reference's parity domain (the cap binds): the oracle is the checker
+        oe, orows, _ = run_oracle_reads(reads, mo, count_hits=False)
+        oce, occ = canon_hip(oe, orows, fidx)
+        assert np.array_equal(ce, oce) and np.array_equal(cc, occ)
+    else:
+        gu.check_against_golden(name, ce, cc)
+    assert sum(i["bytes_sent"]["row_data"] for i in infos) > 0 and sum(i["device_allocs"] for i in infos) >= 0
+
+
 @pytest.mark.parametrize("name,G", [("u150_5k", 3), ("mixed_4k", 4), ("contigs_20k", 8), ("long_2k", 2)])
 def test_ranks_over_id_ranges_equal_reference(name, G, monkeypatch):
     """DISCO_DIST_ID_RANGES=1: the ownership of rounds 1-4 (rank r owns the ids [r per, (r + 1) per)) — what a pass falls back to when it
