@@ -31,7 +31,11 @@ def test_ranks_equal_reference(name, G):
 
 @pytest.mark.parametrize("name,G,extra", [("u150_5k", 2, {}), ("mixed_4k", 3, {}), ("contigs_20k", 8, {}), ("k30_6k", 4, {}), ("contigs_20k", 4, {"DISCO_DIST_ONE_COMM": "1"}),
                                           ("contigs_20k", 3, {"DISCO_DIST_KEYS_ON_PATH": "1"}), ("mixed_4k", 4, {"DISCO_DIST_ID_RANGES": "1"}),
-                                          ("repeats_8k", 3, {}), ("u150_5k", 4, {"DISCO_DIST_PARTITIONED_INDEX": "1"})])
+                                          ("repeats_8k", 3, {}), ("u150_5k", 4, {"DISCO_DIST_PARTITIONED_INDEX": "1"}),
+                                          # the grouping of the own reads: its counting pass inside own_select_kernel (default; every rank's share
+                                          # must reach DISCO_ORDER_MIN_READS) and as a pass of its own
+                                          ("contigs_20k", 2, {"DISCO_DIST_ORDER_TWO_PASSES": "1"}), ("u150_5k", 3, {"DISCO_ORDER_MIN_READS": "1"}),
+                                          ("u150_5k", 3, {"DISCO_ORDER_MIN_READS": "1", "DISCO_DIST_ORDER_TWO_PASSES": "1"})])
 def test_ranks_without_host_waits_in_the_transport(name, G, extra, monkeypatch):
     """DISCO_LOOP_ASYNC=1 (round 6): the in-process transport enqueues its exchanges on the ranks' streams with events between them and
     never waits for a device — RCCL's behaviour. Rounds 4-5 took host waits out of the flow (no sync behind an all-to-all, counts derived
