@@ -4988,7 +4988,8 @@ static int dist_push_survivors(disco_ctx *c)
      * is counted and written again, as before */
     CHK(ensure_cap(c, &c->d_x16b, &c->x16b_cap, std::max<u64>(nloc / 4, 1u << 16)));
     for (int attempt = 0; attempt < 2; attempt++) {
-        const u64 cap = attempt ? n_items : c->x16b_cap;
+        u64 cap = attempt ? n_items : c->x16b_cap;
+        if (!attempt && getenv("DISCO_TEST_TIGHT_PUSH")) cap = std::min<u64>(cap, 1); /* test hook: the first pass loses items, the second one runs */
         HIPCHK(c, hipMemsetAsync(c->d_list_n, 0, sizeof(u64), c->stream));
         CHK(zero_counter(c, CTR_OVERFLOW));
         if (nloc) hipLaunchKernelGGL(emit_push_kernel<true>, dim3(flat_grid(c, nloc, 64)), dim3(64), 0, c->stream, c->d_adj_ref, c->d_adj, c->d_half, c->d_hcnt, c->d_len, own, c->d_x16b, c->d_list_n, cap, c->d_ctr);

@@ -56,6 +56,20 @@ def test_ranks_without_host_waits_in_the_transport(name, G, extra, monkeypatch):
     assert info["world"] == G
 
 
+@pytest.mark.parametrize("name,G,extra", [("contigs_20k", 4, {}), ("mixed_4k", 3, {"DISCO_DIST_ID_RANGES": "1"}), ("u150_5k", 2, {"DISCO_LOOP_ASYNC": "1"})])
+def test_survivor_push_when_the_first_pass_does_not_fit(name, G, extra, monkeypatch):
+    """round 6: the survivors whose smaller endpoint is another rank's are written in ONE pass into the room the exchange buffer has;
+    DISCO_TEST_TIGHT_PUSH=1 gives that pass room for one item — it counts what it lost, the buffer grows, the second pass delivers"""
+    monkeypatch.setenv("DISCO_TEST_TIGHT_PUSH", "1")
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
+    reads, fidx, mo = gu.case_inputs(name)
+    edges, rows, info, infos = run_ranks_reads(reads, mo, G, passes=2)
+    ce, cc = canon_hip(edges, rows, fidx)
+    gu.check_against_golden(name, ce, cc)
+    assert sum(i["bytes_sent"]["push"] for i in infos) > 0
+
+
 @pytest.mark.parametrize("name,G,extra", [("contigs_20k", 4, {}), ("mixed_4k", 3, {"DISCO_DIST_ID_RANGES": "1"}), ("repeats_8k", 3, {}), ("u150_5k", 2, {"DISCO_LOOP_ASYNC": "1"})])
 def test_fetched_rows_when_the_adjacency_array_has_to_move(name, G, extra, monkeypatch):
     """round 6: the rows fetched from other ranks go behind the rank's own rows in the same array (one reference word per node, one kind
