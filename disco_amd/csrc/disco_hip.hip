@@ -1628,7 +1628,10 @@ static int ingest_read_file(disco_ctx *c, int fd, u64 n, u8 *d_text, unsigned th
     CHK(ingest_ring(c));
     /* (the ring's slots need an event each: ev_ring has two, the upload's ev_copied — idle here — the others) */
     hipEvent_t ev[RING_SLOTS] = {c->ev_ring[0], c->ev_ring[1], c->ev_copied[0], c->ev_copied[1]};
-    threads = (unsigned)env_int("DISCO_INGEST_THREADS", (int)threads); /* (measurement: readers of the file, whatever -t says) */
+    /* SIX readers whatever -t says (round 6; DISCO_INGEST_THREADS: measurement): the link, not the page cache, is what the file waits for, and
+     * every reader beyond what keeps the ring full only competes with the DMA engine for the host's memory — 8.1 GB into HBM in 155-160 ms
+     * with 5-6 readers, 195-280 ms with 16, 165-300 with 3-4 (16-core host of this pool, four runs each: profiles/r06_experiments.txt H) */
+    threads = (unsigned)env_int("DISCO_INGEST_THREADS", (int)std::min(threads, 6u));
     threads = std::max(1u, std::min(threads, 64u));
     CHK(copy_stream_after_stream(c));
     const u64 n_chunks = (n + SLOT - 1) / SLOT;
